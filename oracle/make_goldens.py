@@ -1,0 +1,481 @@
+#!/usr/bin/env python3
+"""Golden-vector generator (TEST INFRASTRUCTURE, runs only in the build container).
+
+Imports the *unmodified* reference (JimOhman/model-based-rl at /root/reference) and
+records inputs/outputs of its self-play search path into small .npz fixtures under
+tests/golden/.  The reference itself never travels; only these vectors do.
+
+What is driven (all imported, nothing restated except the 30-line move loop of
+actors.py:131-173, which cannot be imported because actors.py needs ray/gym):
+  mcts.MCTS / mcts.Node / mcts.MinMaxStats      (mcts.py:6-143)
+  networks.FCNetwork                            (networks.py:122-180)
+  config.Config (make_config, select_action)    (config.py:7-84, 87-231)
+  game.Game                                     (game.py:54-126)
+  custom_environments.tic_tac_toe.TicTacToe     (tic_tac_toe.py:5-76)
+  replay_buffer.PrioritizedReplay / SumTree     (replay_buffer.py:6-210, with a ray stub)
+
+Node numbering used in the tree dumps (this is the build's SoA numbering, imposed on the
+reference's object tree so the two can be compared index by index):
+  expansion index e: root = 0, the leaf expanded by simulation s = s + 1
+  node index:        root = 0, child `a` of the node with expansion index e = 1 + e*A + a
+
+Usage:  python oracle/make_goldens.py [outdir]     (default tests/golden)
+"""
+import os
+import random
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = '/root/reference'
+H = 50
+
+
+def _import_reference():
+  if not os.path.isdir(REF):
+    raise SystemExit('reference not mounted at %s (goldens are generated in the build container only)' % REF)
+  ray = types.ModuleType('ray')
+  ray.remote = lambda c: c
+  sys.modules.setdefault('ray', ray)
+  sys.path.insert(0, REF)
+  import config as rconfig
+  import game as rgame
+  import mcts as rmcts
+  import networks as rnetworks
+  import replay_buffer as rreplay
+  from custom_environments.tic_tac_toe import TicTacToe
+  return types.SimpleNamespace(config=rconfig, game=rgame, mcts=rmcts, networks=rnetworks,
+                               replay=rreplay, TicTacToe=TicTacToe)
+
+
+def make_ref_config(ref, argv, action_space, obs_space):
+  """config.make_config() + the scalarisation train.config_generator/launch perform
+  (train.py:66-68, 105-120)."""
+  old = sys.argv
+  sys.argv = ['train.py'] + list(argv)
+  try:
+    cfg = ref.config.make_config()
+  finally:
+    sys.argv = old
+  for key in ('seed', 'num_actors', 'lr_init', 'discount', 'window_size', 'window_step',
+              'batch_size', 'num_simulations', 'num_unroll_steps', 'td_steps'):
+    setattr(cfg, key, getattr(cfg, key)[0])
+  cfg.action_space = action_space
+  cfg.obs_space = obs_space
+  return cfg
+
+
+def set_all_seeds(seed):
+  """utils.set_all_seeds (utils.py:136-144) without the cudnn switches."""
+  torch.manual_seed(seed)
+  random.seed(seed + 2)
+  np.random.seed(seed + 3)
+
+
+WEIGHT_KEYS = None
+
+
+def weights_of(net):
+  sd = net.state_dict()
+  return {('w.' + k): v.detach().cpu().numpy().copy() for k, v in sd.items()}
+
+
+class SyntheticEnv(object):
+  """Shape-faithful stand-in for gym envs that are not installed (LunarLander / -ram shapes).
+  Fixed-length episodes, all actions legal, obs ~ N(0,1), reward ~ U(-1,1)."""
+
+  def __init__(self, obs_dim, n_actions, length, seed):
+    self.obs_dim, self.n, self.length = obs_dim, n_actions, length
+    self.rng = np.random.RandomState(seed)
+    self._elapsed_steps = 0
+    self.was_real_done = False
+    self.last_reward = 0.0
+
+  def seed(self, seed):
+    return
+
+  def legal_actions(self):
+    return np.arange(self.n)
+
+  def reset(self):
+    self._elapsed_steps = 0
+    return self.rng.standard_normal(self.obs_dim).astype(np.float32)
+
+  def step(self, action):
+    self._elapsed_steps += 1
+    done = self._elapsed_steps >= self.length
+    reward = float(self.rng.uniform(-1, 1))
+    self.last_reward = reward
+    self.was_real_done = done
+    return self.rng.standard_normal(self.obs_dim).astype(np.float32), reward, done, {"result": None}
+
+
+class RecordingNet(object):
+  """Forwards to the reference network and records every recurrent_inference I/O."""
+
+  def __init__(self, net):
+    self.net = net
+    self.calls = []
+
+  def initial_inference(self, obs):
+    return self.net.initial_inference(obs)
+
+  def recurrent_inference(self, hidden, action):
+    out = self.net.recurrent_inference(hidden, action)
+    self.calls.append((hidden.detach().numpy().copy().reshape(-1), int(action[0]),
+                       float(out.value.item()), float(out.reward.item()),
+                       out.policy_logits.detach().numpy().copy().reshape(-1),
+                       out.hidden_state.detach().numpy().copy().reshape(-1)))
+    return out
+
+
+class FakeNet(object):
+  """Random 'network' for tree-only traces: exercises rewards, large values, equal logits (ties)."""
+
+  def __init__(self, ref, A, rng, scale, tie_prob):
+    self.ref, self.A, self.rng, self.scale, self.tie_prob = ref, A, rng, scale, tie_prob
+    self.calls = []
+
+  def _out(self, with_reward):
+    v = np.float32(self.rng.standard_normal() * self.scale)
+    r = np.float32(self.rng.standard_normal() * self.scale * 0.5) if with_reward else 0
+    if self.rng.uniform() < 0.1 and with_reward:
+      r = np.float32(0.0)
+    logits = self.rng.standard_normal(self.A).astype(np.float32) * 2
+    if self.rng.uniform() < self.tie_prob:
+      logits[:] = np.float32(self.rng.standard_normal())
+    elif self.rng.uniform() < self.tie_prob:
+      logits[self.rng.randint(self.A)] = logits[self.rng.randint(self.A)]
+    h = self.rng.standard_normal(H).astype(np.float32)
+    NO = self.ref.networks.NetworkOutput
+    value_t = torch.tensor([[v]])
+    reward_t = torch.tensor([[r]]) if with_reward else 0
+    return NO(value_t, reward_t, torch.from_numpy(logits)[None], torch.from_numpy(h)[None]), (v, r, logits, h)
+
+  def initial_inference(self, obs):
+    out, _ = self._out(False)
+    return out
+
+  def recurrent_inference(self, hidden, action):
+    out, (v, r, logits, h) = self._out(True)
+    self.calls.append((hidden.detach().numpy().copy().reshape(-1), int(action[0]), float(v), float(r),
+                       logits.copy(), h.copy()))
+    return out
+
+
+def dump_tree(root, search_paths, A, sims):
+  """Walks the reference's Node objects and lays them out in the build's SoA numbering."""
+  NN = 1 + (sims + 1) * A
+  N = np.zeros(NN, np.int32)
+  W = np.zeros(NN, np.float64)
+  P = np.zeros(NN, np.float64)
+  R = np.zeros(NN, np.float64)
+  E = np.full(NN, -1, np.int32)
+  TP = np.zeros(NN, np.int8)
+  EX = np.zeros(NN, np.uint8)     # node exists (was created by an expand)
+  eidx = {id(root): 0}
+  for s, path in enumerate(search_paths):
+    eidx[id(path[-1])] = s + 1
+
+  def visit(node, idx):
+    N[idx] = node.visit_count
+    W[idx] = node.value_sum
+    P[idx] = node.prior
+    R[idx] = node.reward
+    TP[idx] = node.to_play
+    EX[idx] = 1
+    if node.expanded():
+      e = eidx[id(node)]
+      E[idx] = e
+      for a, child in node.children.items():
+        visit(child, 1 + e * A + int(a))
+
+  visit(root, 0)
+  return dict(N=N, W=W, P=P, R=R, E=E, TP=TP, EX=EX)
+
+
+def choice_uniform_and_action(ref_cfg, root, temperature):
+  """config.select_action (config.py:70-81) + capture of the single uniform np.random.choice
+  consumes when temperature > 0 (legacy RandomState.choice: cdf.searchsorted(u, 'right'))."""
+  state = np.random.get_state()
+  action = ref_cfg.select_action(root, temperature)
+  after = np.random.get_state()
+  u = -1.0
+  if temperature:
+    np.random.set_state(state)
+    u = float(np.random.random_sample())
+    np.random.set_state(after)
+  return int(action), u
+
+
+def play_and_record(ref, cfg, env, net, temperature, n_moves, recording=True):
+  """The move loop of actors.py:131-173 around imported reference objects; returns per-move
+  records plus the history flushes it would have sent to the replay buffer."""
+  A, sims = cfg.action_space, cfg.num_simulations
+  mcts = ref.mcts.MCTS(cfg)
+  game = cfg.new_game(env)
+  moves, flushes = [], []
+  while not game.terminal and len(moves) < n_moves:
+    root = ref.mcts.Node(0)
+    obs = np.float32(game.get_observation(-1))
+    obs_t = torch.from_numpy(np.ascontiguousarray(obs))
+    with torch.inference_mode():
+      init = net.initial_inference(obs_t.unsqueeze(0))
+    legal = np.asarray(game.environment.legal_actions())
+    root.expand(init, game.to_play, legal)
+    prior_pre = np.zeros(A, np.float64)
+    for a, ch in root.children.items():
+      prior_pre[int(a)] = ch.prior
+    rng_state = np.random.get_state()
+    root.add_exploration_noise(cfg.root_dirichlet_alpha, cfg.root_exploration_fraction)
+    after = np.random.get_state()
+    np.random.set_state(rng_state)
+    noise_legal = np.random.dirichlet([cfg.root_dirichlet_alpha] * len(legal))
+    np.random.set_state(after)
+    noise = np.zeros(A, np.float64)
+    noise[legal] = noise_legal
+
+    net.calls = []
+    with torch.inference_mode():
+      paths = mcts.run(root, net)
+    error = root.value() - init.value.item()
+    game.history.errors.append(error)
+    action, u = choice_uniform_and_action(cfg, root, temperature)
+
+    rec = dict(obs=obs.astype(np.float32).reshape(-1), legal=np.isin(np.arange(A), legal).astype(np.uint8),
+               to_play=np.int8(game.to_play), root_value=np.float32(init.value.item()),
+               root_logits=init.policy_logits.detach().numpy().reshape(-1).astype(np.float32),
+               root_hidden=init.hidden_state.detach().numpy().reshape(-1).astype(np.float32),
+               prior_pre=prior_pre, noise=noise,
+               minmax=np.array([mcts.min_max_stats.minimum, mcts.min_max_stats.maximum]),
+               final_root_value=np.float64(root.value()), error=np.float64(error),
+               uniform=np.float64(u), action=np.int32(action), temperature=np.float64(temperature))
+    depth = np.zeros(sims, np.int32)
+    pact = np.full((sims, sims + 1), -1, np.int32)
+    for s, path in enumerate(paths):
+      depth[s] = len(path) - 1
+      node = root
+      for d, nxt in enumerate(path[1:]):
+        a = [k for k, c in node.children.items() if c is nxt][0]
+        pact[s, d] = int(a)
+        node = nxt
+    rec['leaf_depth'] = depth
+    rec['path_actions'] = pact
+    rec['sim_parent_hidden'] = np.stack([c[0] for c in net.calls]).astype(np.float32)
+    rec['sim_action'] = np.array([c[1] for c in net.calls], np.int32)
+    rec['sim_value'] = np.array([c[2] for c in net.calls], np.float32)
+    rec['sim_reward'] = np.array([c[3] for c in net.calls], np.float32)
+    rec['sim_logits'] = np.stack([c[4] for c in net.calls]).astype(np.float32)
+    rec['sim_hidden'] = np.stack([c[5] for c in net.calls]).astype(np.float32)
+    tree = dump_tree(root, paths, A, sims)
+    for k, v in tree.items():
+      rec['tree_' + k] = v
+    # minimum top-2 margin over all UCB decisions is not recoverable after the fact; the
+    # final-root margin is recorded as a cheap proxy for "is this move near a tie".
+    moves.append(rec)
+
+    game.apply(action)
+    game.store_search_statistics(root)
+    rec['child_visits'] = np.asarray(game.history.child_visits[-1], np.float64)
+
+    save_history = (game.history_idx - game.previous_collect_to) == cfg.max_history_length
+    if save_history or game.done or game.terminal:
+      overlap = cfg.num_unroll_steps + cfg.td_steps
+      if not game.history.dones[game.previous_collect_to - 1]:
+        collect_from = max(0, game.previous_collect_to - overlap)
+      else:
+        collect_from = game.previous_collect_to
+      history = game.get_history_sequence(collect_from)
+      ignore = overlap if not game.done else None
+      flushes.append(dict(collect_from=collect_from, ignore=-1 if ignore is None else ignore,
+                          terminal=bool(game.terminal), at_move=len(moves), history=history))
+    if game.step >= cfg.max_steps:
+      break
+  return moves, flushes, game
+
+
+def stack_moves(moves, prefix=''):
+  out = {}
+  for k in moves[0]:
+    out[prefix + k] = np.stack([np.asarray(m[k]) for m in moves])
+  return out
+
+
+def history_arrays(h, A, prefix):
+  return {
+      prefix + 'observations': np.stack([np.asarray(o, np.float32).reshape(-1) for o in h.observations]),
+      prefix + 'child_visits': np.asarray(h.child_visits, np.float64).reshape(-1, A),
+      prefix + 'root_values': np.asarray(h.root_values, np.float64),
+      prefix + 'actions': np.asarray(h.actions, np.int32),
+      prefix + 'rewards': np.asarray(h.rewards, np.float64),
+      prefix + 'errors': np.asarray(h.errors, np.float64),
+      prefix + 'dones': np.asarray(h.dones, np.uint8),
+      prefix + 'steps': np.asarray(h.steps, np.int32),
+      prefix + 'to_play': np.asarray(h.to_play, np.int8),
+  }
+
+
+# ----------------------------------------------------------------------------- G1: network I/O
+def gen_net(ref, outdir, name, argv, O, A, seed, save_weights=True):
+  cfg = make_ref_config(ref, argv, A, (O,))
+  set_all_seeds(seed)
+  net = ref.networks.FCNetwork(O, A, torch.device('cpu'), cfg)
+  net.eval()
+  # perturb LN affine + biases so the fixture does not sit on PyTorch's defaults (1, 0)
+  g = torch.Generator().manual_seed(seed + 100)
+  with torch.no_grad():
+    net.LN.weight.add_(0.2 * torch.randn(H, generator=g))
+    net.LN.bias.add_(0.1 * torch.randn(H, generator=g))
+  rng = np.random.RandomState(seed + 7)
+  rows = 64
+  obs = rng.standard_normal((rows, O)).astype(np.float32)
+  if 'TicTacToe' in argv:
+    obs = rng.randint(-1, 2, size=(rows, O)).astype(np.float32)
+  acts = rng.randint(0, A, size=rows).astype(np.int32)
+  out = weights_of(net) if save_weights else {'weights_file': np.array('g1_net_lunar.npz')}
+  with torch.inference_mode():
+    init_v, init_l, init_h = [], [], []
+    rec_v, rec_r, rec_l, rec_h = [], [], [], []
+    for i in range(rows):          # batch-1, exactly like the reference's actors
+      o = net.initial_inference(torch.from_numpy(obs[i:i + 1]))
+      init_v.append(o.value.item()); init_l.append(o.policy_logits.numpy()[0].copy())
+      init_h.append(o.hidden_state.numpy()[0].copy())
+      r = net.recurrent_inference(o.hidden_state, [int(acts[i])])
+      rec_v.append(r.value.item()); rec_r.append(r.reward.item())
+      rec_l.append(r.policy_logits.numpy()[0].copy()); rec_h.append(r.hidden_state.numpy()[0].copy())
+    # raw (un-transformed) support logits for the value head, to pin the inverse transform alone
+    vlogits = net.value_head(torch.from_numpy(np.stack(init_h))).numpy().copy()
+    vinv = cfg.inverse_value_transform(torch.from_numpy(vlogits)).numpy().reshape(-1).copy()
+  out.update(obs=obs, actions=acts, init_value=np.array(init_v, np.float32), init_logits=np.stack(init_l),
+             init_hidden=np.stack(init_h), rec_value=np.array(rec_v, np.float32),
+             rec_reward=np.array(rec_r, np.float32), rec_logits=np.stack(rec_l), rec_hidden=np.stack(rec_h),
+             support_logits=vlogits.astype(np.float32), support_inverse=vinv.astype(np.float32),
+             O=np.int32(O), A=np.int32(A), seed=np.int32(seed))
+  np.savez_compressed(os.path.join(outdir, name), **out)
+  return net, cfg
+
+
+# ----------------------------------------------------------------------------- G2: tree traces
+def gen_tree_traces(ref, outdir, nets):
+  specs = [
+      # name, argv, O, A, fake(scale, tie_prob) or None, temperature, moves
+      ('g2_tree_ttt_fc', ['--environment', 'TicTacToe', '--two_players', '--known_bounds', '-1', '1',
+                          '--discount', '1', '--num_simulations', '30', '--seed', '0'], 9, 9, None, 1.0, 32),
+      ('g2_tree_lunar_fc', ['--num_simulations', '30', '--seed', '1'], 8, 4, None, 1.0, 32),
+      ('g2_tree_pong_fc', ['--num_simulations', '50', '--seed', '2'], 128, 6, None, 0.5, 16),
+      ('g2_tree_fake_1p', ['--num_simulations', '30', '--seed', '3'], 8, 4, (3.0, 0.15), 1.0, 32),
+      ('g2_tree_fake_2p', ['--environment', 'TicTacToe', '--two_players', '--discount', '0.997',
+                           '--num_simulations', '30', '--seed', '4'], 9, 9, (2.0, 0.15), 0.25, 32),
+      ('g2_tree_fake_bounds', ['--known_bounds', '-2', '2', '--num_simulations', '50', '--seed', '5',
+                               '--init_value_score', '0.5'], 8, 6, (4.0, 0.3), 1.0, 16),
+  ]
+  for name, argv, O, A, fake, temp, n_moves in specs:
+    cfg = make_ref_config(ref, argv, A, (O,))
+    set_all_seeds(cfg.seed)
+    if fake is None:
+      net = RecordingNet(nets[(O, A)][0])
+    else:
+      net = FakeNet(ref, A, np.random.RandomState(cfg.seed + 11), *fake)
+    moves = []
+    ep = 0
+    while len(moves) < n_moves:
+      if 'TicTacToe' in argv:
+        env = ref.TicTacToe()
+      else:
+        env = SyntheticEnv(O, A, 12, cfg.seed * 100 + ep)
+      m, _, _ = play_and_record(ref, cfg, env, net, temp, n_moves - len(moves))
+      moves += m
+      ep += 1
+    out = stack_moves(moves)
+    out.update(A=np.int32(A), O=np.int32(O), sims=np.int32(cfg.num_simulations),
+               two_players=np.int32(bool(cfg.two_players)), discount=np.float64(cfg.discount),
+               pb_c_base=np.float64(cfg.pb_c_base), pb_c_init=np.float64(cfg.pb_c_init),
+               init_value_score=np.float64(cfg.init_value_score),
+               known_bounds=np.array([np.nan if b is None else b for b in cfg.known_bounds], np.float64),
+               alpha=np.float64(cfg.root_dirichlet_alpha), frac=np.float64(cfg.root_exploration_fraction))
+    if fake is None:
+      out['weights_file'] = np.array(nets[(O, A)][1])
+    np.savez_compressed(os.path.join(outdir, name), **out)
+    print(name, 'moves', len(moves), 'mean depth %.2f max %d' % (out['leaf_depth'].mean(), out['leaf_depth'].max()))
+
+
+# ----------------------------------------------------------------------------- G3: full games + G4 replay
+def gen_games(ref, outdir, nets):
+  argv = ['--environment', 'TicTacToe', '--two_players', '--known_bounds', '-1', '1', '--discount', '1',
+          '--num_simulations', '30', '--seed', '0', '--window_size', '60000']
+  for gi, (temp, max_hist) in enumerate([(1.0, 500), (0.1, 500), (0.0, 500), (1.0, 4)]):
+    cfg = make_ref_config(ref, argv + ['--max_history_length', str(max_hist)], 9, (9,))
+    env = ref.TicTacToe()
+    replay = ref.replay.PrioritizedReplay(cfg)   # seeds np.random/random (replay_buffer.py:104-106) in ITS process
+    set_all_seeds(cfg.seed + 0)                  # actor_key 0 (actors.py:20); separate process in the reference
+    net = RecordingNet(nets[(9, 9)][0])
+    out = {}
+    all_moves = []
+    flush_meta = []
+    n_games = 3
+    for g in range(n_games):
+      moves, flushes, game = play_and_record(ref, cfg, env, net, temp, 1000)
+      for m in moves:
+        m['game'] = np.int32(g)
+      all_moves += moves
+      for f in flushes:
+        k = len(flush_meta)
+        st = (np.random.get_state(), random.getstate())
+        replay.save_history(f['history'], ignore=None if f['ignore'] < 0 else f['ignore'], terminal=f['terminal'])
+        np.random.set_state(st[0]); random.setstate(st[1])
+        out.update(history_arrays(f['history'], 9, 'flush%d_' % k))
+        flush_meta.append([g, f['at_move'], f['collect_from'], f['ignore'], int(f['terminal']),
+                           replay.tree.num_memories, replay.throughput['frames'], replay.throughput['games']])
+        out['flush%d_total_priority' % k] = np.float64(replay.tree.total_priority)
+    out.update(stack_moves(all_moves))
+    out['flush_meta'] = np.asarray(flush_meta, np.int64)
+    out['n_flushes'] = np.int32(len(flush_meta))
+    out['replay_leaves'] = replay.tree.tree[replay.tree.max_capacity - 1:
+                                            replay.tree.max_capacity - 1 + replay.tree.num_memories].copy()
+    out['replay_total'] = np.float64(replay.tree.total_priority)
+    # G4: one sample_batch under a fixed `random` seed; records the stratified draws it consumed
+    replay.batch_size = 16
+    random.seed(1234); np.random.seed(4321)
+    rs = random.getstate()
+    (bobs, bact, (trew, tval, tpol)), idxs, isw = replay.sample_batch()
+    random.setstate(rs)
+    seg = replay.tree.total_priority / 16
+    draws = np.array([random.uniform(seg * i, seg * (i + 1)) for i in range(16)])
+    out.update(sample_obs=bobs, sample_actions=np.asarray(bact, np.int32), sample_target_rewards=trew,
+               sample_target_values=tval, sample_target_policies=tpol, sample_idxs=np.asarray(idxs, np.int64),
+               sample_is_weights=np.asarray(isw, np.float64), sample_draws=draws,
+               sample_np_seed=np.int32(4321), max_capacity=np.int64(replay.tree.max_capacity))
+    out['weights_file'] = np.array(nets[(9, 9)][1])
+    out.update(A=np.int32(9), O=np.int32(9), sims=np.int32(30), two_players=np.int32(1),
+               discount=np.float64(cfg.discount), pb_c_base=np.float64(cfg.pb_c_base),
+               pb_c_init=np.float64(cfg.pb_c_init), init_value_score=np.float64(cfg.init_value_score),
+               known_bounds=np.array(cfg.known_bounds, np.float64), alpha=np.float64(0.25), frac=np.float64(0.25),
+               temperature_cfg=np.float64(temp), max_history_length=np.int32(max_hist),
+               num_unroll_steps=np.int32(cfg.num_unroll_steps), td_steps=np.int32(cfg.td_steps),
+               epsilon=np.float64(cfg.epsilon), per_alpha=np.float64(cfg.alpha), per_beta=np.float64(cfg.beta))
+    np.savez_compressed(os.path.join(outdir, 'g3_game_ttt_%d' % gi), **out)
+    print('g3_game_ttt_%d' % gi, 'moves', len(all_moves), 'flushes', len(flush_meta))
+
+
+def main():
+  outdir = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden')
+  outdir = os.path.abspath(outdir)
+  os.makedirs(outdir, exist_ok=True)
+  torch.set_num_threads(1)
+  ref = _import_reference()
+  nets = {}
+  nets[(9, 9)] = (gen_net(ref, outdir, 'g1_net_ttt', ['--environment', 'TicTacToe', '--two_players'], 9, 9, 0)[0],
+                  'g1_net_ttt.npz')
+  nets[(8, 4)] = (gen_net(ref, outdir, 'g1_net_lunar', [], 8, 4, 1)[0], 'g1_net_lunar.npz')
+  nets[(128, 6)] = (gen_net(ref, outdir, 'g1_net_pong', [], 128, 6, 2)[0], 'g1_net_pong.npz')
+  gen_net(ref, outdir, 'g1_net_lunar_notransform', ['--no_target_transform'], 8, 4, 1, save_weights=False)
+  gen_tree_traces(ref, outdir, nets)
+  gen_games(ref, outdir, nets)
+  total = sum(os.path.getsize(os.path.join(outdir, f)) for f in os.listdir(outdir) if f.endswith('.npz'))
+  print('total fixture bytes', total)
+
+
+if __name__ == '__main__':
+  main()
