@@ -1,0 +1,170 @@
+/*
+ * mz_engine.h -- C ABI of the MI355X-native MuZero self-play / MCTS engine (libmz_hip.so).
+ *
+ * The reference (JimOhman/model-based-rl) is pure Python with no FFI: its search path is reached by
+ * duck-typed calls.  This header is the boundary a native replacement of that path
+ * exports; the Python mirror in model-based-rl_amd/ (mcts.py, actors.py, ...) binds it with ctypes
+ * (cffi.dlopen works on the same symbols) and keeps the reference's class surface on top.
+ * Each entry point cites the reference code it replaces (file:line relative to the reference root).
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; the message is mz_last_error() (thread-local).
+ *     Nothing throws across the ABI.  (Reference convention: Python exceptions, e.g. actors.py:41.)
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); all work is
+ *     asynchronous on it.  An engine is not thread-safe; use one engine per GPU per process.
+ *   - pointers marked [dev] are device pointers (e.g. tensor.data_ptr()), owned by the caller and
+ *     alive until the stream reaches the end of the call's work; [host] are host pointers.
+ *   - B = num_envs trees are searched in lock-step; A = action_space; H = 50 (FCNetwork hidden_dim).
+ *   - node numbering inside a tree: expansion index e: root 0, the leaf expanded by simulation s is
+ *     s+1 (also its hidden-state slot); node index: root 0, child a of the node with expansion index
+ *     e is 1 + e*A + a.  NN = 1 + (num_simulations+1)*A nodes per tree.
+ */
+#ifndef MZ_ENGINE_H
+#define MZ_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MZ_HIDDEN 50       /* networks.py:135 */
+#define MZ_FC_WIDTH 512    /* networks.py:60,75,88,101,114 */
+#define MZ_MAX_ACTIONS 32
+#define MZ_MAX_SUPPORT 32
+
+typedef struct mz_engine mz_engine;
+
+/* The subset of the reference's Config (config.py:87-231) the search path reads. */
+typedef struct mz_config {
+  int32_t num_envs;             /* B; rounded up internally to a multiple of 16 */
+  int32_t obs_dim;              /* prod(config.obs_space) */
+  int32_t action_space;         /* config.action_space, <= MZ_MAX_ACTIONS */
+  int32_t num_simulations;      /* --num_simulations */
+  int32_t two_players;          /* --two_players */
+  int32_t has_min_bound;        /* --known_bounds[0] is not None */
+  int32_t has_max_bound;        /* --known_bounds[1] is not None */
+  int32_t value_support_min, value_support_max;    /* --value_support, size <= MZ_MAX_SUPPORT */
+  int32_t reward_support_min, reward_support_max;  /* --reward_support */
+  int32_t no_target_transform;  /* --no_target_transform */
+  double min_bound, max_bound;  /* --known_bounds */
+  double discount;              /* --discount */
+  double pb_c_base, pb_c_init;  /* --pb_c_base / --pb_c_init */
+  double init_value_score;      /* --init_value_score */
+  double root_dirichlet_alpha;  /* --root_dirichlet_alpha */
+  double root_exploration_fraction; /* --root_exploration_fraction */
+  uint64_t seed;                /* counter-based device RNG key (throughput mode) */
+  int32_t env_id_offset;        /* global id of env 0 (rank * num_envs when actors are sharded over GPUs) */
+  int32_t reserved;
+} mz_config;
+
+const char *mz_last_error(void);
+int mz_version(void);
+
+/* MCTS.__init__ (mcts.py:66-76) + Actor.__init__'s network/device set-up (actors.py:33-47).
+ * Allocates every device pool (node SoA, hidden-state pool, packed weights, scratch). */
+int mz_create(const mz_config *cfg, mz_engine **out);
+int mz_destroy(mz_engine *e);
+
+/* Number of float32 parameters of FCNetwork for this config (networks.py:137-144). */
+size_t mz_num_weights(const mz_engine *e);
+
+/* BaseNetwork.load_weights (networks.py:36-37; actors.py:81-85).  `flat` is the reference's
+ * state_dict concatenated in its own key order: representation_head.{fc1,out}.{weight,bias},
+ * value_head.{fc1,value}, policy_head.{fc1,policy}, reward_head.{fc1,reward},
+ * transition_head.{fc1,out}, LN.{weight,bias}; Linear weights [out][in] row-major.
+ * on_device != 0: flat is [dev] (e.g. the buffer an RCCL broadcast just filled); else [host]. */
+int mz_set_weights(mz_engine *e, const float *flat, size_t n, int on_device, void *stream);
+
+/* BaseNetwork.initial_inference (networks.py:26-29) for B observations, actors.py:139.
+ * obs [dev][B][obs_dim] float32 (already normalised, actors.py:134-137).  Fills hidden slot 0, the
+ * root value and the root policy logits inside the engine. */
+int mz_initial_inference(mz_engine *e, const float *obs, void *stream);
+
+/* Same, but with network outputs computed elsewhere (any torch network): hidden [dev][B][50] or NULL,
+ * value [dev][B], logits [dev][B][A]. */
+int mz_root_load(mz_engine *e, const float *hidden, const float *value, const float *logits, void *stream);
+
+/* Read back what initial inference produced: value [dev][B], logits [dev][B][A], hidden [dev][B][50]
+ * (any may be NULL). */
+int mz_root_outputs(mz_engine *e, float *value, float *logits, float *hidden, void *stream);
+
+/* Node(0) + root.expand + root.add_exploration_noise + MinMaxStats.reset
+ * (actors.py:132,141-143; mcts.py:47-61,79).
+ * to_play [dev][B] int8 or NULL (= +1);  legal [dev][B][A] uint8 or NULL (= all legal);
+ * noise [dev][B][A] float64: the Dirichlet draw scattered to the legal positions (parity mode, drawn
+ * by the host's numpy in the reference's order), or NULL with use_device_rng != 0 to draw it on the
+ * device from the counter-based RNG keyed (seed, env, move), or NULL with use_device_rng == 0 for no
+ * noise at all (evaluation, evaluate.py). */
+int mz_root_prepare(mz_engine *e, const int8_t *to_play, const uint8_t *legal, const double *noise,
+                    int use_device_rng, uint64_t move_counter, void *stream);
+
+/* MCTS.run (mcts.py:78-102) for all B trees with the engine's own FCNetwork kernels:
+ * num_simulations x { select_child descent, recurrent_inference, expand, backpropagate },
+ * no host synchronisation. */
+int mz_search(mz_engine *e, int num_simulations, void *stream);
+
+/* The same loop opened up for an external network (MuZeroNetwork/TinyNetwork through PyTorch, or
+ * recorded outputs in the parity tests):
+ *   mz_select        = the descent of mcts.py:83-94; outputs (any may be NULL):
+ *                      leaf_node, parent_slot (hidden slot of search_path[-2]), action, depth [dev][B] int32
+ *   mz_gather_hidden = hidden_out[b] = hidden pool[b][parent_slot[b]]  ([dev][B][50])
+ *   mz_expand_backup = node.expand (mcts.py:97) + backpropagate (mcts.py:99,126-143) with
+ *                      value/reward [dev][B], logits [dev][B][A], hidden [dev][B][50] or NULL. */
+int mz_select(mz_engine *e, int32_t *leaf_node, int32_t *parent_slot, int32_t *action, int32_t *depth,
+              void *stream);
+int mz_gather_hidden(mz_engine *e, float *hidden_out, void *stream);
+int mz_expand_backup(mz_engine *e, const float *value, const float *reward, const float *logits,
+                     const float *hidden, void *stream);
+
+/* BaseNetwork.recurrent_inference (networks.py:31-34) on arbitrary rows, outside any tree:
+ * hidden_in [dev][n][50], action [dev][n] int32 -> hidden_out [dev][n][50], reward/value [dev][n],
+ * logits [dev][n][A].  n <= num_envs.  (Network parity tests; evaluate.py-style callers.) */
+int mz_recurrent_inference(mz_engine *e, const float *hidden_in, const int32_t *action, int n,
+                           float *hidden_out, float *reward, float *value, float *logits, void *stream);
+
+/* End of a move: Config.select_action (config.py:70-81), Game.store_search_statistics
+ * (game.py:106-115), root error (actors.py:147-148).
+ * temperature [dev][B] float64; uniform [dev][B] float64 in [0,1) (the draw np.random.choice would
+ * consume; NULL = device RNG keyed (seed, env, move)).  temperature 0 picks the
+ * floor(u*n_ties)-th arg-max child.  Outputs (any may be NULL): action [dev][B] int32,
+ * child_visits [dev][B][A] float64, root_value [dev][B] float64, error [dev][B] float64
+ * (root value - initial value), visit_counts [dev][B][A] int32. */
+int mz_finalize(mz_engine *e, const double *temperature, const double *uniform, uint64_t move_counter,
+                int32_t *action, double *child_visits, double *root_value, double *error,
+                int32_t *visit_counts, void *stream);
+
+/* Raw tree dump (Node objects of mcts.py:28-45 in SoA form) to [host] arrays, synchronous.
+ * Each per-node array is [B][NN]; minmax [B][2]; legal_mask [B] (bit a = root child a exists);
+ * noise [B][A] (the Dirichlet draw last mixed in).  Any pointer may be NULL. */
+int mz_export_tree(mz_engine *e, int32_t *N, double *W, double *P, float *R, int32_t *E, int8_t *TP,
+                   uint32_t *legal_mask, double *minmax, double *noise, float *hidden_pool);
+
+/* Introspection for tests/bench. */
+int mz_nodes_per_tree(const mz_engine *e);
+int mz_padded_envs(const mz_engine *e);
+
+/* ---- on-device self-play loop (actors.py:126-176 for B synthetic fixed-length envs) ----------
+ * Synthetic env (gym/ALE are not installed on either box): observation
+ * obs_t[i] = Irwin-Hall(4) approximation of N(0,1) from Philox4x32-10 keyed (seed, env, episode, t),
+ * reward_t = U(-1,1) keyed likewise, all actions legal, done at t == episode_len.
+ * mz_selfplay_steps runs `moves` complete moves: obs -> initial inference -> root -> search ->
+ * select_action -> env.step -> experience record appended to a device ring.
+ * Each record is rec_floats() float32: obs[O], child_visits[A], root_value, error, reward,
+ * then as int32 bit patterns: action, done, step, env_id, episode.
+ * mz_selfplay_drain copies the records produced since the last drain into `out` [host, pinned
+ * preferred] asynchronously on `stream` and returns their count through *n_records after the
+ * stream is synchronised by the caller (records are laid out move-major: [moves][B]). */
+int mz_selfplay_reset(mz_engine *e, int episode_len, double temperature, void *stream);
+int mz_selfplay_steps(mz_engine *e, int moves, void *stream);
+int mz_selfplay_rec_floats(const mz_engine *e);
+int mz_selfplay_ring_moves(const mz_engine *e);
+int mz_selfplay_drain(mz_engine *e, float *out, int max_moves, int *n_moves, void *stream);
+/* observation the synthetic env would emit for (env, episode, t): [host] out[obs_dim]; and reward */
+int mz_synth_obs(const mz_engine *e, int env, int episode, int t, float *out_obs, float *out_reward);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MZ_ENGINE_H */

@@ -1,0 +1,99 @@
+"""ctypes binding of libmz_hip.so (include/mz_engine.h).  ABI-mode only: plain extern "C" symbols, so
+cffi.dlopen() on the same header works too where cffi is installed (it is not in this image).
+
+There is NO CPU fallback: if the HIP library is missing or no GPU is visible, loading/creating fails
+loudly."""
+import ctypes as C
+import os
+import subprocess
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
+_SO = os.path.join(_CSRC, 'libmz_hip.so')
+_SOURCES = ['mz_engine.hip', 'mz_common.h', 'mz_net.hip.h', 'mz_tree.hip.h', 'mz_rng.h', 'mz_selfplay.hip.h',
+            'mz_selfplay_abi.inc', 'mz_fused.hip.h']
+_lib = None
+
+HIPCC_FLAGS = ['-O3', '--offload-arch=gfx950', '-ffp-contract=off', '-std=c++17', '-fPIC', '-shared']
+
+
+class MzConfig(C.Structure):
+  _fields_ = [('num_envs', C.c_int32), ('obs_dim', C.c_int32), ('action_space', C.c_int32),
+              ('num_simulations', C.c_int32), ('two_players', C.c_int32), ('has_min_bound', C.c_int32),
+              ('has_max_bound', C.c_int32), ('value_support_min', C.c_int32), ('value_support_max', C.c_int32),
+              ('reward_support_min', C.c_int32), ('reward_support_max', C.c_int32),
+              ('no_target_transform', C.c_int32), ('min_bound', C.c_double), ('max_bound', C.c_double),
+              ('discount', C.c_double), ('pb_c_base', C.c_double), ('pb_c_init', C.c_double),
+              ('init_value_score', C.c_double), ('root_dirichlet_alpha', C.c_double),
+              ('root_exploration_fraction', C.c_double), ('seed', C.c_uint64), ('env_id_offset', C.c_int32),
+              ('reserved', C.c_int32)]
+
+
+def stale():
+  if not os.path.exists(_SO):
+    return True
+  t = os.path.getmtime(_SO)
+  inc = os.path.join(_CSRC, '..', '..', 'include', 'mz_engine.h')
+  srcs = [os.path.join(_CSRC, s) for s in _SOURCES] + [inc]
+  return any(os.path.exists(s) and os.path.getmtime(s) > t for s in srcs)
+
+
+def build(force=False, verbose=False):
+  """hipcc cross-compiles for gfx950 without a GPU; the .so stays in-tree (csrc/)."""
+  if force or stale():
+    cmd = ['hipcc'] + HIPCC_FLAGS + ['mz_engine.hip', '-o', 'libmz_hip.so']
+    if verbose:
+      print(' '.join(cmd))
+    subprocess.check_call(cmd, cwd=_CSRC)
+  return _SO
+
+
+_VP, _I, _D, _U64, _SZ = C.c_void_p, C.c_int, C.c_double, C.c_uint64, C.c_size_t
+
+SIGNATURES = {
+    'mz_last_error': (C.c_char_p, []),
+    'mz_version': (_I, []),
+    'mz_create': (_I, [C.POINTER(MzConfig), C.POINTER(_VP)]),
+    'mz_destroy': (_I, [_VP]),
+    'mz_num_weights': (_SZ, [_VP]),
+    'mz_set_weights': (_I, [_VP, _VP, _SZ, _I, _VP]),
+    'mz_initial_inference': (_I, [_VP, _VP, _VP]),
+    'mz_root_load': (_I, [_VP, _VP, _VP, _VP, _VP]),
+    'mz_root_outputs': (_I, [_VP, _VP, _VP, _VP, _VP]),
+    'mz_root_prepare': (_I, [_VP, _VP, _VP, _VP, _I, _U64, _VP]),
+    'mz_search': (_I, [_VP, _I, _VP]),
+    'mz_select': (_I, [_VP, _VP, _VP, _VP, _VP, _VP]),
+    'mz_gather_hidden': (_I, [_VP, _VP, _VP]),
+    'mz_expand_backup': (_I, [_VP, _VP, _VP, _VP, _VP, _VP]),
+    'mz_recurrent_inference': (_I, [_VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP]),
+    'mz_finalize': (_I, [_VP, _VP, _VP, _U64, _VP, _VP, _VP, _VP, _VP, _VP]),
+    'mz_export_tree': (_I, [_VP] * 11),
+    'mz_nodes_per_tree': (_I, [_VP]),
+    'mz_padded_envs': (_I, [_VP]),
+    'mz_selfplay_reset': (_I, [_VP, _I, _D, _VP]),
+    'mz_selfplay_steps': (_I, [_VP, _I, _VP]),
+    'mz_selfplay_rec_floats': (_I, [_VP]),
+    'mz_selfplay_ring_moves': (_I, [_VP]),
+    'mz_selfplay_drain': (_I, [_VP, _VP, _I, C.POINTER(_I), _VP]),
+    'mz_synth_obs': (_I, [_VP, _I, _I, _I, _VP, _VP]),
+}
+
+
+def load():
+  global _lib
+  if _lib is not None:
+    return _lib
+  if not os.path.exists(_SO):
+    raise RuntimeError('libmz_hip.so is not built (%s). Build it with `python -c "import __graft_entry__ as g; '
+                       'g.build()"`; this engine has no CPU fallback.' % _SO)
+  lib = C.CDLL(_SO)
+  for name, (res, args) in SIGNATURES.items():
+    fn = getattr(lib, name)      # AttributeError if the library does not export a declared symbol
+    fn.restype, fn.argtypes = res, args
+  _lib = lib
+  return lib
+
+
+def check(rc, what=''):
+  if rc != 0:
+    msg = load().mz_last_error()
+    raise RuntimeError('%s failed: %s' % (what or 'mz call', msg.decode() if msg else 'unknown error'))

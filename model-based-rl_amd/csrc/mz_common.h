@@ -1,0 +1,57 @@
+// mz_common.h -- device-side views shared by the tree and network kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MZ_H 50          // FCNetwork hidden_dim (reference networks.py:135)
+#define MZ_HS 52         // hidden-state row stride in the pool (16-byte aligned rows, pad = 0)
+#define MZ_F 512         // FC head width
+#define MZ_ROWS 16       // trees per workgroup = MFMA N dimension of v_mfma_f32_16x16x4_f32
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Struct-of-arrays node pool: one slab of NN nodes per tree, children of one node contiguous.
+// Node numbering: root 0; child a of the node with expansion index e is 1 + e*A + a.
+struct TreeView {
+  int32_t *N;        // [B][NN] visit_count            (mcts.py:32)
+  double *W;         // [B][NN] value_sum              (mcts.py:33)
+  double *P;         // [B][NN] prior                  (mcts.py:36)
+  float *R;          // [B][NN] reward (float32 network scalar, exact in double) (mcts.py:34)
+  int32_t *E;        // [B][NN] expansion index / hidden slot, -1 = leaf (mcts.py:39-40)
+  int8_t *TP;        // [B][NN] to_play                (mcts.py:37)
+  uint32_t *legal;   // [B] bit a = root child a exists (actors.py:141-142)
+  double *mn, *mx;   // [B] MinMaxStats                (mcts.py:6-25)
+  int32_t *nexp;     // [B] expansions so far
+  int32_t *path;     // [B][PL] last search path (node indices)
+  int32_t *plen;     // [B]
+  int8_t *leaf_tp;   // [B] to_play at the selected leaf
+  int32_t *leaf, *slot, *act, *depth;   // [B] outputs of the last descent
+  float *hpool;      // [B][sims+1][MZ_HS] hidden states of expanded nodes
+  float *value, *reward, *logits;       // network outputs of the current simulation: [B],[B],[B][A]
+  float *root_value; // [B] initial_inference value (actors.py:147)
+  float *root_logits;// [B][A]
+  double *noise;     // [B][A] Dirichlet draw mixed into the root
+  const double *logtab;   // [sims+2] log((n+base+1)/base)+init   (host libm, mcts.py:116)
+  const double *sqrttab;  // [sims+2] sqrt(n)                      (host libm, mcts.py:117)
+  int B, A, sims, NN, PL;
+  int two_players, has_min, has_max;
+  double min_bound, max_bound, discount, init_value_score;
+};
+
+// Packed FCNetwork weights in MFMA operand order (see mz_net.hip.h).
+struct NetView {
+  const f32x4 *w0, *b0;   // representation fc1   [4][2][ks0][64], [4][8][64]
+  const f32x4 *w0o;       // representation out   [4 jt][4][8][64]
+  const float *b0o;       // [64]
+  const f32x4 *w1, *b1;   // dynamics fc1 (reward | transition)  [4][4][ks1][64], [4][16][64]
+  const f32x4 *w2;        // reward out (2 jt) | transition out (4 jt): [6][4][8][64]
+  const float *b2;        // [32 | 64]
+  const f32x4 *w3, *b3;   // prediction fc1 (value | policy)     [4][4][13][64], [4][16][64]
+  const f32x4 *w4;        // value out (2 jt) | policy out (JTP jt)
+  const float *b4;        // [32 | 16*JTP]
+  const float *lnw, *lnb; // [64] LayerNorm affine (pad 0)
+  int ks0, ks1, ks3;      // k-steps (K/4) of the three fc1 stages
+  int O, A, jtp;
+  int Sr, Sv, rmin, vmin; // support sizes / minima (config.py:12-19)
+  int no_transform;       // --no_target_transform
+};

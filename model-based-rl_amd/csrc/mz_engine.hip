@@ -1,0 +1,531 @@
+// mz_engine.hip -- host side of libmz_hip.so: the C ABI of include/mz_engine.h over the gfx950
+// kernels in mz_tree.hip.h / mz_net.hip.h / mz_selfplay.hip.h.  No torch types, no CPU fallback:
+// every entry point launches HIP kernels on the stream it is given.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/mz_engine.h"
+
+#define MZ_MAX_ACTIONS_K MZ_MAX_ACTIONS
+#include "mz_common.h"
+#include "mz_net.hip.h"
+#include "mz_rng.h"
+#include "mz_tree.hip.h"
+#include "mz_selfplay.hip.h"
+
+static thread_local std::string g_err;
+
+static int fail(const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return -1;
+}
+
+#define HIPCHECK(x)                                                                        \
+  do {                                                                                     \
+    hipError_t err_ = (x);                                                                 \
+    if (err_ != hipSuccess) return fail("%s: %s (%s:%d)", #x, hipGetErrorString(err_), __FILE__, __LINE__); \
+  } while (0)
+
+struct mz_engine {
+  mz_config cfg;
+  int B, Bp, A, O, sims, NN, PL, G, jtp;
+  TreeView tv;
+  NetView nv;
+  std::vector<void *> allocs;
+  float *flat_dev = nullptr;
+  int32_t *pack_idx = nullptr;
+  float *packed = nullptr;
+  size_t n_flat = 0, n_packed = 0;
+  bool weights_set = false;
+  int sims_done = 0;
+  bool selection_valid = false;
+  bool root_ready = false;
+  hipStream_t cap_stream = nullptr;
+  hipGraphExec_t search_graph = nullptr;
+  int search_graph_sims = 0;
+  bool use_graph = true;
+  SelfplayState sp;
+  hipGraphExec_t move_graph = nullptr;
+};
+
+template <typename T>
+static int dmalloc(mz_engine *e, T **p, size_t n) {
+  void *q = nullptr;
+  HIPCHECK(hipMalloc(&q, n * sizeof(T) + 64));
+  HIPCHECK(hipMemset(q, 0, n * sizeof(T) + 64));
+  e->allocs.push_back(q);
+  *p = (T *)q;
+  return 0;
+}
+
+// ---------------------------------------------------------------- weight layout
+struct FlatLayout {
+  size_t rep_w1, rep_b1, rep_w2, rep_b2, val_w1, val_b1, val_w2, val_b2, pol_w1, pol_b1, pol_w2, pol_b2, rew_w1,
+      rew_b1, rew_w2, rew_b2, tr_w1, tr_b1, tr_w2, tr_b2, ln_w, ln_b, total;
+};
+
+static FlatLayout flat_layout(int O, int A, int Sv, int Sr) {
+  FlatLayout L;
+  size_t off = 0;
+  auto take = [&](size_t n) { size_t o = off; off += n; return o; };
+  const int K = MZ_H + A;
+  L.rep_w1 = take((size_t)MZ_F * O); L.rep_b1 = take(MZ_F); L.rep_w2 = take((size_t)MZ_H * MZ_F); L.rep_b2 = take(MZ_H);
+  L.val_w1 = take((size_t)MZ_F * MZ_H); L.val_b1 = take(MZ_F); L.val_w2 = take((size_t)Sv * MZ_F); L.val_b2 = take(Sv);
+  L.pol_w1 = take((size_t)MZ_F * MZ_H); L.pol_b1 = take(MZ_F); L.pol_w2 = take((size_t)A * MZ_F); L.pol_b2 = take(A);
+  L.rew_w1 = take((size_t)MZ_F * K); L.rew_b1 = take(MZ_F); L.rew_w2 = take((size_t)Sr * MZ_F); L.rew_b2 = take(Sr);
+  L.tr_w1 = take((size_t)MZ_F * K); L.tr_b1 = take(MZ_F); L.tr_w2 = take((size_t)MZ_H * MZ_F); L.tr_b2 = take(MZ_H);
+  L.ln_w = take(MZ_H); L.ln_b = take(MZ_H);
+  L.total = off;
+  return L;
+}
+
+// fc1 pack: weights [4 waves][NT/4][ks][64][4], bias [4][NT][64][4]; NT = 8*NH tiles per wave, tile t of
+// wave w = head t/8, features 128w + 16(t%8) + 0..15.
+static void fill_fc1(std::vector<int32_t> &idx, size_t wpos, size_t bpos, int NH, const size_t *woff,
+                     const size_t *boff, int K, int ks) {
+  const int NT = 8 * NH, TG = NT / 4;
+  for (int w = 0; w < 4; ++w)
+    for (int tg = 0; tg < TG; ++tg)
+      for (int s = 0; s < ks; ++s)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int i = 0; i < 4; ++i) {
+            const int t = 4 * tg + i, head = t / 8, tt = t % 8;
+            const int nf = 128 * w + 16 * tt + (lane & 15), k = 4 * s + (lane >> 4);
+            idx[wpos + ((((size_t)(w * TG + tg) * ks + s) * 64 + lane) * 4 + i)] =
+                k < K ? (int32_t)(woff[head] + (size_t)nf * K + k) : -1;
+          }
+  for (int w = 0; w < 4; ++w)
+    for (int t = 0; t < NT; ++t)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int r = 0; r < 4; ++r) {
+          const int head = t / 8, tt = t % 8;
+          const int nf = 128 * w + 16 * tt + 4 * (lane >> 4) + r;
+          idx[bpos + (((size_t)(w * NT + t) * 64 + lane) * 4 + r)] = (int32_t)(boff[head] + nf);
+        }
+}
+
+// fc2 pack: [JT][4 waves][8 tiles][64][4]: A operand row j = 16jt + (lane&15), k = 128w + 16t + 4(lane>>4) + r
+static void fill_fc2(std::vector<int32_t> &idx, size_t wpos, int JT, size_t woff, int J) {
+  for (int jt = 0; jt < JT; ++jt)
+    for (int w = 0; w < 4; ++w)
+      for (int t = 0; t < 8; ++t)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int r = 0; r < 4; ++r) {
+            const int j = 16 * jt + (lane & 15), nf = 128 * w + 16 * t + 4 * (lane >> 4) + r;
+            idx[wpos + ((((size_t)(jt * 4 + w) * 8 + t) * 64 + lane) * 4 + r)] =
+                j < J ? (int32_t)(woff + (size_t)j * MZ_F + nf) : -1;
+          }
+}
+
+static void fill_vec(std::vector<int32_t> &idx, size_t pos, int padded, size_t off, int n) {
+  for (int i = 0; i < padded; ++i) idx[pos + i] = i < n ? (int32_t)(off + i) : -1;
+}
+
+static int build_packing(mz_engine *e) {
+  const int O = e->O, A = e->A;
+  const int Sv = e->cfg.value_support_max - e->cfg.value_support_min + 1;
+  const int Sr = e->cfg.reward_support_max - e->cfg.reward_support_min + 1;
+  const FlatLayout L = flat_layout(O, A, Sv, Sr);
+  e->n_flat = L.total;
+  const int ks0 = (O + 3) / 4, ks1 = (MZ_H + A + 3) / 4, ks3 = (MZ_H + 3) / 4;
+  const int jtp = e->jtp;
+  size_t pos = 0;
+  auto seg = [&](size_t n) { size_t p = pos; pos += (n + 3) & ~(size_t)3; return p; };
+  const size_t p_w0 = seg((size_t)4 * 2 * ks0 * 256), p_b0 = seg(4 * 8 * 256), p_w0o = seg(4 * 4 * 8 * 256), p_b0o = seg(64);
+  const size_t p_w1 = seg((size_t)4 * 4 * ks1 * 256), p_b1 = seg(4 * 16 * 256), p_w2 = seg(6 * 4 * 8 * 256), p_b2 = seg(96);
+  const size_t p_w3 = seg((size_t)4 * 4 * ks3 * 256), p_b3 = seg(4 * 16 * 256);
+  const size_t p_w4 = seg((size_t)(2 + jtp) * 4 * 8 * 256), p_b4 = seg(32 + 16 * jtp);
+  const size_t p_lnw = seg(64), p_lnb = seg(64);
+  e->n_packed = pos;
+  std::vector<int32_t> idx(pos, -1);
+  {
+    size_t wo[2] = {L.rep_w1, 0}, bo[2] = {L.rep_b1, 0};
+    fill_fc1(idx, p_w0, p_b0, 1, wo, bo, O, ks0);
+    fill_fc2(idx, p_w0o, 4, L.rep_w2, MZ_H);
+    fill_vec(idx, p_b0o, 64, L.rep_b2, MZ_H);
+  }
+  {
+    size_t wo[2] = {L.rew_w1, L.tr_w1}, bo[2] = {L.rew_b1, L.tr_b1};
+    fill_fc1(idx, p_w1, p_b1, 2, wo, bo, MZ_H + A, ks1);
+    fill_fc2(idx, p_w2, 2, L.rew_w2, Sr);
+    fill_fc2(idx, p_w2 + (size_t)2 * 4 * 8 * 256, 4, L.tr_w2, MZ_H);
+    fill_vec(idx, p_b2, 32, L.rew_b2, Sr);
+    fill_vec(idx, p_b2 + 32, 64, L.tr_b2, MZ_H);
+  }
+  {
+    size_t wo[2] = {L.val_w1, L.pol_w1}, bo[2] = {L.val_b1, L.pol_b1};
+    fill_fc1(idx, p_w3, p_b3, 2, wo, bo, MZ_H, ks3);
+    fill_fc2(idx, p_w4, 2, L.val_w2, Sv);
+    fill_fc2(idx, p_w4 + (size_t)2 * 4 * 8 * 256, jtp, L.pol_w2, A);
+    fill_vec(idx, p_b4, 32, L.val_b2, Sv);
+    fill_vec(idx, p_b4 + 32, 16 * jtp, L.pol_b2, A);
+  }
+  fill_vec(idx, p_lnw, 64, L.ln_w, MZ_H);
+  fill_vec(idx, p_lnb, 64, L.ln_b, MZ_H);
+
+  if (dmalloc(e, &e->pack_idx, pos)) return -1;
+  if (dmalloc(e, &e->packed, pos)) return -1;
+  if (dmalloc(e, &e->flat_dev, L.total)) return -1;
+  HIPCHECK(hipMemcpy(e->pack_idx, idx.data(), pos * sizeof(int32_t), hipMemcpyHostToDevice));
+  NetView &n = e->nv;
+  const float *P = e->packed;
+  n.w0 = (const f32x4 *)(P + p_w0); n.b0 = (const f32x4 *)(P + p_b0); n.w0o = (const f32x4 *)(P + p_w0o); n.b0o = P + p_b0o;
+  n.w1 = (const f32x4 *)(P + p_w1); n.b1 = (const f32x4 *)(P + p_b1); n.w2 = (const f32x4 *)(P + p_w2); n.b2 = P + p_b2;
+  n.w3 = (const f32x4 *)(P + p_w3); n.b3 = (const f32x4 *)(P + p_b3); n.w4 = (const f32x4 *)(P + p_w4); n.b4 = P + p_b4;
+  n.lnw = P + p_lnw; n.lnb = P + p_lnb;
+  n.ks0 = ks0; n.ks1 = ks1; n.ks3 = ks3; n.O = O; n.A = A; n.jtp = jtp;
+  n.Sr = Sr; n.Sv = Sv; n.rmin = e->cfg.reward_support_min; n.vmin = e->cfg.value_support_min;
+  n.no_transform = e->cfg.no_target_transform;
+  return 0;
+}
+
+// ---------------------------------------------------------------- ABI
+extern "C" {
+
+const char *mz_last_error(void) { return g_err.c_str(); }
+int mz_version(void) { return 1; }
+
+int mz_create(const mz_config *cfg, mz_engine **out) {
+  if (!cfg || !out) return fail("mz_create: null argument");
+  *out = nullptr;
+  if (cfg->num_envs <= 0) return fail("mz_create: num_envs must be > 0");
+  if (cfg->action_space < 1 || cfg->action_space > MZ_MAX_ACTIONS)
+    return fail("mz_create: action_space %d outside [1,%d]", cfg->action_space, MZ_MAX_ACTIONS);
+  if (cfg->obs_dim < 1) return fail("mz_create: obs_dim must be >= 1");
+  if (cfg->num_simulations < 1 || cfg->num_simulations > 4096) return fail("mz_create: num_simulations out of range");
+  const int Sv = cfg->value_support_max - cfg->value_support_min + 1;
+  const int Sr = cfg->reward_support_max - cfg->reward_support_min + 1;
+  if (Sv < 1 || Sv > MZ_MAX_SUPPORT || Sr < 1 || Sr > MZ_MAX_SUPPORT)
+    return fail("mz_create: support size must be in [1,%d] (value %d, reward %d)", MZ_MAX_SUPPORT, Sv, Sr);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail("mz_create: no HIP device visible (this engine has no CPU path)");
+  mz_engine *e = new mz_engine();
+  e->cfg = *cfg;
+  e->B = cfg->num_envs;
+  e->Bp = (cfg->num_envs + MZ_ROWS - 1) / MZ_ROWS * MZ_ROWS;
+  e->A = cfg->action_space;
+  e->O = cfg->obs_dim;
+  e->sims = cfg->num_simulations;
+  e->NN = 1 + (e->sims + 1) * e->A;
+  e->PL = e->sims + 2;
+  e->G = e->A <= 4 ? 4 : (e->A <= 8 ? 8 : (e->A <= 16 ? 16 : 32));
+  e->jtp = e->A <= 16 ? 1 : 2;
+  e->use_graph = getenv("MZ_NO_GRAPH") == nullptr;
+  TreeView &t = e->tv;
+  memset(&t, 0, sizeof t);
+  const size_t nb = (size_t)e->Bp, nn = nb * e->NN;
+#define DM(p, n) if (dmalloc(e, &(p), (n))) { mz_destroy(e); return -1; }
+  DM(t.N, nn) DM(t.W, nn) DM(t.P, nn) DM(t.R, nn) DM(t.E, nn) DM(t.TP, nn)
+  DM(t.legal, nb) DM(t.mn, nb) DM(t.mx, nb) DM(t.nexp, nb) DM(t.path, nb * e->PL) DM(t.plen, nb) DM(t.leaf_tp, nb)
+  DM(t.leaf, nb) DM(t.slot, nb) DM(t.act, nb) DM(t.depth, nb)
+  DM(t.hpool, nb * (e->sims + 1) * MZ_HS)
+  DM(t.value, nb) DM(t.reward, nb) DM(t.logits, nb * e->A) DM(t.root_value, nb) DM(t.root_logits, nb * e->A)
+  DM(t.noise, nb * e->A)
+  double *logtab, *sqrttab;
+  DM(logtab, e->sims + 2) DM(sqrttab, e->sims + 2)
+#undef DM
+  {
+    // mcts.py:116-117: math.log((N + base + 1) / base) + init and math.sqrt(N), for every N a parent
+    // can have inside one search -- libm on the host, the values CPython computes.
+    std::vector<double> lt(e->sims + 2), st(e->sims + 2);
+    for (int i = 0; i < e->sims + 2; ++i) {
+      lt[i] = log(((double)i + cfg->pb_c_base + 1) / cfg->pb_c_base) + cfg->pb_c_init;
+      st[i] = sqrt((double)i);
+    }
+    if (hipMemcpy(logtab, lt.data(), lt.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(sqrttab, st.data(), st.size() * 8, hipMemcpyHostToDevice) != hipSuccess) {
+      mz_destroy(e);
+      return fail("mz_create: table upload failed");
+    }
+  }
+  t.logtab = logtab; t.sqrttab = sqrttab;
+  t.B = e->B; t.A = e->A; t.sims = e->sims; t.NN = e->NN; t.PL = e->PL;
+  t.two_players = cfg->two_players; t.has_min = cfg->has_min_bound; t.has_max = cfg->has_max_bound;
+  t.min_bound = cfg->min_bound; t.max_bound = cfg->max_bound; t.discount = cfg->discount;
+  t.init_value_score = cfg->init_value_score;
+  if (build_packing(e)) { mz_destroy(e); return -1; }
+  if (hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking) != hipSuccess) {
+    mz_destroy(e);
+    return fail("mz_create: stream creation failed");
+  }
+  memset(&e->sp, 0, sizeof e->sp);
+  *out = e;
+  return 0;
+}
+
+int mz_destroy(mz_engine *e) {
+  if (!e) return 0;
+  hipDeviceSynchronize();
+  if (e->search_graph) hipGraphExecDestroy(e->search_graph);
+  if (e->move_graph) hipGraphExecDestroy(e->move_graph);
+  if (e->cap_stream) hipStreamDestroy(e->cap_stream);
+  for (void *p : e->allocs) hipFree(p);
+  if (e->sp.host_ring) hipHostFree(e->sp.host_ring);
+  delete e;
+  return 0;
+}
+
+size_t mz_num_weights(const mz_engine *e) { return e ? e->n_flat : 0; }
+int mz_nodes_per_tree(const mz_engine *e) { return e ? e->NN : -1; }
+int mz_padded_envs(const mz_engine *e) { return e ? e->Bp : -1; }
+
+int mz_set_weights(mz_engine *e, const float *flat, size_t n, int on_device, void *stream) {
+  if (!e || !flat) return fail("mz_set_weights: null argument");
+  if (n != e->n_flat) return fail("mz_set_weights: expected %zu floats, got %zu", e->n_flat, n);
+  hipStream_t s = (hipStream_t)stream;
+  const float *src = flat;
+  if (!on_device) {
+    HIPCHECK(hipMemcpyAsync(e->flat_dev, flat, n * sizeof(float), hipMemcpyHostToDevice, s));
+    src = e->flat_dev;
+  }
+  const int threads = 256;
+  const unsigned blocks = (unsigned)((e->n_packed + threads - 1) / threads);
+  hipLaunchKernelGGL(k_pack_weights, dim3(blocks), dim3(threads), 0, s, src, e->pack_idx, e->packed, e->n_packed);
+  HIPCHECK(hipGetLastError());
+  if (!on_device) HIPCHECK(hipStreamSynchronize(s));   // the host buffer may be freed by the caller
+  e->weights_set = true;
+  return 0;
+}
+
+#define NET_LAUNCH(kern, grid, s, ...)                                                        \
+  do {                                                                                        \
+    if (e->jtp == 1) hipLaunchKernelGGL(kern<1>, dim3(grid), dim3(256), 0, s, __VA_ARGS__);    \
+    else hipLaunchKernelGGL(kern<2>, dim3(grid), dim3(256), 0, s, __VA_ARGS__);                \
+  } while (0)
+
+#define TREE_LAUNCH(kern, s, ...)                                                             \
+  do {                                                                                        \
+    const int threads_ = 256;                                                                 \
+    const int total_ = e->B * e->G;                                                           \
+    const int blocks_ = (total_ + threads_ - 1) / threads_;                                   \
+    switch (e->G) {                                                                           \
+      case 4: hipLaunchKernelGGL(kern<4>, dim3(blocks_), dim3(threads_), 0, s, __VA_ARGS__); break;   \
+      case 8: hipLaunchKernelGGL(kern<8>, dim3(blocks_), dim3(threads_), 0, s, __VA_ARGS__); break;   \
+      case 16: hipLaunchKernelGGL(kern<16>, dim3(blocks_), dim3(threads_), 0, s, __VA_ARGS__); break; \
+      default: hipLaunchKernelGGL(kern<32>, dim3(blocks_), dim3(threads_), 0, s, __VA_ARGS__); break; \
+    }                                                                                         \
+  } while (0)
+
+int mz_initial_inference(mz_engine *e, const float *obs, void *stream) {
+  if (!e || !obs) return fail("mz_initial_inference: null argument");
+  if (!e->weights_set) return fail("mz_initial_inference: weights not set (call mz_set_weights)");
+  hipStream_t s = (hipStream_t)stream;
+  NET_LAUNCH(k_net_initial, e->Bp / MZ_ROWS, s, e->nv, e->tv, obs);
+  HIPCHECK(hipGetLastError());
+  e->root_ready = false;
+  return 0;
+}
+
+int mz_root_load(mz_engine *e, const float *hidden, const float *value, const float *logits, void *stream) {
+  if (!e || !value || !logits) return fail("mz_root_load: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  HIPCHECK(hipMemcpyAsync(e->tv.root_value, value, (size_t)e->B * sizeof(float), hipMemcpyDeviceToDevice, s));
+  HIPCHECK(hipMemcpyAsync(e->tv.root_logits, logits, (size_t)e->B * e->A * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (hidden) {
+    const int n = e->B * MZ_HS;
+    hipLaunchKernelGGL(k_scatter_hidden, dim3((n + 255) / 256), dim3(256), 0, s, e->tv, hidden, 1);
+    HIPCHECK(hipGetLastError());
+  }
+  e->root_ready = false;
+  return 0;
+}
+
+__global__ void k_copy_root_hidden(TreeView t, float *out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= t.B * MZ_H) return;
+  const int b = i / MZ_H, k = i % MZ_H;
+  out[i] = t.hpool[(size_t)b * (t.sims + 1) * MZ_HS + k];
+}
+
+int mz_root_outputs(mz_engine *e, float *value, float *logits, float *hidden, void *stream) {
+  if (!e) return fail("mz_root_outputs: null engine");
+  hipStream_t s = (hipStream_t)stream;
+  if (value) HIPCHECK(hipMemcpyAsync(value, e->tv.root_value, (size_t)e->B * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (logits)
+    HIPCHECK(hipMemcpyAsync(logits, e->tv.root_logits, (size_t)e->B * e->A * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (hidden) {
+    const int n = e->B * MZ_H;
+    hipLaunchKernelGGL(k_copy_root_hidden, dim3((n + 255) / 256), dim3(256), 0, s, e->tv, hidden);
+    HIPCHECK(hipGetLastError());
+  }
+  return 0;
+}
+
+int mz_root_prepare(mz_engine *e, const int8_t *to_play, const uint8_t *legal, const double *noise,
+                    int use_device_rng, uint64_t move_counter, void *stream) {
+  if (!e) return fail("mz_root_prepare: null engine");
+  hipStream_t s = (hipStream_t)stream;
+  const double *nz = noise;
+  if (!noise && use_device_rng) {
+    const int threads = 128;
+    hipLaunchKernelGGL(k_dirichlet, dim3((e->B + threads - 1) / threads), dim3(threads), 0, s, e->tv, legal,
+                       e->cfg.root_dirichlet_alpha, e->cfg.seed, move_counter, (const unsigned long long *)nullptr,
+                       e->cfg.env_id_offset);
+    HIPCHECK(hipGetLastError());
+    nz = e->tv.noise;
+  } else if (noise) {
+    HIPCHECK(hipMemcpyAsync(e->tv.noise, noise, (size_t)e->B * e->A * sizeof(double), hipMemcpyDeviceToDevice, s));
+  }
+  TREE_LAUNCH(k_tree_root, s, e->tv, to_play, legal, nz, e->cfg.root_exploration_fraction, 1);
+  HIPCHECK(hipGetLastError());
+  e->sims_done = 0;
+  e->selection_valid = true;
+  e->root_ready = true;
+  return 0;
+}
+
+static int launch_search(mz_engine *e, int num_simulations, bool selection_valid, int sims_done, hipStream_t s) {
+  for (int i = 0; i < num_simulations; ++i) {
+    if (!selection_valid) TREE_LAUNCH(k_tree_select, s, e->tv);
+    NET_LAUNCH(k_net_recurrent_tree, e->Bp / MZ_ROWS, s, e->nv, e->tv, sims_done + i + 1);
+    const int more = (i + 1 < num_simulations) ? 1 : 0;
+    TREE_LAUNCH(k_tree_step, s, e->tv, more);
+    selection_valid = more;
+  }
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
+
+int mz_search(mz_engine *e, int num_simulations, void *stream) {
+  if (!e) return fail("mz_search: null engine");
+  if (!e->weights_set) return fail("mz_search: weights not set (call mz_set_weights)");
+  if (!e->root_ready) return fail("mz_search: call mz_root_prepare first");
+  if (num_simulations < 1 || e->sims_done + num_simulations > e->sims)
+    return fail("mz_search: %d + %d simulations exceed the pool sized for num_simulations = %d", e->sims_done,
+                num_simulations, e->sims);
+  hipStream_t s = (hipStream_t)stream;
+  const bool graphable = e->use_graph && e->selection_valid && e->sims_done == 0;
+  if (graphable) {
+    if (!e->search_graph || e->search_graph_sims != num_simulations) {
+      if (e->search_graph) { hipGraphExecDestroy(e->search_graph); e->search_graph = nullptr; }
+      hipGraph_t g = nullptr;
+      HIPCHECK(hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal));
+      int rc = launch_search(e, num_simulations, true, 0, e->cap_stream);
+      hipError_t ce = hipStreamEndCapture(e->cap_stream, &g);
+      if (rc || ce != hipSuccess) return fail("mz_search: graph capture failed");
+      HIPCHECK(hipGraphInstantiate(&e->search_graph, g, nullptr, nullptr, 0));
+      hipGraphDestroy(g);
+      e->search_graph_sims = num_simulations;
+    }
+    HIPCHECK(hipGraphLaunch(e->search_graph, s));
+  } else {
+    if (launch_search(e, num_simulations, e->selection_valid, e->sims_done, s)) return -1;
+  }
+  e->sims_done += num_simulations;
+  e->selection_valid = false;
+  return 0;
+}
+
+int mz_select(mz_engine *e, int32_t *leaf_node, int32_t *parent_slot, int32_t *action, int32_t *depth, void *stream) {
+  if (!e) return fail("mz_select: null engine");
+  if (!e->root_ready) return fail("mz_select: call mz_root_prepare first");
+  if (e->sims_done >= e->sims) return fail("mz_select: all %d simulations already done", e->sims);
+  hipStream_t s = (hipStream_t)stream;
+  if (!e->selection_valid) {
+    TREE_LAUNCH(k_tree_select, s, e->tv);
+    HIPCHECK(hipGetLastError());
+    e->selection_valid = true;
+  }
+  const size_t nb = (size_t)e->B * sizeof(int32_t);
+  if (leaf_node) HIPCHECK(hipMemcpyAsync(leaf_node, e->tv.leaf, nb, hipMemcpyDeviceToDevice, s));
+  if (parent_slot) HIPCHECK(hipMemcpyAsync(parent_slot, e->tv.slot, nb, hipMemcpyDeviceToDevice, s));
+  if (action) HIPCHECK(hipMemcpyAsync(action, e->tv.act, nb, hipMemcpyDeviceToDevice, s));
+  if (depth) HIPCHECK(hipMemcpyAsync(depth, e->tv.depth, nb, hipMemcpyDeviceToDevice, s));
+  return 0;
+}
+
+int mz_gather_hidden(mz_engine *e, float *hidden_out, void *stream) {
+  if (!e || !hidden_out) return fail("mz_gather_hidden: null argument");
+  if (!e->selection_valid) return fail("mz_gather_hidden: call mz_select first");
+  const int n = e->B * MZ_H;
+  hipLaunchKernelGGL(k_gather_hidden, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->tv, hidden_out);
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
+
+int mz_expand_backup(mz_engine *e, const float *value, const float *reward, const float *logits,
+                     const float *hidden, void *stream) {
+  if (!e || !value || !reward || !logits) return fail("mz_expand_backup: null argument");
+  if (!e->selection_valid) return fail("mz_expand_backup: call mz_select first");
+  hipStream_t s = (hipStream_t)stream;
+  if (hidden) {
+    const int n = e->B * MZ_HS;
+    hipLaunchKernelGGL(k_scatter_hidden, dim3((n + 255) / 256), dim3(256), 0, s, e->tv, hidden, 0);
+  }
+  TREE_LAUNCH(k_tree_expand_backup, s, e->tv, value, reward, logits);
+  HIPCHECK(hipGetLastError());
+  e->sims_done += 1;
+  e->selection_valid = false;
+  return 0;
+}
+
+int mz_recurrent_inference(mz_engine *e, const float *hidden_in, const int32_t *action, int n, float *hidden_out,
+                           float *reward, float *value, float *logits, void *stream) {
+  if (!e || !hidden_in || !action || !hidden_out || !reward || !value || !logits)
+    return fail("mz_recurrent_inference: null argument");
+  if (!e->weights_set) return fail("mz_recurrent_inference: weights not set (call mz_set_weights)");
+  if (n < 1) return fail("mz_recurrent_inference: n must be >= 1");
+  NET_LAUNCH(k_net_recurrent_rows, (n + MZ_ROWS - 1) / MZ_ROWS, (hipStream_t)stream, e->nv, hidden_in, action, n,
+             hidden_out, reward, value, logits);
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
+
+int mz_finalize(mz_engine *e, const double *temperature, const double *uniform, uint64_t move_counter,
+                int32_t *action, double *child_visits, double *root_value, double *error, int32_t *visit_counts,
+                void *stream) {
+  if (!e) return fail("mz_finalize: null engine");
+  if (action && !temperature) return fail("mz_finalize: temperature is required when action is requested");
+  const int threads = 128;
+  hipLaunchKernelGGL(k_tree_finalize, dim3((e->B + threads - 1) / threads), dim3(threads), 0, (hipStream_t)stream,
+                     e->tv, temperature, uniform, e->cfg.seed, move_counter, (const unsigned long long *)nullptr,
+                     e->cfg.env_id_offset, action, child_visits, root_value, error, visit_counts);
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
+
+int mz_export_tree(mz_engine *e, int32_t *N, double *W, double *P, float *R, int32_t *E, int8_t *TP,
+                   uint32_t *legal_mask, double *minmax, double *noise, float *hidden_pool) {
+  if (!e) return fail("mz_export_tree: null engine");
+  HIPCHECK(hipDeviceSynchronize());
+  const size_t nn = (size_t)e->B * e->NN;
+  const TreeView &t = e->tv;
+  if (N) HIPCHECK(hipMemcpy(N, t.N, nn * 4, hipMemcpyDeviceToHost));
+  if (W) HIPCHECK(hipMemcpy(W, t.W, nn * 8, hipMemcpyDeviceToHost));
+  if (P) HIPCHECK(hipMemcpy(P, t.P, nn * 8, hipMemcpyDeviceToHost));
+  if (R) HIPCHECK(hipMemcpy(R, t.R, nn * 4, hipMemcpyDeviceToHost));
+  if (E) HIPCHECK(hipMemcpy(E, t.E, nn * 4, hipMemcpyDeviceToHost));
+  if (TP) HIPCHECK(hipMemcpy(TP, t.TP, nn, hipMemcpyDeviceToHost));
+  if (legal_mask) HIPCHECK(hipMemcpy(legal_mask, t.legal, (size_t)e->B * 4, hipMemcpyDeviceToHost));
+  if (minmax) {
+    std::vector<double> mn(e->B), mx(e->B);
+    HIPCHECK(hipMemcpy(mn.data(), t.mn, (size_t)e->B * 8, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(mx.data(), t.mx, (size_t)e->B * 8, hipMemcpyDeviceToHost));
+    for (int b = 0; b < e->B; ++b) { minmax[2 * b] = mn[b]; minmax[2 * b + 1] = mx[b]; }
+  }
+  if (noise) HIPCHECK(hipMemcpy(noise, t.noise, (size_t)e->B * e->A * 8, hipMemcpyDeviceToHost));
+  if (hidden_pool) {
+    std::vector<float> tmp((size_t)e->B * (e->sims + 1) * MZ_HS);
+    HIPCHECK(hipMemcpy(tmp.data(), t.hpool, tmp.size() * 4, hipMemcpyDeviceToHost));
+    for (size_t r = 0; r < (size_t)e->B * (e->sims + 1); ++r)
+      memcpy(hidden_pool + r * MZ_H, tmp.data() + r * MZ_HS, MZ_H * sizeof(float));
+  }
+  return 0;
+}
+
+#include "mz_selfplay_abi.inc"
+
+}  // extern "C"

@@ -1,0 +1,104 @@
+// mz_selfplay.hip.h -- the device-resident part of Actor.play_game (reference actors.py:126-176) for B
+// synthetic fixed-length environments: observation generation, Dirichlet noise, env step and the
+// experience record (what Game.apply / store_search_statistics append to History, game.py:79-115).
+#pragma once
+#include "mz_common.h"
+#include "mz_rng.h"
+
+struct SelfplayState {
+  int episode_len;
+  int rec_floats, ring_moves;
+  int32_t *t;            // [B] env._elapsed_steps
+  int32_t *episode;      // [B] episodes finished
+  float *obs;            // [Bp][O] current observation (History.observations[-1])
+  double *temp;          // [B] visit-softmax temperature (actors.py:128-129)
+  int32_t *action;       // [B]
+  double *child_visits;  // [B][A]
+  double *root_value, *error;   // [B]
+  unsigned long long *move_dev;  // [1] moves completed (device-side counter, keys the RNG and the ring)
+  float *ring;           // [ring_moves][B][rec_floats]
+  float *host_ring;      // pinned staging for drains (optional)
+  unsigned long long moves_host, drained;
+  int env_offset;
+  bool ready;
+};
+
+// Gamma(alpha) by Marsaglia-Tsang (alpha < 1: boost with U^(1/alpha)); counter-based draws.
+__device__ inline double mz_gamma(double alpha, uint64_t seed, uint32_t env, uint64_t move, uint32_t a) {
+  const double aa = alpha < 1.0 ? alpha + 1.0 : alpha;
+  const double d = aa - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+  const uint32_t c1 = (uint32_t)move, c3 = (MZ_RNG_DIRICHLET << 24) | ((uint32_t)(move >> 32) & 0xFFFFFFu);
+  double g = d;
+  uint32_t ctr = 0;
+  for (int it = 0; it < 64; ++it) {
+    const mz_u4 r0 = mz_philox(seed, env, c1, a | (ctr++ << 8), c3);
+    const mz_u4 r1 = mz_philox(seed, env, c1, a | (ctr++ << 8), c3);
+    const double u1 = 1.0 - mz_u01(r0.x, r0.y), u2 = mz_u01(r0.z, r0.w);   // u1 in (0,1]
+    const double x = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+    double v = 1.0 + c * x;
+    if (v <= 0.0) continue;
+    v = v * v * v;
+    const double u = 1.0 - mz_u01(r1.x, r1.y);
+    if (log(u) < 0.5 * x * x + d - d * v + d * log(v)) { g = d * v; break; }
+  }
+  if (alpha < 1.0) {
+    const mz_u4 r = mz_philox(seed, env, c1, a | (0xFFFFFFu << 8), c3);
+    g *= pow(1.0 - mz_u01(r.x, r.y), 1.0 / alpha);
+  }
+  return g;
+}
+
+// noise[b] ~ Dirichlet(alpha * 1_legal)  (the draw of np.random.dirichlet in mcts.py:59, from the
+// device RNG instead of numpy's global stream; parity runs pass numpy's draw in instead)
+__global__ void k_dirichlet(TreeView t, const uint8_t *legal, double alpha, uint64_t seed, uint64_t move_val,
+                            const unsigned long long *move_ptr, int env_offset) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= t.B) return;
+  const uint64_t move = move_ptr ? (uint64_t)*move_ptr : move_val;
+  const int A = t.A;
+  double g[MZ_MAX_ACTIONS_K];
+  double sum = 0.0;
+  int nlegal = 0;
+  for (int a = 0; a < A; ++a) {
+    const bool ok = legal ? legal[(size_t)b * A + a] != 0 : true;
+    g[a] = ok ? mz_gamma(alpha, seed, (uint32_t)(env_offset + b), move, (uint32_t)a) : 0.0;
+    sum += g[a];
+    nlegal += ok;
+  }
+  for (int a = 0; a < A; ++a) {
+    const bool ok = legal ? legal[(size_t)b * A + a] != 0 : true;
+    t.noise[(size_t)b * A + a] = ok ? (sum > 0.0 ? g[a] / sum : 1.0 / nlegal) : 0.0;
+  }
+}
+
+// current observation of every env (Game.get_observation(-1), game.py:117-121)
+__global__ void k_env_obs(SelfplayState sp, int B, int O, uint64_t seed) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * O) return;
+  const int b = i / O, k = i % O;
+  sp.obs[i] = mz_synth_obs_elem(seed, (uint32_t)(sp.env_offset + b), (uint32_t)sp.episode[b], (uint32_t)sp.t[b],
+                                (uint32_t)k);
+}
+
+// Game.apply (game.py:79-104) on the synthetic env + the experience record of this move.
+// record: obs[O], child_visits[A] (float32), root_value, error, reward, then int32 bit patterns:
+// action, done, step (pre-step), env_id, episode.
+__global__ void k_env_step_record(SelfplayState sp, int B, int O, int A, uint64_t seed) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const unsigned long long move = *sp.move_dev;
+  float *rec = sp.ring + ((size_t)(move % (unsigned long long)sp.ring_moves) * B + b) * sp.rec_floats;
+  const int t = sp.t[b], ep = sp.episode[b];
+  for (int k = 0; k < O; ++k) rec[k] = sp.obs[(size_t)b * O + k];
+  for (int a = 0; a < A; ++a) rec[O + a] = (float)sp.child_visits[(size_t)b * A + a];
+  const float reward = mz_synth_reward(seed, (uint32_t)(sp.env_offset + b), (uint32_t)ep, (uint32_t)t);
+  const int done = (t + 1 >= sp.episode_len) ? 1 : 0;
+  rec[O + A + 0] = (float)sp.root_value[b];
+  rec[O + A + 1] = (float)sp.error[b];
+  rec[O + A + 2] = reward;
+  int32_t *ri = (int32_t *)(rec + O + A + 3);
+  ri[0] = sp.action[b]; ri[1] = done; ri[2] = t; ri[3] = sp.env_offset + b; ri[4] = ep;
+  if (done) { sp.t[b] = 0; sp.episode[b] = ep + 1; } else { sp.t[b] = t + 1; }
+}
+
+__global__ void k_move_advance(SelfplayState sp) { *sp.move_dev += 1ull; }

@@ -1,0 +1,309 @@
+// mz_tree.hip.h -- MCTS tree kernels over the SoA node pool (gfx950).
+//
+// One group of G lanes (G = power of two >= A, <= 32) owns one tree; a 64-wide wavefront carries 64/G
+// trees.  Children of a node are contiguous, so the G lanes of a group read one coalesced segment per
+// array per level; the arg-max over children is a log2(G)-step shuffle reduction inside the group.
+// All tree arithmetic is IEEE double in the reference's operation order (this TU is compiled with
+// -ffp-contract=off); log() and sqrt() of the integer parent visit count come from host-built tables
+// (libm, the same values CPython's math.log/math.sqrt return), exp() is the device's.
+#pragma once
+#include "mz_common.h"
+#include "mz_rng.h"
+
+// MinMaxStats.normalize, reference mcts.py:16-21
+__device__ __forceinline__ double mz_normalize(double v, double mn, double mx) {
+  if (mx > mn) return (v - mn) / (mx - mn);
+  if (mx == mn) return 1.0;
+  return v;
+}
+
+// The descent of MCTS.run (mcts.py:83-94) with MCTS.select_child (104-113) and ucb_score (115-124).
+template <int G>
+__device__ __forceinline__ void mz_tree_select(const TreeView &t, int b, int lane) {
+  const int A = t.A;
+  const size_t o = (size_t)b * t.NN;
+  int32_t *path = t.path + (size_t)b * t.PL;
+  const double mn = t.mn[b], mx = t.mx[b];
+  const uint32_t legal = t.legal[b];
+  int node = 0, parent = 0, len = 1, a_sel = -1;
+  int tp = t.TP[o];
+  if (lane == 0) path[0] = 0;
+  int e = t.E[o];
+  while (e >= 0) {
+    const int Np = t.N[o + node];
+    const int ch = 1 + e * A + lane;
+    const bool valid = lane < A && (node != 0 || ((legal >> lane) & 1u));
+    double score = 0.0;
+    int best = -1;
+    if (valid) {
+      const int Nc = t.N[o + ch];
+      const double p = t.P[o + ch];
+      if (Np == 0) {
+        score = p;                                     // fresh root: rank by prior (mcts.py:105-108)
+      } else {
+        double pb_c = t.logtab[Np];                    // log((Np+base+1)/base) + init
+        pb_c *= t.sqrttab[Np] / (double)(Nc + 1);
+        const double prior_score = pb_c * p;
+        double value_score;
+        if (Nc > 0) {
+          const double q = t.W[o + ch] / (double)Nc;
+          const double v = t.two_players ? -q : q;
+          value_score = mz_normalize((double)t.R[o + ch] + t.discount * v, mn, mx);
+        } else {
+          value_score = t.init_value_score;
+        }
+        score = prior_score + value_score;
+      }
+      best = lane;
+    }
+    // tuple max over (score, action): ties go to the largest action (mcts.py:106-112)
+#pragma unroll
+    for (int off = G / 2; off >= 1; off >>= 1) {
+      const double os = __shfl_xor(score, off, G);
+      const int ob = __shfl_xor(best, off, G);
+      const bool take = ob >= 0 && (best < 0 || os > score || (os == score && ob > best));
+      if (take) { score = os; best = ob; }
+    }
+    a_sel = best;
+    parent = node;
+    node = 1 + e * A + a_sel;
+    if (lane == 0) path[len] = node;
+    ++len;
+    if (t.two_players) tp = -tp;
+    e = t.E[o + node];
+  }
+  if (lane == 0) {
+    t.plen[b] = len;
+    t.leaf_tp[b] = (int8_t)tp;
+    t.leaf[b] = node;
+    t.slot[b] = t.E[o + parent];
+    t.act[b] = a_sel;
+    t.depth[b] = len - 1;
+  }
+}
+
+// Node.expand for the selected leaf (mcts.py:47-55, all actions: mcts.py:97) followed by
+// MCTS.backpropagate (mcts.py:126-143).  value/reward/logits: this tree's network outputs.
+template <int G>
+__device__ __forceinline__ void mz_tree_expand_backup(const TreeView &t, int b, int lane, float value,
+                                                      float reward, const float *logits) {
+  const int A = t.A;
+  const size_t o = (size_t)b * t.NN;
+  const int32_t *path = t.path + (size_t)b * t.PL;
+  const int len = t.plen[b];
+  const int tp = t.leaf_tp[b];
+  const int e = t.nexp[b];
+  const int leafnode = path[len - 1];
+  // priors: exp(logit) in double, no max-shift, Python sum() order 0 + p0 + p1 + ...
+  const double p = (lane < A) ? exp((double)logits[lane]) : 0.0;
+  double sum = 0.0;
+  for (int a = 0; a < A; ++a) sum = sum + __shfl(p, a, G);
+  if (lane < A) {
+    const int ch = 1 + e * A + lane;
+    t.N[o + ch] = 0; t.W[o + ch] = 0.0; t.R[o + ch] = 0.f; t.E[o + ch] = -1; t.TP[o + ch] = 1;
+    t.P[o + ch] = p / sum;
+  }
+  if (lane == 0) {
+    t.E[o + leafnode] = e;
+    t.nexp[b] = e + 1;
+    const double g = t.discount;
+    double mn = t.mn[b], mx = t.mx[b];
+    double v = (double)value;
+    for (int idx = 0; idx < len; ++idx) {
+      const int node = path[len - 1 - idx];
+      const int ntp = (idx == 0) ? tp : (int)t.TP[o + node];
+      const double r_node = (idx == 0) ? (double)reward : (double)t.R[o + node];
+      const double w = t.W[o + node] + ((ntp == tp) ? v : -v);
+      const int n = t.N[o + node] + 1;
+      t.W[o + node] = w;
+      t.N[o + node] = n;
+      const double r = (t.two_players && ntp == tp) ? -r_node : r_node;
+      if (idx < len - 1) {
+        const double q = w / (double)n;
+        const double new_q = t.two_players ? r_node - g * q : r_node + g * q;
+        mn = new_q < mn ? new_q : mn;
+        mx = new_q > mx ? new_q : mx;
+      }
+      v = r + g * v;
+    }
+    t.TP[o + leafnode] = (int8_t)tp;
+    t.R[o + leafnode] = reward;
+    t.mn[b] = mn;
+    t.mx[b] = mx;
+  }
+}
+
+// Node(0) + root.expand(legal) + add_exploration_noise + MinMaxStats.reset
+// (actors.py:132,141-143; mcts.py:47-61,79).
+template <int G>
+__device__ __forceinline__ void mz_tree_root(const TreeView &t, int b, int lane, int to_play, uint32_t legal,
+                                             const float *logits, const double *noise, double frac) {
+  const int A = t.A;
+  const size_t o = (size_t)b * t.NN;
+  const bool ok = lane < A && ((legal >> lane) & 1u);
+  const double p = ok ? exp((double)logits[lane]) : 0.0;
+  double sum = 0.0;
+  for (int a = 0; a < A; ++a) sum = sum + __shfl(p, a, G);      // + 0.0 for illegal slots is exact
+  if (lane < A) {
+    const int ch = 1 + lane;
+    double prior = ok ? p / sum : 0.0;
+    if (ok && noise) prior = prior * (1 - frac) + noise[lane] * frac;
+    t.N[o + ch] = 0; t.W[o + ch] = 0.0; t.R[o + ch] = 0.f; t.E[o + ch] = -1; t.TP[o + ch] = ok ? 1 : 0;
+    t.P[o + ch] = prior;
+  }
+  if (lane == 0) {
+    t.N[o] = 0; t.W[o] = 0.0; t.R[o] = 0.f; t.E[o] = 0; t.TP[o] = (int8_t)to_play; t.P[o] = 0.0;
+    t.nexp[b] = 1;
+    t.legal[b] = legal;
+    t.mn[b] = t.has_min ? t.min_bound : __builtin_inf();
+    t.mx[b] = t.has_max ? t.max_bound : -__builtin_inf();
+    t.plen[b] = 0;
+  }
+}
+
+// ------------------------------------------------------------------ kernels (one launch per phase)
+template <int G>
+__global__ void k_tree_select(TreeView t) {
+  const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = gt / G, lane = gt % G;
+  if (b >= t.B) return;
+  mz_tree_select<G>(t, b, lane);
+}
+
+template <int G>
+__global__ void k_tree_expand_backup(TreeView t, const float *value, const float *reward, const float *logits) {
+  const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = gt / G, lane = gt % G;
+  if (b >= t.B) return;
+  mz_tree_expand_backup<G>(t, b, lane, value[b], reward[b], logits + (size_t)b * t.A);
+}
+
+// expand+backup of simulation s fused with the descent of simulation s+1 (one launch per simulation)
+template <int G>
+__global__ void k_tree_step(TreeView t, int do_select) {
+  const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = gt / G, lane = gt % G;
+  if (b >= t.B) return;
+  mz_tree_expand_backup<G>(t, b, lane, t.value[b], t.reward[b], t.logits + (size_t)b * t.A);
+  if (do_select) {
+    __threadfence_block();          // lane 0's node updates -> visible to the group's other lanes
+    mz_tree_select<G>(t, b, lane);
+  }
+}
+
+template <int G>
+__global__ void k_tree_root(TreeView t, const int8_t *to_play, const uint8_t *legal, const double *noise,
+                            double frac, int then_select) {
+  const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = gt / G, lane = gt % G;
+  if (b >= t.B) return;
+  uint32_t mask = 0;
+  if (legal) {
+    for (int a = 0; a < t.A; ++a) mask |= (legal[(size_t)b * t.A + a] ? 1u : 0u) << a;
+  } else {
+    mask = (t.A >= 32) ? 0xFFFFFFFFu : ((1u << t.A) - 1u);
+  }
+  mz_tree_root<G>(t, b, lane, to_play ? (int)to_play[b] : 1, mask, t.root_logits + (size_t)b * t.A,
+                  noise ? noise + (size_t)b * t.A : nullptr, frac);
+  if (then_select) {
+    __threadfence_block();
+    mz_tree_select<G>(t, b, lane);
+  }
+}
+
+// numpy's pairwise float64 sum for n < 128 (ndarray.sum of a contiguous vector), config.py:76
+__device__ inline double mz_np_sum(const double *a, int n) {
+  if (n < 8) {
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s = s + a[i];
+    return s;
+  }
+  double r[8];
+  int i;
+  for (i = 0; i < 8; ++i) r[i] = a[i];
+  for (i = 8; i < n - (n % 8); i += 8)
+    for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+  double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+  for (; i < n; ++i) res += a[i];
+  return res;
+}
+
+// Config.select_action (config.py:70-81) + Game.store_search_statistics (game.py:106-115) + root error
+// (actors.py:147-148).  One thread per tree (A <= 32 children, once per move).
+__global__ void k_tree_finalize(TreeView t, const double *temperature, const double *uniform, uint64_t seed,
+                                uint64_t move_val, const unsigned long long *move_ptr, int env_offset,
+                                int32_t *action, double *child_visits, double *root_value, double *error,
+                                int32_t *visit_counts) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= t.B) return;
+  const int A = t.A;
+  const size_t o = (size_t)b * t.NN;
+  const uint32_t legal = t.legal[b];
+  int acts[MZ_MAX_ACTIONS_K];
+  double d[MZ_MAX_ACTIONS_K];
+  int n = 0;
+  long sumv = 0;
+  for (int a = 0; a < A; ++a) {
+    const bool ok = (legal >> a) & 1u;
+    const int c = ok ? t.N[o + 1 + a] : 0;
+    if (visit_counts) visit_counts[(size_t)b * A + a] = c;
+    if (!ok) continue;
+    acts[n] = a; d[n] = (double)c; sumv += c; ++n;
+  }
+  if (child_visits)
+    for (int a = 0; a < A; ++a)
+      child_visits[(size_t)b * A + a] = ((legal >> a) & 1u) ? (double)t.N[o + 1 + a] / (double)sumv : 0.0;
+  const double rv = t.N[o] == 0 ? 0.0 : t.W[o] / (double)t.N[o];
+  if (root_value) root_value[b] = rv;
+  if (error) error[b] = rv - (double)t.root_value[b];
+  if (!action) return;
+  const double T = temperature[b];
+  double u;
+  if (uniform) {
+    u = uniform[b];
+  } else {
+    const uint64_t move = move_ptr ? (uint64_t)*move_ptr : move_val;
+    mz_u4 r = mz_philox(seed, (uint32_t)(env_offset + b), (uint32_t)move, (uint32_t)(move >> 32), MZ_RNG_ACTION << 24);
+    u = mz_u01(r.x, r.y);
+  }
+  int idx = 0;
+  if (T != 0.0) {
+    const double ex = 1 / T;
+    if (ex != 1.0) for (int i = 0; i < n; ++i) d[i] = pow(d[i], ex);
+    const double s = mz_np_sum(d, n);
+    for (int i = 0; i < n; ++i) d[i] = d[i] / s;
+    double c = 0.0;
+    for (int i = 0; i < n; ++i) { c = c + d[i]; d[i] = c; }
+    const double last = d[n - 1];
+    for (int i = 0; i < n; ++i) d[i] = d[i] / last;
+    while (idx < n && d[idx] <= u) ++idx;            // searchsorted(side='right')
+    if (idx >= n) idx = n - 1;
+  } else {
+    double m = -1.0;
+    int nt = 0;
+    for (int i = 0; i < n; ++i) m = d[i] > m ? d[i] : m;
+    for (int i = 0; i < n; ++i) nt += (d[i] == m);
+    int k = (int)(u * nt);
+    if (k >= nt) k = nt - 1;
+    for (int i = 0; i < n; ++i)
+      if (d[i] == m) { if (k == 0) { idx = i; break; } --k; }
+  }
+  action[b] = acts[idx];
+}
+
+// hidden_out[b] = pool[b][slot[b]]  (what the reference hands to recurrent_inference, mcts.py:94-96)
+__global__ void k_gather_hidden(TreeView t, float *out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= t.B * MZ_H) return;
+  const int b = i / MZ_H, k = i % MZ_H;
+  out[i] = t.hpool[((size_t)b * (t.sims + 1) + t.slot[b]) * MZ_HS + k];
+}
+
+// store an externally computed hidden state into the slot the next expansion will own
+__global__ void k_scatter_hidden(TreeView t, const float *in, int root) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= t.B * MZ_HS) return;
+  const int b = i / MZ_HS, k = i % MZ_HS;
+  const int slot = root ? 0 : t.nexp[b];
+  t.hpool[((size_t)b * (t.sims + 1) + slot) * MZ_HS + k] = k < MZ_H ? in[(size_t)b * MZ_H + k] : 0.f;
+}

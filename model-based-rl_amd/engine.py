@@ -1,0 +1,244 @@
+"""Batched device engine: B search trees in lock-step on one MI355X, through the C ABI.
+
+torch is used for device memory and streams only; every computation below is a HIP kernel in
+csrc/ reached through libmz_hip.so.  Mirrors, batched over B environments, what one reference Actor
+does per move (actors.py:131-153): initial inference, root expand + noise, MCTS.run, select_action."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _abi
+
+H = 50
+
+WEIGHT_ORDER = [
+    'representation_head.fc1.weight', 'representation_head.fc1.bias',
+    'representation_head.out.weight', 'representation_head.out.bias',
+    'value_head.fc1.weight', 'value_head.fc1.bias', 'value_head.value.weight', 'value_head.value.bias',
+    'policy_head.fc1.weight', 'policy_head.fc1.bias', 'policy_head.policy.weight', 'policy_head.policy.bias',
+    'reward_head.fc1.weight', 'reward_head.fc1.bias', 'reward_head.reward.weight', 'reward_head.reward.bias',
+    'transition_head.fc1.weight', 'transition_head.fc1.bias', 'transition_head.out.weight', 'transition_head.out.bias',
+    'LN.weight', 'LN.bias',
+]
+
+
+def flatten_weights(weights):
+  """state_dict (reference key names, networks.py:137-144) -> one float32 vector in ABI order."""
+  parts = []
+  for k in WEIGHT_ORDER:
+    v = weights[k]
+    v = v.detach().to('cpu', torch.float32).reshape(-1) if torch.is_tensor(v) else torch.from_numpy(
+        np.ascontiguousarray(v, np.float32).reshape(-1))
+    parts.append(v)
+  return torch.cat(parts).contiguous()
+
+
+def _ptr(t):
+  return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class Engine(object):
+
+  def __init__(self, num_envs, obs_dim, action_space, num_simulations, two_players=False,
+               known_bounds=(None, None), value_support=(-15, 15), reward_support=(-15, 15),
+               no_target_transform=False, discount=0.997, pb_c_base=19652, pb_c_init=1.25, init_value_score=0.0,
+               root_dirichlet_alpha=0.25, root_exploration_fraction=0.25, seed=0, env_id_offset=0, device=None):
+    if not torch.cuda.is_available():
+      raise RuntimeError('model_based_rl_amd.Engine needs a HIP device (torch.cuda.is_available() is False); '
+                         'there is no CPU path.')
+    self.lib = _abi.load()
+    self.device = torch.device(device if device is not None else 'cuda:0')
+    torch.cuda.set_device(self.device)
+    lo, hi = known_bounds
+    self.B, self.O, self.A, self.sims = int(num_envs), int(obs_dim), int(action_space), int(num_simulations)
+    self.cfg = _abi.MzConfig(
+        self.B, self.O, self.A, self.sims, int(bool(two_players)), int(lo is not None), int(hi is not None),
+        int(value_support[0]), int(value_support[1]), int(reward_support[0]), int(reward_support[1]),
+        int(bool(no_target_transform)), 0.0 if lo is None else float(lo), 0.0 if hi is None else float(hi),
+        float(discount), float(pb_c_base), float(pb_c_init), float(init_value_score), float(root_dirichlet_alpha),
+        float(root_exploration_fraction), int(seed), int(env_id_offset), 0)
+    h = C.c_void_p()
+    _abi.check(self.lib.mz_create(C.byref(self.cfg), C.byref(h)), 'mz_create')
+    self._h = h
+    self.NN = self.lib.mz_nodes_per_tree(self._h)
+    self.num_weights = self.lib.mz_num_weights(self._h)
+    self._keep = []
+
+  @classmethod
+  def from_config(cls, config, num_envs, device=None, seed=None, env_id_offset=0):
+    """Build from a reference-style Config (config.py:87-231 attribute names)."""
+    obs_dim = int(np.prod(config.obs_space))
+    return cls(num_envs, obs_dim, config.action_space, config.num_simulations,
+               two_players=getattr(config, 'two_players', False),
+               known_bounds=tuple(getattr(config, 'known_bounds', (None, None))),
+               value_support=tuple(getattr(config, 'value_support', (-15, 15))),
+               reward_support=tuple(getattr(config, 'reward_support', (-15, 15))),
+               no_target_transform=getattr(config, 'no_target_transform', False), discount=config.discount,
+               pb_c_base=config.pb_c_base, pb_c_init=config.pb_c_init,
+               init_value_score=getattr(config, 'init_value_score', 0.0),
+               root_dirichlet_alpha=config.root_dirichlet_alpha,
+               root_exploration_fraction=config.root_exploration_fraction,
+               seed=(config.seed if seed is None else seed) or 0, env_id_offset=env_id_offset, device=device)
+
+  def close(self):
+    if getattr(self, '_h', None):
+      self.lib.mz_destroy(self._h)
+      self._h = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:
+      pass
+
+  @property
+  def stream(self):
+    return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+  def _dev(self, x, dtype):
+    if x is None:
+      return None
+    if not torch.is_tensor(x):
+      x = torch.as_tensor(np.ascontiguousarray(x))
+    x = x.to(self.device, dtype).contiguous()
+    self._keep.append(x)
+    if len(self._keep) > 64:
+      del self._keep[:32]
+    return x
+
+  # ---- weights (networks.py:36-37, actors.py:81-85)
+  def set_weights(self, weights):
+    if isinstance(weights, dict):
+      weights = flatten_weights(weights)
+    if not torch.is_tensor(weights):
+      weights = torch.from_numpy(np.ascontiguousarray(weights, np.float32))
+    weights = weights.reshape(-1)
+    if weights.numel() != self.num_weights:
+      raise ValueError('expected %d weights, got %d' % (self.num_weights, weights.numel()))
+    on_dev = weights.is_cuda
+    w = weights.to(torch.float32).contiguous()
+    _abi.check(self.lib.mz_set_weights(self._h, _ptr(w), w.numel(), int(on_dev), self.stream), 'mz_set_weights')
+    if on_dev:
+      self._keep.append(w)
+
+  # ---- network
+  def initial_inference(self, obs):
+    obs = self._dev(obs, torch.float32).reshape(self.B, self.O)
+    _abi.check(self.lib.mz_initial_inference(self._h, _ptr(obs), self.stream), 'mz_initial_inference')
+
+  def root_load(self, value, logits, hidden=None):
+    value = self._dev(value, torch.float32); logits = self._dev(logits, torch.float32)
+    hidden = self._dev(hidden, torch.float32)
+    _abi.check(self.lib.mz_root_load(self._h, _ptr(hidden), _ptr(value), _ptr(logits), self.stream), 'mz_root_load')
+
+  def root_outputs(self):
+    v = torch.empty(self.B, dtype=torch.float32, device=self.device)
+    lg = torch.empty(self.B, self.A, dtype=torch.float32, device=self.device)
+    h = torch.empty(self.B, H, dtype=torch.float32, device=self.device)
+    _abi.check(self.lib.mz_root_outputs(self._h, _ptr(v), _ptr(lg), _ptr(h), self.stream), 'mz_root_outputs')
+    return v, lg, h
+
+  def recurrent_inference(self, hidden, action):
+    hidden = self._dev(hidden, torch.float32).reshape(-1, H)
+    action = self._dev(action, torch.int32)
+    n = hidden.shape[0]
+    ho = torch.empty(n, H, dtype=torch.float32, device=self.device)
+    r = torch.empty(n, dtype=torch.float32, device=self.device)
+    v = torch.empty(n, dtype=torch.float32, device=self.device)
+    lg = torch.empty(n, self.A, dtype=torch.float32, device=self.device)
+    _abi.check(self.lib.mz_recurrent_inference(self._h, _ptr(hidden), _ptr(action), n, _ptr(ho), _ptr(r), _ptr(v),
+                                               _ptr(lg), self.stream), 'mz_recurrent_inference')
+    return ho, r, v, lg
+
+  # ---- tree
+  def root_prepare(self, to_play=None, legal=None, noise=None, device_rng=False, move=0):
+    to_play = self._dev(to_play, torch.int8)
+    legal = self._dev(legal, torch.uint8)
+    noise = self._dev(noise, torch.float64)
+    _abi.check(self.lib.mz_root_prepare(self._h, _ptr(to_play), _ptr(legal), _ptr(noise), int(device_rng), int(move),
+                                        self.stream), 'mz_root_prepare')
+
+  def search(self, num_simulations=None):
+    n = self.sims if num_simulations is None else int(num_simulations)
+    _abi.check(self.lib.mz_search(self._h, n, self.stream), 'mz_search')
+
+  def select(self):
+    out = [torch.empty(self.B, dtype=torch.int32, device=self.device) for _ in range(4)]
+    _abi.check(self.lib.mz_select(self._h, *[_ptr(o) for o in out], self.stream), 'mz_select')
+    return out   # leaf_node, parent_slot, action, depth
+
+  def gather_hidden(self):
+    h = torch.empty(self.B, H, dtype=torch.float32, device=self.device)
+    _abi.check(self.lib.mz_gather_hidden(self._h, _ptr(h), self.stream), 'mz_gather_hidden')
+    return h
+
+  def expand_backup(self, value, reward, logits, hidden=None):
+    value = self._dev(value, torch.float32); reward = self._dev(reward, torch.float32)
+    logits = self._dev(logits, torch.float32); hidden = self._dev(hidden, torch.float32)
+    _abi.check(self.lib.mz_expand_backup(self._h, _ptr(value), _ptr(reward), _ptr(logits), _ptr(hidden), self.stream),
+               'mz_expand_backup')
+
+  def finalize(self, temperature, uniform=None, move=0):
+    t = torch.as_tensor(np.broadcast_to(np.asarray(temperature, np.float64), (self.B,)).copy())
+    t = self._dev(t, torch.float64)
+    u = self._dev(uniform, torch.float64)
+    action = torch.empty(self.B, dtype=torch.int32, device=self.device)
+    cv = torch.empty(self.B, self.A, dtype=torch.float64, device=self.device)
+    rv = torch.empty(self.B, dtype=torch.float64, device=self.device)
+    err = torch.empty(self.B, dtype=torch.float64, device=self.device)
+    vc = torch.empty(self.B, self.A, dtype=torch.int32, device=self.device)
+    _abi.check(self.lib.mz_finalize(self._h, _ptr(t), _ptr(u), int(move), _ptr(action), _ptr(cv), _ptr(rv), _ptr(err),
+                                    _ptr(vc), self.stream), 'mz_finalize')
+    return dict(action=action, child_visits=cv, root_value=rv, error=err, visit_counts=vc)
+
+  def export_tree(self, hidden=False):
+    B, NN, A = self.B, self.NN, self.A
+    d = dict(N=np.zeros((B, NN), np.int32), W=np.zeros((B, NN)), P=np.zeros((B, NN)),
+             R=np.zeros((B, NN), np.float32), E=np.zeros((B, NN), np.int32), TP=np.zeros((B, NN), np.int8),
+             legal=np.zeros(B, np.uint32), minmax=np.zeros((B, 2)), noise=np.zeros((B, A)))
+    hp = np.zeros((B, self.sims + 1, H), np.float32) if hidden else None
+    p = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+    _abi.check(self.lib.mz_export_tree(self._h, p(d['N']), p(d['W']), p(d['P']), p(d['R']), p(d['E']), p(d['TP']),
+                                       p(d['legal']), p(d['minmax']), p(d['noise']), p(hp)), 'mz_export_tree')
+    if hidden:
+      d['hidden'] = hp
+    # EX (node exists): root, legal root children, and every child slab of an expanded node
+    EX = np.zeros((B, NN), np.uint8)
+    EX[:, 0] = 1
+    for a in range(A):
+      EX[:, 1 + a] = (d['legal'] >> a) & 1
+    exp_idx = d['E']
+    for b in range(B):
+      for e in np.unique(exp_idx[b][exp_idx[b] > 0]):
+        EX[b, 1 + e * A:1 + (e + 1) * A] = 1
+    d['EX'] = EX
+    return d
+
+  # ---- on-device self-play (actors.py:126-176 on synthetic envs)
+  def selfplay_reset(self, episode_len, temperature=1.0):
+    _abi.check(self.lib.mz_selfplay_reset(self._h, int(episode_len), float(temperature), self.stream),
+               'mz_selfplay_reset')
+    self.rec_floats = self.lib.mz_selfplay_rec_floats(self._h)
+    self.ring_moves = self.lib.mz_selfplay_ring_moves(self._h)
+
+  def selfplay_steps(self, moves):
+    _abi.check(self.lib.mz_selfplay_steps(self._h, int(moves), self.stream), 'mz_selfplay_steps')
+
+  def selfplay_drain(self, out=None, max_moves=None):
+    """Asynchronous D2H of the records produced since the last drain into pinned memory; returns
+    (host tensor [n_moves, B, rec_floats], n_moves).  Synchronise the stream before reading."""
+    max_moves = self.ring_moves if max_moves is None else int(max_moves)
+    if out is None:
+      out = torch.empty(max_moves, self.B, self.rec_floats, dtype=torch.float32).pin_memory()
+    n = C.c_int(0)
+    _abi.check(self.lib.mz_selfplay_drain(self._h, C.c_void_p(out.data_ptr()), max_moves, C.byref(n), self.stream),
+               'mz_selfplay_drain')
+    return out, n.value
+
+  def synth_obs(self, env, episode, t):
+    obs = np.zeros(self.O, np.float32)
+    r = C.c_float(0)
+    _abi.check(self.lib.mz_synth_obs(self._h, env, episode, t, obs.ctypes.data_as(C.c_void_p), C.byref(r)),
+               'mz_synth_obs')
+    return obs, float(r.value)
