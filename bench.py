@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""Headline benchmark: self-play env-steps/sec at num_simulations=30 (BASELINE.json).
+
+One "step" = one complete move of every environment on this rank: observation -> initial inference ->
+root expand + Dirichlet noise -> 30 x {select, recurrent inference, expand, backup} -> action sampling ->
+env.step -> experience record; records are drained D2H into pinned memory and ingested by the host
+prioritized replay (the reference's own metric: experiences accepted by save_history per wall-second,
+replay_buffer.py:121 / learners.py:94-109).  N > 1: one process per GPU, environments sharded by global env
+id, weights broadcast from rank 0 over RCCL; no data-path collective (scaling = weak).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+      bench.py --gpus N --steps K --warmup W
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+# BASELINE.json configs[1]: LunarLander-v2 shapes, FCNetwork, 30 simulations, 4096 parallel envs per GPU
+B, O, A, SIMS, EPISODE_LEN = 4096, 8, 4, 30, 256
+CHUNK = 8                       # moves per drain/ingest chunk
+FLOP_PER_SIM = 2 * 512 * (312 + 3 * A)            # 331 776 for A = 4
+FLOP_PER_ROOT = 2 * 512 * (O + 181 + A)           # 197 632
+PEAK_F32_MFMA_TFLOPS = 157.3                      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+
+
+def cpu_baseline(weights):
+  """The CPU oracle (C restatement of the reference path, oracle/mz_oracle.c) timed on ONE host core on a
+  bounded sample of the same workload.  Reported beside the GPU number; it is not the target."""
+  from oracle import oracle as orc
+  envs, moves = 64, 4
+  rng = np.random.RandomState(0)
+  net = orc.FCNet(weights, O, A)
+  t = orc.Trees(orc.tree_cfg(A, SIMS), envs)
+  obs = rng.standard_normal((envs, O)).astype(np.float32)
+  noise = rng.dirichlet([0.25] * A, size=envs)
+  t.search_fc(net, obs, np.ones(envs, np.int8), None, noise, 0.25)      # warm-up
+  t0 = time.perf_counter()
+  for _ in range(moves):
+    t.search_fc(net, obs, np.ones(envs, np.int8), None, noise, 0.25)
+    t.finalize(1.0, rng.uniform(size=envs))
+  dt = time.perf_counter() - t0
+  return {'value': envs * moves / dt, 'unit': 'env-steps/s', 'cores': 1, 'kind': 'port',
+          'sample': '%d envs x %d moves x %d simulations, oracle/mz_oracle.c (gcc -O2, scalar float32 net + '
+                    'double tree), %.1f s' % (envs, moves, SIMS, dt),
+          'host_cpus': os.cpu_count()}
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=512)
+  ap.add_argument('--warmup', type=int, default=64)
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  args = ap.parse_args()
+
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  rank = int(os.environ.get('RANK', '0'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  dist = None
+  if world > 1:
+    import torch.distributed as dist
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+  elif args.gpus > 1:
+    raise SystemExit('--gpus %d needs the torch.distributed.run launcher (one process per GPU)' % args.gpus)
+  device = torch.device('cuda', local_rank)
+  torch.cuda.set_device(device)
+
+  from model_based_rl_amd.engine import Engine, flatten_weights
+  from model_based_rl_amd.networks import FCNetwork
+  from model_based_rl_amd.replay_buffer import PrioritizedReplay
+
+  # random-init FCNetwork, torch.manual_seed(0) default init; rank 0 owns the weights
+  torch.manual_seed(0)
+  net = FCNetwork(O, A, torch.device('cpu'), types.SimpleNamespace()).eval()
+  flat = flatten_weights(net.state_dict()).to(device)
+  if rank != 0:
+    flat.zero_()
+  eng = Engine(B, O, A, SIMS, seed=1234, env_id_offset=rank * B, device=device)
+
+  def sync_weights():
+    if dist is not None:
+      dist.broadcast(flat, src=0)          # RCCL over xGMI: one flattened f32 buffer (0.79 MB)
+    eng.set_weights(flat)
+
+  sync_weights()
+  cfg = types.SimpleNamespace(batch_size=256, epsilon=0.01, alpha=1.0, beta=1.0, obs_space=(O,), action_space=A,
+                              window_size=1 << 21, window_step=None, num_unroll_steps=5, td_steps=10,
+                              max_history_length=500, discount=0.997, seed=0)
+  replay = PrioritizedReplay(cfg)
+  eng.selfplay_reset(EPISODE_LEN, 1.0, stagger=True)
+  rec = eng.rec_floats
+  pinned = [torch.empty(CHUNK, B, rec, dtype=torch.float32).pin_memory() for _ in range(2)]
+  events = [torch.cuda.Event(), torch.cuda.Event()]
+
+  def run(moves, count):
+    """moves in chunks; D2H + host ingest of chunk i-1 overlap the GPU work of chunk i."""
+    pending = None
+    done = 0
+    k = 0
+    while done < moves:
+      m = min(CHUNK, moves - done)
+      eng.selfplay_steps(m)
+      buf, n = eng.selfplay_drain(pinned[k & 1], m)
+      events[k & 1].record(torch.cuda.current_stream(device))
+      if pending is not None:
+        pb, pn, pe = pending
+        pe.synchronize()
+        replay.ingest_records(pb, pn, B)
+      pending = (buf, n, events[k & 1])
+      done += m
+      k += 1
+    pb, pn, pe = pending
+    pe.synchronize()
+    replay.ingest_records(pb, pn, B)
+
+  def barrier():
+    torch.cuda.synchronize(device)
+    if dist is not None:
+      dist.barrier()
+      torch.cuda.synchronize(device)
+
+  # priming (untimed, not part of --warmup): every env finishes its first, partial (staggered) episode, so
+  # that from here on B/EPISODE_LEN episodes end per move and the replay accepts B frames per move on
+  # average -- the steady state the reference's frames_per_second metric is defined on
+  run(EPISODE_LEN, False)
+  run(args.warmup, False)
+  barrier()
+  frames0 = replay.get_throughput()['frames']
+  t0 = time.perf_counter()
+  run(args.steps, True)
+  barrier()
+  dt = time.perf_counter() - t0
+  frames = replay.get_throughput()['frames'] - frames0
+  if dist is not None:
+    tt = torch.tensor([dt], dtype=torch.float64, device=device)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    ff = torch.tensor([frames], dtype=torch.float64, device=device)
+    dist.all_reduce(ff, op=dist.ReduceOp.SUM)
+    frames = float(ff.item())
+  env_steps = world * B * args.steps       # env.step() calls in the timed region, all ranks
+
+  # per-kernel durations: the same launches, eagerly, with hipEvents between them on the launch stream
+  net_ms = tree_ms = 0.0
+  reps = 8
+  obs = torch.randn(B, O, device=device)
+  for i in range(reps):
+    eng.initial_inference(obs)
+    eng.root_prepare(None, None, None, device_rng=True, move=10 ** 6 + i)
+    a, b = eng.search_profiled()
+    net_ms += a
+    tree_ms += b
+  net_us = 1e3 * net_ms / (reps * SIMS)
+  tree_us = 1e3 * tree_ms / (reps * SIMS)
+
+  if rank == 0:
+    value = frames / dt
+    flops_per_launch = FLOP_PER_SIM * B
+    achieved = flops_per_launch / (net_us * 1e-6) / 1e12
+    traffic = None
+    tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
+    if os.path.exists(tfile):
+      traffic = json.load(open(tfile)).get('k_net_recurrent_tree', {}).get('hbm_bytes_per_launch')
+    out = {
+        'metric': 'env-steps/sec (self-play, whole node) at num_simulations=30',
+        'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'LunarLander-v2 shapes (obs 8, actions 4), FCNetwork, num_simulations=30, '
+                               '%d parallel self-play envs per GPU, synthetic fixed-length episodes T=%d, '
+                               'random-init weights (torch.manual_seed(0))' % (B, EPISODE_LEN),
+                   'envs_per_gpu': B, 'num_simulations': SIMS, 'episode_len': EPISODE_LEN,
+                   'priming': '%d untimed moves before warm-up so episode ends are in steady state' % EPISODE_LEN,
+                   'sharding': 'env-id sharded, %d rank(s), RCCL weight broadcast' % world},
+        'env_steps_executed_per_s': env_steps / dt,
+        'mcts_sims_per_s_per_gpu': env_steps * SIMS / dt / world,
+        'roofline': {'bound': 'mfma', 'kernel': 'k_net_recurrent_tree', 'achieved': achieved,
+                     'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS,
+                     'traffic': traffic, 'us_per_launch': net_us, 'flop_per_launch': flops_per_launch,
+                     'tree_step_us_per_launch': tree_us,
+                     'whole_path_frac': (env_steps / dt / world) * (SIMS * FLOP_PER_SIM + FLOP_PER_ROOT) / 1e12 /
+                                        PEAK_F32_MFMA_TFLOPS},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+      out['cpu_baseline'] = cpu_baseline({k: v.numpy() for k, v in net.state_dict().items()})
+    print(json.dumps(out), flush=True)
+  if dist is not None:
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

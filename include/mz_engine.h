@@ -105,6 +105,11 @@ int mz_root_prepare(mz_engine *e, const int8_t *to_play, const uint8_t *legal, c
  * no host synchronisation. */
 int mz_search(mz_engine *e, int num_simulations, void *stream);
 
+/* Diagnostic twin of mz_search (call right after mz_root_prepare): the same launches, eagerly, with a
+ * hipEvent between every pair of launches on `stream`; synchronous.  ms_out[0] = summed time of the
+ * num_simulations recurrent-inference launches, ms_out[1] = summed time of the tree-step launches. */
+int mz_search_profiled(mz_engine *e, int num_simulations, float *ms_out, void *stream);
+
 /* The same loop opened up for an external network (MuZeroNetwork/TinyNetwork through PyTorch, or
  * recorded outputs in the parity tests):
  *   mz_select        = the descent of mcts.py:83-94; outputs (any may be NULL):
@@ -155,8 +160,9 @@ int mz_padded_envs(const mz_engine *e);
  * then as int32 bit patterns: action, done, step, env_id, episode.
  * mz_selfplay_drain copies the records produced since the last drain into `out` [host, pinned
  * preferred] asynchronously on `stream` and returns their count through *n_records after the
- * stream is synchronised by the caller (records are laid out move-major: [moves][B]). */
-int mz_selfplay_reset(mz_engine *e, int episode_len, double temperature, void *stream);
+ * stream is synchronised by the caller (records are laid out move-major: [moves][B]).
+ * stagger != 0: env i starts its first episode at t0 = hash(env id) % episode_len (uniform episode ends). */
+int mz_selfplay_reset(mz_engine *e, int episode_len, double temperature, int stagger, void *stream);
 int mz_selfplay_steps(mz_engine *e, int moves, void *stream);
 int mz_selfplay_rec_floats(const mz_engine *e);
 int mz_selfplay_ring_moves(const mz_engine *e);

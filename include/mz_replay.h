@@ -1,0 +1,77 @@
+/*
+ * mz_replay.h -- C ABI of the host-side prioritized replay (libmz_replay.so, plain C++17, no GPU code).
+ *
+ * Replaces the ingest side of the reference's PrioritizedReplay / SumTree (replay_buffer.py:6-122) and the
+ * actor's history flush logic (actors.py:160-173, game.py:41-51,123-126) for experience records that arrive
+ * from the GPU in bulk (mz_selfplay_drain, include/mz_engine.h) instead of as pickled HistorySlices over Ray.
+ * Arithmetic follows the reference exactly: priority = (|error| + epsilon)^alpha in double, SumTree.update
+ * propagates `change` leaf-to-root one leaf at a time in arrival order, so tree sums are bit-identical to the
+ * reference's for the same sequence of histories.
+ *
+ * Returns 0 on success, <0 on error (message: mzr_last_error()).  Not thread-safe per handle.
+ */
+#ifndef MZ_REPLAY_H
+#define MZ_REPLAY_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mz_replay mz_replay;
+
+typedef struct mzr_config {
+  int64_t window_size;        /* --window_size  (SumTree max_capacity) */
+  int64_t window_step;        /* --window_step or window_size when None (replay_buffer.py:94-98) */
+  int32_t obs_dim, action_space;
+  int32_t num_unroll_steps;   /* K */
+  int32_t td_steps;
+  int32_t max_history_length; /* --max_history_length (actors.py:160) */
+  int32_t batch_size;
+  double epsilon, alpha, beta, beta_increment_per_sampling;   /* replay_buffer.py:73-77 */
+  double discount;
+  uint64_t seed;
+} mzr_config;
+
+const char *mzr_last_error(void);
+
+/* PrioritizedReplay.__init__ (replay_buffer.py:71-106) */
+int mzr_create(const mzr_config *cfg, mz_replay **out);
+int mzr_destroy(mz_replay *r);
+
+/* PrioritizedReplay.get_priorities (replay_buffer.py:110-111) */
+int mzr_priorities(const mz_replay *r, const double *errors, int64_t n, double *out);
+
+/* SumTree.add / update / get_leaf / total_priority (replay_buffer.py:19-66); positions_out may be NULL */
+int mzr_tree_add(mz_replay *r, const double *priorities, int64_t n, int64_t *positions_out);
+int mzr_tree_update(mz_replay *r, const int64_t *idxs, const double *priorities, int64_t n);
+int64_t mzr_tree_get_leaf(const mz_replay *r, double value);
+double mzr_total_priority(const mz_replay *r);
+int64_t mzr_size(const mz_replay *r);                  /* PrioritizedReplay.size: tree.num_memories */
+int mzr_tree_leaves(const mz_replay *r, int64_t n, double *out);
+
+/* PrioritizedReplay.save_history (replay_buffer.py:113-122) for one history slice given as arrays:
+ * n steps, errors[n]; ignore < 0 means None.  The step payload (obs [n][O], child_visits [n][A], root_values,
+ * rewards, actions, dones, to_play) is copied into the replay's own storage.  Any payload pointer may be NULL
+ * (priorities-only ingest). */
+int mzr_save_history(mz_replay *r, int64_t n, const double *errors, int64_t ignore, int terminal,
+                     const float *obs, const float *child_visits, const double *root_values, const float *rewards,
+                     const int32_t *actions, const uint8_t *dones, const int8_t *to_play);
+
+/* Bulk ingest of device records (layout of mz_selfplay_drain: [n_moves][B][rec_floats], rec = obs[O],
+ * child_visits[A], root_value, error, reward, then int32 bits action, done, step, env_id, episode).
+ * Re-creates per environment what Actor.play_game does after each move (actors.py:160-173): histories are
+ * accumulated per env and flushed to save_history when max_history_length steps were collected (with the
+ * overlap/ignore rules) or the episode is done.  frames/games: PrioritizedReplay.throughput. */
+int mzr_ingest_records(mz_replay *r, const float *records, int n_moves, int B, int rec_floats);
+
+int64_t mzr_frames(const mz_replay *r);   /* throughput['frames'] (replay_buffer.py:121) */
+int64_t mzr_games(const mz_replay *r);    /* throughput['games'] */
+int mzr_add_initial_throughput(mz_replay *r, int64_t frames, int64_t games);   /* replay_buffer.py:106-108 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

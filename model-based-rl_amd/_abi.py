@@ -61,6 +61,7 @@ SIGNATURES = {
     'mz_root_outputs': (_I, [_VP, _VP, _VP, _VP, _VP]),
     'mz_root_prepare': (_I, [_VP, _VP, _VP, _VP, _I, _U64, _VP]),
     'mz_search': (_I, [_VP, _I, _VP]),
+    'mz_search_profiled': (_I, [_VP, _I, _VP, _VP]),
     'mz_select': (_I, [_VP, _VP, _VP, _VP, _VP, _VP]),
     'mz_gather_hidden': (_I, [_VP, _VP, _VP]),
     'mz_expand_backup': (_I, [_VP, _VP, _VP, _VP, _VP, _VP]),
@@ -69,7 +70,7 @@ SIGNATURES = {
     'mz_export_tree': (_I, [_VP] * 11),
     'mz_nodes_per_tree': (_I, [_VP]),
     'mz_padded_envs': (_I, [_VP]),
-    'mz_selfplay_reset': (_I, [_VP, _I, _D, _VP]),
+    'mz_selfplay_reset': (_I, [_VP, _I, _D, _I, _VP]),
     'mz_selfplay_steps': (_I, [_VP, _I, _VP]),
     'mz_selfplay_rec_floats': (_I, [_VP]),
     'mz_selfplay_ring_moves': (_I, [_VP]),
@@ -91,6 +92,70 @@ def load():
     fn.restype, fn.argtypes = res, args
   _lib = lib
   return lib
+
+
+# ---------------------------------------------------------------- host replay library (include/mz_replay.h)
+_RSO = os.path.join(_CSRC, 'libmz_replay.so')
+_rlib = None
+_I64 = C.c_int64
+
+
+class MzrConfig(C.Structure):
+  _fields_ = [('window_size', _I64), ('window_step', _I64), ('obs_dim', C.c_int32), ('action_space', C.c_int32),
+              ('num_unroll_steps', C.c_int32), ('td_steps', C.c_int32), ('max_history_length', C.c_int32),
+              ('batch_size', C.c_int32), ('epsilon', _D), ('alpha', _D), ('beta', _D),
+              ('beta_increment_per_sampling', _D), ('discount', _D), ('seed', _U64)]
+
+
+REPLAY_SIGNATURES = {
+    'mzr_last_error': (C.c_char_p, []),
+    'mzr_create': (_I, [C.POINTER(MzrConfig), C.POINTER(_VP)]),
+    'mzr_destroy': (_I, [_VP]),
+    'mzr_priorities': (_I, [_VP, _VP, _I64, _VP]),
+    'mzr_tree_add': (_I, [_VP, _VP, _I64, _VP]),
+    'mzr_tree_update': (_I, [_VP, _VP, _VP, _I64]),
+    'mzr_tree_get_leaf': (_I64, [_VP, _D]),
+    'mzr_total_priority': (_D, [_VP]),
+    'mzr_size': (_I64, [_VP]),
+    'mzr_tree_leaves': (_I, [_VP, _I64, _VP]),
+    'mzr_save_history': (_I, [_VP, _I64, _VP, _I64, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    'mzr_ingest_records': (_I, [_VP, _VP, _I, _I, _I]),
+    'mzr_frames': (_I64, [_VP]),
+    'mzr_games': (_I64, [_VP]),
+    'mzr_add_initial_throughput': (_I, [_VP, _I64, _I64]),
+}
+
+
+def build_replay(force=False, verbose=False):
+  src = os.path.join(_CSRC, 'mz_replay.cpp')
+  hdr = os.path.join(_CSRC, '..', '..', 'include', 'mz_replay.h')
+  if force or not os.path.exists(_RSO) or os.path.getmtime(_RSO) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    cmd = ['g++', '-O2', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared', 'mz_replay.cpp', '-o',
+           'libmz_replay.so']
+    if verbose:
+      print(' '.join(cmd))
+    subprocess.check_call(cmd, cwd=_CSRC)
+  return _RSO
+
+
+def load_replay():
+  global _rlib
+  if _rlib is not None:
+    return _rlib
+  if not os.path.exists(_RSO):
+    raise RuntimeError('libmz_replay.so is not built (%s); run __graft_entry__.build()' % _RSO)
+  lib = C.CDLL(_RSO)
+  for name, (res, args) in REPLAY_SIGNATURES.items():
+    fn = getattr(lib, name)
+    fn.restype, fn.argtypes = res, args
+  _rlib = lib
+  return lib
+
+
+def check_replay(rc, what=''):
+  if rc != 0:
+    msg = load_replay().mzr_last_error()
+    raise RuntimeError('%s failed: %s' % (what or 'mzr call', msg.decode() if msg else 'unknown error'))
 
 
 def check(rc, what=''):

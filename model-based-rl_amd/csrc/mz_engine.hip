@@ -429,6 +429,37 @@ int mz_search(mz_engine *e, int num_simulations, void *stream) {
   return 0;
 }
 
+int mz_search_profiled(mz_engine *e, int num_simulations, float *ms_out, void *stream) {
+  if (!e || !ms_out) return fail("mz_search_profiled: null argument");
+  if (!e->weights_set) return fail("mz_search_profiled: weights not set (call mz_set_weights)");
+  if (!e->root_ready || !e->selection_valid || e->sims_done != 0)
+    return fail("mz_search_profiled: call right after mz_root_prepare");
+  if (num_simulations < 1 || num_simulations > e->sims) return fail("mz_search_profiled: bad num_simulations");
+  hipStream_t s = (hipStream_t)stream;
+  std::vector<hipEvent_t> ev(2 * num_simulations + 1);
+  for (auto &x : ev) HIPCHECK(hipEventCreate(&x));
+  HIPCHECK(hipEventRecord(ev[0], s));
+  for (int i = 0; i < num_simulations; ++i) {
+    NET_LAUNCH(k_net_recurrent_tree, e->Bp / MZ_ROWS, s, e->nv, e->tv, i + 1);
+    HIPCHECK(hipEventRecord(ev[2 * i + 1], s));
+    const int more = (i + 1 < num_simulations) ? 1 : 0;
+    TREE_LAUNCH(k_tree_step, s, e->tv, more);
+    HIPCHECK(hipEventRecord(ev[2 * i + 2], s));
+  }
+  HIPCHECK(hipStreamSynchronize(s));
+  ms_out[0] = ms_out[1] = 0.f;
+  for (int i = 0; i < num_simulations; ++i) {
+    float a = 0.f, b = 0.f;
+    HIPCHECK(hipEventElapsedTime(&a, ev[2 * i], ev[2 * i + 1]));
+    HIPCHECK(hipEventElapsedTime(&b, ev[2 * i + 1], ev[2 * i + 2]));
+    ms_out[0] += a; ms_out[1] += b;
+  }
+  for (auto &x : ev) hipEventDestroy(x);
+  e->sims_done = num_simulations;
+  e->selection_valid = false;
+  return 0;
+}
+
 int mz_select(mz_engine *e, int32_t *leaf_node, int32_t *parent_slot, int32_t *action, int32_t *depth, void *stream) {
   if (!e) return fail("mz_select: null engine");
   if (!e->root_ready) return fail("mz_select: call mz_root_prepare first");

@@ -1,0 +1,256 @@
+// mz_replay.cpp -- libmz_replay.so: host-side prioritized replay ingest (include/mz_replay.h).
+// Plain C++17, no GPU code.  Arithmetic and update order follow the reference's SumTree /
+// PrioritizedReplay (replay_buffer.py) exactly; see the header for the citations.
+#include "../../include/mz_replay.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <memory>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_err;
+static int fail(const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return -1;
+}
+
+// one HistorySlice (game.py:5-16) as flat arrays; leaves point into it as (history, step)
+struct Hist {
+  int64_t n = 0;
+  std::vector<float> obs, child_visits, rewards;
+  std::vector<double> root_values;
+  std::vector<int32_t> actions;
+  std::vector<uint8_t> dones;
+  std::vector<int8_t> to_play;
+};
+
+// what Game/Actor keep per environment between flushes (game.py:54-77, actors.py:160-169)
+struct EnvGame {
+  std::vector<float> recs;      // records from absolute history index `base` on
+  int64_t base = 0;             // history index of recs[0]
+  int64_t history_idx = 0;      // game.history_idx
+  int64_t previous_collect_to = 0;
+  bool done_at_last_flush = false;
+};
+
+struct mz_replay {
+  mzr_config c;
+  // SumTree (replay_buffer.py:8-17)
+  int64_t max_capacity, capacity_step, capacity, prev_capacity = 0, num_memories = 0, position = 0;
+  std::vector<double> tree;
+  std::vector<std::shared_ptr<Hist>> leaf_hist;
+  std::vector<int32_t> leaf_step;
+  int64_t frames = 0, games = 0;
+  std::vector<EnvGame> envs;
+  // scratch
+  std::vector<double> errs, pri, rootv;
+  std::vector<float> obs, cv, rew;
+  std::vector<int32_t> act;
+  std::vector<uint8_t> done;
+  std::vector<int8_t> tp;
+};
+
+// SumTree.update, replay_buffer.py:34-40
+static inline void tree_update(mz_replay *r, int64_t idx, double priority) {
+  double *t = r->tree.data();
+  const double change = priority - t[idx];
+  t[idx] = priority;
+  while (idx != 0) {
+    idx = (idx - 1) / 2;
+    t[idx] += change;
+  }
+}
+
+// SumTree.add, replay_buffer.py:19-32
+static void tree_add(mz_replay *r, const double *priorities, int64_t n, const std::shared_ptr<Hist> &h,
+                     int64_t *positions_out) {
+  for (int64_t step = 0; step < n; ++step) {
+    const int64_t idx = r->position + r->max_capacity - 1;
+    r->leaf_hist[r->position] = h;
+    r->leaf_step[r->position] = (int32_t)step;
+    if (positions_out) positions_out[step] = r->position;
+    tree_update(r, idx, priorities[step]);
+    if (r->position >= r->prev_capacity) r->num_memories += 1;
+    r->position = (r->position + 1) % r->capacity;
+    if (r->position == 0) {
+      r->prev_capacity = r->capacity;
+      const int64_t next = r->capacity + r->capacity_step;
+      r->capacity = next < r->max_capacity ? next : r->max_capacity;
+    }
+  }
+}
+
+static int save_history(mz_replay *r, int64_t n, const double *errors, int64_t ignore, int terminal,
+                        const float *obs, const float *child_visits, const double *root_values,
+                        const float *rewards, const int32_t *actions, const uint8_t *dones, const int8_t *to_play) {
+  // replay_buffer.py:113-119: errors[:-ignore] (python: ignore == 0 would give an empty list)
+  int64_t keep = n;
+  if (ignore >= 0) keep = ignore == 0 ? 0 : (n - ignore > 0 ? n - ignore : 0);
+  std::shared_ptr<Hist> h;
+  if (obs || child_visits || root_values || rewards || actions || dones || to_play) {
+    h = std::make_shared<Hist>();
+    h->n = n;
+    const int O = r->c.obs_dim, A = r->c.action_space;
+    if (obs) h->obs.assign(obs, obs + n * O);
+    if (child_visits) h->child_visits.assign(child_visits, child_visits + n * A);
+    if (root_values) h->root_values.assign(root_values, root_values + n);
+    if (rewards) h->rewards.assign(rewards, rewards + n);
+    if (actions) h->actions.assign(actions, actions + n);
+    if (dones) h->dones.assign(dones, dones + n);
+    if (to_play) h->to_play.assign(to_play, to_play + n);
+  }
+  if ((int64_t)r->pri.size() < keep) r->pri.resize(keep);
+  for (int64_t i = 0; i < keep; ++i) r->pri[i] = pow(fabs(errors[i]) + r->c.epsilon, r->c.alpha);
+  tree_add(r, r->pri.data(), keep, h, nullptr);
+  r->frames += keep;                       // replay_buffer.py:121
+  if (terminal) r->games += 1;             // replay_buffer.py:122
+  return 0;
+}
+
+extern "C" {
+
+const char *mzr_last_error(void) { return g_err.c_str(); }
+
+int mzr_create(const mzr_config *cfg, mz_replay **out) {
+  if (!cfg || !out) return fail("mzr_create: null argument");
+  if (cfg->window_size < 1 || cfg->window_step < 1 || cfg->window_step > cfg->window_size)
+    return fail("mzr_create: need 1 <= window_step <= window_size");
+  if (cfg->obs_dim < 1 || cfg->action_space < 1) return fail("mzr_create: bad obs_dim/action_space");
+  mz_replay *r = new mz_replay();
+  r->c = *cfg;
+  r->max_capacity = cfg->window_size;
+  r->capacity_step = cfg->window_step;
+  r->capacity = cfg->window_step;
+  r->tree.assign((size_t)(2 * cfg->window_size - 1), 0.0);
+  r->leaf_hist.resize((size_t)cfg->window_size);
+  r->leaf_step.assign((size_t)cfg->window_size, 0);
+  *out = r;
+  return 0;
+}
+
+int mzr_destroy(mz_replay *r) {
+  delete r;
+  return 0;
+}
+
+int mzr_priorities(const mz_replay *r, const double *errors, int64_t n, double *out) {
+  if (!r || !errors || !out) return fail("mzr_priorities: null argument");
+  for (int64_t i = 0; i < n; ++i) out[i] = pow(fabs(errors[i]) + r->c.epsilon, r->c.alpha);
+  return 0;
+}
+
+int mzr_tree_add(mz_replay *r, const double *priorities, int64_t n, int64_t *positions_out) {
+  if (!r || !priorities) return fail("mzr_tree_add: null argument");
+  tree_add(r, priorities, n, nullptr, positions_out);
+  return 0;
+}
+
+int mzr_tree_update(mz_replay *r, const int64_t *idxs, const double *priorities, int64_t n) {
+  if (!r || !idxs || !priorities) return fail("mzr_tree_update: null argument");
+  const int64_t len = 2 * r->max_capacity - 1;
+  for (int64_t i = 0; i < n; ++i) {
+    if (idxs[i] < 0 || idxs[i] >= len) return fail("mzr_tree_update: index %lld out of range", (long long)idxs[i]);
+    tree_update(r, idxs[i], priorities[i]);
+  }
+  return 0;
+}
+
+// SumTree.get_leaf, replay_buffer.py:42-62 (returns the tree index of the leaf)
+int64_t mzr_tree_get_leaf(const mz_replay *r, double value) {
+  const int64_t len = 2 * r->max_capacity - 1;
+  const double *t = r->tree.data();
+  int64_t parent = 0;
+  for (;;) {
+    const int64_t left = 2 * parent + 1;
+    if (left >= len) return parent;
+    if (value <= t[left]) parent = left;
+    else { value -= t[left]; parent = left + 1; }
+  }
+}
+
+double mzr_total_priority(const mz_replay *r) { return r->tree[0]; }
+int64_t mzr_size(const mz_replay *r) { return r->num_memories; }
+int mzr_tree_leaves(const mz_replay *r, int64_t n, double *out) {
+  if (!r || !out || n > r->max_capacity) return fail("mzr_tree_leaves: bad argument");
+  memcpy(out, r->tree.data() + r->max_capacity - 1, (size_t)n * sizeof(double));
+  return 0;
+}
+
+int mzr_save_history(mz_replay *r, int64_t n, const double *errors, int64_t ignore, int terminal, const float *obs,
+                     const float *child_visits, const double *root_values, const float *rewards,
+                     const int32_t *actions, const uint8_t *dones, const int8_t *to_play) {
+  if (!r || (n > 0 && !errors)) return fail("mzr_save_history: null argument");
+  return save_history(r, n, errors, ignore, terminal, obs, child_visits, root_values, rewards, actions, dones, to_play);
+}
+
+int mzr_ingest_records(mz_replay *r, const float *records, int n_moves, int B, int rec_floats) {
+  if (!r || !records) return fail("mzr_ingest_records: null argument");
+  const int O = r->c.obs_dim, A = r->c.action_space;
+  if (rec_floats != O + A + 8) return fail("mzr_ingest_records: rec_floats %d != obs_dim+action_space+8 = %d", rec_floats, O + A + 8);
+  if ((int)r->envs.size() < B) r->envs.resize(B);
+  const int64_t overlap = r->c.num_unroll_steps + r->c.td_steps;
+  for (int m = 0; m < n_moves; ++m) {
+    for (int b = 0; b < B; ++b) {
+      const float *rec = records + ((size_t)m * B + b) * rec_floats;
+      const int32_t *ri = (const int32_t *)(rec + O + A + 3);
+      const bool done = ri[1] != 0;
+      EnvGame &g = r->envs[b];
+      g.recs.insert(g.recs.end(), rec, rec + rec_floats);
+      g.history_idx += 1;
+      // actors.py:160-169
+      const bool save = (g.history_idx - g.previous_collect_to) == r->c.max_history_length;
+      if (!(save || done)) continue;
+      const bool d_prev = g.previous_collect_to == 0 ? done : g.done_at_last_flush;   // dones[prev-1] (index -1 when prev == 0)
+      int64_t collect_from = d_prev ? g.previous_collect_to
+                                    : (g.previous_collect_to - overlap > 0 ? g.previous_collect_to - overlap : 0);
+      const int64_t n = g.history_idx - collect_from;
+      const int64_t ignore = done ? -1 : overlap;
+      if ((int64_t)r->errs.size() < n) {
+        r->errs.resize(n); r->rootv.resize(n); r->rew.resize(n); r->act.resize(n); r->done.resize(n); r->tp.resize(n);
+      }
+      if ((int64_t)r->obs.size() < n * O) r->obs.resize(n * O);
+      if ((int64_t)r->cv.size() < n * A) r->cv.resize(n * A);
+      for (int64_t i = 0; i < n; ++i) {
+        const float *q = g.recs.data() + (size_t)(collect_from - g.base + i) * rec_floats;
+        const int32_t *qi = (const int32_t *)(q + O + A + 3);
+        memcpy(r->obs.data() + i * O, q, O * sizeof(float));
+        memcpy(r->cv.data() + i * A, q + O, A * sizeof(float));
+        r->rootv[i] = (double)q[O + A]; r->errs[i] = (double)q[O + A + 1]; r->rew[i] = q[O + A + 2];
+        r->act[i] = qi[0]; r->done[i] = (uint8_t)(qi[1] != 0); r->tp[i] = 1;
+      }
+      save_history(r, n, r->errs.data(), ignore, done ? 1 : 0, r->obs.data(), r->cv.data(), r->rootv.data(),
+                   r->rew.data(), r->act.data(), r->done.data(), r->tp.data());
+      g.previous_collect_to = g.history_idx;
+      g.done_at_last_flush = done;
+      if (done) {           // terminal: run_selfplay starts a new Game (actors.py:94-97)
+        g.recs.clear(); g.base = 0; g.history_idx = 0; g.previous_collect_to = 0; g.done_at_last_flush = false;
+      } else {              // keep only what the next slice can still reach back to
+        const int64_t nb = g.history_idx - overlap > 0 ? g.history_idx - overlap : 0;
+        if (nb > g.base) {
+          g.recs.erase(g.recs.begin(), g.recs.begin() + (size_t)(nb - g.base) * rec_floats);
+          g.base = nb;
+        }
+      }
+    }
+  }
+  return 0;
+}
+
+int64_t mzr_frames(const mz_replay *r) { return r->frames; }
+int64_t mzr_games(const mz_replay *r) { return r->games; }
+int mzr_add_initial_throughput(mz_replay *r, int64_t frames, int64_t games) {
+  if (!r) return fail("mzr_add_initial_throughput: null");
+  r->frames += frames; r->games += games;
+  return 0;
+}
+
+}  // extern "C"

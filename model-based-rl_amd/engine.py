@@ -163,6 +163,13 @@ class Engine(object):
     n = self.sims if num_simulations is None else int(num_simulations)
     _abi.check(self.lib.mz_search(self._h, n, self.stream), 'mz_search')
 
+  def search_profiled(self, num_simulations=None):
+    """-> (ms of all recurrent-inference launches, ms of all tree-step launches) for one search."""
+    n = self.sims if num_simulations is None else int(num_simulations)
+    ms = (C.c_float * 2)()
+    _abi.check(self.lib.mz_search_profiled(self._h, n, ms, self.stream), 'mz_search_profiled')
+    return float(ms[0]), float(ms[1])
+
   def select(self):
     out = [torch.empty(self.B, dtype=torch.int32, device=self.device) for _ in range(4)]
     _abi.check(self.lib.mz_select(self._h, *[_ptr(o) for o in out], self.stream), 'mz_select')
@@ -216,8 +223,8 @@ class Engine(object):
     return d
 
   # ---- on-device self-play (actors.py:126-176 on synthetic envs)
-  def selfplay_reset(self, episode_len, temperature=1.0):
-    _abi.check(self.lib.mz_selfplay_reset(self._h, int(episode_len), float(temperature), self.stream),
+  def selfplay_reset(self, episode_len, temperature=1.0, stagger=False):
+    _abi.check(self.lib.mz_selfplay_reset(self._h, int(episode_len), float(temperature), int(stagger), self.stream),
                'mz_selfplay_reset')
     self.rec_floats = self.lib.mz_selfplay_rec_floats(self._h)
     self.ring_moves = self.lib.mz_selfplay_ring_moves(self._h)

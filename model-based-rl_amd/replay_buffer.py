@@ -1,0 +1,139 @@
+"""Host-side prioritized replay with the reference's surface (replay_buffer.py:6-210), backed by the
+native library libmz_replay.so (include/mz_replay.h): SumTree arithmetic and update order are the
+reference's, so sums are bit-identical for the same sequence of histories.
+
+PrioritizedReplay.{save_history, size, get_throughput, add_initial_throughput, get_priorities, update}
+keep the reference's signatures; `ingest_records` is the bulk path used by the GPU actor pool (records
+from Engine.selfplay_drain) and applies the actor-side flush rules (actors.py:160-169) per environment.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+
+
+def _p(a):
+  return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class SumTree(object):
+  """replay_buffer.py:6-66 over the native tree (payload handling lives in PrioritizedReplay)."""
+
+  def __init__(self, max_capacity, capacity_step, _owner=None, obs_dim=1, action_space=1):
+    self.max_capacity, self.capacity_step = int(max_capacity), int(capacity_step)
+    self.lib = _abi.load_replay()
+    if _owner is None:
+      cfg = _abi.MzrConfig(self.max_capacity, self.capacity_step, obs_dim, action_space, 5, 10, 500, 256, 0.01, 1.0,
+                           1.0, 0.001, 0.997, 0)
+      h = C.c_void_p()
+      _abi.check_replay(self.lib.mzr_create(C.byref(cfg), C.byref(h)), 'mzr_create')
+      self._h, self._own = h, True
+    else:
+      self._h, self._own = _owner, False
+
+  def __del__(self):
+    if getattr(self, '_own', False) and getattr(self, '_h', None):
+      self.lib.mzr_destroy(self._h)
+      self._h = None
+
+  def add(self, priorities, history=None):
+    pri = np.ascontiguousarray(priorities, np.float64)
+    pos = np.zeros(pri.size, np.int64)
+    _abi.check_replay(self.lib.mzr_tree_add(self._h, _p(pri), pri.size, _p(pos)), 'mzr_tree_add')
+    return pos
+
+  def update(self, idx, priority):
+    idx = np.ascontiguousarray(np.atleast_1d(idx), np.int64)
+    pri = np.ascontiguousarray(np.atleast_1d(priority), np.float64)
+    _abi.check_replay(self.lib.mzr_tree_update(self._h, _p(idx), _p(pri), idx.size), 'mzr_tree_update')
+
+  def get_leaf_index(self, value):
+    return int(self.lib.mzr_tree_get_leaf(self._h, float(value)))
+
+  @property
+  def total_priority(self):
+    return float(self.lib.mzr_total_priority(self._h))
+
+  @property
+  def num_memories(self):
+    return int(self.lib.mzr_size(self._h))
+
+  def leaves(self, n=None):
+    n = self.num_memories if n is None else int(n)
+    out = np.zeros(n, np.float64)
+    _abi.check_replay(self.lib.mzr_tree_leaves(self._h, n, _p(out)), 'mzr_tree_leaves')
+    return out
+
+
+class PrioritizedReplay(object):
+
+  def __init__(self, config):
+    self.config = config
+    self.batch_size = config.batch_size
+    self.epsilon, self.alpha, self.beta = config.epsilon, config.alpha, config.beta
+    self.obs_dim = int(np.prod(config.obs_space))
+    self.action_space = int(config.action_space)
+    capacity = int(config.window_size)
+    step = int(config.window_step) if getattr(config, 'window_step', None) is not None else capacity
+    self.lib = _abi.load_replay()
+    cfg = _abi.MzrConfig(capacity, step, self.obs_dim, self.action_space, int(config.num_unroll_steps),
+                         int(config.td_steps), int(getattr(config, 'max_history_length', 500)), int(config.batch_size),
+                         float(config.epsilon), float(config.alpha), float(config.beta),
+                         float(getattr(config, 'beta_increment_per_sampling', 0.001)), float(config.discount),
+                         int(config.seed or 0))
+    h = C.c_void_p()
+    _abi.check_replay(self.lib.mzr_create(C.byref(cfg), C.byref(h)), 'mzr_create')
+    self._h = h
+    self.tree = SumTree(capacity, step, _owner=self._h)
+
+  def __del__(self):
+    if getattr(self, '_h', None):
+      self.lib.mzr_destroy(self._h)
+      self._h = None
+
+  # replay_buffer.py:106-108
+  def add_initial_throughput(self, frames, games):
+    _abi.check_replay(self.lib.mzr_add_initial_throughput(self._h, int(frames), int(games)))
+
+  # replay_buffer.py:110-111
+  def get_priorities(self, errors):
+    errors = np.ascontiguousarray(errors, np.float64)
+    out = np.zeros_like(errors)
+    _abi.check_replay(self.lib.mzr_priorities(self._h, _p(errors), errors.size, _p(out)))
+    return out
+
+  # replay_buffer.py:113-122; `history` is a HistorySlice-like object (game.py:5-16)
+  def save_history(self, history, ignore=None, terminal=False):
+    n = len(history.errors)
+    errors = np.ascontiguousarray(history.errors, np.float64)
+    O, A = self.obs_dim, self.action_space
+    obs = np.ascontiguousarray(np.asarray(history.observations[:n], np.float32).reshape(n, O)) if n else None
+    cv = np.ascontiguousarray(np.asarray(history.child_visits, np.float32).reshape(n, A)) if n else None
+    rv = np.ascontiguousarray(history.root_values, np.float64)
+    rew = np.ascontiguousarray(history.rewards, np.float32)
+    act = np.ascontiguousarray(history.actions, np.int32)
+    dn = np.ascontiguousarray(history.dones, np.uint8)
+    tp = np.ascontiguousarray(history.to_play, np.int8)
+    _abi.check_replay(self.lib.mzr_save_history(self._h, n, _p(errors), -1 if ignore is None else int(ignore),
+                                                int(bool(terminal)), _p(obs), _p(cv), _p(rv), _p(rew), _p(act), _p(dn),
+                                                _p(tp)), 'mzr_save_history')
+
+  def ingest_records(self, records, n_moves, B):
+    """records: float32 [n_moves, B, rec_floats] host array/tensor from Engine.selfplay_drain."""
+    if hasattr(records, 'data_ptr'):
+      ptr, rec = C.c_void_p(records.data_ptr()), int(records.shape[-1])
+    else:
+      records = np.ascontiguousarray(records, np.float32)
+      ptr, rec = _p(records), int(records.shape[-1])
+    _abi.check_replay(self.lib.mzr_ingest_records(self._h, ptr, int(n_moves), int(B), rec), 'mzr_ingest_records')
+
+  # replay_buffer.py:200-203
+  def update(self, idxs, errors):
+    self.tree.update(np.asarray(idxs, np.int64), self.get_priorities(errors))
+
+  def size(self):
+    return int(self.lib.mzr_size(self._h))
+
+  def get_throughput(self):
+    return {'frames': int(self.lib.mzr_frames(self._h)), 'games': int(self.lib.mzr_games(self._h))}
