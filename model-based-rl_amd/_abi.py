@@ -62,6 +62,7 @@ SIGNATURES = {
     'mz_root_prepare': (_I, [_VP, _VP, _VP, _VP, _I, _U64, _VP]),
     'mz_search': (_I, [_VP, _I, _VP]),
     'mz_search_profiled': (_I, [_VP, _I, _VP, _VP]),
+    'mz_search_phase_profile': (_I, [_VP, _I, _VP, _VP]),
     'mz_select': (_I, [_VP, _VP, _VP, _VP, _VP, _VP]),
     'mz_gather_hidden': (_I, [_VP, _VP, _VP]),
     'mz_expand_backup': (_I, [_VP, _VP, _VP, _VP, _VP, _VP]),

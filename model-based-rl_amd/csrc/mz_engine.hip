@@ -19,6 +19,7 @@
 #include "mz_rng.h"
 #include "mz_tree.hip.h"
 #include "mz_selfplay.hip.h"
+#include "mz_fused.hip.h"
 
 static thread_local std::string g_err;
 
@@ -58,6 +59,10 @@ struct mz_engine {
   bool use_graph = true;
   SelfplayState sp;
   hipGraphExec_t move_graph = nullptr;
+  const f32x4 *wstream = nullptr;   // per-wave cyclic weight stream for the fused search kernel
+  int ws_np = 0;
+  bool use_fused = true;
+  unsigned long long *prof_buf = nullptr;   // non-null only inside mz_search_phase_profile
 };
 
 template <typename T>
@@ -148,6 +153,9 @@ static int build_packing(mz_engine *e) {
   const size_t p_w3 = seg((size_t)4 * 4 * ks3 * 256), p_b3 = seg(4 * 16 * 256);
   const size_t p_w4 = seg((size_t)(2 + jtp) * 4 * 8 * 256), p_b4 = seg(32 + 16 * jtp);
   const size_t p_lnw = seg(64), p_lnb = seg(64);
+  const int np = 16 + 4 * ks1 + 8 * 6 + 16 + 4 * ks3 + 8 * (2 + jtp);
+  const size_t p_ws = seg((size_t)4 * np * 256);
+  e->ws_np = np;
   e->n_packed = pos;
   std::vector<int32_t> idx(pos, -1);
   {
@@ -174,6 +182,25 @@ static int build_packing(mz_engine *e) {
   }
   fill_vec(idx, p_lnw, 64, L.ln_w, MZ_H);
   fill_vec(idx, p_lnb, 64, L.ln_b, MZ_H);
+  // the fused kernel's weight stream: per wave, the 1-KiB pieces above in consumption order
+  for (int w = 0; w < 4; ++w) {
+    size_t piece = 0;
+    auto put = [&](size_t src) {
+      memcpy(&idx[p_ws + ((size_t)w * np + piece) * 256], &idx[src], 256 * sizeof(int32_t));
+      ++piece;
+    };
+    for (int t = 0; t < 16; ++t) put(p_b1 + (size_t)(w * 16 + t) * 256);
+    for (int st = 0; st < ks1; ++st)
+      for (int tg = 0; tg < 4; ++tg) put(p_w1 + ((size_t)(w * 4 + tg) * ks1 + st) * 256);
+    for (int t = 0; t < 8; ++t)
+      for (int jt = 0; jt < 6; ++jt) put(p_w2 + ((size_t)(jt * 4 + w) * 8 + t) * 256);
+    for (int t = 0; t < 16; ++t) put(p_b3 + (size_t)(w * 16 + t) * 256);
+    for (int st = 0; st < ks3; ++st)
+      for (int tg = 0; tg < 4; ++tg) put(p_w3 + ((size_t)(w * 4 + tg) * ks3 + st) * 256);
+    for (int t = 0; t < 8; ++t)
+      for (int jt = 0; jt < 2 + jtp; ++jt) put(p_w4 + ((size_t)(jt * 4 + w) * 8 + t) * 256);
+    if ((int)piece != np) return fail("internal: weight stream has %zu pieces, expected %d", piece, np);
+  }
 
   if (dmalloc(e, &e->pack_idx, pos)) return -1;
   if (dmalloc(e, &e->packed, pos)) return -1;
@@ -185,11 +212,82 @@ static int build_packing(mz_engine *e) {
   n.w1 = (const f32x4 *)(P + p_w1); n.b1 = (const f32x4 *)(P + p_b1); n.w2 = (const f32x4 *)(P + p_w2); n.b2 = P + p_b2;
   n.w3 = (const f32x4 *)(P + p_w3); n.b3 = (const f32x4 *)(P + p_b3); n.w4 = (const f32x4 *)(P + p_w4); n.b4 = P + p_b4;
   n.lnw = P + p_lnw; n.lnb = P + p_lnb;
+  e->wstream = (const f32x4 *)(P + p_ws);
   n.ks0 = ks0; n.ks1 = ks1; n.ks3 = ks3; n.O = O; n.A = A; n.jtp = jtp;
   n.Sr = Sr; n.Sv = Sv; n.rmin = e->cfg.reward_support_min; n.vmin = e->cfg.value_support_min;
   n.no_transform = e->cfg.no_target_transform;
   return 0;
 }
+
+#define NET_LAUNCH(kern, grid, s, ...)                                                        \
+  do {                                                                                        \
+    if (e->jtp == 1) hipLaunchKernelGGL(kern<1>, dim3(grid), dim3(256), 0, s, __VA_ARGS__);    \
+    else hipLaunchKernelGGL(kern<2>, dim3(grid), dim3(256), 0, s, __VA_ARGS__);                \
+  } while (0)
+
+#define TREE_LAUNCH(kern, s, ...)                                                             \
+  do {                                                                                        \
+    const int threads_ = 256;                                                                 \
+    const int total_ = e->B * e->G;                                                           \
+    const int blocks_ = (total_ + threads_ - 1) / threads_;                                   \
+    switch (e->G) {                                                                           \
+      case 4: hipLaunchKernelGGL(kern<4>, dim3(blocks_), dim3(threads_), 0, s, __VA_ARGS__); break;   \
+      case 8: hipLaunchKernelGGL(kern<8>, dim3(blocks_), dim3(threads_), 0, s, __VA_ARGS__); break;   \
+      case 16: hipLaunchKernelGGL(kern<16>, dim3(blocks_), dim3(threads_), 0, s, __VA_ARGS__); break; \
+      default: hipLaunchKernelGGL(kern<32>, dim3(blocks_), dim3(threads_), 0, s, __VA_ARGS__); break; \
+    }                                                                                         \
+  } while (0)
+
+
+template <int JTP, int G>
+static int launch_fused_t(mz_engine *e, int num_simulations, int sims_done, hipStream_t s) {
+  static bool attr_set = false;
+  const size_t lds = (size_t)MZ_FUSED_LDS_FLOATS * sizeof(float);
+  if (!attr_set) {
+    HIPCHECK(hipFuncSetAttribute((const void *)k_search_fused<JTP, G, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)lds));
+    attr_set = true;
+  }
+  if (e->prof_buf) {
+    HIPCHECK(hipFuncSetAttribute((const void *)k_search_fused<JTP, G, true>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_search_fused<JTP, G, true>), dim3(e->Bp / MZ_ROWS), dim3(256), lds, s, e->nv, e->tv,
+                       e->wstream, e->ws_np, num_simulations, sims_done, e->prof_buf);
+  } else {
+    hipLaunchKernelGGL((k_search_fused<JTP, G, false>), dim3(e->Bp / MZ_ROWS), dim3(256), lds, s, e->nv, e->tv,
+                       e->wstream, e->ws_np, num_simulations, sims_done, (unsigned long long *)nullptr);
+  }
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
+
+static int launch_fused(mz_engine *e, int num_simulations, int sims_done, hipStream_t s) {
+  if (e->jtp == 1) {
+    switch (e->G) {
+      case 4: return launch_fused_t<1, 4>(e, num_simulations, sims_done, s);
+      case 8: return launch_fused_t<1, 8>(e, num_simulations, sims_done, s);
+      default: return launch_fused_t<1, 16>(e, num_simulations, sims_done, s);
+    }
+  }
+  return launch_fused_t<2, 32>(e, num_simulations, sims_done, s);
+}
+
+static int launch_search(mz_engine *e, int num_simulations, bool selection_valid, int sims_done, hipStream_t s) {
+  if (e->use_fused) {
+    if (!selection_valid) TREE_LAUNCH(k_tree_select, s, e->tv);
+    return launch_fused(e, num_simulations, sims_done, s);
+  }
+  for (int i = 0; i < num_simulations; ++i) {
+    if (!selection_valid) TREE_LAUNCH(k_tree_select, s, e->tv);
+    NET_LAUNCH(k_net_recurrent_tree, e->Bp / MZ_ROWS, s, e->nv, e->tv, sims_done + i + 1);
+    const int more = (i + 1 < num_simulations) ? 1 : 0;
+    TREE_LAUNCH(k_tree_step, s, e->tv, more);
+    selection_valid = more;
+  }
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
+
 
 // ---------------------------------------------------------------- ABI
 extern "C" {
@@ -224,6 +322,7 @@ int mz_create(const mz_config *cfg, mz_engine **out) {
   e->G = e->A <= 4 ? 4 : (e->A <= 8 ? 8 : (e->A <= 16 ? 16 : 32));
   e->jtp = e->A <= 16 ? 1 : 2;
   e->use_graph = getenv("MZ_NO_GRAPH") == nullptr;
+  e->use_fused = getenv("MZ_NO_FUSED") == nullptr;
   TreeView &t = e->tv;
   memset(&t, 0, sizeof t);
   const size_t nb = (size_t)e->Bp, nn = nb * e->NN;
@@ -300,25 +399,6 @@ int mz_set_weights(mz_engine *e, const float *flat, size_t n, int on_device, voi
   return 0;
 }
 
-#define NET_LAUNCH(kern, grid, s, ...)                                                        \
-  do {                                                                                        \
-    if (e->jtp == 1) hipLaunchKernelGGL(kern<1>, dim3(grid), dim3(256), 0, s, __VA_ARGS__);    \
-    else hipLaunchKernelGGL(kern<2>, dim3(grid), dim3(256), 0, s, __VA_ARGS__);                \
-  } while (0)
-
-#define TREE_LAUNCH(kern, s, ...)                                                             \
-  do {                                                                                        \
-    const int threads_ = 256;                                                                 \
-    const int total_ = e->B * e->G;                                                           \
-    const int blocks_ = (total_ + threads_ - 1) / threads_;                                   \
-    switch (e->G) {                                                                           \
-      case 4: hipLaunchKernelGGL(kern<4>, dim3(blocks_), dim3(threads_), 0, s, __VA_ARGS__); break;   \
-      case 8: hipLaunchKernelGGL(kern<8>, dim3(blocks_), dim3(threads_), 0, s, __VA_ARGS__); break;   \
-      case 16: hipLaunchKernelGGL(kern<16>, dim3(blocks_), dim3(threads_), 0, s, __VA_ARGS__); break; \
-      default: hipLaunchKernelGGL(kern<32>, dim3(blocks_), dim3(threads_), 0, s, __VA_ARGS__); break; \
-    }                                                                                         \
-  } while (0)
-
 int mz_initial_inference(mz_engine *e, const float *obs, void *stream) {
   if (!e || !obs) return fail("mz_initial_inference: null argument");
   if (!e->weights_set) return fail("mz_initial_inference: weights not set (call mz_set_weights)");
@@ -387,18 +467,6 @@ int mz_root_prepare(mz_engine *e, const int8_t *to_play, const uint8_t *legal, c
   return 0;
 }
 
-static int launch_search(mz_engine *e, int num_simulations, bool selection_valid, int sims_done, hipStream_t s) {
-  for (int i = 0; i < num_simulations; ++i) {
-    if (!selection_valid) TREE_LAUNCH(k_tree_select, s, e->tv);
-    NET_LAUNCH(k_net_recurrent_tree, e->Bp / MZ_ROWS, s, e->nv, e->tv, sims_done + i + 1);
-    const int more = (i + 1 < num_simulations) ? 1 : 0;
-    TREE_LAUNCH(k_tree_step, s, e->tv, more);
-    selection_valid = more;
-  }
-  HIPCHECK(hipGetLastError());
-  return 0;
-}
-
 int mz_search(mz_engine *e, int num_simulations, void *stream) {
   if (!e) return fail("mz_search: null engine");
   if (!e->weights_set) return fail("mz_search: weights not set (call mz_set_weights)");
@@ -455,6 +523,36 @@ int mz_search_profiled(mz_engine *e, int num_simulations, float *ms_out, void *s
     ms_out[0] += a; ms_out[1] += b;
   }
   for (auto &x : ev) hipEventDestroy(x);
+  e->sims_done = num_simulations;
+  e->selection_valid = false;
+  return 0;
+}
+
+int mz_search_phase_profile(mz_engine *e, int num_simulations, unsigned long long *cycles_out, void *stream) {
+  if (!e || !cycles_out) return fail("mz_search_phase_profile: null argument");
+  if (!e->use_fused) return fail("mz_search_phase_profile: fused kernel disabled");
+  if (!e->root_ready || !e->selection_valid || e->sims_done != 0)
+    return fail("mz_search_phase_profile: call right after mz_root_prepare");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t n = (size_t)(e->Bp / MZ_ROWS) * 4 * MZ_NPHASE;
+  unsigned long long *buf = nullptr;
+  HIPCHECK(hipMalloc((void **)&buf, n * 8));
+  HIPCHECK(hipMemsetAsync(buf, 0, n * 8, s));
+  e->prof_buf = buf;
+  int rc = launch_fused(e, num_simulations, 0, s);
+  e->prof_buf = nullptr;
+  if (rc) { hipFree(buf); return -1; }
+  HIPCHECK(hipStreamSynchronize(s));
+  std::vector<unsigned long long> h(n);
+  HIPCHECK(hipMemcpy(h.data(), buf, n * 8, hipMemcpyDeviceToHost));
+  hipFree(buf);
+  // average over workgroups, per wave and phase: cycles_out[4][MZ_NPHASE]
+  for (int w = 0; w < 4; ++w)
+    for (int p = 0; p < MZ_NPHASE; ++p) {
+      unsigned long long sum = 0;
+      for (int g = 0; g < e->Bp / MZ_ROWS; ++g) sum += h[((size_t)g * 4 + w) * MZ_NPHASE + p];
+      cycles_out[w * MZ_NPHASE + p] = sum / (unsigned long long)(e->Bp / MZ_ROWS);
+    }
   e->sims_done = num_simulations;
   e->selection_valid = false;
   return 0;

@@ -19,7 +19,7 @@ __device__ __forceinline__ double mz_normalize(double v, double mn, double mx) {
 
 // The descent of MCTS.run (mcts.py:83-94) with MCTS.select_child (104-113) and ucb_score (115-124).
 template <int G>
-__device__ __forceinline__ void mz_tree_select(const TreeView &t, int b, int lane) {
+__device__ __forceinline__ void mz_tree_select(const TreeView &t, int b, int lane, int &slot_out, int &act_out) {
   const int A = t.A;
   const size_t o = (size_t)b * t.NN;
   int32_t *path = t.path + (size_t)b * t.PL;
@@ -72,14 +72,22 @@ __device__ __forceinline__ void mz_tree_select(const TreeView &t, int b, int lan
     if (t.two_players) tp = -tp;
     e = t.E[o + node];
   }
+  slot_out = t.E[o + parent];
+  act_out = a_sel;
   if (lane == 0) {
     t.plen[b] = len;
     t.leaf_tp[b] = (int8_t)tp;
     t.leaf[b] = node;
-    t.slot[b] = t.E[o + parent];
+    t.slot[b] = slot_out;
     t.act[b] = a_sel;
     t.depth[b] = len - 1;
   }
+}
+
+template <int G>
+__device__ __forceinline__ void mz_tree_select(const TreeView &t, int b, int lane) {
+  int s_, a_;
+  mz_tree_select<G>(t, b, lane, s_, a_);
 }
 
 // Node.expand for the selected leaf (mcts.py:47-55, all actions: mcts.py:97) followed by

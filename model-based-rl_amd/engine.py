@@ -170,6 +170,13 @@ class Engine(object):
     _abi.check(self.lib.mz_search_profiled(self._h, n, ms, self.stream), 'mz_search_profiled')
     return float(ms[0]), float(ms[1])
 
+  def search_phase_profile(self, num_simulations=None):
+    n = self.sims if num_simulations is None else int(num_simulations)
+    out = np.zeros((4, 12), np.uint64)
+    _abi.check(self.lib.mz_search_phase_profile(self._h, n, out.ctypes.data_as(C.c_void_p), self.stream),
+               'mz_search_phase_profile')
+    return out
+
   def select(self):
     out = [torch.empty(self.B, dtype=torch.int32, device=self.device) for _ in range(4)]
     _abi.check(self.lib.mz_select(self._h, *[_ptr(o) for o in out], self.stream), 'mz_select')
