@@ -121,6 +121,23 @@ static void fill_fc1(std::vector<int32_t> &idx, size_t wpos, size_t bpos, int NH
         }
 }
 
+// fc1 pack for the fused kernel: as fill_fc1 (two heads), but input column K carries the bias
+static void fill_fc1_biascol(std::vector<int32_t> &idx, size_t wpos, const size_t *woff, const size_t *boff, int K,
+                             int ks) {
+  for (int w = 0; w < 4; ++w)
+    for (int tg = 0; tg < 4; ++tg)
+      for (int s = 0; s < ks; ++s)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int i = 0; i < 4; ++i) {
+            const int t = 4 * tg + i, head = t / 8, tt = t % 8;
+            const int nf = 128 * w + 16 * tt + (lane & 15), k = 4 * s + (lane >> 4);
+            int32_t v = -1;
+            if (k < K) v = (int32_t)(woff[head] + (size_t)nf * K + k);
+            else if (k == K) v = (int32_t)(boff[head] + nf);
+            idx[wpos + ((((size_t)(w * 4 + tg) * ks + s) * 64 + lane) * 4 + i)] = v;
+          }
+}
+
 // fc2 pack: [JT][4 waves][8 tiles][64][4]: A operand row j = 16jt + (lane&15), k = 128w + 16t + 4(lane>>4) + r
 static void fill_fc2(std::vector<int32_t> &idx, size_t wpos, int JT, size_t woff, int J) {
   for (int jt = 0; jt < JT; ++jt)
@@ -153,7 +170,10 @@ static int build_packing(mz_engine *e) {
   const size_t p_w3 = seg((size_t)4 * 4 * ks3 * 256), p_b3 = seg(4 * 16 * 256);
   const size_t p_w4 = seg((size_t)(2 + jtp) * 4 * 8 * 256), p_b4 = seg(32 + 16 * jtp);
   const size_t p_lnw = seg(64), p_lnb = seg(64);
-  const int np = 16 + 4 * ks1 + 8 * 6 + 16 + 4 * ks3 + 8 * (2 + jtp);
+  // fused kernel: fc1 weights with the bias as one more input column (constant-1 input), no bias pieces
+  const int ks1f = (MZ_H + A + 1 + 3) / 4, ks3f = (MZ_H + 1 + 3) / 4;
+  const size_t p_w1f = seg((size_t)4 * 4 * ks1f * 256), p_w3f = seg((size_t)4 * 4 * ks3f * 256);
+  const int np = 4 * ks1f + 8 * 6 + 4 * ks3f + 8 * (2 + jtp);
   const size_t p_ws = seg((size_t)4 * np * 256);
   e->ws_np = np;
   e->n_packed = pos;
@@ -182,6 +202,12 @@ static int build_packing(mz_engine *e) {
   }
   fill_vec(idx, p_lnw, 64, L.ln_w, MZ_H);
   fill_vec(idx, p_lnb, 64, L.ln_b, MZ_H);
+  {
+    size_t wo[2] = {L.rew_w1, L.tr_w1}, bo[2] = {L.rew_b1, L.tr_b1};
+    fill_fc1_biascol(idx, p_w1f, wo, bo, MZ_H + A, ks1f);
+    size_t wo3[2] = {L.val_w1, L.pol_w1}, bo3[2] = {L.val_b1, L.pol_b1};
+    fill_fc1_biascol(idx, p_w3f, wo3, bo3, MZ_H, ks3f);
+  }
   // the fused kernel's weight stream: per wave, the 1-KiB pieces above in consumption order
   for (int w = 0; w < 4; ++w) {
     size_t piece = 0;
@@ -189,14 +215,12 @@ static int build_packing(mz_engine *e) {
       memcpy(&idx[p_ws + ((size_t)w * np + piece) * 256], &idx[src], 256 * sizeof(int32_t));
       ++piece;
     };
-    for (int t = 0; t < 16; ++t) put(p_b1 + (size_t)(w * 16 + t) * 256);
-    for (int st = 0; st < ks1; ++st)
-      for (int tg = 0; tg < 4; ++tg) put(p_w1 + ((size_t)(w * 4 + tg) * ks1 + st) * 256);
+    for (int st = 0; st < ks1f; ++st)
+      for (int tg = 0; tg < 4; ++tg) put(p_w1f + ((size_t)(w * 4 + tg) * ks1f + st) * 256);
     for (int t = 0; t < 8; ++t)
       for (int jt = 0; jt < 6; ++jt) put(p_w2 + ((size_t)(jt * 4 + w) * 8 + t) * 256);
-    for (int t = 0; t < 16; ++t) put(p_b3 + (size_t)(w * 16 + t) * 256);
-    for (int st = 0; st < ks3; ++st)
-      for (int tg = 0; tg < 4; ++tg) put(p_w3 + ((size_t)(w * 4 + tg) * ks3 + st) * 256);
+    for (int st = 0; st < ks3f; ++st)
+      for (int tg = 0; tg < 4; ++tg) put(p_w3f + ((size_t)(w * 4 + tg) * ks3f + st) * 256);
     for (int t = 0; t < 8; ++t)
       for (int jt = 0; jt < 2 + jtp; ++jt) put(p_w4 + ((size_t)(jt * 4 + w) * 8 + t) * 256);
     if ((int)piece != np) return fail("internal: weight stream has %zu pieces, expected %d", piece, np);
