@@ -13,7 +13,8 @@ _SOURCES = ['mz_engine.hip', 'mz_common.h', 'mz_net.hip.h', 'mz_tree.hip.h', 'mz
             'mz_selfplay_abi.inc', 'mz_fused.hip.h']
 _lib = None
 
-HIPCC_FLAGS = ['-O3', '--offload-arch=gfx950', '-ffp-contract=off', '-std=c++17', '-fPIC', '-shared']
+HIPCC_FLAGS = ['-O3', '--offload-arch=gfx950', '-ffp-contract=off', '-std=c++17', '-fPIC', '-shared', '-Wno-unused-value',
+               '-Wno-unused-result']
 
 
 class MzConfig(C.Structure):

@@ -60,7 +60,7 @@ struct mz_engine {
   SelfplayState sp;
   hipGraphExec_t move_graph = nullptr;
   const f32x4 *wstream = nullptr;   // per-wave cyclic weight stream for the fused search kernel
-  int ws_np = 0;
+  int ks1sel = 0;                   // fc1 k-steps of the fused kernel instantiation chosen for this A
   bool use_fused = true;
   unsigned long long *prof_buf = nullptr;   // non-null only inside mz_search_phase_profile
 };
@@ -170,12 +170,14 @@ static int build_packing(mz_engine *e) {
   const size_t p_w3 = seg((size_t)4 * 4 * ks3 * 256), p_b3 = seg(4 * 16 * 256);
   const size_t p_w4 = seg((size_t)(2 + jtp) * 4 * 8 * 256), p_b4 = seg(32 + 16 * jtp);
   const size_t p_lnw = seg(64), p_lnb = seg(64);
-  // fused kernel: fc1 weights with the bias as one more input column (constant-1 input), no bias pieces
-  const int ks1f = (MZ_H + A + 1 + 3) / 4, ks3f = (MZ_H + 1 + 3) / 4;
+  // fused kernel: fc1 weights with the bias as one more input column (constant-1 input); the k-step
+  // count is that of the kernel instantiation chosen for this action count (zero-padded above 50+A+1)
+  const int ks1f = e->ks1sel, ks3f = (MZ_H + 1 + 3) / 4;
   const size_t p_w1f = seg((size_t)4 * 4 * ks1f * 256), p_w3f = seg((size_t)4 * 4 * ks3f * 256);
-  const int np = 4 * ks1f + 8 * 6 + 4 * ks3f + 8 * (2 + jtp);
-  const size_t p_ws = seg((size_t)4 * np * 256);
-  e->ws_np = np;
+  const int nj2 = 2 + jtp;
+  const int real_steps = ks1f + 12 + ks3f + 2 * nj2;
+  const int nsteps = (real_steps + MZ_NB - 1) / MZ_NB * MZ_NB;
+  const size_t p_ws = seg((size_t)4 * nsteps * 4 * 256);
   e->n_packed = pos;
   std::vector<int32_t> idx(pos, -1);
   {
@@ -208,11 +210,11 @@ static int build_packing(mz_engine *e) {
     size_t wo3[2] = {L.val_w1, L.pol_w1}, bo3[2] = {L.val_b1, L.pol_b1};
     fill_fc1_biascol(idx, p_w3f, wo3, bo3, MZ_H, ks3f);
   }
-  // the fused kernel's weight stream: per wave, the 1-KiB pieces above in consumption order
+  // the fused kernel's weight stream: per wave [nsteps][4 pieces][64 lanes][4], consumption order
   for (int w = 0; w < 4; ++w) {
     size_t piece = 0;
     auto put = [&](size_t src) {
-      memcpy(&idx[p_ws + ((size_t)w * np + piece) * 256], &idx[src], 256 * sizeof(int32_t));
+      memcpy(&idx[p_ws + ((size_t)w * nsteps * 4 + piece) * 256], &idx[src], 256 * sizeof(int32_t));
       ++piece;
     };
     for (int st = 0; st < ks1f; ++st)
@@ -222,8 +224,9 @@ static int build_packing(mz_engine *e) {
     for (int st = 0; st < ks3f; ++st)
       for (int tg = 0; tg < 4; ++tg) put(p_w3f + ((size_t)(w * 4 + tg) * ks3f + st) * 256);
     for (int t = 0; t < 8; ++t)
-      for (int jt = 0; jt < 2 + jtp; ++jt) put(p_w4 + ((size_t)(jt * 4 + w) * 8 + t) * 256);
-    if ((int)piece != np) return fail("internal: weight stream has %zu pieces, expected %d", piece, np);
+      for (int jt = 0; jt < nj2; ++jt) put(p_w4 + ((size_t)(jt * 4 + w) * 8 + t) * 256);
+    if ((int)piece != real_steps * 4) return fail("internal: weight stream has %zu pieces, expected %d", piece, real_steps * 4);
+    // the remaining (nsteps - real_steps) * 4 pieces are padding (index -1 -> 0.0), loaded but never used
   }
 
   if (dmalloc(e, &e->pack_idx, pos)) return -1;
@@ -263,37 +266,31 @@ static int build_packing(mz_engine *e) {
   } while (0)
 
 
-template <int JTP, int G>
+template <int KS1, int JTP, int G>
 static int launch_fused_t(mz_engine *e, int num_simulations, int sims_done, hipStream_t s) {
-  static bool attr_set = false;
-  const size_t lds = (size_t)MZ_FUSED_LDS_FLOATS * sizeof(float);
-  if (!attr_set) {
-    HIPCHECK(hipFuncSetAttribute((const void *)k_search_fused<JTP, G, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)lds));
-    attr_set = true;
-  }
   if (e->prof_buf) {
-    HIPCHECK(hipFuncSetAttribute((const void *)k_search_fused<JTP, G, true>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_search_fused<JTP, G, true>), dim3(e->Bp / MZ_ROWS), dim3(256), lds, s, e->nv, e->tv,
-                       e->wstream, e->ws_np, num_simulations, sims_done, e->prof_buf);
+    hipLaunchKernelGGL((k_search_fused<KS1, JTP, G, true>), dim3(e->Bp / MZ_ROWS), dim3(256), 0, s, e->nv, e->tv,
+                       e->wstream, num_simulations, sims_done, e->prof_buf);
   } else {
-    hipLaunchKernelGGL((k_search_fused<JTP, G, false>), dim3(e->Bp / MZ_ROWS), dim3(256), lds, s, e->nv, e->tv,
-                       e->wstream, e->ws_np, num_simulations, sims_done, (unsigned long long *)nullptr);
+    hipLaunchKernelGGL((k_search_fused<KS1, JTP, G, false>), dim3(e->Bp / MZ_ROWS), dim3(256), 0, s, e->nv, e->tv,
+                       e->wstream, num_simulations, sims_done, (unsigned long long *)nullptr);
   }
   HIPCHECK(hipGetLastError());
   return 0;
 }
 
+// fused-kernel instantiations: (fc1 k-steps, policy tiles, lanes per tree) by action count
+static int fused_ks1(int A) { return A <= 5 ? 14 : (A <= 13 ? 16 : (A <= 21 ? 18 : 21)); }
+
 static int launch_fused(mz_engine *e, int num_simulations, int sims_done, hipStream_t s) {
-  if (e->jtp == 1) {
-    switch (e->G) {
-      case 4: return launch_fused_t<1, 4>(e, num_simulations, sims_done, s);
-      case 8: return launch_fused_t<1, 8>(e, num_simulations, sims_done, s);
-      default: return launch_fused_t<1, 16>(e, num_simulations, sims_done, s);
-    }
-  }
-  return launch_fused_t<2, 32>(e, num_simulations, sims_done, s);
+  const int A = e->A;
+  if (A <= 4) return launch_fused_t<14, 1, 4>(e, num_simulations, sims_done, s);
+  if (A <= 5) return launch_fused_t<14, 1, 8>(e, num_simulations, sims_done, s);
+  if (A <= 8) return launch_fused_t<16, 1, 8>(e, num_simulations, sims_done, s);
+  if (A <= 13) return launch_fused_t<16, 1, 16>(e, num_simulations, sims_done, s);
+  if (A <= 16) return launch_fused_t<18, 1, 16>(e, num_simulations, sims_done, s);
+  if (A <= 21) return launch_fused_t<18, 2, 32>(e, num_simulations, sims_done, s);
+  return launch_fused_t<21, 2, 32>(e, num_simulations, sims_done, s);
 }
 
 static int launch_search(mz_engine *e, int num_simulations, bool selection_valid, int sims_done, hipStream_t s) {
@@ -345,6 +342,7 @@ int mz_create(const mz_config *cfg, mz_engine **out) {
   e->PL = e->sims + 2;
   e->G = e->A <= 4 ? 4 : (e->A <= 8 ? 8 : (e->A <= 16 ? 16 : 32));
   e->jtp = e->A <= 16 ? 1 : 2;
+  e->ks1sel = fused_ks1(e->A);
   e->use_graph = getenv("MZ_NO_GRAPH") == nullptr;
   e->use_fused = getenv("MZ_NO_FUSED") == nullptr;
   TreeView &t = e->tv;

@@ -6,150 +6,65 @@
 //   the matrix cores  ->  [tree lanes] expand + backup + next descent.   Trees never leave their
 //   workgroup, so there is no grid-wide synchronisation and no host round trip between simulations.
 //
-// Weight streaming: every wave consumes its share of the network (~210 KiB per simulation) as ONE cyclic
-// stream of 1-KiB pieces laid out in exactly the order the MFMAs need them.  Pieces travel L2 -> LDS by
-// LDS-DMA (global_load_lds_dwordx4) into a per-wave ring and are read back with one ds_read_b128 per
-// piece; the ring runs WS_A0 pieces ahead of consumption behind a COUNTED s_waitcnt vmcnt(WS_A0), also
-// across the barriers and the tree phases (raw s_barrier, never a vmcnt(0) drain in the loop), so the
-// L2 latency is paid once per launch instead of once per piece.  Because the stream is cyclic the
-// prefetch for simulation s+1 is in flight while simulation s finishes.
+// Weight streaming.  Each wave consumes its share of the network (~185 KiB per simulation) as one cyclic
+// stream of STEPS; a step = four 1-KiB pieces = the A operands of 16 MFMAs, laid out in consumption order
+// (bias = the weight column of a constant-1 input, so there are no bias pieces).  Pieces go L2 -> VGPR
+// with plain global_load_dwordx4 into a ring of NB register buffers, NB-1 steps (>= 2000 cycles) ahead of
+// use.  The whole per-simulation schedule is unrolled so that every buffer index is a compile-time
+// constant; the stream is padded to a multiple of NB steps per simulation so the ring position is the
+// same at the top of every simulation and the prefetch runs across simulation boundaries, barriers and
+// the tree phase.   (Measured dead end, kept out: LDS-DMA (global_load_lds) rings filled by the MFMA
+// waves themselves -- each 1-KiB piece costs the issuing wave ~150 cycles of issue time, 4 per 16 MFMAs,
+// which halves the MFMA rate; see DESIGN.md.)
 #pragma once
 #include "mz_common.h"
 #include "mz_net.hip.h"
 #include "mz_tree.hip.h"
+#include <utility>
 
-#define WS_R 28     // ring slots (1 KiB each) per wave
-#define WS_A0 20    // pieces in flight ahead of consumption; WS_A0 + 8 <= WS_R
-
-struct WS {
-  const f32x4 *src;   // this wave's stream + lane
-  f32x4 *ring;        // this wave's ring (wave-uniform LDS base)
-  unsigned ring_lds;  // its LDS byte address
-  int gpos, islot, cslot, np;
-  unsigned long long wait_cycles;
-};
-
-// One 1-KiB piece L2 -> LDS (global_load_lds_dwordx4: LDS address = M0 + lane*16, global address per lane).
-// Issued from inline asm ON PURPOSE: hipcc models the builtin form as a FLAT access that may touch LDS
-// and, while one is pending, turns every counted s_waitcnt lgkmcnt(N) it inserts into lgkmcnt(0) -- which
-// puts a full LDS-latency stall in front of the first MFMA of every step.  The RAW ordering DMA -> ds_read
-// is done by hand with the counted vmcnt in pipe_fetch.
-__device__ __forceinline__ void ws_issue(WS &s) {
-  {
-    const unsigned lds = __builtin_amdgcn_readfirstlane(s.ring_lds + (unsigned)s.islot * 1024u);
-    const f32x4 *g = s.src + (size_t)s.gpos * 64;
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds), "v"(g) : "memory", "m0");
-  }
-  s.gpos = (s.gpos + 1 == s.np) ? 0 : s.gpos + 1;
-  s.islot = (s.islot + 1 == WS_R) ? 0 : s.islot + 1;
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N-1>{})
+template <class F, int... Is>
+__device__ __forceinline__ void mz_static_for_impl(F &&f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void mz_static_for(F &&f) {
+  mz_static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-// MFMA from inline asm with the accumulator tied in place ("+a"): left to itself hipcc, in this kernel,
-// stages every accumulator through one scratch tile (4 v_accvgpr_mov per MFMA, all MFMAs serialised on it).
-// Nothing else in an asm statement is visible to its hazard recogniser, so mz_mfma_fence() supplies the
-// MFMA-result -> VALU wait states once per stage.
+#define MZ_NB 5      // register ring depth in steps (prefetch distance NB-1 steps)
+#define MZ_XE 36     // row stride of the x-tile extension [one-hot(action) | 1 | 0 ...] (k >= 50)
+
+// per-simulation schedule (in steps of 16 MFMAs per wave)
+template <int KS1, int JTP>
+struct FusedSched {
+  static constexpr int FC1 = KS1;               // dynamics fc1: K = 50 + A + 1 (bias column), 4 per step
+  static constexpr int FC2 = 12;                // reward (2 tiles) + next hidden (4 tiles): 48 pieces
+  static constexpr int P1 = (MZ_H + 1 + 3) / 4; // prediction fc1: K = 51 -> 13 steps
+  static constexpr int P2 = 2 * (2 + JTP);      // value (2 tiles) + policy (JTP tiles)
+  static constexpr int REAL = FC1 + FC2 + P1 + P2;
+  static constexpr int NSTEPS = (REAL + MZ_NB - 1) / MZ_NB * MZ_NB;   // padded with dummy steps
+};
+
+// MFMA from inline asm with the accumulator tied in place ("+a").  Left to itself hipcc, in this kernel,
+// stages every accumulator through one scratch tile (4 v_accvgpr_mov per MFMA, all MFMAs serialised on
+// it).  Its hazard recogniser does not look inside asm, so mz_mfma_fence() supplies the MFMA-result ->
+// VALU wait states once per stage.
 __device__ __forceinline__ void mz_mfma_a(f32x4 &c, float a, float b) {
   asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
 template <int N>
 __device__ __forceinline__ void mz_mfma_fence(f32x4 (&acc)[N]) {
-  if constexpr (N == 16) {
-    asm volatile("s_nop 15\n\ts_nop 7"
-                 : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]), "+a"(acc[4]), "+a"(acc[5]), "+a"(acc[6]),
-                   "+a"(acc[7]), "+a"(acc[8]), "+a"(acc[9]), "+a"(acc[10]), "+a"(acc[11]), "+a"(acc[12]),
-                   "+a"(acc[13]), "+a"(acc[14]), "+a"(acc[15]));
-  } else {
 #pragma unroll
-    for (int i = 0; i < N; ++i) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc[i]));
-  }
-}
-
-// Pipeline invariant at the start of every 4-piece step: the step's own pieces are already in registers
-// (`cur`), WS_A0 younger pieces are in flight and the oldest four of those belong to the next step.
-// pipe_fetch: wait for those four (counted vmcnt), start reading them (ds_read_b128, consumed one step
-// later so their LDS latency hides under this step's 16 MFMAs).  The four new DMA pieces of the step are
-// issued one per MFMA group so that they take issue slots the matrix pipe leaves free.
-__device__ unsigned long long g_wait_cycles_dummy;
-__device__ __forceinline__ void pipe_fetch(WS &s, int lane, f32x4 (&nxt)[4]) {
-#ifdef MZ_PROF_WAIT
-  __builtin_amdgcn_sched_barrier(0);
-  const unsigned long long t0_ = __builtin_amdgcn_s_memtime();
-  __builtin_amdgcn_sched_barrier(0);
-#endif
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WS_A0 - 4) : "memory");
-#ifdef MZ_PROF_WAIT
-  __builtin_amdgcn_sched_barrier(0);
-  s.wait_cycles += __builtin_amdgcn_s_memtime() - t0_;
-  __builtin_amdgcn_sched_barrier(0);
-#endif
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    nxt[p] = s.ring[s.cslot * 64 + lane];
-    s.cslot = (s.cslot + 1 == WS_R) ? 0 : s.cslot + 1;
-  }
+  for (int i = 0; i < N; ++i) asm volatile("s_nop 7" : "+a"(acc[i]));
+  asm volatile("s_nop 15" ::: "memory");
 }
 
 __device__ __forceinline__ void mz_bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// B operand of an fc1 k-step: x[m][k] from the row-major tile (k < 50); one-hot(action) (networks.py:167-174)
-// and the constant-1 column that carries the bias (k - 50 == ones_k) above that.
-#define MZ_XE 36   // row stride of the extension tile: [one-hot(action) | 1 | 0...] for k >= 50
 __device__ __forceinline__ float mz_xval(const float *xR, const float *xE, int m, int k) {
   const float *p = (k < MZ_H) ? (xR + m * MZ_HS + k) : (xE + m * MZ_XE + (k - MZ_H));
   return *p;
-}
-
-// fc1 (two 512-wide heads, 16 tiles per wave) from the stream: ks steps of 4 pieces; bias = weight column
-// of the constant-1 input.
-__device__ __forceinline__ void pfc1(WS &s, const float *xR, const float *xE, int ks, int lane,
-                                     f32x4 (&cur)[4], f32x4 (&acc)[16]) {
-  const int g = lane >> 4, m = lane & 15;
-#pragma unroll
-  for (int t = 0; t < 16; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float xc = mz_xval(xR, xE, m, g);
-  for (int st = 0; st < ks; ++st) {
-    f32x4 nxt[4];
-    pipe_fetch(s, lane, nxt);
-    const float xn = mz_xval(xR, xE, m, 4 * (st + 1) + g);   // beyond the last step: reads pad, unused
-#pragma unroll
-    for (int tg = 0; tg < 4; ++tg) {
-      ws_issue(s);
-      mz_mfma_a(acc[4 * tg + 0], cur[tg][0], xc);
-      mz_mfma_a(acc[4 * tg + 1], cur[tg][1], xc);
-      mz_mfma_a(acc[4 * tg + 2], cur[tg][2], xc);
-      mz_mfma_a(acc[4 * tg + 3], cur[tg][3], xc);
-    }
-#pragma unroll
-    for (int p = 0; p < 4; ++p) cur[p] = nxt[p];
-    xc = xn;
-  }
-  mz_mfma_fence<16>(acc);
-}
-
-// fc2 from the stream: NJ output tiles per hidden tile t (the first JA take hid[t], the rest hid[8+t]);
-// pieces arrive in (t, jt) order, four per step; the r loop is outermost inside a step so that
-// consecutive MFMAs hit different accumulators.
-template <int NJ, int JA>
-__device__ __forceinline__ void pfc2(WS &s, int lane, f32x4 (&cur)[4], const f32x4 (&hid)[16], f32x4 (&out)[NJ]) {
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) out[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int step = 0; step < 2 * NJ; ++step) {
-    f32x4 nxt[4];
-    pipe_fetch(s, lane, nxt);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      ws_issue(s);
-#pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {
-        const int q = 4 * step + q4, t = q / NJ, jt = q % NJ;
-        mz_mfma_a(out[jt], cur[q4][r], hid[jt < JA ? t : 8 + t][r]);
-      }
-    }
-#pragma unroll
-    for (int p = 0; p < 4; ++p) cur[p] = nxt[p];
-  }
-  mz_mfma_fence<NJ>(out);
 }
 
 template <int JTOT>
@@ -228,7 +143,7 @@ __device__ __forceinline__ float mz_support_to_scalar8(const float *fin, int row
   return v;
 }
 
-#define MZ_FUSED_LDS_FLOATS (4 * WS_R * 256 + 16 * MZ_HS + 4 * 6 * 256 + 96 * 16 + 16 + 16 + 16 * 32 + 16 + 96 + 64 + 64 + 64 + 2 * 16 * MZ_XE)
+#define MZ_FUSED_LDS_FLOATS (16 * MZ_HS + 4 * 6 * 256 + 96 * 16 + 16 + 16 + 16 * 32 + 96 + 64 + 64 + 64 + 2 * 16 * MZ_XE)
 
 // PROF: diagnostic build only (mz_search_phase_profile): per-wave cycle totals of each phase of the loop.
 #define MZ_NPHASE 12
@@ -241,30 +156,33 @@ __device__ __forceinline__ float mz_support_to_scalar8(const float *fin, int row
     tlast = now_;                                                              \
   }
 
-template <int JTP, int G, bool PROF>
-__global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, const f32x4 *wstream, int np,
-                                                          int nsims, int slot0, unsigned long long *prof) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  f32x4 *ring = (f32x4 *)smem;
-  float *xR = smem + 4 * WS_R * 256;
-  float *red = xR + 16 * MZ_HS;
-  float *fin = red + 4 * 6 * 256;
+template <int KS1, int JTP, int G, bool PROF>
+__global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, const f32x4 *wstream, int nsims,
+                                                          int slot0, unsigned long long *prof) {
+  using SC = FusedSched<KS1, JTP>;
+  constexpr int NB = MZ_NB, NSTEPS = SC::NSTEPS;
+  constexpr int E_FC1 = SC::FC1, E_FC2 = E_FC1 + SC::FC2, E_P1 = E_FC2 + SC::P1, E_P2 = E_P1 + SC::P2;
+  constexpr int NJ2 = 2 + JTP;
+
+  __shared__ __attribute__((aligned(16))) float smem[MZ_FUSED_LDS_FLOATS];
+  float *xR = smem;                       // [16][MZ_HS] x tile, row-major
+  float *red = xR + 16 * MZ_HS;           // split-K partials [4][6][4][64]
+  float *fin = red + 4 * 6 * 256;         // combined outputs [96][16]
   float *s_val = fin + 96 * 16;
   float *s_rew = s_val + 16;
-  float *s_lg = s_rew + 16;
-  int *s_act = (int *)(s_lg + 16 * 32);
-  float *s_b2 = (float *)(s_act + 16);
+  float *s_lg = s_rew + 16;               // [16][32]
+  float *s_b2 = s_lg + 16 * 32;
   float *s_b4 = s_b2 + 96;
   float *s_lnw = s_b4 + 64;
   float *s_lnb = s_lnw + 64;
-  float *xEd = s_lnb + 64;            // [16][MZ_XE] dynamics input extension: one-hot(action), then 1 (bias column)
-  float *xEp = xEd + 16 * MZ_XE;      // [16][MZ_XE] prediction input extension: 1 (bias column), then 0
+  float *xEd = s_lnb + 64;                // [16][MZ_XE] dynamics extension: one-hot(action), then 1 (bias column)
+  float *xEp = xEd + 16 * MZ_XE;          // [16][MZ_XE] prediction extension: 1 (bias column), then 0
 
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+  const int g4 = lane >> 4, m16 = lane & 15;
   const int b0 = blockIdx.x * MZ_ROWS;
   const size_t per_tree = (size_t)(t.sims + 1) * MZ_HS;
 
-  // constants -> LDS (ordinary loads only BEFORE the first LDS-DMA is in flight)
   if (tid < 96) s_b2[tid] = n.b2[tid];
   if (tid < 32 + 16 * JTP) s_b4[tid] = n.b4[tid];
   if (tid < 64) { s_lnw[tid] = n.lnw[tid]; s_lnb[tid] = n.lnb[tid]; }
@@ -282,20 +200,20 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
     }
   }
 
-  WS ws;
-  ws.src = wstream + (size_t)w * np * 64 + lane;
-  ws.ring = ring + w * WS_R * 64;
-  ws.ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char *)(ws.ring);
-  ws.np = np; ws.gpos = 0; ws.islot = 0; ws.cslot = 0; ws.wait_cycles = 0;
-  __syncthreads();
-  __builtin_amdgcn_s_waitcnt(0x0F70);
-#pragma unroll 1
-  for (int i = 0; i < WS_A0; ++i) ws_issue(ws);
-  f32x4 cur[4];
-  pipe_fetch(ws, lane, cur);
+  // this wave's stream: [NSTEPS][4 pieces][64 lanes] f32x4.  Wave-uniform base in SGPRs + per-lane byte
+  // offset in one VGPR: every piece is then "s_base + const, v_off" (saddr form) and no per-piece 64-bit
+  // VGPR address exists that the compiler could hoist out of the simulation loop and spill.
+  const char *wbase = (const char *)(wstream + (size_t)__builtin_amdgcn_readfirstlane(w) * NSTEPS * 256);
+  const unsigned lane_off = (unsigned)lane * 16u;
+#define MZ_WLOAD(step, piece)                                                             \
+  (*(const __attribute__((address_space(1))) f32x4 *)((const __attribute__((address_space(1))) char *)wbase + \
+                                                       (size_t)(((step) * 4 + (piece)) * 1024) + lane_off))
+  f32x4 Bf[NB][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) ws_issue(ws);
-  const int ks1f = (MZ_H + n.A + 1 + 3) / 4, ks3f = (MZ_H + 1 + 3) / 4;
+  for (int s = 0; s < NB - 1; ++s) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) Bf[s][p] = MZ_WLOAD(s, p);
+  }
 
   unsigned long long pacc[MZ_NPHASE];
   unsigned long long tlast = 0;
@@ -303,8 +221,11 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
     for (int i = 0; i < MZ_NPHASE; ++i) pacc[i] = 0;
     tlast = __builtin_amdgcn_s_memtime();
   }
+  __syncthreads();
+
   for (int sim = 0; sim < nsims; ++sim) {
-    // ---- gather: x tile = [hidden of search_path[-2] | action]  (mcts.py:94-96)
+    asm volatile("" : "+s"(wbase));     // keep address arithmetic inside the loop (scalar adds, no LICM)
+    // ---- gather: x tile = [hidden of search_path[-2] | one-hot(action) | 1]  (mcts.py:94-96)
     {
       int i = 0;
       for (int mt = tid / G; mt < 16; mt += 256 / G, ++i) {
@@ -318,57 +239,124 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
     mz_bar();
     STAMP(1)
 
-    // ---- network: dynamics + prediction (networks.py:31-34)
-    {
-      f32x4 acc[16];
-      pfc1(ws, xR, xEd, ks1f, lane, cur, acc);
-      mz_relu<16>(acc);
-      STAMP(2)
-      f32x4 out[6];
-      pfc2<6, 2>(ws, lane, cur, acc, out);
-      STAMP(3)
-      scombine<6>(red, fin, out, s_b2, tid);
-      STAMP(4)
-    }
-    {
-      const int col = 8 * (w & 1) + (lane >> 3), q = lane & 7;
-      if (w < 2) {
-        sln_relu8(fin, xR, s_lnw, s_lnb, 32, col, q);
-      } else {
-        const float r = mz_support_to_scalar8(fin, 0, n.Sr, n.rmin, n.no_transform, col, q);
-        if (q == 0) s_rew[col] = r;
+    // ---- network: dynamics + prediction (networks.py:31-34), NSTEPS steps fully unrolled
+    f32x4 acc[16];
+    float hid[16][4];
+    f32x4 out2[6];
+    f32x4 out4[NJ2];
+    mz_static_for<NSTEPS>([&](auto S_) __attribute__((always_inline)) {
+      constexpr int s = decltype(S_)::value;
+      // prefetch step s + NB - 1 (cyclic: the tail of a simulation prefetches the head of the next)
+      {
+        constexpr int ps = (s + NB - 1) % NSTEPS, pb = (s + NB - 1) % NB;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) Bf[pb][p] = MZ_WLOAD(ps, p);
       }
-    }
-    mz_bar();
-    STAMP(5)
-    if (tid < 16 * (MZ_HS / 4)) {      // next hidden state -> pool slot of this expansion
-      const int m = tid / (MZ_HS / 4), c = tid % (MZ_HS / 4);
-      f32x4 *dst = (f32x4 *)(t.hpool + (size_t)(b0 + m) * per_tree + (size_t)(slot0 + sim + 1) * MZ_HS);
-      dst[c] = *(const f32x4 *)(xR + m * MZ_HS + 4 * c);
-    }
-    {
-      f32x4 acc[16];
-      pfc1(ws, xR, xEp, ks3f, lane, cur, acc);
-      mz_relu<16>(acc);
-      STAMP(6)
-      f32x4 out[2 + JTP];
-      pfc2<2 + JTP, 2>(ws, lane, cur, acc, out);
-      STAMP(7)
-      scombine<2 + JTP>(red, fin, out, s_b4, tid);
-      STAMP(8)
-    }
-    if (w < 2) {
-      const int col = 8 * w + (lane >> 3), q = lane & 7;
-      const float v = mz_support_to_scalar8(fin, 0, n.Sv, n.vmin, n.no_transform, col, q);
-      if (q == 0) s_val[col] = v;
-    } else {
-      for (int idx = tid - 128; idx < 16 * n.A; idx += 128) {
-        const int m = idx / n.A, a = idx % n.A;
-        s_lg[m * 32 + a] = fin[(32 + a) * 16 + m];
+      constexpr int cb = s % NB;
+      if constexpr (s < E_FC1 || (s >= E_FC2 && s < E_P1)) {
+        // fc1 step: 16 tiles of this wave x one k-step; x from the tile (+ extension for k >= 50)
+        constexpr bool dyn = s < E_FC1;
+        constexpr int st = dyn ? s : s - E_FC2;
+        if constexpr (st == 0) {
+#pragma unroll
+          for (int tt = 0; tt < 16; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const float x = mz_xval(xR, dyn ? xEd : xEp, m16, 4 * st + g4);
+#pragma unroll
+        for (int tg = 0; tg < 4; ++tg) {
+          mz_mfma_a(acc[4 * tg + 0], Bf[cb][tg][0], x);
+          mz_mfma_a(acc[4 * tg + 1], Bf[cb][tg][1], x);
+          mz_mfma_a(acc[4 * tg + 2], Bf[cb][tg][2], x);
+          mz_mfma_a(acc[4 * tg + 3], Bf[cb][tg][3], x);
+        }
+        if constexpr (s == E_FC1 - 1 || s == E_P1 - 1) {
+          mz_mfma_fence<16>(acc);
+#pragma unroll
+          for (int tt = 0; tt < 16; ++tt) {
+            hid[tt][0] = fmaxf(acc[tt][0], 0.f); hid[tt][1] = fmaxf(acc[tt][1], 0.f);
+            hid[tt][2] = fmaxf(acc[tt][2], 0.f); hid[tt][3] = fmaxf(acc[tt][3], 0.f);
+          }
+          // VALU write -> MFMA SrcB read needs wait states the compiler cannot see are needed (the MFMAs
+          // are asm): pin every hid value behind a volatile asm with an s_nop
+#pragma unroll
+          for (int tt = 0; tt < 16; ++tt)
+            asm volatile("s_nop 1" : "+v"(hid[tt][0]), "+v"(hid[tt][1]), "+v"(hid[tt][2]), "+v"(hid[tt][3]));
+          if constexpr (s == E_FC1 - 1) { STAMP(2) } else { STAMP(6) }
+        }
+      } else if constexpr (s < E_FC2) {
+        // dynamics fc2: pieces in (t, jt) order, 6 tiles per hidden tile: jt 0,1 reward (hid[t]), 2..5 next hidden (hid[8+t])
+        constexpr int step = s - E_FC1;
+        if constexpr (step == 0) {
+#pragma unroll
+          for (int j = 0; j < 6; ++j) out2[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const int q = 4 * step + q4, tt = q / 6, jt = q % 6;
+            mz_mfma_a(out2[jt], Bf[cb][q4][r], hid[jt < 2 ? tt : 8 + tt][r]);
+          }
+        }
+        if constexpr (s == E_FC2 - 1) {
+          mz_mfma_fence<6>(out2);
+          STAMP(3)
+          scombine<6>(red, fin, out2, s_b2, tid);
+          STAMP(4)
+          {
+            const int col = 8 * (w & 1) + (lane >> 3), q = lane & 7;
+            if (w < 2) {
+              sln_relu8(fin, xR, s_lnw, s_lnb, 32, col, q);
+            } else {
+              const float r = mz_support_to_scalar8(fin, 0, n.Sr, n.rmin, n.no_transform, col, q);
+              if (q == 0) s_rew[col] = r;
+            }
+          }
+          mz_bar();
+          STAMP(5)
+          if (tid < 16 * (MZ_HS / 4)) {      // next hidden state -> pool slot of this expansion
+            const int m = tid / (MZ_HS / 4), c = tid % (MZ_HS / 4);
+            f32x4 *dst = (f32x4 *)(t.hpool + (size_t)(b0 + m) * per_tree + (size_t)(slot0 + sim + 1) * MZ_HS);
+            dst[c] = *(const f32x4 *)(xR + m * MZ_HS + 4 * c);
+          }
+        }
+      } else if constexpr (s >= E_P1 && s < E_P2) {
+        // prediction fc2: NJ2 tiles per hidden tile: jt 0,1 value (hid[t]), 2.. policy (hid[8+t])
+        constexpr int step = s - E_P1;
+        if constexpr (step == 0) {
+#pragma unroll
+          for (int j = 0; j < NJ2; ++j) out4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const int q = 4 * step + q4, tt = q / NJ2, jt = q % NJ2;
+            mz_mfma_a(out4[jt], Bf[cb][q4][r], hid[jt < 2 ? tt : 8 + tt][r]);
+          }
+        }
+        if constexpr (s == E_P2 - 1) {
+          mz_mfma_fence<NJ2>(out4);
+          STAMP(7)
+          scombine<NJ2>(red, fin, out4, s_b4, tid);
+          STAMP(8)
+          if (w < 2) {
+            const int col = 8 * w + (lane >> 3), q = lane & 7;
+            const float v = mz_support_to_scalar8(fin, 0, n.Sv, n.vmin, n.no_transform, col, q);
+            if (q == 0) s_val[col] = v;
+          } else {
+            for (int idx = tid - 128; idx < 16 * n.A; idx += 128) {
+              const int m = idx / n.A, a = idx % n.A;
+              s_lg[m * 32 + a] = fin[(32 + a) * 16 + m];
+            }
+          }
+        }
       }
-    }
-    // the hidden-state stores are older than the last WS_A0 DMA pieces: complete after this wait
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WS_A0) : "memory");
+      // s >= E_P2: padding steps (prefetch only)
+    });
+    // every wave's hidden-state stores must have landed before the tree lanes may gather them: they are
+    // older than the last 16 weight loads, so vmcnt(16) covers them without draining the prefetch ring
+    __builtin_amdgcn_s_waitcnt(0x4F70);     // vmcnt(16)
     mz_bar();
     STAMP(9)
 
@@ -386,15 +374,8 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
         }
       }
     }
-    // No ordinary VMEM load may be pending (from the compiler's point of view either) when the network
-    // phase starts: a pending VGPR-destination load makes hipcc put s_waitcnt vmcnt(0) -- a full drain of
-    // the DMA ring -- in front of the first overwrite of that VGPR INSIDE the MFMA loops.  A real
-    // S_WAITCNT (not inline asm) is what its wait-count pass understands.  vmcnt(0) only: 0x0F70.
-    __builtin_amdgcn_s_waitcnt(0x0F70);
     STAMP(10)
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (PROF) pacc[11] = ws.wait_cycles;
   if (PROF && lane == 0)
     for (int i = 0; i < MZ_NPHASE; ++i) prof[((size_t)blockIdx.x * 4 + w) * MZ_NPHASE + i] = pacc[i];
 }

@@ -1,0 +1,42 @@
+"""Debug helper: fused search kernel vs the separate-kernel path (MZ_NO_FUSED=1) on identical inputs."""
+import os, subprocess, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+def run(tag, nsim, A=4, O=8, B=64):
+  import types, torch
+  from model_based_rl_amd.engine import Engine
+  from model_based_rl_amd.networks import FCNetwork
+  torch.manual_seed(0)
+  net = FCNetwork(O, A, torch.device('cpu'), types.SimpleNamespace()).eval()
+  with torch.no_grad():
+    for p in net.parameters():
+      if p.dim() == 1: p.add_(0.1 * torch.randn_like(p))
+  eng = Engine(B, O, A, 30, seed=1)
+  eng.set_weights(net.state_dict())
+  rng = np.random.RandomState(0)
+  obs = rng.standard_normal((B, O)).astype(np.float32)
+  noise = rng.dirichlet([0.25] * A, size=B)
+  eng.initial_inference(obs)
+  eng.root_prepare(None, None, noise)
+  eng.search(nsim)
+  ex = eng.export_tree(hidden=True)
+  np.savez('/tmp/dbg_%s.npz' % tag, **ex)
+
+if __name__ == '__main__':
+  if len(sys.argv) > 1:
+    run(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]))
+  else:
+    for A in (4,):
+      for nsim in (1,):
+        subprocess.check_call([sys.executable, __file__, 'fused', str(nsim), str(A)])
+        subprocess.check_call([sys.executable, __file__, 'plain', str(nsim), str(A)], env=dict(os.environ, MZ_NO_FUSED='1'))
+        a, b = np.load('/tmp/dbg_fused.npz'), np.load('/tmp/dbg_plain.npz')
+        print('A', A, 'nsim', nsim, {k: float(np.abs(a[k].astype(np.float64) - b[k].astype(np.float64)).max()) for k in ('N', 'W', 'P', 'R', 'E', 'hidden')})
+        if nsim == 1:
+          d = np.abs(a['hidden'][:, 1] - b['hidden'][:, 1])
+          print('  hidden slot1 max diff per row (first 16):', np.round(d.max(1)[:16], 4))
+          np.set_printoptions(linewidth=200, precision=3, suppress=True)
+          print('  fused h1 row0', a['hidden'][0, 1])
+          print('  plain h1 row0', b['hidden'][0, 1])
+          print('  W root', a['W'][:4, 0], b['W'][:4, 0], ' R leaf', a['R'][:2, 1:5], b['R'][:2, 1:5])
