@@ -294,7 +294,7 @@ static int launch_fused(mz_engine *e, int num_simulations, int sims_done, hipStr
 }
 
 static int launch_search(mz_engine *e, int num_simulations, bool selection_valid, int sims_done, hipStream_t s) {
-  if (e->use_fused) {
+  if (e->use_fused && e->sims + 2 <= MZ_FUSED_MAXPL) {
     if (!selection_valid) TREE_LAUNCH(k_tree_select, s, e->tv);
     return launch_fused(e, num_simulations, sims_done, s);
   }

@@ -143,7 +143,8 @@ __device__ __forceinline__ float mz_support_to_scalar8(const float *fin, int row
   return v;
 }
 
-#define MZ_FUSED_LDS_FLOATS (16 * MZ_HS + 4 * 6 * 256 + 96 * 16 + 16 + 16 + 16 * 32 + 96 + 64 + 64 + 64 + 2 * 16 * MZ_XE)
+#define MZ_FUSED_MAXPL 64   // search-path slots per tree kept in LDS: num_simulations + 2 <= 64
+#define MZ_FUSED_LDS_FLOATS (16 * MZ_HS + 4 * 6 * 256 + 96 * 16 + 16 + 16 + 16 * 32 + 96 + 64 + 64 + 64 + 2 * 16 * MZ_XE + 16 * MZ_FUSED_MAXPL)
 
 // PROF: diagnostic build only (mz_search_phase_profile): per-wave cycle totals of each phase of the loop.
 #define MZ_NPHASE 12
@@ -177,6 +178,7 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
   float *s_lnb = s_lnw + 64;
   float *xEd = s_lnb + 64;                // [16][MZ_XE] dynamics extension: one-hot(action), then 1 (bias column)
   float *xEp = xEd + 16 * MZ_XE;          // [16][MZ_XE] prediction extension: 1 (bias column), then 0
+  int *s_path = (int *)(xEp + 16 * MZ_XE); // [16][MZ_FUSED_MAXPL] pending search path of every tree
 
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
   const int g4 = lane >> 4, m16 = lane & 15;
@@ -188,15 +190,28 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
   if (tid < 64) { s_lnw[tid] = n.lnw[tid]; s_lnb[tid] = n.lnb[tid]; }
   for (int i = tid; i < 16 * MZ_XE; i += 256) xEp[i] = (i % MZ_XE == 0) ? 1.f : 0.f;
 
-  // tree-lane mapping: group of G lanes per tree, 256/G trees per pass
-  const int tl = tid % G;
-  int my_slot[(16 * G + 255) / 256], my_act[(16 * G + 255) / 256];
-  {
-    int i = 0;
-    for (int mt = tid / G; mt < 16; mt += 256 / G, ++i) {
-      const int b = b0 + mt;
-      my_slot[i] = (b < t.B) ? t.slot[b] : 0;
-      my_act[i] = (b < t.B) ? t.act[b] : 0;
+  // tree-lane mapping: TL lanes per tree (16, or 32 when A > 16), 256/TL trees per pass
+  constexpr int TL = (G <= 16) ? 16 : 32;
+  constexpr int NPASS = 16 * TL / 256;
+  const int tl = tid % TL;
+  int my_slot[NPASS], my_act[NPASS];
+  TreeRegs tr[NPASS];
+#pragma unroll
+  for (int i = 0; i < NPASS; ++i) {
+    const int mt = tid / TL + i * (256 / TL);
+    const int b = b0 + mt;
+    my_slot[i] = 0; my_act[i] = 0;
+    tr[i].len = 1; tr[i].tp = 1; tr[i].root_tp = 1; tr[i].legal = 0; tr[i].mn = 0.0; tr[i].mx = 0.0;
+    if (b < t.B) {
+      my_slot[i] = t.slot[b];
+      my_act[i] = t.act[b];
+      tr[i].len = t.plen[b];
+      tr[i].tp = t.leaf_tp[b];
+      tr[i].root_tp = t.TP[(size_t)b * t.NN];
+      tr[i].legal = t.legal[b];
+      tr[i].mn = t.mn[b];
+      tr[i].mx = t.mx[b];
+      for (int k = tl; k < tr[i].len; k += TL) s_path[mt * MZ_FUSED_MAXPL + k] = t.path[(size_t)b * t.PL + k];
     }
   }
 
@@ -226,14 +241,13 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
   for (int sim = 0; sim < nsims; ++sim) {
     asm volatile("" : "+s"(wbase));     // keep address arithmetic inside the loop (scalar adds, no LICM)
     // ---- gather: x tile = [hidden of search_path[-2] | one-hot(action) | 1]  (mcts.py:94-96)
-    {
-      int i = 0;
-      for (int mt = tid / G; mt < 16; mt += 256 / G, ++i) {
-        const int b = b0 + mt;
-        const f32x4 *src = (const f32x4 *)(t.hpool + (size_t)b * per_tree + (size_t)my_slot[i] * MZ_HS);
-        for (int c = tl; c < MZ_HS / 4; c += G) *(f32x4 *)(xR + mt * MZ_HS + 4 * c) = src[c];
-        for (int c = tl; c < MZ_XE; c += G) xEd[mt * MZ_XE + c] = (c == my_act[i] || c == n.A) ? 1.f : 0.f;
-      }
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) {
+      const int mt = tid / TL + i * (256 / TL);
+      const int b = b0 + mt;
+      const f32x4 *src = (const f32x4 *)(t.hpool + (size_t)b * per_tree + (size_t)my_slot[i] * MZ_HS);
+      for (int c = tl; c < MZ_HS / 4; c += TL) *(f32x4 *)(xR + mt * MZ_HS + 4 * c) = src[c];
+      for (int c = tl; c < MZ_XE; c += TL) xEd[mt * MZ_XE + c] = (c == my_act[i] || c == n.A) ? 1.f : 0.f;
     }
     STAMP(0)
     mz_bar();
@@ -361,20 +375,21 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
     STAMP(9)
 
     // ---- tree: expand + backup (mcts.py:97-99), then the next descent (mcts.py:83-92)
-    {
-      int i = 0;
-      for (int mt = tid / G; mt < 16; mt += 256 / G, ++i) {
-        const int b = b0 + mt;
-        if (b < t.B) {
-          mz_tree_expand_backup<G>(t, b, tl, s_val[mt], s_rew[mt], s_lg + mt * 32);
-          if (sim + 1 < nsims) {
-            __threadfence_block();
-            mz_tree_select<G>(t, b, tl, my_slot[i], my_act[i]);
-          }
-        }
-      }
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) {
+      const int mt = tid / TL + i * (256 / TL);
+      const int b = b0 + mt;
+      if (b < t.B)
+        mz_tree_step_fused<TL>(t, b, tl, slot0 + sim + 1, s_val[mt], s_rew[mt], s_lg + mt * 32,
+                               s_path + mt * MZ_FUSED_MAXPL, tr[i], sim + 1 < nsims, my_slot[i], my_act[i]);
     }
     STAMP(10)
+  }
+  // per-tree scalars back to the pool (what export / a later mz_select continue from)
+#pragma unroll
+  for (int i = 0; i < NPASS; ++i) {
+    const int b = b0 + tid / TL + i * (256 / TL);
+    if (b < t.B && tl == 0) { t.mn[b] = tr[i].mn; t.mx[b] = tr[i].mx; t.nexp[b] = slot0 + nsims + 1; }
   }
   if (PROF && lane == 0)
     for (int i = 0; i < MZ_NPHASE; ++i) prof[((size_t)blockIdx.x * 4 + w) * MZ_NPHASE + i] = pacc[i];

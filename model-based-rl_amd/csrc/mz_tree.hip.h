@@ -169,6 +169,150 @@ __device__ __forceinline__ void mz_tree_root(const TreeView &t, int b, int lane,
   }
 }
 
+// ------------------------------------------------------------------ fused-kernel tree step
+// State a tree's lanes keep in registers between the simulations of one fused launch.
+struct TreeRegs {
+  int len;          // len(search_path) of the pending descent
+  int tp;           // to_play at its leaf
+  int root_tp;      // root.to_play
+  uint32_t legal;   // root child mask
+  double mn, mx;    // MinMaxStats
+};
+
+// expand + backpropagate for the pending leaf, then (do_select) the next descent -- the same arithmetic as
+// mz_tree_expand_backup / mz_tree_select, reorganised so that the chain of DEPENDENT memory round trips is
+// short: TL (16 or 32) lanes per tree; the search path lives in LDS (s_path); the backup loads every path
+// node at once (lane j = j-th node from the leaf) and runs the value recurrence through shuffles; in the
+// descent each child lane also loads its own expansion index and visit count, so the winner's are
+// forwarded by shuffle and a level costs ONE round trip.
+template <int TL>
+__device__ __forceinline__ void mz_tree_step_fused(const TreeView &t, int b, int lane, int e_new, float value,
+                                                   float reward, const float *logits, int *s_path, TreeRegs &tr,
+                                                   bool do_select, int &slot_out, int &act_out) {
+  const int A = t.A;
+  const size_t o = (size_t)b * t.NN;
+  const int len = tr.len, tp = tr.tp;
+  const double g = t.discount;
+  const bool two = t.two_players != 0;
+  const int leafnode = s_path[len - 1];
+
+  // ---- Node.expand (mcts.py:47-55): priors of the new children
+  {
+    const double p = (lane < A) ? exp((double)logits[lane]) : 0.0;
+    double sum = 0.0;
+    for (int a = 0; a < A; ++a) sum = sum + __shfl(p, a, TL);
+    if (lane < A) {
+      const int ch = 1 + e_new * A + lane;
+      t.N[o + ch] = 0; t.W[o + ch] = 0.0; t.R[o + ch] = 0.f; t.E[o + ch] = -1; t.TP[o + ch] = 1;
+      t.P[o + ch] = p / sum;
+    }
+    if (lane == 0) { t.E[o + leafnode] = e_new; t.TP[o + leafnode] = (int8_t)tp; t.R[o + leafnode] = reward; }
+  }
+
+  // ---- MCTS.backpropagate (mcts.py:126-143), TL path nodes per round
+  double v_cur = (double)value;
+  double mn_c = __builtin_inf(), mx_c = -__builtin_inf();
+  int root_n = 0;
+  for (int base = 0; base < len; base += TL) {
+    const int j = base + lane;
+    const bool act = j < len;
+    const int node = act ? s_path[len - 1 - j] : 0;
+    double Wn = 0.0, r_node = 0.0;
+    int Nn = 0, ntp = tp;
+    if (act) {
+      Wn = t.W[o + node];
+      Nn = t.N[o + node];
+      if (j == 0) { r_node = (double)reward; ntp = tp; }
+      else { r_node = (double)t.R[o + node]; ntp = (int)t.TP[o + node]; }
+    }
+    const double r_signed = (two && ntp == tp) ? -r_node : r_node;
+    const int cnt = (len - base) < TL ? (len - base) : TL;
+    double my_v = 0.0;
+    for (int jj = 0; jj < cnt; ++jj) {
+      if (lane == jj) my_v = v_cur;
+      v_cur = __shfl(r_signed, jj, TL) + g * v_cur;
+    }
+    if (act) {
+      const double w = Wn + ((ntp == tp) ? my_v : -my_v);
+      const int n = Nn + 1;
+      t.W[o + node] = w;
+      t.N[o + node] = n;
+      if (j < len - 1) {
+        const double q = w / (double)n;
+        const double new_q = two ? r_node - g * q : r_node + g * q;
+        mn_c = new_q; mx_c = new_q;
+      } else {
+        root_n = n;
+      }
+    }
+  }
+#pragma unroll
+  for (int off = TL / 2; off >= 1; off >>= 1) {
+    const double a = __shfl_xor(mn_c, off, TL), c = __shfl_xor(mx_c, off, TL);
+    mn_c = a < mn_c ? a : mn_c;
+    mx_c = c > mx_c ? c : mx_c;
+    root_n |= __shfl_xor(root_n, off, TL);
+  }
+  tr.mn = mn_c < tr.mn ? mn_c : tr.mn;
+  tr.mx = mx_c > tr.mx ? mx_c : tr.mx;
+  if (!do_select) return;
+
+  // ---- the next descent (mcts.py:83-92, 104-124)
+  __threadfence_block();
+  const double mn = tr.mn, mx = tr.mx;
+  int node = 0, e = 0, Np = root_n, tpc = tr.root_tp, len2 = 1, a_sel = -1, parent_e = 0;
+  if (lane == 0) s_path[0] = 0;
+  while (e >= 0) {
+    const int ch = 1 + e * A + lane;
+    const bool valid = lane < A && (node != 0 || ((tr.legal >> lane) & 1u));
+    double score = 0.0;
+    int best = -1, Nc = 0, Ec = -1;
+    if (valid) {
+      Nc = t.N[o + ch];
+      Ec = t.E[o + ch];
+      const double p = t.P[o + ch];
+      const double wc = t.W[o + ch];
+      const double rc = (double)t.R[o + ch];
+      if (Np == 0) {
+        score = p;
+      } else {
+        double pb_c = t.logtab[Np];
+        pb_c *= t.sqrttab[Np] / (double)(Nc + 1);
+        const double prior_score = pb_c * p;
+        double value_score;
+        if (Nc > 0) {
+          const double q = wc / (double)Nc;
+          const double vv = two ? -q : q;
+          value_score = mz_normalize(rc + g * vv, mn, mx);
+        } else {
+          value_score = t.init_value_score;
+        }
+        score = prior_score + value_score;
+      }
+      best = lane;
+    }
+#pragma unroll
+    for (int off = TL / 2; off >= 1; off >>= 1) {
+      const double os = __shfl_xor(score, off, TL);
+      const int ob = __shfl_xor(best, off, TL);
+      const bool take = ob >= 0 && (best < 0 || os > score || (os == score && ob > best));
+      if (take) { score = os; best = ob; }
+    }
+    a_sel = best;
+    parent_e = e;
+    node = 1 + e * A + a_sel;
+    if (lane == 0) s_path[len2] = node;
+    ++len2;
+    if (two) tpc = -tpc;
+    e = __shfl(Ec, a_sel, TL);
+    Np = __shfl(Nc, a_sel, TL);
+  }
+  tr.len = len2;
+  tr.tp = tpc;
+  slot_out = parent_e;
+  act_out = a_sel;
+}
+
 // ------------------------------------------------------------------ kernels (one launch per phase)
 template <int G>
 __global__ void k_tree_select(TreeView t) {
