@@ -62,6 +62,7 @@ struct mz_engine {
   const f32x4 *wstream = nullptr;   // per-wave cyclic weight stream for the fused search kernel
   int ks1sel = 0;                   // fc1 k-steps of the fused kernel instantiation chosen for this A
   bool use_fused = true;
+  bool use_lds_trees = true;
   unsigned long long *prof_buf = nullptr;   // non-null only inside mz_search_phase_profile
 };
 
@@ -266,17 +267,37 @@ static int build_packing(mz_engine *e) {
   } while (0)
 
 
-template <int KS1, int JTP, int G>
-static int launch_fused_t(mz_engine *e, int num_simulations, int sims_done, hipStream_t s) {
+template <int KS1, int JTP, int G, bool LT>
+static int launch_fused_lt(mz_engine *e, int num_simulations, int sims_done, hipStream_t s) {
+  static bool attr_set = false, attr_set_prof = false;
+  const size_t dyn = mz_fused_dyn_lds(e->sims, e->NN, LT);
   if (e->prof_buf) {
-    hipLaunchKernelGGL((k_search_fused<KS1, JTP, G, true>), dim3(e->Bp / MZ_ROWS), dim3(256), 0, s, e->nv, e->tv,
-                       e->wstream, num_simulations, sims_done, e->prof_buf);
+    if (!attr_set_prof) {
+      HIPCHECK(hipFuncSetAttribute((const void *)k_search_fused<KS1, JTP, G, LT, true>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)sizeof(float) * MZ_FUSED_LDS_FLOATS));
+      attr_set_prof = true;
+    }
+    hipLaunchKernelGGL((k_search_fused<KS1, JTP, G, LT, true>), dim3(e->Bp / MZ_ROWS), dim3(256), dyn, s, e->nv,
+                       e->tv, e->wstream, num_simulations, sims_done, e->prof_buf);
   } else {
-    hipLaunchKernelGGL((k_search_fused<KS1, JTP, G, false>), dim3(e->Bp / MZ_ROWS), dim3(256), 0, s, e->nv, e->tv,
-                       e->wstream, num_simulations, sims_done, (unsigned long long *)nullptr);
+    if (!attr_set) {
+      HIPCHECK(hipFuncSetAttribute((const void *)k_search_fused<KS1, JTP, G, LT, false>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)sizeof(float) * MZ_FUSED_LDS_FLOATS));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((k_search_fused<KS1, JTP, G, LT, false>), dim3(e->Bp / MZ_ROWS), dim3(256), dyn, s, e->nv,
+                       e->tv, e->wstream, num_simulations, sims_done, (unsigned long long *)nullptr);
   }
   HIPCHECK(hipGetLastError());
   return 0;
+}
+
+// trees in LDS when 16 of them fit beside the kernel's static LDS (160 KiB per CU), else in the global pool
+template <int KS1, int JTP, int G>
+static int launch_fused_t(mz_engine *e, int num_simulations, int sims_done, hipStream_t s) {
+  const size_t need = sizeof(float) * MZ_FUSED_LDS_FLOATS + mz_fused_dyn_lds(e->sims, e->NN, true);
+  if (e->use_lds_trees && need <= 160 * 1024) return launch_fused_lt<KS1, JTP, G, true>(e, num_simulations, sims_done, s);
+  return launch_fused_lt<KS1, JTP, G, false>(e, num_simulations, sims_done, s);
 }
 
 // fused-kernel instantiations: (fc1 k-steps, policy tiles, lanes per tree) by action count
@@ -345,6 +366,7 @@ int mz_create(const mz_config *cfg, mz_engine **out) {
   e->ks1sel = fused_ks1(e->A);
   e->use_graph = getenv("MZ_NO_GRAPH") == nullptr;
   e->use_fused = getenv("MZ_NO_FUSED") == nullptr;
+  e->use_lds_trees = getenv("MZ_NO_LDS_TREES") == nullptr;
   TreeView &t = e->tv;
   memset(&t, 0, sizeof t);
   const size_t nb = (size_t)e->Bp, nn = nb * e->NN;
@@ -355,8 +377,8 @@ int mz_create(const mz_config *cfg, mz_engine **out) {
   DM(t.hpool, nb * (e->sims + 1) * MZ_HS)
   DM(t.value, nb) DM(t.reward, nb) DM(t.logits, nb * e->A) DM(t.root_value, nb) DM(t.root_logits, nb * e->A)
   DM(t.noise, nb * e->A)
-  double *logtab, *sqrttab;
-  DM(logtab, e->sims + 2) DM(sqrttab, e->sims + 2)
+  double *logtab, *sqrttab, *pbctab;
+  DM(logtab, e->sims + 2) DM(sqrttab, e->sims + 2) DM(pbctab, (size_t)(e->sims + 2) * (e->sims + 2))
 #undef DM
   {
     // mcts.py:116-117: math.log((N + base + 1) / base) + init and math.sqrt(N), for every N a parent
@@ -366,13 +388,23 @@ int mz_create(const mz_config *cfg, mz_engine **out) {
       lt[i] = log(((double)i + cfg->pb_c_base + 1) / cfg->pb_c_base) + cfg->pb_c_init;
       st[i] = sqrt((double)i);
     }
-    if (hipMemcpy(logtab, lt.data(), lt.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
+    // pb_c for every (parent visits, child visits) pair, in the reference's operation order
+    // (pb_c = log(..) + init; pb_c *= sqrt(Np) / (Nc + 1)); IEEE double on the host, no contraction
+    const int T = e->sims + 2;
+    std::vector<double> pt((size_t)T * T);
+    for (int np = 0; np < T; ++np)
+      for (int nc = 0; nc < T; ++nc) {
+        volatile double q = st[np] / (double)(nc + 1);
+        volatile double v = lt[np] * q;
+        pt[(size_t)np * T + nc] = v;
+      }
+    if (hipMemcpy(pbctab, pt.data(), pt.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(sqrttab, st.data(), st.size() * 8, hipMemcpyHostToDevice) != hipSuccess) {
       mz_destroy(e);
       return fail("mz_create: table upload failed");
     }
   }
-  t.logtab = logtab; t.sqrttab = sqrttab;
+  t.logtab = logtab; t.sqrttab = sqrttab; t.pbctab = pbctab;
   t.B = e->B; t.A = e->A; t.sims = e->sims; t.NN = e->NN; t.PL = e->PL;
   t.two_players = cfg->two_players; t.has_min = cfg->has_min_bound; t.has_max = cfg->has_max_bound;
   t.min_bound = cfg->min_bound; t.max_bound = cfg->max_bound; t.discount = cfg->discount;

@@ -90,16 +90,30 @@ __device__ __forceinline__ void scombine(float *red, float *fin, const f32x4 (&o
   mz_bar();
 }
 
+// 8-lane (half-row) all-reduce by DPP: quad_perm xor 1, xor 2, then row_half_mirror
+template <int CTRL>
+__device__ __forceinline__ float mz_dpp(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float mz_sum8(float x) {
+  x += mz_dpp<0xB1>(x); x += mz_dpp<0x4E>(x); x += mz_dpp<0x141>(x);
+  return x;
+}
+__device__ __forceinline__ float mz_max8(float x) {
+  x = fmaxf(x, mz_dpp<0xB1>(x)); x = fmaxf(x, mz_dpp<0x4E>(x)); x = fmaxf(x, mz_dpp<0x141>(x));
+  return x;
+}
+
 // relu(LayerNorm) of fin rows [row0,row0+50), column m -> row-major tile xR[m][0..51]; 8 lanes per column
 __device__ __forceinline__ void sln_relu8(const float *fin, float *xR, const float *lnw, const float *lnb, int row0,
                                           int m, int q) {
   float s = 0.f;
   for (int f = q; f < MZ_H; f += 8) s += fin[(row0 + f) * 16 + m];
-  s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+  s = mz_sum8(s);
   const float mean = s / (float)MZ_H;
   float v = 0.f;
   for (int f = q; f < MZ_H; f += 8) { const float d = fin[(row0 + f) * 16 + m] - mean; v += d * d; }
-  v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+  v = mz_sum8(v);
   const float rstd = 1.0f / sqrtf(v / (float)MZ_H + 1e-5f);
   for (int f = q; f < MZ_HS; f += 8) {
     float y = 0.f;
@@ -121,18 +135,18 @@ __device__ __forceinline__ float mz_support_to_scalar8(const float *fin, int row
     x[i] = bin < S ? fin[(row0 + bin) * 16 + m] : -__builtin_inff();
     mx = fmaxf(mx, x[i]);
   }
-  mx = fmaxf(mx, __shfl_xor(mx, 1)); mx = fmaxf(mx, __shfl_xor(mx, 2)); mx = fmaxf(mx, __shfl_xor(mx, 4));
+  mx = mz_max8(mx);
   float e[4], sum = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     e[i] = (q + 8 * i < S) ? expf(x[i] - mx) : 0.f;
     sum += e[i];
   }
-  sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
+  sum = mz_sum8(sum);
   float v = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) v += (float)(smin + q + 8 * i) * (e[i] / sum);
-  v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+  v = mz_sum8(v);
   if (!no_transform) {
     const float sgn = (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f);
     float t = (fabsf(v) + 1.f) + 0.001f;
@@ -157,7 +171,14 @@ __device__ __forceinline__ float mz_support_to_scalar8(const float *fin, int row
     tlast = now_;                                                              \
   }
 
-template <int KS1, int JTP, int G, bool PROF>
+// dynamic LDS of the fused kernel: pb_c table [(sims+2)^2] doubles, then (LT) the 16 trees' node arrays
+__host__ __device__ inline size_t mz_fused_dyn_lds(int sims, int NN, bool lt) {
+  size_t b = (size_t)(sims + 2) * (sims + 2) * 8;
+  if (lt) b += (size_t)16 * NN * (8 + 8 + 4 + 2 + 2 + 1) + 64;
+  return b;
+}
+
+template <int KS1, int JTP, int G, bool LT, bool PROF>
 __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, const f32x4 *wstream, int nsims,
                                                           int slot0, unsigned long long *prof) {
   using SC = FusedSched<KS1, JTP>;
@@ -166,6 +187,15 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
   constexpr int NJ2 = 2 + JTP;
 
   __shared__ __attribute__((aligned(16))) float smem[MZ_FUSED_LDS_FLOATS];
+  extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
+  double *s_pbc = (double *)dyn_lds;       // pb_c(Np, Nc) table (host-computed, exact), [sims+2][sims+2]
+  // (LT) the workgroup's 16 trees live in LDS for the whole launch
+  double *l_W = s_pbc + (t.sims + 2) * (t.sims + 2);
+  double *l_P = l_W + 16 * t.NN;
+  float *l_R = (float *)(l_P + 16 * t.NN);
+  int16_t *l_N = (int16_t *)(l_R + 16 * t.NN);
+  int16_t *l_E = l_N + 16 * t.NN;
+  int8_t *l_TP = (int8_t *)(l_E + 16 * t.NN);
   float *xR = smem;                       // [16][MZ_HS] x tile, row-major
   float *red = xR + 16 * MZ_HS;           // split-K partials [4][6][4][64]
   float *fin = red + 4 * 6 * 256;         // combined outputs [96][16]
@@ -189,6 +219,7 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
   if (tid < 32 + 16 * JTP) s_b4[tid] = n.b4[tid];
   if (tid < 64) { s_lnw[tid] = n.lnw[tid]; s_lnb[tid] = n.lnb[tid]; }
   for (int i = tid; i < 16 * MZ_XE; i += 256) xEp[i] = (i % MZ_XE == 0) ? 1.f : 0.f;
+  for (int i = tid; i < (t.sims + 2) * (t.sims + 2); i += 256) s_pbc[i] = t.pbctab[i];
 
   // tree-lane mapping: TL lanes per tree (16, or 32 when A > 16), 256/TL trees per pass
   constexpr int TL = (G <= 16) ? 16 : 32;
@@ -196,10 +227,18 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
   const int tl = tid % TL;
   int my_slot[NPASS], my_act[NPASS];
   TreeRegs tr[NPASS];
+  TreeMem<LT> tm[NPASS];
 #pragma unroll
   for (int i = 0; i < NPASS; ++i) {
     const int mt = tid / TL + i * (256 / TL);
     const int b = b0 + mt;
+    if constexpr (LT) {
+      const int o = mt * t.NN;
+      tm[i].N = l_N + o; tm[i].W = l_W + o; tm[i].P = l_P + o; tm[i].R = l_R + o; tm[i].E = l_E + o; tm[i].TP = l_TP + o;
+    } else {
+      const size_t o = (size_t)(b < t.B ? b : 0) * t.NN;
+      tm[i].N = t.N + o; tm[i].W = t.W + o; tm[i].P = t.P + o; tm[i].R = t.R + o; tm[i].E = t.E + o; tm[i].TP = t.TP + o;
+    }
     my_slot[i] = 0; my_act[i] = 0;
     tr[i].len = 1; tr[i].tp = 1; tr[i].root_tp = 1; tr[i].legal = 0; tr[i].mn = 0.0; tr[i].mx = 0.0;
     if (b < t.B) {
@@ -212,6 +251,14 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
       tr[i].mn = t.mn[b];
       tr[i].mx = t.mx[b];
       for (int k = tl; k < tr[i].len; k += TL) s_path[mt * MZ_FUSED_MAXPL + k] = t.path[(size_t)b * t.PL + k];
+      if constexpr (LT) {       // bring the existing part of the tree (root, expanded slabs) into LDS
+        const size_t o = (size_t)b * t.NN;
+        const int have = 1 + (slot0 + 1) * t.A;
+        for (int k = tl; k < have; k += TL) {
+          tm[i].N[k] = (int16_t)t.N[o + k]; tm[i].W[k] = t.W[o + k]; tm[i].P[k] = t.P[o + k]; tm[i].R[k] = t.R[o + k];
+          tm[i].E[k] = (int16_t)t.E[o + k]; tm[i].TP[k] = t.TP[o + k];
+        }
+      }
     }
   }
 
@@ -258,6 +305,7 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
     float hid[16][4];
     f32x4 out2[6];
     f32x4 out4[NJ2];
+    float xq = 0.f;       // B operand of the NEXT fc1 step (read one step ahead)
     mz_static_for<NSTEPS>([&](auto S_) __attribute__((always_inline)) {
       constexpr int s = decltype(S_)::value;
       // prefetch step s + NB - 1 (cyclic: the tail of a simulation prefetches the head of the next)
@@ -275,7 +323,9 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
 #pragma unroll
           for (int tt = 0; tt < 16; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        const float x = mz_xval(xR, dyn ? xEd : xEp, m16, 4 * st + g4);
+        if constexpr (st == 0) xq = mz_xval(xR, dyn ? xEd : xEp, m16, g4);
+        const float x = xq;
+        if constexpr (st + 1 < (dyn ? SC::FC1 : SC::P1)) xq = mz_xval(xR, dyn ? xEd : xEp, m16, 4 * (st + 1) + g4);
 #pragma unroll
         for (int tg = 0; tg < 4; ++tg) {
           mz_mfma_a(acc[4 * tg + 0], Bf[cb][tg][0], x);
@@ -380,8 +430,8 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
       const int mt = tid / TL + i * (256 / TL);
       const int b = b0 + mt;
       if (b < t.B)
-        mz_tree_step_fused<TL>(t, b, tl, slot0 + sim + 1, s_val[mt], s_rew[mt], s_lg + mt * 32,
-                               s_path + mt * MZ_FUSED_MAXPL, tr[i], sim + 1 < nsims, my_slot[i], my_act[i]);
+        mz_tree_step_fused<TL, LT>(t, tm[i], tl, slot0 + sim + 1, s_val[mt], s_rew[mt], s_lg + mt * 32,
+                               s_path + mt * MZ_FUSED_MAXPL, s_pbc, tr[i], sim + 1 < nsims, my_slot[i], my_act[i]);
     }
     STAMP(10)
   }
@@ -390,6 +440,16 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
   for (int i = 0; i < NPASS; ++i) {
     const int b = b0 + tid / TL + i * (256 / TL);
     if (b < t.B && tl == 0) { t.mn[b] = tr[i].mn; t.mx[b] = tr[i].mx; t.nexp[b] = slot0 + nsims + 1; }
+    if constexpr (LT) {
+      if (b < t.B) {
+        const size_t o = (size_t)b * t.NN;
+        const int have = 1 + (slot0 + nsims + 1) * t.A;
+        for (int k = tl; k < have; k += TL) {
+          t.N[o + k] = tm[i].N[k]; t.W[o + k] = tm[i].W[k]; t.P[o + k] = tm[i].P[k]; t.R[o + k] = tm[i].R[k];
+          t.E[o + k] = tm[i].E[k]; t.TP[o + k] = tm[i].TP[k];
+        }
+      }
+    }
   }
   if (PROF && lane == 0)
     for (int i = 0; i < MZ_NPHASE; ++i) prof[((size_t)blockIdx.x * 4 + w) * MZ_NPHASE + i] = pacc[i];

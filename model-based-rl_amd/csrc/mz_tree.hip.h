@@ -41,8 +41,7 @@ __device__ __forceinline__ void mz_tree_select(const TreeView &t, int b, int lan
       if (Np == 0) {
         score = p;                                     // fresh root: rank by prior (mcts.py:105-108)
       } else {
-        double pb_c = t.logtab[Np];                    // log((Np+base+1)/base) + init
-        pb_c *= t.sqrttab[Np] / (double)(Nc + 1);
+        const double pb_c = t.pbctab[Np * (t.sims + 2) + Nc];   // (log((Np+base+1)/base)+init) * (sqrt(Np)/(Nc+1))
         const double prior_score = pb_c * p;
         double value_score;
         if (Nc > 0) {
@@ -179,18 +178,24 @@ struct TreeRegs {
   double mn, mx;    // MinMaxStats
 };
 
+// One tree's node arrays: its slab of the global pool (LT = false) or a copy the fused kernel keeps in LDS
+// for the whole launch (LT = true; visit counts and expansion indices narrowed to 16 bit).
+template <bool LT> struct TreeMem;
+template <> struct TreeMem<false> { int32_t *N; double *W; double *P; float *R; int32_t *E; int8_t *TP; };
+template <> struct TreeMem<true> { int16_t *N; double *W; double *P; float *R; int16_t *E; int8_t *TP; };
+
 // expand + backpropagate for the pending leaf, then (do_select) the next descent -- the same arithmetic as
 // mz_tree_expand_backup / mz_tree_select, reorganised so that the chain of DEPENDENT memory round trips is
 // short: TL (16 or 32) lanes per tree; the search path lives in LDS (s_path); the backup loads every path
 // node at once (lane j = j-th node from the leaf) and runs the value recurrence through shuffles; in the
 // descent each child lane also loads its own expansion index and visit count, so the winner's are
 // forwarded by shuffle and a level costs ONE round trip.
-template <int TL>
-__device__ __forceinline__ void mz_tree_step_fused(const TreeView &t, int b, int lane, int e_new, float value,
-                                                   float reward, const float *logits, int *s_path, TreeRegs &tr,
-                                                   bool do_select, int &slot_out, int &act_out) {
+template <int TL, bool LT>
+__device__ __forceinline__ void mz_tree_step_fused(const TreeView &t, const TreeMem<LT> &tm, int lane, int e_new,
+                                                   float value, float reward, const float *logits, int *s_path,
+                                                   const double *pbctab, TreeRegs &tr, bool do_select,
+                                                   int &slot_out, int &act_out) {
   const int A = t.A;
-  const size_t o = (size_t)b * t.NN;
   const int len = tr.len, tp = tr.tp;
   const double g = t.discount;
   const bool two = t.two_players != 0;
@@ -203,10 +208,10 @@ __device__ __forceinline__ void mz_tree_step_fused(const TreeView &t, int b, int
     for (int a = 0; a < A; ++a) sum = sum + __shfl(p, a, TL);
     if (lane < A) {
       const int ch = 1 + e_new * A + lane;
-      t.N[o + ch] = 0; t.W[o + ch] = 0.0; t.R[o + ch] = 0.f; t.E[o + ch] = -1; t.TP[o + ch] = 1;
-      t.P[o + ch] = p / sum;
+      tm.N[ch] = 0; tm.W[ch] = 0.0; tm.R[ch] = 0.f; tm.E[ch] = -1; tm.TP[ch] = 1;
+      tm.P[ch] = p / sum;
     }
-    if (lane == 0) { t.E[o + leafnode] = e_new; t.TP[o + leafnode] = (int8_t)tp; t.R[o + leafnode] = reward; }
+    if (lane == 0) { tm.E[leafnode] = e_new; tm.TP[leafnode] = (int8_t)tp; tm.R[leafnode] = reward; }
   }
 
   // ---- MCTS.backpropagate (mcts.py:126-143), TL path nodes per round
@@ -220,10 +225,10 @@ __device__ __forceinline__ void mz_tree_step_fused(const TreeView &t, int b, int
     double Wn = 0.0, r_node = 0.0;
     int Nn = 0, ntp = tp;
     if (act) {
-      Wn = t.W[o + node];
-      Nn = t.N[o + node];
+      Wn = tm.W[node];
+      Nn = tm.N[node];
       if (j == 0) { r_node = (double)reward; ntp = tp; }
-      else { r_node = (double)t.R[o + node]; ntp = (int)t.TP[o + node]; }
+      else { r_node = (double)tm.R[node]; ntp = (int)tm.TP[node]; }
     }
     const double r_signed = (two && ntp == tp) ? -r_node : r_node;
     const int cnt = (len - base) < TL ? (len - base) : TL;
@@ -235,8 +240,8 @@ __device__ __forceinline__ void mz_tree_step_fused(const TreeView &t, int b, int
     if (act) {
       const double w = Wn + ((ntp == tp) ? my_v : -my_v);
       const int n = Nn + 1;
-      t.W[o + node] = w;
-      t.N[o + node] = n;
+      tm.W[node] = w;
+      tm.N[node] = n;
       if (j < len - 1) {
         const double q = w / (double)n;
         const double new_q = two ? r_node - g * q : r_node + g * q;
@@ -268,17 +273,15 @@ __device__ __forceinline__ void mz_tree_step_fused(const TreeView &t, int b, int
     double score = 0.0;
     int best = -1, Nc = 0, Ec = -1;
     if (valid) {
-      Nc = t.N[o + ch];
-      Ec = t.E[o + ch];
-      const double p = t.P[o + ch];
-      const double wc = t.W[o + ch];
-      const double rc = (double)t.R[o + ch];
+      Nc = tm.N[ch];
+      Ec = tm.E[ch];
+      const double p = tm.P[ch];
+      const double wc = tm.W[ch];
+      const double rc = (double)tm.R[ch];
       if (Np == 0) {
         score = p;
       } else {
-        double pb_c = t.logtab[Np];
-        pb_c *= t.sqrttab[Np] / (double)(Nc + 1);
-        const double prior_score = pb_c * p;
+        const double prior_score = pbctab[Np * (t.sims + 2) + Nc] * p;
         double value_score;
         if (Nc > 0) {
           const double q = wc / (double)Nc;
