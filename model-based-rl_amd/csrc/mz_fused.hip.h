@@ -431,7 +431,8 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
       const int b = b0 + mt;
       if (b < t.B)
         mz_tree_step_fused<TL, LT>(t, tm[i], tl, slot0 + sim + 1, s_val[mt], s_rew[mt], s_lg + mt * 32,
-                               s_path + mt * MZ_FUSED_MAXPL, s_pbc, tr[i], sim + 1 < nsims, my_slot[i], my_act[i]);
+                               s_path + mt * MZ_FUSED_MAXPL, (double *)red + mt * 96, s_pbc, tr[i], sim + 1 < nsims,
+                                   my_slot[i], my_act[i]);
     }
     STAMP(10)
   }

@@ -169,6 +169,34 @@ __device__ __forceinline__ void mz_tree_root(const TreeView &t, int b, int lane,
 }
 
 // ------------------------------------------------------------------ fused-kernel tree step
+// Cross-lane moves inside one row of 16 lanes by DPP (one VALU op per 32 bits, no LDS crossbar trip):
+// quad_perm xor 1 / xor 2, row_half_mirror (i <-> 7-i), row_mirror (i <-> 15-i).  For a reduction under a
+// total order any pairing that eventually joins all lanes gives every lane the same result.
+template <int CTRL>
+__device__ __forceinline__ int mz_dpp_i(int x) {
+  return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true);
+}
+template <int CTRL>
+__device__ __forceinline__ double mz_dpp_d(double x) {
+  const int lo = mz_dpp_i<CTRL>(__double2loint(x)), hi = mz_dpp_i<CTRL>(__double2hiint(x));
+  return __hiloint2double(hi, lo);
+}
+// partner exchange for step `off` (1, 2, 4, 8 inside a row; 16 across the two rows of a 32-lane group)
+template <int OFF>
+__device__ __forceinline__ int mz_xchg_i(int x) {
+  if constexpr (OFF == 1) return mz_dpp_i<0xB1>(x);
+  else if constexpr (OFF == 2) return mz_dpp_i<0x4E>(x);
+  else if constexpr (OFF == 4) return mz_dpp_i<0x141>(x);
+  else if constexpr (OFF == 8) return mz_dpp_i<0x140>(x);
+  else return __shfl_xor(x, 16);
+}
+template <int OFF>
+__device__ __forceinline__ double mz_xchg_d(double x) {
+  if constexpr (OFF <= 8) return __hiloint2double(mz_xchg_i<OFF>(__double2hiint(x)), mz_xchg_i<OFF>(__double2loint(x)));
+  else return __shfl_xor(x, 16);
+}
+
+
 // State a tree's lanes keep in registers between the simulations of one fused launch.
 struct TreeRegs {
   int len;          // len(search_path) of the pending descent
@@ -193,8 +221,8 @@ template <> struct TreeMem<true> { int16_t *N; double *W; double *P; float *R; i
 template <int TL, bool LT>
 __device__ __forceinline__ void mz_tree_step_fused(const TreeView &t, const TreeMem<LT> &tm, int lane, int e_new,
                                                    float value, float reward, const float *logits, int *s_path,
-                                                   const double *pbctab, TreeRegs &tr, bool do_select,
-                                                   int &slot_out, int &act_out) {
+                                                   double *s_stage, const double *pbctab, TreeRegs &tr,
+                                                   bool do_select, int &slot_out, int &act_out) {
   const int A = t.A;
   const int len = tr.len, tp = tr.tp;
   const double g = t.discount;
@@ -204,8 +232,9 @@ __device__ __forceinline__ void mz_tree_step_fused(const TreeView &t, const Tree
   // ---- Node.expand (mcts.py:47-55): priors of the new children
   {
     const double p = (lane < A) ? exp((double)logits[lane]) : 0.0;
+    if (lane < A) s_stage[lane] = p;              // every lane then adds them up in Python's sum() order
     double sum = 0.0;
-    for (int a = 0; a < A; ++a) sum = sum + __shfl(p, a, TL);
+    for (int a = 0; a < A; ++a) sum = sum + s_stage[a];
     if (lane < A) {
       const int ch = 1 + e_new * A + lane;
       tm.N[ch] = 0; tm.W[ch] = 0.0; tm.R[ch] = 0.f; tm.E[ch] = -1; tm.TP[ch] = 1;
@@ -233,9 +262,10 @@ __device__ __forceinline__ void mz_tree_step_fused(const TreeView &t, const Tree
     const double r_signed = (two && ntp == tp) ? -r_node : r_node;
     const int cnt = (len - base) < TL ? (len - base) : TL;
     double my_v = 0.0;
-    for (int jj = 0; jj < cnt; ++jj) {
+    if (act) s_stage[32 + lane] = r_signed;       // the recurrence value = reward + discount*value runs in
+    for (int jj = 0; jj < cnt; ++jj) {             // every lane; lane j keeps the value its node receives
       if (lane == jj) my_v = v_cur;
-      v_cur = __shfl(r_signed, jj, TL) + g * v_cur;
+      v_cur = s_stage[32 + jj] + g * v_cur;
     }
     if (act) {
       const double w = Wn + ((ntp == tp) ? my_v : -my_v);
@@ -251,13 +281,16 @@ __device__ __forceinline__ void mz_tree_step_fused(const TreeView &t, const Tree
       }
     }
   }
-#pragma unroll
-  for (int off = TL / 2; off >= 1; off >>= 1) {
-    const double a = __shfl_xor(mn_c, off, TL), c = __shfl_xor(mx_c, off, TL);
-    mn_c = a < mn_c ? a : mn_c;
-    mx_c = c > mx_c ? c : mx_c;
-    root_n |= __shfl_xor(root_n, off, TL);
+#define MZ_MM_STEP(OFF)                                                         \
+  {                                                                             \
+    const double a_ = mz_xchg_d<OFF>(mn_c), c_ = mz_xchg_d<OFF>(mx_c);         \
+    mn_c = a_ < mn_c ? a_ : mn_c;                                               \
+    mx_c = c_ > mx_c ? c_ : mx_c;                                               \
+    root_n |= mz_xchg_i<OFF>(root_n);                                           \
   }
+  MZ_MM_STEP(1) MZ_MM_STEP(2) MZ_MM_STEP(4) MZ_MM_STEP(8)
+  if constexpr (TL == 32) MZ_MM_STEP(16)
+#undef MZ_MM_STEP
   tr.mn = mn_c < tr.mn ? mn_c : tr.mn;
   tr.mx = mx_c > tr.mx ? mx_c : tr.mx;
   if (!do_select) return;
@@ -294,21 +327,25 @@ __device__ __forceinline__ void mz_tree_step_fused(const TreeView &t, const Tree
       }
       best = lane;
     }
-#pragma unroll
-    for (int off = TL / 2; off >= 1; off >>= 1) {
-      const double os = __shfl_xor(score, off, TL);
-      const int ob = __shfl_xor(best, off, TL);
-      const bool take = ob >= 0 && (best < 0 || os > score || (os == score && ob > best));
-      if (take) { score = os; best = ob; }
-    }
+    // tuple max over (score, action) with the winner's expansion index and visit count as payload
+#define MZ_AM_STEP(OFF)                                                                          \
+  {                                                                                              \
+    const double os = mz_xchg_d<OFF>(score);                                                     \
+    const int ob = mz_xchg_i<OFF>(best), oe = mz_xchg_i<OFF>(Ec), on = mz_xchg_i<OFF>(Nc);       \
+    const bool take = ob >= 0 && (best < 0 || os > score || (os == score && ob > best));         \
+    if (take) { score = os; best = ob; Ec = oe; Nc = on; }                                       \
+  }
+    MZ_AM_STEP(1) MZ_AM_STEP(2) MZ_AM_STEP(4) MZ_AM_STEP(8)
+    if constexpr (TL == 32) MZ_AM_STEP(16)
+#undef MZ_AM_STEP
     a_sel = best;
     parent_e = e;
     node = 1 + e * A + a_sel;
     if (lane == 0) s_path[len2] = node;
     ++len2;
     if (two) tpc = -tpc;
-    e = __shfl(Ec, a_sel, TL);
-    Np = __shfl(Nc, a_sel, TL);
+    e = Ec;
+    Np = Nc;
   }
   tr.len = len2;
   tr.tp = tpc;
