@@ -39,7 +39,7 @@ def cpu_baseline(weights):
   """The CPU oracle (C restatement of the reference path, oracle/mz_oracle.c) timed on ONE host core on a
   bounded sample of the same workload.  Reported beside the GPU number; it is not the target."""
   from oracle import oracle as orc
-  envs, moves = 64, 4
+  envs, moves = 256, 40       # ~10-15 s of single-core work
   rng = np.random.RandomState(0)
   net = orc.FCNet(weights, O, A)
   t = orc.Trees(orc.tree_cfg(A, SIMS), envs)
@@ -154,27 +154,31 @@ def main():
     frames = float(ff.item())
   env_steps = world * B * args.steps       # env.step() calls in the timed region, all ranks
 
-  # per-kernel durations: the same launches, eagerly, with hipEvents between them on the launch stream
-  net_ms = tree_ms = 0.0
-  reps = 8
+  # dominant kernel = k_search_fused (one launch = all 30 simulations of all 4096 trees: descent, f32-MFMA
+  # dynamics+prediction, expand, backup).  Its duration is measured live with HIP events on the stream it
+  # is launched on, around the mz_search call alone (root preparation is outside the bracket).
+  reps = 20
   obs = torch.randn(B, O, device=device)
+  stream = torch.cuda.current_stream(device)
+  ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
+  ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
   for i in range(reps):
     eng.initial_inference(obs)
     eng.root_prepare(None, None, None, device_rng=True, move=10 ** 6 + i)
-    a, b = eng.search_profiled()
-    net_ms += a
-    tree_ms += b
-  net_us = 1e3 * net_ms / (reps * SIMS)
-  tree_us = 1e3 * tree_ms / (reps * SIMS)
+    ev0[i].record(stream)
+    eng.search()
+    ev1[i].record(stream)
+  torch.cuda.synchronize(device)
+  search_us = 1e3 * float(np.median([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
 
   if rank == 0:
     value = frames / dt
-    flops_per_launch = FLOP_PER_SIM * B
-    achieved = flops_per_launch / (net_us * 1e-6) / 1e12
+    flops_per_launch = SIMS * FLOP_PER_SIM * B        # algorithmic: SURVEY.md s8(d) per-simulation figure x sims x trees
+    achieved = flops_per_launch / (search_us * 1e-6) / 1e12
     traffic = None
     tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
     if os.path.exists(tfile):
-      traffic = json.load(open(tfile)).get('k_net_recurrent_tree', {}).get('hbm_bytes_per_launch')
+      traffic = json.load(open(tfile)).get('k_search_fused', {}).get('hbm_bytes_per_launch')
     out = {
         'metric': 'env-steps/sec (self-play, whole node) at num_simulations=30',
         'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -188,10 +192,9 @@ def main():
                    'sharding': 'env-id sharded, %d rank(s), RCCL weight broadcast' % world},
         'env_steps_executed_per_s': env_steps / dt,
         'mcts_sims_per_s_per_gpu': env_steps * SIMS / dt / world,
-        'roofline': {'bound': 'mfma', 'kernel': 'k_net_recurrent_tree', 'achieved': achieved,
+        'roofline': {'bound': 'mfma', 'kernel': 'k_search_fused', 'achieved': achieved,
                      'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS,
-                     'traffic': traffic, 'us_per_launch': net_us, 'flop_per_launch': flops_per_launch,
-                     'tree_step_us_per_launch': tree_us,
+                     'traffic': traffic, 'us_per_launch': search_us, 'flop_per_launch': flops_per_launch,
                      'whole_path_frac': (env_steps / dt / world) * (SIMS * FLOP_PER_SIM + FLOP_PER_ROOT) / 1e12 /
                                         PEAK_F32_MFMA_TFLOPS},
     }
