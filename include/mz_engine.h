@@ -100,6 +100,15 @@ int mz_root_outputs(mz_engine *e, float *value, float *logits, float *hidden, vo
 int mz_root_prepare(mz_engine *e, const int8_t *to_play, const uint8_t *legal, const double *noise,
                     int use_device_rng, uint64_t move_counter, void *stream);
 
+/* Root from priors the caller already holds (its own Node.expand + add_exploration_noise, mcts.py:47-61):
+ * priors [dev][B][A] float64 (entries of illegal actions ignored).  Used by the batch-1 MCTS.run front-end. */
+int mz_root_set_priors(mz_engine *e, const int8_t *to_play, const uint8_t *legal, const double *priors,
+                       void *stream);
+
+/* The search path of the pending descent (after mz_select): paths [dev][B][num_simulations+2] node indices,
+ * lengths [dev][B].  (MCTS.run returns these as `search_paths`, mcts.py:101-102.) */
+int mz_last_paths(mz_engine *e, int32_t *paths, int32_t *lengths, void *stream);
+
 /* MCTS.run (mcts.py:78-102) for all B trees with the engine's own FCNetwork kernels:
  * num_simulations x { select_child descent, recurrent_inference, expand, backpropagate },
  * no host synchronisation. */

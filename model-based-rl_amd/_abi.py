@@ -61,6 +61,8 @@ SIGNATURES = {
     'mz_root_load': (_I, [_VP, _VP, _VP, _VP, _VP]),
     'mz_root_outputs': (_I, [_VP, _VP, _VP, _VP, _VP]),
     'mz_root_prepare': (_I, [_VP, _VP, _VP, _VP, _I, _U64, _VP]),
+    'mz_root_set_priors': (_I, [_VP, _VP, _VP, _VP, _VP]),
+    'mz_last_paths': (_I, [_VP, _VP, _VP, _VP]),
     'mz_search': (_I, [_VP, _I, _VP]),
     'mz_search_profiled': (_I, [_VP, _I, _VP, _VP]),
     'mz_search_phase_profile': (_I, [_VP, _I, _VP, _VP]),

@@ -1,0 +1,191 @@
+"""Self-play actor with the reference's surface (actors.py:16-182): Actor(actor_key, config, storage,
+replay_buffer, state=None) with launch / run_selfplay / play_game / sync_weights / load_state.
+
+One Actor = one GPU = `config.num_envs` environments searched in lock-step (the reference runs one
+environment per Ray actor process).  Two paths:
+  * synthetic on-device environments (shape-faithful stand-ins for the gym envs that are not installed):
+    the whole move loop of actors.py:131-173 runs on the device (Engine.selfplay_steps), experience records
+    come back through pinned memory and are ingested by the native replay (replay.ingest_records);
+  * host environments (TicTacToe, or any gym-0.x style env): the per-move body is driven from Python,
+    batched over the actor's games; with `config.parity_rng` the Dirichlet noise and the action samples
+    come from numpy's global stream in the reference's order, which makes a one-environment actor
+    reproduce the reference's games move for move (tests/test_actor_parity.py).
+"""
+import random
+import time
+from copy import deepcopy
+
+import numpy as np
+import torch
+
+from .engine import Engine, flatten_weights
+from .envs import get_environment
+
+
+def set_all_seeds(seed):
+  """utils.py:136-144: torch s, cuda s+1, random s+2, numpy s+3."""
+  if seed is None:
+    seed = random.randint(0, 1000)
+  torch.manual_seed(seed)
+  if torch.cuda.is_available():
+    torch.cuda.manual_seed_all(seed + 1)
+  random.seed(seed + 2)
+  np.random.seed(seed + 3)
+
+
+def _call(obj, name, *args, **kwargs):
+  """obj.name(...) for plain objects, obj.name.remote(...) + get for rayshim/ray handles."""
+  fn = getattr(obj, name)
+  if hasattr(fn, 'remote'):
+    return fn.remote(*args, **kwargs).result()
+  return fn(*args, **kwargs)
+
+
+class Actor(object):
+
+  def __init__(self, actor_key, config, storage, replay_buffer, state=None):
+    set_all_seeds(config.seed + actor_key if config.seed is not None else None)
+    self.actor_key = actor_key
+    self.config = deepcopy(config)
+    self.storage, self.replay_buffer = storage, replay_buffer
+    if not torch.cuda.is_available():
+      raise RuntimeError('GPU was requested but torch.cuda.is_available() is False.')   # actors.py:41
+    ids = getattr(config, 'actors_gpu_device_ids', None)
+    self.device = torch.device('cuda', ids[actor_key] if ids else torch.cuda.current_device())
+    self.host_env = config.environment == 'TicTacToe'
+    self.num_envs = int(getattr(config, 'num_envs', 1))
+    self.engine = Engine.from_config(config, self.num_envs, device=self.device,
+                                     seed=(config.seed or 0) + actor_key, env_id_offset=actor_key * self.num_envs)
+    if self.host_env:
+      self.environments = [get_environment(config) for _ in range(self.num_envs)]
+      for env in self.environments:
+        env.seed(config.seed)
+    if config.fixed_temperatures:
+      self.temperature = config.fixed_temperatures[actor_key]
+    if getattr(config, 'norm_obs', False):
+      self.obs_min = np.array(config.obs_range[::2], dtype=np.float32)
+      self.obs_range = np.array(config.obs_range[1::2], dtype=np.float32) - self.obs_min
+    self.experiences_collected = 0
+    self.training_step = 0
+    self.games_played = 0
+    self.move_counter = 0
+    if state is not None:
+      self.load_state(state)
+
+  # actors.py:75-79
+  def load_state(self, state):
+    self.engine.set_weights(state['weights'])
+    self.training_step = state['training_step']
+    self.games_played = state['actor_games'][self.actor_key]
+
+  # actors.py:81-85
+  def sync_weights(self, force=False):
+    weights, training_step = _call(self.storage, 'get_weights', self.games_played, self.actor_key)
+    if training_step != self.training_step or force:
+      self.engine.set_weights(weights)
+      self.training_step = training_step
+
+  def _temperature(self):
+    if self.config.fixed_temperatures:
+      return self.temperature
+    return self.config.visit_softmax_temperature(self.training_step)
+
+  # ---------------------------------------------------------------- host environments
+  def play_game(self, games):
+    """actors.py:126-176 for a batch of Game objects (one per environment of this actor), until every
+    game is terminal.  `games` may be a single Game (reference call style)."""
+    games = games if isinstance(games, (list, tuple)) else [games]
+    assert len(games) == self.num_envs
+    cfg, eng, A = self.config, self.engine, self.config.action_space
+    temperature = self._temperature()
+    live = [True] * len(games)
+    while any(live):
+      obs = np.stack([np.float32(g.get_observation(-1)).reshape(-1) for g in games])
+      if getattr(cfg, 'norm_obs', False):
+        obs = (obs - self.obs_min) / self.obs_range
+      legal = np.zeros((len(games), A), np.uint8)
+      noise = np.zeros((len(games), A)) if cfg.parity_rng else None
+      for i, g in enumerate(games):
+        acts = np.asarray(g.environment.legal_actions())
+        legal[i, acts] = 1
+        if cfg.parity_rng:       # mcts.py:59, one draw per move of length #legal
+          noise[i, acts] = np.random.dirichlet([cfg.root_dirichlet_alpha] * len(acts))
+      to_play = np.array([g.to_play for g in games], np.int8)
+      eng.initial_inference(obs)
+      eng.root_prepare(to_play, legal, noise, device_rng=not cfg.parity_rng, move=self.move_counter)
+      eng.search()
+      if cfg.parity_rng and temperature:
+        uniform = np.random.random_sample(len(games))   # the draw np.random.choice(n, p=...) consumes (config.py:77)
+      else:
+        uniform = None if not cfg.parity_rng else np.zeros(len(games))
+      out = {k: v.cpu().numpy() for k, v in eng.finalize(temperature, uniform, move=self.move_counter).items()}
+      self.move_counter += 1
+      for i, g in enumerate(games):
+        if not live[i]:
+          continue
+        action = int(out['action'][i])
+        if cfg.parity_rng and not temperature:             # config.py:79: numpy's own tie draw
+          vc = out['visit_counts'][i][np.flatnonzero(legal[i])]
+          action = int(np.flatnonzero(legal[i])[np.random.choice(np.where(vc == vc.max())[0])])
+        g.history.errors.append(float(out['error'][i]))
+        g.apply(action)
+        g.store_search_statistics(out['child_visits'][i], float(out['root_value'][i]))
+        self.experiences_collected += 1
+        if self.experiences_collected % cfg.weight_sync_frequency == 0:
+          self.sync_weights()
+        # actors.py:160-169
+        if (g.history_idx - g.previous_collect_to) == cfg.max_history_length or g.done or g.terminal:
+          overlap = cfg.num_unroll_steps + cfg.td_steps
+          if not g.history.dones[g.previous_collect_to - 1]:
+            collect_from = max(0, g.previous_collect_to - overlap)
+          else:
+            collect_from = g.previous_collect_to
+          history = g.get_history_sequence(collect_from)
+          _call(self.replay_buffer, 'save_history', history, ignore=None if g.done else overlap, terminal=g.terminal)
+        if g.step >= cfg.max_steps:
+          g.environment.was_real_done = True
+          live[i] = False
+        if g.terminal:
+          live[i] = False
+
+  # ---------------------------------------------------------------- run loop
+  def run_selfplay(self, max_moves=None, chunk=8):
+    while not _call(self.storage, 'is_ready'):
+      time.sleep(0.05)
+    self.sync_weights(force=True)
+    cfg = self.config
+    if self.host_env:
+      while self.training_step < cfg.training_steps and (max_moves is None or self.move_counter < max_moves):
+        games = [cfg.new_game(env) for env in self.environments]
+        self.play_game(games)
+        self.games_played += len(games)
+      return
+    # synthetic on-device environments
+    eng = self.engine
+    eng.selfplay_reset(cfg.episode_length, self._temperature(), stagger=True)
+    pinned = [torch.empty(chunk, eng.B, eng.rec_floats, dtype=torch.float32).pin_memory() for _ in range(2)]
+    events = [torch.cuda.Event(), torch.cuda.Event()]
+    pending, k = None, 0
+    sync_every = max(1, cfg.weight_sync_frequency)      # experiences per environment between weight pulls
+    while self.training_step < cfg.training_steps and (max_moves is None or self.move_counter < max_moves):
+      eng.selfplay_steps(chunk)
+      buf, n = eng.selfplay_drain(pinned[k & 1], chunk)
+      events[k & 1].record(torch.cuda.current_stream(self.device))
+      if pending is not None:
+        pending[2].synchronize()
+        _call(self.replay_buffer, 'ingest_records', pending[0], pending[1], eng.B)
+      pending = (buf, n, events[k & 1])
+      k += 1
+      self.move_counter += chunk
+      self.experiences_collected += chunk * eng.B
+      if (self.move_counter // sync_every) != ((self.move_counter - chunk) // sync_every):
+        self.sync_weights()
+    if pending is not None:
+      pending[2].synchronize()
+      _call(self.replay_buffer, 'ingest_records', pending[0], pending[1], eng.B)
+    self.sync_weights(force=True)
+
+  def launch(self, max_moves=None):
+    print('Actor-{} is online on {}.'.format(self.actor_key, self.device))
+    with torch.inference_mode():
+      self.run_selfplay(max_moves=max_moves)

@@ -1,0 +1,117 @@
+"""Configuration for the self-play path: the flags of the reference's config.py:87-231 that the search /
+actor / replay-ingest path reads, with the reference's names and defaults, plus the pool size of the GPU
+actor (`--num_envs`).  `Config` carries the helper methods callers use on it (config.py:21-84).
+Flags outside the path (optimizer, lr schedule, Atari wrappers, ...) are accepted where they are cheap to
+carry and otherwise not re-created."""
+import argparse
+
+import numpy as np
+
+
+class Config(object):
+
+  def __init__(self, args):
+    self.__dict__.update(args)
+    lo, hi = self.value_support
+    self.value_support_min, self.value_support_max = lo, hi
+    self.value_support_range = list(range(lo, hi + 1))
+    self.value_support_size = hi - lo + 1
+    lo, hi = self.reward_support
+    self.reward_support_min, self.reward_support_max = lo, hi
+    self.reward_support_range = list(range(lo, hi + 1))
+    self.reward_support_size = hi - lo + 1
+
+  # config.py:41-49
+  def visit_softmax_temperature(self, training_step):
+    steps, temps = self.visit_softmax_steps, self.visit_softmax_temperatures
+    for boundary, temp in zip(steps, temps):
+      if training_step <= boundary:
+        return temp
+    return temps[len(steps)]
+
+  # config.py:70-81 (for Node objects; the batched engine does this in mz_finalize)
+  @staticmethod
+  def select_action(node, temperature=0.):
+    actions = list(node.children.keys())
+    counts = np.array([child.visit_count for child in node.children.values()])
+    if temperature:
+      dist = counts ** (1 / temperature)
+      dist = dist / dist.sum()
+      idx = np.random.choice(len(actions), p=dist)
+    else:
+      idx = np.random.choice(np.where(counts == counts.max())[0])
+    return actions[idx]
+
+  def new_game(self, environment):
+    from .game import Game
+    return Game(environment, self)
+
+
+def build_parser():
+  p = argparse.ArgumentParser(description='MI355X-native MuZero self-play (reference flag names)')
+  a = p.add_argument
+  a('--architecture', type=str, default='FCNetwork', choices=['FCNetwork'])
+  a('--value_support', nargs=2, type=int, default=[-15, 15])
+  a('--reward_support', nargs=2, type=int, default=[-15, 15])
+  a('--no_support', action='store_true')
+  a('--no_target_transform', action='store_true')
+  a('--seed', type=int, default=None)
+  a('--environment', type=str, default='LunarLander-v2')
+  a('--two_players', action='store_true')
+  a('--obs_range', nargs='+', type=float, default=None)
+  a('--norm_obs', action='store_true')
+  a('--clip_rewards', action='store_true')
+  a('--episode_life', action='store_true')
+  a('--sticky_actions', type=int, default=1)
+  a('--num_actors', type=int, default=1)
+  a('--num_envs', type=int, default=4096, help='environments searched in lock-step by one GPU actor')
+  a('--episode_length', type=int, default=256, help='synthetic fixed-length episodes (gym is not installed)')
+  a('--max_steps', type=int, default=40000)
+  a('--num_simulations', type=int, default=30)
+  a('--max_history_length', type=int, default=500)
+  a('--visit_softmax_temperatures', nargs=3, type=float, default=[1.0, 0.5, 0.25])
+  a('--visit_softmax_steps', nargs=2, type=int, default=[15000, 30000])
+  a('--fixed_temperatures', nargs='+', type=float, default=[])
+  a('--root_dirichlet_alpha', type=float, default=0.25)
+  a('--root_exploration_fraction', type=float, default=0.25)
+  a('--init_value_score', type=float, default=0.0)
+  a('--known_bounds', nargs=2, type=float, default=[None, None])
+  a('--pb_c_base', type=int, default=19652)
+  a('--pb_c_init', type=float, default=1.25)
+  a('--window_size', type=int, default=100000)
+  a('--window_step', type=int, default=None)
+  a('--epsilon', type=float, default=0.01)
+  a('--alpha', type=float, default=1.)
+  a('--beta', type=float, default=1.)
+  a('--beta_increment_per_sampling', type=float, default=0.001)
+  a('--training_steps', type=int, default=100000000)
+  a('--num_unroll_steps', type=int, default=5)
+  a('--td_steps', type=int, default=10)
+  a('--batch_size', type=int, default=256)
+  a('--stored_before_train', type=int, default=50000)
+  a('--send_weights_frequency', type=int, default=500)
+  a('--weight_sync_frequency', type=int, default=1000)
+  a('--discount', type=float, default=0.997)
+  a('--use_gpu_for', nargs='+', type=str, default=['actors'], choices=['actors', 'learner'])
+  a('--actors_gpu_device_ids', nargs='+', type=int, default=None)
+  a('--group_tag', type=str, default=None)
+  a('--run_tag', type=str, default=None)
+  a('--actor_log_frequency', type=int, default=1)
+  a('--parity_rng', action='store_true',
+    help="draw Dirichlet noise / action samples from numpy's global stream in the reference's order")
+  return p
+
+
+ENV_SHAPES = {   # (action_space, obs_space) of the environments the reference's README runs
+    'TicTacToe': (9, (9,)), 'LunarLander-v2': (4, (8,)), 'Pong-ramNoFrameskip-v4': (6, (128,)),
+    'Breakout-ramNoFrameskip-v4': (4, (128,)),
+}
+
+
+def make_config(argv=None, **overrides):
+  args = vars(build_parser().parse_args(argv))
+  args.update(overrides)
+  cfg = Config(args)
+  if cfg.environment in ENV_SHAPES and not hasattr(cfg, 'action_space'):
+    cfg.action_space, cfg.obs_space = ENV_SHAPES[cfg.environment]   # train.py:66-68 probes the env for these
+  return cfg

@@ -314,6 +314,13 @@ static int launch_fused(mz_engine *e, int num_simulations, int sims_done, hipStr
   return launch_fused_t<21, 2, 32>(e, num_simulations, sims_done, s);
 }
 
+static int launch_root_priors(mz_engine *e, const int8_t *to_play, const uint8_t *legal, const double *priors,
+                              hipStream_t s) {
+  TREE_LAUNCH(k_tree_root_priors, s, e->tv, to_play, legal, priors);
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
+
 static int launch_search(mz_engine *e, int num_simulations, bool selection_valid, int sims_done, hipStream_t s) {
   if (e->use_fused && e->sims + 2 <= MZ_FUSED_MAXPL) {
     if (!selection_valid) TREE_LAUNCH(k_tree_select, s, e->tv);
@@ -548,6 +555,25 @@ int mz_search(mz_engine *e, int num_simulations, void *stream) {
   }
   e->sims_done += num_simulations;
   e->selection_valid = false;
+  return 0;
+}
+
+int mz_root_set_priors(mz_engine *e, const int8_t *to_play, const uint8_t *legal, const double *priors,
+                       void *stream) {
+  if (!e || !priors) return fail("mz_root_set_priors: null argument");
+  if (launch_root_priors(e, to_play, legal, priors, (hipStream_t)stream)) return -1;
+  e->sims_done = 0;
+  e->selection_valid = true;
+  e->root_ready = true;
+  return 0;
+}
+
+int mz_last_paths(mz_engine *e, int32_t *paths, int32_t *lengths, void *stream) {
+  if (!e) return fail("mz_last_paths: null engine");
+  if (!e->selection_valid) return fail("mz_last_paths: no pending descent (call mz_select first)");
+  hipStream_t s = (hipStream_t)stream;
+  if (paths) HIPCHECK(hipMemcpyAsync(paths, e->tv.path, (size_t)e->B * e->PL * 4, hipMemcpyDeviceToDevice, s));
+  if (lengths) HIPCHECK(hipMemcpyAsync(lengths, e->tv.plen, (size_t)e->B * 4, hipMemcpyDeviceToDevice, s));
   return 0;
 }
 

@@ -403,6 +403,35 @@ __global__ void k_tree_root(TreeView t, const int8_t *to_play, const uint8_t *le
   }
 }
 
+// root children priors given directly (a caller that already ran Node.expand / add_exploration_noise on
+// its own objects, e.g. the batch-1 MCTS.run front-end): Node(0) + children + MinMaxStats.reset
+template <int G>
+__global__ void k_tree_root_priors(TreeView t, const int8_t *to_play, const uint8_t *legal, const double *priors) {
+  const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = gt / G, lane = gt % G;
+  if (b >= t.B) return;
+  const int A = t.A;
+  const size_t o = (size_t)b * t.NN;
+  uint32_t mask = 0;
+  for (int a = 0; a < A; ++a) mask |= ((legal ? legal[(size_t)b * A + a] : 1) ? 1u : 0u) << a;
+  if (lane < A) {
+    const bool ok = (mask >> lane) & 1u;
+    const int ch = 1 + lane;
+    t.N[o + ch] = 0; t.W[o + ch] = 0.0; t.R[o + ch] = 0.f; t.E[o + ch] = -1; t.TP[o + ch] = ok ? 1 : 0;
+    t.P[o + ch] = ok ? priors[(size_t)b * A + lane] : 0.0;
+  }
+  if (lane == 0) {
+    t.N[o] = 0; t.W[o] = 0.0; t.R[o] = 0.f; t.E[o] = 0; t.TP[o] = to_play ? to_play[b] : (int8_t)1; t.P[o] = 0.0;
+    t.nexp[b] = 1;
+    t.legal[b] = mask;
+    t.mn[b] = t.has_min ? t.min_bound : __builtin_inf();
+    t.mx[b] = t.has_max ? t.max_bound : -__builtin_inf();
+    t.plen[b] = 0;
+  }
+  __threadfence_block();
+  mz_tree_select<G>(t, b, lane);
+}
+
 // numpy's pairwise float64 sum for n < 128 (ndarray.sum of a contiguous vector), config.py:76
 __device__ inline double mz_np_sum(const double *a, int n) {
   if (n < 8) {

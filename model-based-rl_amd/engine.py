@@ -159,6 +159,18 @@ class Engine(object):
     _abi.check(self.lib.mz_root_prepare(self._h, _ptr(to_play), _ptr(legal), _ptr(noise), int(device_rng), int(move),
                                         self.stream), 'mz_root_prepare')
 
+  def root_set_priors(self, priors, to_play=None, legal=None):
+    to_play = self._dev(to_play, torch.int8); legal = self._dev(legal, torch.uint8)
+    priors = self._dev(priors, torch.float64)
+    _abi.check(self.lib.mz_root_set_priors(self._h, _ptr(to_play), _ptr(legal), _ptr(priors), self.stream),
+               'mz_root_set_priors')
+
+  def last_paths(self):
+    paths = torch.empty(self.B, self.sims + 2, dtype=torch.int32, device=self.device)
+    lens = torch.empty(self.B, dtype=torch.int32, device=self.device)
+    _abi.check(self.lib.mz_last_paths(self._h, _ptr(paths), _ptr(lens), self.stream), 'mz_last_paths')
+    return paths, lens
+
   def search(self, num_simulations=None):
     n = self.sims if num_simulations is None else int(num_simulations)
     _abi.check(self.lib.mz_search(self._h, n, self.stream), 'mz_search')

@@ -1,0 +1,178 @@
+"""GPU: the reference-shaped surface on top of the engine.
+
+test_actor_reproduces_reference_games -- a one-environment Actor in parity mode (numpy's global stream, the
+reference's seeds) replays the reference's recorded TicTacToe self-play games (goldens g3): same actions, same
+visit distributions, same history slices reaching the replay buffer, same replay tree totals.  This is the
+whole path a1-a18 of SURVEY.md s8 against the reference itself.
+"""
+import os
+import types
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+class RecordingReplay(object):
+  def __init__(self, inner):
+    self.inner, self.calls = inner, []
+
+  def save_history(self, history, ignore=None, terminal=False):
+    self.calls.append((history, ignore, terminal))
+    self.inner.save_history(history, ignore=ignore, terminal=terminal)
+
+
+@pytest.mark.parametrize('gi,temp', [(0, 1.0), (1, 0.1), (2, 0.0), (3, 1.0)])
+def test_actor_reproduces_reference_games(gi, temp):
+  from oracle import oracle as orc
+  from model_based_rl_amd.actors import Actor
+  from model_based_rl_amd.config import make_config
+  from model_based_rl_amd.replay_buffer import PrioritizedReplay
+  from model_based_rl_amd.shared_storage import SharedStorage
+  g = np.load(os.path.join(G, 'g3_game_ttt_%d.npz' % gi))
+  cfg = make_config(['--environment', 'TicTacToe', '--two_players', '--known_bounds', '-1', '1', '--discount', '1',
+                     '--num_simulations', '30', '--seed', '0', '--num_envs', '1', '--parity_rng', '--window_size', '60000',
+                     '--max_history_length', str(int(g['max_history_length'])), '--fixed_temperatures', str(temp)])
+  storage = SharedStorage(cfg)
+  storage.store_weights(orc.load_weights(g), 0)
+  replay = RecordingReplay(PrioritizedReplay(cfg))
+  actor = Actor(0, cfg, storage, replay)
+  actor.sync_weights(force=True)
+  moves = g['action'].shape[0]
+  m = 0
+  same_moves = 0
+  diverged = False
+  for game_no in range(3):
+    game = cfg.new_game(actor.environments[0])
+    actor.play_game(game)
+    h = game.history
+    n = len(h.actions)
+    ga = g['action'][m:m + n]
+    if not diverged and np.array_equal(np.asarray(h.actions), ga):
+      assert np.array_equal(np.asarray(h.child_visits), g['child_visits'][m:m + n])
+      assert np.abs(np.asarray(h.root_values) - g['final_root_value'][m:m + n]).max() <= 5e-4
+      assert np.abs(np.asarray(h.errors) - g['error'][m:m + n]).max() <= 5e-4
+      same_moves += n
+    else:
+      diverged = True      # a flipped near-tie changes the game (and the numpy stream) from there on
+    m += n
+    if m >= moves:
+      break
+  # the engine's network agrees with PyTorch-CPU to ~1e-6, so whole games are reproduced; allow one late flip
+  assert same_moves >= 0.6 * moves, (same_moves, moves)
+  if not diverged:
+    assert len(replay.calls) == int(g['n_flushes'])
+    for k, (hist, ignore, terminal) in enumerate(replay.calls):
+      meta = g['flush_meta'][k]
+      assert (-1 if ignore is None else ignore) == int(meta[3]) and int(terminal) == int(meta[4])
+      assert np.array_equal(np.asarray(hist.actions), g['flush%d_actions' % k])
+    assert replay.inner.size() == int(g['flush_meta'][-1][5])
+    assert abs(replay.inner.tree.total_priority - float(g['replay_total'])) <= 1e-2
+  actor.engine.close()
+
+
+class ReplayNet(object):
+  """network object that returns the reference's recorded outputs (a fake for MCTS.run)."""
+  def __init__(self, g, m):
+    from model_based_rl_amd.networks import NetworkOutput
+    import torch
+    self.g, self.m, self.s, self.NO, self.torch = g, m, 0, NetworkOutput, torch
+
+  def recurrent_inference(self, hidden, action):
+    g, m, s, t = self.g, self.m, self.s, self.torch
+    assert int(action[0]) == int(g['sim_action'][m, s])
+    assert np.array_equal(hidden.numpy().reshape(-1), g['sim_parent_hidden'][m, s])
+    self.s += 1
+    return self.NO(t.tensor([[g['sim_value'][m, s]]]), t.tensor([[g['sim_reward'][m, s]]]),
+                   t.from_numpy(g['sim_logits'][m, s][None].copy()), t.from_numpy(g['sim_hidden'][m, s][None].copy()))
+
+
+@pytest.mark.parametrize('name', ['g2_tree_ttt_fc', 'g2_tree_fake_1p', 'g2_tree_fake_bounds'])
+def test_mcts_run_frontend_matches_reference_tree(name):
+  """MCTS(config).run(root, network) with Node objects: visit counts, value sums, MinMax, search paths."""
+  import torch
+  from model_based_rl_amd.mcts import MCTS, Node
+  from model_based_rl_amd.networks import NetworkOutput
+  g = np.load(os.path.join(G, name + '.npz'))
+  A, sims = int(g['A']), int(g['sims'])
+  kb = [None if np.isnan(x) else float(x) for x in g['known_bounds']]
+  cfg = types.SimpleNamespace(num_simulations=sims, action_space=A, two_players=bool(g['two_players']),
+                              known_bounds=kb, discount=float(g['discount']), pb_c_base=float(g['pb_c_base']),
+                              pb_c_init=float(g['pb_c_init']), init_value_score=float(g['init_value_score']))
+  mcts = MCTS(cfg)
+  for m in range(0, g['action'].shape[0], 5):
+    root = Node(0)
+    init = NetworkOutput(torch.tensor([[g['root_value'][m]]]), 0, torch.from_numpy(g['root_logits'][m][None].copy()),
+                         torch.from_numpy(g['root_hidden'][m][None].copy()))
+    legal = np.flatnonzero(g['legal'][m])
+    root.expand(init, int(g['to_play'][m]), legal)
+    for a in legal:                                   # the recorded Dirichlet draw instead of a fresh one
+      root.children[int(a)].prior = root.children[int(a)].prior * (1 - float(g['frac'])) + g['noise'][m, a] * float(g['frac'])
+    paths = mcts.run(root, ReplayNet(g, m))
+    assert [len(p) - 1 for p in paths] == list(g['leaf_depth'][m])
+    counts = np.zeros(A, np.int64)
+    for a, ch in root.children.items():
+      counts[a] = ch.visit_count
+    assert np.array_equal(counts, g['tree_N'][m, 1:1 + A])
+    assert root.value() == float(g['final_root_value'][m])
+    assert (mcts.min_max_stats.minimum, mcts.min_max_stats.maximum) == tuple(g['minmax'][m])
+    assert paths[-1][-1].expanded() and paths[0][0] is root
+
+
+def test_device_selfplay_records_and_sharding():
+  """on-device self-play loop: record contents vs the synthetic-env definition, episode bookkeeping, and
+  shard invariance: envs [16,32) searched by a second engine with env_id_offset 16 produce the records the
+  one-engine run produced for those env ids."""
+  from oracle import oracle as orc
+  from model_based_rl_amd.engine import Engine
+  g = np.load(os.path.join(G, 'g1_net_lunar.npz'))
+  w = orc.load_weights(g)
+  O, A, T, moves = 8, 4, 5, 12
+
+  def run(B, off):
+    eng = Engine(B, O, A, 30, seed=77, env_id_offset=off)
+    eng.set_weights(w)
+    eng.selfplay_reset(T, 1.0, stagger=False)
+    eng.selfplay_steps(moves)
+    buf, n = eng.selfplay_drain()
+    import torch
+    torch.cuda.synchronize()
+    return eng, buf[:n].numpy().copy()
+
+  eng, rec = run(32, 0)
+  assert rec.shape == (moves, 32, O + A + 8)
+  ints = rec[..., O + A + 3:].view(np.int32)
+  for m in range(moves):
+    assert np.array_equal(ints[m, :, 2], np.full(32, m % T))            # step
+    assert np.array_equal(ints[m, :, 4], np.full(32, m // T))           # episode
+    assert np.array_equal(ints[m, :, 1], np.full(32, int(m % T == T - 1)))   # done
+    assert np.array_equal(ints[m, :, 3], np.arange(32))                 # env id
+  for (m, b) in [(0, 0), (3, 7), (7, 31), (11, 16)]:
+    obs, rew = eng.synth_obs(b, m // T, m % T)
+    assert np.array_equal(rec[m, b, :O], obs) and rec[m, b, O + A + 2] == np.float32(rew)
+  cv = rec[..., O:O + A]
+  assert np.allclose(cv.sum(-1), 1.0, atol=1e-6) and np.all(cv * 30 == np.round(cv * 30))
+  acts = ints[..., 0]
+  assert np.all(np.take_along_axis(cv, acts[..., None], -1) > 0)
+  assert 0.15 < np.abs(rec[..., :O]).mean() / 0.8 < 1.5                 # roughly unit-variance observations
+  # last move against the oracle, with the Dirichlet draw the device used
+  noise = eng.export_tree()['noise']
+  t = orc.Trees(orc.tree_cfg(A, 30), 32)
+  t.search_fc(orc.FCNet(w, O, A), rec[-1, :, :O], np.ones(32, np.int8), None, noise, 0.25)
+  _, cvo, rvo, _ = t.finalize(1.0, np.zeros(32))
+  same = np.all(np.abs(cvo - cv[-1]) < 1e-6, axis=1)
+  assert same.mean() >= 0.9
+  assert np.abs(rvo - rec[-1, :, O + A])[same].max() < 5e-4
+  eng.close()
+  eng2, rec2 = run(16, 16)
+  assert np.array_equal(rec2, rec[:, 16:32])
+  eng2.close()
+
+
+def test_train_driver_selfplay_only():
+  from model_based_rl_amd import train
+  thr = train.main(['--environment', 'LunarLander-v2', '--num_envs', '64', '--num_simulations', '8', '--seed', '3',
+                    '--episode_length', '6', '--max_moves', '24', '--window_size', '4096'])
+  assert thr['games'] >= 64 * 3 and 64 * 18 <= thr['frames'] <= 64 * 24

@@ -1,0 +1,113 @@
+"""CPU tests of the host-side mirror of the reference interface: TicTacToe rules and Game bookkeeping
+against the reference's recorded games (goldens g3), config helpers, the ray shim, shared storage."""
+import glob
+import os
+import types
+
+import numpy as np
+import pytest
+
+G = os.path.join(os.path.dirname(__file__), 'golden')
+FILES = sorted(glob.glob(os.path.join(G, 'g3_game_*.npz')))
+
+
+def make_cfg(**kw):
+  from model_based_rl_amd.config import make_config
+  argv = ['--environment', 'TicTacToe', '--two_players', '--known_bounds', '-1', '1', '--discount', '1', '--seed', '0']
+  cfg = make_config(argv)
+  for k, v in kw.items():
+    setattr(cfg, k, v)
+  return cfg
+
+
+@pytest.mark.parametrize('path', FILES, ids=[os.path.basename(f)[:-4] for f in FILES])
+def test_tictactoe_and_game_reproduce_reference_histories(path):
+  """replaying the reference's recorded actions through envs.TicTacToe + game.Game gives the reference's
+  observations, legal sets, to_play, rewards, dones, steps and history slices (flush rules included)."""
+  from model_based_rl_amd.envs import TicTacToe
+  from model_based_rl_amd.game import Game
+  g = np.load(path)
+  cfg = make_cfg(max_history_length=int(g['max_history_length']))
+  env = TicTacToe()
+  moves = g['action'].shape[0]
+  m = 0
+  flush_k = 0
+  while m < moves:
+    game = Game(env, cfg)
+    in_game = 0
+    while not game.terminal and m < moves:
+      obs = np.float32(game.get_observation(-1))
+      assert np.array_equal(obs, g['obs'][m])
+      legal = np.isin(np.arange(9), env.legal_actions()).astype(np.uint8)
+      assert np.array_equal(legal, g['legal'][m])
+      assert game.to_play == int(g['to_play'][m])
+      game.history.errors.append(float(g['error'][m]))
+      game.apply(int(g['action'][m]))
+      game.store_search_statistics(g['child_visits'][m], float(g['final_root_value'][m]))
+      m += 1
+      in_game += 1
+      if (game.history_idx - game.previous_collect_to) == cfg.max_history_length or game.done or game.terminal:
+        overlap = cfg.num_unroll_steps + cfg.td_steps
+        collect_from = max(0, game.previous_collect_to - overlap) if not game.history.dones[game.previous_collect_to - 1] \
+            else game.previous_collect_to
+        h = game.get_history_sequence(collect_from)
+        meta = g['flush_meta'][flush_k]
+        assert collect_from == int(meta[2]) and in_game == int(meta[1])
+        assert (-1 if game.done else overlap) == int(meta[3]) and int(game.terminal) == int(meta[4])
+        pre = 'flush%d_' % flush_k
+        assert np.array_equal(np.stack([np.float32(o) for o in h.observations]), g[pre + 'observations'])
+        for f in ('actions', 'rewards', 'dones', 'steps', 'to_play', 'root_values', 'errors'):
+          assert np.array_equal(np.asarray(getattr(h, f), g[pre + f].dtype), g[pre + f]), f
+        assert np.array_equal(np.asarray(h.child_visits), g[pre + 'child_visits'])
+        flush_k += 1
+  assert flush_k == int(g['n_flushes'])
+
+
+def test_config_defaults_and_temperature_schedule():
+  from model_based_rl_amd.config import make_config
+  c = make_config([])
+  assert (c.num_simulations, c.discount, c.pb_c_base, c.pb_c_init) == (30, 0.997, 19652, 1.25)
+  assert (c.root_dirichlet_alpha, c.root_exploration_fraction, c.max_history_length) == (0.25, 0.25, 500)
+  assert c.value_support_size == 31 and c.reward_support_range[0] == -15
+  assert c.known_bounds == [None, None] and c.action_space == 4 and c.obs_space == (8,)
+  assert [c.visit_softmax_temperature(s) for s in (0, 15000, 15001, 30000, 30001)] == [1.0, 1.0, 0.5, 0.5, 0.25]
+
+
+def test_select_action_matches_numpy_stream():
+  from model_based_rl_amd.config import Config
+  from model_based_rl_amd.mcts import Node
+  root = Node(0)
+  for a, n in zip((0, 2, 5), (3, 20, 7)):
+    root.children[a] = Node(0.1); root.children[a].visit_count = n
+  np.random.seed(5); a1 = Config.select_action(root, 1.0)
+  np.random.seed(5)
+  p = np.array([3, 20, 7]) / 30.0
+  assert a1 == (0, 2, 5)[np.random.choice(3, p=p)]
+  assert Config.select_action(root, 0) == 2
+
+
+def test_rayshim_runs_calls_in_order_and_propagates_errors():
+  from model_based_rl_amd import rayshim as ray
+
+  class Counter(object):
+    def __init__(self, start): self.v = start
+    def add(self, k): self.v += k; return self.v
+    def boom(self): raise ValueError('x')
+
+  h = ray.remote(Counter).remote(10)
+  refs = [h.add.remote(i) for i in range(5)]
+  assert ray.get(refs) == [10, 11, 13, 16, 20]
+  done, pending = ray.wait(refs, num_returns=5)
+  assert len(done) == 5 and not pending
+  with pytest.raises(ValueError):
+    ray.get(h.boom.remote())
+
+
+def test_shared_storage_surface():
+  from model_based_rl_amd.shared_storage import SharedStorage
+  s = SharedStorage(types.SimpleNamespace(num_actors=3))
+  assert not s.is_ready()
+  s.store_weights({'w': 1}, 7)
+  w, step = s.get_weights(games=5, actor_key=2)
+  assert s.is_ready() and w == {'w': 1} and step == 7
+  assert s.get_stats('actor_games') == {0: 0, 1: 0, 2: 5} and s.get_stats()['training_step'] == 7
