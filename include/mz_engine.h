@@ -120,9 +120,9 @@ int mz_search(mz_engine *e, int num_simulations, void *stream);
 int mz_search_profiled(mz_engine *e, int num_simulations, float *ms_out, void *stream);
 
 /* Diagnostic build of the fused search kernel with in-kernel s_memtime stamps (never used for timing
- * claims): cycles_out [host][4 waves][12 phases] = per-wave cycle totals over num_simulations, averaged
+ * claims): cycles_out [host][4 waves][14 phases] = per-wave cycle totals over num_simulations, averaged
  * over workgroups.  Phases: 0 gather, 1 barrier, 2 dynamics fc1, 3 dynamics fc2, 4 combine, 5 LN/reward,
- * 6 store + prediction fc1, 7 prediction fc2, 8 combine, 9 value/logits, 10 tree step. */
+ * 6 store + prediction fc1, 7 prediction fc2, 8 combine, 9 value/logits, 10 expand, 11 backup, 12 descent, 13 rest of the tree step. */
 int mz_search_phase_profile(mz_engine *e, int num_simulations, unsigned long long *cycles_out, void *stream);
 
 /* The same loop opened up for an external network (MuZeroNetwork/TinyNetwork through PyTorch, or

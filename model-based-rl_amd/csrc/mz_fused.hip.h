@@ -161,7 +161,7 @@ __device__ __forceinline__ float mz_support_to_scalar8(const float *fin, int row
 #define MZ_FUSED_LDS_FLOATS (16 * MZ_HS + 4 * 6 * 256 + 96 * 16 + 16 + 16 + 16 * 32 + 96 + 64 + 64 + 64 + 2 * 16 * MZ_XE + 16 * MZ_FUSED_MAXPL)
 
 // PROF: diagnostic build only (mz_search_phase_profile): per-wave cycle totals of each phase of the loop.
-#define MZ_NPHASE 12
+#define MZ_NPHASE 14
 #define STAMP(ph)                                                              \
   if (PROF) {                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                         \
@@ -429,12 +429,14 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
     for (int i = 0; i < NPASS; ++i) {
       const int mt = tid / TL + i * (256 / TL);
       const int b = b0 + mt;
-      if (b < t.B)
+      if (b < t.B) {
+        auto stampf = [&](int k) __attribute__((always_inline)) { STAMP(10 + k) };
         mz_tree_step_fused<TL, LT>(t, tm[i], tl, slot0 + sim + 1, s_val[mt], s_rew[mt], s_lg + mt * 32,
-                               s_path + mt * MZ_FUSED_MAXPL, (double *)red + mt * 96, s_pbc, tr[i], sim + 1 < nsims,
-                                   my_slot[i], my_act[i]);
+                                   s_path + mt * MZ_FUSED_MAXPL, (double *)red + mt * 96, s_pbc, tr[i],
+                                   sim + 1 < nsims, my_slot[i], my_act[i], stampf);
+      }
     }
-    STAMP(10)
+    STAMP(13)
   }
   // per-tree scalars back to the pool (what export / a later mz_select continue from)
 #pragma unroll

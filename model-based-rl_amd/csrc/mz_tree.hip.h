@@ -218,11 +218,14 @@ template <> struct TreeMem<true> { int16_t *N; double *W; double *P; float *R; i
 // node at once (lane j = j-th node from the leaf) and runs the value recurrence through shuffles; in the
 // descent each child lane also loads its own expansion index and visit count, so the winner's are
 // forwarded by shuffle and a level costs ONE round trip.
-template <int TL, bool LT>
+struct MzNoStamp { __device__ __forceinline__ void operator()(int) const {} };
+
+template <int TL, bool LT, class STAMPF = MzNoStamp>
 __device__ __forceinline__ void mz_tree_step_fused(const TreeView &t, const TreeMem<LT> &tm, int lane, int e_new,
                                                    float value, float reward, const float *logits, int *s_path,
                                                    double *s_stage, const double *pbctab, TreeRegs &tr,
-                                                   bool do_select, int &slot_out, int &act_out) {
+                                                   bool do_select, int &slot_out, int &act_out,
+                                                   STAMPF stampf = STAMPF()) {
   const int A = t.A;
   const int len = tr.len, tp = tr.tp;
   const double g = t.discount;
@@ -243,6 +246,7 @@ __device__ __forceinline__ void mz_tree_step_fused(const TreeView &t, const Tree
     if (lane == 0) { tm.E[leafnode] = e_new; tm.TP[leafnode] = (int8_t)tp; tm.R[leafnode] = reward; }
   }
 
+  stampf(0);
   // ---- MCTS.backpropagate (mcts.py:126-143), TL path nodes per round
   double v_cur = (double)value;
   double mn_c = __builtin_inf(), mx_c = -__builtin_inf();
@@ -293,6 +297,7 @@ __device__ __forceinline__ void mz_tree_step_fused(const TreeView &t, const Tree
 #undef MZ_MM_STEP
   tr.mn = mn_c < tr.mn ? mn_c : tr.mn;
   tr.mx = mx_c > tr.mx ? mx_c : tr.mx;
+  stampf(1);
   if (!do_select) return;
 
   // ---- the next descent (mcts.py:83-92, 104-124)
@@ -351,6 +356,7 @@ __device__ __forceinline__ void mz_tree_step_fused(const TreeView &t, const Tree
   tr.tp = tpc;
   slot_out = parent_e;
   act_out = a_sel;
+  stampf(2);
 }
 
 // ------------------------------------------------------------------ kernels (one launch per phase)

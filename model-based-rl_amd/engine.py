@@ -184,7 +184,7 @@ class Engine(object):
 
   def search_phase_profile(self, num_simulations=None):
     n = self.sims if num_simulations is None else int(num_simulations)
-    out = np.zeros((4, 12), np.uint64)
+    out = np.zeros((4, 14), np.uint64)
     _abi.check(self.lib.mz_search_phase_profile(self._h, n, out.ctypes.data_as(C.c_void_p), self.stream),
                'mz_search_phase_profile')
     return out
