@@ -104,6 +104,80 @@ __device__ __forceinline__ float mz_max8(float x) {
   return x;
 }
 
+// 16-lane (full row) all-reduce by DPP: + row_mirror
+__device__ __forceinline__ float mz_sum16(float x) {
+  x += mz_dpp<0xB1>(x); x += mz_dpp<0x4E>(x); x += mz_dpp<0x141>(x); x += mz_dpp<0x140>(x);
+  return x;
+}
+__device__ __forceinline__ float mz_max16(float x) {
+  x = fmaxf(x, mz_dpp<0xB1>(x)); x = fmaxf(x, mz_dpp<0x4E>(x)); x = fmaxf(x, mz_dpp<0x141>(x));
+  x = fmaxf(x, mz_dpp<0x140>(x));
+  return x;
+}
+
+// relu(LayerNorm) of fin rows [row0,row0+50), column m -> xR[m][0..51]; 16 lanes per column
+__device__ __forceinline__ void sln_relu16(const float *fin, float *xR, const float *lnw, const float *lnb, int row0,
+                                           int m, int q) {
+  float x[4], s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int f = q + 16 * i;
+    x[i] = f < MZ_H ? fin[(row0 + f) * 16 + m] : 0.f;
+    s += x[i];
+  }
+  s = mz_sum16(s);
+  const float mean = s / (float)MZ_H;
+  float v = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float d = (q + 16 * i < MZ_H) ? x[i] - mean : 0.f;
+    v += d * d;
+  }
+  v = mz_sum16(v);
+  const float rstd = 1.0f / sqrtf(v / (float)MZ_H + 1e-5f);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int f = q + 16 * i;
+    if (f < MZ_HS) {
+      float y = 0.f;
+      if (f < MZ_H) y = fmaxf((x[i] - mean) * rstd * lnw[f] + lnb[f], 0.f);
+      xR[m * MZ_HS + f] = y;
+    }
+  }
+}
+
+// Config.inverse_transform (config.py:27-33), column m, 16 lanes per column, S <= 32 bins
+__device__ __forceinline__ float mz_support_to_scalar16(const float *fin, int row0, int S, int smin, int no_transform,
+                                                        int m, int q) {
+  float x[2], mx = -__builtin_inff();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int bin = q + 16 * i;
+    x[i] = bin < S ? fin[(row0 + bin) * 16 + m] : -__builtin_inff();
+    mx = fmaxf(mx, x[i]);
+  }
+  mx = mz_max16(mx);
+  float e[2], sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    e[i] = (q + 16 * i < S) ? expf(x[i] - mx) : 0.f;
+    sum += e[i];
+  }
+  sum = mz_sum16(sum);
+  float v = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) v += (float)(smin + q + 16 * i) * (e[i] / sum);
+  v = mz_sum16(v);
+  if (!no_transform) {
+    const float sgn = (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f);
+    float t = (fabsf(v) + 1.f) + 0.001f;
+    t = 1.f + 0.004f * t;
+    t = (sqrtf(t) - 1.f) / 0.002f;
+    v = sgn * (t * t - 1.f);
+  }
+  return v;
+}
+
 // relu(LayerNorm) of fin rows [row0,row0+50), column m -> row-major tile xR[m][0..51]; 8 lanes per column
 __device__ __forceinline__ void sln_relu8(const float *fin, float *xR, const float *lnw, const float *lnb, int row0,
                                           int m, int q) {
@@ -367,14 +441,11 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
           STAMP(3)
           scombine<6>(red, fin, out2, s_b2, tid);
           STAMP(4)
-          {
-            const int col = 8 * (w & 1) + (lane >> 3), q = lane & 7;
-            if (w < 2) {
-              sln_relu8(fin, xR, s_lnw, s_lnb, 32, col, q);
-            } else {
-              const float r = mz_support_to_scalar8(fin, 0, n.Sr, n.rmin, n.no_transform, col, q);
-              if (q == 0) s_rew[col] = r;
-            }
+          {   // every wave: its 4 trees, 16 lanes per tree: LayerNorm+ReLU -> xR, reward scalar -> s_rew
+            const int col = 4 * w + (lane >> 4), q = lane & 15;
+            sln_relu16(fin, xR, s_lnw, s_lnb, 32, col, q);
+            const float r = mz_support_to_scalar16(fin, 0, n.Sr, n.rmin, n.no_transform, col, q);
+            if (q == 0) s_rew[col] = r;
           }
           mz_bar();
           STAMP(5)
@@ -404,15 +475,11 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
           STAMP(7)
           scombine<NJ2>(red, fin, out4, s_b4, tid);
           STAMP(8)
-          if (w < 2) {
-            const int col = 8 * w + (lane >> 3), q = lane & 7;
-            const float v = mz_support_to_scalar8(fin, 0, n.Sv, n.vmin, n.no_transform, col, q);
+          {   // every wave: value scalar + policy logits of its 4 trees
+            const int col = 4 * w + (lane >> 4), q = lane & 15;
+            const float v = mz_support_to_scalar16(fin, 0, n.Sv, n.vmin, n.no_transform, col, q);
             if (q == 0) s_val[col] = v;
-          } else {
-            for (int idx = tid - 128; idx < 16 * n.A; idx += 128) {
-              const int m = idx / n.A, a = idx % n.A;
-              s_lg[m * 32 + a] = fin[(32 + a) * 16 + m];
-            }
+            for (int a = q; a < n.A; a += 16) s_lg[col * 32 + a] = fin[(32 + a) * 16 + col];
           }
         }
       }
