@@ -53,6 +53,29 @@ struct FusedSched {
 __device__ __forceinline__ void mz_mfma_a(f32x4 &c, float a, float b) {
   asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
+// fc1 accumulators live in arch VGPRs: ReLU is then one v_max in place and the tile is the B operand of the
+// following layer as it stands (no v_accvgpr_read copies, no second register set).  The first k-step uses the
+// inline constant 0 as SrcC, so the tiles are never zero-filled.
+__device__ __forceinline__ void mz_mfma_v(f32x4 &c, float a, float b) {
+  asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mz_mfma_v0(f32x4 &c, float a, float b) {
+  asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
+}
+// MFMA results -> VALU: wait states after the LAST MFMA of a stage (the earlier ones are long done)
+__device__ __forceinline__ void mz_mfma_fence16v(f32x4 (&acc)[16]) {
+  asm volatile("s_nop 15\n\ts_nop 7"
+               : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]),
+                 "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11]), "+v"(acc[12]),
+                 "+v"(acc[13]), "+v"(acc[14]), "+v"(acc[15]));
+}
+// VALU (ReLU) results -> MFMA SrcB: two wait states, once for the whole tile set
+__device__ __forceinline__ void mz_valu_fence16v(f32x4 (&acc)[16]) {
+  asm volatile("s_nop 1"
+               : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]),
+                 "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11]), "+v"(acc[12]),
+                 "+v"(acc[13]), "+v"(acc[14]), "+v"(acc[15]));
+}
 template <int N>
 __device__ __forceinline__ void mz_mfma_fence(f32x4 (&acc)[N]) {
 #pragma unroll
@@ -66,6 +89,15 @@ __device__ __forceinline__ float mz_xval(const float *xR, const float *xE, int m
   const float *p = (k < MZ_H) ? (xR + m * MZ_HS + k) : (xE + m * MZ_XE + (k - MZ_H));
   return *p;
 }
+// the same read issued from inline asm, so that it STAYS where it is written (one fc1 step ahead of its use,
+// in front of that step's 16 MFMAs) instead of being sunk by the scheduler to just before its consumer; the
+// value is usable after mz_lds_wait(x).
+__device__ __forceinline__ void mz_xval_async(float &x, const float *xR, const float *xE, int m, int k) {
+  const float *p = (k < MZ_H) ? (xR + m * MZ_HS + k) : (xE + m * MZ_XE + (k - MZ_H));
+  const unsigned addr = (unsigned)(size_t)(const __attribute__((address_space(3))) float *)p;
+  asm volatile("ds_read_b32 %0, %1" : "=v"(x) : "v"(addr));
+}
+__device__ __forceinline__ void mz_lds_wait(float &x) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x)); }
 
 template <int JTOT>
 __device__ __forceinline__ void scombine(float *red, float *fin, const f32x4 (&out)[JTOT], const float *bias,
@@ -375,8 +407,7 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
     STAMP(1)
 
     // ---- network: dynamics + prediction (networks.py:31-34), NSTEPS steps fully unrolled
-    f32x4 acc[16];
-    float hid[16][4];
+    f32x4 acc[16];       // fc1 tiles (arch VGPRs); after the in-place ReLU they are the hidden activations
     f32x4 out2[6];
     f32x4 out4[NJ2];
     float xq = 0.f;       // B operand of the NEXT fc1 step (read one step ahead)
@@ -393,32 +424,33 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
         // fc1 step: 16 tiles of this wave x one k-step; x from the tile (+ extension for k >= 50)
         constexpr bool dyn = s < E_FC1;
         constexpr int st = dyn ? s : s - E_FC2;
-        if constexpr (st == 0) {
-#pragma unroll
-          for (int tt = 0; tt < 16; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        if constexpr (st == 0) xq = mz_xval(xR, dyn ? xEd : xEp, m16, g4);
+        if constexpr (st == 0) mz_xval_async(xq, xR, dyn ? xEd : xEp, m16, g4);
+        mz_lds_wait(xq);
         const float x = xq;
-        if constexpr (st + 1 < (dyn ? SC::FC1 : SC::P1)) xq = mz_xval(xR, dyn ? xEd : xEp, m16, 4 * (st + 1) + g4);
+        if constexpr (st + 1 < (dyn ? SC::FC1 : SC::P1)) mz_xval_async(xq, xR, dyn ? xEd : xEp, m16, 4 * (st + 1) + g4);
 #pragma unroll
         for (int tg = 0; tg < 4; ++tg) {
-          mz_mfma_a(acc[4 * tg + 0], Bf[cb][tg][0], x);
-          mz_mfma_a(acc[4 * tg + 1], Bf[cb][tg][1], x);
-          mz_mfma_a(acc[4 * tg + 2], Bf[cb][tg][2], x);
-          mz_mfma_a(acc[4 * tg + 3], Bf[cb][tg][3], x);
+          if constexpr (st == 0) {
+            mz_mfma_v0(acc[4 * tg + 0], Bf[cb][tg][0], x);
+            mz_mfma_v0(acc[4 * tg + 1], Bf[cb][tg][1], x);
+            mz_mfma_v0(acc[4 * tg + 2], Bf[cb][tg][2], x);
+            mz_mfma_v0(acc[4 * tg + 3], Bf[cb][tg][3], x);
+          } else {
+            mz_mfma_v(acc[4 * tg + 0], Bf[cb][tg][0], x);
+            mz_mfma_v(acc[4 * tg + 1], Bf[cb][tg][1], x);
+            mz_mfma_v(acc[4 * tg + 2], Bf[cb][tg][2], x);
+            mz_mfma_v(acc[4 * tg + 3], Bf[cb][tg][3], x);
+          }
         }
         if constexpr (s == E_FC1 - 1 || s == E_P1 - 1) {
-          mz_mfma_fence<16>(acc);
+          mz_mfma_fence16v(acc);
 #pragma unroll
           for (int tt = 0; tt < 16; ++tt) {
-            hid[tt][0] = fmaxf(acc[tt][0], 0.f); hid[tt][1] = fmaxf(acc[tt][1], 0.f);
-            hid[tt][2] = fmaxf(acc[tt][2], 0.f); hid[tt][3] = fmaxf(acc[tt][3], 0.f);
+            acc[tt][0] = fmaxf(acc[tt][0], 0.f); acc[tt][1] = fmaxf(acc[tt][1], 0.f);
+            acc[tt][2] = fmaxf(acc[tt][2], 0.f); acc[tt][3] = fmaxf(acc[tt][3], 0.f);
           }
-          // VALU write -> MFMA SrcB read needs wait states the compiler cannot see are needed (the MFMAs
-          // are asm): pin every hid value behind a volatile asm with an s_nop
-#pragma unroll
-          for (int tt = 0; tt < 16; ++tt)
-            asm volatile("s_nop 1" : "+v"(hid[tt][0]), "+v"(hid[tt][1]), "+v"(hid[tt][2]), "+v"(hid[tt][3]));
+          // VALU write -> MFMA SrcB read needs wait states the compiler cannot know about (the MFMAs are asm)
+          mz_valu_fence16v(acc);
           if constexpr (s == E_FC1 - 1) { STAMP(2) } else { STAMP(6) }
         }
       } else if constexpr (s < E_FC2) {
@@ -433,7 +465,7 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
 #pragma unroll
           for (int q4 = 0; q4 < 4; ++q4) {
             const int q = 4 * step + q4, tt = q / 6, jt = q % 6;
-            mz_mfma_a(out2[jt], Bf[cb][q4][r], hid[jt < 2 ? tt : 8 + tt][r]);
+            mz_mfma_a(out2[jt], Bf[cb][q4][r], acc[jt < 2 ? tt : 8 + tt][r]);
           }
         }
         if constexpr (s == E_FC2 - 1) {
@@ -467,7 +499,7 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
 #pragma unroll
           for (int q4 = 0; q4 < 4; ++q4) {
             const int q = 4 * step + q4, tt = q / NJ2, jt = q % NJ2;
-            mz_mfma_a(out4[jt], Bf[cb][q4][r], hid[jt < 2 ? tt : 8 + tt][r]);
+            mz_mfma_a(out4[jt], Bf[cb][q4][r], acc[jt < 2 ? tt : 8 + tt][r]);
           }
         }
         if constexpr (s == E_P2 - 1) {
