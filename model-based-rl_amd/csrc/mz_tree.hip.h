@@ -300,45 +300,43 @@ __device__ __forceinline__ void mz_tree_step_fused(const TreeView &t, const Tree
   stampf(1);
   if (!do_select) return;
 
-  // ---- the next descent (mcts.py:83-92, 104-124)
+  // ---- the next descent (mcts.py:83-92, 104-124).  Written branch-free: every lane evaluates the whole
+  // score expression on safe operands and the conditions of the reference (fresh root ranks by prior,
+  // unvisited child gets init_value_score, MinMaxStats.normalize's three cases, illegal root slots) pick
+  // among the results -- a divergent if/else ladder cost more than the arithmetic it skipped.
   __threadfence_block();
   const double mn = tr.mn, mx = tr.mx;
+  const double span = mx - mn;
+  const bool span_pos = mx > mn, span_zero = mx == mn;
+  const int T = t.sims + 2;
   int node = 0, e = 0, Np = root_n, tpc = tr.root_tp, len2 = 1, a_sel = -1, parent_e = 0;
   if (lane == 0) s_path[0] = 0;
   while (e >= 0) {
-    const int ch = 1 + e * A + lane;
-    const bool valid = lane < A && (node != 0 || ((tr.legal >> lane) & 1u));
-    double score = 0.0;
-    int best = -1, Nc = 0, Ec = -1;
-    if (valid) {
-      Nc = tm.N[ch];
-      Ec = tm.E[ch];
-      const double p = tm.P[ch];
-      const double wc = tm.W[ch];
-      const double rc = (double)tm.R[ch];
-      if (Np == 0) {
-        score = p;
-      } else {
-        const double prior_score = pbctab[Np * (t.sims + 2) + Nc] * p;
-        double value_score;
-        if (Nc > 0) {
-          const double q = wc / (double)Nc;
-          const double vv = two ? -q : q;
-          value_score = mz_normalize(rc + g * vv, mn, mx);
-        } else {
-          value_score = t.init_value_score;
-        }
-        score = prior_score + value_score;
-      }
-      best = lane;
-    }
+    const bool valid = (lane < A) & ((node != 0) | (((tr.legal >> lane) & 1u) != 0));
+    const int ch = valid ? 1 + e * A + lane : 0;
+    int Nc = tm.N[ch];
+    int Ec = tm.E[ch];
+    const double p = tm.P[ch];
+    const double wc = tm.W[ch];
+    const double rc = (double)tm.R[ch];
+    const double prior_score = pbctab[Np * T + Nc] * p;
+    const double q = wc / (double)(Nc > 0 ? Nc : 1);
+    const double x = rc + g * (two ? -q : q);
+    const double nrm = (x - mn) / span;
+    const double visited = span_pos ? nrm : (span_zero ? 1.0 : x);
+    const double ucb = prior_score + ((Nc > 0) ? visited : t.init_value_score);
+    double score = (Np == 0) ? p : ucb;
+    int best = valid ? lane : -1;
     // tuple max over (score, action) with the winner's expansion index and visit count as payload
 #define MZ_AM_STEP(OFF)                                                                          \
   {                                                                                              \
     const double os = mz_xchg_d<OFF>(score);                                                     \
     const int ob = mz_xchg_i<OFF>(best), oe = mz_xchg_i<OFF>(Ec), on = mz_xchg_i<OFF>(Nc);       \
-    const bool take = ob >= 0 && (best < 0 || os > score || (os == score && ob > best));         \
-    if (take) { score = os; best = ob; Ec = oe; Nc = on; }                                       \
+    const bool take = (ob >= 0) & ((best < 0) | (os > score) | ((os == score) & (ob > best)));   \
+    score = take ? os : score;                                                                   \
+    best = take ? ob : best;                                                                     \
+    Ec = take ? oe : Ec;                                                                         \
+    Nc = take ? on : Nc;                                                                         \
   }
     MZ_AM_STEP(1) MZ_AM_STEP(2) MZ_AM_STEP(4) MZ_AM_STEP(8)
     if constexpr (TL == 32) MZ_AM_STEP(16)
