@@ -530,7 +530,7 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
       const int b = b0 + mt;
       if (b < t.B) {
         auto stampf = [&](int k) __attribute__((always_inline)) { STAMP(10 + k) };
-        mz_tree_step_fused<TL, LT>(t, tm[i], tl, slot0 + sim + 1, s_val[mt], s_rew[mt], s_lg + mt * 32,
+        mz_tree_step_fused<TL, G, LT>(t, tm[i], tl, slot0 + sim + 1, s_val[mt], s_rew[mt], s_lg + mt * 32,
                                    s_path + mt * MZ_FUSED_MAXPL, (double *)red + mt * 96, s_pbc, tr[i],
                                    sim + 1 < nsims, my_slot[i], my_act[i], stampf);
       }

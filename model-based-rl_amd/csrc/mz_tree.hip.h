@@ -220,7 +220,7 @@ template <> struct TreeMem<true> { int16_t *N; double *W; double *P; float *R; i
 // forwarded by shuffle and a level costs ONE round trip.
 struct MzNoStamp { __device__ __forceinline__ void operator()(int) const {} };
 
-template <int TL, bool LT, class STAMPF = MzNoStamp>
+template <int TL, int G, bool LT, class STAMPF = MzNoStamp>
 __device__ __forceinline__ void mz_tree_step_fused(const TreeView &t, const TreeMem<LT> &tm, int lane, int e_new,
                                                    float value, float reward, const float *logits, int *s_path,
                                                    double *s_stage, const double *pbctab, TreeRegs &tr,
@@ -311,9 +311,12 @@ __device__ __forceinline__ void mz_tree_step_fused(const TreeView &t, const Tree
   const int T = t.sims + 2;
   int node = 0, e = 0, Np = root_n, tpc = tr.root_tp, len2 = 1, a_sel = -1, parent_e = 0;
   if (lane == 0) s_path[0] = 0;
+  // the TL lanes of a tree evaluate the children in TL/G redundant copies (child = lane % G), so the
+  // arg-max needs only log2(G) exchange steps and every lane ends up with the result
+  const int cl = lane % G;
   while (e >= 0) {
-    const bool valid = (lane < A) & ((node != 0) | (((tr.legal >> lane) & 1u) != 0));
-    const int ch = valid ? 1 + e * A + lane : 0;
+    const bool valid = (cl < A) & ((node != 0) | (((tr.legal >> cl) & 1u) != 0));
+    const int ch = valid ? 1 + e * A + cl : 0;
     int Nc = tm.N[ch];
     int Ec = tm.E[ch];
     const double p = tm.P[ch];
@@ -326,7 +329,7 @@ __device__ __forceinline__ void mz_tree_step_fused(const TreeView &t, const Tree
     const double visited = span_pos ? nrm : (span_zero ? 1.0 : x);
     const double ucb = prior_score + ((Nc > 0) ? visited : t.init_value_score);
     double score = (Np == 0) ? p : ucb;
-    int best = valid ? lane : -1;
+    int best = valid ? cl : -1;
     // tuple max over (score, action) with the winner's expansion index and visit count as payload
 #define MZ_AM_STEP(OFF)                                                                          \
   {                                                                                              \
@@ -338,8 +341,11 @@ __device__ __forceinline__ void mz_tree_step_fused(const TreeView &t, const Tree
     Ec = take ? oe : Ec;                                                                         \
     Nc = take ? on : Nc;                                                                         \
   }
-    MZ_AM_STEP(1) MZ_AM_STEP(2) MZ_AM_STEP(4) MZ_AM_STEP(8)
-    if constexpr (TL == 32) MZ_AM_STEP(16)
+    if constexpr (G > 1) MZ_AM_STEP(1)
+    if constexpr (G > 2) MZ_AM_STEP(2)
+    if constexpr (G > 4) MZ_AM_STEP(4)
+    if constexpr (G > 8) MZ_AM_STEP(8)
+    if constexpr (G > 16) MZ_AM_STEP(16)
 #undef MZ_AM_STEP
     a_sel = best;
     parent_e = e;
