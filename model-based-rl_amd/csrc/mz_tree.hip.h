@@ -461,12 +461,10 @@ __device__ inline double mz_np_sum(const double *a, int n) {
 
 // Config.select_action (config.py:70-81) + Game.store_search_statistics (game.py:106-115) + root error
 // (actors.py:147-148).  One thread per tree (A <= 32 children, once per move).
-__global__ void k_tree_finalize(TreeView t, const double *temperature, const double *uniform, uint64_t seed,
-                                uint64_t move_val, const unsigned long long *move_ptr, int env_offset,
-                                int32_t *action, double *child_visits, double *root_value, double *error,
-                                int32_t *visit_counts) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= t.B) return;
+__device__ __forceinline__ void mz_finalize_tree(const TreeView &t, int b, const double *temperature,
+                                                 const double *uniform, uint64_t seed, uint64_t move, int env_offset,
+                                                 int32_t *action, double *child_visits, double *root_value,
+                                                 double *error, int32_t *visit_counts) {
   const int A = t.A;
   const size_t o = (size_t)b * t.NN;
   const uint32_t legal = t.legal[b];
@@ -493,7 +491,6 @@ __global__ void k_tree_finalize(TreeView t, const double *temperature, const dou
   if (uniform) {
     u = uniform[b];
   } else {
-    const uint64_t move = move_ptr ? (uint64_t)*move_ptr : move_val;
     mz_u4 r = mz_philox(seed, (uint32_t)(env_offset + b), (uint32_t)move, (uint32_t)(move >> 32), MZ_RNG_ACTION << 24);
     u = mz_u01(r.x, r.y);
   }
@@ -520,6 +517,18 @@ __global__ void k_tree_finalize(TreeView t, const double *temperature, const dou
       if (d[i] == m) { if (k == 0) { idx = i; break; } --k; }
   }
   action[b] = acts[idx];
+}
+
+
+__global__ void k_tree_finalize(TreeView t, const double *temperature, const double *uniform, uint64_t seed,
+                                uint64_t move_val, const unsigned long long *move_ptr, int env_offset,
+                                int32_t *action, double *child_visits, double *root_value, double *error,
+                                int32_t *visit_counts) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= t.B) return;
+  const uint64_t move = move_ptr ? (uint64_t)*move_ptr : move_val;
+  mz_finalize_tree(t, b, temperature, uniform, seed, move, env_offset, action, child_visits, root_value, error,
+                   visit_counts);
 }
 
 // hidden_out[b] = pool[b][slot[b]]  (what the reference hands to recurrent_inference, mcts.py:94-96)
