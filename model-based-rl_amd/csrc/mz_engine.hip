@@ -177,7 +177,7 @@ static int build_packing(mz_engine *e) {
   const size_t p_w1f = seg((size_t)4 * 4 * ks1f * 256), p_w3f = seg((size_t)4 * 4 * ks3f * 256);
   const int nj2 = 2 + jtp;
   const int real_steps = ks1f + 12 + ks3f + 2 * nj2;
-  const int nsteps = (real_steps + MZ_NB - 1) / MZ_NB * MZ_NB;
+  const int nsteps = MZ_RS + (real_steps - MZ_RS + MZ_NB - 1) / MZ_NB * MZ_NB;   // FusedSched::NSTEPS
   const size_t p_ws = seg((size_t)4 * nsteps * 4 * 256);
   e->n_packed = pos;
   std::vector<int32_t> idx(pos, -1);

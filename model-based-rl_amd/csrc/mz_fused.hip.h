@@ -33,6 +33,8 @@ __device__ __forceinline__ void mz_static_for(F &&f) {
 }
 
 #define MZ_NB 5      // register ring depth in steps (prefetch distance NB-1 steps)
+#define MZ_RS 10     // steps of the stream held in registers (AGPRs) across all simulations: less L2 traffic and
+                     // no load issue in those steps (a streamed step runs at ~37 cycles/MFMA, a resident one at 32)
 #define MZ_XE 36     // row stride of the x-tile extension [one-hot(action) | 1 | 0 ...] (k >= 50)
 
 // per-simulation schedule (in steps of 16 MFMAs per wave)
@@ -43,7 +45,9 @@ struct FusedSched {
   static constexpr int P1 = (MZ_H + 1 + 3) / 4; // prediction fc1: K = 51 -> 13 steps
   static constexpr int P2 = 2 * (2 + JTP);      // value (2 tiles) + policy (JTP tiles)
   static constexpr int REAL = FC1 + FC2 + P1 + P2;
-  static constexpr int NSTEPS = (REAL + MZ_NB - 1) / MZ_NB * MZ_NB;   // padded with dummy steps
+  static constexpr int RS = MZ_RS;              // the first RS steps stay resident in registers for the whole launch
+  static constexpr int NRING = (REAL - RS + MZ_NB - 1) / MZ_NB * MZ_NB;   // streamed steps, padded to the ring depth
+  static constexpr int NSTEPS = RS + NRING;     // schedule length incl. padding steps (prefetch only)
 };
 
 // MFMA from inline asm with the accumulator tied in place ("+a").  Left to itself hipcc, in this kernel,
@@ -58,6 +62,12 @@ __device__ __forceinline__ void mz_mfma_a(f32x4 &c, float a, float b) {
 // inline constant 0 as SrcC, so the tiles are never zero-filled.
 __device__ __forceinline__ void mz_mfma_v(f32x4 &c, float a, float b) {
   asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mz_mfma_va(f32x4 &c, float a, float b) {     // A operand from an AGPR
+  asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(c) : "a"(a), "v"(b));
+}
+__device__ __forceinline__ void mz_mfma_v0a(f32x4 &c, float a, float b) {
+  asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(c) : "a"(a), "v"(b));
 }
 __device__ __forceinline__ void mz_mfma_v0(f32x4 &c, float a, float b) {
   asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
@@ -288,7 +298,8 @@ template <int KS1, int JTP, int G, bool LT, bool PROF>
 __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, const f32x4 *wstream, int nsims,
                                                           int slot0, unsigned long long *prof) {
   using SC = FusedSched<KS1, JTP>;
-  constexpr int NB = MZ_NB, NSTEPS = SC::NSTEPS;
+  constexpr int NB = MZ_NB, NSTEPS = SC::NSTEPS, RS = SC::RS, NRING = SC::NRING;
+  static_assert(RS <= SC::FC1, "resident steps must be fc1 steps of the dynamics stage");
   constexpr int E_FC1 = SC::FC1, E_FC2 = E_FC1 + SC::FC2, E_P1 = E_FC2 + SC::P1, E_P2 = E_P1 + SC::P2;
   constexpr int NJ2 = 2 + JTP;
 
@@ -371,8 +382,18 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
   // this wave's stream: [NSTEPS][4 pieces][64 lanes] f32x4.  Wave-uniform base in SGPRs + per-lane byte
   // offset in one VGPR: every piece is then "s_base + const, v_off" (saddr form) and no per-piece 64-bit
   // VGPR address exists that the compiler could hoist out of the simulation loop and spill.
+  // stream of one wave: [RS resident steps][NRING streamed steps], 4 pieces of 64 lanes x f32x4 each
   const char *wbase = (const char *)(wstream + (size_t)__builtin_amdgcn_readfirstlane(w) * NSTEPS * 256);
   const unsigned lane_off = (unsigned)lane * 16u;
+  f32x4 Rw[RS][4];
+#pragma unroll
+  for (int s = 0; s < RS; ++s) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      Rw[s][p] = *(const __attribute__((address_space(1))) f32x4 *)((const __attribute__((address_space(1))) char *)wbase +
+                                                                    (size_t)((s * 4 + p) * 1024) + lane_off);
+  }
+  wbase += (size_t)RS * 4096;      // from here on: the streamed part, ring step r at wbase + r*4096
 #define MZ_WLOAD(step, piece)                                                             \
   (*(const __attribute__((address_space(1))) f32x4 *)((const __attribute__((address_space(1))) char *)wbase + \
                                                        (size_t)(((step) * 4 + (piece)) * 1024) + lane_off))
@@ -413,13 +434,15 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
     float xq = 0.f;       // B operand of the NEXT fc1 step (read one step ahead)
     mz_static_for<NSTEPS>([&](auto S_) __attribute__((always_inline)) {
       constexpr int s = decltype(S_)::value;
-      // prefetch step s + NB - 1 (cyclic: the tail of a simulation prefetches the head of the next)
-      {
-        constexpr int ps = (s + NB - 1) % NSTEPS, pb = (s + NB - 1) % NB;
+      // streamed steps: prefetch ring step r + NB - 1 (cyclic: the tail of a simulation prefetches the head of
+      // the next); resident steps issue no loads
+      if constexpr (s >= RS) {
+        constexpr int r = s - RS;
+        constexpr int ps = (r + NB - 1) % NRING, pb = (r + NB - 1) % NB;
 #pragma unroll
         for (int p = 0; p < 4; ++p) Bf[pb][p] = MZ_WLOAD(ps, p);
       }
-      constexpr int cb = s % NB;
+      constexpr int cb = (s >= RS ? s - RS : 0) % NB;
       if constexpr (s < E_FC1 || (s >= E_FC2 && s < E_P1)) {
         // fc1 step: 16 tiles of this wave x one k-step; x from the tile (+ extension for k >= 50)
         constexpr bool dyn = s < E_FC1;
@@ -430,7 +453,19 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
         if constexpr (st + 1 < (dyn ? SC::FC1 : SC::P1)) mz_xval_async(xq, xR, dyn ? xEd : xEp, m16, 4 * (st + 1) + g4);
 #pragma unroll
         for (int tg = 0; tg < 4; ++tg) {
-          if constexpr (st == 0) {
+          if constexpr (s < RS) {
+            if constexpr (st == 0) {
+              mz_mfma_v0a(acc[4 * tg + 0], Rw[s][tg][0], x);
+              mz_mfma_v0a(acc[4 * tg + 1], Rw[s][tg][1], x);
+              mz_mfma_v0a(acc[4 * tg + 2], Rw[s][tg][2], x);
+              mz_mfma_v0a(acc[4 * tg + 3], Rw[s][tg][3], x);
+            } else {
+              mz_mfma_va(acc[4 * tg + 0], Rw[s][tg][0], x);
+              mz_mfma_va(acc[4 * tg + 1], Rw[s][tg][1], x);
+              mz_mfma_va(acc[4 * tg + 2], Rw[s][tg][2], x);
+              mz_mfma_va(acc[4 * tg + 3], Rw[s][tg][3], x);
+            }
+          } else if constexpr (st == 0) {
             mz_mfma_v0(acc[4 * tg + 0], Bf[cb][tg][0], x);
             mz_mfma_v0(acc[4 * tg + 1], Bf[cb][tg][1], x);
             mz_mfma_v0(acc[4 * tg + 2], Bf[cb][tg][2], x);
