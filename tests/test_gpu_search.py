@@ -138,3 +138,59 @@ def test_full_game_goldens_end_to_end():
     assert np.abs(out['root_value'] - g['final_root_value'])[eq].max() <= 5e-4
     eng.close()
   assert same / tot >= 0.97, (same, tot)
+
+
+def _run_variant(env_extra, tag):
+  """run_both's engine half in a child process with an environment switch; returns visit counts + W."""
+  import subprocess, sys
+  code = ("import numpy as np, sys; sys.path.insert(0, %r)\n"
+          "from tests.test_gpu_search import run_both\n"
+          "o, e, _ = run_both('g1_net_lunar', 512, 30)\n"
+          "o2, e2, _ = run_both('g1_net_ttt', 64, 30, True, (-1.0, 1.0), 1.0, 0.6)\n"
+          "np.savez('/tmp/mz_%s.npz', vc=o['visit_counts'], W=e['W'], vc2=o2['visit_counts'], W2=e2['W'])\n"
+          ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), tag)
+  subprocess.check_call([sys.executable, '-c', code], env=dict(os.environ, **env_extra))
+  return np.load('/tmp/mz_%s.npz' % tag)
+
+
+def test_all_search_paths_agree_bit_for_bit():
+  """fused kernel with LDS-resident trees (default) and with trees in the global pool (MZ_NO_LDS_TREES) run
+  the same arithmetic: identical trees, bit for bit.  The separate-kernel path (MZ_NO_FUSED) evaluates the
+  network in a different f32 summation order (bias first instead of as the last k column, other reduction
+  trees), so it agrees like two correct f32 implementations do: same visit vectors in >= 99 % of the trees,
+  value sums to 1e-4 relative."""
+  a = _run_variant({}, 'default')
+  b = _run_variant({'MZ_NO_LDS_TREES': '1'}, 'nolds')
+  c = _run_variant({'MZ_NO_FUSED': '1'}, 'nofused')
+  for k in ('vc', 'W', 'vc2', 'W2'):
+    assert np.array_equal(a[k], b[k]), ('lds vs global trees', k)
+  for vk, wk in (('vc', 'W'), ('vc2', 'W2')):
+    same = np.all(a[vk] == c[vk], axis=1)
+    assert same.mean() >= 0.99, same.mean()
+    assert np.abs(a[wk][same, 0] - c[wk][same, 0]).max() <= 1e-4 * (1 + np.abs(c[wk][same, 0]).max())
+
+
+def test_search_in_two_calls_equals_one_call():
+  """mz_search(10) + mz_search(20) continues the same trees (the fused kernel reloads the partial tree)."""
+  from oracle import oracle as orc
+  from model_based_rl_amd.engine import Engine
+  g = np.load(os.path.join(G, 'g1_net_lunar.npz'))
+  w = orc.load_weights(g)
+  rng = np.random.RandomState(5)
+  B = 128
+  obs = rng.standard_normal((B, 8)).astype(np.float32)
+  noise = rng.dirichlet([0.25] * 4, size=B)
+  res = []
+  for split in ((30,), (10, 20), (1, 1, 28)):
+    eng = Engine(B, 8, 4, 30)
+    eng.set_weights(w)
+    eng.initial_inference(obs)
+    eng.root_prepare(None, None, noise)
+    for n in split:
+      eng.search(n)
+    res.append(eng.export_tree())
+    with pytest.raises(RuntimeError, match='exceed'):
+      eng.search(1)
+    eng.close()
+  for k in ('N', 'W', 'E', 'minmax'):
+    assert np.array_equal(res[0][k], res[1][k]) and np.array_equal(res[0][k], res[2][k]), k
