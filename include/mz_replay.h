@@ -67,6 +67,18 @@ int mzr_save_history(mz_replay *r, int64_t n, const double *errors, int64_t igno
  * overlap/ignore rules) or the episode is done.  frames/games: PrioritizedReplay.throughput. */
 int mzr_ingest_records(mz_replay *r, const float *records, int n_moves, int B, int rec_floats);
 
+/* PrioritizedReplay.sample_batch (replay_buffer.py:124-163) + insert_target (165-198) for `bs` stratified
+ * draws.  draws[i] is the value the reference obtains from random.uniform(seg*i, seg*(i+1)) (the caller owns
+ * the RNG; seg = total_priority / bs).  Outputs: obs [bs][O]; actions [bs][K] with -1 where the reference
+ * pads with np.random.randint (history shorter than K after `step`; the caller fills them in element order);
+ * target_rewards / target_values [bs][K+1] float32; target_policies [bs][K+1][A] float32; idxs [bs] tree
+ * indices (what `update` takes back); priorities [bs].  n-step value targets: root_values[i+td] * discount^td
+ * + sum of float32 rewards, sign-flipped where to_play differs, times float32 discounts (in float32, then
+ * added in double); absorbing steps past the end of the history get zero policy / value. */
+int mzr_sample_batch(const mz_replay *r, const double *draws, int bs, float *obs, int32_t *actions,
+                     float *target_rewards, float *target_values, float *target_policies, int64_t *idxs,
+                     double *priorities);
+
 int64_t mzr_frames(const mz_replay *r);   /* throughput['frames'] (replay_buffer.py:121) */
 int64_t mzr_games(const mz_replay *r);    /* throughput['games'] */
 int mzr_add_initial_throughput(mz_replay *r, int64_t frames, int64_t games);   /* replay_buffer.py:106-108 */

@@ -124,6 +124,7 @@ REPLAY_SIGNATURES = {
     'mzr_tree_leaves': (_I, [_VP, _I64, _VP]),
     'mzr_save_history': (_I, [_VP, _I64, _VP, _I64, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     'mzr_ingest_records': (_I, [_VP, _VP, _I, _I, _I]),
+    'mzr_sample_batch': (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     'mzr_frames': (_I64, [_VP]),
     'mzr_games': (_I64, [_VP]),
     'mzr_add_initial_throughput': (_I, [_VP, _I64, _I64]),

@@ -245,6 +245,64 @@ int mzr_ingest_records(mz_replay *r, const float *records, int n_moves, int B, i
   return 0;
 }
 
+int mzr_sample_batch(const mz_replay *r, const double *draws, int bs, float *obs, int32_t *actions,
+                     float *target_rewards, float *target_values, float *target_policies, int64_t *idxs,
+                     double *priorities) {
+  if (!r || !draws || !obs || !actions || !target_rewards || !target_values || !target_policies || !idxs || !priorities)
+    return fail("mzr_sample_batch: null argument");
+  const int O = r->c.obs_dim, A = r->c.action_space, K = r->c.num_unroll_steps, td = r->c.td_steps;
+  const int TL = K + 1;
+  // replay_buffer.py:81-82: discounts as float32, discount**td as a Python float
+  float disc[256];
+  if (K + td > 256) return fail("mzr_sample_batch: num_unroll_steps + td_steps too large");
+  for (int n = 0; n < K + td; ++n) disc[n] = (float)pow(r->c.discount, (double)n);
+  const double disc_td = pow(r->c.discount, (double)td);
+  for (int i = 0; i < bs; ++i) {
+    const int64_t idx = mzr_tree_get_leaf(r, draws[i]);                       // replay_buffer.py:142
+    const int64_t pos = idx - r->max_capacity + 1;
+    const std::shared_ptr<Hist> &h = r->leaf_hist[(size_t)pos];
+    if (!h) return fail("mzr_sample_batch: draw %d hit an empty leaf (buffer smaller than the draw range?)", i);
+    const int64_t step = r->leaf_step[(size_t)pos];
+    idxs[i] = idx;
+    priorities[i] = r->tree[(size_t)idx];
+    if (h->obs.empty() || h->child_visits.empty() || h->root_values.empty())
+      return fail("mzr_sample_batch: history was ingested without payload");
+    memcpy(obs + (size_t)i * O, h->obs.data() + (size_t)step * O, O * sizeof(float));   // 147
+    for (int k = 0; k < K; ++k)                                                        // 149-152
+      actions[(size_t)i * K + k] = (step + k < (int64_t)h->actions.size()) ? h->actions[(size_t)(step + k)] : -1;
+    // insert_target, replay_buffer.py:165-198
+    const int64_t end_index = (int64_t)h->root_values.size();
+    const int64_t n_rewards = (int64_t)h->rewards.size();
+    for (int j = 0; j < TL; ++j) {
+      const int64_t cur = step + j;
+      const float last_reward = (cur > 0 && cur <= n_rewards) ? h->rewards[(size_t)(cur - 1)] : 0.f;
+      float *pol = target_policies + ((size_t)i * TL + j) * A;
+      if (cur < end_index) {
+        const int tp = h->to_play[(size_t)cur];
+        const int64_t boot = cur + td;
+        double value = boot < end_index ? h->root_values[(size_t)boot] * disc_td : 0.0;
+        const int64_t hi = boot < n_rewards ? boot : n_rewards;
+        if (hi > cur) {
+          float acc = 0.f;
+          for (int64_t q = cur; q < hi; ++q) {
+            const float rw = (h->to_play[(size_t)q] != tp) ? -h->rewards[(size_t)q] : h->rewards[(size_t)q];
+            acc += rw * disc[q - cur];
+          }
+          value += (double)acc;
+        }
+        memcpy(pol, h->child_visits.data() + (size_t)cur * A, A * sizeof(float));
+        target_rewards[(size_t)i * TL + j] = last_reward;
+        target_values[(size_t)i * TL + j] = (float)value;
+      } else {
+        for (int a = 0; a < A; ++a) pol[a] = 0.f;
+        target_rewards[(size_t)i * TL + j] = last_reward;
+        target_values[(size_t)i * TL + j] = 0.f;
+      }
+    }
+  }
+  return 0;
+}
+
 int64_t mzr_frames(const mz_replay *r) { return r->frames; }
 int64_t mzr_games(const mz_replay *r) { return r->games; }
 int mzr_add_initial_throughput(mz_replay *r, int64_t frames, int64_t games) {

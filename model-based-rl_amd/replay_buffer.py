@@ -7,6 +7,7 @@ keep the reference's signatures; `ingest_records` is the bulk path used by the G
 from Engine.selfplay_drain) and applies the actor-side flush rules (actors.py:160-169) per environment.
 """
 import ctypes as C
+import random
 
 import numpy as np
 
@@ -86,6 +87,9 @@ class PrioritizedReplay(object):
     _abi.check_replay(self.lib.mzr_create(C.byref(cfg), C.byref(h)), 'mzr_create')
     self._h = h
     self.tree = SumTree(capacity, step, _owner=self._h)
+    if config.seed is not None:          # replay_buffer.py:104-106
+      np.random.seed(config.seed)
+      random.seed(config.seed + 1)
 
   def __del__(self):
     if getattr(self, '_h', None):
@@ -127,6 +131,28 @@ class PrioritizedReplay(object):
       records = np.ascontiguousarray(records, np.float32)
       ptr, rec = _p(records), int(records.shape[-1])
     _abi.check_replay(self.lib.mzr_ingest_records(self._h, ptr, int(n_moves), int(B), rec), 'mzr_ingest_records')
+
+  # replay_buffer.py:124-163 (+ insert_target 165-198 inside the native call)
+  def sample_batch(self):
+    bs, K, A, O = self.batch_size, int(self.config.num_unroll_steps), self.action_space, self.obs_dim
+    if self.beta < 1:
+      self.beta = np.min([1., self.beta + getattr(self.config, 'beta_increment_per_sampling', 0.001)])
+    total = self.tree.total_priority
+    seg = total / bs
+    draws = np.array([random.uniform(seg * i, seg * (i + 1)) for i in range(bs)], np.float64)
+    obs = np.zeros((bs,) + tuple(self.config.obs_space), np.float32)
+    actions = np.zeros((bs, K), np.int32)
+    t_rew = np.zeros((bs, K + 1), np.float32); t_val = np.zeros((bs, K + 1), np.float32)
+    t_pol = np.zeros((bs, K + 1, A), np.float32)
+    idxs = np.zeros(bs, np.int64); pri = np.zeros(bs, np.float64)
+    _abi.check_replay(self.lib.mzr_sample_batch(self._h, _p(draws), bs, _p(obs), _p(actions), _p(t_rew), _p(t_val),
+                                                _p(t_pol), _p(idxs), _p(pri)), 'mzr_sample_batch')
+    for i, k in zip(*np.nonzero(actions < 0)):      # replay_buffer.py:150-151, in the reference's draw order
+      actions[i, k] = np.random.randint(A)
+    probs = pri / total
+    is_weights = np.power(self.tree.num_memories * probs, -self.beta)
+    is_weights /= is_weights.max()
+    return (obs, actions.tolist(), (t_rew, t_val, t_pol)), idxs.tolist(), is_weights
 
   # replay_buffer.py:200-203
   def update(self, idxs, errors):
