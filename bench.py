@@ -72,8 +72,13 @@ def main():
   if world > 1:
     import torch.distributed as dist
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    local_rank = local_rank % max(1, torch.cuda.device_count())   # (several ranks on one GPU only in the gloo self-test)
     torch.cuda.set_device(local_rank)
-    dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    backend = os.environ.get('MZ_BENCH_BACKEND', 'nccl')             # 'nccl' = RCCL over xGMI; 'gloo' for the 1-GPU self-test
+    if backend == 'nccl':
+      dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    else:
+      dist.init_process_group(backend)
   elif args.gpus > 1:
     raise SystemExit('--gpus %d needs the torch.distributed.run launcher (one process per GPU)' % args.gpus)
   device = torch.device('cuda', local_rank)

@@ -92,6 +92,12 @@ def build_parser():
   a('--send_weights_frequency', type=int, default=500)
   a('--weight_sync_frequency', type=int, default=1000)
   a('--discount', type=float, default=0.997)
+  a('--optimizer', type=str, default='AdamW', choices=['RMSprop', 'Adam', 'AdamW', 'SGD'])
+  a('--lr_init', type=float, default=0.0008)
+  a('--weight_decay', type=float, default=1e-4)
+  a('--momentum', type=float, default=0.9)
+  a('--clip_grad', type=int, default=0)
+  a('--save_state_frequency', type=int, default=1000)
   a('--use_gpu_for', nargs='+', type=str, default=['actors'], choices=['actors', 'learner'])
   a('--actors_gpu_device_ids', nargs='+', type=int, default=None)
   a('--group_tag', type=str, default=None)

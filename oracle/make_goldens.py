@@ -477,5 +477,84 @@ def main():
   print('total fixture bytes', total)
 
 
-if __name__ == '__main__':
+if __name__ == '__main__' and (len(sys.argv) < 2 or sys.argv[-1] != 'learner'):
   main()
+
+
+# ----------------------------------------------------------------------------- G5: learner step
+def gen_learner(outdir):
+  """One Learner.update_weights step (learners.py:164-230) of the UNMODIFIED reference on the batch recorded in
+  g3_game_ttt_0 (G4).  learners.py / utils.py / wrappers.py / logger.py import ray, gym, cv2 and tensorboard, none of
+  which is installed; they are replaced by empty stand-in modules for the IMPORT only (nothing of them is executed on
+  this path: the environment is the reference's own TicTacToe, logging calls are no-ops)."""
+  import tempfile
+  ray = types.ModuleType('ray'); ray.remote = lambda c: c; ray.get = lambda x: x
+  sys.modules['ray'] = ray
+  gym = types.ModuleType('gym')
+
+  class _W(object):
+    def __init__(self, env=None):
+      self.env = env
+  gym.Wrapper = gym.ObservationWrapper = gym.RewardWrapper = gym.ActionWrapper = _W
+  spaces = types.ModuleType('gym.spaces'); spaces.Box = object; gym.spaces = spaces
+  sys.modules['gym'] = gym; sys.modules['gym.spaces'] = spaces
+  cv2 = types.ModuleType('cv2'); cv2.ocl = types.SimpleNamespace(setUseOpenCL=lambda x: None)
+  sys.modules['cv2'] = cv2
+  tb = types.ModuleType('torch.utils.tensorboard')
+
+  class SW(object):
+    def __init__(self, *a, **k): pass
+    def add_scalar(self, *a, **k): pass
+    def add_scalars(self, *a, **k): pass
+    def add_histogram(self, *a, **k): pass
+  tb.SummaryWriter = SW
+  sys.modules['torch.utils.tensorboard'] = tb
+  sys.path.insert(0, REF)
+  import config as rconfig
+  import learners as rlearners
+  g = np.load(os.path.join(outdir, 'g3_game_ttt_0.npz'))
+  old = sys.argv
+  sys.argv = ['train.py', '--environment', 'TicTacToe', '--two_players', '--known_bounds', '-1', '1', '--discount', '1',
+              '--seed', '0', '--batch_size', '16', '--window_size', '60000', '--run_tag', 'g5', '--group_tag', 'g5']
+  try:
+    cfg = rconfig.make_config()
+  finally:
+    sys.argv = old
+  for key in ('seed', 'num_actors', 'lr_init', 'discount', 'window_size', 'window_step', 'batch_size', 'num_simulations',
+              'num_unroll_steps', 'td_steps'):
+    setattr(cfg, key, getattr(cfg, key)[0])
+  cfg.action_space, cfg.obs_space = 9, (9,)
+
+  class Sink(object):            # replay / storage handles: record what the learner sends
+    def __init__(self): self.calls = []
+    def __getattr__(self, name):
+      sink = self
+      class M(object):
+        def remote(self_, *a, **k):
+          sink.calls.append((name, a, k)); return None
+      return M()
+  replay, storage = Sink(), Sink()
+  cwd = os.getcwd()
+  os.chdir(tempfile.mkdtemp())
+  try:
+    learner = rlearners.Learner(cfg, storage, replay)
+  finally:
+    os.chdir(cwd)
+  w0 = {('w0.' + k): v.detach().numpy().copy() for k, v in learner.network.state_dict().items()}
+  batch = ((g['sample_obs'].copy(), g['sample_actions'].tolist(),
+            (g['sample_target_rewards'].copy(), g['sample_target_values'].copy(), g['sample_target_policies'].copy())),
+           g['sample_idxs'].tolist(), g['sample_is_weights'].copy())
+  out = dict(w0)
+  for step in range(2):
+    learner.update_weights(batch)
+    out.update({('w%d.' % (step + 1) + k): v.detach().numpy().copy() for k, v in learner.network.state_dict().items()})
+  out['losses'] = np.array([learner.losses_to_log['reward'], learner.losses_to_log['value'], learner.losses_to_log['policy']])
+  upd = [c for c in replay.calls if c[0] == 'update']
+  out['new_errors'] = np.stack([np.asarray(c[1][1], np.float64) for c in upd])
+  out['lr_init'] = np.float64(cfg.lr_init); out['weight_decay'] = np.float64(cfg.weight_decay)
+  np.savez_compressed(os.path.join(outdir, 'g5_learner_ttt'), **out)
+  print('g5_learner_ttt: losses (sum of 2 steps)', out['losses'])
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[-1] == 'learner':
+  gen_learner(os.path.abspath(os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden')))

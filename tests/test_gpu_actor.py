@@ -174,5 +174,16 @@ def test_device_selfplay_records_and_sharding():
 def test_train_driver_selfplay_only():
   from model_based_rl_amd import train
   thr = train.main(['--environment', 'LunarLander-v2', '--num_envs', '64', '--num_simulations', '8', '--seed', '3',
-                    '--episode_length', '6', '--max_moves', '24', '--window_size', '4096'])
+                    '--episode_length', '6', '--max_moves', '24', '--window_size', '4096', '--selfplay_only'])
   assert thr['games'] >= 64 * 3 and 64 * 18 <= thr['frames'] <= 64 * 24
+
+
+def test_train_driver_with_learner():
+  """actors + native replay + learner in one process: the learner publishes weights, waits for
+  stored_before_train experiences, trains a few steps on sampled batches and refreshes priorities."""
+  from model_based_rl_amd import train
+  thr = train.main(['--environment', 'LunarLander-v2', '--num_envs', '64', '--num_simulations', '8', '--seed', '3',
+                    '--episode_length', '6', '--max_moves', '48', '--window_size', '8192', '--stored_before_train', '512',
+                    '--batch_size', '32', '--learner_steps', '5', '--send_weights_frequency', '2', '--use_gpu_for',
+                    'actors', 'learner'])
+  assert thr['frames'] >= 64 * 36
