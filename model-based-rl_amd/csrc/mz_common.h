@@ -41,8 +41,7 @@ struct TreeView {
 
 // Packed FCNetwork weights in MFMA operand order (see mz_net.hip.h).
 struct NetView {
-  const f32x4 *w0, *b0;   // representation fc1   [4][2][ks0][64], [4][8][64]
-  const f32x4 *w0o;       // representation out   [4 jt][4][8][64]
+  const f32x4 *w0o;       // representation out   [4 jt][4][8][64] (source of the root kernel's stream)
   const float *b0o;       // [64]
   const f32x4 *w1, *b1;   // dynamics fc1 (reward | transition)  [4][4][ks1][64], [4][16][64]
   const f32x4 *w2;        // reward out (2 jt) | transition out (4 jt): [6][4][8][64]

@@ -20,6 +20,7 @@
 #include "mz_tree.hip.h"
 #include "mz_selfplay.hip.h"
 #include "mz_fused.hip.h"
+#include "mz_root.hip.h"
 
 static thread_local std::string g_err;
 
@@ -60,6 +61,8 @@ struct mz_engine {
   SelfplayState sp;
   hipGraphExec_t move_graph = nullptr;
   const f32x4 *wstream = nullptr;   // per-wave cyclic weight stream for the fused search kernel
+  const f32x4 *istream = nullptr;   // per-wave weight stream of the root kernel (initial inference)
+  int nst0 = 0;                     // its run-time first-stage steps (obs_dim + 1 columns, two k-steps per step)
   int ks1sel = 0;                   // fc1 k-steps of the fused kernel instantiation chosen for this A
   bool use_fused = true;
   bool use_lds_trees = true;
@@ -166,7 +169,7 @@ static int build_packing(mz_engine *e) {
   const int jtp = e->jtp;
   size_t pos = 0;
   auto seg = [&](size_t n) { size_t p = pos; pos += (n + 3) & ~(size_t)3; return p; };
-  const size_t p_w0 = seg((size_t)4 * 2 * ks0 * 256), p_b0 = seg(4 * 8 * 256), p_w0o = seg(4 * 4 * 8 * 256), p_b0o = seg(64);
+  const size_t p_w0o = seg(4 * 4 * 8 * 256), p_b0o = seg(64);
   const size_t p_w1 = seg((size_t)4 * 4 * ks1 * 256), p_b1 = seg(4 * 16 * 256), p_w2 = seg(6 * 4 * 8 * 256), p_b2 = seg(96);
   const size_t p_w3 = seg((size_t)4 * 4 * ks3 * 256), p_b3 = seg(4 * 16 * 256);
   const size_t p_w4 = seg((size_t)(2 + jtp) * 4 * 8 * 256), p_b4 = seg(32 + 16 * jtp);
@@ -179,11 +182,12 @@ static int build_packing(mz_engine *e) {
   const int real_steps = ks1f + 12 + ks3f + 2 * nj2;
   const int nsteps = MZ_RS + (real_steps - MZ_RS + MZ_NB - 1) / MZ_NB * MZ_NB;   // FusedSched::NSTEPS
   const size_t p_ws = seg((size_t)4 * nsteps * 4 * 256);
+  // root kernel stream: [nst0 first-stage steps][8 representation-out][13 prediction fc1][2*nj2 prediction out]
+  const int nst0 = mz_root_nst0(O), nroot = nst0 + 8 + ks3f + 2 * nj2;
+  const size_t p_is = seg((size_t)4 * nroot * 4 * 256);
   e->n_packed = pos;
   std::vector<int32_t> idx(pos, -1);
   {
-    size_t wo[2] = {L.rep_w1, 0}, bo[2] = {L.rep_b1, 0};
-    fill_fc1(idx, p_w0, p_b0, 1, wo, bo, O, ks0);
     fill_fc2(idx, p_w0o, 4, L.rep_w2, MZ_H);
     fill_vec(idx, p_b0o, 64, L.rep_b2, MZ_H);
   }
@@ -230,17 +234,49 @@ static int build_packing(mz_engine *e) {
     // the remaining (nsteps - real_steps) * 4 pieces are padding (index -1 -> 0.0), loaded but never used
   }
 
+  // the root kernel's stream (mz_root.hip.h).  First stage, wave w, step st, piece p: k-step 2*st + (p>>1),
+  // tiles 4*(p&1)..+3 of the wave's 8 (features 128w + 16*tile + (lane&15)), k = 4*kstep + (lane>>4); column O
+  // carries the bias.
+  for (int w = 0; w < 4; ++w) {
+    const size_t base = p_is + (size_t)w * nroot * 4 * 256;
+    for (int st = 0; st < nst0; ++st)
+      for (int p = 0; p < 4; ++p)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int i = 0; i < 4; ++i) {
+            const int tile = 4 * (p & 1) + i, nf = 128 * w + 16 * tile + (lane & 15);
+            const int k = 4 * (2 * st + (p >> 1)) + (lane >> 4);
+            int32_t v = -1;
+            if (k < O) v = (int32_t)(L.rep_w1 + (size_t)nf * O + k);
+            else if (k == O) v = (int32_t)(L.rep_b1 + nf);
+            idx[base + ((size_t)(st * 4 + p) * 64 + lane) * 4 + i] = v;
+          }
+    size_t piece = (size_t)nst0 * 4;
+    auto put = [&](size_t src) {
+      memcpy(&idx[base + piece * 256], &idx[src], 256 * sizeof(int32_t));
+      ++piece;
+    };
+    for (int t = 0; t < 8; ++t)
+      for (int jt = 0; jt < 4; ++jt) put(p_w0o + ((size_t)(jt * 4 + w) * 8 + t) * 256);
+    for (int st = 0; st < ks3f; ++st)
+      for (int tg = 0; tg < 4; ++tg) put(p_w3f + ((size_t)(w * 4 + tg) * ks3f + st) * 256);
+    for (int t = 0; t < 8; ++t)
+      for (int jt = 0; jt < nj2; ++jt) put(p_w4 + ((size_t)(jt * 4 + w) * 8 + t) * 256);
+    if ((int)piece != nroot * 4) return fail("internal: root stream has %zu pieces, expected %d", piece, nroot * 4);
+  }
+
   if (dmalloc(e, &e->pack_idx, pos)) return -1;
   if (dmalloc(e, &e->packed, pos)) return -1;
   if (dmalloc(e, &e->flat_dev, L.total)) return -1;
   HIPCHECK(hipMemcpy(e->pack_idx, idx.data(), pos * sizeof(int32_t), hipMemcpyHostToDevice));
   NetView &n = e->nv;
   const float *P = e->packed;
-  n.w0 = (const f32x4 *)(P + p_w0); n.b0 = (const f32x4 *)(P + p_b0); n.w0o = (const f32x4 *)(P + p_w0o); n.b0o = P + p_b0o;
+  n.w0o = (const f32x4 *)(P + p_w0o); n.b0o = P + p_b0o;
   n.w1 = (const f32x4 *)(P + p_w1); n.b1 = (const f32x4 *)(P + p_b1); n.w2 = (const f32x4 *)(P + p_w2); n.b2 = P + p_b2;
   n.w3 = (const f32x4 *)(P + p_w3); n.b3 = (const f32x4 *)(P + p_b3); n.w4 = (const f32x4 *)(P + p_w4); n.b4 = P + p_b4;
   n.lnw = P + p_lnw; n.lnb = P + p_lnb;
   e->wstream = (const f32x4 *)(P + p_ws);
+  e->istream = (const f32x4 *)(P + p_is);
+  e->nst0 = nst0;
   n.ks0 = ks0; n.ks1 = ks1; n.ks3 = ks3; n.O = O; n.A = A; n.jtp = jtp;
   n.Sr = Sr; n.Sv = Sv; n.rmin = e->cfg.reward_support_min; n.vmin = e->cfg.value_support_min;
   n.no_transform = e->cfg.no_target_transform;
@@ -266,6 +302,30 @@ static int build_packing(mz_engine *e) {
     }                                                                                         \
   } while (0)
 
+
+// BaseNetwork.initial_inference for all B rows; selfplay: + synthetic observation, root expansion, Dirichlet
+// noise and first descent (mz_root.hip.h)
+template <int JTP>
+static int launch_root_j(mz_engine *e, const float *obs, bool selfplay, hipStream_t s) {
+  const dim3 grid(e->Bp / MZ_ROWS), block(256);
+  const double alpha = e->cfg.root_dirichlet_alpha, frac = e->cfg.root_exploration_fraction;
+#define MZ_ROOT_GO(G_, SP_)                                                                                     \
+  hipLaunchKernelGGL((k_root<JTP, G_, SP_>), grid, block, 0, s, e->nv, e->tv, obs, e->istream, e->nst0, e->sp, \
+                     (uint64_t)e->cfg.seed, alpha, frac)
+  if (!selfplay) MZ_ROOT_GO(4, false);
+  else switch (e->G) {
+    case 4: MZ_ROOT_GO(4, true); break;
+    case 8: MZ_ROOT_GO(8, true); break;
+    case 16: MZ_ROOT_GO(16, true); break;
+    default: MZ_ROOT_GO(32, true); break;
+  }
+#undef MZ_ROOT_GO
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
+static int launch_root(mz_engine *e, const float *obs, bool selfplay, hipStream_t s) {
+  return e->jtp == 1 ? launch_root_j<1>(e, obs, selfplay, s) : launch_root_j<2>(e, obs, selfplay, s);
+}
 
 template <int KS1, int JTP, int G, bool LT>
 static int launch_fused_lt(mz_engine *e, int num_simulations, int sims_done, hipStream_t s) {
@@ -464,8 +524,7 @@ int mz_initial_inference(mz_engine *e, const float *obs, void *stream) {
   if (!e || !obs) return fail("mz_initial_inference: null argument");
   if (!e->weights_set) return fail("mz_initial_inference: weights not set (call mz_set_weights)");
   hipStream_t s = (hipStream_t)stream;
-  NET_LAUNCH(k_net_initial, e->Bp / MZ_ROWS, s, e->nv, e->tv, obs);
-  HIPCHECK(hipGetLastError());
+  if (launch_root(e, obs, false, s)) return -1;
   e->root_ready = false;
   return 0;
 }

@@ -248,39 +248,6 @@ __device__ __forceinline__ void mz_net_recurrent(NetSmem &sm, const NetView &n, 
   mz_net_prediction<JTP>(sm, n, o, tid);
 }
 
-// FCNetwork.representation (networks.py:146-149) on the observation tile, then prediction:
-// BaseNetwork.initial_inference (networks.py:26-29).  obs rows are chunked through xT when
-// obs_dim > MZ_XT_ROWS.
-template <int JTP>
-__device__ __forceinline__ void mz_net_initial(NetSmem &sm, const NetView &n, const NetSink &o,
-                                               const float *obs, int rows, int tid) {
-  const int w = tid >> 6, lane = tid & 63;
-  {
-    f32x4 acc[8];
-    const int chunk_ks = MZ_XT_ROWS / 4;
-    for (int s0 = 0; s0 < n.ks0; s0 += chunk_ks) {
-      const int cnt = (n.ks0 - s0) < chunk_ks ? (n.ks0 - s0) : chunk_ks;
-      if (s0) __syncthreads();
-      for (int idx = tid; idx < 16 * cnt * 4; idx += 256) {
-        const int m = idx / (cnt * 4), kk = idx % (cnt * 4);
-        const int k = s0 * 4 + kk;
-        sm.xT[kk * 16 + m] = (m < rows && k < n.O) ? obs[(size_t)m * n.O + k] : 0.f;
-      }
-      __syncthreads();
-      mz_fc1<8>(n.w0, n.b0, sm.xT, n.ks0, s0, cnt, s0 == 0, w, lane, acc);
-    }
-    mz_relu<8>(acc);
-    f32x4 out[4];
-    mz_fc2<4, 0, 8>(n.w0o, acc, w, lane, out);
-    __syncthreads();
-    mz_combine<4>(sm, out, n.b0o, tid);
-  }
-  if (w == 0) mz_ln_relu(sm, n, 0, lane);
-  __syncthreads();
-  mz_store_hidden(sm, o, tid);
-  mz_net_prediction<JTP>(sm, n, o, tid);
-}
-
 // ------------------------------------------------------------------ kernels
 // recurrent inference for the leaves the last descent selected: gathers parent hidden state +
 // action per tree, writes hidden slot `out_slot` and the per-tree outputs in TreeView.
@@ -332,21 +299,6 @@ __global__ __launch_bounds__(256, 1) void k_net_recurrent_rows(NetView n, const 
   o.reward = reward + b0; o.value = value + b0; o.logits = logits + (size_t)b0 * n.A;
   o.rows = rows;
   mz_net_recurrent<JTP>(sm, n, o, tid);
-}
-
-// initial inference for B observations: hidden slot 0, root value, root logits
-template <int JTP>
-__global__ __launch_bounds__(256, 1) void k_net_initial(NetView n, TreeView t, const float *obs) {
-  __shared__ NetSmem sm;
-  const int tid = threadIdx.x;
-  const int b0 = blockIdx.x * MZ_ROWS;
-  const int rows = (t.B - b0) < 16 ? (t.B - b0) : 16;
-  const size_t per_tree = (size_t)(t.sims + 1) * MZ_HS;
-  NetSink o;
-  o.h_base = t.hpool + (size_t)b0 * per_tree; o.h_stride = per_tree; o.h_pad = 1;
-  o.reward = nullptr; o.value = t.root_value + b0; o.logits = t.root_logits + (size_t)b0 * t.A;
-  o.rows = 16;
-  mz_net_initial<JTP>(sm, n, o, obs + (size_t)b0 * n.O, rows < 0 ? 0 : rows, tid);
 }
 
 // packed[i] = idx[i] >= 0 ? flat[idx[i]] : 0   (weights -> MFMA operand order)

@@ -15,7 +15,8 @@ struct SelfplayState {
   int32_t *action;       // [B]
   double *child_visits;  // [B][A]
   double *root_value, *error;   // [B]
-  unsigned long long *move_dev;  // [1] moves completed (device-side counter, keys the RNG and the ring)
+  unsigned long long *movecnt;   // [B] moves completed by env b (all equal; per-env so that every thread reads and
+                                 // advances only its own counter): keys the RNG and the ring slot
   float *ring;           // [ring_moves][B][rec_floats]
   float *host_ring;      // pinned staging for drains (optional)
   unsigned long long moves_host, drained;
@@ -71,44 +72,14 @@ __global__ void k_dirichlet(TreeView t, const uint8_t *legal, double alpha, uint
   }
 }
 
-// Node(0) + root.expand + add_exploration_noise with the Dirichlet draw made in the kernel: lane a draws
-// Gamma(alpha) for action a, the group normalises (one launch instead of k_dirichlet + k_tree_root)
-template <int G>
-__global__ void k_tree_root_rng(TreeView t, double alpha, double frac, uint64_t seed,
-                                const unsigned long long *move_ptr, int env_offset) {
-  const int gt = blockIdx.x * blockDim.x + threadIdx.x;
-  const int b = gt / G, lane = gt % G;
-  if (b >= t.B) return;
-  const int A = t.A;
-  const uint64_t move = (uint64_t)*move_ptr - 1;       // k_env_obs has already advanced the counter
-  const double gam = lane < A ? mz_gamma(alpha, seed, (uint32_t)(env_offset + b), move, (uint32_t)lane) : 0.0;
-  double sum = 0.0;
-  for (int a = 0; a < A; ++a) sum += __shfl(gam, a, G);
-  if (lane < A) t.noise[(size_t)b * A + lane] = sum > 0.0 ? gam / sum : 1.0 / A;
-  __threadfence_block();
-  const uint32_t mask = (A >= 32) ? 0xFFFFFFFFu : ((1u << A) - 1u);
-  mz_tree_root<G>(t, b, lane, 1, mask, t.root_logits + (size_t)b * A, t.noise + (size_t)b * A, frac);
-  __threadfence_block();
-  mz_tree_select<G>(t, b, lane);
-}
-
-// current observation of every env (Game.get_observation(-1), game.py:117-121)
-__global__ void k_env_obs(SelfplayState sp, int B, int O, uint64_t seed) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0) *sp.move_dev += 1ull;     // move counter: this move's index is (*move_dev - 1) for the later kernels
-  if (i >= B * O) return;
-  const int b = i / O, k = i % O;
-  sp.obs[i] = mz_synth_obs_elem(seed, (uint32_t)(sp.env_offset + b), (uint32_t)sp.episode[b], (uint32_t)sp.t[b],
-                                (uint32_t)k);
-}
-
 // Game.apply (game.py:79-104) on the synthetic env + the experience record of this move.
 // record: obs[O], child_visits[A] (float32), root_value, error, reward, then int32 bit patterns:
 // action, done, step (pre-step), env_id, episode.
 __global__ void k_env_step_record(TreeView tv, SelfplayState sp, int B, int O, int A, uint64_t seed) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  const unsigned long long move = *sp.move_dev - 1ull;
+  const unsigned long long move = sp.movecnt[b];
+  sp.movecnt[b] = move + 1ull;
   // Config.select_action + store_search_statistics + root error for this tree (same code as mz_finalize)
   mz_finalize_tree(tv, b, sp.temp, nullptr, seed, move, sp.env_offset, sp.action, sp.child_visits, sp.root_value,
                    sp.error, nullptr);

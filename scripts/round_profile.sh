@@ -1,0 +1,17 @@
+#!/bin/bash
+# One gpurun call that refreshes every measured artifact of a round:
+#   scripts/round_profile.sh <tag>      (run on the GPU box from the repo root; outputs under gpurun_out/)
+# bench line, rocprofv3 kernel stats of the same command, the two PMC passes (separate runs, no trace domains), traffic.json
+TAG=${1:-r01}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+cd $R
+python3 bench.py > $O/bench_$TAG.json 2> $O/bench_$TAG.err
+tail -c 1500 $O/bench_$TAG.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$TAG -- python3 bench.py --steps 128 --warmup 16 --no-cpu-baseline > $O/bench_prof_$TAG.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$TAG -- python3 bench.py --steps 32 --warmup 4 --no-cpu-baseline > $O/pmc_fetch_$TAG.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_$TAG -- python3 bench.py --steps 32 --warmup 4 --no-cpu-baseline > $O/pmc_write_$TAG.log 2>&1
+python3 scripts/make_traffic.py $O/pmc_fetch_$TAG $O/pmc_write_$TAG $O/traffic_$TAG.json > /dev/null
+f=$(find $O/prof_$TAG -name "*kernel_stats.csv" | head -1); head -8 "$f"
