@@ -110,6 +110,7 @@ def main():
   rec = eng.rec_floats
   pinned = [torch.empty(CHUNK, B, rec, dtype=torch.float32).pin_memory() for _ in range(2)]
   events = [torch.cuda.Event(), torch.cuda.Event()]
+  copy_stream = torch.cuda.Stream(device)
 
   def run(moves, count):
     """moves in chunks; D2H + host ingest of chunk i-1 overlap the GPU work of chunk i."""
@@ -119,8 +120,8 @@ def main():
     while done < moves:
       m = min(CHUNK, moves - done)
       eng.selfplay_steps(m)
-      buf, n = eng.selfplay_drain(pinned[k & 1], m)
-      events[k & 1].record(torch.cuda.current_stream(device))
+      buf, n = eng.selfplay_drain(pinned[k & 1], m, copy_stream=copy_stream)   # overlaps the next chunk's moves
+      events[k & 1].record(copy_stream)
       if pending is not None:
         pb, pn, pe = pending
         pe.synchronize()

@@ -175,7 +175,10 @@ int mz_padded_envs(const mz_engine *e);
  * then as int32 bit patterns: action, done, step, env_id, episode.
  * mz_selfplay_drain copies the records produced since the last drain into `out` [host, pinned
  * preferred] asynchronously on `stream` and returns their count through *n_records after the
- * stream is synchronised by the caller (records are laid out move-major: [moves][B]).
+ * stream is synchronised by the caller (records are laid out move-major: [moves][B]).  `stream` may be a
+ * copy stream other than the one mz_selfplay_steps ran on, provided the caller orders it behind those steps
+ * (event): later moves then overlap the copy, the ring keeps them in different slots.
+ * mz_selfplay_steps issues up to 16 moves as one hipGraph launch (3 kernels per move: root, search, step+record).
  * stagger != 0: env i starts its first episode at t0 = hash(env id) % episode_len (uniform episode ends). */
 int mz_selfplay_reset(mz_engine *e, int episode_len, double temperature, int stagger, void *stream);
 int mz_selfplay_steps(mz_engine *e, int moves, void *stream);

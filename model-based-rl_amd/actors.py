@@ -165,12 +165,13 @@ class Actor(object):
     eng.selfplay_reset(cfg.episode_length, self._temperature(), stagger=True)
     pinned = [torch.empty(chunk, eng.B, eng.rec_floats, dtype=torch.float32).pin_memory() for _ in range(2)]
     events = [torch.cuda.Event(), torch.cuda.Event()]
+    copy_stream = torch.cuda.Stream(self.device)        # D2H of chunk i overlaps the moves of chunk i+1
     pending, k = None, 0
     sync_every = max(1, cfg.weight_sync_frequency)      # experiences per environment between weight pulls
     while self.training_step < cfg.training_steps and (max_moves is None or self.move_counter < max_moves):
       eng.selfplay_steps(chunk)
-      buf, n = eng.selfplay_drain(pinned[k & 1], chunk)
-      events[k & 1].record(torch.cuda.current_stream(self.device))
+      buf, n = eng.selfplay_drain(pinned[k & 1], chunk, copy_stream=copy_stream)
+      events[k & 1].record(copy_stream)
       if pending is not None:
         pending[2].synchronize()
         _call(self.replay_buffer, 'ingest_records', pending[0], pending[1], eng.B)

@@ -40,6 +40,8 @@ static int fail(const char *fmt, ...) {
     if (err_ != hipSuccess) return fail("%s: %s (%s:%d)", #x, hipGetErrorString(err_), __FILE__, __LINE__); \
   } while (0)
 
+#define MZ_GRAPH_MOVES 16    // most self-play moves captured into one hipGraph (3 kernel nodes per move)
+
 struct mz_engine {
   mz_config cfg;
   int B, Bp, A, O, sims, NN, PL, G, jtp;
@@ -59,7 +61,7 @@ struct mz_engine {
   int search_graph_sims = 0;
   bool use_graph = true;
   SelfplayState sp;
-  hipGraphExec_t move_graph = nullptr;
+  hipGraphExec_t move_graph[MZ_GRAPH_MOVES + 1] = {};   // [k] = hipGraph of k consecutive self-play moves
   const f32x4 *wstream = nullptr;   // per-wave cyclic weight stream for the fused search kernel
   const f32x4 *istream = nullptr;   // per-wave weight stream of the root kernel (initial inference)
   int nst0 = 0;                     // its run-time first-stage steps (obs_dim + 1 columns, two k-steps per step)
@@ -490,7 +492,7 @@ int mz_destroy(mz_engine *e) {
   if (!e) return 0;
   hipDeviceSynchronize();
   if (e->search_graph) hipGraphExecDestroy(e->search_graph);
-  if (e->move_graph) hipGraphExecDestroy(e->move_graph);
+  for (auto &g : e->move_graph) if (g) hipGraphExecDestroy(g);
   if (e->cap_stream) hipStreamDestroy(e->cap_stream);
   for (void *p : e->allocs) hipFree(p);
   if (e->sp.host_ring) hipHostFree(e->sp.host_ring);

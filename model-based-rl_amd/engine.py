@@ -251,14 +251,20 @@ class Engine(object):
   def selfplay_steps(self, moves):
     _abi.check(self.lib.mz_selfplay_steps(self._h, int(moves), self.stream), 'mz_selfplay_steps')
 
-  def selfplay_drain(self, out=None, max_moves=None):
+  def selfplay_drain(self, out=None, max_moves=None, copy_stream=None):
     """Asynchronous D2H of the records produced since the last drain into pinned memory; returns
-    (host tensor [n_moves, B, rec_floats], n_moves).  Synchronise the stream before reading."""
+    (host tensor [n_moves, B, rec_floats], n_moves).  Synchronise the stream before reading.
+    copy_stream: issue the copy there, ordered after the work queued on the current stream so far -- the next
+    moves on the current stream then overlap the copy (the ring keeps them in different slots)."""
     max_moves = self.ring_moves if max_moves is None else int(max_moves)
     if out is None:
       out = torch.empty(max_moves, self.B, self.rec_floats, dtype=torch.float32).pin_memory()
     n = C.c_int(0)
-    _abi.check(self.lib.mz_selfplay_drain(self._h, C.c_void_p(out.data_ptr()), max_moves, C.byref(n), self.stream),
+    stream = self.stream
+    if copy_stream is not None:
+      copy_stream.wait_stream(torch.cuda.current_stream(self.device))
+      stream = C.c_void_p(copy_stream.cuda_stream)
+    _abi.check(self.lib.mz_selfplay_drain(self._h, C.c_void_p(out.data_ptr()), max_moves, C.byref(n), stream),
                'mz_selfplay_drain')
     return out, n.value
 
