@@ -68,6 +68,7 @@ struct mz_engine {
   int ks1sel = 0;                   // fc1 k-steps of the fused kernel instantiation chosen for this A
   bool use_fused = true;
   bool use_lds_trees = true;
+  bool fuse_record = false;         // set by the self-play loop around its search launch: finalize + record in the kernel tail
   unsigned long long *prof_buf = nullptr;   // non-null only inside mz_search_phase_profile
 };
 
@@ -340,7 +341,7 @@ static int launch_fused_lt(mz_engine *e, int num_simulations, int sims_done, hip
       attr_set_prof = true;
     }
     hipLaunchKernelGGL((k_search_fused<KS1, JTP, G, LT, true>), dim3(e->Bp / MZ_ROWS), dim3(256), dyn, s, e->nv,
-                       e->tv, e->wstream, num_simulations, sims_done, e->prof_buf);
+                       e->tv, e->wstream, num_simulations, sims_done, e->prof_buf, e->sp, 0, (uint64_t)e->cfg.seed);
   } else {
     if (!attr_set) {
       HIPCHECK(hipFuncSetAttribute((const void *)k_search_fused<KS1, JTP, G, LT, false>,
@@ -348,7 +349,8 @@ static int launch_fused_lt(mz_engine *e, int num_simulations, int sims_done, hip
       attr_set = true;
     }
     hipLaunchKernelGGL((k_search_fused<KS1, JTP, G, LT, false>), dim3(e->Bp / MZ_ROWS), dim3(256), dyn, s, e->nv,
-                       e->tv, e->wstream, num_simulations, sims_done, (unsigned long long *)nullptr);
+                       e->tv, e->wstream, num_simulations, sims_done, (unsigned long long *)nullptr, e->sp,
+                       e->fuse_record ? 1 : 0, (uint64_t)e->cfg.seed);
   }
   HIPCHECK(hipGetLastError());
   return 0;

@@ -20,6 +20,7 @@
 #include "mz_common.h"
 #include "mz_net.hip.h"
 #include "mz_tree.hip.h"
+#include "mz_selfplay.hip.h"
 #include <utility>
 
 // compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N-1>{})
@@ -296,9 +297,54 @@ __host__ __device__ inline size_t mz_fused_dyn_lds(int sims, int NN, bool lt) {
   return b;
 }
 
+// What Actor.play_game does after MCTS.run (actors.py:147-158) for one tree of the self-play loop, by the tree's
+// own lanes at the end of the search launch while its nodes are still in LDS: Config.select_action,
+// Game.store_search_statistics, root error, Game.apply on the synthetic env and the experience record
+// (the stand-alone k_env_step_record does the same from the global pool).  Lane a stages child a's visit count
+// in LDS, lane 0 then runs the reference's sequential arithmetic (mz_sample_index) on the staged vector.
+template <int TL, bool LT>
+__device__ __forceinline__ void mz_finalize_record(const TreeView &t, const TreeMem<LT> &tm, const SelfplayState &sp,
+                                                   int b, int lane, uint32_t legal, uint64_t seed, double *stage,
+                                                   int O) {
+  const int A = t.A;
+  const bool ok = lane < A && ((legal >> lane) & 1u);
+  const int c = ok ? (int)tm.N[1 + lane] : 0;
+  int sumv = c;
+#pragma unroll
+  for (int off = TL / 2; off >= 1; off >>= 1) sumv += __shfl_xor(sumv, off, TL);
+  double *d = stage;
+  int *acts = (int *)(stage + 32);
+  const int pos = __popc(legal & ((1u << lane) - 1u));
+  if (ok) { d[pos] = (double)c; acts[pos] = lane; }
+  const unsigned long long move = sp.movecnt[b];
+  float *rec = sp.ring + ((size_t)(move % (unsigned long long)sp.ring_moves) * t.B + b) * sp.rec_floats;
+  for (int k = lane; k < O; k += TL) rec[k] = sp.obs[(size_t)b * O + k];
+  if (lane < A) rec[O + lane] = (float)(ok ? (double)c / (double)sumv : 0.0);
+  if (lane == 0) {
+    const int n = __popc(legal);
+    const int N0 = (int)tm.N[0];
+    const double rv = N0 == 0 ? 0.0 : tm.W[0] / (double)N0;
+    const double err = rv - (double)t.root_value[b];
+    const uint32_t env = (uint32_t)(sp.env_offset + b);
+    const mz_u4 r = mz_philox(seed, env, (uint32_t)move, (uint32_t)(move >> 32), MZ_RNG_ACTION << 24);
+    const int idx = mz_sample_index(d, n, sp.temp[b], mz_u01(r.x, r.y));
+    const int action = acts[idx];
+    const int tt = sp.t[b], ep = sp.episode[b];
+    const int done = (tt + 1 >= sp.episode_len) ? 1 : 0;
+    rec[O + A + 0] = (float)rv;
+    rec[O + A + 1] = (float)err;
+    rec[O + A + 2] = mz_synth_reward(seed, env, (uint32_t)ep, (uint32_t)tt);
+    int32_t *ri = (int32_t *)(rec + O + A + 3);
+    ri[0] = action; ri[1] = done; ri[2] = tt; ri[3] = (int32_t)env; ri[4] = ep;
+    if (done) { sp.t[b] = 0; sp.episode[b] = ep + 1; } else { sp.t[b] = tt + 1; }
+    sp.movecnt[b] = move + 1ull;
+  }
+}
+
 template <int KS1, int JTP, int G, bool LT, bool PROF>
 __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, const f32x4 *wstream, int nsims,
-                                                          int slot0, unsigned long long *prof) {
+                                                          int slot0, unsigned long long *prof, SelfplayState sp,
+                                                          int record, uint64_t seed) {
   using SC = FusedSched<KS1, JTP>;
   constexpr int NB = MZ_NB, NSTEPS = SC::NSTEPS, RS = SC::RS, NRING = SC::NRING;
   static_assert(RS <= SC::FC1, "resident steps must be fc1 steps of the dynamics stage");
@@ -573,6 +619,13 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
       }
     }
     STAMP(13)
+  }
+  if (record) {     // self-play loop: action, visit distribution, env step and experience record of this move
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) {
+      const int mt = tid / TL + i * (256 / TL);
+      if (b0 + mt < t.B) mz_finalize_record<TL, LT>(t, tm[i], sp, b0 + mt, tl, tr[i].legal, seed, (double *)red + mt * 96, n.O);
+    }
   }
   // per-tree scalars back to the pool (what export / a later mz_select continue from)
 #pragma unroll

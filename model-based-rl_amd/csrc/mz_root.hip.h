@@ -14,7 +14,7 @@
 #include "mz_fused.hip.h"
 #include "mz_selfplay.hip.h"
 
-#define MZ_ROOT_NB 4        // register ring depth of the unrolled part (steps)
+#define MZ_ROOT_NB 6       // register ring depth of the unrolled part (steps): the stream is L2-cold at every launch
 #define MZ_ROOT_KCH 256     // observation columns per LDS chunk (32 steps)
 #define MZ_ROOT_XS 260      // row stride of the observation tile (== 4 mod 32: rows 4 banks apart)
 
@@ -258,9 +258,7 @@ __global__ __launch_bounds__(256, 1) void k_root(NetView n, TreeView t, const fl
         if (tl < A) t.noise[(size_t)b * A + tl] = sum > 0.0 ? gam / sum : 1.0 / A;
         __threadfence_block();
         const uint32_t mask = (A >= 32) ? 0xFFFFFFFFu : ((1u << A) - 1u);
-        mz_tree_root<G>(t, b, tl, 1, mask, s_lg + mt * 32, t.noise + (size_t)b * A, frac);
-        __threadfence_block();
-        mz_tree_select<G>(t, b, tl);
+        mz_tree_root<G, true>(t, b, tl, 1, mask, s_lg + mt * 32, t.noise + (size_t)b * A, frac);
       }
     }
   }

@@ -4,6 +4,7 @@
 #pragma once
 #include "mz_common.h"
 #include "mz_rng.h"
+#include "mz_tree.hip.h"
 
 struct SelfplayState {
   int episode_len;

@@ -142,7 +142,10 @@ __device__ __forceinline__ void mz_tree_expand_backup(const TreeView &t, int b, 
 
 // Node(0) + root.expand(legal) + add_exploration_noise + MinMaxStats.reset
 // (actors.py:132,141-143; mcts.py:47-61,79).
-template <int G>
+// SELECT: also perform the first descent of MCTS.run from the registers.  At a fresh root (N = 0) select_child
+// ranks the children by (prior, action) (mcts.py:105-108) and the chosen child is a leaf, so the descent needs
+// nothing from memory: path = [0, 1 + a*], parent slot 0.
+template <int G, bool SELECT = false>
 __device__ __forceinline__ void mz_tree_root(const TreeView &t, int b, int lane, int to_play, uint32_t legal,
                                              const float *logits, const double *noise, double frac) {
   const int A = t.A;
@@ -165,6 +168,32 @@ __device__ __forceinline__ void mz_tree_root(const TreeView &t, int b, int lane,
     t.mn[b] = t.has_min ? t.min_bound : __builtin_inf();
     t.mx[b] = t.has_max ? t.max_bound : -__builtin_inf();
     t.plen[b] = 0;
+  }
+  if constexpr (SELECT) {
+    double score = 0.0;
+    int best = -1;
+    if (ok) {
+      score = p / sum;
+      if (noise) score = score * (1 - frac) + noise[lane] * frac;
+      best = lane;
+    }
+#pragma unroll
+    for (int off = G / 2; off >= 1; off >>= 1) {
+      const double os = __shfl_xor(score, off, G);
+      const int ob = __shfl_xor(best, off, G);
+      const bool take = ob >= 0 && (best < 0 || os > score || (os == score && ob > best));
+      if (take) { score = os; best = ob; }
+    }
+    if (lane == 0) {
+      int32_t *path = t.path + (size_t)b * t.PL;
+      path[0] = 0; path[1] = 1 + best;
+      t.plen[b] = 2;
+      t.leaf_tp[b] = (int8_t)(t.two_players ? -to_play : to_play);
+      t.leaf[b] = 1 + best;
+      t.slot[b] = 0;
+      t.act[b] = best;
+      t.depth[b] = 1;
+    }
   }
 }
 
@@ -459,6 +488,35 @@ __device__ inline double mz_np_sum(const double *a, int n) {
   return res;
 }
 
+// Config.select_action (config.py:70-81) on the n visit counts d[0..n) (as doubles, child insertion order) with
+// the uniform u that np.random.choice / the tie-break consumes; returns the index into the legal-action list.
+// d is overwritten.  d may live in LDS (the fused kernel stages it there) or in private memory.
+__device__ __forceinline__ int mz_sample_index(double *d, int n, double T, double u) {
+  int idx = 0;
+  if (T != 0.0) {
+    const double ex = 1 / T;
+    if (ex != 1.0) for (int i = 0; i < n; ++i) d[i] = pow(d[i], ex);
+    const double s = mz_np_sum(d, n);
+    for (int i = 0; i < n; ++i) d[i] = d[i] / s;
+    double c = 0.0;
+    for (int i = 0; i < n; ++i) { c = c + d[i]; d[i] = c; }
+    const double last = d[n - 1];
+    for (int i = 0; i < n; ++i) d[i] = d[i] / last;
+    while (idx < n && d[idx] <= u) ++idx;            // searchsorted(side='right')
+    if (idx >= n) idx = n - 1;
+  } else {
+    double m = -1.0;
+    int nt = 0;
+    for (int i = 0; i < n; ++i) m = d[i] > m ? d[i] : m;
+    for (int i = 0; i < n; ++i) nt += (d[i] == m);
+    int k = (int)(u * nt);
+    if (k >= nt) k = nt - 1;
+    for (int i = 0; i < n; ++i)
+      if (d[i] == m) { if (k == 0) { idx = i; break; } --k; }
+  }
+  return idx;
+}
+
 // Config.select_action (config.py:70-81) + Game.store_search_statistics (game.py:106-115) + root error
 // (actors.py:147-148).  One thread per tree (A <= 32 children, once per move).
 __device__ __forceinline__ void mz_finalize_tree(const TreeView &t, int b, const double *temperature,
@@ -494,28 +552,7 @@ __device__ __forceinline__ void mz_finalize_tree(const TreeView &t, int b, const
     mz_u4 r = mz_philox(seed, (uint32_t)(env_offset + b), (uint32_t)move, (uint32_t)(move >> 32), MZ_RNG_ACTION << 24);
     u = mz_u01(r.x, r.y);
   }
-  int idx = 0;
-  if (T != 0.0) {
-    const double ex = 1 / T;
-    if (ex != 1.0) for (int i = 0; i < n; ++i) d[i] = pow(d[i], ex);
-    const double s = mz_np_sum(d, n);
-    for (int i = 0; i < n; ++i) d[i] = d[i] / s;
-    double c = 0.0;
-    for (int i = 0; i < n; ++i) { c = c + d[i]; d[i] = c; }
-    const double last = d[n - 1];
-    for (int i = 0; i < n; ++i) d[i] = d[i] / last;
-    while (idx < n && d[idx] <= u) ++idx;            // searchsorted(side='right')
-    if (idx >= n) idx = n - 1;
-  } else {
-    double m = -1.0;
-    int nt = 0;
-    for (int i = 0; i < n; ++i) m = d[i] > m ? d[i] : m;
-    for (int i = 0; i < n; ++i) nt += (d[i] == m);
-    int k = (int)(u * nt);
-    if (k >= nt) k = nt - 1;
-    for (int i = 0; i < n; ++i)
-      if (d[i] == m) { if (k == 0) { idx = i; break; } --k; }
-  }
+  const int idx = mz_sample_index(d, n, T, u);
   action[b] = acts[idx];
 }
 
