@@ -171,6 +171,50 @@ def test_device_selfplay_records_and_sharding():
   eng2.close()
 
 
+@pytest.mark.parametrize('A,sims,T,temp', [(4, 30, 5, 1.0), (6, 12, 4, 0.5), (3, 9, 3, 0.0), (18, 8, 3, 1.0)])
+def test_selfplay_loop_equals_stepwise_abi(A, sims, T, temp):
+  """The fused per-move kernels of the device loop (root kernel with in-kernel observation + Dirichlet + first
+  descent; search kernel whose tail samples the action, steps the env and writes the record) against the
+  stepwise C ABI on the same engine configuration: mz_initial_inference -> mz_root_prepare(device RNG) ->
+  mz_search -> mz_finalize, fed with mz_synth_obs.  Same device functions, same keys => every record field is
+  bit-identical."""
+  import torch
+  from model_based_rl_amd.engine import Engine
+  from model_based_rl_amd.networks import FCNetwork
+  from model_based_rl_amd.engine import flatten_weights
+  O, B, moves = 8, 48, 7
+  torch.manual_seed(5)
+  cfg = types.SimpleNamespace(value_support=(-15, 15), reward_support=(-15, 15), no_support=False,
+                              no_target_transform=False)
+  net = FCNetwork(O, A, torch.device('cpu'), cfg)
+  flat = flatten_weights(net.state_dict())
+  loop = Engine(B, O, A, sims, seed=99, env_id_offset=7)
+  loop.set_weights(flat)
+  loop.selfplay_reset(T, temp, stagger=False)
+  loop.selfplay_steps(moves)
+  buf, n = loop.selfplay_drain()
+  torch.cuda.synchronize()
+  rec = buf[:n].numpy().copy()
+  loop.close()
+  ints = rec[..., O + A + 3:].view(np.int32)
+
+  step = Engine(B, O, A, sims, seed=99, env_id_offset=7)
+  step.set_weights(flat)
+  for m in range(moves):
+    obs = np.stack([step.synth_obs(7 + b, m // T, m % T)[0] for b in range(B)])
+    assert np.array_equal(rec[m, :, :O], obs)
+    step.initial_inference(torch.from_numpy(obs).cuda())
+    step.root_prepare(None, None, None, device_rng=True, move=m)
+    step.search()
+    out = step.finalize(temp, None, move=m)
+    torch.cuda.synchronize()
+    assert np.array_equal(ints[m, :, 0], out['action'].cpu().numpy())
+    assert np.array_equal(rec[m, :, O:O + A], out['child_visits'].cpu().numpy().astype(np.float32))
+    assert np.array_equal(rec[m, :, O + A], out['root_value'].cpu().numpy().astype(np.float32))
+    assert np.array_equal(rec[m, :, O + A + 1], out['error'].cpu().numpy().astype(np.float32))
+  step.close()
+
+
 def test_train_driver_selfplay_only():
   from model_based_rl_amd import train
   thr = train.main(['--environment', 'LunarLander-v2', '--num_envs', '64', '--num_simulations', '8', '--seed', '3',
