@@ -183,7 +183,8 @@ static int build_packing(mz_engine *e) {
   const size_t p_w1f = seg((size_t)4 * 4 * ks1f * 256), p_w3f = seg((size_t)4 * 4 * ks3f * 256);
   const int nj2 = 2 + jtp;
   const int real_steps = ks1f + 12 + ks3f + 2 * nj2;
-  const int nsteps = MZ_RS + (real_steps - MZ_RS + MZ_NB - 1) / MZ_NB * MZ_NB;   // FusedSched::NSTEPS
+  const int rs = mz_fused_rs(ks1f, jtp);
+  const int nsteps = rs + (real_steps - rs + MZ_NB - 1) / MZ_NB * MZ_NB;   // FusedSched::NSTEPS
   const size_t p_ws = seg((size_t)4 * nsteps * 4 * 256);
   // root kernel stream: [nst0 first-stage steps][8 representation-out][13 prediction fc1][2*nj2 prediction out]
   const int nst0 = mz_root_nst0(O), nroot = nst0 + 8 + ks3f + 2 * nj2;

@@ -34,8 +34,10 @@ __device__ __forceinline__ void mz_static_for(F &&f) {
 }
 
 #define MZ_NB 5      // register ring depth in steps (prefetch distance NB-1 steps)
-#define MZ_RS 10     // steps of the stream held in registers (AGPRs) across all simulations: less L2 traffic and
-                     // no load issue in those steps (a streamed step runs at ~37 cycles/MFMA, a resident one at 32)
+// steps of the stream held in registers (AGPRs) across all simulations: less L2 traffic and no load issue in those
+// steps (a streamed step runs at ~37 cycles/MFMA, a resident one at 32).  As many as the register file takes
+// without scratch: the wide-action instantiations (two tree passes, two policy tiles) have fewer to spare.
+__host__ __device__ constexpr int mz_fused_rs(int ks1, int jtp) { return jtp > 1 ? 8 : (ks1 > 16 ? 10 : (ks1 > 14 ? 11 : 12)); }
 #define MZ_XE 36     // row stride of the x-tile extension [one-hot(action) | 1 | 0 ...] (k >= 50)
 
 // per-simulation schedule (in steps of 16 MFMAs per wave)
@@ -46,7 +48,7 @@ struct FusedSched {
   static constexpr int P1 = (MZ_H + 1 + 3) / 4; // prediction fc1: K = 51 -> 13 steps
   static constexpr int P2 = 2 * (2 + JTP);      // value (2 tiles) + policy (JTP tiles)
   static constexpr int REAL = FC1 + FC2 + P1 + P2;
-  static constexpr int RS = MZ_RS;              // the first RS steps stay resident in registers for the whole launch
+  static constexpr int RS = mz_fused_rs(KS1, JTP);            // the first RS steps stay resident in registers for the whole launch
   static constexpr int NRING = (REAL - RS + MZ_NB - 1) / MZ_NB * MZ_NB;   // streamed steps, padded to the ring depth
   static constexpr int NSTEPS = RS + NRING;     // schedule length incl. padding steps (prefetch only)
 };
