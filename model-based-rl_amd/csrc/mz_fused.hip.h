@@ -225,49 +225,81 @@ __device__ __forceinline__ float mz_support_to_scalar16(const float *fin, int ro
   return v;
 }
 
-// relu(LayerNorm) of fin rows [row0,row0+50), column m -> row-major tile xR[m][0..51]; 8 lanes per column
-__device__ __forceinline__ void sln_relu8(const float *fin, float *xR, const float *lnw, const float *lnb, int row0,
-                                          int m, int q) {
-  float s = 0.f;
-  for (int f = q; f < MZ_H; f += 8) s += fin[(row0 + f) * 16 + m];
+// ---- epilogues straight from the split-K partials (no combined tile, one barrier less per epilogue).
+// Every wave leaves its JTOT partial tiles in LDS as one 16-byte vector per lane and tile (red4[(w*6+jt)*64+lane]);
+// a consumer lane then adds up bias + the four waves' partials of exactly the outputs it needs, in wave order.
+template <int JTOT>
+__device__ __forceinline__ void mz_partials_out(float *red, const f32x4 (&out)[JTOT], int tid) {
+  const int w = tid >> 6, lane = tid & 63;
+  f32x4 *red4 = (f32x4 *)red;
+#pragma unroll
+  for (int jt = 0; jt < JTOT; ++jt) red4[(w * 6 + jt) * 64 + lane] = out[jt];
+  mz_bar();
+}
+// output row n (= 16*jt + 4*g + r), column m
+__device__ __forceinline__ float mz_comb_at(const float *red, const float *bias, int n, int m) {
+  const float *p = red + (((n >> 4) * 64 + ((n >> 2) & 3) * 16 + m) << 2) + (n & 3);
+  float s = bias[n];
+  s += p[0 * 6 * 256]; s += p[1 * 6 * 256]; s += p[2 * 6 * 256]; s += p[3 * 6 * 256];
+  return s;
+}
+
+// relu(LayerNorm) of output rows [row0,row0+50), column m -> row-major tile xR[m][0..51]; 8 lanes per column
+__device__ __forceinline__ void sln_relu8p(const float *red, const float *bias, float *xR, const float *lnw,
+                                           const float *lnb, int row0, int m, int q) {
+  float x[7], s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int f = q + 8 * i;
+    x[i] = f < MZ_H ? mz_comb_at(red, bias, row0 + f, m) : 0.f;
+    s += x[i];
+  }
   s = mz_sum8(s);
   const float mean = s / (float)MZ_H;
   float v = 0.f;
-  for (int f = q; f < MZ_H; f += 8) { const float d = fin[(row0 + f) * 16 + m] - mean; v += d * d; }
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const float d = (q + 8 * i < MZ_H) ? x[i] - mean : 0.f;
+    v += d * d;
+  }
   v = mz_sum8(v);
   const float rstd = 1.0f / sqrtf(v / (float)MZ_H + 1e-5f);
-  for (int f = q; f < MZ_HS; f += 8) {
-    float y = 0.f;
-    if (f < MZ_H) {
-      y = (fin[(row0 + f) * 16 + m] - mean) * rstd * lnw[f] + lnb[f];
-      y = fmaxf(y, 0.f);
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int f = q + 8 * i;
+    if (f < MZ_HS) {
+      float y = 0.f;
+      if (f < MZ_H) y = fmaxf((x[i] - mean) * rstd * lnw[f] + lnb[f], 0.f);
+      xR[m * MZ_HS + f] = y;
     }
-    xR[m * MZ_HS + f] = y;
   }
 }
 
-// Config.inverse_transform (config.py:27-33), column m, 8 lanes per column, S <= 32 bins
-__device__ __forceinline__ float mz_support_to_scalar8(const float *fin, int row0, int S, int smin, int no_transform,
-                                                       int m, int q) {
-  float x[4], mx = -__builtin_inff();
+// Config.inverse_transform (config.py:27-33) of output rows [row0,row0+S), column m; L lanes per column (8 or 16),
+// S <= 32 bins
+template <int L>
+__device__ __forceinline__ float mz_support_to_scalar_p(const float *red, const float *bias, int row0, int S, int smin,
+                                                        int no_transform, int m, int q) {
+  constexpr int NB = 32 / L;
+  float x[NB], mx = -__builtin_inff();
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int bin = q + 8 * i;
-    x[i] = bin < S ? fin[(row0 + bin) * 16 + m] : -__builtin_inff();
+  for (int i = 0; i < NB; ++i) {
+    const int bin = q + L * i;
+    x[i] = bin < S ? mz_comb_at(red, bias, row0 + bin, m) : -__builtin_inff();
     mx = fmaxf(mx, x[i]);
   }
-  mx = mz_max8(mx);
-  float e[4], sum = 0.f;
+  mx = (L == 8) ? mz_max8(mx) : mz_max16(mx);
+  float e[NB], sum = 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    e[i] = (q + 8 * i < S) ? expf(x[i] - mx) : 0.f;
+  for (int i = 0; i < NB; ++i) {
+    e[i] = (q + L * i < S) ? expf(x[i] - mx) : 0.f;
     sum += e[i];
   }
-  sum = mz_sum8(sum);
+  sum = (L == 8) ? mz_sum8(sum) : mz_sum16(sum);
   float v = 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) v += (float)(smin + q + 8 * i) * (e[i] / sum);
-  v = mz_sum8(v);
+  for (int i = 0; i < NB; ++i) v += (float)(smin + q + L * i) * (e[i] / sum);
+  v = (L == 8) ? mz_sum8(v) : mz_sum16(v);
   if (!no_transform) {
     const float sgn = (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f);
     float t = (fabsf(v) + 1.f) + 0.001f;
@@ -279,7 +311,7 @@ __device__ __forceinline__ float mz_support_to_scalar8(const float *fin, int row
 }
 
 #define MZ_FUSED_MAXPL 64   // search-path slots per tree kept in LDS: num_simulations + 2 <= 64
-#define MZ_FUSED_LDS_FLOATS (16 * MZ_HS + 4 * 6 * 256 + 96 * 16 + 16 + 16 + 16 * 32 + 96 + 64 + 64 + 64 + 2 * 16 * MZ_XE + 16 * MZ_FUSED_MAXPL)
+#define MZ_FUSED_LDS_FLOATS (16 * MZ_HS + 4 * 6 * 256 + 16 + 16 + 16 * 32 + 96 + 64 + 64 + 64 + 2 * 16 * MZ_XE + 16 * MZ_FUSED_MAXPL)
 
 // PROF: diagnostic build only (mz_search_phase_profile): per-wave cycle totals of each phase of the loop.
 #define MZ_NPHASE 14
@@ -365,8 +397,7 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
   int8_t *l_TP = (int8_t *)(l_E + 16 * t.NN);
   float *xR = smem;                       // [16][MZ_HS] x tile, row-major
   float *red = xR + 16 * MZ_HS;           // split-K partials [4][6][4][64]
-  float *fin = red + 4 * 6 * 256;         // combined outputs [96][16]
-  float *s_val = fin + 96 * 16;
+  float *s_val = red + 4 * 6 * 256;
   float *s_rew = s_val + 16;
   float *s_lg = s_rew + 16;               // [16][32]
   float *s_b2 = s_lg + 16 * 32;
@@ -556,13 +587,18 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
         if constexpr (s == E_FC2 - 1) {
           mz_mfma_fence<6>(out2);
           STAMP(3)
-          scombine<6>(red, fin, out2, s_b2, tid);
+          mz_partials_out<6>(red, out2, tid);
           STAMP(4)
-          {   // every wave: its 4 trees, 16 lanes per tree: LayerNorm+ReLU -> xR, reward scalar -> s_rew
-            const int col = 4 * w + (lane >> 4), q = lane & 15;
-            sln_relu16(fin, xR, s_lnw, s_lnb, 32, col, q);
-            const float r = mz_support_to_scalar16(fin, 0, n.Sr, n.rmin, n.no_transform, col, q);
-            if (q == 0) s_rew[col] = r;
+          // waves 0,1: LayerNorm+ReLU of 8 trees each -> xR; waves 2,3: reward scalar of 8 trees each -> s_rew
+          // (8 lanes per tree; the two chains run side by side on different SIMDs)
+          {
+            const int col = 8 * (w & 1) + (lane >> 3), q = lane & 7;
+            if (w < 2) {
+              sln_relu8p(red, s_b2, xR, s_lnw, s_lnb, 32, col, q);
+            } else {
+              const float r = mz_support_to_scalar_p<8>(red, s_b2, 0, n.Sr, n.rmin, n.no_transform, col, q);
+              if (q == 0) s_rew[col] = r;
+            }
           }
           mz_bar();
           STAMP(5)
@@ -590,13 +626,13 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
         if constexpr (s == E_P2 - 1) {
           mz_mfma_fence<NJ2>(out4);
           STAMP(7)
-          scombine<NJ2>(red, fin, out4, s_b4, tid);
+          mz_partials_out<NJ2>(red, out4, tid);
           STAMP(8)
-          {   // every wave: value scalar + policy logits of its 4 trees
+          {   // every wave: value scalar + policy logits of its 4 trees (the trees its tree lanes own)
             const int col = 4 * w + (lane >> 4), q = lane & 15;
-            const float v = mz_support_to_scalar16(fin, 0, n.Sv, n.vmin, n.no_transform, col, q);
+            const float v = mz_support_to_scalar_p<16>(red, s_b4, 0, n.Sv, n.vmin, n.no_transform, col, q);
             if (q == 0) s_val[col] = v;
-            for (int a = q; a < n.A; a += 16) s_lg[col * 32 + a] = fin[(32 + a) * 16 + col];
+            for (int a = q; a < n.A; a += 16) s_lg[col * 32 + a] = mz_comb_at(red, s_b4, 32 + a, col);
           }
         }
       }

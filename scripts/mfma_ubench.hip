@@ -22,7 +22,9 @@ __global__ __launch_bounds__(512, 2) void k(const f32x4 *w, float *out, unsigned
       *(const __attribute__((address_space(1))) f32x4 *)((const __attribute__((address_space(1))) char *)wb + \
                                                            (size_t)((((it_) & 31) * 4 + p) * 1024) + lo);
   f32x4 b[4], c[4], d[4];
-  if (MODE >= 2) { LD(b, 0) LD(c, 1) LD(d, 2) }
+  float junk[8];
+  for (int i = 0; i < 8; ++i) junk[i] = x + i;
+  if (MODE >= 2 && MODE <= 4) { LD(b, 0) LD(c, 1) LD(d, 2) }
   if (MODE == 4) {
     // loads from inline asm, one after every 4th MFMA; manual counted vmcnt
     const __attribute__((address_space(1))) char *gb = (const __attribute__((address_space(1))) char *)wb;
@@ -40,7 +42,7 @@ __global__ __launch_bounds__(512, 2) void k(const f32x4 *w, float *out, unsigned
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   } else
   for (int it = 0; it < iters; it += 4) {
-    if (MODE >= 2) {     // ring of 4 buffers, loads 3 steps ahead, 4 loads per 16 MFMAs
+    if (MODE >= 2 && MODE <= 3) {     // ring of 4 buffers, loads 3 steps ahead, 4 loads per 16 MFMAs
       _Pragma("unroll") for (int t = 0; t < 16; ++t) MFMA(acc[t], a[t >> 2][t & 3], x);
       LD(a, it + 4)
       if (MODE == 3) x += 1.0f;
@@ -51,6 +53,14 @@ __global__ __launch_bounds__(512, 2) void k(const f32x4 *w, float *out, unsigned
       _Pragma("unroll") for (int t = 0; t < 16; ++t) MFMA(acc[t], d[t >> 2][t & 3], x);
       LD(d, it + 7)
     } else if (MODE == 4) { }
+    else if (MODE >= 5) {   // resident operands + (MODE-4) pinned VALU ops behind every MFMA: does VALU hide in the MFMA shadow?
+      for (int u = 0; u < 4; ++u) {
+        _Pragma("unroll") for (int t = 0; t < 16; ++t) {
+          MFMA(acc[t], a[t >> 2][t & 3], x);
+          _Pragma("unroll") for (int v = 0; v < MODE - 4; ++v) asm volatile("v_max_f32 %0, %0, %0" : "+v"(junk[(t + v) & 7]));
+        }
+      }
+    }
     else if (MODE == 1) {
       for (int u = 0; u < 4; ++u) { _Pragma("unroll") for (int t = 0; t < 16; ++t) MFMAV(acc[t], a[t >> 2][t & 3], x); }
     } else {
@@ -60,6 +70,7 @@ __global__ __launch_bounds__(512, 2) void k(const f32x4 *w, float *out, unsigned
   unsigned long long t1 = __builtin_amdgcn_s_memtime();
   float r = 0;
   for (int i = 0; i < 16; ++i) r += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  if (MODE >= 5) for (int i = 0; i < 8; ++i) r += junk[i];
   out[threadIdx.x + blockIdx.x * 512] = r;
   if (lane == 0) cyc[blockIdx.x * 8 + (threadIdx.x >> 6)] = t1 - t0;
 }
@@ -70,14 +81,18 @@ int main() {
   hipMalloc(&out, 256 * 512 * 4); hipMemset(out, 0, 256 * 512 * 4);
   hipMalloc(&cyc, 2048 * 8);
   const int iters = 2000;
-  for (int nthreads = 256; nthreads <= 512; nthreads += 256)
-  for (int mode = 0; mode < 5; ++mode) {
+  for (int nthreads = 256; nthreads <= 256; nthreads += 256)
+  for (int mode = 0; mode < 9; ++mode) {
     for (int rep = 0; rep < 2; ++rep) {
       if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(256), dim3(nthreads), 0, 0, w, out, cyc, iters);
       if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(256), dim3(nthreads), 0, 0, w, out, cyc, iters);
       if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(256), dim3(nthreads), 0, 0, w, out, cyc, iters);
       if (mode == 3) hipLaunchKernelGGL(k<3>, dim3(256), dim3(nthreads), 0, 0, w, out, cyc, iters);
       if (mode == 4) hipLaunchKernelGGL(k<4>, dim3(256), dim3(nthreads), 0, 0, w, out, cyc, iters);
+      if (mode == 5) hipLaunchKernelGGL(k<5>, dim3(256), dim3(nthreads), 0, 0, w, out, cyc, iters);
+      if (mode == 6) hipLaunchKernelGGL(k<6>, dim3(256), dim3(nthreads), 0, 0, w, out, cyc, iters);
+      if (mode == 7) hipLaunchKernelGGL(k<8>, dim3(256), dim3(nthreads), 0, 0, w, out, cyc, iters);
+      if (mode == 8) hipLaunchKernelGGL(k<12>, dim3(256), dim3(nthreads), 0, 0, w, out, cyc, iters);
       hipDeviceSynchronize();
     }
     unsigned long long h[2048];
