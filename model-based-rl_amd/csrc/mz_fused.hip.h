@@ -244,18 +244,21 @@ __device__ __forceinline__ float mz_comb_at(const float *red, const float *bias,
   return s;
 }
 
-// relu(LayerNorm) of output rows [row0,row0+50), column m -> row-major tile xR[m][0..51]; 8 lanes per column
+// relu(LayerNorm) of output rows [row0,row0+50), column m -> row-major tile xR[m][0..51]; 8 lanes per column.
+// All LDS reads are unconditional (rows up to row0+55 exist and are exact zeros: zero weights, zero bias, zero
+// LayerNorm affine) so that they issue as one batch instead of one exec-masked block each.
 __device__ __forceinline__ void sln_relu8p(const float *red, const float *bias, float *xR, const float *lnw,
                                            const float *lnb, int row0, int m, int q) {
-  float x[7], s = 0.f;
+  float x[7], gw[7], gb[7], s = 0.f;
 #pragma unroll
   for (int i = 0; i < 7; ++i) {
-    const int f = q + 8 * i;
-    x[i] = f < MZ_H ? mz_comb_at(red, bias, row0 + f, m) : 0.f;
+    x[i] = mz_comb_at(red, bias, row0 + q + 8 * i, m);
+    gw[i] = lnw[q + 8 * i];
+    gb[i] = lnb[q + 8 * i];
     s += x[i];
   }
   s = mz_sum8(s);
-  const float mean = s / (float)MZ_H;
+  const float mean = s * (1.0f / (float)MZ_H);
   float v = 0.f;
 #pragma unroll
   for (int i = 0; i < 7; ++i) {
@@ -263,20 +266,17 @@ __device__ __forceinline__ void sln_relu8p(const float *red, const float *bias, 
     v += d * d;
   }
   v = mz_sum8(v);
-  const float rstd = 1.0f / sqrtf(v / (float)MZ_H + 1e-5f);
+  const float rstd = 1.0f / sqrtf(v * (1.0f / (float)MZ_H) + 1e-5f);
 #pragma unroll
   for (int i = 0; i < 7; ++i) {
     const int f = q + 8 * i;
-    if (f < MZ_HS) {
-      float y = 0.f;
-      if (f < MZ_H) y = fmaxf((x[i] - mean) * rstd * lnw[f] + lnb[f], 0.f);
-      xR[m * MZ_HS + f] = y;
-    }
+    const float y = fmaxf((x[i] - mean) * rstd * gw[i] + gb[i], 0.f);     // f >= 50: affine is 0 -> 0
+    if (f < MZ_HS) xR[m * MZ_HS + f] = y;
   }
 }
 
 // Config.inverse_transform (config.py:27-33) of output rows [row0,row0+S), column m; L lanes per column (8 or 16),
-// S <= 32 bins
+// S <= 32 bins (rows row0..row0+31 exist; the reads are unconditional, see above)
 template <int L>
 __device__ __forceinline__ float mz_support_to_scalar_p(const float *red, const float *bias, int row0, int S, int smin,
                                                         int no_transform, int m, int q) {
@@ -284,21 +284,22 @@ __device__ __forceinline__ float mz_support_to_scalar_p(const float *red, const 
   float x[NB], mx = -__builtin_inff();
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
-    const int bin = q + L * i;
-    x[i] = bin < S ? mz_comb_at(red, bias, row0 + bin, m) : -__builtin_inff();
+    const float raw = mz_comb_at(red, bias, row0 + q + L * i, m);
+    x[i] = (q + L * i < S) ? raw : -__builtin_inff();
     mx = fmaxf(mx, x[i]);
   }
   mx = (L == 8) ? mz_max8(mx) : mz_max16(mx);
   float e[NB], sum = 0.f;
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
-    e[i] = (q + L * i < S) ? expf(x[i] - mx) : 0.f;
+    e[i] = expf(x[i] - mx);          // exp(-inf) = 0 for the padding bins
     sum += e[i];
   }
   sum = (L == 8) ? mz_sum8(sum) : mz_sum16(sum);
+  const float rs = 1.0f / sum;
   float v = 0.f;
 #pragma unroll
-  for (int i = 0; i < NB; ++i) v += (float)(smin + q + L * i) * (e[i] / sum);
+  for (int i = 0; i < NB; ++i) v += (float)(smin + q + L * i) * (e[i] * rs);
   v = (L == 8) ? mz_sum8(v) : mz_sum16(v);
   if (!no_transform) {
     const float sgn = (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f);
