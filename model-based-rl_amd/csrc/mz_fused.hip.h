@@ -226,81 +226,113 @@ __device__ __forceinline__ float mz_support_to_scalar16(const float *fin, int ro
 }
 
 // ---- epilogues straight from the split-K partials (no combined tile, one barrier less per epilogue).
-// Every wave leaves its JTOT partial tiles in LDS as one 16-byte vector per lane and tile (red4[(w*6+jt)*64+lane]);
-// a consumer lane then adds up bias + the four waves' partials of exactly the outputs it needs, in wave order.
+// Every wave leaves its JTOT partial tiles in LDS as one 16-byte vector per lane and tile: the vector of lane
+// (g, m) = rows 16jt+4g..+3 of column m sits at red4[(w*6+jt)*64 + 16g + (m ^ ((g + 4(jt&1)) & 7))]; a consumer
+// lane then adds up bias + the four waves' partials of exactly the outputs it needs, in wave order.  The XOR
+// spreads the eight row quads a column's consumer lanes fetch in one instruction over the eight 16-byte bank
+// groups (unswizzled they all fall into bank group m mod 8: an 8-way conflict on every read).
 template <int JTOT>
 __device__ __forceinline__ void mz_partials_out(float *red, const f32x4 (&out)[JTOT], int tid) {
   const int w = tid >> 6, lane = tid & 63;
   f32x4 *red4 = (f32x4 *)red;
 #pragma unroll
-  for (int jt = 0; jt < JTOT; ++jt) red4[(w * 6 + jt) * 64 + lane] = out[jt];
+  for (int jt = 0; jt < JTOT; ++jt) red4[(w * 6 + jt) * 64 + (lane ^ (((lane >> 4) + 4 * (jt & 1)) & 7))] = out[jt];
   mz_bar();
 }
-// output row n (= 16*jt + 4*g + r), column m
-__device__ __forceinline__ float mz_comb_at(const float *red, const float *bias, int n, int m) {
-  const float *p = red + (((n >> 4) * 64 + ((n >> 2) & 3) * 16 + m) << 2) + (n & 3);
-  float s = bias[n];
-  s += p[0 * 6 * 256]; s += p[1 * 6 * 256]; s += p[2 * 6 * 256]; s += p[3 * 6 * 256];
+// The epilogue lanes fetch their inputs as 16-byte vectors (four consecutive output rows = one lane's slice of a
+// partial tile) with ds_read_b128 issued from inline asm, all of them back to back, and wait ONCE.  Left to the
+// compiler (VGPR budget exhausted in this kernel) every read was followed by its own s_waitcnt lgkmcnt(0): ~25
+// exposed LDS round trips per epilogue.
+// (One address register per base + immediate offsets: a separate "v" address per asm read would be loop
+// invariant, get hoisted out of the simulation loop and spill.)
+template <int OFF>
+__device__ __forceinline__ void mz_lds128(f32x4 &dst, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+__device__ __forceinline__ unsigned mz_lds_addr(const void *p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) void *)p;
+}
+struct MzQuad { f32x4 b, p0, p1, p2, p3; };      // bias + the four waves' partials of rows n0..n0+3, column m
+// LDS byte address of wave 0's partial vector of rows n0..n0+3 (n0 % 4 == 0), column m
+__device__ __forceinline__ unsigned mz_quad_addr(const float *red, int n0, int m) {
+  const int jt = n0 >> 4, g = (n0 >> 2) & 3;
+  return mz_lds_addr((const f32x4 *)red + (jt * 64 + g * 16 + (m ^ ((g + 4 * (jt & 1)) & 7))));
+}
+template <int BOFF>
+__device__ __forceinline__ void mz_quad_issue(MzQuad &o, unsigned paddr, unsigned baddr) {
+  mz_lds128<BOFF>(o.b, baddr);
+  mz_lds128<0>(o.p0, paddr); mz_lds128<6 * 64 * 16>(o.p1, paddr); mz_lds128<12 * 64 * 16>(o.p2, paddr);
+  mz_lds128<18 * 64 * 16>(o.p3, paddr);
+}
+__device__ __forceinline__ f32x4 mz_quad_sum(const MzQuad &o) {      // same order as the tile-wide combine
+  f32x4 s = o.b;
+  s += o.p0; s += o.p1; s += o.p2; s += o.p3;
   return s;
 }
+#define MZ_Q(o) "+v"(o.b), "+v"(o.p0), "+v"(o.p1), "+v"(o.p2), "+v"(o.p3)
 
-// relu(LayerNorm) of output rows [row0,row0+50), column m -> row-major tile xR[m][0..51]; 8 lanes per column.
-// All LDS reads are unconditional (rows up to row0+55 exist and are exact zeros: zero weights, zero bias, zero
-// LayerNorm affine) so that they issue as one batch instead of one exec-masked block each.
+// relu(LayerNorm) of output rows [row0,row0+50), column m -> row-major tile xR[m][0..51]; 8 lanes per column,
+// lane q owns the feature quads q and q+8.  Rows up to row0+63 exist and are exact zeros beyond 50 (zero
+// weights, bias and LayerNorm affine), so nothing is conditional but the variance term and the last store.
 __device__ __forceinline__ void sln_relu8p(const float *red, const float *bias, float *xR, const float *lnw,
                                            const float *lnb, int row0, int m, int q) {
-  float x[7], gw[7], gb[7], s = 0.f;
-#pragma unroll
-  for (int i = 0; i < 7; ++i) {
-    x[i] = mz_comb_at(red, bias, row0 + q + 8 * i, m);
-    gw[i] = lnw[q + 8 * i];
-    gb[i] = lnb[q + 8 * i];
-    s += x[i];
-  }
+  MzQuad A, B;
+  f32x4 wA, wB, bA, bB;
+  const unsigned ba = mz_lds_addr(bias + row0 + 4 * q), wa = mz_lds_addr(lnw + 4 * q);
+  mz_quad_issue<0>(A, mz_quad_addr(red, row0 + 4 * q, m), ba);
+  mz_quad_issue<128>(B, mz_quad_addr(red, row0 + 4 * q + 32, m), ba);
+  asm volatile("s_waitcnt lgkmcnt(0)" : MZ_Q(A), MZ_Q(B));
+  const f32x4 xa = mz_quad_sum(A), xb = mz_quad_sum(B);
+  // the affine parameters (lnb = lnw + 64 floats) arrive under the two reductions
+  mz_lds128<0>(wA, wa); mz_lds128<128>(wB, wa);
+  mz_lds128<256>(bA, wa); mz_lds128<384>(bB, wa);
+  float s = ((xa[0] + xa[1]) + (xa[2] + xa[3])) + ((xb[0] + xb[1]) + (xb[2] + xb[3]));
   s = mz_sum8(s);
   const float mean = s * (1.0f / (float)MZ_H);
   float v = 0.f;
+  f32x4 da, db;
 #pragma unroll
-  for (int i = 0; i < 7; ++i) {
-    const float d = (q + 8 * i < MZ_H) ? x[i] - mean : 0.f;
-    v += d * d;
+  for (int r = 0; r < 4; ++r) {
+    da[r] = xa[r] - mean;                                      // features 4q+r < 32: always valid
+    db[r] = (4 * q + 32 + r < MZ_H) ? xb[r] - mean : 0.f;
+    v += da[r] * da[r];
+    v += db[r] * db[r];
   }
   v = mz_sum8(v);
   const float rstd = 1.0f / sqrtf(v * (1.0f / (float)MZ_H) + 1e-5f);
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wA), "+v"(wB), "+v"(bA), "+v"(bB));
+  f32x4 ya, yb;
 #pragma unroll
-  for (int i = 0; i < 7; ++i) {
-    const int f = q + 8 * i;
-    const float y = fmaxf((x[i] - mean) * rstd * gw[i] + gb[i], 0.f);     // f >= 50: affine is 0 -> 0
-    if (f < MZ_HS) xR[m * MZ_HS + f] = y;
+  for (int r = 0; r < 4; ++r) {
+    ya[r] = fmaxf(da[r] * rstd * wA[r] + bA[r], 0.f);
+    yb[r] = fmaxf(db[r] * rstd * wB[r] + bB[r], 0.f);          // f >= 50: affine is 0 -> 0
   }
+  *(f32x4 *)(xR + m * MZ_HS + 4 * q) = ya;
+  if (4 * q + 32 < MZ_HS) *(f32x4 *)(xR + m * MZ_HS + 4 * q + 32) = yb;
 }
 
-// Config.inverse_transform (config.py:27-33) of output rows [row0,row0+S), column m; L lanes per column (8 or 16),
-// S <= 32 bins (rows row0..row0+31 exist; the reads are unconditional, see above)
-template <int L>
-__device__ __forceinline__ float mz_support_to_scalar_p(const float *red, const float *bias, int row0, int S, int smin,
-                                                        int no_transform, int m, int q) {
-  constexpr int NB = 32 / L;
-  float x[NB], mx = -__builtin_inff();
+// Config.inverse_transform (config.py:27-33) of the S <= 32 bins in x (lane q of the 8 lanes of a column holds
+// bins 4q..4q+3)
+__device__ __forceinline__ float mz_support_to_scalar_q(const f32x4 &raw, int S, int smin, int no_transform, int q) {
+  float x[4], mx = -__builtin_inff();
 #pragma unroll
-  for (int i = 0; i < NB; ++i) {
-    const float raw = mz_comb_at(red, bias, row0 + q + L * i, m);
-    x[i] = (q + L * i < S) ? raw : -__builtin_inff();
-    mx = fmaxf(mx, x[i]);
+  for (int r = 0; r < 4; ++r) {
+    x[r] = (4 * q + r < S) ? raw[r] : -__builtin_inff();
+    mx = fmaxf(mx, x[r]);
   }
-  mx = (L == 8) ? mz_max8(mx) : mz_max16(mx);
-  float e[NB], sum = 0.f;
+  mx = mz_max8(mx);
+  float e[4], sum = 0.f;
 #pragma unroll
-  for (int i = 0; i < NB; ++i) {
-    e[i] = expf(x[i] - mx);          // exp(-inf) = 0 for the padding bins
-    sum += e[i];
+  for (int r = 0; r < 4; ++r) {
+    e[r] = expf(x[r] - mx);          // exp(-inf) = 0 for the padding bins
+    sum += e[r];
   }
-  sum = (L == 8) ? mz_sum8(sum) : mz_sum16(sum);
+  sum = mz_sum8(sum);
   const float rs = 1.0f / sum;
   float v = 0.f;
 #pragma unroll
-  for (int i = 0; i < NB; ++i) v += (float)(smin + q + L * i) * (e[i] * rs);
-  v = (L == 8) ? mz_sum8(v) : mz_sum16(v);
+  for (int r = 0; r < 4; ++r) v += (float)(smin + 4 * q + r) * (e[r] * rs);
+  v = mz_sum8(v);
   if (!no_transform) {
     const float sgn = (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f);
     float t = (fabsf(v) + 1.f) + 0.001f;
@@ -496,6 +528,8 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
 
   for (int sim = 0; sim < nsims; ++sim) {
     asm volatile("" : "+s"(wbase));     // keep address arithmetic inside the loop (scalar adds, no LICM)
+    int lane_e = lane;                  // epilogue lane index, laundered: the LDS addresses derived from it are
+    asm volatile("" : "+v"(lane_e));    // recomputed every simulation instead of living in registers all along
     // ---- gather: x tile = [hidden of search_path[-2] | one-hot(action) | 1]  (mcts.py:94-96)
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
@@ -593,11 +627,14 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
           // waves 0,1: LayerNorm+ReLU of 8 trees each -> xR; waves 2,3: reward scalar of 8 trees each -> s_rew
           // (8 lanes per tree; the two chains run side by side on different SIMDs)
           {
-            const int col = 8 * (w & 1) + (lane >> 3), q = lane & 7;
+            const int col = 8 * (w & 1) + (lane_e >> 3), q = lane_e & 7;
             if (w < 2) {
               sln_relu8p(red, s_b2, xR, s_lnw, s_lnb, 32, col, q);
             } else {
-              const float r = mz_support_to_scalar_p<8>(red, s_b2, 0, n.Sr, n.rmin, n.no_transform, col, q);
+              MzQuad Q;
+              mz_quad_issue<0>(Q, mz_quad_addr(red, 4 * q, col), mz_lds_addr(s_b2 + 4 * q));
+              asm volatile("s_waitcnt lgkmcnt(0)" : MZ_Q(Q));
+              const float r = mz_support_to_scalar_q(mz_quad_sum(Q), n.Sr, n.rmin, n.no_transform, q);
               if (q == 0) s_rew[col] = r;
             }
           }
@@ -629,11 +666,19 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
           STAMP(7)
           mz_partials_out<NJ2>(red, out4, tid);
           STAMP(8)
-          {   // every wave: value scalar + policy logits of its 4 trees (the trees its tree lanes own)
-            const int col = 4 * w + (lane >> 4), q = lane & 15;
-            const float v = mz_support_to_scalar_p<16>(red, s_b4, 0, n.Sv, n.vmin, n.no_transform, col, q);
+          {   // every wave: value scalar + policy logits of its 4 trees (the trees its tree lanes own); both halves
+              // of a tree's 16 lanes compute the value (8 lanes x 4 bins), lane q < ceil(A/4) forwards 4 logits
+            const int col = 4 * w + (lane_e >> 4), q = lane_e & 15, q8 = q & 7;
+            MzQuad V, L;
+            const unsigned ba = mz_lds_addr(s_b4 + 4 * q8);
+            mz_quad_issue<0>(V, mz_quad_addr(red, 4 * q8, col), ba);
+            asm volatile("s_waitcnt lgkmcnt(0)" : MZ_Q(V));
+            const f32x4 vs = mz_quad_sum(V);
+            mz_quad_issue<128>(L, mz_quad_addr(red, 32 + 4 * q8, col), ba);      // arrives under the value chain
+            const float v = mz_support_to_scalar_q(vs, n.Sv, n.vmin, n.no_transform, q8);
             if (q == 0) s_val[col] = v;
-            for (int a = q; a < n.A; a += 16) s_lg[col * 32 + a] = mz_comb_at(red, s_b4, 32 + a, col);
+            asm volatile("s_waitcnt lgkmcnt(0)" : MZ_Q(L));
+            if (q < 8 && 4 * q < n.A) *(f32x4 *)(s_lg + col * 32 + 4 * q) = mz_quad_sum(L);
           }
         }
       }
