@@ -360,7 +360,7 @@ __device__ __forceinline__ float mz_support_to_scalar_q(const f32x4 &raw, int S,
 // dynamic LDS of the fused kernel: pb_c table [(sims+2)^2] doubles, then (LT) the 16 trees' node arrays
 __host__ __device__ inline size_t mz_fused_dyn_lds(int sims, int NN, bool lt) {
   size_t b = (size_t)(sims + 2) * (sims + 2) * 8;
-  if (lt) b += (size_t)16 * NN * (8 + 8 + 4 + 2 + 2 + 1) + 64;
+  if (lt) b += (size_t)16 * NN * (8 + 8 + 8 + 4 + 2 + 2 + 1) + 64;
   return b;
 }
 
@@ -424,7 +424,8 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
   // (LT) the workgroup's 16 trees live in LDS for the whole launch
   double *l_W = s_pbc + (t.sims + 2) * (t.sims + 2);
   double *l_P = l_W + 16 * t.NN;
-  float *l_R = (float *)(l_P + 16 * t.NN);
+  double *l_Q = l_P + 16 * t.NN;
+  float *l_R = (float *)(l_Q + 16 * t.NN);
   int16_t *l_N = (int16_t *)(l_R + 16 * t.NN);
   int16_t *l_E = l_N + 16 * t.NN;
   int8_t *l_TP = (int8_t *)(l_E + 16 * t.NN);
@@ -466,6 +467,7 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
     if constexpr (LT) {
       const int o = mt * t.NN;
       tm[i].N = l_N + o; tm[i].W = l_W + o; tm[i].P = l_P + o; tm[i].R = l_R + o; tm[i].E = l_E + o; tm[i].TP = l_TP + o;
+      tm[i].Q = l_Q + o;
     } else {
       const size_t o = (size_t)(b < t.B ? b : 0) * t.NN;
       tm[i].N = t.N + o; tm[i].W = t.W + o; tm[i].P = t.P + o; tm[i].R = t.R + o; tm[i].E = t.E + o; tm[i].TP = t.TP + o;
@@ -487,6 +489,7 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
         const int have = 1 + (slot0 + 1) * t.A;
         for (int k = tl; k < have; k += TL) {
           tm[i].N[k] = (int16_t)t.N[o + k]; tm[i].W[k] = t.W[o + k]; tm[i].P[k] = t.P[o + k]; tm[i].R[k] = t.R[o + k];
+          tm[i].Q[k] = t.N[o + k] > 0 ? t.W[o + k] / (double)t.N[o + k] : 0.0;      // a continued search: same quotient the backup caches
           tm[i].E[k] = (int16_t)t.E[o + k]; tm[i].TP[k] = t.TP[o + k];
         }
       }

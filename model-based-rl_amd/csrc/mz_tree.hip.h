@@ -239,7 +239,9 @@ struct TreeRegs {
 // for the whole launch (LT = true; visit counts and expansion indices narrowed to 16 bit).
 template <bool LT> struct TreeMem;
 template <> struct TreeMem<false> { int32_t *N; double *W; double *P; float *R; int32_t *E; int8_t *TP; };
-template <> struct TreeMem<true> { int16_t *N; double *W; double *P; float *R; int16_t *E; int8_t *TP; };
+// The LDS copy also caches Q = W/N of every visited node (the backup computes that quotient anyway for the
+// MinMaxStats update), so the descent reads it instead of dividing once per level.
+template <> struct TreeMem<true> { int16_t *N; double *W; double *P; float *R; int16_t *E; int8_t *TP; double *Q; };
 
 // expand + backpropagate for the pending leaf, then (do_select) the next descent -- the same arithmetic as
 // mz_tree_expand_backup / mz_tree_select, reorganised so that the chain of DEPENDENT memory round trips is
@@ -307,6 +309,7 @@ __device__ __forceinline__ void mz_tree_step_fused(const TreeView &t, const Tree
       tm.N[node] = n;
       if (j < len - 1) {
         const double q = w / (double)n;
+        if constexpr (LT) tm.Q[node] = q;        // Node.value() of this node until its next visit
         const double new_q = two ? r_node - g * q : r_node + g * q;
         mn_c = new_q; mx_c = new_q;
       } else {
@@ -349,10 +352,11 @@ __device__ __forceinline__ void mz_tree_step_fused(const TreeView &t, const Tree
     int Nc = tm.N[ch];
     int Ec = tm.E[ch];
     const double p = tm.P[ch];
-    const double wc = tm.W[ch];
     const double rc = (double)tm.R[ch];
     const double prior_score = pbctab[Np * T + Nc] * p;
-    const double q = wc / (double)(Nc > 0 ? Nc : 1);
+    double q;
+    if constexpr (LT) q = tm.Q[ch];        // cached by the backup; unused (may be stale or garbage) while Nc == 0
+    else q = tm.W[ch] / (double)(Nc > 0 ? Nc : 1);
     const double x = rc + g * (two ? -q : q);
     const double nrm = (x - mn) / span;
     const double visited = span_pos ? nrm : (span_zero ? 1.0 : x);
