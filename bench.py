@@ -63,6 +63,8 @@ def main():
   ap.add_argument('--steps', type=int, default=512)
   ap.add_argument('--warmup', type=int, default=64)
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--sync-every', type=int, default=128,
+                  help='moves between weight pulls (the path\'s one exchange: broadcast + repack); 0 = only once')
   args = ap.parse_args()
 
   world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -119,6 +121,8 @@ def main():
     k = 0
     while done < moves:
       m = min(CHUNK, moves - done)
+      if args.sync_every and done and done % args.sync_every == 0:
+        sync_weights()       # Actor.sync_weights (actors.py:81-85): fresh weights from the storage rank, in stream order
       eng.selfplay_steps(m)
       buf, n = eng.selfplay_drain(pinned[k & 1], m, copy_stream=copy_stream)   # overlaps the next chunk's moves
       events[k & 1].record(copy_stream)
@@ -195,7 +199,9 @@ def main():
                                'random-init weights (torch.manual_seed(0))' % (B, EPISODE_LEN),
                    'envs_per_gpu': B, 'num_simulations': SIMS, 'episode_len': EPISODE_LEN,
                    'priming': '%d untimed moves before warm-up so episode ends are in steady state' % EPISODE_LEN,
-                   'sharding': 'env-id sharded, %d rank(s), RCCL weight broadcast' % world},
+                   'sharding': 'env-id sharded, %d rank(s), RCCL weight broadcast' % world,
+                   'weight_sync': 'flat f32 buffer broadcast from rank 0 + repack every %d moves, inside the timed region'
+                                  % args.sync_every},
         'env_steps_executed_per_s': env_steps / dt,
         'mcts_sims_per_s_per_gpu': env_steps * SIMS / dt / world,
         'roofline': {'bound': 'mfma', 'kernel': 'k_search_fused', 'achieved': achieved,
