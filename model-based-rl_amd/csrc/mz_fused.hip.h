@@ -37,7 +37,10 @@ __device__ __forceinline__ void mz_static_for(F &&f) {
 // steps of the stream held in registers (AGPRs) across all simulations: less L2 traffic and no load issue in those
 // steps (a streamed step runs at ~37 cycles/MFMA, a resident one at 32).  As many as the register file takes
 // without scratch: the wide-action instantiations (two tree passes, two policy tiles) have fewer to spare.
-__host__ __device__ constexpr int mz_fused_rs(int ks1, int jtp) { return jtp > 1 ? 8 : (ks1 > 16 ? 10 : (ks1 > 14 ? 11 : 12)); }
+#ifndef MZ_RS_MAIN
+#define MZ_RS_MAIN 12
+#endif
+__host__ __device__ constexpr int mz_fused_rs(int ks1, int jtp) { return jtp > 1 ? 8 : (ks1 > 16 ? 10 : (ks1 > 14 ? 11 : MZ_RS_MAIN)); }
 #define MZ_XE 36     // row stride of the x-tile extension [one-hot(action) | 1 | 0 ...] (k >= 50)
 
 // per-simulation schedule (in steps of 16 MFMAs per wave)
