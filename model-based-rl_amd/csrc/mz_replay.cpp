@@ -52,7 +52,8 @@ struct mz_replay {
   int64_t frames = 0, games = 0;
   std::vector<EnvGame> envs;
   // scratch
-  std::vector<double> errs, pri, rootv;
+  std::vector<double> errs, pri, rootv, chg;
+  std::vector<int64_t> cur;
   std::vector<float> obs, cv, rew;
   std::vector<int32_t> act;
   std::vector<uint8_t> done;
@@ -70,23 +71,54 @@ static inline void tree_update(mz_replay *r, int64_t idx, double priority) {
   }
 }
 
+// SumTree.update for a run of leaves in arrival order, level by level instead of leaf by leaf.  Every node
+// still receives its `change` terms in arrival order (a run never wraps, so its leaf indices increase and a
+// shallower leaf -- which reaches a common ancestor one round earlier -- is also the earlier arrival), hence
+// the sums are bit-identical to the reference's one-leaf-at-a-time walk; but consecutive leaves share their
+// ancestors, so the upper levels stay in registers / L1 instead of being re-walked per leaf.
+static void tree_update_run(mz_replay *r, int64_t first_idx, const double *priorities, int64_t n) {
+  double *t = r->tree.data();
+  if ((int64_t)r->chg.size() < n) { r->chg.resize(n); r->cur.resize(n); }
+  double *chg = r->chg.data();
+  int64_t *cur = r->cur.data();
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t idx = first_idx + i;
+    chg[i] = priorities[i] - t[idx];
+    t[idx] = priorities[i];
+    cur[i] = idx;
+  }
+  for (bool more = true; more;) {
+    more = false;
+    for (int64_t i = 0; i < n; ++i) {
+      if (cur[i] == 0) continue;
+      cur[i] = (cur[i] - 1) / 2;
+      t[cur[i]] += chg[i];
+      more = true;
+    }
+  }
+}
+
 // SumTree.add, replay_buffer.py:19-32
 static void tree_add(mz_replay *r, const double *priorities, int64_t n, const std::shared_ptr<Hist> &h,
                      int64_t *positions_out) {
+  int64_t run_start = 0;                       // [run_start, step) = leaves at consecutive positions, not yet summed
+  int64_t run_idx = r->position + r->max_capacity - 1;
   for (int64_t step = 0; step < n; ++step) {
-    const int64_t idx = r->position + r->max_capacity - 1;
     r->leaf_hist[r->position] = h;
     r->leaf_step[r->position] = (int32_t)step;
     if (positions_out) positions_out[step] = r->position;
-    tree_update(r, idx, priorities[step]);
     if (r->position >= r->prev_capacity) r->num_memories += 1;
     r->position = (r->position + 1) % r->capacity;
     if (r->position == 0) {
+      tree_update_run(r, run_idx, priorities + run_start, step + 1 - run_start);
+      run_start = step + 1;
+      run_idx = r->max_capacity - 1;
       r->prev_capacity = r->capacity;
       const int64_t next = r->capacity + r->capacity_step;
       r->capacity = next < r->max_capacity ? next : r->max_capacity;
     }
   }
+  if (run_start < n) tree_update_run(r, run_idx, priorities + run_start, n - run_start);
 }
 
 static int save_history(mz_replay *r, int64_t n, const double *errors, int64_t ignore, int terminal,
@@ -109,7 +141,10 @@ static int save_history(mz_replay *r, int64_t n, const double *errors, int64_t i
     if (to_play) h->to_play.assign(to_play, to_play + n);
   }
   if ((int64_t)r->pri.size() < keep) r->pri.resize(keep);
-  for (int64_t i = 0; i < keep; ++i) r->pri[i] = pow(fabs(errors[i]) + r->c.epsilon, r->c.alpha);
+  if (r->c.alpha == 1.0)      // pow(x, 1.0) == x exactly: skip the libm call
+    for (int64_t i = 0; i < keep; ++i) r->pri[i] = fabs(errors[i]) + r->c.epsilon;
+  else
+    for (int64_t i = 0; i < keep; ++i) r->pri[i] = pow(fabs(errors[i]) + r->c.epsilon, r->c.alpha);
   tree_add(r, r->pri.data(), keep, h, nullptr);
   r->frames += keep;                       // replay_buffer.py:121
   if (terminal) r->games += 1;             // replay_buffer.py:122
