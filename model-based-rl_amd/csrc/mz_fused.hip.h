@@ -63,6 +63,11 @@ struct FusedSched {
 __device__ __forceinline__ void mz_mfma_a(f32x4 &c, float a, float b) {
   asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
+// first product of an accumulation chain: SrcC = inline constant 0, so the tile is never zero-filled (the zero
+// fill of AGPR tiles shows up as v_accvgpr_mov instructions from a zero tile, inside the MFMA stream)
+__device__ __forceinline__ void mz_mfma_a0(f32x4 &c, float a, float b) {
+  asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&a"(c) : "v"(a), "v"(b));
+}
 // fc1 accumulators live in arch VGPRs: ReLU is then one v_max in place and the tile is the B operand of the
 // following layer as it stands (no v_accvgpr_read copies, no second register set).  The first k-step uses the
 // inline constant 0 as SrcC, so the tiles are never zero-filled.
@@ -97,6 +102,14 @@ __device__ __forceinline__ void mz_mfma_fence(f32x4 (&acc)[N]) {
 #pragma unroll
   for (int i = 0; i < N; ++i) asm volatile("s_nop 7" : "+a"(acc[i]));
   asm volatile("s_nop 15" ::: "memory");
+}
+
+// ReLU as ONE instruction: fmaxf() (and the fmed3 builtin) on a value that comes out of inline asm is preceded by
+// a canonicalising v_max x,x,x (maxnum semantics for signalling NaNs).  A float is negative exactly when its bit
+// pattern is a negative int32, so max_i32(bits, 0) is relu(x) (-0 -> +0) with nothing to canonicalise.
+__device__ __forceinline__ float mz_relu1(float x) {
+  const int b = __builtin_bit_cast(int, x);
+  return __builtin_bit_cast(float, b > 0 ? b : 0);
 }
 
 __device__ __forceinline__ void mz_bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -503,20 +516,23 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
   // offset in one VGPR: every piece is then "s_base + const, v_off" (saddr form) and no per-piece 64-bit
   // VGPR address exists that the compiler could hoist out of the simulation loop and spill.
   // stream of one wave: [RS resident steps][NRING streamed steps], 4 pieces of 64 lanes x f32x4 each
+  // Buffer addressing: the wave's stream is one buffer resource (4 SGPRs), the lane offset one VGPR, the piece a
+  // scalar offset + immediate -- no VALU address arithmetic in the MFMA stream (with flat/global addressing the
+  // compiler kept base + lane offset as a 64-bit VGPR pair and spent two VALU adds per step on it; every
+  // non-MFMA instruction in a dense MFMA stream costs issue time).
   const char *wbase = (const char *)(wstream + (size_t)__builtin_amdgcn_readfirstlane(w) * NSTEPS * 256);
-  const unsigned lane_off = (unsigned)lane * 16u;
+  const __amdgpu_buffer_rsrc_t wrsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void *)wbase, 0, NSTEPS * 4096, 0x00020000);
+  const int lane_off = lane * 16;
+#define MZ_BLOAD(byteoff) __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane_off, (byteoff), 0))
   f32x4 Rw[RS][4];
 #pragma unroll
   for (int s = 0; s < RS; ++s) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
-      Rw[s][p] = *(const __attribute__((address_space(1))) f32x4 *)((const __attribute__((address_space(1))) char *)wbase +
-                                                                    (size_t)((s * 4 + p) * 1024) + lane_off);
+    for (int p = 0; p < 4; ++p) Rw[s][p] = MZ_BLOAD((s * 4 + p) * 1024);
   }
-  wbase += (size_t)RS * 4096;      // from here on: the streamed part, ring step r at wbase + r*4096
-#define MZ_WLOAD(step, piece)                                                             \
-  (*(const __attribute__((address_space(1))) f32x4 *)((const __attribute__((address_space(1))) char *)wbase + \
-                                                       (size_t)(((step) * 4 + (piece)) * 1024) + lane_off))
+  // the streamed part follows the resident one: ring step r at byte RS*4096 + r*4096
+#define MZ_WLOAD(step, piece) MZ_BLOAD(RS * 4096 + ((step) * 4 + (piece)) * 1024)
   f32x4 Bf[NB][4];
 #pragma unroll
   for (int s = 0; s < NB - 1; ++s) {
@@ -533,7 +549,6 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
   __syncthreads();
 
   for (int sim = 0; sim < nsims; ++sim) {
-    asm volatile("" : "+s"(wbase));     // keep address arithmetic inside the loop (scalar adds, no LICM)
     int lane_e = lane;                  // epilogue lane index, laundered: the LDS addresses derived from it are
     asm volatile("" : "+v"(lane_e));    // recomputed every simulation instead of living in registers all along
     // ---- gather: x tile = [hidden of search_path[-2] | one-hot(action) | 1]  (mcts.py:94-96)
@@ -603,8 +618,8 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
           mz_mfma_fence16v(acc);
 #pragma unroll
           for (int tt = 0; tt < 16; ++tt) {
-            acc[tt][0] = fmaxf(acc[tt][0], 0.f); acc[tt][1] = fmaxf(acc[tt][1], 0.f);
-            acc[tt][2] = fmaxf(acc[tt][2], 0.f); acc[tt][3] = fmaxf(acc[tt][3], 0.f);
+            acc[tt][0] = mz_relu1(acc[tt][0]); acc[tt][1] = mz_relu1(acc[tt][1]);
+            acc[tt][2] = mz_relu1(acc[tt][2]); acc[tt][3] = mz_relu1(acc[tt][3]);
           }
           // VALU write -> MFMA SrcB read needs wait states the compiler cannot know about (the MFMAs are asm)
           mz_valu_fence16v(acc);
@@ -613,16 +628,13 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
       } else if constexpr (s < E_FC2) {
         // dynamics fc2: pieces in (t, jt) order, 6 tiles per hidden tile: jt 0,1 reward (hid[t]), 2..5 next hidden (hid[8+t])
         constexpr int step = s - E_FC1;
-        if constexpr (step == 0) {
-#pragma unroll
-          for (int j = 0; j < 6; ++j) out2[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
 #pragma unroll
           for (int q4 = 0; q4 < 4; ++q4) {
             const int q = 4 * step + q4, tt = q / 6, jt = q % 6;
-            mz_mfma_a(out2[jt], Bf[cb][q4][r], acc[jt < 2 ? tt : 8 + tt][r]);
+            if (q < 6 && r == 0) mz_mfma_a0(out2[jt], Bf[cb][q4][r], acc[jt < 2 ? tt : 8 + tt][r]);
+            else mz_mfma_a(out2[jt], Bf[cb][q4][r], acc[jt < 2 ? tt : 8 + tt][r]);
           }
         }
         if constexpr (s == E_FC2 - 1) {
@@ -655,16 +667,13 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
       } else if constexpr (s >= E_P1 && s < E_P2) {
         // prediction fc2: NJ2 tiles per hidden tile: jt 0,1 value (hid[t]), 2.. policy (hid[8+t])
         constexpr int step = s - E_P1;
-        if constexpr (step == 0) {
-#pragma unroll
-          for (int j = 0; j < NJ2; ++j) out4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
 #pragma unroll
           for (int q4 = 0; q4 < 4; ++q4) {
             const int q = 4 * step + q4, tt = q / NJ2, jt = q % NJ2;
-            mz_mfma_a(out4[jt], Bf[cb][q4][r], acc[jt < 2 ? tt : 8 + tt][r]);
+            if (q < NJ2 && r == 0) mz_mfma_a0(out4[jt], Bf[cb][q4][r], acc[jt < 2 ? tt : 8 + tt][r]);
+            else mz_mfma_a(out4[jt], Bf[cb][q4][r], acc[jt < 2 ? tt : 8 + tt][r]);
           }
         }
         if constexpr (s == E_P2 - 1) {

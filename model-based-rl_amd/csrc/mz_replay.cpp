@@ -26,6 +26,7 @@ static int fail(const char *fmt, ...) {
 // one HistorySlice (game.py:5-16) as flat arrays; leaves point into it as (history, step)
 struct Hist {
   int64_t n = 0;
+  int64_t refs = 0;             // leaves pointing at this slice (single-threaded handle: plain counter)
   std::vector<float> obs, child_visits, rewards;
   std::vector<double> root_values;
   std::vector<int32_t> actions;
@@ -47,13 +48,12 @@ struct mz_replay {
   // SumTree (replay_buffer.py:8-17)
   int64_t max_capacity, capacity_step, capacity, prev_capacity = 0, num_memories = 0, position = 0;
   std::vector<double> tree;
-  std::vector<std::shared_ptr<Hist>> leaf_hist;
+  std::vector<Hist *> leaf_hist;   // owned through Hist::refs
   std::vector<int32_t> leaf_step;
   int64_t frames = 0, games = 0;
   std::vector<EnvGame> envs;
   // scratch
   std::vector<double> errs, pri, rootv, chg;
-  std::vector<int64_t> cur;
   std::vector<float> obs, cv, rew;
   std::vector<int32_t> act;
   std::vector<uint8_t> done;
@@ -71,40 +71,64 @@ static inline void tree_update(mz_replay *r, int64_t idx, double priority) {
   }
 }
 
-// SumTree.update for a run of leaves in arrival order, level by level instead of leaf by leaf.  Every node
-// still receives its `change` terms in arrival order (a run never wraps, so its leaf indices increase and a
-// shallower leaf -- which reaches a common ancestor one round earlier -- is also the earlier arrival), hence
-// the sums are bit-identical to the reference's one-leaf-at-a-time walk; but consecutive leaves share their
-// ancestors, so the upper levels stay in registers / L1 instead of being re-walked per leaf.
+// SumTree.update (replay_buffer.py:34-40) for a run of leaves at consecutive tree indices, in arrival order.
+// Every node must receive its `change` terms in arrival order for the float64 sums to equal the reference's
+// one-leaf-at-a-time walk; the order between different nodes is free.  The upper levels, where the whole run
+// sits under one node, are therefore summed in ONE pass over the leaves with one running sum per level
+// (independent add chains instead of a store-to-load dependent walk per leaf); the lower levels walk runs of
+// leaves that share a node with the sum in a register.
 static void tree_update_run(mz_replay *r, int64_t first_idx, const double *priorities, int64_t n) {
   double *t = r->tree.data();
-  if ((int64_t)r->chg.size() < n) { r->chg.resize(n); r->cur.resize(n); }
+  if ((int64_t)r->chg.size() < n) r->chg.resize(n);
   double *chg = r->chg.data();
-  int64_t *cur = r->cur.data();
   for (int64_t i = 0; i < n; ++i) {
-    const int64_t idx = first_idx + i;
-    chg[i] = priorities[i] - t[idx];
-    t[idx] = priorities[i];
-    cur[i] = idx;
+    chg[i] = priorities[i] - t[first_idx + i];
+    t[first_idx + i] = priorities[i];
   }
-  for (bool more = true; more;) {
-    more = false;
-    for (int64_t i = 0; i < n; ++i) {
-      if (cur[i] == 0) continue;
-      cur[i] = (cur[i] - 1) / 2;
-      t[cur[i]] += chg[i];
-      more = true;
+  // 1-based heap numbering: node j has parent j >> 1.  Split where the leaf depth changes (j crosses a power of 2).
+  for (int64_t a = 0; a < n;) {
+    const uint64_t j0 = (uint64_t)(first_idx + a) + 1;
+    const int depth = 63 - __builtin_clzll(j0);
+    int64_t b = n;
+    const uint64_t next_pow = (uint64_t)1 << (depth + 1);
+    if (j0 + (uint64_t)(n - a) > next_pow) b = a + (int64_t)(next_pow - j0);
+    const uint64_t j1 = (uint64_t)(first_idx + b - 1) + 1;      // last leaf of this sub-run
+    int L = 1;
+    for (; L <= depth && (j0 >> L) != (j1 >> L); ++L) {          // levels with several nodes under the run
+      int64_t i = a;
+      while (i < b) {
+        const uint64_t node = ((uint64_t)(first_idx + i) + 1) >> L;
+        double acc = t[node - 1];
+        do { acc += chg[i]; ++i; } while (i < b && ((((uint64_t)(first_idx + i) + 1) >> L) == node));
+        t[node - 1] = acc;
+      }
     }
+    if (L <= depth) {                                            // levels L..depth: one node each
+      double acc[64];
+      const int nl = depth - L + 1;
+      for (int k = 0; k < nl; ++k) acc[k] = t[(j0 >> (L + k)) - 1];
+      for (int64_t i = a; i < b; ++i) {
+        const double c = chg[i];
+        for (int k = 0; k < nl; ++k) acc[k] += c;
+      }
+      for (int k = 0; k < nl; ++k) t[(j0 >> (L + k)) - 1] = acc[k];
+    }
+    a = b;
   }
 }
 
 // SumTree.add, replay_buffer.py:19-32
-static void tree_add(mz_replay *r, const double *priorities, int64_t n, const std::shared_ptr<Hist> &h,
+static void tree_add(mz_replay *r, const double *priorities, int64_t n, Hist *h,
                      int64_t *positions_out) {
   int64_t run_start = 0;                       // [run_start, step) = leaves at consecutive positions, not yet summed
   int64_t run_idx = r->position + r->max_capacity - 1;
   for (int64_t step = 0; step < n; ++step) {
-    r->leaf_hist[r->position] = h;
+    {
+      Hist *&slot = r->leaf_hist[r->position];
+      if (slot && --slot->refs == 0) delete slot;
+      slot = h;
+      if (h) ++h->refs;
+    }
     r->leaf_step[r->position] = (int32_t)step;
     if (positions_out) positions_out[step] = r->position;
     if (r->position >= r->prev_capacity) r->num_memories += 1;
@@ -127,9 +151,9 @@ static int save_history(mz_replay *r, int64_t n, const double *errors, int64_t i
   // replay_buffer.py:113-119: errors[:-ignore] (python: ignore == 0 would give an empty list)
   int64_t keep = n;
   if (ignore >= 0) keep = ignore == 0 ? 0 : (n - ignore > 0 ? n - ignore : 0);
-  std::shared_ptr<Hist> h;
+  Hist *h = nullptr;
   if (obs || child_visits || root_values || rewards || actions || dones || to_play) {
-    h = std::make_shared<Hist>();
+    h = new Hist();
     h->n = n;
     const int O = r->c.obs_dim, A = r->c.action_space;
     if (obs) h->obs.assign(obs, obs + n * O);
@@ -146,6 +170,7 @@ static int save_history(mz_replay *r, int64_t n, const double *errors, int64_t i
   else
     for (int64_t i = 0; i < keep; ++i) r->pri[i] = pow(fabs(errors[i]) + r->c.epsilon, r->c.alpha);
   tree_add(r, r->pri.data(), keep, h, nullptr);
+  if (h && h->refs == 0) delete h;         // no kept step points at it (everything was `ignore`d)
   r->frames += keep;                       // replay_buffer.py:121
   if (terminal) r->games += 1;             // replay_buffer.py:122
   return 0;
@@ -166,13 +191,16 @@ int mzr_create(const mzr_config *cfg, mz_replay **out) {
   r->capacity_step = cfg->window_step;
   r->capacity = cfg->window_step;
   r->tree.assign((size_t)(2 * cfg->window_size - 1), 0.0);
-  r->leaf_hist.resize((size_t)cfg->window_size);
+  r->leaf_hist.assign((size_t)cfg->window_size, nullptr);
   r->leaf_step.assign((size_t)cfg->window_size, 0);
   *out = r;
   return 0;
 }
 
 int mzr_destroy(mz_replay *r) {
+  if (r)
+    for (Hist *&h : r->leaf_hist)
+      if (h) { if (--h->refs == 0) delete h; h = nullptr; }
   delete r;
   return 0;
 }
@@ -249,21 +277,31 @@ int mzr_ingest_records(mz_replay *r, const float *records, int n_moves, int B, i
                                     : (g.previous_collect_to - overlap > 0 ? g.previous_collect_to - overlap : 0);
       const int64_t n = g.history_idx - collect_from;
       const int64_t ignore = done ? -1 : overlap;
-      if ((int64_t)r->errs.size() < n) {
-        r->errs.resize(n); r->rootv.resize(n); r->rew.resize(n); r->act.resize(n); r->done.resize(n); r->tp.resize(n);
+      // PrioritizedReplay.save_history (replay_buffer.py:113-122) with the HistorySlice built straight from the
+      // env's records (same arithmetic as save_history() above, one copy less)
+      {
+        Hist *h = new Hist();
+        h->n = n;
+        h->obs.resize((size_t)n * O); h->child_visits.resize((size_t)n * A); h->root_values.resize((size_t)n);
+        h->rewards.resize((size_t)n); h->actions.resize((size_t)n); h->dones.resize((size_t)n); h->to_play.assign((size_t)n, 1);
+        int64_t keep = n;
+        if (ignore >= 0) keep = ignore == 0 ? 0 : (n - ignore > 0 ? n - ignore : 0);
+        if ((int64_t)r->pri.size() < n) r->pri.resize(n);
+        const float *q = g.recs.data() + (size_t)(collect_from - g.base) * rec_floats;
+        for (int64_t i = 0; i < n; ++i, q += rec_floats) {
+          const int32_t *qi = (const int32_t *)(q + O + A + 3);
+          memcpy(h->obs.data() + i * O, q, O * sizeof(float));
+          memcpy(h->child_visits.data() + i * A, q + O, A * sizeof(float));
+          h->root_values[i] = (double)q[O + A]; h->rewards[i] = q[O + A + 2];
+          h->actions[i] = qi[0]; h->dones[i] = (uint8_t)(qi[1] != 0);
+          const double e = fabs((double)q[O + A + 1]) + r->c.epsilon;
+          r->pri[i] = r->c.alpha == 1.0 ? e : pow(e, r->c.alpha);
+        }
+        tree_add(r, r->pri.data(), keep, h, nullptr);
+        if (h->refs == 0) delete h;
+        r->frames += keep;
+        if (done) r->games += 1;
       }
-      if ((int64_t)r->obs.size() < n * O) r->obs.resize(n * O);
-      if ((int64_t)r->cv.size() < n * A) r->cv.resize(n * A);
-      for (int64_t i = 0; i < n; ++i) {
-        const float *q = g.recs.data() + (size_t)(collect_from - g.base + i) * rec_floats;
-        const int32_t *qi = (const int32_t *)(q + O + A + 3);
-        memcpy(r->obs.data() + i * O, q, O * sizeof(float));
-        memcpy(r->cv.data() + i * A, q + O, A * sizeof(float));
-        r->rootv[i] = (double)q[O + A]; r->errs[i] = (double)q[O + A + 1]; r->rew[i] = q[O + A + 2];
-        r->act[i] = qi[0]; r->done[i] = (uint8_t)(qi[1] != 0); r->tp[i] = 1;
-      }
-      save_history(r, n, r->errs.data(), ignore, done ? 1 : 0, r->obs.data(), r->cv.data(), r->rootv.data(),
-                   r->rew.data(), r->act.data(), r->done.data(), r->tp.data());
       g.previous_collect_to = g.history_idx;
       g.done_at_last_flush = done;
       if (done) {           // terminal: run_selfplay starts a new Game (actors.py:94-97)
@@ -295,7 +333,7 @@ int mzr_sample_batch(const mz_replay *r, const double *draws, int bs, float *obs
   for (int i = 0; i < bs; ++i) {
     const int64_t idx = mzr_tree_get_leaf(r, draws[i]);                       // replay_buffer.py:142
     const int64_t pos = idx - r->max_capacity + 1;
-    const std::shared_ptr<Hist> &h = r->leaf_hist[(size_t)pos];
+    const Hist *h = r->leaf_hist[(size_t)pos];
     if (!h) return fail("mzr_sample_batch: draw %d hit an empty leaf (buffer smaller than the draw range?)", i);
     const int64_t step = r->leaf_step[(size_t)pos];
     idxs[i] = idx;
