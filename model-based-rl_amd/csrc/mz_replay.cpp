@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <memory>
 #include <string>
 #include <vector>
@@ -43,6 +44,9 @@ struct EnvGame {
   bool done_at_last_flush = false;
 };
 
+// a history slice built during an env-major ingest pass, waiting for its (move, env)-ordered tree insertion
+struct Pending { int m, b; struct Hist *h; int64_t keep; size_t pri_off; bool done; };
+
 struct mz_replay {
   mzr_config c;
   // SumTree (replay_buffer.py:8-17)
@@ -53,7 +57,8 @@ struct mz_replay {
   int64_t frames = 0, games = 0;
   std::vector<EnvGame> envs;
   // scratch
-  std::vector<double> errs, pri, rootv, chg;
+  std::vector<double> errs, pri, rootv, chg, pend_pri;
+  std::vector<struct Pending> pend;
   std::vector<float> obs, cv, rew;
   std::vector<int32_t> act;
   std::vector<uint8_t> done;
@@ -261,12 +266,20 @@ int mzr_ingest_records(mz_replay *r, const float *records, int n_moves, int B, i
   if (rec_floats != O + A + 8) return fail("mzr_ingest_records: rec_floats %d != obs_dim+action_space+8 = %d", rec_floats, O + A + 8);
   if ((int)r->envs.size() < B) r->envs.resize(B);
   const int64_t overlap = r->c.num_unroll_steps + r->c.td_steps;
-  for (int m = 0; m < n_moves; ++m) {
-    for (int b = 0; b < B; ++b) {
+  // Environment-major: an env's bookkeeping and the tail of its record buffer are touched once per call
+  // instead of once per move (4096 envs x 3 cold cache lines per record were the bulk of the ingest time).  The
+  // history slices are built as they fall due; their insertion into the sum tree is deferred and replayed in
+  // (move, env) order, i.e. exactly the arrival order of a move-major walk.
+  std::vector<Pending> &pend = r->pend;
+  std::vector<double> &pris = r->pend_pri;
+  pend.clear();
+  pris.clear();
+  for (int b = 0; b < B; ++b) {
+    EnvGame &g = r->envs[b];
+    for (int m = 0; m < n_moves; ++m) {
       const float *rec = records + ((size_t)m * B + b) * rec_floats;
       const int32_t *ri = (const int32_t *)(rec + O + A + 3);
       const bool done = ri[1] != 0;
-      EnvGame &g = r->envs[b];
       g.recs.insert(g.recs.end(), rec, rec + rec_floats);
       g.history_idx += 1;
       // actors.py:160-169
@@ -286,7 +299,9 @@ int mzr_ingest_records(mz_replay *r, const float *records, int n_moves, int B, i
         h->rewards.resize((size_t)n); h->actions.resize((size_t)n); h->dones.resize((size_t)n); h->to_play.assign((size_t)n, 1);
         int64_t keep = n;
         if (ignore >= 0) keep = ignore == 0 ? 0 : (n - ignore > 0 ? n - ignore : 0);
-        if ((int64_t)r->pri.size() < n) r->pri.resize(n);
+        const size_t off = pris.size();
+        pris.resize(off + (size_t)n);
+        double *pri = pris.data() + off;
         const float *q = g.recs.data() + (size_t)(collect_from - g.base) * rec_floats;
         for (int64_t i = 0; i < n; ++i, q += rec_floats) {
           const int32_t *qi = (const int32_t *)(q + O + A + 3);
@@ -295,12 +310,9 @@ int mzr_ingest_records(mz_replay *r, const float *records, int n_moves, int B, i
           h->root_values[i] = (double)q[O + A]; h->rewards[i] = q[O + A + 2];
           h->actions[i] = qi[0]; h->dones[i] = (uint8_t)(qi[1] != 0);
           const double e = fabs((double)q[O + A + 1]) + r->c.epsilon;
-          r->pri[i] = r->c.alpha == 1.0 ? e : pow(e, r->c.alpha);
+          pri[i] = r->c.alpha == 1.0 ? e : pow(e, r->c.alpha);
         }
-        tree_add(r, r->pri.data(), keep, h, nullptr);
-        if (h->refs == 0) delete h;
-        r->frames += keep;
-        if (done) r->games += 1;
+        pend.push_back(Pending{m, b, h, keep, off, done});
       }
       g.previous_collect_to = g.history_idx;
       g.done_at_last_flush = done;
@@ -314,6 +326,13 @@ int mzr_ingest_records(mz_replay *r, const float *records, int n_moves, int B, i
         }
       }
     }
+  }
+  std::stable_sort(pend.begin(), pend.end(), [](const Pending &x, const Pending &y) { return x.m < y.m; });   // b already ascending
+  for (const Pending &p : pend) {
+    tree_add(r, pris.data() + p.pri_off, p.keep, p.h, nullptr);
+    if (p.h->refs == 0) delete p.h;
+    r->frames += p.keep;
+    if (p.done) r->games += 1;
   }
   return 0;
 }

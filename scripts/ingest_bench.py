@@ -10,7 +10,7 @@ rng = np.random.RandomState(0)
 t = ((np.arange(B, dtype=np.uint32) * np.uint32(2654435761)) >> 8) % T
 ep = np.zeros(B, np.int32)
 ts = []
-for it in range(120):
+for it in range(200):
   rec = rng.standard_normal((8, B, O + A + 8)).astype(np.float32)
   ints = rec[..., O + A + 3:].view(np.int32)
   for m in range(8):
@@ -18,5 +18,7 @@ for it in range(120):
     done = t + 1 >= T
     ep += done; t = np.where(done, 0, t + 1)
   t0 = time.perf_counter(); rp.ingest_records(rec, 8, B); ts.append(time.perf_counter() - t0)
+full = np.array(ts) * 1e3
+print('slowest calls (index: ms):', ', '.join('%d: %.1f' % (i, full[i]) for i in np.argsort(full)[-6:][::-1]))
 ts = np.array(ts[60:]) * 1e3
 print('ingest of 8 moves x 4096 envs: median %.2f ms, p90 %.2f, max %.2f ms; frames %d' % (np.median(ts), np.percentile(ts, 90), ts.max(), rp.get_throughput()['frames']))
