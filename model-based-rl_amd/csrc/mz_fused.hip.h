@@ -512,6 +512,17 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
     }
   }
 
+  // hidden state of the pending descent's parent, 16 bytes per lane (lanes 13.. of a tree duplicate column 12);
+  // refreshed by every descent (speculative gather, mz_tree_step_fused)
+  f32x4 hv[NPASS];
+  unsigned hoff[NPASS];
+#pragma unroll
+  for (int i = 0; i < NPASS; ++i) {
+    const int b = b0 + tid / TL + i * (256 / TL);
+    hoff[i] = (unsigned)(((size_t)(b < t.B ? b : 0) * per_tree) * 4) + (unsigned)((tl < MZ_HS / 4 ? tl : MZ_HS / 4 - 1) * 16);
+    hv[i] = *(const f32x4 *)((const char *)t.hpool + hoff[i] + (size_t)my_slot[i] * (MZ_HS * 4));
+  }
+
   // this wave's stream: [NSTEPS][4 pieces][64 lanes] f32x4.  Wave-uniform base in SGPRs + per-lane byte
   // offset in one VGPR: every piece is then "s_base + const, v_off" (saddr form) and no per-piece 64-bit
   // VGPR address exists that the compiler could hoist out of the simulation loop and spill.
@@ -552,12 +563,12 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
     int lane_e = lane;                  // epilogue lane index, laundered: the LDS addresses derived from it are
     asm volatile("" : "+v"(lane_e));    // recomputed every simulation instead of living in registers all along
     // ---- gather: x tile = [hidden of search_path[-2] | one-hot(action) | 1]  (mcts.py:94-96)
+    // (the parent's hidden state was requested during the descent that chose it -- hv[], see mz_tree_step_fused)
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
       const int mt = tid / TL + i * (256 / TL);
-      const int b = b0 + mt;
-      const f32x4 *src = (const f32x4 *)(t.hpool + (size_t)b * per_tree + (size_t)my_slot[i] * MZ_HS);
-      for (int c = tl; c < MZ_HS / 4; c += TL) *(f32x4 *)(xR + mt * MZ_HS + 4 * c) = src[c];
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(hv[i]));
+      if (tl < MZ_HS / 4) *(f32x4 *)(xR + mt * MZ_HS + 4 * tl) = hv[i];
       for (int c = tl; c < MZ_XE; c += TL) xEd[mt * MZ_XE + c] = (c == my_act[i] || c == n.A) ? 1.f : 0.f;
     }
     STAMP(0)
@@ -714,7 +725,7 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
         auto stampf = [&](int k) __attribute__((always_inline)) { STAMP(10 + k) };
         mz_tree_step_fused<TL, G, LT>(t, tm[i], tl, slot0 + sim + 1, s_val[mt], s_rew[mt], s_lg + mt * 32,
                                    s_path + mt * MZ_FUSED_MAXPL, (double *)red + mt * 96, s_pbc, tr[i],
-                                   sim + 1 < nsims, my_slot[i], my_act[i], stampf);
+                                   sim + 1 < nsims, my_slot[i], my_act[i], t.hpool, hoff[i], hv[i], stampf);
       }
     }
     STAMP(13)

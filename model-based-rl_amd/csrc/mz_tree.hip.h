@@ -256,6 +256,7 @@ __device__ __forceinline__ void mz_tree_step_fused(const TreeView &t, const Tree
                                                    float value, float reward, const float *logits, int *s_path,
                                                    double *s_stage, const double *pbctab, TreeRegs &tr,
                                                    bool do_select, int &slot_out, int &act_out,
+                                                   const float *hpool, unsigned hoff, f32x4 &hv,
                                                    STAMPF stampf = STAMPF()) {
   const int A = t.A;
   const int len = tr.len, tp = tr.tp;
@@ -347,6 +348,14 @@ __device__ __forceinline__ void mz_tree_step_fused(const TreeView &t, const Tree
   // arg-max needs only log2(G) exchange steps and every lane ends up with the result
   const int cl = lane % G;
   while (e >= 0) {
+    // Speculative gather: the node being descended through is the leaf's parent if this turns out to be the last
+    // level, so its hidden state (this lane's 16 bytes of it) is requested now and the L2 round trip runs under the
+    // level's arithmetic; a deeper level simply overwrites the request (loads return in order).  Issued from asm:
+    // the compiler would put a vmcnt(0) in front of every re-use of the destination register.  The consumer waits
+    // with s_waitcnt vmcnt(0) (mz_fused.hip.h, gather).
+    // ("+v": the destination stays allocated to hv between requests -- an earlier request may still be in
+    // flight, so nothing else, not even this request's address, may be computed in those registers)
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(hv) : "v"(hoff + (unsigned)e * (unsigned)(MZ_HS * 4)), "s"(hpool));
     const bool valid = (cl < A) & ((node != 0) | (((tr.legal >> cl) & 1u) != 0));
     const int ch = valid ? 1 + e * A + cl : 0;
     int Nc = tm.N[ch];
@@ -388,6 +397,7 @@ __device__ __forceinline__ void mz_tree_step_fused(const TreeView &t, const Tree
     if (two) tpc = -tpc;
     e = Ec;
     Np = Nc;
+    asm volatile("" : "+v"(hv));     // the request is in flight: keep its destination registers reserved
   }
   tr.len = len2;
   tr.tp = tpc;
