@@ -10,7 +10,7 @@ import subprocess
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 _SO = os.path.join(_CSRC, 'libmz_hip.so')
 _SOURCES = ['mz_engine.hip', 'mz_common.h', 'mz_net.hip.h', 'mz_tree.hip.h', 'mz_rng.h', 'mz_selfplay.hip.h',
-            'mz_selfplay_abi.inc', 'mz_fused.hip.h']
+            'mz_selfplay_abi.inc', 'mz_fused.hip.h', 'mz_root.hip.h']
 _lib = None
 
 HIPCC_FLAGS = ['-O3', '--offload-arch=gfx950', '-ffp-contract=off', '-std=c++17', '-fPIC', '-shared', '-Wno-unused-value',
@@ -41,7 +41,7 @@ def stale():
 def build(force=False, verbose=False):
   """hipcc cross-compiles for gfx950 without a GPU; the .so stays in-tree (csrc/)."""
   if force or stale():
-    cmd = ['hipcc'] + HIPCC_FLAGS + ['mz_engine.hip', '-o', 'libmz_hip.so']
+    cmd = ['hipcc'] + HIPCC_FLAGS + os.environ.get('MZ_HIPCC_EXTRA', '').split() + ['mz_engine.hip', '-o', 'libmz_hip.so']
     if verbose:
       print(' '.join(cmd))
     subprocess.check_call(cmd, cwd=_CSRC)

@@ -543,7 +543,8 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
     for (int p = 0; p < 4; ++p) Rw[s][p] = MZ_BLOAD((s * 4 + p) * 1024);
   }
   // the streamed part follows the resident one: ring step r at byte RS*4096 + r*4096
-#define MZ_WLOAD(step, piece) MZ_BLOAD(RS * 4096 + ((step) * 4 + (piece)) * 1024)
+  // (piece offset as the instruction's immediate, step offset as the scalar offset: one s_mov per step instead of four)
+#define MZ_WLOAD(step, piece) __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane_off + (piece) * 1024, (RS + (step)) * 4096, 0))
   f32x4 Bf[NB][4];
 #pragma unroll
   for (int s = 0; s < NB - 1; ++s) {
@@ -589,6 +590,11 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
         constexpr int ps = (r + NB - 1) % NRING, pb = (r + NB - 1) % NB;
 #pragma unroll
         for (int p = 0; p < 4; ++p) Bf[pb][p] = MZ_WLOAD(ps, p);
+        // this step's own pieces were requested NB - 1 steps ago: exactly 4 (NB - 1) younger requests are allowed to be
+        // outstanding.  ONE explicit wait per step -- left alone the compiler emits a counted wait in front of each of the
+        // step's four pieces, and every instruction in the MFMA stream costs issue time.
+        static_assert(NB == 5, "vmcnt(16) below assumes a prefetch distance of 4 steps");
+        __builtin_amdgcn_s_waitcnt(0x4F70);     // vmcnt(16)
       }
       constexpr int cb = (s >= RS ? s - RS : 0) % NB;
       if constexpr (s < E_FC1 || (s >= E_FC2 && s < E_P1)) {

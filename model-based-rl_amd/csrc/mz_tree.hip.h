@@ -251,6 +251,53 @@ template <> struct TreeMem<true> { int16_t *N; double *W; double *P; float *R; i
 // forwarded by shuffle and a level costs ONE round trip.
 struct MzNoStamp { __device__ __forceinline__ void operator()(int) const {} };
 
+// Hook of the descent loop: enter(e) at the top of every level (e = expansion index of the node being descended
+// through, i.e. the leaf's parent if this level turns out to be the last), leave() at its bottom.
+struct MzNoLevelHook {
+  __device__ __forceinline__ void enter(int) const {}
+  __device__ __forceinline__ void leave() const {}
+};
+// Speculative gather of the parent's hidden state (4-wave fused kernel): the node being descended through is the
+// leaf's parent if this turns out to be the last level, so its hidden state (this lane's 16 bytes of it) is requested
+// now and the L2 round trip runs under the level's arithmetic; a deeper level simply overwrites the request (loads
+// return in order).  Issued from asm: the compiler would put a vmcnt(0) in front of every re-use of the destination
+// register.  The consumer waits with s_waitcnt vmcnt(0) (mz_fused.hip.h, gather).
+// ("+v": the destination stays allocated to hv between requests -- an earlier request may still be in flight, so
+// nothing else, not even this request's address, may be computed in those registers)
+struct MzHiddenPrefetch {
+  const float *hpool; unsigned hoff; f32x4 &hv;
+  __device__ __forceinline__ void enter(int e) const {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(hv) : "v"(hoff + (unsigned)e * (unsigned)(MZ_HS * 4)), "s"(hpool));
+  }
+  __device__ __forceinline__ void leave() const { asm volatile("" : "+v"(hv)); }   // in flight: keep the destination reserved
+};
+
+// ---- Node.expand (mcts.py:47-55) for the pending leaf: priors of the new children, leaf bookkeeping
+template <int TL, bool LT>
+__device__ __forceinline__ void mz_tree_expand_f(const TreeView &t, const TreeMem<LT> &tm, int lane, int e_new,
+                                                 float reward, const float *logits, const int *s_path,
+                                                 double *s_stage, const TreeRegs &tr) {
+  const int A = t.A;
+  const int leafnode = s_path[tr.len - 1];
+  const double p = (lane < A) ? exp((double)logits[lane]) : 0.0;
+  if (lane < A) s_stage[lane] = p;              // every lane then adds them up in Python's sum() order
+  double sum = 0.0;
+  for (int a = 0; a < A; ++a) sum = sum + s_stage[a];
+  if (lane < A) {
+    const int ch = 1 + e_new * A + lane;
+    tm.N[ch] = 0; tm.W[ch] = 0.0; tm.R[ch] = 0.f; tm.E[ch] = -1; tm.TP[ch] = 1;
+    tm.P[ch] = p / sum;
+  }
+  if (lane == 0) { tm.E[leafnode] = e_new; tm.TP[leafnode] = (int8_t)tr.tp; tm.R[leafnode] = reward; }
+}
+
+template <int TL, int G, bool LT, class LEVELF, class STAMPF>
+__device__ __forceinline__ void mz_tree_backup_select_f(const TreeView &t, const TreeMem<LT> &tm, int lane,
+                                                        float value, float reward, int *s_path, double *s_stage,
+                                                        const double *pbctab, TreeRegs &tr, bool do_select,
+                                                        int &slot_out, int &act_out, const LEVELF &levelf,
+                                                        STAMPF stampf);
+
 template <int TL, int G, bool LT, class STAMPF = MzNoStamp>
 __device__ __forceinline__ void mz_tree_step_fused(const TreeView &t, const TreeMem<LT> &tm, int lane, int e_new,
                                                    float value, float reward, const float *logits, int *s_path,
@@ -258,27 +305,24 @@ __device__ __forceinline__ void mz_tree_step_fused(const TreeView &t, const Tree
                                                    bool do_select, int &slot_out, int &act_out,
                                                    const float *hpool, unsigned hoff, f32x4 &hv,
                                                    STAMPF stampf = STAMPF()) {
+  mz_tree_expand_f<TL, LT>(t, tm, lane, e_new, reward, logits, s_path, s_stage, tr);
+  stampf(0);
+  mz_tree_backup_select_f<TL, G, LT>(t, tm, lane, value, reward, s_path, s_stage, pbctab, tr, do_select, slot_out,
+                                     act_out, MzHiddenPrefetch{hpool, hoff, hv}, stampf);
+}
+
+// MCTS.backpropagate for the pending leaf, then (do_select) the next descent
+template <int TL, int G, bool LT, class LEVELF, class STAMPF>
+__device__ __forceinline__ void mz_tree_backup_select_f(const TreeView &t, const TreeMem<LT> &tm, int lane,
+                                                        float value, float reward, int *s_path, double *s_stage,
+                                                        const double *pbctab, TreeRegs &tr, bool do_select,
+                                                        int &slot_out, int &act_out, const LEVELF &levelf,
+                                                        STAMPF stampf) {
   const int A = t.A;
   const int len = tr.len, tp = tr.tp;
   const double g = t.discount;
   const bool two = t.two_players != 0;
-  const int leafnode = s_path[len - 1];
 
-  // ---- Node.expand (mcts.py:47-55): priors of the new children
-  {
-    const double p = (lane < A) ? exp((double)logits[lane]) : 0.0;
-    if (lane < A) s_stage[lane] = p;              // every lane then adds them up in Python's sum() order
-    double sum = 0.0;
-    for (int a = 0; a < A; ++a) sum = sum + s_stage[a];
-    if (lane < A) {
-      const int ch = 1 + e_new * A + lane;
-      tm.N[ch] = 0; tm.W[ch] = 0.0; tm.R[ch] = 0.f; tm.E[ch] = -1; tm.TP[ch] = 1;
-      tm.P[ch] = p / sum;
-    }
-    if (lane == 0) { tm.E[leafnode] = e_new; tm.TP[leafnode] = (int8_t)tp; tm.R[leafnode] = reward; }
-  }
-
-  stampf(0);
   // ---- MCTS.backpropagate (mcts.py:126-143), TL path nodes per round
   double v_cur = (double)value;
   double mn_c = __builtin_inf(), mx_c = -__builtin_inf();
@@ -348,14 +392,7 @@ __device__ __forceinline__ void mz_tree_step_fused(const TreeView &t, const Tree
   // arg-max needs only log2(G) exchange steps and every lane ends up with the result
   const int cl = lane % G;
   while (e >= 0) {
-    // Speculative gather: the node being descended through is the leaf's parent if this turns out to be the last
-    // level, so its hidden state (this lane's 16 bytes of it) is requested now and the L2 round trip runs under the
-    // level's arithmetic; a deeper level simply overwrites the request (loads return in order).  Issued from asm:
-    // the compiler would put a vmcnt(0) in front of every re-use of the destination register.  The consumer waits
-    // with s_waitcnt vmcnt(0) (mz_fused.hip.h, gather).
-    // ("+v": the destination stays allocated to hv between requests -- an earlier request may still be in
-    // flight, so nothing else, not even this request's address, may be computed in those registers)
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(hv) : "v"(hoff + (unsigned)e * (unsigned)(MZ_HS * 4)), "s"(hpool));
+    levelf.enter(e);
     const bool valid = (cl < A) & ((node != 0) | (((tr.legal >> cl) & 1u) != 0));
     const int ch = valid ? 1 + e * A + cl : 0;
     int Nc = tm.N[ch];
@@ -397,7 +434,7 @@ __device__ __forceinline__ void mz_tree_step_fused(const TreeView &t, const Tree
     if (two) tpc = -tpc;
     e = Ec;
     Np = Nc;
-    asm volatile("" : "+v"(hv));     // the request is in flight: keep its destination registers reserved
+    levelf.leave();
   }
   tr.len = len2;
   tr.tp = tpc;
