@@ -349,18 +349,18 @@ __device__ __forceinline__ float mz_support_to_scalar_q(const f32x4 &raw, int S,
 #pragma unroll
   for (int r = 0; r < 4; ++r) v += (float)(smin + 4 * q + r) * (e[r] * rs);
   v = mz_sum8(v);
-  if (!no_transform) {
-    const float sgn = (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f);
-    float t = (fabsf(v) + 1.f) + 0.001f;
-    t = 1.f + 0.004f * t;
-    t = (sqrtf(t) - 1.f) / 0.002f;
-    v = sgn * (t * t - 1.f);
-  }
-  return v;
+  // (computed unconditionally and selected: a branch here would end the basic block and with it the scheduler's
+  // freedom to interleave this chain with the caller's other work)
+  const float sgn = (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f);
+  float t = (fabsf(v) + 1.f) + 0.001f;
+  t = 1.f + 0.004f * t;
+  t = (sqrtf(t) - 1.f) / 0.002f;
+  const float vt = sgn * (t * t - 1.f);
+  return no_transform ? v : vt;
 }
 
 #define MZ_FUSED_MAXPL 64   // search-path slots per tree kept in LDS: num_simulations + 2 <= 64
-#define MZ_FUSED_LDS_FLOATS (16 * MZ_HS + 4 * 6 * 256 + 16 + 16 + 16 * 32 + 96 + 64 + 64 + 64 + 2 * 16 * MZ_XE + 16 * MZ_FUSED_MAXPL)
+#define MZ_FUSED_LDS_FLOATS (16 * MZ_HS + 4 * 6 * 256 + 16 + 16 + 16 * 32 + 96 + 64 + 64 + 64 + 2 * 16 * MZ_XE + 16 * MZ_FUSED_MAXPL + 16 * 96 * 2)
 
 // PROF: diagnostic build only (mz_search_phase_profile): per-wave cycle totals of each phase of the loop.
 #define MZ_NPHASE 14
@@ -457,10 +457,13 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
   float *xEd = s_lnb + 64;                // [16][MZ_XE] dynamics extension: one-hot(action), then 1 (bias column)
   float *xEp = xEd + 16 * MZ_XE;          // [16][MZ_XE] prediction extension: 1 (bias column), then 0
   int *s_path = (int *)(xEp + 16 * MZ_XE); // [16][MZ_FUSED_MAXPL] pending search path of every tree
+  double *s_stage = (double *)(s_path + 16 * MZ_FUSED_MAXPL);      // [16][96] staging of the tree step (its own: the
+                                                                   // tree step of one wave overlaps other waves' epilogue)
 
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
   const int g4 = lane >> 4, m16 = lane & 15;
   const int b0 = blockIdx.x * MZ_ROWS;
+  const bool full = b0 + MZ_ROWS <= t.B;       // (wave-uniform) all 16 trees of this workgroup exist
   const size_t per_tree = (size_t)(t.sims + 1) * MZ_HS;
 
   if (tid < 96) s_b2[tid] = n.b2[tid];
@@ -696,10 +699,15 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
         if constexpr (s == E_P2 - 1) {
           mz_mfma_fence<NJ2>(out4);
           STAMP(7)
+          // every wave's hidden-state stores must have landed before the tree lanes may gather them: they are older
+          // than the last 16 weight loads, so vmcnt(16) covers them without draining the prefetch ring; the barrier
+          // inside mz_partials_out then publishes them
+          __builtin_amdgcn_s_waitcnt(0x4F70);     // vmcnt(16)
           mz_partials_out<NJ2>(red, out4, tid);
           STAMP(8)
-          {   // every wave: value scalar + policy logits of its 4 trees (the trees its tree lanes own); both halves
-              // of a tree's 16 lanes compute the value (8 lanes x 4 bins), lane q < ceil(A/4) forwards 4 logits
+          if constexpr (TL != 16) {
+              // every wave: value scalar + policy logits of 4 trees -> LDS; both halves of a tree's 16 lanes compute the
+              // value (8 lanes x 4 bins), lane q < ceil(A/4) forwards 4 logits
             const int col = 4 * w + (lane_e >> 4), q = lane_e & 15, q8 = q & 7;
             MzQuad V, L;
             const unsigned ba = mz_lds_addr(s_b4 + 4 * q8);
@@ -716,22 +724,48 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
       }
       // s >= E_P2: padding steps (prefetch only)
     });
-    // every wave's hidden-state stores must have landed before the tree lanes may gather them: they are
-    // older than the last 16 weight loads, so vmcnt(16) covers them without draining the prefetch ring
-    __builtin_amdgcn_s_waitcnt(0x4F70);     // vmcnt(16)
-    mz_bar();
-    STAMP(9)
-
-    // ---- tree: expand + backup (mcts.py:97-99), then the next descent (mcts.py:83-92)
+    if constexpr (TL == 16) {
+      // ---- value scalar, logits, then the tree step (expand + backup, mcts.py:97-99; next descent, mcts.py:83-92) of
+      // the 4 trees this wave's lanes own, with no barrier in between: nothing here is exchanged across waves (the
+      // wave that owns a tree reads its value and logits straight from the partials), and written as ONE straight
+      // line so that the two long dependent chains -- f32 softmax + inverse transform of the value, f64 exp +
+      // normalisation of the priors -- interleave in the instruction stream instead of running back to back.
+      const int mt = tid / TL;
+      const int q8 = tl & 7;
+      MzQuad V, L;
+      const unsigned ba = mz_lds_addr(s_b4 + 4 * q8);
+      mz_quad_issue<0>(V, mz_quad_addr(red, 4 * q8, mt), ba);
+      mz_quad_issue<128>(L, mz_quad_addr(red, 32 + 4 * q8, mt), ba);
+      asm volatile("s_waitcnt lgkmcnt(0)" : MZ_Q(V), MZ_Q(L));
+      if (tl < 8 && 4 * tl < n.A) *(f32x4 *)(s_lg + mt * 32 + 4 * tl) = mz_quad_sum(L);
+      const float v = mz_support_to_scalar_q(mz_quad_sum(V), n.Sv, n.vmin, n.no_transform, q8);
+      const double pe = exp((double)s_lg[mt * 32 + (tl < n.A ? tl : 0)]);     // mcts.py:52 (unconditional: no branch)
+      double pr = (tl < n.A) ? pe : 0.0;
+      asm volatile("" : "+v"(pr));       // pinned here: left alone, the compiler sinks the exp chain into the branch below
+      STAMP(9)
+      auto stampf = [&](int k) __attribute__((always_inline)) { STAMP(10 + k) };
+      if (full || b0 + mt < t.B) {
+        mz_tree_expand_f<TL, LT>(t, tm[0], tl, slot0 + sim + 1, s_rew[mt], pr, s_path + mt * MZ_FUSED_MAXPL,
+                                 s_stage + mt * 96, tr[0]);
+        stampf(0);
+        mz_tree_backup_select_f<TL, G, LT>(t, tm[0], tl, v, s_rew[mt], s_path + mt * MZ_FUSED_MAXPL, s_stage + mt * 96,
+                                           s_pbc, tr[0], sim + 1 < nsims, my_slot[0], my_act[0],
+                                           MzHiddenPrefetch{t.hpool, hoff[0], hv[0]}, stampf);
+      }
+    } else {
+      mz_bar();
+      STAMP(9)
+      // ---- tree: expand + backup (mcts.py:97-99), then the next descent (mcts.py:83-92)
 #pragma unroll
-    for (int i = 0; i < NPASS; ++i) {
-      const int mt = tid / TL + i * (256 / TL);
-      const int b = b0 + mt;
-      if (b < t.B) {
-        auto stampf = [&](int k) __attribute__((always_inline)) { STAMP(10 + k) };
-        mz_tree_step_fused<TL, G, LT>(t, tm[i], tl, slot0 + sim + 1, s_val[mt], s_rew[mt], s_lg + mt * 32,
-                                   s_path + mt * MZ_FUSED_MAXPL, (double *)red + mt * 96, s_pbc, tr[i],
-                                   sim + 1 < nsims, my_slot[i], my_act[i], t.hpool, hoff[i], hv[i], stampf);
+      for (int i = 0; i < NPASS; ++i) {
+        const int mt = tid / TL + i * (256 / TL);
+        const int b = b0 + mt;
+        if (b < t.B) {
+          auto stampf = [&](int k) __attribute__((always_inline)) { STAMP(10 + k) };
+          mz_tree_step_fused<TL, G, LT>(t, tm[i], tl, slot0 + sim + 1, s_val[mt], s_rew[mt], s_lg + mt * 32,
+                                     s_path + mt * MZ_FUSED_MAXPL, s_stage + mt * 96, s_pbc, tr[i],
+                                     sim + 1 < nsims, my_slot[i], my_act[i], t.hpool, hoff[i], hv[i], stampf);
+        }
       }
     }
     STAMP(13)
@@ -740,7 +774,7 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
       const int mt = tid / TL + i * (256 / TL);
-      if (b0 + mt < t.B) mz_finalize_record<TL, LT>(t, tm[i], sp, b0 + mt, tl, tr[i].legal, seed, (double *)red + mt * 96, n.O);
+      if (b0 + mt < t.B) mz_finalize_record<TL, LT>(t, tm[i], sp, b0 + mt, tl, tr[i].legal, seed, s_stage + mt * 96, n.O);
     }
   }
   // per-tree scalars back to the pool (what export / a later mz_select continue from)

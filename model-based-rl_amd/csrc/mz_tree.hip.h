@@ -272,14 +272,15 @@ struct MzHiddenPrefetch {
   __device__ __forceinline__ void leave() const { asm volatile("" : "+v"(hv)); }   // in flight: keep the destination reserved
 };
 
-// ---- Node.expand (mcts.py:47-55) for the pending leaf: priors of the new children, leaf bookkeeping
+// ---- Node.expand (mcts.py:47-55) for the pending leaf: priors of the new children, leaf bookkeeping.
+// p = math.exp(logit of action `lane`) (0 for lane >= A), computed by the caller (so that it can be scheduled
+// beside other work)
 template <int TL, bool LT>
 __device__ __forceinline__ void mz_tree_expand_f(const TreeView &t, const TreeMem<LT> &tm, int lane, int e_new,
-                                                 float reward, const float *logits, const int *s_path,
+                                                 float reward, double p, const int *s_path,
                                                  double *s_stage, const TreeRegs &tr) {
   const int A = t.A;
   const int leafnode = s_path[tr.len - 1];
-  const double p = (lane < A) ? exp((double)logits[lane]) : 0.0;
   if (lane < A) s_stage[lane] = p;              // every lane then adds them up in Python's sum() order
   double sum = 0.0;
   for (int a = 0; a < A; ++a) sum = sum + s_stage[a];
@@ -305,7 +306,7 @@ __device__ __forceinline__ void mz_tree_step_fused(const TreeView &t, const Tree
                                                    bool do_select, int &slot_out, int &act_out,
                                                    const float *hpool, unsigned hoff, f32x4 &hv,
                                                    STAMPF stampf = STAMPF()) {
-  mz_tree_expand_f<TL, LT>(t, tm, lane, e_new, reward, logits, s_path, s_stage, tr);
+  mz_tree_expand_f<TL, LT>(t, tm, lane, e_new, reward, (lane < t.A) ? exp((double)logits[lane]) : 0.0, s_path, s_stage, tr);
   stampf(0);
   mz_tree_backup_select_f<TL, G, LT>(t, tm, lane, value, reward, s_path, s_stage, pbctab, tr, do_select, slot_out,
                                      act_out, MzHiddenPrefetch{hpool, hoff, hv}, stampf);
