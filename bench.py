@@ -27,34 +27,64 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
 
-# BASELINE.json configs[1]: LunarLander-v2 shapes, FCNetwork, 30 simulations, 4096 parallel envs per GPU
-B, O, A, SIMS, EPISODE_LEN = 4096, 8, 4, 30, 256
+# BASELINE.json configs[1] (the headline, default): LunarLander-v2 shapes, FCNetwork, 30 simulations, 4096 parallel
+# envs per GPU.  --workload pong = configs[3]'s shapes on one GPU (Pong-ram: obs 128, 6 actions, 50 simulations), a
+# secondary line for profiles/, never the headline.
+WORKLOADS = {'lunar': ('LunarLander-v2', 4096, 8, 4, 30, 256), 'pong': ('Pong-ramNoFrameskip-v4', 4096, 128, 6, 50, 1024)}
+WNAME, B, O, A, SIMS, EPISODE_LEN = WORKLOADS['lunar']
+for _i, _a in enumerate(sys.argv):
+  if _a == '--workload' and _i + 1 < len(sys.argv):
+    WNAME, B, O, A, SIMS, EPISODE_LEN = WORKLOADS[sys.argv[_i + 1]]
 CHUNK = 8                       # moves per drain/ingest chunk
 FLOP_PER_SIM = 2 * 512 * (312 + 3 * A)            # 331 776 for A = 4
-FLOP_PER_ROOT = 2 * 512 * (O + 181 + A)           # 197 632
+FLOP_PER_ROOT = 2 * 512 * (O + 181 + A)           # 197 632 for O = 8, A = 4
 PEAK_F32_MFMA_TFLOPS = 157.3                      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 
 
 def cpu_baseline(weights):
-  """The CPU oracle (C restatement of the reference path, oracle/mz_oracle.c) timed on ONE host core on a
-  bounded sample of the same workload.  Reported beside the GPU number; it is not the target."""
+  """The CPU oracle (C restatement of the reference path, oracle/mz_oracle.c) timed on the host cores on a bounded
+  sample of the same workload: one thread per core (up to 64), every thread its own batch of environments -- the
+  layout of the reference's Ray actors (one single-threaded process per actor, train.py:63,72).  The C call releases
+  the GIL.  Reported beside the GPU number; it is not the target."""
+  import threading
   from oracle import oracle as orc
-  envs, moves = 256, 40       # ~10-15 s of single-core work
-  rng = np.random.RandomState(0)
+  envs, moves = 256, 24       # ~10 s of work per core
+  cores = max(1, min(64, os.cpu_count() or 1))
   net = orc.FCNet(weights, O, A)
-  t = orc.Trees(orc.tree_cfg(A, SIMS), envs)
-  obs = rng.standard_normal((envs, O)).astype(np.float32)
-  noise = rng.dirichlet([0.25] * A, size=envs)
-  t.search_fc(net, obs, np.ones(envs, np.int8), None, noise, 0.25)      # warm-up
+
+  def make(seed):
+    rng = np.random.RandomState(seed)
+    t = orc.Trees(orc.tree_cfg(A, SIMS), envs)
+    obs = rng.standard_normal((envs, O)).astype(np.float32)
+    noise = rng.dirichlet([0.25] * A, size=envs)
+    return rng, t, obs, noise
+
+  def work(state, n):
+    rng, t, obs, noise = state
+    for _ in range(n):
+      t.search_fc(net, obs, np.ones(envs, np.int8), None, noise, 0.25)
+      t.finalize(1.0, rng.uniform(size=envs))
+
+  one = make(0)
+  work(one, 1)                # warm-up
   t0 = time.perf_counter()
-  for _ in range(moves):
-    t.search_fc(net, obs, np.ones(envs, np.int8), None, noise, 0.25)
-    t.finalize(1.0, rng.uniform(size=envs))
+  work(one, moves // 4)
+  dt1 = time.perf_counter() - t0
+  single = envs * (moves // 4) / dt1
+  states = [make(i) for i in range(cores)]
+  for st in states:
+    work(st, 1)
+  threads = [threading.Thread(target=work, args=(st, moves)) for st in states]
+  t0 = time.perf_counter()
+  for th in threads:
+    th.start()
+  for th in threads:
+    th.join()
   dt = time.perf_counter() - t0
-  return {'value': envs * moves / dt, 'unit': 'env-steps/s', 'cores': 1, 'kind': 'port',
-          'sample': '%d envs x %d moves x %d simulations, oracle/mz_oracle.c (gcc -O2, scalar float32 net + '
-                    'double tree), %.1f s' % (envs, moves, SIMS, dt),
-          'host_cpus': os.cpu_count()}
+  return {'value': cores * envs * moves / dt, 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port',
+          'sample': '%d threads x %d envs x %d moves x %d simulations, oracle/mz_oracle.c (gcc -O2, scalar float32 net + '
+                    'double tree), %.1f s' % (cores, envs, moves, SIMS, dt),
+          'single_core_value': single, 'host_cpus': os.cpu_count()}
 
 
 def main():
@@ -63,6 +93,7 @@ def main():
   ap.add_argument('--steps', type=int, default=512)
   ap.add_argument('--warmup', type=int, default=64)
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--workload', choices=sorted(WORKLOADS), default='lunar')
   ap.add_argument('--sync-every', type=int, default=128,
                   help='moves between weight pulls (the path\'s one exchange: broadcast + repack); 0 = only once')
   args = ap.parse_args()
@@ -188,15 +219,15 @@ def main():
     traffic = None
     tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
     if os.path.exists(tfile):
-      traffic = json.load(open(tfile)).get('k_search_fused', {}).get('hbm_bytes_per_launch')
+      traffic = json.load(open(tfile)).get('k_search_fused', {}).get('hbm_bytes_per_launch') if WNAME.startswith('Lunar') else None
     out = {
-        'metric': 'env-steps/sec (self-play, whole node) at num_simulations=30',
+        'metric': 'env-steps/sec (self-play, whole node) at num_simulations=%d' % SIMS,
         'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': 'LunarLander-v2 shapes (obs 8, actions 4), FCNetwork, num_simulations=30, '
+        'config': {'workload': '%s shapes (obs %d, actions %d), FCNetwork, num_simulations=%d, '
                                '%d parallel self-play envs per GPU, synthetic fixed-length episodes T=%d, '
-                               'random-init weights (torch.manual_seed(0))' % (B, EPISODE_LEN),
+                               'random-init weights (torch.manual_seed(0))' % (WNAME, O, A, SIMS, B, EPISODE_LEN),
                    'envs_per_gpu': B, 'num_simulations': SIMS, 'episode_len': EPISODE_LEN,
                    'priming': '%d untimed moves before warm-up so episode ends are in steady state' % EPISODE_LEN,
                    'sharding': 'env-id sharded, %d rank(s), RCCL weight broadcast' % world,

@@ -375,7 +375,7 @@ __device__ __forceinline__ float mz_support_to_scalar_q(const f32x4 &raw, int S,
 
 // dynamic LDS of the fused kernel: pb_c table [(sims+2)^2] doubles, then (LT) the 16 trees' node arrays
 __host__ __device__ inline size_t mz_fused_dyn_lds(int sims, int NN, bool lt) {
-  size_t b = (size_t)(sims + 2) * (sims + 2) * 8;
+  size_t b = (size_t)(sims + 2) * 64 * 8;        // pb_c table, rows 64 entries apart
   if (lt) b += (size_t)16 * NN * (8 + 8 + 8 + 4 + 2 + 2 + 1) + 64;
   return b;
 }
@@ -436,9 +436,9 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
 
   __shared__ __attribute__((aligned(16))) float smem[MZ_FUSED_LDS_FLOATS];
   extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
-  double *s_pbc = (double *)dyn_lds;       // pb_c(Np, Nc) table (host-computed, exact), [sims+2][sims+2]
+  double *s_pbc = (double *)dyn_lds;       // pb_c(Np, Nc) table (host-computed, exact), [sims+2][64]
   // (LT) the workgroup's 16 trees live in LDS for the whole launch
-  double *l_W = s_pbc + (t.sims + 2) * (t.sims + 2);
+  double *l_W = s_pbc + (t.sims + 2) * 64;
   double *l_P = l_W + 16 * t.NN;
   double *l_Q = l_P + 16 * t.NN;
   float *l_R = (float *)(l_Q + 16 * t.NN);
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
   if (tid < 32 + 16 * JTP) s_b4[tid] = n.b4[tid];
   if (tid < 64) { s_lnw[tid] = n.lnw[tid]; s_lnb[tid] = n.lnb[tid]; }
   for (int i = tid; i < 16 * MZ_XE; i += 256) xEp[i] = (i % MZ_XE == 0) ? 1.f : 0.f;
-  for (int i = tid; i < (t.sims + 2) * (t.sims + 2); i += 256) s_pbc[i] = t.pbctab[i];
+  for (int i = tid; i < (t.sims + 2) * (t.sims + 2); i += 256) s_pbc[(i / (t.sims + 2)) * 64 + i % (t.sims + 2)] = t.pbctab[i];
 
   // tree-lane mapping: TL lanes per tree (16, or 32 when A > 16), 256/TL trees per pass
   constexpr int TL = (G <= 16) ? 16 : 32;

@@ -386,7 +386,21 @@ __device__ __forceinline__ void mz_tree_backup_select_f(const TreeView &t, const
   const double mn = tr.mn, mx = tr.mx;
   const double span = mx - mn;
   const bool span_pos = mx > mn, span_zero = mx == mn;
-  const int T = t.sims + 2;
+  // MinMaxStats.normalize divides by the same span at every level of this descent: the reciprocal (the rcp + two
+  // Newton steps of the compiler's own f64 division) is taken once, a level then costs mul + fma + fma -- the tail
+  // of that same expansion, bit-identical to (x - mn) / span as long as v_div_scale would not rescale the operands
+  // (scripts/fastdiv_check.hip: 0 differences in 8e7 quotients).  Outside a generous exponent window the level
+  // falls back to the division itself.
+  double yspan = 0.0;
+  bool fast_ok = true;
+  if (span_pos) {
+    fast_ok = (span > 0x1p-200) & (span < 0x1p200);
+    double y0 = __builtin_amdgcn_rcp(span);
+    double e0 = __builtin_fma(-span, y0, 1.0);
+    y0 = __builtin_fma(y0, e0, y0);
+    e0 = __builtin_fma(-span, y0, 1.0);
+    yspan = __builtin_fma(y0, e0, y0);
+  }
   int node = 0, e = 0, Np = root_n, tpc = tr.root_tp, len2 = 1, a_sel = -1, parent_e = 0;
   if (lane == 0) s_path[0] = 0;
   // the TL lanes of a tree evaluate the children in TL/G redundant copies (child = lane % G), so the
@@ -395,31 +409,36 @@ __device__ __forceinline__ void mz_tree_backup_select_f(const TreeView &t, const
   while (e >= 0) {
     levelf.enter(e);
     const bool valid = (cl < A) & ((node != 0) | (((tr.legal >> cl) & 1u) != 0));
-    const int ch = valid ? 1 + e * A + cl : 0;
-    int Nc = tm.N[ch];
-    int Ec = tm.E[ch];
+    const int ch = valid ? 1 + __mul24(e, A) + cl : 0;
+    const int Nc = tm.N[ch];
+    const int Ec = tm.E[ch];
     const double p = tm.P[ch];
     const double rc = (double)tm.R[ch];
-    const double prior_score = pbctab[Np * T + Nc] * p;
+    const double prior_score = pbctab[(Np << 6) + Nc] * p;       // table rows are 64 entries apart (a shift, no multiply)
     double q;
     if constexpr (LT) q = tm.Q[ch];        // cached by the backup; unused (may be stale or garbage) while Nc == 0
     else q = tm.W[ch] / (double)(Nc > 0 ? Nc : 1);
     const double x = rc + g * (two ? -q : q);
-    const double nrm = (x - mn) / span;
+    const double xm = x - mn;
+    const double q0 = xm * yspan;
+    const double r0 = __builtin_fma(-span, q0, xm);
+    double nrm = __builtin_fma(r0, yspan, q0);
+    if (!fast_ok) nrm = xm / span;
     const double visited = span_pos ? nrm : (span_zero ? 1.0 : x);
     const double ucb = prior_score + ((Nc > 0) ? visited : t.init_value_score);
-    double score = (Np == 0) ? p : ucb;
+    // tuple max over (score, action); absent children carry score -inf and action -1 (no finite score loses to them,
+    // and among themselves nothing is taken), the winner's expansion index and visit count ride along in one word
+    double score = valid ? ((Np == 0) ? p : ucb) : -__builtin_inf();
     int best = valid ? cl : -1;
-    // tuple max over (score, action) with the winner's expansion index and visit count as payload
+    int pay = (Nc << 16) | (Ec & 0xffff);
 #define MZ_AM_STEP(OFF)                                                                          \
   {                                                                                              \
     const double os = mz_xchg_d<OFF>(score);                                                     \
-    const int ob = mz_xchg_i<OFF>(best), oe = mz_xchg_i<OFF>(Ec), on = mz_xchg_i<OFF>(Nc);       \
-    const bool take = (ob >= 0) & ((best < 0) | (os > score) | ((os == score) & (ob > best)));   \
+    const int ob = mz_xchg_i<OFF>(best), op = mz_xchg_i<OFF>(pay);                               \
+    const bool take = (os > score) | ((os == score) & (ob > best));                              \
     score = take ? os : score;                                                                   \
     best = take ? ob : best;                                                                     \
-    Ec = take ? oe : Ec;                                                                         \
-    Nc = take ? on : Nc;                                                                         \
+    pay = take ? op : pay;                                                                       \
   }
     if constexpr (G > 1) MZ_AM_STEP(1)
     if constexpr (G > 2) MZ_AM_STEP(2)
@@ -429,12 +448,12 @@ __device__ __forceinline__ void mz_tree_backup_select_f(const TreeView &t, const
 #undef MZ_AM_STEP
     a_sel = best;
     parent_e = e;
-    node = 1 + e * A + a_sel;
+    node = 1 + __mul24(e, A) + a_sel;
     if (lane == 0) s_path[len2] = node;
     ++len2;
     if (two) tpc = -tpc;
-    e = Ec;
-    Np = Nc;
+    e = (int)(int16_t)(pay & 0xffff);
+    Np = pay >> 16;
     levelf.leave();
   }
   tr.len = len2;
