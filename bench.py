@@ -195,22 +195,16 @@ def main():
     frames = float(ff.item())
   env_steps = world * B * args.steps       # env.step() calls in the timed region, all ranks
 
-  # dominant kernel = k_search_fused (one launch = all 30 simulations of all 4096 trees: descent, f32-MFMA
-  # dynamics+prediction, expand, backup).  Its duration is measured live with HIP events on the stream it
-  # is launched on, around the mz_search call alone (root preparation is outside the bracket).
-  reps = 20
-  obs = torch.randn(B, O, device=device)
-  stream = torch.cuda.current_stream(device)
-  ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
-  ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
-  for i in range(reps):
-    eng.initial_inference(obs)
-    eng.root_prepare(None, None, None, device_rng=True, move=10 ** 6 + i)
-    ev0[i].record(stream)
-    eng.search()
-    ev1[i].record(stream)
-  torch.cuda.synchronize(device)
-  search_us = 1e3 * float(np.median([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+  # dominant kernel = k_search_fused (one launch = all simulations of all trees of this rank + the end of the move:
+  # descent, f32-MFMA dynamics + prediction, expand, backup, action/record).  Its duration is measured live with HIP
+  # events on the stream it is launched on: start / stop events of every dispatch (mz_selfplay_steps_timed, the
+  # timestamps rocprofv3's kernel trace reports) over a stretch of the same self-play loop, launched back to back.
+  durs = []
+  for _ in range(4):
+    durs += eng.selfplay_steps_timed(CHUNK)
+    eng.selfplay_drain(pinned[0], CHUNK)
+    torch.cuda.synchronize(device)
+  search_us = 1e3 * float(np.mean(durs[CHUNK:]))       # (first chunk = warm-up)
 
   if rank == 0:
     value = frames / dt

@@ -119,6 +119,11 @@ int mz_search(mz_engine *e, int num_simulations, void *stream);
  * num_simulations recurrent-inference launches, ms_out[1] = summed time of the tree-step launches. */
 int mz_search_profiled(mz_engine *e, int num_simulations, float *ms_out, void *stream);
 
+/* mz_search with HIP events bracketing the dispatch of the fused search kernel itself (hipExtLaunchKernelGGL start /
+ * stop events on `stream`, the same timestamps rocprofv3's kernel trace reports); call right after mz_root_prepare;
+ * synchronous.  ms_out[0] = duration of the launch in milliseconds.  bench.py's roofline figure comes from here. */
+int mz_search_timed(mz_engine *e, int num_simulations, float *ms_out, void *stream);
+
 /* Diagnostic build of the fused search kernel with in-kernel s_memtime stamps (never used for timing
  * claims): cycles_out [host][4 waves][14 phases] = per-wave cycle totals over num_simulations, averaged
  * over workgroups.  Phases: 0 gather, 1 barrier, 2 dynamics fc1, 3 dynamics fc2, 4 combine, 5 LN/reward,
@@ -182,6 +187,11 @@ int mz_padded_envs(const mz_engine *e);
  * stagger != 0: env i starts its first episode at t0 = hash(env id) % episode_len (uniform episode ends). */
 int mz_selfplay_reset(mz_engine *e, int episode_len, double temperature, int stagger, void *stream);
 int mz_selfplay_steps(mz_engine *e, int moves, void *stream);
+/* mz_selfplay_steps with one pair of HIP events around every search-kernel dispatch (hipExtLaunchKernelGGL start / stop
+ * events on `stream`: the timestamps rocprofv3's kernel trace reports).  The k moves are launched eagerly, back to back,
+ * with no synchronisation in between (the state of the timed loop); synchronous at the end.  ms_out [host][k] =
+ * duration of each search launch in milliseconds.  bench.py's roofline figure is the mean of these. */
+int mz_selfplay_steps_timed(mz_engine *e, int k, float *ms_out, void *stream);
 int mz_selfplay_rec_floats(const mz_engine *e);
 int mz_selfplay_ring_moves(const mz_engine *e);
 int mz_selfplay_drain(mz_engine *e, float *out, int max_moves, int *n_moves, void *stream);

@@ -65,6 +65,7 @@ SIGNATURES = {
     'mz_last_paths': (_I, [_VP, _VP, _VP, _VP]),
     'mz_search': (_I, [_VP, _I, _VP]),
     'mz_search_profiled': (_I, [_VP, _I, _VP, _VP]),
+    'mz_search_timed': (_I, [_VP, _I, _VP, _VP]),
     'mz_search_phase_profile': (_I, [_VP, _I, _VP, _VP]),
     'mz_select': (_I, [_VP, _VP, _VP, _VP, _VP, _VP]),
     'mz_gather_hidden': (_I, [_VP, _VP, _VP]),
@@ -76,6 +77,7 @@ SIGNATURES = {
     'mz_padded_envs': (_I, [_VP]),
     'mz_selfplay_reset': (_I, [_VP, _I, _D, _I, _VP]),
     'mz_selfplay_steps': (_I, [_VP, _I, _VP]),
+    'mz_selfplay_steps_timed': (_I, [_VP, _I, _VP, _VP]),
     'mz_selfplay_rec_floats': (_I, [_VP]),
     'mz_selfplay_ring_moves': (_I, [_VP]),
     'mz_selfplay_drain': (_I, [_VP, _VP, _I, C.POINTER(_I), _VP]),

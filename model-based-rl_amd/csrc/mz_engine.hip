@@ -2,6 +2,7 @@
 // kernels in mz_tree.hip.h / mz_net.hip.h / mz_selfplay.hip.h.  No torch types, no CPU fallback:
 // every entry point launches HIP kernels on the stream it is given.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -70,6 +71,7 @@ struct mz_engine {
   bool use_lds_trees = true;
   bool fuse_record = false;         // set by the self-play loop around its search launch: finalize + record in the kernel tail
   unsigned long long *prof_buf = nullptr;   // non-null only inside mz_search_phase_profile
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;   // non-null only inside mz_search_timed: bracket the search kernel's dispatch
 };
 
 template <typename T>
@@ -349,6 +351,11 @@ static int launch_fused_lt(mz_engine *e, int num_simulations, int sims_done, hip
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)sizeof(float) * MZ_FUSED_LDS_FLOATS));
       attr_set = true;
     }
+    if (e->ev_start)      // timestamps of the dispatch itself (what rocprofv3's kernel trace reports), no launch gap inside
+      hipExtLaunchKernelGGL((k_search_fused<KS1, JTP, G, LT, false>), dim3(e->Bp / MZ_ROWS), dim3(256), dyn, s,
+                            e->ev_start, e->ev_stop, 0, e->nv, e->tv, e->wstream, num_simulations, sims_done,
+                            (unsigned long long *)nullptr, e->sp, e->fuse_record ? 1 : 0, (uint64_t)e->cfg.seed);
+    else
     hipLaunchKernelGGL((k_search_fused<KS1, JTP, G, LT, false>), dim3(e->Bp / MZ_ROWS), dim3(256), dyn, s, e->nv,
                        e->tv, e->wstream, num_simulations, sims_done, (unsigned long long *)nullptr, e->sp,
                        e->fuse_record ? 1 : 0, (uint64_t)e->cfg.seed);
@@ -667,6 +674,30 @@ int mz_search_profiled(mz_engine *e, int num_simulations, float *ms_out, void *s
     ms_out[0] += a; ms_out[1] += b;
   }
   for (auto &x : ev) hipEventDestroy(x);
+  e->sims_done = num_simulations;
+  e->selection_valid = false;
+  return 0;
+}
+
+int mz_search_timed(mz_engine *e, int num_simulations, float *ms_out, void *stream) {
+  if (!e || !ms_out) return fail("mz_search_timed: null argument");
+  if (!e->use_fused || e->sims + 2 > MZ_FUSED_MAXPL) return fail("mz_search_timed: fused kernel not in use");
+  if (!e->weights_set) return fail("mz_search_timed: weights not set (call mz_set_weights)");
+  if (!e->root_ready || !e->selection_valid || e->sims_done != 0)
+    return fail("mz_search_timed: call right after mz_root_prepare");
+  if (num_simulations < 1 || num_simulations > e->sims) return fail("mz_search_timed: bad num_simulations");
+  hipStream_t s = (hipStream_t)stream;
+  HIPCHECK(hipEventCreate(&e->ev_start));
+  HIPCHECK(hipEventCreate(&e->ev_stop));
+  const int rc = launch_fused(e, num_simulations, 0, s);
+  hipError_t se = hipStreamSynchronize(s);
+  float ms = 0.f;
+  hipError_t te = (rc == 0 && se == hipSuccess) ? hipEventElapsedTime(&ms, e->ev_start, e->ev_stop) : hipErrorUnknown;
+  hipEventDestroy(e->ev_start); hipEventDestroy(e->ev_stop);
+  e->ev_start = e->ev_stop = nullptr;
+  if (rc) return -1;
+  if (se != hipSuccess || te != hipSuccess) return fail("mz_search_timed: %s", hipGetErrorString(se != hipSuccess ? se : te));
+  *ms_out = ms;
   e->sims_done = num_simulations;
   e->selection_valid = false;
   return 0;

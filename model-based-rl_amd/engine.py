@@ -182,6 +182,13 @@ class Engine(object):
     _abi.check(self.lib.mz_search_profiled(self._h, n, ms, self.stream), 'mz_search_profiled')
     return float(ms[0]), float(ms[1])
 
+  def search_timed(self, num_simulations=None):
+    """mz_search with events around the search kernel's own dispatch; returns milliseconds (synchronous)."""
+    n = self.sims if num_simulations is None else int(num_simulations)
+    ms = (C.c_float * 1)()
+    _abi.check(self.lib.mz_search_timed(self._h, n, ms, self.stream), 'mz_search_timed')
+    return float(ms[0])
+
   def search_phase_profile(self, num_simulations=None):
     n = self.sims if num_simulations is None else int(num_simulations)
     out = np.zeros((4, 14), np.uint64)
@@ -250,6 +257,13 @@ class Engine(object):
 
   def selfplay_steps(self, moves):
     _abi.check(self.lib.mz_selfplay_steps(self._h, int(moves), self.stream), 'mz_selfplay_steps')
+
+  def selfplay_steps_timed(self, moves):
+    """moves self-play moves launched eagerly back to back, events around every search-kernel dispatch;
+    returns the durations in milliseconds (synchronous)."""
+    ms = (C.c_float * int(moves))()
+    _abi.check(self.lib.mz_selfplay_steps_timed(self._h, int(moves), ms, self.stream), 'mz_selfplay_steps_timed')
+    return [float(x) for x in ms]
 
   def selfplay_drain(self, out=None, max_moves=None, copy_stream=None):
     """Asynchronous D2H of the records produced since the last drain into pinned memory; returns
