@@ -69,6 +69,7 @@ struct mz_engine {
   int ks1sel = 0;                   // fc1 k-steps of the fused kernel instantiation chosen for this A
   bool use_fused = true;
   bool use_lds_trees = true;
+  bool use_lds_hybrid = true;
   bool fuse_record = false;         // set by the self-play loop around its search launch: finalize + record in the kernel tail
   unsigned long long *prof_buf = nullptr;   // non-null only inside mz_search_phase_profile
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;   // non-null only inside mz_search_timed: bracket the search kernel's dispatch
@@ -333,14 +334,14 @@ static int launch_root(mz_engine *e, const float *obs, bool selfplay, hipStream_
   return e->jtp == 1 ? launch_root_j<1>(e, obs, selfplay, s) : launch_root_j<2>(e, obs, selfplay, s);
 }
 
-template <int KS1, int JTP, int G, bool LT>
+template <int KS1, int JTP, int G, int LT>
 static int launch_fused_lt(mz_engine *e, int num_simulations, int sims_done, hipStream_t s) {
   static bool attr_set = false, attr_set_prof = false;
   const size_t dyn = mz_fused_dyn_lds(e->sims, e->NN, LT);
   if (e->prof_buf) {
     if (!attr_set_prof) {
       HIPCHECK(hipFuncSetAttribute((const void *)k_search_fused<KS1, JTP, G, LT, true>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)sizeof(float) * MZ_FUSED_LDS_FLOATS));
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)sizeof(float) * mz_fused_lds_floats(LT)));
       attr_set_prof = true;
     }
     hipLaunchKernelGGL((k_search_fused<KS1, JTP, G, LT, true>), dim3(e->Bp / MZ_ROWS), dim3(256), dyn, s, e->nv,
@@ -348,7 +349,7 @@ static int launch_fused_lt(mz_engine *e, int num_simulations, int sims_done, hip
   } else {
     if (!attr_set) {
       HIPCHECK(hipFuncSetAttribute((const void *)k_search_fused<KS1, JTP, G, LT, false>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)sizeof(float) * MZ_FUSED_LDS_FLOATS));
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)sizeof(float) * mz_fused_lds_floats(LT)));
       attr_set = true;
     }
     if (e->ev_start)      // timestamps of the dispatch itself (what rocprofv3's kernel trace reports), no launch gap inside
@@ -364,12 +365,17 @@ static int launch_fused_lt(mz_engine *e, int num_simulations, int sims_done, hip
   return 0;
 }
 
-// trees in LDS when 16 of them fit beside the kernel's static LDS (160 KiB per CU), else in the global pool
+// trees in LDS when 16 of them fit beside the kernel's static LDS (160 KiB per CU); if not, at least the fields the
+// descent reads (N, E, P, reward + discount * Q); else in the global pool
 template <int KS1, int JTP, int G>
 static int launch_fused_t(mz_engine *e, int num_simulations, int sims_done, hipStream_t s) {
-  const size_t need = sizeof(float) * MZ_FUSED_LDS_FLOATS + mz_fused_dyn_lds(e->sims, e->NN, true);
-  if (e->use_lds_trees && need <= 160 * 1024) return launch_fused_lt<KS1, JTP, G, true>(e, num_simulations, sims_done, s);
-  return launch_fused_lt<KS1, JTP, G, false>(e, num_simulations, sims_done, s);
+  if (e->use_lds_trees) {
+    if (sizeof(float) * mz_fused_lds_floats(1) + mz_fused_dyn_lds(e->sims, e->NN, 1) <= 160 * 1024)
+      return launch_fused_lt<KS1, JTP, G, 1>(e, num_simulations, sims_done, s);
+    if (e->use_lds_hybrid && sizeof(float) * mz_fused_lds_floats(2) + mz_fused_dyn_lds(e->sims, e->NN, 2) <= 160 * 1024)
+      return launch_fused_lt<KS1, JTP, G, 2>(e, num_simulations, sims_done, s);
+  }
+  return launch_fused_lt<KS1, JTP, G, 0>(e, num_simulations, sims_done, s);
 }
 
 // fused-kernel instantiations: (fc1 k-steps, policy tiles, lanes per tree) by action count
@@ -446,6 +452,7 @@ int mz_create(const mz_config *cfg, mz_engine **out) {
   e->use_graph = getenv("MZ_NO_GRAPH") == nullptr;
   e->use_fused = getenv("MZ_NO_FUSED") == nullptr;
   e->use_lds_trees = getenv("MZ_NO_LDS_TREES") == nullptr;
+  e->use_lds_hybrid = getenv("MZ_NO_LDS_HYBRID") == nullptr;
   TreeView &t = e->tv;
   memset(&t, 0, sizeof t);
   const size_t nb = (size_t)e->Bp, nn = nb * e->NN;

@@ -360,7 +360,9 @@ __device__ __forceinline__ float mz_support_to_scalar_q(const f32x4 &raw, int S,
 }
 
 #define MZ_FUSED_MAXPL 64   // search-path slots per tree kept in LDS: num_simulations + 2 <= 64
-#define MZ_FUSED_LDS_FLOATS (16 * MZ_HS + 4 * 6 * 256 + 16 + 16 + 16 * 32 + 96 + 64 + 64 + 64 + 2 * 16 * MZ_XE + 16 * MZ_FUSED_MAXPL + 16 * 96 * 2)
+#define MZ_FUSED_LDS_BASE (16 * MZ_HS + 4 * 6 * 256 + 16 + 16 + 16 * 32 + 96 + 64 + 64 + 64 + 2 * 16 * MZ_XE + 16 * MZ_FUSED_MAXPL)
+// + the tree step's own staging [16][96] doubles, except beside large trees (LT = 2), where it shares the partials' space
+__host__ __device__ constexpr int mz_fused_lds_floats(int lt) { return MZ_FUSED_LDS_BASE + (lt == 2 ? 0 : 16 * 96 * 2); }
 
 // PROF: diagnostic build only (mz_search_phase_profile): per-wave cycle totals of each phase of the loop.
 #define MZ_NPHASE 14
@@ -373,10 +375,12 @@ __device__ __forceinline__ float mz_support_to_scalar_q(const f32x4 &raw, int S,
     tlast = now_;                                                              \
   }
 
-// dynamic LDS of the fused kernel: pb_c table [(sims+2)^2] doubles, then (LT) the 16 trees' node arrays
-__host__ __device__ inline size_t mz_fused_dyn_lds(int sims, int NN, bool lt) {
-  size_t b = (size_t)(sims + 2) * 64 * 8;        // pb_c table, rows 64 entries apart
-  if (lt) b += (size_t)16 * NN * (8 + 8 + 8 + 4 + 2 + 2 + 1) + 64;
+// dynamic LDS of the fused kernel: pb_c table, then the 16 trees' node arrays (lt = 1: everything + Q cache, rows of the
+// table 64 apart; lt = 2: N, E, P, X only, rows sims + 2 apart; lt = 0: table only)
+__host__ __device__ inline size_t mz_fused_dyn_lds(int sims, int NN, int lt) {
+  size_t b = (size_t)(sims + 2) * (lt == 2 ? sims + 2 : 64) * 8;
+  if (lt == 1) b += (size_t)16 * NN * (8 + 8 + 8 + 4 + 2 + 2 + 1) + 64;
+  if (lt == 2) b += (size_t)16 * NN * (8 + 8 + 2 + 2) + 64;
   return b;
 }
 
@@ -385,7 +389,7 @@ __host__ __device__ inline size_t mz_fused_dyn_lds(int sims, int NN, bool lt) {
 // Game.store_search_statistics, root error, Game.apply on the synthetic env and the experience record
 // (the stand-alone k_env_step_record does the same from the global pool).  Lane a stages child a's visit count
 // in LDS, lane 0 then runs the reference's sequential arithmetic (mz_sample_index) on the staged vector.
-template <int TL, bool LT>
+template <int TL, int LT>
 __device__ __forceinline__ void mz_finalize_record(const TreeView &t, const TreeMem<LT> &tm, const SelfplayState &sp,
                                                    int b, int lane, uint32_t legal, uint64_t seed, double *stage,
                                                    int O) {
@@ -424,7 +428,7 @@ __device__ __forceinline__ void mz_finalize_record(const TreeView &t, const Tree
   }
 }
 
-template <int KS1, int JTP, int G, bool LT, bool PROF>
+template <int KS1, int JTP, int G, int LT, bool PROF>
 __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, const f32x4 *wstream, int nsims,
                                                           int slot0, unsigned long long *prof, SelfplayState sp,
                                                           int record, uint64_t seed) {
@@ -434,15 +438,16 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
   constexpr int E_FC1 = SC::FC1, E_FC2 = E_FC1 + SC::FC2, E_P1 = E_FC2 + SC::P1, E_P2 = E_P1 + SC::P2;
   constexpr int NJ2 = 2 + JTP;
 
-  __shared__ __attribute__((aligned(16))) float smem[MZ_FUSED_LDS_FLOATS];
+  __shared__ __attribute__((aligned(16))) float smem[mz_fused_lds_floats(LT)];
   extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
-  double *s_pbc = (double *)dyn_lds;       // pb_c(Np, Nc) table (host-computed, exact), [sims+2][64]
-  // (LT) the workgroup's 16 trees live in LDS for the whole launch
-  double *l_W = s_pbc + (t.sims + 2) * 64;
-  double *l_P = l_W + 16 * t.NN;
-  double *l_Q = l_P + 16 * t.NN;
-  float *l_R = (float *)(l_Q + 16 * t.NN);
-  int16_t *l_N = (int16_t *)(l_R + 16 * t.NN);
+  double *s_pbc = (double *)dyn_lds;       // pb_c(Np, Nc) table (host-computed, exact), rows PBS entries apart
+  const int PBS = (LT == 2) ? t.sims + 2 : 64;
+  // (LT = 1, 2) the workgroup's 16 trees live in LDS for the whole launch (LT = 2: the descent's fields only)
+  double *l_P = s_pbc + (t.sims + 2) * PBS;
+  double *l_Q = l_P + 16 * t.NN;                     // X cache
+  double *l_W = l_Q + 16 * t.NN;                     // LT = 1 only from here on
+  float *l_R = (float *)(l_W + 16 * t.NN);
+  int16_t *l_N = (LT == 2) ? (int16_t *)l_W : (int16_t *)(l_R + 16 * t.NN);
   int16_t *l_E = l_N + 16 * t.NN;
   int8_t *l_TP = (int8_t *)(l_E + 16 * t.NN);
   float *xR = smem;                       // [16][MZ_HS] x tile, row-major
@@ -457,8 +462,9 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
   float *xEd = s_lnb + 64;                // [16][MZ_XE] dynamics extension: one-hot(action), then 1 (bias column)
   float *xEp = xEd + 16 * MZ_XE;          // [16][MZ_XE] prediction extension: 1 (bias column), then 0
   int *s_path = (int *)(xEp + 16 * MZ_XE); // [16][MZ_FUSED_MAXPL] pending search path of every tree
-  double *s_stage = (double *)(s_path + 16 * MZ_FUSED_MAXPL);      // [16][96] staging of the tree step (its own: the
-                                                                   // tree step of one wave overlaps other waves' epilogue)
+  // [16][96] staging of the tree step: its own (the tree step of one wave overlaps other waves' epilogue), except
+  // beside large trees, where it shares the partials' space and the tree step starts behind a barrier
+  double *s_stage = (LT == 2) ? (double *)red : (double *)(s_path + 16 * MZ_FUSED_MAXPL);
 
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
   const int g4 = lane >> 4, m16 = lane & 15;
@@ -470,7 +476,7 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
   if (tid < 32 + 16 * JTP) s_b4[tid] = n.b4[tid];
   if (tid < 64) { s_lnw[tid] = n.lnw[tid]; s_lnb[tid] = n.lnb[tid]; }
   for (int i = tid; i < 16 * MZ_XE; i += 256) xEp[i] = (i % MZ_XE == 0) ? 1.f : 0.f;
-  for (int i = tid; i < (t.sims + 2) * (t.sims + 2); i += 256) s_pbc[(i / (t.sims + 2)) * 64 + i % (t.sims + 2)] = t.pbctab[i];
+  for (int i = tid; i < (t.sims + 2) * (t.sims + 2); i += 256) s_pbc[(i / (t.sims + 2)) * PBS + i % (t.sims + 2)] = t.pbctab[i];
 
   // tree-lane mapping: TL lanes per tree (16, or 32 when A > 16), 256/TL trees per pass
   constexpr int TL = (G <= 16) ? 16 : 32;
@@ -483,10 +489,15 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
   for (int i = 0; i < NPASS; ++i) {
     const int mt = tid / TL + i * (256 / TL);
     const int b = b0 + mt;
-    if constexpr (LT) {
+    if constexpr (LT == 1) {
       const int o = mt * t.NN;
       tm[i].N = l_N + o; tm[i].W = l_W + o; tm[i].P = l_P + o; tm[i].R = l_R + o; tm[i].E = l_E + o; tm[i].TP = l_TP + o;
-      tm[i].Q = l_Q + o;
+      tm[i].X = l_Q + o;
+    } else if constexpr (LT == 2) {
+      const int o = mt * t.NN;
+      const size_t og = (size_t)(b < t.B ? b : 0) * t.NN;
+      tm[i].N = l_N + o; tm[i].E = l_E + o; tm[i].P = l_P + o; tm[i].X = l_Q + o;
+      tm[i].W = t.W + og; tm[i].R = t.R + og; tm[i].TP = t.TP + og;
     } else {
       const size_t o = (size_t)(b < t.B ? b : 0) * t.NN;
       tm[i].N = t.N + o; tm[i].W = t.W + o; tm[i].P = t.P + o; tm[i].R = t.R + o; tm[i].E = t.E + o; tm[i].TP = t.TP + o;
@@ -503,13 +514,25 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
       tr[i].mn = t.mn[b];
       tr[i].mx = t.mx[b];
       for (int k = tl; k < tr[i].len; k += TL) s_path[mt * MZ_FUSED_MAXPL + k] = t.path[(size_t)b * t.PL + k];
-      if constexpr (LT) {       // bring the existing part of the tree (root, expanded slabs) into LDS
+      if constexpr (LT == 1) {       // bring the existing part of the tree (root, expanded slabs) into LDS
         const size_t o = (size_t)b * t.NN;
         const int have = 1 + (slot0 + 1) * t.A;
         for (int k = tl; k < have; k += TL) {
           tm[i].N[k] = (int16_t)t.N[o + k]; tm[i].W[k] = t.W[o + k]; tm[i].P[k] = t.P[o + k]; tm[i].R[k] = t.R[o + k];
-          tm[i].Q[k] = t.N[o + k] > 0 ? t.W[o + k] / (double)t.N[o + k] : 0.0;      // a continued search: same quotient the backup caches
+          const double qk = t.N[o + k] > 0 ? t.W[o + k] / (double)t.N[o + k] : 0.0;      // a continued search: what the backup
+          const double rk = (double)t.R[o + k];                                           // would have cached
+          tm[i].X[k] = t.two_players ? rk - t.discount * qk : rk + t.discount * qk;
           tm[i].E[k] = (int16_t)t.E[o + k]; tm[i].TP[k] = t.TP[o + k];
+        }
+      } else if constexpr (LT == 2) {
+        const size_t o = (size_t)b * t.NN;
+        const int have = 1 + (slot0 + 1) * t.A;
+        for (int k = tl; k < have; k += TL) {
+          const int nk = t.N[o + k];
+          tm[i].N[k] = (int16_t)nk; tm[i].P[k] = t.P[o + k]; tm[i].E[k] = (int16_t)t.E[o + k];
+          const double qk = nk > 0 ? t.W[o + k] / (double)nk : 0.0;      // a continued search: what the backup would have cached
+          const double rk = (double)t.R[o + k];
+          tm[i].X[k] = t.two_players ? rk - t.discount * qk : rk + t.discount * qk;
         }
       }
     }
@@ -705,7 +728,7 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
           __builtin_amdgcn_s_waitcnt(0x4F70);     // vmcnt(16)
           mz_partials_out<NJ2>(red, out4, tid);
           STAMP(8)
-          if constexpr (TL != 16) {
+          if constexpr (TL != 16 || LT == 2) {
               // every wave: value scalar + policy logits of 4 trees -> LDS; both halves of a tree's 16 lanes compute the
               // value (8 lanes x 4 bins), lane q < ceil(A/4) forwards 4 logits
             const int col = 4 * w + (lane_e >> 4), q = lane_e & 15, q8 = q & 7;
@@ -724,7 +747,7 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
       }
       // s >= E_P2: padding steps (prefetch only)
     });
-    if constexpr (TL == 16) {
+    if constexpr (TL == 16 && LT != 2) {
       // ---- value scalar, logits, then the tree step (expand + backup, mcts.py:97-99; next descent, mcts.py:83-92) of
       // the 4 trees this wave's lanes own, with no barrier in between: nothing here is exchanged across waves (the
       // wave that owns a tree reads its value and logits straight from the partials), and written as ONE straight
@@ -745,7 +768,7 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
       STAMP(9)
       auto stampf = [&](int k) __attribute__((always_inline)) { STAMP(10 + k) };
       if (full || b0 + mt < t.B) {
-        mz_tree_expand_f<TL, LT>(t, tm[0], tl, slot0 + sim + 1, s_rew[mt], pr, s_path + mt * MZ_FUSED_MAXPL,
+        mz_tree_expand_f<TL, G, LT>(t, tm[0], tl, slot0 + sim + 1, s_rew[mt], pr, s_path + mt * MZ_FUSED_MAXPL,
                                  s_stage + mt * 96, tr[0]);
         stampf(0);
         mz_tree_backup_select_f<TL, G, LT>(t, tm[0], tl, v, s_rew[mt], s_path + mt * MZ_FUSED_MAXPL, s_stage + mt * 96,
@@ -782,13 +805,13 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
   for (int i = 0; i < NPASS; ++i) {
     const int b = b0 + tid / TL + i * (256 / TL);
     if (b < t.B && tl == 0) { t.mn[b] = tr[i].mn; t.mx[b] = tr[i].mx; t.nexp[b] = slot0 + nsims + 1; }
-    if constexpr (LT) {
+    if constexpr (LT != 0) {
       if (b < t.B) {
         const size_t o = (size_t)b * t.NN;
         const int have = 1 + (slot0 + nsims + 1) * t.A;
         for (int k = tl; k < have; k += TL) {
-          t.N[o + k] = tm[i].N[k]; t.W[o + k] = tm[i].W[k]; t.P[o + k] = tm[i].P[k]; t.R[o + k] = tm[i].R[k];
-          t.E[o + k] = tm[i].E[k]; t.TP[o + k] = tm[i].TP[k];
+          t.N[o + k] = tm[i].N[k]; t.P[o + k] = tm[i].P[k]; t.E[o + k] = tm[i].E[k];
+          if constexpr (LT == 1) { t.W[o + k] = tm[i].W[k]; t.R[o + k] = tm[i].R[k]; t.TP[o + k] = tm[i].TP[k]; }
         }
       }
     }

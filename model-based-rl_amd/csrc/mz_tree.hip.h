@@ -235,13 +235,18 @@ struct TreeRegs {
   double mn, mx;    // MinMaxStats
 };
 
-// One tree's node arrays: its slab of the global pool (LT = false) or a copy the fused kernel keeps in LDS
-// for the whole launch (LT = true; visit counts and expansion indices narrowed to 16 bit).
-template <bool LT> struct TreeMem;
-template <> struct TreeMem<false> { int32_t *N; double *W; double *P; float *R; int32_t *E; int8_t *TP; };
-// The LDS copy also caches Q = W/N of every visited node (the backup computes that quotient anyway for the
-// MinMaxStats update), so the descent reads it instead of dividing once per level.
-template <> struct TreeMem<true> { int16_t *N; double *W; double *P; float *R; int16_t *E; int8_t *TP; double *Q; };
+// One tree's node arrays, three placements (LT):
+//   0  its slab of the global pool;
+//   1  a copy the fused kernel keeps in LDS for the whole launch (visit counts and expansion indices narrowed to
+//      16 bit), plus a cache X = reward + discount * (+-Q) of every visited node, the term MinMaxStats normalises: the
+//      backup computes it anyway for the MinMaxStats update (same operations, same order as the descent's own
+//      expression), so the descent reads one double instead of R and W/N and divides nothing;
+//   2  trees too large for (1): only what the DESCENT reads lives in LDS -- N, E, P and X -- while W, R and to_play,
+//      which only expand and backup touch (once per simulation, all path nodes in parallel), stay in the global pool.
+template <int LT> struct TreeMem;
+template <> struct TreeMem<0> { int32_t *N; double *W; double *P; float *R; int32_t *E; int8_t *TP; };
+template <> struct TreeMem<1> { int16_t *N; double *W; double *P; float *R; int16_t *E; int8_t *TP; double *X; };
+template <> struct TreeMem<2> { int16_t *N; double *W; double *P; float *R; int16_t *E; int8_t *TP; double *X; };
 
 // expand + backpropagate for the pending leaf, then (do_select) the next descent -- the same arithmetic as
 // mz_tree_expand_backup / mz_tree_select, reorganised so that the chain of DEPENDENT memory round trips is
@@ -275,15 +280,16 @@ struct MzHiddenPrefetch {
 // ---- Node.expand (mcts.py:47-55) for the pending leaf: priors of the new children, leaf bookkeeping.
 // p = math.exp(logit of action `lane`) (0 for lane >= A), computed by the caller (so that it can be scheduled
 // beside other work)
-template <int TL, bool LT>
+template <int TL, int G, int LT>
 __device__ __forceinline__ void mz_tree_expand_f(const TreeView &t, const TreeMem<LT> &tm, int lane, int e_new,
                                                  float reward, double p, const int *s_path,
                                                  double *s_stage, const TreeRegs &tr) {
   const int A = t.A;
   const int leafnode = s_path[tr.len - 1];
-  if (lane < A) s_stage[lane] = p;              // every lane then adds them up in Python's sum() order
-  double sum = 0.0;
-  for (int a = 0; a < A; ++a) sum = sum + s_stage[a];
+  if (lane < G) s_stage[lane] = p;              // every lane then adds them up in Python's sum() order (G >= A terms:
+  double sum = 0.0;                             // the lanes beyond A contribute exact zeros at the end of the sum)
+#pragma unroll
+  for (int a = 0; a < G; ++a) sum = sum + s_stage[a];
   if (lane < A) {
     const int ch = 1 + e_new * A + lane;
     tm.N[ch] = 0; tm.W[ch] = 0.0; tm.R[ch] = 0.f; tm.E[ch] = -1; tm.TP[ch] = 1;
@@ -292,28 +298,28 @@ __device__ __forceinline__ void mz_tree_expand_f(const TreeView &t, const TreeMe
   if (lane == 0) { tm.E[leafnode] = e_new; tm.TP[leafnode] = (int8_t)tr.tp; tm.R[leafnode] = reward; }
 }
 
-template <int TL, int G, bool LT, class LEVELF, class STAMPF>
+template <int TL, int G, int LT, class LEVELF, class STAMPF>
 __device__ __forceinline__ void mz_tree_backup_select_f(const TreeView &t, const TreeMem<LT> &tm, int lane,
                                                         float value, float reward, int *s_path, double *s_stage,
                                                         const double *pbctab, TreeRegs &tr, bool do_select,
                                                         int &slot_out, int &act_out, const LEVELF &levelf,
                                                         STAMPF stampf);
 
-template <int TL, int G, bool LT, class STAMPF = MzNoStamp>
+template <int TL, int G, int LT, class STAMPF = MzNoStamp>
 __device__ __forceinline__ void mz_tree_step_fused(const TreeView &t, const TreeMem<LT> &tm, int lane, int e_new,
                                                    float value, float reward, const float *logits, int *s_path,
                                                    double *s_stage, const double *pbctab, TreeRegs &tr,
                                                    bool do_select, int &slot_out, int &act_out,
                                                    const float *hpool, unsigned hoff, f32x4 &hv,
                                                    STAMPF stampf = STAMPF()) {
-  mz_tree_expand_f<TL, LT>(t, tm, lane, e_new, reward, (lane < t.A) ? exp((double)logits[lane]) : 0.0, s_path, s_stage, tr);
+  mz_tree_expand_f<TL, G, LT>(t, tm, lane, e_new, reward, (lane < t.A) ? exp((double)logits[lane]) : 0.0, s_path, s_stage, tr);
   stampf(0);
   mz_tree_backup_select_f<TL, G, LT>(t, tm, lane, value, reward, s_path, s_stage, pbctab, tr, do_select, slot_out,
                                      act_out, MzHiddenPrefetch{hpool, hoff, hv}, stampf);
 }
 
 // MCTS.backpropagate for the pending leaf, then (do_select) the next descent
-template <int TL, int G, bool LT, class LEVELF, class STAMPF>
+template <int TL, int G, int LT, class LEVELF, class STAMPF>
 __device__ __forceinline__ void mz_tree_backup_select_f(const TreeView &t, const TreeMem<LT> &tm, int lane,
                                                         float value, float reward, int *s_path, double *s_stage,
                                                         const double *pbctab, TreeRegs &tr, bool do_select,
@@ -355,8 +361,8 @@ __device__ __forceinline__ void mz_tree_backup_select_f(const TreeView &t, const
       tm.N[node] = n;
       if (j < len - 1) {
         const double q = w / (double)n;
-        if constexpr (LT) tm.Q[node] = q;        // Node.value() of this node until its next visit
         const double new_q = two ? r_node - g * q : r_node + g * q;
+        if constexpr (LT != 0) tm.X[node] = new_q;     // = reward + discount * (two ? -Q : Q), what the descent normalises
         mn_c = new_q; mx_c = new_q;
       } else {
         root_n = n;
@@ -382,7 +388,8 @@ __device__ __forceinline__ void mz_tree_backup_select_f(const TreeView &t, const
   // score expression on safe operands and the conditions of the reference (fresh root ranks by prior,
   // unvisited child gets init_value_score, MinMaxStats.normalize's three cases, illegal root slots) pick
   // among the results -- a divergent if/else ladder cost more than the arithmetic it skipped.
-  __threadfence_block();
+  if constexpr (LT == 0) __threadfence_block();
+  else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the descent reads LDS only
   const double mn = tr.mn, mx = tr.mx;
   const double span = mx - mn;
   const bool span_pos = mx > mn, span_zero = mx == mn;
@@ -413,22 +420,31 @@ __device__ __forceinline__ void mz_tree_backup_select_f(const TreeView &t, const
     const int Nc = tm.N[ch];
     const int Ec = tm.E[ch];
     const double p = tm.P[ch];
-    const double rc = (double)tm.R[ch];
-    const double prior_score = pbctab[(Np << 6) + Nc] * p;       // table rows are 64 entries apart (a shift, no multiply)
-    double q;
-    if constexpr (LT) q = tm.Q[ch];        // cached by the backup; unused (may be stale or garbage) while Nc == 0
-    else q = tm.W[ch] / (double)(Nc > 0 ? Nc : 1);
-    const double x = rc + g * (two ? -q : q);
+    // pb_c table in LDS: rows 64 entries apart where it fits (a shift, no multiply), sims + 2 apart beside large trees
+    const double prior_score = pbctab[(LT == 2 ? __mul24(Np, t.sims + 2) : (Np << 6)) + Nc] * p;
+    double x;        // reward + discount * (+-Q) of the child; unused (may be stale or garbage) while Nc == 0
+    if constexpr (LT != 0) {
+      x = tm.X[ch];                                // cached by the backup
+    } else {
+      const double q = tm.W[ch] / (double)(Nc > 0 ? Nc : 1);
+      x = (double)tm.R[ch] + g * (two ? -q : q);
+    }
     const double xm = x - mn;
     const double q0 = xm * yspan;
     const double r0 = __builtin_fma(-span, q0, xm);
     double nrm = __builtin_fma(r0, yspan, q0);
-    if (!fast_ok) nrm = xm / span;
+    if (!fast_ok) {                            // (never in practice)
+      double sp_ = span;
+      asm volatile("" : "+v"(sp_));            // not speculatable: left alone, the compiler turns this branch into a
+      nrm = xm / sp_;                          // select and evaluates the division at every level after all
+    }
     const double visited = span_pos ? nrm : (span_zero ? 1.0 : x);
     const double ucb = prior_score + ((Nc > 0) ? visited : t.init_value_score);
     // tuple max over (score, action); absent children carry score -inf and action -1 (no finite score loses to them,
     // and among themselves nothing is taken), the winner's expansion index and visit count ride along in one word
-    double score = valid ? ((Np == 0) ? p : ucb) : -__builtin_inf();
+    // (a descent of this function always follows a backup: the root and every expanded node on the way down have been
+    // visited, so mcts.py:105's fresh-root case, rank by prior, cannot occur here)
+    double score = valid ? ucb : -__builtin_inf();
     int best = valid ? cl : -1;
     int pay = (Nc << 16) | (Ec & 0xffff);
 #define MZ_AM_STEP(OFF)                                                                          \
