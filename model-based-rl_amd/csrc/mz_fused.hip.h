@@ -503,13 +503,14 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
       tm[i].N = t.N + o; tm[i].W = t.W + o; tm[i].P = t.P + o; tm[i].R = t.R + o; tm[i].E = t.E + o; tm[i].TP = t.TP + o;
     }
     my_slot[i] = 0; my_act[i] = 0;
-    tr[i].len = 1; tr[i].tp = 1; tr[i].root_tp = 1; tr[i].legal = 0; tr[i].mn = 0.0; tr[i].mx = 0.0;
+    tr[i].len = 1; tr[i].tp = 1; tr[i].root_tp = 1; tr[i].legal = 0; tr[i].mn = 0.0; tr[i].mx = 0.0; tr[i].root_n = 0;
     if (b < t.B) {
       my_slot[i] = t.slot[b];
       my_act[i] = t.act[b];
       tr[i].len = t.plen[b];
       tr[i].tp = t.leaf_tp[b];
       tr[i].root_tp = t.TP[(size_t)b * t.NN];
+      tr[i].root_n = t.N[(size_t)b * t.NN];
       tr[i].legal = t.legal[b];
       tr[i].mn = t.mn[b];
       tr[i].mx = t.mx[b];

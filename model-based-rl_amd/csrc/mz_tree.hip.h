@@ -232,6 +232,7 @@ struct TreeRegs {
   int tp;           // to_play at its leaf
   int root_tp;      // root.to_play
   uint32_t legal;   // root child mask
+  int root_n;       // root.visit_count (every backup adds one: kept here instead of being fished out of the path)
   double mn, mx;    // MinMaxStats
 };
 
@@ -333,7 +334,6 @@ __device__ __forceinline__ void mz_tree_backup_select_f(const TreeView &t, const
   // ---- MCTS.backpropagate (mcts.py:126-143), TL path nodes per round
   double v_cur = (double)value;
   double mn_c = __builtin_inf(), mx_c = -__builtin_inf();
-  int root_n = 0;
   for (int base = 0; base < len; base += TL) {
     const int j = base + lane;
     const bool act = j < len;
@@ -350,7 +350,20 @@ __device__ __forceinline__ void mz_tree_backup_select_f(const TreeView &t, const
     const int cnt = (len - base) < TL ? (len - base) : TL;
     double my_v = 0.0;
     if (act) s_stage[32 + lane] = r_signed;       // the recurrence value = reward + discount*value runs in
-    for (int jj = 0; jj < cnt; ++jj) {             // every lane; lane j keeps the value its node receives
+    {                                              // every lane; lane j keeps the value its node receives.
+      // The first four staged rewards come in two 16-byte reads and the recurrence runs on registers (most paths are
+      // no longer than that); a select keeps the steps beyond the path's end from taking effect.
+      typedef double f64x2 __attribute__((ext_vector_type(2)));
+      const f64x2 ra = *(const f64x2 *)(s_stage + 32), rb = *(const f64x2 *)(s_stage + 34);
+      const double rj[4] = {ra[0], ra[1], rb[0], rb[1]};
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const double vn = rj[jj] + g * v_cur;
+        my_v = (lane == jj) ? v_cur : my_v;
+        v_cur = (jj < cnt) ? vn : v_cur;
+      }
+    }
+    for (int jj = 4; jj < cnt; ++jj) {
       if (lane == jj) my_v = v_cur;
       v_cur = s_stage[32 + jj] + g * v_cur;
     }
@@ -364,17 +377,15 @@ __device__ __forceinline__ void mz_tree_backup_select_f(const TreeView &t, const
         const double new_q = two ? r_node - g * q : r_node + g * q;
         if constexpr (LT != 0) tm.X[node] = new_q;     // = reward + discount * (two ? -Q : Q), what the descent normalises
         mn_c = new_q; mx_c = new_q;
-      } else {
-        root_n = n;
       }
     }
   }
+  tr.root_n += 1;
 #define MZ_MM_STEP(OFF)                                                         \
   {                                                                             \
     const double a_ = mz_xchg_d<OFF>(mn_c), c_ = mz_xchg_d<OFF>(mx_c);         \
     mn_c = a_ < mn_c ? a_ : mn_c;                                               \
     mx_c = c_ > mx_c ? c_ : mx_c;                                               \
-    root_n |= mz_xchg_i<OFF>(root_n);                                           \
   }
   MZ_MM_STEP(1) MZ_MM_STEP(2) MZ_MM_STEP(4) MZ_MM_STEP(8)
   if constexpr (TL == 32) MZ_MM_STEP(16)
@@ -408,7 +419,7 @@ __device__ __forceinline__ void mz_tree_backup_select_f(const TreeView &t, const
     e0 = __builtin_fma(-span, y0, 1.0);
     yspan = __builtin_fma(y0, e0, y0);
   }
-  int node = 0, e = 0, Np = root_n, tpc = tr.root_tp, len2 = 1, a_sel = -1, parent_e = 0;
+  int node = 0, e = 0, Np = tr.root_n, tpc = tr.root_tp, len2 = 1, a_sel = -1, parent_e = 0;
   if (lane == 0) s_path[0] = 0;
   // the TL lanes of a tree evaluate the children in TL/G redundant copies (child = lane % G), so the
   // arg-max needs only log2(G) exchange steps and every lane ends up with the result
