@@ -171,6 +171,47 @@ def test_device_selfplay_records_and_sharding():
   eng2.close()
 
 
+def test_timed_launches_are_the_same_moves():
+  """mz_selfplay_steps_timed (eager launches, events around every search dispatch -- bench.py's roofline clock) and
+  mz_search_timed produce exactly what the untimed entry points produce, and report plausible durations."""
+  import torch
+  from oracle import oracle as orc
+  from model_based_rl_amd.engine import Engine
+  g = np.load(os.path.join(G, 'g1_net_lunar.npz'))
+  w = orc.load_weights(g)
+  recs = []
+  for timed in (False, True):
+    eng = Engine(64, 8, 4, 30, seed=5)
+    eng.set_weights(w)
+    eng.selfplay_reset(7, 1.0, stagger=True)
+    if timed:
+      ms = eng.selfplay_steps_timed(6)
+      assert len(ms) == 6 and all(0.01 < x < 50.0 for x in ms), ms
+    else:
+      eng.selfplay_steps(6)
+    buf, n = eng.selfplay_drain()
+    torch.cuda.synchronize()
+    recs.append(buf[:n].numpy().copy())
+    eng.close()
+  assert np.array_equal(recs[0], recs[1])
+  trees = []
+  obs = np.random.RandomState(2).standard_normal((64, 8)).astype(np.float32)
+  noise = np.random.RandomState(3).dirichlet([0.25] * 4, size=64)
+  for timed in (False, True):
+    eng = Engine(64, 8, 4, 30)
+    eng.set_weights(w)
+    eng.initial_inference(obs)
+    eng.root_prepare(None, None, noise)
+    if timed:
+      assert 0.01 < eng.search_timed() < 50.0
+    else:
+      eng.search()
+    trees.append(eng.export_tree())
+    eng.close()
+  for k in ('N', 'W', 'E', 'minmax'):
+    assert np.array_equal(trees[0][k], trees[1][k]), k
+
+
 @pytest.mark.parametrize('A,sims,T,temp', [(4, 30, 5, 1.0), (6, 12, 4, 0.5), (3, 9, 3, 0.0), (18, 8, 3, 1.0)])
 def test_selfplay_loop_equals_stepwise_abi(A, sims, T, temp):
   """The fused per-move kernels of the device loop (root kernel with in-kernel observation + Dirichlet + first

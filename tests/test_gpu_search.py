@@ -147,14 +147,17 @@ def _run_variant(env_extra, tag):
           "from tests.test_gpu_search import run_both\n"
           "o, e, _ = run_both('g1_net_lunar', 512, 30)\n"
           "o2, e2, _ = run_both('g1_net_ttt', 64, 30, True, (-1.0, 1.0), 1.0, 0.6)\n"
-          "np.savez('/tmp/mz_%s.npz', vc=o['visit_counts'], W=e['W'], vc2=o2['visit_counts'], W2=e2['W'])\n"
+          "o3, e3, _ = run_both('g1_net_pong', 64, 50)\n"
+          "np.savez('/tmp/mz_%s.npz', vc=o['visit_counts'], W=e['W'], vc2=o2['visit_counts'], W2=e2['W'],\n"
+          "         vc3=o3['visit_counts'], W3=e3['W'], P3=e3['P'], E3=e3['E'])\n"
           ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), tag)
   subprocess.check_call([sys.executable, '-c', code], env=dict(os.environ, **env_extra))
   return np.load('/tmp/mz_%s.npz' % tag)
 
 
 def test_all_search_paths_agree_bit_for_bit():
-  """fused kernel with LDS-resident trees (default) and with trees in the global pool (MZ_NO_LDS_TREES) run
+  """fused kernel with LDS-resident trees (default; for the 50-simulation / 6-action shape: only the descent's fields
+  in LDS, the rest in the global pool) and with trees in the global pool (MZ_NO_LDS_TREES) run
   the same arithmetic: identical trees, bit for bit.  The separate-kernel path (MZ_NO_FUSED) evaluates the
   network in a different f32 summation order (bias first instead of as the last k column, other reduction
   trees), so it agrees like two correct f32 implementations do: same visit vectors in >= 99 % of the trees,
@@ -162,7 +165,7 @@ def test_all_search_paths_agree_bit_for_bit():
   a = _run_variant({}, 'default')
   b = _run_variant({'MZ_NO_LDS_TREES': '1'}, 'nolds')
   c = _run_variant({'MZ_NO_FUSED': '1'}, 'nofused')
-  for k in ('vc', 'W', 'vc2', 'W2'):
+  for k in ('vc', 'W', 'vc2', 'W2', 'vc3', 'W3', 'P3', 'E3'):
     assert np.array_equal(a[k], b[k]), ('lds vs global trees', k)
   for vk, wk in (('vc', 'W'), ('vc2', 'W2')):
     same = np.all(a[vk] == c[vk], axis=1)
