@@ -41,15 +41,28 @@ FLOP_PER_ROOT = 2 * 512 * (O + 181 + A)           # 197 632 for O = 8, A = 4
 PEAK_F32_MFMA_TFLOPS = 157.3                      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 
 
+def _usable_cores():
+  """cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (the GPU boxes expose
+  256 logical CPUs but run the job under a 16-CPU quota; threads beyond the quota only time-slice)."""
+  n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+  try:
+    quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+    if quota != 'max':
+      n = min(n, max(1, int(int(quota) / int(period))))
+  except (OSError, ValueError):
+    pass
+  return n
+
+
 def cpu_baseline(weights):
   """The CPU oracle (C restatement of the reference path, oracle/mz_oracle.c) timed on the host cores on a bounded
-  sample of the same workload: one thread per core (up to 64), every thread its own batch of environments -- the
+  sample of the same workload: one thread per usable core (up to 64), every thread its own batch of environments -- the
   layout of the reference's Ray actors (one single-threaded process per actor, train.py:63,72).  The C call releases
   the GIL.  Reported beside the GPU number; it is not the target."""
   import threading
   from oracle import oracle as orc
   envs, moves = 256, 24       # ~10 s of work per core
-  cores = max(1, min(64, os.cpu_count() or 1))
+  cores = max(1, min(64, _usable_cores()))
   net = orc.FCNet(weights, O, A)
 
   def make(seed):
@@ -84,7 +97,7 @@ def cpu_baseline(weights):
   return {'value': cores * envs * moves / dt, 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port',
           'sample': '%d threads x %d envs x %d moves x %d simulations, oracle/mz_oracle.c (gcc -O2, scalar float32 net + '
                     'double tree), %.1f s' % (cores, envs, moves, SIMS, dt),
-          'single_core_value': single, 'host_cpus': os.cpu_count()}
+          'single_core_value': single, 'host_cpus': os.cpu_count(), 'usable_cores': _usable_cores()}
 
 
 def main():
