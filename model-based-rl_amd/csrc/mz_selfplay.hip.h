@@ -25,29 +25,33 @@ struct SelfplayState {
   bool ready;
 };
 
-// Gamma(alpha) by Marsaglia-Tsang (alpha < 1: boost with U^(1/alpha)); counter-based draws.
+// Gamma(alpha) by Marsaglia-Tsang (alpha < 1: boost with U^(1/alpha)); counter-based draws.  float32 on the hardware's
+// own log2 / exp2 / cos / sqrt: this is a noise source, not a parity quantity (parity runs pass numpy's draw in), and
+// the float64 libm version of the same sampler cost 5.5 us of every move (a quarter of the root kernel).
+__device__ inline float mz_u01f(uint32_t r) { return (float)(r >> 8) * (1.0f / 16777216.0f); }      // [0, 1)
 __device__ inline double mz_gamma(double alpha, uint64_t seed, uint32_t env, uint64_t move, uint32_t a) {
-  const double aa = alpha < 1.0 ? alpha + 1.0 : alpha;
-  const double d = aa - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+  const float al = (float)alpha;
+  const float aa = al < 1.0f ? al + 1.0f : al;
+  const float d = aa - 1.0f / 3.0f, c = 1.0f / __builtin_amdgcn_sqrtf(9.0f * d);
+  const float LN2 = 0.69314718f;
   const uint32_t c1 = (uint32_t)move, c3 = (MZ_RNG_DIRICHLET << 24) | ((uint32_t)(move >> 32) & 0xFFFFFFu);
-  double g = d;
+  float g = d;
   uint32_t ctr = 0;
   for (int it = 0; it < 64; ++it) {
     const mz_u4 r0 = mz_philox(seed, env, c1, a | (ctr++ << 8), c3);
-    const mz_u4 r1 = mz_philox(seed, env, c1, a | (ctr++ << 8), c3);
-    const double u1 = 1.0 - mz_u01(r0.x, r0.y), u2 = mz_u01(r0.z, r0.w);   // u1 in (0,1]
-    const double x = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
-    double v = 1.0 + c * x;
-    if (v <= 0.0) continue;
+    const float u1 = 1.0f - mz_u01f(r0.x), u2 = mz_u01f(r0.y);                       // u1 in (0,1]
+    const float x = __builtin_amdgcn_sqrtf(-2.0f * LN2 * __builtin_amdgcn_logf(u1)) * __builtin_amdgcn_cosf(u2);   // cos(2 pi u2)
+    float v = 1.0f + c * x;
+    if (v <= 0.0f) continue;
     v = v * v * v;
-    const double u = 1.0 - mz_u01(r1.x, r1.y);
-    if (log(u) < 0.5 * x * x + d - d * v + d * log(v)) { g = d * v; break; }
+    const float u = 1.0f - mz_u01f(r0.z);
+    if (LN2 * __builtin_amdgcn_logf(u) < 0.5f * x * x + d - d * v + d * LN2 * __builtin_amdgcn_logf(v)) { g = d * v; break; }
   }
-  if (alpha < 1.0) {
+  if (al < 1.0f) {
     const mz_u4 r = mz_philox(seed, env, c1, a | (0xFFFFFFu << 8), c3);
-    g *= pow(1.0 - mz_u01(r.x, r.y), 1.0 / alpha);
+    g *= __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(1.0f - mz_u01f(r.x)) / al);
   }
-  return g;
+  return (double)g;
 }
 
 // noise[b] ~ Dirichlet(alpha * 1_legal)  (the draw of np.random.dirichlet in mcts.py:59, from the

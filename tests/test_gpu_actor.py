@@ -171,6 +171,34 @@ def test_device_selfplay_records_and_sharding():
   eng2.close()
 
 
+def test_device_dirichlet_matches_numpy_distribution():
+  """throughput mode draws the root noise on the device (Marsaglia-Tsang gamma on Philox, float32 transcendentals): it
+  is Dirichlet(alpha * 1_A) like mcts.py:59's np.random.dirichlet -- sums to 1, mean 1/A, variance and quantiles of
+  the marginal Beta(alpha, alpha (A - 1)) against numpy's own sampler."""
+  import torch
+  from oracle import oracle as orc
+  from model_based_rl_amd.engine import Engine
+  g = np.load(os.path.join(G, 'g1_net_lunar.npz'))
+  w = orc.load_weights(g)
+  B, A, alpha = 4096, 4, 0.25
+  eng = Engine(B, 8, A, 30, seed=11)
+  eng.set_weights(w)
+  xs = []
+  for m in range(8):
+    eng.initial_inference(torch.randn(B, 8, device='cuda'))
+    eng.root_prepare(None, None, None, device_rng=True, move=m)
+    xs.append(eng.export_tree()['noise'])
+  eng.close()
+  x = np.concatenate(xs)
+  assert not np.isnan(x).any() and np.abs(x.sum(1) - 1).max() < 1e-12 and x.min() >= 0
+  assert np.abs(x.mean(0) - 1 / A).max() < 0.01
+  assert np.abs(x.var(0) - (1 / A) * (1 - 1 / A) / (alpha * A + 1)).max() < 0.005
+  ref = np.random.RandomState(0).dirichlet([alpha] * A, size=x.shape[0])
+  for q in (0.25, 0.5, 0.75, 0.9, 0.99):
+    assert abs(np.quantile(x[:, 1], q) - np.quantile(ref[:, 1], q)) < 0.02, q
+  assert np.abs(np.corrcoef(x[:-B, 0], x[B:, 0])[0, 1]) < 0.03       # consecutive moves of an env: independent draws
+
+
 def test_timed_launches_are_the_same_moves():
   """mz_selfplay_steps_timed (eager launches, events around every search dispatch -- bench.py's roofline clock) and
   mz_search_timed produce exactly what the untimed entry points produce, and report plausible durations."""
