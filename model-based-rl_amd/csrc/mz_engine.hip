@@ -189,6 +189,9 @@ static int build_packing(mz_engine *e) {
   const int rs = mz_fused_rs(ks1f, jtp);
   const int nsteps = rs + (real_steps - rs + MZ_NB - 1) / MZ_NB * MZ_NB;   // FusedSched::NSTEPS
   const size_t p_ws = seg((size_t)4 * nsteps * 4 * 256);
+  // A operands of the small MFMA (mz_fused.hip.h): rows 48..51 of the next hidden state; the policy head when A <= 4
+  const size_t p_h4 = seg((size_t)4 * 8 * 256), p_p4 = seg((size_t)4 * 8 * 256);
+  const bool p4 = A <= 4;
   // root kernel stream: [nst0 first-stage steps][8 representation-out][13 prediction fc1][2*nj2 prediction out]
   const int nst0 = mz_root_nst0(O), nroot = nst0 + 8 + ks3f + 2 * nj2;
   const size_t p_is = seg((size_t)4 * nroot * 4 * 256);
@@ -222,6 +225,16 @@ static int build_packing(mz_engine *e) {
     size_t wo3[2] = {L.val_w1, L.pol_w1}, bo3[2] = {L.val_b1, L.pol_b1};
     fill_fc1_biascol(idx, p_w3f, wo3, bo3, MZ_H, ks3f);
   }
+  // small-MFMA pieces, [wave][t][lane][r]: lane l carries output row l & 3 for the features 128w + 16t + 4(l >> 4) + r
+  for (int w = 0; w < 4; ++w)
+    for (int t = 0; t < 8; ++t)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int r = 0; r < 4; ++r) {
+          const int row = lane & 3, nf = 128 * w + 16 * t + 4 * (lane >> 4) + r;
+          const size_t o = ((size_t)(w * 8 + t) * 64 + lane) * 4 + r;
+          idx[p_h4 + o] = 48 + row < MZ_H ? (int32_t)(L.tr_w2 + (size_t)(48 + row) * MZ_F + nf) : -1;
+          idx[p_p4 + o] = row < A ? (int32_t)(L.pol_w2 + (size_t)row * MZ_F + nf) : -1;
+        }
   // the fused kernel's weight stream: per wave [nsteps][4 pieces][64 lanes][4], consumption order
   for (int w = 0; w < 4; ++w) {
     size_t piece = 0;
@@ -232,11 +245,12 @@ static int build_packing(mz_engine *e) {
     for (int st = 0; st < ks1f; ++st)
       for (int tg = 0; tg < 4; ++tg) put(p_w1f + ((size_t)(w * 4 + tg) * ks1f + st) * 256);
     for (int t = 0; t < 8; ++t)
-      for (int jt = 0; jt < 6; ++jt) put(p_w2 + ((size_t)(jt * 4 + w) * 8 + t) * 256);
+      for (int jt = 0; jt < 6; ++jt) put(jt == 5 ? p_h4 + (size_t)(w * 8 + t) * 256 : p_w2 + ((size_t)(jt * 4 + w) * 8 + t) * 256);
     for (int st = 0; st < ks3f; ++st)
       for (int tg = 0; tg < 4; ++tg) put(p_w3f + ((size_t)(w * 4 + tg) * ks3f + st) * 256);
     for (int t = 0; t < 8; ++t)
-      for (int jt = 0; jt < nj2; ++jt) put(p_w4 + ((size_t)(jt * 4 + w) * 8 + t) * 256);
+      for (int jt = 0; jt < nj2; ++jt)
+        put(p4 && jt == 2 ? p_p4 + (size_t)(w * 8 + t) * 256 : p_w4 + ((size_t)(jt * 4 + w) * 8 + t) * 256);
     if ((int)piece != real_steps * 4) return fail("internal: weight stream has %zu pieces, expected %d", piece, real_steps * 4);
     // the remaining (nsteps - real_steps) * 4 pieces are padding (index -1 -> 0.0), loaded but never used
   }

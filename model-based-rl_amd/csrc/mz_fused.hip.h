@@ -68,6 +68,19 @@ __device__ __forceinline__ void mz_mfma_a(f32x4 &c, float a, float b) {
 __device__ __forceinline__ void mz_mfma_a0(f32x4 &c, float a, float b) {
   asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&a"(c) : "v"(a), "v"(b));
 }
+// v_mfma_f32_4x4x1_16b_f32: sixteen independent 4x4 outer products per instruction (block = lane / 4: row r of the
+// result comes from the A operand of lane 4 * block + r, column lane % 4 from the B operand of the lane itself;
+// scripts/mfma4x4_check.hip).  With the B operand = a hidden tile as it stands (lane: tree = lane & 15, feature
+// 16 t + 4 (lane >> 4) + r) one instruction multiplies FOUR output rows by the 16 trees over the four features the
+// wave's four lane rows hold, at 11.5 cycles instead of 32: output layers with 4 (or 2) useful rows -- the policy head
+// of a 4-action game, rows 48..49 of the 50-wide hidden state -- stop paying for a 16-row tile.  The result of lane
+// (g, m) is the partial sum over its own lane row's features: the consumer adds up 4 waves x 4 lane rows.
+__device__ __forceinline__ void mz_mfma4_a(f32x4 &c, float a, float b) {
+  asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mz_mfma4_a0(f32x4 &c, float a, float b) {
+  asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, 0" : "=&a"(c) : "v"(a), "v"(b));
+}
 // fc1 accumulators live in arch VGPRs: ReLU is then one v_max in place and the tile is the B operand of the
 // following layer as it stands (no v_accvgpr_read copies, no second register set).  The first k-step uses the
 // inline constant 0 as SrcC, so the tiles are never zero-filled.
@@ -247,12 +260,16 @@ __device__ __forceinline__ float mz_support_to_scalar16(const float *fin, int ro
 // lane then adds up bias + the four waves' partials of exactly the outputs it needs, in wave order.  The XOR
 // spreads the eight row quads a column's consumer lanes fetch in one instruction over the eight 16-byte bank
 // groups (unswizzled they all fall into bank group m mod 8: an 8-way conflict on every read).
-template <int JTOT>
+// SMALL: bit mask of the tiles that hold 4-row results of the small MFMA (one vector per lane, kept in lane order)
+template <int JTOT, int SMALL = 0>
 __device__ __forceinline__ void mz_partials_out(float *red, const f32x4 (&out)[JTOT], int tid) {
   const int w = tid >> 6, lane = tid & 63;
   f32x4 *red4 = (f32x4 *)red;
 #pragma unroll
-  for (int jt = 0; jt < JTOT; ++jt) red4[(w * 6 + jt) * 64 + (lane ^ (((lane >> 4) + 4 * (jt & 1)) & 7))] = out[jt];
+  for (int jt = 0; jt < JTOT; ++jt) {
+    if ((SMALL >> jt) & 1) red4[(w * 6 + jt) * 64 + lane] = out[jt];
+    else red4[(w * 6 + jt) * 64 + (lane ^ (((lane >> 4) + 4 * (jt & 1)) & 7))] = out[jt];
+  }
   mz_bar();
 }
 // The epilogue lanes fetch their inputs as 16-byte vectors (four consecutive output rows = one lane's slice of a
@@ -296,9 +313,29 @@ __device__ __forceinline__ void sln_relu8p(const float *red, const float *bias, 
   f32x4 wA, wB, bA, bB;
   const unsigned ba = mz_lds_addr(bias + row0 + 4 * q), wa = mz_lds_addr(lnw + 4 * q);
   mz_quad_issue<0>(A, mz_quad_addr(red, row0 + 4 * q, m), ba);
-  mz_quad_issue<128>(B, mz_quad_addr(red, row0 + 4 * q + 32, m), ba);
+  // second quad, features 32 + 4q..: lanes q < 4 own rows of the 16-row tile row0/16 + 2 as before; features 48..51
+  // come out of the small MFMA (tile row0/16 + 3's slot: one vector per wave and lane row g) -- lanes q = 4..7 add up
+  // the four lane rows of wave q - 4 each, a quad reduction joins the waves, lane q = 4 keeps the sum (features >= 52
+  // do not exist: exact zeros).  One address + one stride per lane serve both cases.
+  const int jt5 = (row0 >> 4) + 3;
+  const unsigned pb = (q < 4) ? mz_quad_addr(red, row0 + 4 * q + 32, m)
+                              : mz_lds_addr((const f32x4 *)red + (((q - 4) * 6 + jt5) * 64 + m));
+  const unsigned st = (q < 4) ? 6u * 1024u : 256u;
+  mz_lds128<128>(B.b, ba);
+  mz_lds128<0>(B.p0, pb); mz_lds128<0>(B.p1, pb + st); mz_lds128<0>(B.p2, pb + 2 * st); mz_lds128<0>(B.p3, pb + 3 * st);
   asm volatile("s_waitcnt lgkmcnt(0)" : MZ_Q(A), MZ_Q(B));
-  const f32x4 xa = mz_quad_sum(A), xb = mz_quad_sum(B);
+  const f32x4 xa = mz_quad_sum(A);
+  f32x4 xb;
+  {
+    f32x4 ps = B.p0;
+    ps += B.p1; ps += B.p2; ps += B.p3;
+    f32x4 tot;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { float v = ps[r]; v += mz_dpp<0xB1>(v); v += mz_dpp<0x4E>(v); tot[r] = v; }   // over the quad q = 4..7
+    const f32x4 big = B.b + ps, small = B.b + tot;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xb[r] = (q < 4) ? big[r] : ((q == 4) ? small[r] : 0.f);
+  }
   // the affine parameters (lnb = lnw + 64 floats) arrive under the two reductions
   mz_lds128<0>(wA, wa); mz_lds128<128>(wB, wa);
   mz_lds128<256>(bA, wa); mz_lds128<384>(bB, wa);
@@ -325,6 +362,20 @@ __device__ __forceinline__ void sln_relu8p(const float *red, const float *bias, 
   }
   *(f32x4 *)(xR + m * MZ_HS + 4 * q) = ya;
   if (4 * q + 32 < MZ_HS) *(f32x4 *)(xR + m * MZ_HS + 4 * q + 32) = yb;
+}
+
+// policy logits of a 4-action game out of the small MFMA (tile 2's slot of the prediction partials): lane tl of the
+// tree's 16 lanes fetches the vector of (wave tl >> 2, lane row tl & 3), a 16-lane reduction adds them up: every
+// lane ends up with all four logits (+ bias)
+__device__ __forceinline__ f32x4 mz_logits4(const float *red, const float *bias, int m, int tl) {
+  f32x4 pv, bv;
+  mz_lds128<0>(pv, mz_lds_addr((const f32x4 *)red + (((tl >> 2) * 6 + 2) * 64 + 16 * (tl & 3) + m)));
+  mz_lds128<0>(bv, mz_lds_addr(bias));
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pv), "+v"(bv));
+  f32x4 o;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) o[r] = bv[r] + mz_sum16(pv[r]);
+  return o;
 }
 
 // Config.inverse_transform (config.py:27-33) of the S <= 32 bins in x (lane q of the 8 lanes of a column holds
@@ -437,6 +488,7 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
   static_assert(RS <= SC::FC1, "resident steps must be fc1 steps of the dynamics stage");
   constexpr int E_FC1 = SC::FC1, E_FC2 = E_FC1 + SC::FC2, E_P1 = E_FC2 + SC::P1, E_P2 = E_P1 + SC::P2;
   constexpr int NJ2 = 2 + JTP;
+  constexpr bool P4 = (G == 4);          // at most 4 actions: the policy head runs on the small MFMA
 
   __shared__ __attribute__((aligned(16))) float smem[mz_fused_lds_floats(LT)];
   extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
@@ -677,14 +729,17 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
 #pragma unroll
           for (int q4 = 0; q4 < 4; ++q4) {
             const int q = 4 * step + q4, tt = q / 6, jt = q % 6;
-            if (q < 6 && r == 0) mz_mfma_a0(out2[jt], Bf[cb][q4][r], acc[jt < 2 ? tt : 8 + tt][r]);
+            if (jt == 5) {         // rows 48..51 of the next hidden state: small MFMA
+              if (q < 6 && r == 0) mz_mfma4_a0(out2[jt], Bf[cb][q4][r], acc[8 + tt][r]);
+              else mz_mfma4_a(out2[jt], Bf[cb][q4][r], acc[8 + tt][r]);
+            } else if (q < 6 && r == 0) mz_mfma_a0(out2[jt], Bf[cb][q4][r], acc[jt < 2 ? tt : 8 + tt][r]);
             else mz_mfma_a(out2[jt], Bf[cb][q4][r], acc[jt < 2 ? tt : 8 + tt][r]);
           }
         }
         if constexpr (s == E_FC2 - 1) {
           mz_mfma_fence<6>(out2);
           STAMP(3)
-          mz_partials_out<6>(red, out2, tid);
+          mz_partials_out<6, 1 << 5>(red, out2, tid);
           STAMP(4)
           // waves 0,1: LayerNorm+ReLU of 8 trees each -> xR; waves 2,3: reward scalar of 8 trees each -> s_rew
           // (8 lanes per tree; the two chains run side by side on different SIMDs)
@@ -716,7 +771,14 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
 #pragma unroll
           for (int q4 = 0; q4 < 4; ++q4) {
             const int q = 4 * step + q4, tt = q / NJ2, jt = q % NJ2;
-            if (q < NJ2 && r == 0) mz_mfma_a0(out4[jt], Bf[cb][q4][r], acc[jt < 2 ? tt : 8 + tt][r]);
+            if (P4 && jt == 2) {   // the four policy logits: small MFMA
+              // two small MFMAs on the same accumulator back to back (the step's last piece at r, its first at r + 1):
+              // a 2-pass MFMA's result is not forwarded to an immediately following SrcC read, and the compiler does
+              // not see inside asm -- without these wait states the second product went missing
+              if (q4 == 0 && r > 0 && (4 * step + 3) % NJ2 == 2) asm volatile("s_nop 7" : "+a"(out4[jt]));
+              if (q < NJ2 && r == 0) mz_mfma4_a0(out4[jt], Bf[cb][q4][r], acc[8 + tt][r]);
+              else mz_mfma4_a(out4[jt], Bf[cb][q4][r], acc[8 + tt][r]);
+            } else if (q < NJ2 && r == 0) mz_mfma_a0(out4[jt], Bf[cb][q4][r], acc[jt < 2 ? tt : 8 + tt][r]);
             else mz_mfma_a(out4[jt], Bf[cb][q4][r], acc[jt < 2 ? tt : 8 + tt][r]);
           }
         }
@@ -727,7 +789,7 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
           // than the last 16 weight loads, so vmcnt(16) covers them without draining the prefetch ring; the barrier
           // inside mz_partials_out then publishes them
           __builtin_amdgcn_s_waitcnt(0x4F70);     // vmcnt(16)
-          mz_partials_out<NJ2>(red, out4, tid);
+          mz_partials_out<NJ2, P4 ? 1 << 2 : 0>(red, out4, tid);
           STAMP(8)
           if constexpr (TL != 16 || LT == 2) {
               // every wave: value scalar + policy logits of 4 trees -> LDS; both halves of a tree's 16 lanes compute the
@@ -738,11 +800,16 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
             mz_quad_issue<0>(V, mz_quad_addr(red, 4 * q8, col), ba);
             asm volatile("s_waitcnt lgkmcnt(0)" : MZ_Q(V));
             const f32x4 vs = mz_quad_sum(V);
-            mz_quad_issue<128>(L, mz_quad_addr(red, 32 + 4 * q8, col), ba);      // arrives under the value chain
+            if constexpr (!P4) mz_quad_issue<128>(L, mz_quad_addr(red, 32 + 4 * q8, col), ba);      // arrives under the value chain
             const float v = mz_support_to_scalar_q(vs, n.Sv, n.vmin, n.no_transform, q8);
             if (q == 0) s_val[col] = v;
-            asm volatile("s_waitcnt lgkmcnt(0)" : MZ_Q(L));
-            if (q < 8 && 4 * q < n.A) *(f32x4 *)(s_lg + col * 32 + 4 * q) = mz_quad_sum(L);
+            if constexpr (!P4) asm volatile("s_waitcnt lgkmcnt(0)" : MZ_Q(L));
+            if constexpr (P4) {
+              const f32x4 lg4 = mz_logits4(red, s_b4 + 32, col, q);
+              if (q == 0) *(f32x4 *)(s_lg + col * 32) = lg4;
+            } else {
+              if (q < 8 && 4 * q < n.A) *(f32x4 *)(s_lg + col * 32 + 4 * q) = mz_quad_sum(L);
+            }
           }
         }
       }
@@ -759,11 +826,22 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
       MzQuad V, L;
       const unsigned ba = mz_lds_addr(s_b4 + 4 * q8);
       mz_quad_issue<0>(V, mz_quad_addr(red, 4 * q8, mt), ba);
-      mz_quad_issue<128>(L, mz_quad_addr(red, 32 + 4 * q8, mt), ba);
-      asm volatile("s_waitcnt lgkmcnt(0)" : MZ_Q(V), MZ_Q(L));
-      if (tl < 8 && 4 * tl < n.A) *(f32x4 *)(s_lg + mt * 32 + 4 * tl) = mz_quad_sum(L);
+      if constexpr (P4) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : MZ_Q(V));
+      } else {
+        mz_quad_issue<128>(L, mz_quad_addr(red, 32 + 4 * q8, mt), ba);
+        asm volatile("s_waitcnt lgkmcnt(0)" : MZ_Q(V), MZ_Q(L));
+      }
+      float lgl;          // this lane's logit (lane a = action a)
+      if constexpr (P4) {
+        const f32x4 lg4 = mz_logits4(red, s_b4 + 32, mt, tl);
+        lgl = (tl & 2) ? ((tl & 1) ? lg4[3] : lg4[2]) : ((tl & 1) ? lg4[1] : lg4[0]);
+      } else {
+        if (tl < 8 && 4 * tl < n.A) *(f32x4 *)(s_lg + mt * 32 + 4 * tl) = mz_quad_sum(L);
+        lgl = s_lg[mt * 32 + (tl < n.A ? tl : 0)];
+      }
       const float v = mz_support_to_scalar_q(mz_quad_sum(V), n.Sv, n.vmin, n.no_transform, q8);
-      const double pe = exp((double)s_lg[mt * 32 + (tl < n.A ? tl : 0)]);     // mcts.py:52 (unconditional: no branch)
+      const double pe = exp((double)lgl);     // mcts.py:52 (unconditional: no branch)
       double pr = (tl < n.A) ? pe : 0.0;
       asm volatile("" : "+v"(pr));       // pinned here: left alone, the compiler sinks the exp chain into the branch below
       STAMP(9)

@@ -456,16 +456,16 @@ __device__ __forceinline__ void mz_tree_backup_select_f(const TreeView &t, const
     // (a descent of this function always follows a backup: the root and every expanded node on the way down have been
     // visited, so mcts.py:105's fresh-root case, rank by prior, cannot occur here)
     double score = valid ? ucb : -__builtin_inf();
-    int best = valid ? cl : -1;
-    int pay = (Nc << 16) | (Ec & 0xffff);
+    // one word per child: action + 1 (0 = absent) above expansion index + 1 above visit count -- between two lanes of a
+    // group the actions differ, so comparing the words compares the actions, and the winner's E / N ride along
+    int key = Nc | ((Ec + 1) << 8) | (valid ? (cl + 1) << 16 : 0);
 #define MZ_AM_STEP(OFF)                                                                          \
   {                                                                                              \
     const double os = mz_xchg_d<OFF>(score);                                                     \
-    const int ob = mz_xchg_i<OFF>(best), op = mz_xchg_i<OFF>(pay);                               \
-    const bool take = (os > score) | ((os == score) & (ob > best));                              \
+    const int ok = mz_xchg_i<OFF>(key);                                                          \
+    const bool take = (os > score) | ((os == score) & (ok > key));                               \
     score = take ? os : score;                                                                   \
-    best = take ? ob : best;                                                                     \
-    pay = take ? op : pay;                                                                       \
+    key = take ? ok : key;                                                                       \
   }
     if constexpr (G > 1) MZ_AM_STEP(1)
     if constexpr (G > 2) MZ_AM_STEP(2)
@@ -473,14 +473,14 @@ __device__ __forceinline__ void mz_tree_backup_select_f(const TreeView &t, const
     if constexpr (G > 8) MZ_AM_STEP(8)
     if constexpr (G > 16) MZ_AM_STEP(16)
 #undef MZ_AM_STEP
-    a_sel = best;
+    a_sel = (key >> 16) - 1;
     parent_e = e;
     node = 1 + __mul24(e, A) + a_sel;
     if (lane == 0) s_path[len2] = node;
     ++len2;
     if (two) tpc = -tpc;
-    e = (int)(int16_t)(pay & 0xffff);
-    Np = pay >> 16;
+    e = ((key >> 8) & 0xff) - 1;
+    Np = key & 0xff;
     levelf.leave();
   }
   tr.len = len2;
