@@ -158,6 +158,12 @@ def main():
   events = [torch.cuda.Event(), torch.cuda.Event()]
   copy_stream = torch.cuda.Stream(device)
 
+  def wait(ev):
+    # the chunk's copy is a few milliseconds out: sleep-poll instead of spinning a core on hipEventSynchronize (one
+    # process per GPU shares the host's cores with seven others)
+    while not ev.query():
+      time.sleep(0.0002)
+
   def run(moves, count):
     """moves in chunks; D2H + host ingest of chunk i-1 overlap the GPU work of chunk i."""
     pending = None
@@ -172,13 +178,13 @@ def main():
       events[k & 1].record(copy_stream)
       if pending is not None:
         pb, pn, pe = pending
-        pe.synchronize()
+        wait(pe)
         replay.ingest_records(pb, pn, B)
       pending = (buf, n, events[k & 1])
       done += m
       k += 1
     pb, pn, pe = pending
-    pe.synchronize()
+    wait(pe)
     replay.ingest_records(pb, pn, B)
 
   def barrier():
@@ -195,9 +201,11 @@ def main():
   barrier()
   frames0 = replay.get_throughput()['frames']
   t0 = time.perf_counter()
+  c0 = time.process_time()
   run(args.steps, True)
   barrier()
   dt = time.perf_counter() - t0
+  host_cores_busy = (time.process_time() - c0) / dt      # CPU seconds of this rank (all its threads) per wall second
   frames = replay.get_throughput()['frames'] - frames0
   if dist is not None:
     tt = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -241,6 +249,7 @@ def main():
                    'weight_sync': 'flat f32 buffer broadcast from rank 0 + repack every %d moves, inside the timed region'
                                   % args.sync_every},
         'env_steps_executed_per_s': env_steps / dt,
+        'host_cores_busy_per_rank': host_cores_busy,
         'mcts_sims_per_s_per_gpu': env_steps * SIMS / dt / world,
         'roofline': {'bound': 'mfma', 'kernel': 'k_search_fused', 'achieved': achieved,
                      'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS,
