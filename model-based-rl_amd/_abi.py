@@ -89,6 +89,10 @@ def load():
   global _lib
   if _lib is not None:
     return _lib
+  # torch first: it brings its own copy of the HIP runtime, and a process must end up with ONE -- loaded the other way
+  # round (this library, then torch), the library binds the system's runtime and sees no device once torch has
+  # initialised its own
+  import torch  # noqa: F401
   if not os.path.exists(_SO):
     raise RuntimeError('libmz_hip.so is not built (%s). Build it with `python -c "import __graft_entry__ as g; '
                        'g.build()"`; this engine has no CPU fallback.' % _SO)
