@@ -649,7 +649,8 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
       const int mt = tid / TL + i * (256 / TL);
       asm volatile("s_waitcnt vmcnt(0)" : "+v"(hv[i]));
       if (tl < MZ_HS / 4) *(f32x4 *)(xR + mt * MZ_HS + 4 * tl) = hv[i];
-      for (int c = tl; c < MZ_XE; c += TL) xEd[mt * MZ_XE + c] = (c == my_act[i] || c == n.A) ? 1.f : 0.f;
+      // (only the columns the KS1 k-steps of the dynamics fc1 reach: k < 4 KS1)
+      for (int c = tl; c < 4 * KS1 - MZ_H; c += TL) xEd[mt * MZ_XE + c] = (c == my_act[i] || c == n.A) ? 1.f : 0.f;
     }
     STAMP(0)
     mz_bar();
