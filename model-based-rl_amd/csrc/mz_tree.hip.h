@@ -335,21 +335,20 @@ __device__ __forceinline__ void mz_tree_backup_select_f(const TreeView &t, const
   double v_cur = (double)value;
   double mn_c = __builtin_inf(), mx_c = -__builtin_inf();
   for (int base = 0; base < len; base += TL) {
+    // (written for few branches: every lane loads -- lanes beyond the path's end load the root's fields, which exist --
+    // and computes; only the stores are predicated.  Divergent ifs around the loads and the division cost more in
+    // exec-mask bookkeeping than the work they skipped.)
     const int j = base + lane;
     const bool act = j < len;
-    const int node = act ? s_path[len - 1 - j] : 0;
-    double Wn = 0.0, r_node = 0.0;
-    int Nn = 0, ntp = tp;
-    if (act) {
-      Wn = tm.W[node];
-      Nn = tm.N[node];
-      if (j == 0) { r_node = (double)reward; ntp = tp; }
-      else { r_node = (double)tm.R[node]; ntp = (int)tm.TP[node]; }
-    }
+    const int node = s_path[act ? len - 1 - j : 0];
+    const double Wn = tm.W[node];
+    const int Nn = tm.N[node];
+    const double r_node = (j == 0) ? (double)reward : (double)tm.R[node];
+    const int ntp = (j == 0) ? tp : (int)tm.TP[node];
     const double r_signed = (two && ntp == tp) ? -r_node : r_node;
     const int cnt = (len - base) < TL ? (len - base) : TL;
     double my_v = 0.0;
-    if (act) s_stage[32 + lane] = r_signed;       // the recurrence value = reward + discount*value runs in
+    s_stage[32 + lane] = r_signed;                 // the recurrence value = reward + discount*value runs in
     {                                              // every lane; lane j keeps the value its node receives.
       // The first four staged rewards come in two 16-byte reads and the recurrence runs on registers (most paths are
       // no longer than that); a select keeps the steps beyond the path's end from taking effect.
@@ -367,18 +366,18 @@ __device__ __forceinline__ void mz_tree_backup_select_f(const TreeView &t, const
       if (lane == jj) my_v = v_cur;
       v_cur = s_stage[32 + jj] + g * v_cur;
     }
+    const double w = Wn + ((ntp == tp) ? my_v : -my_v);
+    const int n = Nn + 1;
+    const double q = w / (double)n;
+    const double new_q = two ? r_node - g * q : r_node + g * q;     // = reward + discount * (two ? -Q : Q)
     if (act) {
-      const double w = Wn + ((ntp == tp) ? my_v : -my_v);
-      const int n = Nn + 1;
       tm.W[node] = w;
       tm.N[node] = n;
-      if (j < len - 1) {
-        const double q = w / (double)n;
-        const double new_q = two ? r_node - g * q : r_node + g * q;
-        if constexpr (LT != 0) tm.X[node] = new_q;     // = reward + discount * (two ? -Q : Q), what the descent normalises
-        mn_c = new_q; mx_c = new_q;
-      }
+      if constexpr (LT != 0) tm.X[node] = new_q;     // what the descent normalises (the root's is never read)
     }
+    const bool inner = act & (j < len - 1);          // MinMaxStats.update for every node but the root (mcts.py:136-141)
+    mn_c = inner ? new_q : mn_c;
+    mx_c = inner ? new_q : mx_c;
   }
   tr.root_n += 1;
 #define MZ_MM_STEP(OFF)                                                         \
