@@ -81,6 +81,9 @@ def run_both(name, B, sims, two=False, bounds=(None, None), discount=0.997, lega
     ((24, 30), 128, 12, True, (-3.0, 3.0), 0.99, 1.0),                 # widest instantiation
     ((8, 5), 200, 60, False, (None, None), 0.997, 1.0),                # A = 5 (8-lane groups), deep search
     ((8, 2), 64, 16, False, (None, None), 0.997, 1.0),                 # A = 2
+    ((8, 4), 96, 60, False, (None, None), 0.997, 1.0),                 # 4 actions, trees too large for LDS: descent fields in
+                                                                       # LDS + small-MFMA policy head behind the barrier
+    ((8, 3), 50, 30, True, (-2.0, 2.0), 0.99, 0.8),                    # A = 3, two players, illegal moves
 ])
 def test_search_vs_oracle(name, B, sims, two, bounds, discount, legal_p):
   out, ex, ref = run_both(name, B, sims, two, bounds, discount, legal_p)
