@@ -6,16 +6,19 @@
 //   the matrix cores  ->  [tree lanes] expand + backup + next descent.   Trees never leave their
 //   workgroup, so there is no grid-wide synchronisation and no host round trip between simulations.
 //
-// Weight streaming.  Each wave consumes its share of the network (~185 KiB per simulation) as one cyclic
+// Weight streaming.  Each wave consumes its share of the network (~180 KiB per simulation) as one cyclic
 // stream of STEPS; a step = four 1-KiB pieces = the A operands of 16 MFMAs, laid out in consumption order
-// (bias = the weight column of a constant-1 input, so there are no bias pieces).  Pieces go L2 -> VGPR
-// with plain global_load_dwordx4 into a ring of NB register buffers, NB-1 steps (>= 2000 cycles) ahead of
-// use.  The whole per-simulation schedule is unrolled so that every buffer index is a compile-time
-// constant; the stream is padded to a multiple of NB steps per simulation so the ring position is the
-// same at the top of every simulation and the prefetch runs across simulation boundaries, barriers and
-// the tree phase.   (Measured dead end, kept out: LDS-DMA (global_load_lds) rings filled by the MFMA
-// waves themselves -- each 1-KiB piece costs the issuing wave ~150 cycles of issue time, 4 per 16 MFMAs,
-// which halves the MFMA rate; see DESIGN.md.)
+// (bias = the weight column of a constant-1 input, so there are no bias pieces).  The first steps stay resident
+// in AGPRs for the whole launch; the others go L2 -> VGPR with buffer_load_dwordx4 into a ring of NB register
+// buffers, NB-1 steps (>= 2000 cycles) ahead of use.  The whole per-simulation schedule is unrolled so that every
+// buffer index is a compile-time constant; the stream is padded to a multiple of NB steps per simulation so the
+// ring position is the same at the top of every simulation and the prefetch runs across simulation boundaries,
+// barriers and the tree phase.  Every instruction in the MFMA stream costs issue time (the f32 "matrix core" IS
+// the vector ALU), so a streamed step carries exactly five besides its MFMAs: four loads and one counted wait.
+// Output rows that would fill a 16-row tile with padding (rows 48..49 of the hidden state, the policy head of a
+// 4-action game) run on v_mfma_f32_4x4x1_16b_f32 instead (mz_mfma4_*).
+// (Measured dead ends, kept out: LDS-DMA (global_load_lds) rings filled by the MFMA waves themselves -- each 1-KiB
+// piece costs the issuing wave ~150 cycles of issue time; a wave-specialised 8-wave variant; see DESIGN.md.)
 #pragma once
 #include "mz_common.h"
 #include "mz_net.hip.h"
