@@ -394,7 +394,15 @@ __device__ __forceinline__ float mz_support_to_scalar_q(const f32x4 &raw, int S,
   float e[4], sum = 0.f;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    e[r] = expf(x[r] - mx);          // exp(-inf) = 0 for the padding bins
+    // expf(d), d = x - max <= 0, written out: the device library's own arithmetic (hi/lo split of d * log2(e), exp2 of
+    // the fraction, ldexp) without its overflow / underflow clamps -- d <= 0 cannot overflow, results below
+    // 2^-149 may come out as that instead of 0, and the padding bins are set to 0 outright (exp(-inf) relied on the clamp)
+    const float d = raw[r] - mx;
+    const float th = d * 0x1.715476p+0f;
+    const float tl = __builtin_fmaf(d, 0x1.4ae0bep-26f, __builtin_fmaf(d, 0x1.715476p+0f, -th));
+    const float ri = __builtin_rintf(th);
+    const float y = __builtin_amdgcn_exp2f((th - ri) + tl);
+    e[r] = (4 * q + r < S) ? __builtin_ldexpf(y, (int)ri) : 0.f;
     sum += e[r];
   }
   sum = mz_sum8(sum);
