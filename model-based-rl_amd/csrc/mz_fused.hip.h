@@ -178,8 +178,13 @@ __device__ __forceinline__ float mz_sum8(float x) {
   x += mz_dpp<0xB1>(x); x += mz_dpp<0x4E>(x); x += mz_dpp<0x141>(x);
   return x;
 }
+// (one v_max_f32_dpp per step from asm: through fmaxf the compiler emits v_mov_dpp + a canonicalising v_max + the
+// v_max -- the operands here are sums of MFMA results, never signalling NaNs.  s_nop 1: VALU write -> DPP read)
 __device__ __forceinline__ float mz_max8(float x) {
-  x = fmaxf(x, mz_dpp<0xB1>(x)); x = fmaxf(x, mz_dpp<0x4E>(x)); x = fmaxf(x, mz_dpp<0x141>(x));
+  asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+               "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+               "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1"
+               : "+v"(x));
   return x;
 }
 
