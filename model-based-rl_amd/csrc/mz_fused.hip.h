@@ -639,7 +639,11 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
   }
   // the streamed part follows the resident one: ring step r at byte RS*4096 + r*4096
   // (piece offset as the instruction's immediate, step offset as the scalar offset: one s_mov per step instead of four)
-#define MZ_WLOAD(step, piece) __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane_off + (piece) * 1024, (RS + (step)) * 4096, 0))
+#define MZ_WLOAD(step, piece) __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane_off + (piece) * 1024, sbase + (step) * 4096, 0))
+  // scalar offset of ring step 0.  Laundered through asm at the top of every simulation: as a known constant the
+  // compiler materialises one SGPR per step of the unrolled schedule (33 of them), spills other scalars to make room
+  // and pays v_readlane reloads inside the MFMA stream; as an opaque base a step costs one s_add
+  int sbase = RS * 4096;
   f32x4 Bf[NB][4];
 #pragma unroll
   for (int s = 0; s < NB - 1; ++s) {
@@ -656,6 +660,7 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
   __syncthreads();
 
   for (int sim = 0; sim < nsims; ++sim) {
+    asm volatile("" : "+s"(sbase));
     int lane_e = lane;                  // epilogue lane index, laundered: the LDS addresses derived from it are
     asm volatile("" : "+v"(lane_e));    // recomputed every simulation instead of living in registers all along
     // ---- gather: x tile = [hidden of search_path[-2] | one-hot(action) | 1]  (mcts.py:94-96)
