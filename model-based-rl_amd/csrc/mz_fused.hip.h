@@ -686,16 +686,24 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
       constexpr int s = decltype(S_)::value;
       // streamed steps: prefetch ring step r + NB - 1 (cyclic: the tail of a simulation prefetches the head of
       // the next); resident steps issue no loads
+      // fc2 steps: the compiler's hazard recogniser wants one instruction between two groups of four MFMAs that
+      // accumulate into the same four tiles and fills the slot with s_nop 0 (three per step) -- so those steps issue
+      // their four prefetch loads one per slot instead of up front (SPREAD), and wait for their own pieces first
+      constexpr bool SPREAD = (s >= E_FC1 && s < E_FC2) || (s >= E_P1 && s < E_P2);
+      constexpr int pf_r = s >= RS ? s - RS : 0;
+      constexpr int pf_ps = (pf_r + NB - 1) % NRING, pf_pb = (pf_r + NB - 1) % NB;
       if constexpr (s >= RS) {
-        constexpr int r = s - RS;
-        constexpr int ps = (r + NB - 1) % NRING, pb = (r + NB - 1) % NB;
+        static_assert(NB == 5, "the vmcnt values below assume a prefetch distance of 4 steps");
+        if constexpr (SPREAD) {
+          __builtin_amdgcn_s_waitcnt(0x0F7C);     // vmcnt(12): this step's loads are not out yet
+        } else {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) Bf[pb][p] = MZ_WLOAD(ps, p);
-        // this step's own pieces were requested NB - 1 steps ago: exactly 4 (NB - 1) younger requests are allowed to be
-        // outstanding.  ONE explicit wait per step -- left alone the compiler emits a counted wait in front of each of the
-        // step's four pieces, and every instruction in the MFMA stream costs issue time.
-        static_assert(NB == 5, "vmcnt(16) below assumes a prefetch distance of 4 steps");
-        __builtin_amdgcn_s_waitcnt(0x4F70);     // vmcnt(16)
+          for (int p = 0; p < 4; ++p) Bf[pf_pb][p] = MZ_WLOAD(pf_ps, p);
+          // this step's own pieces were requested NB - 1 steps ago: exactly 4 (NB - 1) younger requests are allowed to
+          // be outstanding.  ONE explicit wait per step -- left alone the compiler emits a counted wait in front of each
+          // of the step's four pieces, and every instruction in the MFMA stream costs issue time.
+          __builtin_amdgcn_s_waitcnt(0x4F70);     // vmcnt(16)
+        }
       }
       constexpr int cb = (s >= RS ? s - RS : 0) % NB;
       if constexpr (s < E_FC1 || (s >= E_FC2 && s < E_P1)) {
@@ -757,6 +765,8 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
             } else if (q < 6 && r == 0) mz_mfma_a0(out2[jt], Bf[cb][q4][r], acc[jt < 2 ? tt : 8 + tt][r]);
             else mz_mfma_a(out2[jt], Bf[cb][q4][r], acc[jt < 2 ? tt : 8 + tt][r]);
           }
+          Bf[pf_pb][r] = MZ_WLOAD(pf_ps, r);
+          __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (s == E_FC2 - 1) {
           mz_mfma_fence<6>(out2);
@@ -803,6 +813,8 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
             } else if (q < NJ2 && r == 0) mz_mfma_a0(out4[jt], Bf[cb][q4][r], acc[jt < 2 ? tt : 8 + tt][r]);
             else mz_mfma_a(out4[jt], Bf[cb][q4][r], acc[jt < 2 ? tt : 8 + tt][r]);
           }
+          Bf[pf_pb][r] = MZ_WLOAD(pf_ps, r);
+          __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (s == E_P2 - 1) {
           mz_mfma_fence<NJ2>(out4);
