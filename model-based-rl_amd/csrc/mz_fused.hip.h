@@ -360,7 +360,9 @@ __device__ __forceinline__ void sln_relu8p(const float *red, const float *bias, 
     v += db[r] * db[r];
   }
   v = mz_sum8(v);
-  const float rstd = 1.0f / sqrtf(v * (1.0f / (float)MZ_H) + 1e-5f);
+  // v_rsq_f32 (1 ulp) instead of a correctly rounded sqrt followed by a correctly rounded division (two roundings,
+  // ~25 instructions on the epilogue's critical chain): either is within an ulp of the true value
+  const float rstd = __builtin_amdgcn_rsqf(v * (1.0f / (float)MZ_H) + 1e-5f);
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wA), "+v"(wB), "+v"(bA), "+v"(bB));
   f32x4 ya, yb;
 #pragma unroll
