@@ -413,7 +413,7 @@ __device__ __forceinline__ float mz_support_to_scalar_q(const f32x4 &raw, int S,
     sum += e[r];
   }
   sum = mz_sum8(sum);
-  const float rs = 1.0f / sum;
+  const float rs = __builtin_amdgcn_rcpf(sum);      // (1 ulp; the probabilities were e * (1 / sum) already, not e / sum)
   float v = 0.f;
 #pragma unroll
   for (int r = 0; r < 4; ++r) v += (float)(smin + 4 * q + r) * (e[r] * rs);
