@@ -143,6 +143,15 @@ __device__ __forceinline__ void mz_xval_async(float &x, const float *xR, const f
   asm volatile("ds_read_b32 %0, %1" : "=v"(x) : "v"(addr));
 }
 __device__ __forceinline__ void mz_lds_wait(float &x) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x)); }
+// the B operands of two consecutive k-steps inside the hidden columns, xR[m][4 st + g] and xR[m][4 st + 4 + g], with
+// one ds_read2_b32 (xbase = LDS address of xR[m][g]; ST even): one read and one wait per two fc1 steps, one address
+// register for all of them
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int ST>
+__device__ __forceinline__ void mz_xpair_async(f32x2 &x, unsigned xbase) {
+  asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(x) : "v"(xbase), "n"(4 * ST), "n"(4 * ST + 4));
+}
+__device__ __forceinline__ void mz_lds_wait2(f32x2 &x) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x)); }
 
 // combine the four waves' split-K partial tiles (+ bias) into fin[n][m].  Partials are exchanged as one
 // 16-byte vector per lane and tile (ds_write_b128 / ds_read_b128): 6 + 4 LDS instructions per lane instead of
@@ -683,7 +692,9 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
     f32x4 acc[16];       // fc1 tiles (arch VGPRs); after the in-place ReLU they are the hidden activations
     f32x4 out2[6];
     f32x4 out4[NJ2];
-    float xq = 0.f;       // B operand of the NEXT fc1 step (read one step ahead)
+    float xq = 0.f;       // B operand of the NEXT fc1 step (read one step ahead; the steps beyond the hidden columns)
+    f32x2 xpair[2];       // B operands of fc1 steps 0..11, two per read
+    const unsigned xbase = mz_lds_addr(xR + m16 * MZ_HS + g4);
     mz_static_for<NSTEPS>([&](auto S_) __attribute__((always_inline)) {
       constexpr int s = decltype(S_)::value;
       // streamed steps: prefetch ring step r + NB - 1 (cyclic: the tail of a simulation prefetches the head of
@@ -712,10 +723,24 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
         // fc1 step: 16 tiles of this wave x one k-step; x from the tile (+ extension for k >= 50)
         constexpr bool dyn = s < E_FC1;
         constexpr int st = dyn ? s : s - E_FC2;
-        if constexpr (st == 0) mz_xval_async(xq, xR, dyn ? xEd : xEp, m16, g4);
-        mz_lds_wait(xq);
-        const float x = xq;
-        if constexpr (st + 1 < (dyn ? SC::FC1 : SC::P1)) mz_xval_async(xq, xR, dyn ? xEd : xEp, m16, 4 * (st + 1) + g4);
+        constexpr int NST = dyn ? SC::FC1 : SC::P1;
+        float x;
+        if constexpr (st < 12) {        // k-steps 0..11 lie inside the 50 hidden columns: fetched in pairs
+          f32x2 &cur = xpair[(st / 2) % 2];
+          if constexpr (st % 2 == 0) {
+            if constexpr (st == 0) mz_xpair_async<0>(cur, xbase);
+            mz_lds_wait2(cur);
+            x = cur[0];
+            if constexpr (st + 2 < 12) mz_xpair_async<st + 2>(xpair[(st / 2 + 1) % 2], xbase);
+          } else {
+            x = cur[1];
+            if constexpr (st == 11 && NST > 12) mz_xval_async(xq, xR, dyn ? xEd : xEp, m16, 4 * 12 + g4);
+          }
+        } else {                        // the last k-steps reach into the extension (one-hot / bias columns)
+          mz_lds_wait(xq);
+          x = xq;
+          if constexpr (st + 1 < NST) mz_xval_async(xq, xR, dyn ? xEd : xEp, m16, 4 * (st + 1) + g4);
+        }
 #pragma unroll
         for (int tg = 0; tg < 4; ++tg) {
           if constexpr (s < RS) {
