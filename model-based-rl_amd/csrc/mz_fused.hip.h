@@ -597,6 +597,11 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
       if constexpr (LT == 1) {       // bring the existing part of the tree (root, expanded slabs) into LDS
         const size_t o = (size_t)b * t.NN;
         const int have = 1 + (slot0 + 1) * t.A;
+        // every node this launch can create starts as a fresh Node (mcts.py:30-37): visit_count 0, value_sum 0, reward 0,
+        // no children, to_play 1 -- written once here, so that an expansion only has to set the priors
+        for (int k = have + tl; k < t.NN; k += TL) {
+          tm[i].N[k] = 0; tm[i].W[k] = 0.0; tm[i].R[k] = 0.f; tm[i].E[k] = -1; tm[i].TP[k] = 1;
+        }
         for (int k = tl; k < have; k += TL) {
           tm[i].N[k] = (int16_t)t.N[o + k]; tm[i].W[k] = t.W[o + k]; tm[i].P[k] = t.P[o + k]; tm[i].R[k] = t.R[o + k];
           const double qk = t.N[o + k] > 0 ? t.W[o + k] / (double)t.N[o + k] : 0.0;      // a continued search: what the backup

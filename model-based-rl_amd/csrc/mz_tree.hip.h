@@ -293,7 +293,8 @@ __device__ __forceinline__ void mz_tree_expand_f(const TreeView &t, const TreeMe
   for (int a = 0; a < G; ++a) sum = sum + s_stage[a];
   if (lane < A) {
     const int ch = 1 + e_new * A + lane;
-    tm.N[ch] = 0; tm.W[ch] = 0.0; tm.R[ch] = 0.f; tm.E[ch] = -1; tm.TP[ch] = 1;
+    // (LT = 1: the kernel's prologue has written the fresh-Node fields of every node this launch can create)
+    if constexpr (LT != 1) { tm.N[ch] = 0; tm.W[ch] = 0.0; tm.R[ch] = 0.f; tm.E[ch] = -1; tm.TP[ch] = 1; }
     tm.P[ch] = p / sum;
   }
   if (lane == 0) { tm.E[leafnode] = e_new; tm.TP[leafnode] = (int8_t)tr.tp; tm.R[leafnode] = reward; }
