@@ -115,9 +115,14 @@ __device__ __forceinline__ void mz_valu_fence16v(f32x4 (&acc)[16]) {
 }
 template <int N>
 __device__ __forceinline__ void mz_mfma_fence(f32x4 (&acc)[N]) {
-#pragma unroll
-  for (int i = 0; i < N; ++i) asm volatile("s_nop 7" : "+a"(acc[i]));
-  asm volatile("s_nop 15" ::: "memory");
+  static_assert(N >= 1 && N <= 6, "out tiles");
+  // one wait for the LAST MFMA's result (24 wait states), all tiles tied to it
+  if constexpr (N == 6) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]), "+a"(acc[4]), "+a"(acc[5]) :: "memory");
+  else if constexpr (N == 5) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]), "+a"(acc[4]) :: "memory");
+  else if constexpr (N == 4) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]) :: "memory");
+  else if constexpr (N == 3) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]) :: "memory");
+  else if constexpr (N == 2) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc[0]), "+a"(acc[1]) :: "memory");
+  else asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc[0]) :: "memory");
 }
 
 // ReLU as ONE instruction: fmaxf() (and the fmed3 builtin) on a value that comes out of inline asm is preceded by
