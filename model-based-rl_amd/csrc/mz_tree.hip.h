@@ -335,6 +335,10 @@ __device__ __forceinline__ void mz_tree_backup_select_f(const TreeView &t, const
   // ---- MCTS.backpropagate (mcts.py:126-143), TL path nodes per round
   double v_cur = (double)value;
   double mn_c = __builtin_inf(), mx_c = -__builtin_inf();
+  // MinMaxStats.update over the path: when no path in this wave has more than four nodes below the root, the nodes'
+  // values go through LDS (one write, two 16-byte reads, three v_min_f64 + three v_max_f64, quiet NaN = "no node",
+  // which minNum / maxNum ignore) instead of a four-step DPP reduction of two doubles over the tree's 16 lanes
+  const bool shortp = __builtin_amdgcn_ballot_w64(len > 5) == 0;
   for (int base = 0; base < len; base += TL) {
     // (written for few branches: every lane loads -- lanes beyond the path's end load the root's fields, which exist --
     // and computes; only the stores are predicated.  Divergent ifs around the loads and the division cost more in
@@ -379,8 +383,20 @@ __device__ __forceinline__ void mz_tree_backup_select_f(const TreeView &t, const
     const bool inner = act & (j < len - 1);          // MinMaxStats.update for every node but the root (mcts.py:136-141)
     mn_c = inner ? new_q : mn_c;
     mx_c = inner ? new_q : mx_c;
+    if (shortp) s_stage[64 + lane] = inner ? new_q : __builtin_nan("");
   }
   tr.root_n += 1;
+  if (shortp) {
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    const f64x2 qa = *(const f64x2 *)(s_stage + 64), qb = *(const f64x2 *)(s_stage + 66);
+    double n01, n23, x01, x23;
+    asm("v_min_f64 %0, %1, %2" : "=v"(n01) : "v"(qa[0]), "v"(qa[1]));
+    asm("v_min_f64 %0, %1, %2" : "=v"(n23) : "v"(qb[0]), "v"(qb[1]));
+    asm("v_max_f64 %0, %1, %2" : "=v"(x01) : "v"(qa[0]), "v"(qa[1]));
+    asm("v_max_f64 %0, %1, %2" : "=v"(x23) : "v"(qb[0]), "v"(qb[1]));
+    asm("v_min_f64 %0, %1, %2" : "=v"(mn_c) : "v"(n01), "v"(n23));
+    asm("v_max_f64 %0, %1, %2" : "=v"(mx_c) : "v"(x01), "v"(x23));
+  } else {
 #define MZ_MM_STEP(OFF)                                                         \
   {                                                                             \
     const double a_ = mz_xchg_d<OFF>(mn_c), c_ = mz_xchg_d<OFF>(mx_c);         \
@@ -390,7 +406,8 @@ __device__ __forceinline__ void mz_tree_backup_select_f(const TreeView &t, const
   MZ_MM_STEP(1) MZ_MM_STEP(2) MZ_MM_STEP(4) MZ_MM_STEP(8)
   if constexpr (TL == 32) MZ_MM_STEP(16)
 #undef MZ_MM_STEP
-  tr.mn = mn_c < tr.mn ? mn_c : tr.mn;
+  }
+  tr.mn = mn_c < tr.mn ? mn_c : tr.mn;         // (a NaN -- no node below the root -- compares false: nothing changes)
   tr.mx = mx_c > tr.mx ? mx_c : tr.mx;
   stampf(1);
   if (!do_select) return;
