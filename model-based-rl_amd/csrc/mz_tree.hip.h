@@ -287,12 +287,12 @@ __device__ __forceinline__ void mz_tree_expand_f(const TreeView &t, const TreeMe
                                                  double *s_stage, const TreeRegs &tr) {
   const int A = t.A;
   const int leafnode = s_path[tr.len - 1];
-  if (lane < G) s_stage[lane] = p;              // every lane then adds them up in Python's sum() order (G >= A terms:
+  s_stage[lane] = p;                            // every lane then adds them up in Python's sum() order (G >= A terms:
   double sum = 0.0;                             // the lanes beyond A contribute exact zeros at the end of the sum)
 #pragma unroll
   for (int a = 0; a < G; ++a) sum = sum + s_stage[a];
   if (lane < A) {
-    const int ch = 1 + e_new * A + lane;
+    const int ch = 1 + __mul24(e_new, A) + lane;
     // (LT = 1: the kernel's prologue has written the fresh-Node fields of every node this launch can create)
     if constexpr (LT != 1) { tm.N[ch] = 0; tm.W[ch] = 0.0; tm.R[ch] = 0.f; tm.E[ch] = -1; tm.TP[ch] = 1; }
     tm.P[ch] = p / sum;
