@@ -8,7 +8,7 @@ import os
 import subprocess
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
-_SO = os.path.join(_CSRC, 'libmz_hip.so')
+_SO = os.environ.get('MZ_HIP_LIB') or os.path.join(_CSRC, 'libmz_hip.so')      # (MZ_HIP_LIB: A/B runs of two builds on one box)
 _SOURCES = ['mz_engine.hip', 'mz_common.h', 'mz_net.hip.h', 'mz_tree.hip.h', 'mz_rng.h', 'mz_selfplay.hip.h',
             'mz_selfplay_abi.inc', 'mz_fused.hip.h', 'mz_root.hip.h']
 _lib = None
