@@ -99,9 +99,10 @@ __device__ __forceinline__ void mz_mfma_v0a(f32x4 &c, float a, float b) {
 __device__ __forceinline__ void mz_mfma_v0(f32x4 &c, float a, float b) {
   asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
 }
-// MFMA results -> VALU: wait states after the LAST MFMA of a stage (the earlier ones are long done)
+// MFMA results -> VALU: wait states after the LAST MFMA of a stage (the earlier ones are long done): 17, the 8-pass
+// MFMA needs 11
 __device__ __forceinline__ void mz_mfma_fence16v(f32x4 (&acc)[16]) {
-  asm volatile("s_nop 15\n\ts_nop 7"
+  asm volatile("s_nop 15\n\ts_nop 0"
                : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]),
                  "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11]), "+v"(acc[12]),
                  "+v"(acc[13]), "+v"(acc[14]), "+v"(acc[15]));
@@ -117,12 +118,12 @@ template <int N>
 __device__ __forceinline__ void mz_mfma_fence(f32x4 (&acc)[N]) {
   static_assert(N >= 1 && N <= 6, "out tiles");
   // one wait for the LAST MFMA's result (24 wait states), all tiles tied to it
-  if constexpr (N == 6) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]), "+a"(acc[4]), "+a"(acc[5]) :: "memory");
-  else if constexpr (N == 5) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]), "+a"(acc[4]) :: "memory");
-  else if constexpr (N == 4) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]) :: "memory");
-  else if constexpr (N == 3) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]) :: "memory");
-  else if constexpr (N == 2) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc[0]), "+a"(acc[1]) :: "memory");
-  else asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc[0]) :: "memory");
+  if constexpr (N == 6) asm volatile("s_nop 15\n\ts_nop 0" : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]), "+a"(acc[4]), "+a"(acc[5]) :: "memory");
+  else if constexpr (N == 5) asm volatile("s_nop 15\n\ts_nop 0" : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]), "+a"(acc[4]) :: "memory");
+  else if constexpr (N == 4) asm volatile("s_nop 15\n\ts_nop 0" : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]) :: "memory");
+  else if constexpr (N == 3) asm volatile("s_nop 15\n\ts_nop 0" : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]) :: "memory");
+  else if constexpr (N == 2) asm volatile("s_nop 15\n\ts_nop 0" : "+a"(acc[0]), "+a"(acc[1]) :: "memory");
+  else asm volatile("s_nop 15\n\ts_nop 0" : "+a"(acc[0]) :: "memory");
 }
 
 // ReLU as ONE instruction: fmaxf() (and the fmed3 builtin) on a value that comes out of inline asm is preceded by
