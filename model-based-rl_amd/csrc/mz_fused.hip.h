@@ -36,14 +36,18 @@ __device__ __forceinline__ void mz_static_for(F &&f) {
   mz_static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-#define MZ_NB 5      // register ring depth in steps (prefetch distance NB-1 steps)
+#ifndef MZ_NB
+#define MZ_NB 4      // register ring depth in steps (prefetch distance NB-1 steps = ~1600 cycles; A/B on one box:
+#endif               // 4 buffers + 13 resident steps 406 us, 5 + 12: 410, 3 + 14: 407)
+// s_waitcnt vmcnt(N), nothing else waited for (gfx9 encoding: vmcnt in bits 3:0 and 15:14, expcnt 6:4, lgkmcnt 11:8)
+#define MZ_VMCNT(N) (((N) & 15) | (((N) >> 4) << 14) | 0x0F70)
 // steps of the stream held in registers (AGPRs) across all simulations: less L2 traffic and no load issue in those
 // steps (a streamed step runs at ~37 cycles/MFMA, a resident one at 32).  As many as the register file takes
 // without scratch: the wide-action instantiations (two tree passes, two policy tiles) have fewer to spare.
 #ifndef MZ_RS_MAIN
-#define MZ_RS_MAIN 12
+#define MZ_RS_MAIN 13
 #endif
-__host__ __device__ constexpr int mz_fused_rs(int ks1, int jtp) { return jtp > 1 ? 8 : (ks1 > 16 ? 10 : (ks1 > 14 ? 11 : MZ_RS_MAIN)); }
+__host__ __device__ constexpr int mz_fused_rs(int ks1, int jtp) { return jtp > 1 ? 9 : (ks1 > 16 ? 11 : (ks1 > 14 ? 12 : MZ_RS_MAIN)); }
 #define MZ_XE 36     // row stride of the x-tile extension [one-hot(action) | 1 | 0 ...] (k >= 50)
 
 // per-simulation schedule (in steps of 16 MFMAs per wave)
@@ -717,16 +721,15 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
       constexpr int pf_r = s >= RS ? s - RS : 0;
       constexpr int pf_ps = (pf_r + NB - 1) % NRING, pf_pb = (pf_r + NB - 1) % NB;
       if constexpr (s >= RS) {
-        static_assert(NB == 5, "the vmcnt values below assume a prefetch distance of 4 steps");
         if constexpr (SPREAD) {
-          __builtin_amdgcn_s_waitcnt(0x0F7C);     // vmcnt(12): this step's loads are not out yet
+          __builtin_amdgcn_s_waitcnt(MZ_VMCNT(4 * (NB - 2)));     // (12 for NB = 5) this step's loads are not out yet
         } else {
 #pragma unroll
           for (int p = 0; p < 4; ++p) Bf[pf_pb][p] = MZ_WLOAD(pf_ps, p);
           // this step's own pieces were requested NB - 1 steps ago: exactly 4 (NB - 1) younger requests are allowed to
           // be outstanding.  ONE explicit wait per step -- left alone the compiler emits a counted wait in front of each
           // of the step's four pieces, and every instruction in the MFMA stream costs issue time.
-          __builtin_amdgcn_s_waitcnt(0x4F70);     // vmcnt(16)
+          __builtin_amdgcn_s_waitcnt(MZ_VMCNT(4 * (NB - 1)));     // (16 for NB = 5)
         }
       }
       constexpr int cb = (s >= RS ? s - RS : 0) % NB;
@@ -860,7 +863,7 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
           // every wave's hidden-state stores must have landed before the tree lanes may gather them: they are older
           // than the last 16 weight loads, so vmcnt(16) covers them without draining the prefetch ring; the barrier
           // inside mz_partials_out then publishes them
-          __builtin_amdgcn_s_waitcnt(0x4F70);     // vmcnt(16)
+          __builtin_amdgcn_s_waitcnt(MZ_VMCNT(4 * (NB - 1)));
           mz_partials_out<NJ2, P4 ? 1 << 2 : 0>(red, out4, tid);
           STAMP(8)
           if constexpr (TL != 16 || LT == 2) {
