@@ -107,9 +107,11 @@ def main():
   ap.add_argument('--warmup', type=int, default=64)
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--workload', choices=sorted(WORKLOADS), default='lunar')
+  ap.add_argument('--chunk', type=int, default=CHUNK, help='moves per drain / ingest chunk')
   ap.add_argument('--sync-every', type=int, default=128,
                   help='moves between weight pulls (the path\'s one exchange: broadcast + repack); 0 = only once')
   args = ap.parse_args()
+  chunk = max(1, args.chunk)
 
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
@@ -154,7 +156,7 @@ def main():
   replay = PrioritizedReplay(cfg)
   eng.selfplay_reset(EPISODE_LEN, 1.0, stagger=True)
   rec = eng.rec_floats
-  pinned = [torch.empty(CHUNK, B, rec, dtype=torch.float32).pin_memory() for _ in range(2)]
+  pinned = [torch.empty(chunk, B, rec, dtype=torch.float32).pin_memory() for _ in range(2)]
   events = [torch.cuda.Event(), torch.cuda.Event()]
   copy_stream = torch.cuda.Stream(device)
 
@@ -170,7 +172,7 @@ def main():
     done = 0
     k = 0
     while done < moves:
-      m = min(CHUNK, moves - done)
+      m = min(chunk, moves - done)
       if args.sync_every and done and done % args.sync_every == 0:
         sync_weights()       # Actor.sync_weights (actors.py:81-85): fresh weights from the storage rank, in stream order
       eng.selfplay_steps(m)
@@ -222,10 +224,10 @@ def main():
   # timestamps rocprofv3's kernel trace reports) over a stretch of the same self-play loop, launched back to back.
   durs = []
   for _ in range(4):
-    durs += eng.selfplay_steps_timed(CHUNK)
-    eng.selfplay_drain(pinned[0], CHUNK)
+    durs += eng.selfplay_steps_timed(chunk)
+    eng.selfplay_drain(pinned[0], chunk)
     torch.cuda.synchronize(device)
-  search_us = 1e3 * float(np.mean(durs[CHUNK:]))       # (first chunk = warm-up)
+  search_us = 1e3 * float(np.mean(durs[chunk:]))       # (first chunk = warm-up)
 
   if rank == 0:
     value = frames / dt
