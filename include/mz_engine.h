@@ -56,7 +56,8 @@ typedef struct mz_config {
   double root_exploration_fraction; /* --root_exploration_fraction */
   uint64_t seed;                /* counter-based device RNG key (throughput mode) */
   int32_t env_id_offset;        /* global id of env 0 (rank * num_envs when actors are sharded over GPUs) */
-  int32_t reserved;
+  int32_t no_support;           /* --no_support: value / reward heads are single scalars (networks.py:135-136), returned
+                                 * untransformed in eval mode (networks.py:153,161); the supports above are ignored */
 } mz_config;
 
 const char *mz_last_error(void);

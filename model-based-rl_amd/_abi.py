@@ -26,7 +26,7 @@ class MzConfig(C.Structure):
               ('discount', C.c_double), ('pb_c_base', C.c_double), ('pb_c_init', C.c_double),
               ('init_value_score', C.c_double), ('root_dirichlet_alpha', C.c_double),
               ('root_exploration_fraction', C.c_double), ('seed', C.c_uint64), ('env_id_offset', C.c_int32),
-              ('reserved', C.c_int32)]
+              ('no_support', C.c_int32)]
 
 
 def stale():

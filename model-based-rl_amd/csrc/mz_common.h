@@ -53,5 +53,5 @@ struct NetView {
   int ks0, ks1, ks3;      // k-steps (K/4) of the three fc1 stages
   int O, A, jtp;
   int Sr, Sv, rmin, vmin; // support sizes / minima (config.py:12-19)
-  int no_transform;       // --no_target_transform
+  int no_transform;       // 1 = --no_target_transform, 2 = --no_support (scalar heads, Sr = Sv = 1)
 };

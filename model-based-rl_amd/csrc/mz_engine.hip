@@ -167,8 +167,8 @@ static void fill_vec(std::vector<int32_t> &idx, size_t pos, int padded, size_t o
 
 static int build_packing(mz_engine *e) {
   const int O = e->O, A = e->A;
-  const int Sv = e->cfg.value_support_max - e->cfg.value_support_min + 1;
-  const int Sr = e->cfg.reward_support_max - e->cfg.reward_support_min + 1;
+  const int Sv = e->cfg.no_support ? 1 : e->cfg.value_support_max - e->cfg.value_support_min + 1;   // networks.py:135-136
+  const int Sr = e->cfg.no_support ? 1 : e->cfg.reward_support_max - e->cfg.reward_support_min + 1;
   const FlatLayout L = flat_layout(O, A, Sv, Sr);
   e->n_flat = L.total;
   const int ks0 = (O + 3) / 4, ks1 = (MZ_H + A + 3) / 4, ks3 = (MZ_H + 3) / 4;
@@ -299,8 +299,10 @@ static int build_packing(mz_engine *e) {
   e->istream = (const f32x4 *)(P + p_is);
   e->nst0 = nst0;
   n.ks0 = ks0; n.ks1 = ks1; n.ks3 = ks3; n.O = O; n.A = A; n.jtp = jtp;
-  n.Sr = Sr; n.Sv = Sv; n.rmin = e->cfg.reward_support_min; n.vmin = e->cfg.value_support_min;
-  n.no_transform = e->cfg.no_target_transform;
+  n.Sr = Sr; n.Sv = Sv;
+  n.rmin = e->cfg.no_support ? 0 : e->cfg.reward_support_min;   // (0: mz_support_to_scalar_q adds the raw output to it)
+  n.vmin = e->cfg.no_support ? 0 : e->cfg.value_support_min;
+  n.no_transform = e->cfg.no_support ? 2 : (e->cfg.no_target_transform ? 1 : 0);
   return 0;
 }
 
@@ -444,8 +446,8 @@ int mz_create(const mz_config *cfg, mz_engine **out) {
     return fail("mz_create: action_space %d outside [1,%d]", cfg->action_space, MZ_MAX_ACTIONS);
   if (cfg->obs_dim < 1) return fail("mz_create: obs_dim must be >= 1");
   if (cfg->num_simulations < 1 || cfg->num_simulations > 4096) return fail("mz_create: num_simulations out of range");
-  const int Sv = cfg->value_support_max - cfg->value_support_min + 1;
-  const int Sr = cfg->reward_support_max - cfg->reward_support_min + 1;
+  const int Sv = cfg->no_support ? 1 : cfg->value_support_max - cfg->value_support_min + 1;
+  const int Sr = cfg->no_support ? 1 : cfg->reward_support_max - cfg->reward_support_min + 1;
   if (Sv < 1 || Sv > MZ_MAX_SUPPORT || Sr < 1 || Sr > MZ_MAX_SUPPORT)
     return fail("mz_create: support size must be in [1,%d] (value %d, reward %d)", MZ_MAX_SUPPORT, Sv, Sr);
   int ndev = 0;

@@ -249,7 +249,9 @@ __device__ __forceinline__ void sln_relu16(const float *fin, float *xR, const fl
   }
 }
 
-// Config.inverse_transform (config.py:27-33), column m, 16 lanes per column, S <= 32 bins
+// Config.inverse_transform (config.py:27-33), column m, 16 lanes per column, S <= 32 bins.
+// no_transform: 0 = transform, 1 = --no_target_transform, 2 = --no_support (S == 1; networks.py:153,161 return the
+// head's scalar untouched)
 __device__ __forceinline__ float mz_support_to_scalar16(const float *fin, int row0, int S, int smin, int no_transform,
                                                         int m, int q) {
   float x[2], mx = -__builtin_inff();
@@ -270,6 +272,7 @@ __device__ __forceinline__ float mz_support_to_scalar16(const float *fin, int ro
   float v = 0.f;
 #pragma unroll
   for (int i = 0; i < 2; ++i) v += (float)(smin + q + 16 * i) * (e[i] / sum);
+  if (no_transform == 2) v = (q == 0) ? x[0] : 0.f;   // --no_support: the head's single output as it is
   v = mz_sum16(v);
   if (!no_transform) {
     const float sgn = (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f);
@@ -407,35 +410,41 @@ __device__ __forceinline__ f32x4 mz_logits4(const float *red, const float *bias,
   return o;
 }
 
-// Config.inverse_transform (config.py:27-33) of the S <= 32 bins in x (lane q of the 8 lanes of a column holds
-// bins 4q..4q+3)
-__device__ __forceinline__ float mz_support_to_scalar_q(const f32x4 &raw, int S, int smin, int no_transform, int q) {
-  float x[4], mx = -__builtin_inff();
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    x[r] = (4 * q + r < S) ? raw[r] : -__builtin_inff();
-    mx = fmaxf(mx, x[r]);
-  }
+// Config.inverse_transform (config.py:27-33) of the 32 bins in raw (lane q of the 8 lanes of a column holds bins
+// 4q..4q+3).  Bins beyond the support size arrive as MZ_PAD_BIN (their bias in LDS, weights zero): exp(d) of those is
+// 2^(about -1.4e9) = 0 exactly, so they drop out of the maximum, the sum and the expectation without a mask
+// (exact as long as the real logits stay within +-1e8).
+// no_transform: 0 = transform, 1 = --no_target_transform, 2 = --no_support (one output; networks.py:153,161 return it as it is)
+#define MZ_PAD_BIN (-1.0e9f)
+__device__ __forceinline__ float mz_support_to_scalar_q(const f32x4 &raw, int smin, int no_transform, int q) {
+  float mx = fmaxf(fmaxf(raw[0], raw[1]), fmaxf(raw[2], raw[3]));
   mx = mz_max8(mx);
   float e[4], sum = 0.f;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     // expf(d), d = x - max <= 0, written out: the device library's own arithmetic (hi/lo split of d * log2(e), exp2 of
     // the fraction, ldexp) without its overflow / underflow clamps -- d <= 0 cannot overflow, results below
-    // 2^-149 may come out as that instead of 0, and the padding bins are set to 0 outright (exp(-inf) relied on the clamp)
+    // 2^-149 may come out as that instead of 0
     const float d = raw[r] - mx;
     const float th = d * 0x1.715476p+0f;
     const float tl = __builtin_fmaf(d, 0x1.4ae0bep-26f, __builtin_fmaf(d, 0x1.715476p+0f, -th));
     const float ri = __builtin_rintf(th);
     const float y = __builtin_amdgcn_exp2f((th - ri) + tl);
-    e[r] = (4 * q + r < S) ? __builtin_ldexpf(y, (int)ri) : 0.f;
+    e[r] = __builtin_ldexpf(y, (int)ri);
     sum += e[r];
   }
   sum = mz_sum8(sum);
   const float rs = __builtin_amdgcn_rcpf(sum);      // (1 ulp; the probabilities were e * (1 / sum) already, not e / sum)
-  float v = 0.f;
+  // --no_support (one output, 31 padding bins): p is 1 for that output and 0 elsewhere, so with the output itself
+  // in the place of bin 0's support value the expectation below returns it exactly (this select sits beside the
+  // softmax chain, not in it)
+  // (as arithmetic with a 0 / 1 scalar rather than a select: a lane mask held across the simulation loop costs two
+  // scalar registers this kernel does not have; the host passes smin = 0 with --no_support)
+  const float k2 = (no_transform == 2) ? 1.f : 0.f;
+  const float c0 = __builtin_fmaf(k2, raw[0], (float)(smin + 4 * q));
+  float v = c0 * (e[0] * rs);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) v += (float)(smin + 4 * q + r) * (e[r] * rs);
+  for (int r = 1; r < 4; ++r) v += (float)(smin + 4 * q + r) * (e[r] * rs);
   v = mz_sum8(v);
   // (computed unconditionally and selected: a branch here would end the basic block and with it the scheduler's
   // freedom to interleave this chain with the caller's other work)
@@ -561,8 +570,10 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
   const bool full = b0 + MZ_ROWS <= t.B;       // (wave-uniform) all 16 trees of this workgroup exist
   const size_t per_tree = (size_t)(t.sims + 1) * MZ_HS;
 
-  if (tid < 96) s_b2[tid] = n.b2[tid];
-  if (tid < 32 + 16 * JTP) s_b4[tid] = n.b4[tid];
+  // (the padding bins of the two 32-row support tiles get MZ_PAD_BIN as their bias: their softmax terms come out as
+  // exact zeros in mz_support_to_scalar_q with no per-bin masking there)
+  if (tid < 96) s_b2[tid] = (tid < 32 && tid >= n.Sr) ? MZ_PAD_BIN : n.b2[tid];
+  if (tid < 32 + 16 * JTP) s_b4[tid] = (tid < 32 && tid >= n.Sv) ? MZ_PAD_BIN : n.b4[tid];
   if (tid < 64) { s_lnw[tid] = n.lnw[tid]; s_lnb[tid] = n.lnb[tid]; }
   for (int i = tid; i < 16 * MZ_XE; i += 256) xEp[i] = (i % MZ_XE == 0) ? 1.f : 0.f;
   for (int i = tid; i < (t.sims + 2) * (t.sims + 2); i += 256) s_pbc[(i / (t.sims + 2)) * PBS + i % (t.sims + 2)] = t.pbctab[i];
@@ -824,7 +835,7 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
               MzQuad Q;
               mz_quad_issue<0>(Q, mz_quad_addr(red, 4 * q, col), mz_lds_addr(s_b2 + 4 * q));
               asm volatile("s_waitcnt lgkmcnt(0)" : MZ_Q(Q));
-              const float r = mz_support_to_scalar_q(mz_quad_sum(Q), n.Sr, n.rmin, n.no_transform, q);
+              const float r = mz_support_to_scalar_q(mz_quad_sum(Q), n.rmin, n.no_transform, q);
               if (q == 0) s_rew[col] = r;
             }
           }
@@ -876,7 +887,7 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
             asm volatile("s_waitcnt lgkmcnt(0)" : MZ_Q(V));
             const f32x4 vs = mz_quad_sum(V);
             if constexpr (!P4) mz_quad_issue<128>(L, mz_quad_addr(red, 32 + 4 * q8, col), ba);      // arrives under the value chain
-            const float v = mz_support_to_scalar_q(vs, n.Sv, n.vmin, n.no_transform, q8);
+            const float v = mz_support_to_scalar_q(vs, n.vmin, n.no_transform, q8);
             if (q == 0) s_val[col] = v;
             if constexpr (!P4) asm volatile("s_waitcnt lgkmcnt(0)" : MZ_Q(L));
             if constexpr (P4) {
@@ -915,7 +926,7 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
         if (tl < 8 && 4 * tl < n.A) *(f32x4 *)(s_lg + mt * 32 + 4 * tl) = mz_quad_sum(L);
         lgl = s_lg[mt * 32 + (tl < n.A ? tl : 0)];
       }
-      const float v = mz_support_to_scalar_q(mz_quad_sum(V), n.Sv, n.vmin, n.no_transform, q8);
+      const float v = mz_support_to_scalar_q(mz_quad_sum(V), n.vmin, n.no_transform, q8);
       const double pe = exp((double)lgl);     // mcts.py:52 (unconditional: no branch)
       double pr = (tl < n.A) ? pe : 0.0;
       asm volatile("" : "+v"(pr));       // pinned here: left alone, the compiler sinks the exp chain into the branch below

@@ -155,6 +155,7 @@ __device__ __forceinline__ float mz_support_to_scalar(const float *fin, int row0
   sum += __shfl_xor(sum, 2);
   float v = 0.f;
   for (int i = q; i < S; i += 4) v += (float)(smin + i) * (expf(fin[(row0 + i) * 16 + m] - mx) / sum);
+  if (no_transform == 2) v = (q == 0) ? fin[row0 * 16 + m] : 0.f;   // --no_support: the head's single output
   v += __shfl_xor(v, 1);
   v += __shfl_xor(v, 2);
   if (!no_transform) {

@@ -42,7 +42,7 @@ class Engine(object):
 
   def __init__(self, num_envs, obs_dim, action_space, num_simulations, two_players=False,
                known_bounds=(None, None), value_support=(-15, 15), reward_support=(-15, 15),
-               no_target_transform=False, discount=0.997, pb_c_base=19652, pb_c_init=1.25, init_value_score=0.0,
+               no_target_transform=False, no_support=False, discount=0.997, pb_c_base=19652, pb_c_init=1.25, init_value_score=0.0,
                root_dirichlet_alpha=0.25, root_exploration_fraction=0.25, seed=0, env_id_offset=0, device=None):
     if not torch.cuda.is_available():
       raise RuntimeError('model_based_rl_amd.Engine needs a HIP device (torch.cuda.is_available() is False); '
@@ -57,7 +57,7 @@ class Engine(object):
         int(value_support[0]), int(value_support[1]), int(reward_support[0]), int(reward_support[1]),
         int(bool(no_target_transform)), 0.0 if lo is None else float(lo), 0.0 if hi is None else float(hi),
         float(discount), float(pb_c_base), float(pb_c_init), float(init_value_score), float(root_dirichlet_alpha),
-        float(root_exploration_fraction), int(seed), int(env_id_offset), 0)
+        float(root_exploration_fraction), int(seed), int(env_id_offset), int(bool(no_support)))
     h = C.c_void_p()
     _abi.check(self.lib.mz_create(C.byref(self.cfg), C.byref(h)), 'mz_create')
     self._h = h
@@ -74,7 +74,8 @@ class Engine(object):
                known_bounds=tuple(getattr(config, 'known_bounds', (None, None))),
                value_support=tuple(getattr(config, 'value_support', (-15, 15))),
                reward_support=tuple(getattr(config, 'reward_support', (-15, 15))),
-               no_target_transform=getattr(config, 'no_target_transform', False), discount=config.discount,
+               no_target_transform=getattr(config, 'no_target_transform', False),
+               no_support=getattr(config, 'no_support', False), discount=config.discount,
                pb_c_base=config.pb_c_base, pb_c_init=config.pb_c_init,
                init_value_score=getattr(config, 'init_value_score', 0.0),
                root_dirichlet_alpha=config.root_dirichlet_alpha,

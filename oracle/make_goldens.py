@@ -347,7 +347,7 @@ def gen_net(ref, outdir, name, argv, O, A, seed, save_weights=True):
       rec_l.append(r.policy_logits.numpy()[0].copy()); rec_h.append(r.hidden_state.numpy()[0].copy())
     # raw (un-transformed) support logits for the value head, to pin the inverse transform alone
     vlogits = net.value_head(torch.from_numpy(np.stack(init_h))).numpy().copy()
-    vinv = cfg.inverse_value_transform(torch.from_numpy(vlogits)).numpy().reshape(-1).copy()
+    vinv = (vlogits if cfg.no_support else cfg.inverse_value_transform(torch.from_numpy(vlogits)).numpy()).reshape(-1).copy()
   out.update(obs=obs, actions=acts, init_value=np.array(init_v, np.float32), init_logits=np.stack(init_l),
              init_hidden=np.stack(init_h), rec_value=np.array(rec_v, np.float32),
              rec_reward=np.array(rec_r, np.float32), rec_logits=np.stack(rec_l), rec_hidden=np.stack(rec_h),
@@ -471,6 +471,7 @@ def main():
   nets[(8, 4)] = (gen_net(ref, outdir, 'g1_net_lunar', [], 8, 4, 1)[0], 'g1_net_lunar.npz')
   nets[(128, 6)] = (gen_net(ref, outdir, 'g1_net_pong', [], 128, 6, 2)[0], 'g1_net_pong.npz')
   gen_net(ref, outdir, 'g1_net_lunar_notransform', ['--no_target_transform'], 8, 4, 1, save_weights=False)
+  gen_net(ref, outdir, 'g1_net_lunar_nosupport', ['--no_support'], 8, 4, 3)
   gen_tree_traces(ref, outdir, nets)
   gen_games(ref, outdir, nets)
   total = sum(os.path.getsize(os.path.join(outdir, f)) for f in os.listdir(outdir) if f.endswith('.npz'))

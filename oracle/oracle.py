@@ -150,11 +150,11 @@ class Trees(object):
 class FCNet(object):
   """float32 FCNetwork forward (networks.py:122-180) over a dict of reference-named weights."""
 
-  def __init__(self, weights, O, A, support=(-15, 15), no_target_transform=False):
+  def __init__(self, weights, O, A, support=(-15, 15), no_target_transform=False, no_support=False):
     self.O, self.A = int(O), int(A)
-    self.S = support[1] - support[0] + 1
+    self.S = 1 if no_support else support[1] - support[0] + 1      # networks.py:135-136
     self._keep = [np.ascontiguousarray(weights[k], np.float32) for k in WEIGHT_ORDER]
-    self.c = FC(self.O, self.A, self.S, int(support[0]), int(bool(no_target_transform)),
+    self.c = FC(self.O, self.A, self.S, int(support[0]), 2 if no_support else int(bool(no_target_transform)),
                 *[a.ctypes.data_as(_FP) for a in self._keep])
 
   def initial(self, obs):

@@ -240,8 +240,9 @@ def test_timed_launches_are_the_same_moves():
     assert np.array_equal(trees[0][k], trees[1][k]), k
 
 
-@pytest.mark.parametrize('A,sims,T,temp', [(4, 30, 5, 1.0), (6, 12, 4, 0.5), (3, 9, 3, 0.0), (18, 8, 3, 1.0)])
-def test_selfplay_loop_equals_stepwise_abi(A, sims, T, temp):
+@pytest.mark.parametrize('A,sims,T,temp,ns', [(4, 30, 5, 1.0, False), (6, 12, 4, 0.5, False), (3, 9, 3, 0.0, False),
+                                              (18, 8, 3, 1.0, False), (4, 30, 5, 1.0, True)])
+def test_selfplay_loop_equals_stepwise_abi(A, sims, T, temp, ns):
   """The fused per-move kernels of the device loop (root kernel with in-kernel observation + Dirichlet + first
   descent; search kernel whose tail samples the action, steps the env and writes the record) against the
   stepwise C ABI on the same engine configuration: mz_initial_inference -> mz_root_prepare(device RNG) ->
@@ -253,11 +254,11 @@ def test_selfplay_loop_equals_stepwise_abi(A, sims, T, temp):
   from model_based_rl_amd.engine import flatten_weights
   O, B, moves = 8, 48, 7
   torch.manual_seed(5)
-  cfg = types.SimpleNamespace(value_support=(-15, 15), reward_support=(-15, 15), no_support=False,
+  cfg = types.SimpleNamespace(value_support=(-15, 15), reward_support=(-15, 15), no_support=ns,
                               no_target_transform=False)
   net = FCNetwork(O, A, torch.device('cpu'), cfg)
   flat = flatten_weights(net.state_dict())
-  loop = Engine(B, O, A, sims, seed=99, env_id_offset=7)
+  loop = Engine(B, O, A, sims, seed=99, env_id_offset=7, no_support=ns)
   loop.set_weights(flat)
   loop.selfplay_reset(T, temp, stagger=False)
   loop.selfplay_steps(moves)
@@ -267,7 +268,7 @@ def test_selfplay_loop_equals_stepwise_abi(A, sims, T, temp):
   loop.close()
   ints = rec[..., O + A + 3:].view(np.int32)
 
-  step = Engine(B, O, A, sims, seed=99, env_id_offset=7)
+  step = Engine(B, O, A, sims, seed=99, env_id_offset=7, no_support=ns)
   step.set_weights(flat)
   for m in range(moves):
     obs = np.stack([step.synth_obs(7 + b, m // T, m % T)[0] for b in range(B)])

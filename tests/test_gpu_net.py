@@ -12,20 +12,22 @@ pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(__file__), 'golden')
 
 
-def engine_for(g, B, nt=False, sims=4):
+def engine_for(g, B, nt=False, sims=4, ns=False):
   from model_based_rl_amd.engine import Engine
   from oracle import oracle as orc
   w = orc.load_weights(g)
-  eng = Engine(B, int(g['O']), int(g['A']), sims, no_target_transform=nt)
+  eng = Engine(B, int(g['O']), int(g['A']), sims, no_target_transform=nt, no_support=ns)
   eng.set_weights({k: v for k, v in w.items()})
   return eng, w
 
 
-@pytest.mark.parametrize('name', ['g1_net_ttt', 'g1_net_lunar', 'g1_net_pong', 'g1_net_lunar_notransform'])
+@pytest.mark.parametrize('name', ['g1_net_ttt', 'g1_net_lunar', 'g1_net_pong', 'g1_net_lunar_notransform',
+                                  'g1_net_lunar_nosupport'])
 def test_net_vs_golden(name):
   g = np.load(os.path.join(G, name + '.npz'))
-  nt = name.endswith('notransform')
-  eng, _ = engine_for(g, 64, nt)
+  ns = name.endswith('nosupport')
+  nt = name.endswith('notransform') or ns
+  eng, _ = engine_for(g, 64, nt and not ns, ns=ns)
   eng.initial_inference(g['obs'])
   v, lg, h = [x.cpu().numpy() for x in eng.root_outputs()]
   assert np.abs(h - g['init_hidden']).max() <= TOL

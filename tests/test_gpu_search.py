@@ -47,6 +47,7 @@ def run_both(name, B, sims, two=False, bounds=(None, None), discount=0.997, lega
     g = np.load(os.path.join(G, name + '.npz'))
     w = orc.load_weights(g)
     O, A = int(g['O']), int(g['A'])
+  ns = isinstance(name, str) and name.endswith('nosupport')      # --no_support network: scalar value / reward heads
   rng = np.random.RandomState(seed)
   obs = rng.standard_normal((B, O)).astype(np.float32)
   legal = (rng.uniform(size=(B, A)) < legal_p).astype(np.uint8)
@@ -54,7 +55,7 @@ def run_both(name, B, sims, two=False, bounds=(None, None), discount=0.997, lega
   noise = rng.dirichlet([0.25] * A, size=B) * legal
   noise /= noise.sum(1, keepdims=True)
   tp = rng.choice([-1, 1], size=B).astype(np.int8) if two else np.ones(B, np.int8)
-  eng = Engine(B, O, A, sims, two_players=two, known_bounds=bounds, discount=discount)
+  eng = Engine(B, O, A, sims, two_players=two, known_bounds=bounds, discount=discount, no_support=ns)
   eng.set_weights(w)
   eng.initial_inference(obs)
   eng.root_prepare(tp, legal, noise)
@@ -65,7 +66,7 @@ def run_both(name, B, sims, two=False, bounds=(None, None), discount=0.997, lega
   ex = eng.export_tree(hidden=True)
   eng.close()
   t = orc.Trees(orc.tree_cfg(A, sims, two, bounds, discount), B)
-  net = orc.FCNet(w, O, A)
+  net = orc.FCNet(w, O, A, no_support=ns)
   hpool, v0 = t.search_fc(net, obs, tp, legal, noise, 0.25)
   action, cv, rv, vc = t.finalize(temp, u)
   return out, ex, dict(action=action, child_visits=cv, root_value=rv, visit_counts=vc, hpool=hpool, v0=v0,
@@ -84,6 +85,8 @@ def run_both(name, B, sims, two=False, bounds=(None, None), discount=0.997, lega
     ((8, 4), 96, 60, False, (None, None), 0.997, 1.0),                 # 4 actions, trees too large for LDS: descent fields in
                                                                        # LDS + small-MFMA policy head behind the barrier
     ((8, 3), 50, 30, True, (-2.0, 2.0), 0.99, 0.8),                    # A = 3, two players, illegal moves
+    ('g1_net_lunar_nosupport', 1024, 30, False, (None, None), 0.997, 1.0),   # --no_support: scalar heads, no transform
+    ('g1_net_lunar_nosupport', 64, 60, False, (None, None), 0.997, 1.0),     # the same through the hybrid-placement kernel
 ])
 def test_search_vs_oracle(name, B, sims, two, bounds, discount, legal_p):
   out, ex, ref = run_both(name, B, sims, two, bounds, discount, legal_p)

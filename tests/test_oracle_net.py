@@ -33,12 +33,14 @@ def scalar_close(got, want, transformed=True):
   assert np.mean(d <= TOL) >= 0.90, np.mean(d <= TOL)
 
 
-@pytest.mark.parametrize('name', ['g1_net_ttt', 'g1_net_lunar', 'g1_net_pong', 'g1_net_lunar_notransform'])
+@pytest.mark.parametrize('name', ['g1_net_ttt', 'g1_net_lunar', 'g1_net_pong', 'g1_net_lunar_notransform',
+                                  'g1_net_lunar_nosupport'])
 def test_fc_forward(name):
   g = np.load(os.path.join(G, name + '.npz'))
   w = orc.load_weights(g)
-  nt = name.endswith('notransform')
-  net = orc.FCNet(w, int(g['O']), int(g['A']), no_target_transform=nt)
+  ns = name.endswith('nosupport')               # --no_support: scalar heads, no inverse transform (networks.py:135-136,153)
+  nt = name.endswith('notransform') or ns
+  net = orc.FCNet(w, int(g['O']), int(g['A']), no_target_transform=nt, no_support=ns)
   h, v, lg = net.initial(g['obs'])
   assert np.abs(h - g['init_hidden']).max() <= TOL
   assert np.abs(lg - g['init_logits']).max() <= TOL
