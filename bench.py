@@ -28,13 +28,16 @@ if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
 
 # BASELINE.json configs[1] (the headline, default): LunarLander-v2 shapes, FCNetwork, 30 simulations, 4096 parallel
-# envs per GPU.  --workload pong = configs[3]'s shapes on one GPU (Pong-ram: obs 128, 6 actions, 50 simulations), a
-# secondary line for profiles/, never the headline.
+# envs per GPU.  Secondary lines for profiles/, never the headline: --workload pong = configs[3]'s shapes on one GPU
+# (Pong-ram: 128 uint8 observations with --norm_obs 0 255, 6 actions, 50 simulations); --workload breakout =
+# configs[4] (MuZeroNetwork through PyTorch-ROCm behind the external-inference entry points, bench_torch.py).
 WORKLOADS = {'lunar': ('LunarLander-v2', 4096, 8, 4, 30, 256), 'pong': ('Pong-ramNoFrameskip-v4', 4096, 128, 6, 50, 1024)}
 WNAME, B, O, A, SIMS, EPISODE_LEN = WORKLOADS['lunar']
 for _i, _a in enumerate(sys.argv):
-  if _a == '--workload' and _i + 1 < len(sys.argv):
+  if _a == '--workload' and _i + 1 < len(sys.argv) and sys.argv[_i + 1] in WORKLOADS:
     WNAME, B, O, A, SIMS, EPISODE_LEN = WORKLOADS[sys.argv[_i + 1]]
+  if _a == '--envs' and _i + 1 < len(sys.argv):
+    B = int(sys.argv[_i + 1])                # (tests: a small pool; the line then says so in config.envs_per_gpu)
 CHUNK = 8                       # moves per drain/ingest chunk
 FLOP_PER_SIM = 2 * 512 * (312 + 3 * A)            # 331 776 for A = 4
 FLOP_PER_ROOT = 2 * 512 * (O + 181 + A)           # 197 632 for O = 8, A = 4
@@ -97,7 +100,47 @@ def cpu_baseline(weights):
   return {'value': cores * envs * moves / dt, 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port',
           'sample': '%d threads x %d envs x %d moves x %d simulations, oracle/mz_oracle.c (gcc -O2, scalar float32 net + '
                     'double tree), %.1f s' % (cores, envs, moves, SIMS, dt),
-          'single_core_value': single, 'host_cpus': os.cpu_count(), 'usable_cores': _usable_cores()}
+          'single_core_value': single, 'host_cpus': os.cpu_count(), 'usable_cores': _usable_cores(),
+          'cpu_model': _cpu_model()}
+
+
+def _cpu_model():
+  try:
+    for line in open('/proc/cpuinfo'):
+      if line.startswith('model name'):
+        return line.split(':', 1)[1].strip()
+  except OSError:
+    pass
+  return 'unknown'
+
+
+def cpu_baseline_reference_shaped():
+  """The reference's own shape of the path on the host cores: oracle/ref_shaped.py (batch-1 PyTorch-CPU restatement
+  of actors.py:131-153 + mcts.py:78-143, one environment per single-threaded process -- the reference's Ray actor
+  layout, train.py:63,72), one process per usable core.  Its fidelity to the imported reference is measured in the
+  build container (scripts/ref_shaped_ratio.py -> profiles/r02_ref_shaped_ratio.json: ratio 1.02-1.04).  The children
+  are fresh interpreters that never touch the GPU."""
+  import subprocess
+  cores = max(1, min(64, _usable_cores()))
+  moves = 600 if SIMS <= 30 else 350          # ~8-10 s per process
+  env = dict(os.environ, OMP_NUM_THREADS='1', MKL_NUM_THREADS='1', HIP_VISIBLE_DEVICES='', ROCR_VISIBLE_DEVICES='')
+  cmd = [sys.executable, os.path.join(ROOT, 'oracle', 'ref_shaped.py'), '--obs', str(O), '--actions', str(A), '--sims',
+         str(SIMS), '--moves', str(moves)]
+  t0 = time.perf_counter()
+  procs = [subprocess.Popen(cmd + ['--seed', str(i)], stdout=subprocess.PIPE, env=env) for i in range(cores)]
+  rates = []
+  for pr in procs:
+    out = pr.communicate(timeout=600)[0].decode().strip().splitlines()
+    if pr.returncode == 0 and out:
+      rates.append(json.loads(out[-1])['env_steps_per_s'])
+  wall = time.perf_counter() - t0
+  if not rates:
+    return None
+  return {'value': float(np.sum(rates)), 'unit': 'env-steps/s', 'cores': len(rates), 'kind': 'reference-shaped',
+          'per_core_value': float(np.mean(rates)),
+          'sample': '%d single-threaded processes x 1 env x %d moves x %d simulations, oracle/ref_shaped.py (batch-1 '
+                    'PyTorch-CPU, the reference\'s op sequence), %.1f s wall incl. interpreter start' % (len(rates), moves, SIMS, wall),
+          'fidelity': 'profiles/r02_ref_shaped_ratio.json (timed beside the imported reference in the build container)'}
 
 
 def main():
@@ -106,17 +149,26 @@ def main():
   ap.add_argument('--steps', type=int, default=512)
   ap.add_argument('--warmup', type=int, default=64)
   ap.add_argument('--no-cpu-baseline', action='store_true')
-  ap.add_argument('--workload', choices=sorted(WORKLOADS), default='lunar')
+  ap.add_argument('--workload', choices=sorted(WORKLOADS) + ['breakout'], default='lunar')
+  ap.add_argument('--envs', type=int, default=None, help='override the number of environments per GPU (tests)')
   ap.add_argument('--chunk', type=int, default=CHUNK, help='moves per drain / ingest chunk')
   ap.add_argument('--sync-every', type=int, default=128,
-                  help='moves between weight pulls (the path\'s one exchange: broadcast + repack); 0 = only once')
+                  help='moves between weight pulls (the path\'s one exchange: broadcast + repack)')
+  ap.add_argument('--min-seconds', type=float, default=1.2,
+                  help='the --steps block is repeated back to back until the timed region is at least this long')
+  ap.add_argument('--dump-records', default=None,
+                  help='(tests) save this rank\'s experience records of the first moves after reset to <path>.rank<r>.npy')
   args = ap.parse_args()
+  if args.workload == 'breakout':
+    import bench_torch             # secondary line: MuZeroNetwork through PyTorch-ROCm (BASELINE.json configs[4])
+    return bench_torch.main(args)
   chunk = max(1, args.chunk)
 
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
   dist = None
+  backend = None
   if world > 1:
     import torch.distributed as dist
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -131,34 +183,42 @@ def main():
     raise SystemExit('--gpus %d needs the torch.distributed.run launcher (one process per GPU)' % args.gpus)
   device = torch.device('cuda', local_rank)
   torch.cuda.set_device(device)
+  coll_dev = device if backend != 'gloo' else torch.device('cpu')     # where collective buffers live
 
   from model_based_rl_amd.engine import Engine, flatten_weights
   from model_based_rl_amd.networks import FCNetwork
   from model_based_rl_amd.replay_buffer import PrioritizedReplay
+  from model_based_rl_amd.shared_storage import broadcast_flat
 
   # random-init FCNetwork, torch.manual_seed(0) default init; rank 0 owns the weights
   torch.manual_seed(0)
   net = FCNetwork(O, A, torch.device('cpu'), types.SimpleNamespace()).eval()
-  flat = flatten_weights(net.state_dict()).to(device)
+  flat = flatten_weights(net.state_dict()).to(coll_dev)
   if rank != 0:
     flat.zero_()
   eng = Engine(B, O, A, SIMS, seed=1234, env_id_offset=rank * B, device=device)
+  n_syncs = [0]
 
   def sync_weights():
-    if dist is not None:
-      dist.broadcast(flat, src=0)          # RCCL over xGMI: one flattened f32 buffer (0.79 MB)
-    eng.set_weights(flat)
+    broadcast_flat(flat, src=0)            # RCCL over xGMI: one flattened f32 buffer (0.79 MB); no-op on one rank
+    eng.set_weights(flat if flat.is_cuda else flat.to(device))
+    n_syncs[0] += 1
 
   sync_weights()
   cfg = types.SimpleNamespace(batch_size=256, epsilon=0.01, alpha=1.0, beta=1.0, obs_space=(O,), action_space=A,
                               window_size=1 << 21, window_step=None, num_unroll_steps=5, td_steps=10,
                               max_history_length=500, discount=0.997, seed=0)
   replay = PrioritizedReplay(cfg)
+  ram = '-ram' in WNAME
+  if ram:        # the -ram- envs: byte observations, --norm_obs --obs_range 0 255 inside the root kernel (actors.py:134-137)
+    eng.selfplay_set_obs(uint8_obs=True, obs_min=[0.0], obs_range=[255.0])
   eng.selfplay_reset(EPISODE_LEN, 1.0, stagger=True)
   rec = eng.rec_floats
   pinned = [torch.empty(chunk, B, rec, dtype=torch.float32).pin_memory() for _ in range(2)]
   events = [torch.cuda.Event(), torch.cuda.Event()]
   copy_stream = torch.cuda.Stream(device)
+  dump = [] if args.dump_records else None
+  state = {'gmove': 0, 'sync_every': max(chunk, args.sync_every), 'last_sync_q': 0}
 
   def wait(ev):
     # the chunk's copy is a few milliseconds out: sleep-poll instead of spinning a core on hipEventSynchronize (one
@@ -166,28 +226,43 @@ def main():
     while not ev.query():
       time.sleep(0.0002)
 
-  def run(moves, count):
-    """moves in chunks; D2H + host ingest of chunk i-1 overlap the GPU work of chunk i."""
+  def run(blocks, marks=None):
+    """blocks: list of step counts, run back to back in ONE pipelined stream of chunks (D2H + host ingest of chunk
+    i-1 overlap the GPU work of chunk i, across block boundaries too).  marks: list that receives one GPU event per
+    block boundary (recorded on the compute stream behind the block's last move)."""
     pending = None
-    done = 0
     k = 0
-    while done < moves:
-      m = min(chunk, moves - done)
-      if args.sync_every and done and done % args.sync_every == 0:
-        sync_weights()       # Actor.sync_weights (actors.py:81-85): fresh weights from the storage rank, in stream order
-      eng.selfplay_steps(m)
-      buf, n = eng.selfplay_drain(pinned[k & 1], m, copy_stream=copy_stream)   # overlaps the next chunk's moves
-      events[k & 1].record(copy_stream)
-      if pending is not None:
-        pb, pn, pe = pending
-        wait(pe)
-        replay.ingest_records(pb, pn, B)
-      pending = (buf, n, events[k & 1])
-      done += m
-      k += 1
-    pb, pn, pe = pending
-    wait(pe)
-    replay.ingest_records(pb, pn, B)
+    for steps in blocks:
+      done = 0
+      while done < steps:
+        m = min(chunk, steps - done)
+        g0 = state['gmove']
+        if g0 // state['sync_every'] != state['last_sync_q']:     # a multiple of sync_every was crossed
+          state['last_sync_q'] = g0 // state['sync_every']
+          sync_weights()     # Actor.sync_weights (actors.py:81-85): fresh weights from the storage rank, in stream order
+        eng.selfplay_steps(m)
+        buf, n = eng.selfplay_drain(pinned[k & 1], m, copy_stream=copy_stream)   # overlaps the next chunk's moves
+        events[k & 1].record(copy_stream)
+        if pending is not None:
+          pb, pn, pe = pending
+          wait(pe)
+          if dump is not None and len(dump) < 4:
+            dump.append(pb[:pn].numpy().copy())
+          replay.ingest_records(pb, pn, B)
+        pending = (buf, n, events[k & 1])
+        done += m
+        state['gmove'] += m
+        k += 1
+      if marks is not None:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        marks.append(ev)
+    if pending is not None:
+      pb, pn, pe = pending
+      wait(pe)
+      if dump is not None and len(dump) < 4:
+        dump.append(pb[:pn].numpy().copy())
+      replay.ingest_records(pb, pn, B)
 
   def barrier():
     torch.cuda.synchronize(device)
@@ -198,25 +273,51 @@ def main():
   # priming (untimed, not part of --warmup): every env finishes its first, partial (staggered) episode, so
   # that from here on B/EPISODE_LEN episodes end per move and the replay accepts B frames per move on
   # average -- the steady state the reference's frames_per_second metric is defined on
-  run(EPISODE_LEN, False)
-  run(args.warmup, False)
+  run([EPISODE_LEN])
+  if dump is not None:
+    np.save('%s.rank%d.npy' % (args.dump_records, rank), np.concatenate(dump, 0))
+    dump = None
+  run([args.steps])             # one untimed block: builds the hipGraphs of every chunk size a block uses
+  # calibration: how many --steps blocks make a timed region of >= --min-seconds (same count on every rank)
+  torch.cuda.synchronize(device)
+  t0 = time.perf_counter()
+  run([64])
+  torch.cuda.synchronize(device)
+  est = (time.perf_counter() - t0) / 64
+  repeats = max(1, int(np.ceil(args.min_seconds / max(1e-6, est * args.steps))))
+  repeats = min(repeats, max(1, 200000 // max(1, args.steps)))
+  if dist is not None:
+    rt = torch.tensor([repeats], dtype=torch.int64, device=coll_dev)
+    dist.all_reduce(rt, op=dist.ReduceOp.MAX)
+    repeats = int(rt.item())
+  total = repeats * args.steps
+  # the weight pull (broadcast + repack) fires inside the timed region whatever --steps is
+  state['sync_every'] = max(chunk, min(args.sync_every, max(chunk, total // 2)))
+  state['last_sync_q'] = state['gmove'] // state['sync_every']
+  run([args.warmup] if args.warmup > 0 else [])
   barrier()
   frames0 = replay.get_throughput()['frames']
+  syncs0 = n_syncs[0]
+  marks = []
+  start_ev = torch.cuda.Event(enable_timing=True)
   t0 = time.perf_counter()
   c0 = time.process_time()
-  run(args.steps, True)
+  start_ev.record()
+  run([args.steps] * repeats, marks)
   barrier()
   dt = time.perf_counter() - t0
   host_cores_busy = (time.process_time() - c0) / dt      # CPU seconds of this rank (all its threads) per wall second
   frames = replay.get_throughput()['frames'] - frames0
+  syncs_in_region = n_syncs[0] - syncs0
+  block_ms = [a.elapsed_time(b) / args.steps for a, b in zip([start_ev] + marks[:-1], marks)]   # GPU clock, per step
   if dist is not None:
-    tt = torch.tensor([dt], dtype=torch.float64, device=device)
+    tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
-    ff = torch.tensor([frames], dtype=torch.float64, device=device)
+    ff = torch.tensor([frames], dtype=torch.float64, device=coll_dev)
     dist.all_reduce(ff, op=dist.ReduceOp.SUM)
     frames = float(ff.item())
-  env_steps = world * B * args.steps       # env.step() calls in the timed region, all ranks
+  env_steps = world * B * total            # env.step() calls in the timed region, all ranks
 
   # dominant kernel = k_search_fused (one launch = all simulations of all trees of this rank + the end of the move:
   # descent, f32-MFMA dynamics + prediction, expand, backup, action/record).  Its duration is measured live with HIP
@@ -233,34 +334,46 @@ def main():
     value = frames / dt
     flops_per_launch = SIMS * FLOP_PER_SIM * B        # algorithmic: SURVEY.md s8(d) per-simulation figure x sims x trees
     achieved = flops_per_launch / (search_us * 1e-6) / 1e12
-    traffic = None
+    traffic, traffic_source = None, None
     tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
-    if os.path.exists(tfile):
-      traffic = json.load(open(tfile)).get('k_search_fused', {}).get('hbm_bytes_per_launch') if WNAME.startswith('Lunar') else None
+    if os.path.exists(tfile) and WNAME.startswith('Lunar') and B == 4096:
+      tj = json.load(open(tfile))
+      traffic = tj.get('k_search_fused', {}).get('hbm_bytes_per_launch')
+      traffic_source = 'profiles/traffic.json (builder-run rocprofv3 --pmc passes of this command, %s; not re-measured ' \
+                       'in this run)' % tj.get('tag', 'see file')
     out = {
         'metric': 'env-steps/sec (self-play, whole node) at num_simulations=%d' % SIMS,
         'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'ms_per_step': 1e3 * dt / total, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': '%s shapes (obs %d, actions %d), FCNetwork, num_simulations=%d, '
+        'repeats': repeats, 'timed_steps': total, 'timed_seconds': dt,
+        'ms_per_step_blocks': {'median': float(np.median(block_ms)), 'std': float(np.std(block_ms)),
+                               'min': float(np.min(block_ms)), 'max': float(np.max(block_ms)), 'n': len(block_ms),
+                               'clock': 'GPU events at block boundaries inside the one pipelined timed region'},
+        'config': {'workload': '%s shapes (obs %d%s, actions %d), FCNetwork, num_simulations=%d, '
                                '%d parallel self-play envs per GPU, synthetic fixed-length episodes T=%d, '
-                               'random-init weights (torch.manual_seed(0))' % (WNAME, O, A, SIMS, B, EPISODE_LEN),
+                               'random-init weights (torch.manual_seed(0))'
+                               % (WNAME, O, ' uint8 + norm_obs 0 255' if ram else '', A, SIMS, B, EPISODE_LEN),
                    'envs_per_gpu': B, 'num_simulations': SIMS, 'episode_len': EPISODE_LEN,
                    'priming': '%d untimed moves before warm-up so episode ends are in steady state' % EPISODE_LEN,
+                   'timed_region': 'the --steps block repeated %d times back to back in one pipelined region of %.2f s '
+                                   '(barrier + synchronize on both sides)' % (repeats, dt),
                    'sharding': 'env-id sharded, %d rank(s), RCCL weight broadcast' % world,
-                   'weight_sync': 'flat f32 buffer broadcast from rank 0 + repack every %d moves, inside the timed region'
-                                  % args.sync_every},
+                   'weight_sync': 'flat f32 buffer broadcast from rank 0 + repack every %d moves: %d pulls inside the '
+                                  'timed region' % (state['sync_every'], syncs_in_region)},
         'env_steps_executed_per_s': env_steps / dt,
         'host_cores_busy_per_rank': host_cores_busy,
         'mcts_sims_per_s_per_gpu': env_steps * SIMS / dt / world,
         'roofline': {'bound': 'mfma', 'kernel': 'k_search_fused', 'achieved': achieved,
                      'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS,
-                     'traffic': traffic, 'us_per_launch': search_us, 'flop_per_launch': flops_per_launch,
+                     'traffic': traffic, 'traffic_source': traffic_source, 'us_per_launch': search_us,
+                     'flop_per_launch': flops_per_launch,
                      'whole_path_frac': (env_steps / dt / world) * (SIMS * FLOP_PER_SIM + FLOP_PER_ROOT) / 1e12 /
                                         PEAK_F32_MFMA_TFLOPS},
     }
     if world == 1 and not args.no_cpu_baseline:
       out['cpu_baseline'] = cpu_baseline({k: v.numpy() for k, v in net.state_dict().items()})
+      out['cpu_baseline']['reference_shaped'] = cpu_baseline_reference_shaped()
     print(json.dumps(out), flush=True)
   if dist is not None:
     dist.barrier()

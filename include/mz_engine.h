@@ -175,18 +175,34 @@ int mz_padded_envs(const mz_engine *e);
  * Synthetic env (gym/ALE are not installed on either box): observation
  * obs_t[i] = Irwin-Hall(4) approximation of N(0,1) from Philox4x32-10 keyed (seed, env, episode, t),
  * reward_t = U(-1,1) keyed likewise, all actions legal, done at t == episode_len.
+ * (mz_selfplay_set_obs: byte-valued observations and --norm_obs for the -ram- shapes.)
  * mz_selfplay_steps runs `moves` complete moves: obs -> initial inference -> root -> search ->
  * select_action -> env.step -> experience record appended to a device ring.
- * Each record is rec_floats() float32: obs[O], child_visits[A], root_value, error, reward,
- * then as int32 bit patterns: action, done, step, env_id, episode.
+ * Each record is rec_floats() = obs_dim + action_space + MZ_REC_EXTRA float32 slots: obs[O] (raw, as History keeps
+ * it), child_visits[A], root_value and error as float64 in two slots each (the reference's Python floats,
+ * actors.py:147-148, game.py:112), reward, then as int32 bit patterns: action, done, step, env_id, episode.
  * mz_selfplay_drain copies the records produced since the last drain into `out` [host, pinned
  * preferred] asynchronously on `stream` and returns their count through *n_records after the
  * stream is synchronised by the caller (records are laid out move-major: [moves][B]).  `stream` may be a
  * copy stream other than the one mz_selfplay_steps ran on, provided the caller orders it behind those steps
- * (event): later moves then overlap the copy, the ring keeps them in different slots.
- * mz_selfplay_steps issues up to 16 moves as one hipGraph launch (3 kernels per move: root, search, step+record).
- * stagger != 0: env i starts its first episode at t0 = hash(env id) % episode_len (uniform episode ends). */
+ * (event): later moves then overlap the copy.  The ring normally keeps them in different slots; where it cannot
+ * (records so large that the ring holds few moves), mz_selfplay_steps makes its stream wait for the event the
+ * drain recorded behind its copy before it launches moves into slots the copy may still be reading.
+ * mz_selfplay_steps issues up to 16 moves as one hipGraph launch (2 kernels per move: root, search + end of move).
+ * stagger != 0: env i starts its first episode at t0 = hash(env id) % episode_len (uniform episode ends).
+ * temperature: Config.visit_softmax_temperature at reset; mz_selfplay_set_temperature changes what every env's
+ * NEXT game starts with (actors.py:128-129: evaluated once per game), games in progress keep theirs. */
+#define MZ_REC_EXTRA 10
 int mz_selfplay_reset(mz_engine *e, int episode_len, double temperature, int stagger, void *stream);
+int mz_selfplay_set_temperature(mz_engine *e, double temperature, void *stream);
+/* Observation format of the synthetic env (call before mz_selfplay_reset; synchronous).  uint8_obs != 0: observations
+ * are bytes 0..255 (the -ram- envs).  obs_min / obs_range [host][obs_dim], both or neither: --norm_obs
+ * (actors.py:55-58,134-137): the network input is (obs - obs_min) / obs_range in float32, the record keeps the raw
+ * observation (the learner normalises its own batches, learners.py:167-168). */
+int mz_selfplay_set_obs(mz_engine *e, int uint8_obs, const float *obs_min, const float *obs_range);
+/* keep != 0: every move of the self-play loop also writes its searched tree back to the node pool (so that
+ * mz_export_tree after mz_selfplay_steps shows the last move's tree).  Default 0: the loop never reads it. */
+int mz_selfplay_export_trees(mz_engine *e, int keep);
 int mz_selfplay_steps(mz_engine *e, int moves, void *stream);
 /* mz_selfplay_steps with one pair of HIP events around every search-kernel dispatch (hipExtLaunchKernelGGL start / stop
  * events on `stream`: the timestamps rocprofv3's kernel trace reports).  The k moves are launched eagerly, back to back,

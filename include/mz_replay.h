@@ -61,11 +61,21 @@ int mzr_save_history(mz_replay *r, int64_t n, const double *errors, int64_t igno
                      const int32_t *actions, const uint8_t *dones, const int8_t *to_play);
 
 /* Bulk ingest of device records (layout of mz_selfplay_drain: [n_moves][B][rec_floats], rec = obs[O],
- * child_visits[A], root_value, error, reward, then int32 bits action, done, step, env_id, episode).
+ * child_visits[A] (float32), root_value and error as float64 in two float slots each (the reference keeps both as
+ * Python floats: actors.py:147-148, game.py:112 -- priorities and value targets built from records are therefore
+ * the reference's doubles), reward (float32), then int32 bits action, done, step, env_id, episode:
+ * rec_floats = obs_dim + action_space + MZR_REC_EXTRA.
  * Re-creates per environment what Actor.play_game does after each move (actors.py:160-173): histories are
  * accumulated per env and flushed to save_history when max_history_length steps were collected (with the
- * overlap/ignore rules) or the episode is done.  frames/games: PrioritizedReplay.throughput. */
+ * overlap/ignore rules) or the episode is done.  frames/games: PrioritizedReplay.throughput.
+ * Records describe single-player synthetic episodes: to_play = +1 and `done` ends the game (terminal == done;
+ * --two_players / --episode_life histories go through mzr_save_history).
+ * mzr_ingest_records_from: the B environments of this call are the replay's environments env_base .. env_base+B-1
+ * (one replay fed by several actor ranks: rank r passes env_base = r * B; actors.py:169 -- every reference actor
+ * sends to the ONE replay buffer, train.py:71-72). */
+#define MZR_REC_EXTRA 10
 int mzr_ingest_records(mz_replay *r, const float *records, int n_moves, int B, int rec_floats);
+int mzr_ingest_records_from(mz_replay *r, const float *records, int n_moves, int B, int rec_floats, int env_base);
 
 /* PrioritizedReplay.sample_batch (replay_buffer.py:124-163) + insert_target (165-198) for `bs` stratified
  * draws.  draws[i] is the value the reference obtains from random.uniform(seg*i, seg*(i+1)) (the caller owns

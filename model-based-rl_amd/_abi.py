@@ -76,6 +76,9 @@ SIGNATURES = {
     'mz_nodes_per_tree': (_I, [_VP]),
     'mz_padded_envs': (_I, [_VP]),
     'mz_selfplay_reset': (_I, [_VP, _I, _D, _I, _VP]),
+    'mz_selfplay_set_temperature': (_I, [_VP, _D, _VP]),
+    'mz_selfplay_set_obs': (_I, [_VP, _I, _VP, _VP]),
+    'mz_selfplay_export_trees': (_I, [_VP, _I]),
     'mz_selfplay_steps': (_I, [_VP, _I, _VP]),
     'mz_selfplay_steps_timed': (_I, [_VP, _I, _VP, _VP]),
     'mz_selfplay_rec_floats': (_I, [_VP]),
@@ -130,6 +133,7 @@ REPLAY_SIGNATURES = {
     'mzr_tree_leaves': (_I, [_VP, _I64, _VP]),
     'mzr_save_history': (_I, [_VP, _I64, _VP, _I64, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     'mzr_ingest_records': (_I, [_VP, _VP, _I, _I, _I]),
+    'mzr_ingest_records_from': (_I, [_VP, _VP, _I, _I, _I, _I]),
     'mzr_sample_batch': (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     'mzr_frames': (_I64, [_VP]),
     'mzr_games': (_I64, [_VP]),

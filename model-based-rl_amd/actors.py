@@ -20,6 +20,7 @@ import torch
 
 from .engine import Engine, flatten_weights
 from .envs import get_environment
+from .networks import get_network
 
 
 def set_all_seeds(seed):
@@ -54,8 +55,25 @@ class Actor(object):
     self.device = torch.device('cuda', ids[actor_key] if ids else torch.cuda.current_device())
     self.host_env = config.environment == 'TicTacToe'
     self.num_envs = int(getattr(config, 'num_envs', 1))
-    self.engine = Engine.from_config(config, self.num_envs, device=self.device,
-                                     seed=(config.seed or 0) + actor_key, env_id_offset=actor_key * self.num_envs)
+    # FCNetwork: the engine's own fused HIP kernels.  Any other architecture (MuZeroNetwork / TinyNetwork): the torch
+    # network stays in the loop behind the batched external-inference path (actors.py:45-47 is network-agnostic)
+    self.torch_net = getattr(config, 'architecture', 'FCNetwork') != 'FCNetwork'
+    if self.torch_net:
+      from .torch_search import TorchSelfplay
+      if self.host_env:
+        raise NotImplementedError('host environments are served with FCNetwork; the conv networks take image observations')
+      self.network = get_network(config, self.device).eval()
+      norm = None
+      if getattr(config, 'norm_obs', False):
+        lo = torch.tensor(config.obs_range[::2], dtype=torch.float32, device=self.device)
+        hi = torch.tensor(config.obs_range[1::2], dtype=torch.float32, device=self.device)
+        norm = (lo, hi - lo)
+      self.selfplay = TorchSelfplay(config, self.network, self.num_envs, self.device, seed=(config.seed or 0) + actor_key,
+                                    env_id_offset=actor_key * self.num_envs, norm=norm)
+      self.engine = self.selfplay.search.engine
+    else:
+      self.engine = Engine.from_config(config, self.num_envs, device=self.device,
+                                       seed=(config.seed or 0) + actor_key, env_id_offset=actor_key * self.num_envs)
     if self.host_env:
       self.environments = [get_environment(config) for _ in range(self.num_envs)]
       for env in self.environments:
@@ -65,6 +83,8 @@ class Actor(object):
     if getattr(config, 'norm_obs', False):
       self.obs_min = np.array(config.obs_range[::2], dtype=np.float32)
       self.obs_range = np.array(config.obs_range[1::2], dtype=np.float32) - self.obs_min
+    # index of this actor's first environment among the replay's environments (one replay for all actors, train.py:71-72)
+    self.env_base = actor_key * self.num_envs
     self.experiences_collected = 0
     self.training_step = 0
     self.games_played = 0
@@ -73,8 +93,14 @@ class Actor(object):
       self.load_state(state)
 
   # actors.py:75-79
+  def _set_weights(self, weights):
+    if self.torch_net:
+      self.network.load_weights(weights)            # networks.py:36-37
+    else:
+      self.engine.set_weights(weights)
+
   def load_state(self, state):
-    self.engine.set_weights(state['weights'])
+    self._set_weights(state['weights'])
     self.training_step = state['training_step']
     self.games_played = state['actor_games'][self.actor_key]
 
@@ -82,7 +108,7 @@ class Actor(object):
   def sync_weights(self, force=False):
     weights, training_step = _call(self.storage, 'get_weights', self.games_played, self.actor_key)
     if training_step != self.training_step or force:
-      self.engine.set_weights(weights)
+      self._set_weights(weights)
       self.training_step = training_step
 
   def _temperature(self):
@@ -160,30 +186,94 @@ class Actor(object):
         self.play_game(games)
         self.games_played += len(games)
       return
+    if self.torch_net:
+      return self._run_selfplay_torch(max_moves)
     # synthetic on-device environments
     eng = self.engine
-    eng.selfplay_reset(cfg.episode_length, self._temperature(), stagger=True)
+    if getattr(cfg, 'norm_obs', False) or '-ram' in str(cfg.environment):
+      # the -ram- environments emit bytes; --norm_obs is applied inside the root kernel (actors.py:134-137)
+      norm = getattr(cfg, 'norm_obs', False)
+      eng.selfplay_set_obs(uint8_obs='-ram' in str(cfg.environment), obs_min=self.obs_min if norm else None,
+                           obs_range=self.obs_range if norm else None)
+    temperature = self._temperature()
+    eng.selfplay_reset(cfg.episode_length, temperature, stagger=True)
     pinned = [torch.empty(chunk, eng.B, eng.rec_floats, dtype=torch.float32).pin_memory() for _ in range(2)]
     events = [torch.cuda.Event(), torch.cuda.Event()]
     copy_stream = torch.cuda.Stream(self.device)        # D2H of chunk i overlaps the moves of chunk i+1
     pending, k = None, 0
     sync_every = max(1, cfg.weight_sync_frequency)      # experiences per environment between weight pulls
+    done_col = eng.O + eng.A + 6                        # int32 `done` slot of a record (include/mz_engine.h)
+
+    def hand_over(p):
+      buf, n, ev = p
+      ev.synchronize()
+      # games this actor finished (actors.py:94-99 counts one per play_game return; reported to the storage with the
+      # next weight pull, actors.py:82, shared_storage.py:12-14)
+      self.games_played += int(buf[:n].view(torch.int32)[..., done_col].sum())
+      _call(self.replay_buffer, 'ingest_records', buf, n, eng.B, self.env_base)
+
     while self.training_step < cfg.training_steps and (max_moves is None or self.move_counter < max_moves):
       eng.selfplay_steps(chunk)
       buf, n = eng.selfplay_drain(pinned[k & 1], chunk, copy_stream=copy_stream)
       events[k & 1].record(copy_stream)
       if pending is not None:
-        pending[2].synchronize()
-        _call(self.replay_buffer, 'ingest_records', pending[0], pending[1], eng.B)
+        hand_over(pending)
       pending = (buf, n, events[k & 1])
       k += 1
       self.move_counter += chunk
       self.experiences_collected += chunk * eng.B
       if (self.move_counter // sync_every) != ((self.move_counter - chunk) // sync_every):
         self.sync_weights()
+        # actors.py:128-129: the temperature of the schedule is evaluated at the start of every game; on the device the
+        # new value reaches each environment at its next episode start (games in progress keep theirs)
+        if self._temperature() != temperature:
+          temperature = self._temperature()
+          eng.selfplay_set_temperature(temperature)
     if pending is not None:
-      pending[2].synchronize()
-      _call(self.replay_buffer, 'ingest_records', pending[0], pending[1], eng.B)
+      hand_over(pending)
+    self.sync_weights(force=True)
+
+  def _run_selfplay_torch(self, max_moves=None):
+    """The same loop for a torch network (MuZeroNetwork / TinyNetwork, config 5): one move of all environments per
+    iteration through torch_search.TorchSelfplay; the move's records go D2H on a copy stream while the next move is
+    searched, and reach the replay through the same bulk ingest."""
+    cfg, sp = self.config, self.selfplay
+    temperature = self._temperature()
+    sp.temperature.fill_(temperature)
+    sp.set_temperature(temperature)
+    dev = [torch.empty(sp.B, sp.rec_floats, dtype=torch.float32, device=self.device) for _ in range(2)]
+    pinned = [torch.empty(1, sp.B, sp.rec_floats, dtype=torch.float32).pin_memory() for _ in range(2)]
+    events = [torch.cuda.Event(), torch.cuda.Event()]
+    copy_stream = torch.cuda.Stream(self.device)
+    sync_every = max(1, cfg.weight_sync_frequency)
+    done_col = sp.O + sp.A + 6
+    pending, k = None, 0
+
+    def hand_over(p):
+      buf, ev = p
+      ev.synchronize()
+      self.games_played += int(buf.view(torch.int32)[..., done_col].sum())
+      _call(self.replay_buffer, 'ingest_records', buf, 1, sp.B, self.env_base)
+
+    while self.training_step < cfg.training_steps and (max_moves is None or self.move_counter < max_moves):
+      sp.play_move(dev[k & 1])
+      copy_stream.wait_stream(torch.cuda.current_stream(self.device))
+      with torch.cuda.stream(copy_stream):
+        pinned[k & 1][0].copy_(dev[k & 1], non_blocking=True)
+      events[k & 1].record(copy_stream)
+      if pending is not None:
+        hand_over(pending)
+      pending = (pinned[k & 1], events[k & 1])
+      k += 1
+      self.move_counter += 1
+      self.experiences_collected += sp.B
+      if self.move_counter % sync_every == 0:
+        self.sync_weights()
+        if self._temperature() != temperature:
+          temperature = self._temperature()
+          sp.set_temperature(temperature)
+    if pending is not None:
+      hand_over(pending)
     self.sync_weights(force=True)
 
   def launch(self, max_moves=None):

@@ -50,7 +50,9 @@ class Config(object):
 def build_parser():
   p = argparse.ArgumentParser(description='MI355X-native MuZero self-play (reference flag names)')
   a = p.add_argument
-  a('--architecture', type=str, default='FCNetwork', choices=['FCNetwork'])
+  a('--architecture', type=str, default='FCNetwork', choices=['FCNetwork', 'MuZeroNetwork', 'TinyNetwork'])
+  a('--stack_obs', type=int, default=1)
+  a('--stack_actions', action='store_true')
   a('--value_support', nargs=2, type=int, default=[-15, 15])
   a('--reward_support', nargs=2, type=int, default=[-15, 15])
   a('--no_support', action='store_true')
@@ -111,6 +113,9 @@ def build_parser():
 ENV_SHAPES = {   # (action_space, obs_space) of the environments the reference's README runs
     'TicTacToe': (9, (9,)), 'LunarLander-v2': (4, (8,)), 'Pong-ramNoFrameskip-v4': (6, (128,)),
     'Breakout-ramNoFrameskip-v4': (4, (128,)),
+    # image observations of the Atari wrappers (wrappers.py:422-444: 96x96 frames, stack_obs channels) -- what
+    # MuZeroNetwork / TinyNetwork take (SURVEY.md s7 on BASELINE configs[4])
+    'BreakoutNoFrameskip-v4': (4, (4, 96, 96)), 'PongNoFrameskip-v4': (6, (4, 96, 96)),
 }
 
 

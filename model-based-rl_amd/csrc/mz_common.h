@@ -31,7 +31,6 @@ struct TreeView {
   float *root_value; // [B] initial_inference value (actors.py:147)
   float *root_logits;// [B][A]
   double *noise;     // [B][A] Dirichlet draw mixed into the root
-  const double *logtab;   // [sims+2] log((n+base+1)/base)+init   (host libm, mcts.py:116)
   const double *sqrttab;  // [sims+2] sqrt(n)                      (host libm, mcts.py:117)
   const double *pbctab;   // [sims+2][sims+2] pb_c(Np, Nc) = logtab[Np] * (sqrttab[Np] / (Nc + 1))  (mcts.py:116-117)
   int B, A, sims, NN, PL;

@@ -45,6 +45,7 @@ static int fail(const char *fmt, ...) {
 
 struct mz_engine {
   mz_config cfg;
+  int device = 0;                   // HIP device the engine's pools live on (the current device at mz_create)
   int B, Bp, A, O, sims, NN, PL, G, jtp;
   TreeView tv;
   NetView nv;
@@ -73,7 +74,26 @@ struct mz_engine {
   bool fuse_record = false;         // set by the self-play loop around its search launch: finalize + record in the kernel tail
   unsigned long long *prof_buf = nullptr;   // non-null only inside mz_search_phase_profile
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;   // non-null only inside mz_search_timed: bracket the search kernel's dispatch
+  bool lds_attr_set = false, lds_attr_set_prof = false;   // hipFuncAttributeMaxDynamicSharedMemorySize is per device: set once per engine
+  // record drain on a copy stream (mz_selfplay_drain): event behind the last copy, and how far the compute stream
+  // has been ordered behind the copies
+  hipEvent_t drain_ev = nullptr;
+  hipStream_t drain_stream = nullptr;
+  bool drain_pending = false;
+  unsigned long long drained_ordered = 0;
+  float *obs_norm = nullptr;        // [2][O] --norm_obs minimum and range (device)
+  std::vector<float> obs_norm_host;
 };
+
+// Every ABI entry runs on the engine's own device, whatever the calling thread's current device is (an engine may be
+// driven from a worker thread: rayshim actors, a replay/drain thread).
+#define MZ_ENTER(e)                                                                          \
+  do {                                                                                       \
+    int cur_ = -1;                                                                           \
+    if (hipGetDevice(&cur_) != hipSuccess || cur_ != (e)->device) HIPCHECK(hipSetDevice((e)->device)); \
+  } while (0)
+
+__global__ void k_store_double(double *dst, double v) { *dst = v; }
 
 template <typename T>
 static int dmalloc(mz_engine *e, T **p, size_t n) {
@@ -352,21 +372,20 @@ static int launch_root(mz_engine *e, const float *obs, bool selfplay, hipStream_
 
 template <int KS1, int JTP, int G, int LT>
 static int launch_fused_lt(mz_engine *e, int num_simulations, int sims_done, hipStream_t s) {
-  static bool attr_set = false, attr_set_prof = false;
   const size_t dyn = mz_fused_dyn_lds(e->sims, e->NN, LT);
   if (e->prof_buf) {
-    if (!attr_set_prof) {
+    if (!e->lds_attr_set_prof) {
       HIPCHECK(hipFuncSetAttribute((const void *)k_search_fused<KS1, JTP, G, LT, true>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)sizeof(float) * mz_fused_lds_floats(LT)));
-      attr_set_prof = true;
+      e->lds_attr_set_prof = true;
     }
     hipLaunchKernelGGL((k_search_fused<KS1, JTP, G, LT, true>), dim3(e->Bp / MZ_ROWS), dim3(256), dyn, s, e->nv,
                        e->tv, e->wstream, num_simulations, sims_done, e->prof_buf, e->sp, 0, (uint64_t)e->cfg.seed);
   } else {
-    if (!attr_set) {
+    if (!e->lds_attr_set) {
       HIPCHECK(hipFuncSetAttribute((const void *)k_search_fused<KS1, JTP, G, LT, false>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)sizeof(float) * mz_fused_lds_floats(LT)));
-      attr_set = true;
+      e->lds_attr_set = true;
     }
     if (e->ev_start)      // timestamps of the dispatch itself (what rocprofv3's kernel trace reports), no launch gap inside
       hipExtLaunchKernelGGL((k_search_fused<KS1, JTP, G, LT, false>), dim3(e->Bp / MZ_ROWS), dim3(256), dyn, s,
@@ -454,6 +473,7 @@ int mz_create(const mz_config *cfg, mz_engine **out) {
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     return fail("mz_create: no HIP device visible (this engine has no CPU path)");
   mz_engine *e = new mz_engine();
+  if (hipGetDevice(&e->device) != hipSuccess) { delete e; return fail("mz_create: hipGetDevice failed"); }
   e->cfg = *cfg;
   e->B = cfg->num_envs;
   e->Bp = (cfg->num_envs + MZ_ROWS - 1) / MZ_ROWS * MZ_ROWS;
@@ -479,8 +499,8 @@ int mz_create(const mz_config *cfg, mz_engine **out) {
   DM(t.hpool, nb * (e->sims + 1) * MZ_HS)
   DM(t.value, nb) DM(t.reward, nb) DM(t.logits, nb * e->A) DM(t.root_value, nb) DM(t.root_logits, nb * e->A)
   DM(t.noise, nb * e->A)
-  double *logtab, *sqrttab, *pbctab;
-  DM(logtab, e->sims + 2) DM(sqrttab, e->sims + 2) DM(pbctab, (size_t)(e->sims + 2) * (e->sims + 2))
+  double *sqrttab, *pbctab;
+  DM(sqrttab, e->sims + 2) DM(pbctab, (size_t)(e->sims + 2) * (e->sims + 2))
 #undef DM
   {
     // mcts.py:116-117: math.log((N + base + 1) / base) + init and math.sqrt(N), for every N a parent
@@ -506,7 +526,7 @@ int mz_create(const mz_config *cfg, mz_engine **out) {
       return fail("mz_create: table upload failed");
     }
   }
-  t.logtab = logtab; t.sqrttab = sqrttab; t.pbctab = pbctab;
+  t.sqrttab = sqrttab; t.pbctab = pbctab;
   t.B = e->B; t.A = e->A; t.sims = e->sims; t.NN = e->NN; t.PL = e->PL;
   t.two_players = cfg->two_players; t.has_min = cfg->has_min_bound; t.has_max = cfg->has_max_bound;
   t.min_bound = cfg->min_bound; t.max_bound = cfg->max_bound; t.discount = cfg->discount;
@@ -523,7 +543,9 @@ int mz_create(const mz_config *cfg, mz_engine **out) {
 
 int mz_destroy(mz_engine *e) {
   if (!e) return 0;
+  hipSetDevice(e->device);
   hipDeviceSynchronize();
+  if (e->drain_ev) hipEventDestroy(e->drain_ev);
   if (e->search_graph) hipGraphExecDestroy(e->search_graph);
   for (auto &g : e->move_graph) if (g) hipGraphExecDestroy(g);
   if (e->cap_stream) hipStreamDestroy(e->cap_stream);
@@ -539,6 +561,7 @@ int mz_padded_envs(const mz_engine *e) { return e ? e->Bp : -1; }
 
 int mz_set_weights(mz_engine *e, const float *flat, size_t n, int on_device, void *stream) {
   if (!e || !flat) return fail("mz_set_weights: null argument");
+  MZ_ENTER(e);
   if (n != e->n_flat) return fail("mz_set_weights: expected %zu floats, got %zu", e->n_flat, n);
   hipStream_t s = (hipStream_t)stream;
   const float *src = flat;
@@ -557,6 +580,7 @@ int mz_set_weights(mz_engine *e, const float *flat, size_t n, int on_device, voi
 
 int mz_initial_inference(mz_engine *e, const float *obs, void *stream) {
   if (!e || !obs) return fail("mz_initial_inference: null argument");
+  MZ_ENTER(e);
   if (!e->weights_set) return fail("mz_initial_inference: weights not set (call mz_set_weights)");
   hipStream_t s = (hipStream_t)stream;
   if (launch_root(e, obs, false, s)) return -1;
@@ -566,6 +590,7 @@ int mz_initial_inference(mz_engine *e, const float *obs, void *stream) {
 
 int mz_root_load(mz_engine *e, const float *hidden, const float *value, const float *logits, void *stream) {
   if (!e || !value || !logits) return fail("mz_root_load: null argument");
+  MZ_ENTER(e);
   hipStream_t s = (hipStream_t)stream;
   HIPCHECK(hipMemcpyAsync(e->tv.root_value, value, (size_t)e->B * sizeof(float), hipMemcpyDeviceToDevice, s));
   HIPCHECK(hipMemcpyAsync(e->tv.root_logits, logits, (size_t)e->B * e->A * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -587,6 +612,7 @@ __global__ void k_copy_root_hidden(TreeView t, float *out) {
 
 int mz_root_outputs(mz_engine *e, float *value, float *logits, float *hidden, void *stream) {
   if (!e) return fail("mz_root_outputs: null engine");
+  MZ_ENTER(e);
   hipStream_t s = (hipStream_t)stream;
   if (value) HIPCHECK(hipMemcpyAsync(value, e->tv.root_value, (size_t)e->B * sizeof(float), hipMemcpyDeviceToDevice, s));
   if (logits)
@@ -602,6 +628,7 @@ int mz_root_outputs(mz_engine *e, float *value, float *logits, float *hidden, vo
 int mz_root_prepare(mz_engine *e, const int8_t *to_play, const uint8_t *legal, const double *noise,
                     int use_device_rng, uint64_t move_counter, void *stream) {
   if (!e) return fail("mz_root_prepare: null engine");
+  MZ_ENTER(e);
   hipStream_t s = (hipStream_t)stream;
   const double *nz = noise;
   if (!noise && use_device_rng) {
@@ -624,6 +651,7 @@ int mz_root_prepare(mz_engine *e, const int8_t *to_play, const uint8_t *legal, c
 
 int mz_search(mz_engine *e, int num_simulations, void *stream) {
   if (!e) return fail("mz_search: null engine");
+  MZ_ENTER(e);
   if (!e->weights_set) return fail("mz_search: weights not set (call mz_set_weights)");
   if (!e->root_ready) return fail("mz_search: call mz_root_prepare first");
   if (num_simulations < 1 || e->sims_done + num_simulations > e->sims)
@@ -655,6 +683,7 @@ int mz_search(mz_engine *e, int num_simulations, void *stream) {
 int mz_root_set_priors(mz_engine *e, const int8_t *to_play, const uint8_t *legal, const double *priors,
                        void *stream) {
   if (!e || !priors) return fail("mz_root_set_priors: null argument");
+  MZ_ENTER(e);
   if (launch_root_priors(e, to_play, legal, priors, (hipStream_t)stream)) return -1;
   e->sims_done = 0;
   e->selection_valid = true;
@@ -664,6 +693,7 @@ int mz_root_set_priors(mz_engine *e, const int8_t *to_play, const uint8_t *legal
 
 int mz_last_paths(mz_engine *e, int32_t *paths, int32_t *lengths, void *stream) {
   if (!e) return fail("mz_last_paths: null engine");
+  MZ_ENTER(e);
   if (!e->selection_valid) return fail("mz_last_paths: no pending descent (call mz_select first)");
   hipStream_t s = (hipStream_t)stream;
   if (paths) HIPCHECK(hipMemcpyAsync(paths, e->tv.path, (size_t)e->B * e->PL * 4, hipMemcpyDeviceToDevice, s));
@@ -673,6 +703,7 @@ int mz_last_paths(mz_engine *e, int32_t *paths, int32_t *lengths, void *stream) 
 
 int mz_search_profiled(mz_engine *e, int num_simulations, float *ms_out, void *stream) {
   if (!e || !ms_out) return fail("mz_search_profiled: null argument");
+  MZ_ENTER(e);
   if (!e->weights_set) return fail("mz_search_profiled: weights not set (call mz_set_weights)");
   if (!e->root_ready || !e->selection_valid || e->sims_done != 0)
     return fail("mz_search_profiled: call right after mz_root_prepare");
@@ -704,6 +735,7 @@ int mz_search_profiled(mz_engine *e, int num_simulations, float *ms_out, void *s
 
 int mz_search_timed(mz_engine *e, int num_simulations, float *ms_out, void *stream) {
   if (!e || !ms_out) return fail("mz_search_timed: null argument");
+  MZ_ENTER(e);
   if (!e->use_fused || e->sims + 2 > MZ_FUSED_MAXPL) return fail("mz_search_timed: fused kernel not in use");
   if (!e->weights_set) return fail("mz_search_timed: weights not set (call mz_set_weights)");
   if (!e->root_ready || !e->selection_valid || e->sims_done != 0)
@@ -728,6 +760,7 @@ int mz_search_timed(mz_engine *e, int num_simulations, float *ms_out, void *stre
 
 int mz_search_phase_profile(mz_engine *e, int num_simulations, unsigned long long *cycles_out, void *stream) {
   if (!e || !cycles_out) return fail("mz_search_phase_profile: null argument");
+  MZ_ENTER(e);
   if (!e->use_fused) return fail("mz_search_phase_profile: fused kernel disabled");
   if (!e->root_ready || !e->selection_valid || e->sims_done != 0)
     return fail("mz_search_phase_profile: call right after mz_root_prepare");
@@ -758,6 +791,7 @@ int mz_search_phase_profile(mz_engine *e, int num_simulations, unsigned long lon
 
 int mz_select(mz_engine *e, int32_t *leaf_node, int32_t *parent_slot, int32_t *action, int32_t *depth, void *stream) {
   if (!e) return fail("mz_select: null engine");
+  MZ_ENTER(e);
   if (!e->root_ready) return fail("mz_select: call mz_root_prepare first");
   if (e->sims_done >= e->sims) return fail("mz_select: all %d simulations already done", e->sims);
   hipStream_t s = (hipStream_t)stream;
@@ -776,6 +810,7 @@ int mz_select(mz_engine *e, int32_t *leaf_node, int32_t *parent_slot, int32_t *a
 
 int mz_gather_hidden(mz_engine *e, float *hidden_out, void *stream) {
   if (!e || !hidden_out) return fail("mz_gather_hidden: null argument");
+  MZ_ENTER(e);
   if (!e->selection_valid) return fail("mz_gather_hidden: call mz_select first");
   const int n = e->B * MZ_H;
   hipLaunchKernelGGL(k_gather_hidden, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->tv, hidden_out);
@@ -786,6 +821,7 @@ int mz_gather_hidden(mz_engine *e, float *hidden_out, void *stream) {
 int mz_expand_backup(mz_engine *e, const float *value, const float *reward, const float *logits,
                      const float *hidden, void *stream) {
   if (!e || !value || !reward || !logits) return fail("mz_expand_backup: null argument");
+  MZ_ENTER(e);
   if (!e->selection_valid) return fail("mz_expand_backup: call mz_select first");
   hipStream_t s = (hipStream_t)stream;
   if (hidden) {
@@ -803,6 +839,7 @@ int mz_recurrent_inference(mz_engine *e, const float *hidden_in, const int32_t *
                            float *reward, float *value, float *logits, void *stream) {
   if (!e || !hidden_in || !action || !hidden_out || !reward || !value || !logits)
     return fail("mz_recurrent_inference: null argument");
+  MZ_ENTER(e);
   if (!e->weights_set) return fail("mz_recurrent_inference: weights not set (call mz_set_weights)");
   if (n < 1) return fail("mz_recurrent_inference: n must be >= 1");
   NET_LAUNCH(k_net_recurrent_rows, (n + MZ_ROWS - 1) / MZ_ROWS, (hipStream_t)stream, e->nv, hidden_in, action, n,
@@ -815,6 +852,7 @@ int mz_finalize(mz_engine *e, const double *temperature, const double *uniform, 
                 int32_t *action, double *child_visits, double *root_value, double *error, int32_t *visit_counts,
                 void *stream) {
   if (!e) return fail("mz_finalize: null engine");
+  MZ_ENTER(e);
   if (action && !temperature) return fail("mz_finalize: temperature is required when action is requested");
   const int threads = 128;
   hipLaunchKernelGGL(k_tree_finalize, dim3((e->B + threads - 1) / threads), dim3(threads), 0, (hipStream_t)stream,
@@ -827,6 +865,7 @@ int mz_finalize(mz_engine *e, const double *temperature, const double *uniform, 
 int mz_export_tree(mz_engine *e, int32_t *N, double *W, double *P, float *R, int32_t *E, int8_t *TP,
                    uint32_t *legal_mask, double *minmax, double *noise, float *hidden_pool) {
   if (!e) return fail("mz_export_tree: null engine");
+  MZ_ENTER(e);
   HIPCHECK(hipDeviceSynchronize());
   const size_t nn = (size_t)e->B * e->NN;
   const TreeView &t = e->tv;

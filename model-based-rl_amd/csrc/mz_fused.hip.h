@@ -515,12 +515,16 @@ __device__ __forceinline__ void mz_finalize_record(const TreeView &t, const Tree
     const int action = acts[idx];
     const int tt = sp.t[b], ep = sp.episode[b];
     const int done = (tt + 1 >= sp.episode_len) ? 1 : 0;
-    rec[O + A + 0] = (float)rv;
-    rec[O + A + 1] = (float)err;
-    rec[O + A + 2] = mz_synth_reward(seed, env, (uint32_t)ep, (uint32_t)tt);
-    int32_t *ri = (int32_t *)(rec + O + A + 3);
+    mz_rec_put_double(rec + O + A + 0, rv);
+    mz_rec_put_double(rec + O + A + 2, err);
+    rec[O + A + 4] = mz_synth_reward(seed, env, (uint32_t)ep, (uint32_t)tt);
+    int32_t *ri = (int32_t *)(rec + O + A + 5);
     ri[0] = action; ri[1] = done; ri[2] = tt; ri[3] = (int32_t)env; ri[4] = ep;
-    if (done) { sp.t[b] = 0; sp.episode[b] = ep + 1; } else { sp.t[b] = tt + 1; }
+    if (done) {      // the next game starts: its temperature is evaluated now (actors.py:128-129)
+      sp.t[b] = 0; sp.episode[b] = ep + 1; sp.temp[b] = *sp.temp_next;
+    } else {
+      sp.t[b] = tt + 1;
+    }
     sp.movecnt[b] = move + 1ull;
   }
 }
@@ -970,8 +974,11 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
   for (int i = 0; i < NPASS; ++i) {
     const int b = b0 + tid / TL + i * (256 / TL);
     if (b < t.B && tl == 0) { t.mn[b] = tr[i].mn; t.mx[b] = tr[i].mx; t.nexp[b] = slot0 + nsims + 1; }
+    // the trees themselves: only where somebody can read them -- a search call (export, continued search, finalize
+    // kernel) or a self-play loop asked to keep them; the self-play loop itself rebuilds every tree at the next root
+    // and has finalized this one from LDS above (15 MB of dead stores per launch at 4096 x 125 nodes)
     if constexpr (LT != 0) {
-      if (b < t.B) {
+      if (b < t.B && (!record || sp.export_trees)) {
         const size_t o = (size_t)b * t.NN;
         const int have = 1 + (slot0 + nsims + 1) * t.A;
         for (int k = tl; k < have; k += TL) {

@@ -260,11 +260,23 @@ int mzr_save_history(mz_replay *r, int64_t n, const double *errors, int64_t igno
   return save_history(r, n, errors, ignore, terminal, obs, child_visits, root_values, rewards, actions, dones, to_play);
 }
 
+static inline double rec_double(const float *p) {     // a float64 stored in two float slots (4-byte aligned)
+  double v;
+  memcpy(&v, p, sizeof v);
+  return v;
+}
+
 int mzr_ingest_records(mz_replay *r, const float *records, int n_moves, int B, int rec_floats) {
+  return mzr_ingest_records_from(r, records, n_moves, B, rec_floats, 0);
+}
+
+int mzr_ingest_records_from(mz_replay *r, const float *records, int n_moves, int B, int rec_floats, int env_base) {
   if (!r || !records) return fail("mzr_ingest_records: null argument");
+  if (n_moves < 0 || B < 1 || env_base < 0) return fail("mzr_ingest_records: bad shape (n_moves %d, B %d, env_base %d)", n_moves, B, env_base);
   const int O = r->c.obs_dim, A = r->c.action_space;
-  if (rec_floats != O + A + 8) return fail("mzr_ingest_records: rec_floats %d != obs_dim+action_space+8 = %d", rec_floats, O + A + 8);
-  if ((int)r->envs.size() < B) r->envs.resize(B);
+  if (rec_floats != O + A + MZR_REC_EXTRA)
+    return fail("mzr_ingest_records: rec_floats %d != obs_dim+action_space+%d = %d", rec_floats, MZR_REC_EXTRA, O + A + MZR_REC_EXTRA);
+  if ((int)r->envs.size() < env_base + B) r->envs.resize((size_t)env_base + B);
   const int64_t overlap = r->c.num_unroll_steps + r->c.td_steps;
   // Environment-major: an env's bookkeeping and the tail of its record buffer are touched once per call
   // instead of once per move (4096 envs x 3 cold cache lines per record were the bulk of the ingest time).  The
@@ -275,10 +287,10 @@ int mzr_ingest_records(mz_replay *r, const float *records, int n_moves, int B, i
   pend.clear();
   pris.clear();
   for (int b = 0; b < B; ++b) {
-    EnvGame &g = r->envs[b];
+    EnvGame &g = r->envs[(size_t)env_base + b];
     for (int m = 0; m < n_moves; ++m) {
       const float *rec = records + ((size_t)m * B + b) * rec_floats;
-      const int32_t *ri = (const int32_t *)(rec + O + A + 3);
+      const int32_t *ri = (const int32_t *)(rec + O + A + 5);
       const bool done = ri[1] != 0;
       g.recs.insert(g.recs.end(), rec, rec + rec_floats);
       g.history_idx += 1;
@@ -304,12 +316,12 @@ int mzr_ingest_records(mz_replay *r, const float *records, int n_moves, int B, i
         double *pri = pris.data() + off;
         const float *q = g.recs.data() + (size_t)(collect_from - g.base) * rec_floats;
         for (int64_t i = 0; i < n; ++i, q += rec_floats) {
-          const int32_t *qi = (const int32_t *)(q + O + A + 3);
+          const int32_t *qi = (const int32_t *)(q + O + A + 5);
           memcpy(h->obs.data() + i * O, q, O * sizeof(float));
           memcpy(h->child_visits.data() + i * A, q + O, A * sizeof(float));
-          h->root_values[i] = (double)q[O + A]; h->rewards[i] = q[O + A + 2];
+          h->root_values[i] = rec_double(q + O + A); h->rewards[i] = q[O + A + 4];
           h->actions[i] = qi[0]; h->dones[i] = (uint8_t)(qi[1] != 0);
-          const double e = fabs((double)q[O + A + 1]) + r->c.epsilon;
+          const double e = fabs(rec_double(q + O + A + 2)) + r->c.epsilon;
           pri[i] = r->c.alpha == 1.0 ? e : pow(e, r->c.alpha);
         }
         pend.push_back(Pending{m, b, h, keep, off, done});

@@ -46,6 +46,15 @@ __host__ __device__ inline float mz_synth_obs_elem(uint64_t seed, uint32_t env, 
   return (float)s * 2.6429e-05f;   // 1/(65536*sqrt(4/12)) ~ unit variance
 }
 
+// uint8-valued observation element (the -ram- environments: 128 bytes of console RAM, wrappers-free gym obs of dtype
+// uint8): byte i of the Philox stream keyed (env, episode, t), as a float32 in 0..255
+__host__ __device__ inline float mz_synth_obs_u8(uint64_t seed, uint32_t env, uint32_t episode, uint32_t t, uint32_t i) {
+  mz_u4 r = mz_philox(seed, env, episode, t, (MZ_RNG_OBS << 24) | (i >> 4));
+  const uint32_t sel = (i >> 2) & 3u;
+  const uint32_t word = sel == 0 ? r.x : (sel == 1 ? r.y : (sel == 2 ? r.z : r.w));
+  return (float)((word >> (8u * (i & 3u))) & 255u);
+}
+
 // reward_t ~ U(-1,1) with 24-bit resolution, exact in float32
 __host__ __device__ inline float mz_synth_reward(uint64_t seed, uint32_t env, uint32_t episode, uint32_t t) {
   mz_u4 r = mz_philox(seed, env, episode, t, MZ_RNG_REWARD << 24);

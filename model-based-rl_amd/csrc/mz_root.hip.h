@@ -106,9 +106,10 @@ __global__ __launch_bounds__(256, 1) void k_root(NetView n, TreeView t, const fl
       if (k < O) {
         if (b < t.B) {
           if constexpr (SELFPLAY) {   // Game.get_observation(-1) of the synthetic env (game.py:117-121)
-            v = mz_synth_obs_elem(seed, (uint32_t)(sp.env_offset + b), (uint32_t)sp.episode[b], (uint32_t)sp.t[b],
-                                  (uint32_t)k);
-            sp.obs[(size_t)b * O + k] = v;
+            const uint32_t env = (uint32_t)(sp.env_offset + b), ep = (uint32_t)sp.episode[b], tt = (uint32_t)sp.t[b];
+            v = sp.obs_u8 ? mz_synth_obs_u8(seed, env, ep, tt, (uint32_t)k) : mz_synth_obs_elem(seed, env, ep, tt, (uint32_t)k);
+            sp.obs[(size_t)b * O + k] = v;            // History.observations keeps the raw observation (game.py:93-96)
+            if (sp.obs_min) v = (v - sp.obs_min[k]) / sp.obs_rng[k];      // actors.py:134-137, float32 like numpy's
           } else {
             v = obs_in[(size_t)b * O + k];
           }

@@ -12,7 +12,11 @@ struct SelfplayState {
   int32_t *t;            // [B] env._elapsed_steps
   int32_t *episode;      // [B] episodes finished
   float *obs;            // [Bp][O] current observation (History.observations[-1])
-  double *temp;          // [B] visit-softmax temperature (actors.py:128-129)
+  double *temp;          // [B] visit-softmax temperature of the env's CURRENT game (actors.py:128-129: evaluated once per game)
+  double *temp_next;     // [1] temperature the next game of every env starts with (mz_selfplay_set_temperature)
+  const float *obs_min, *obs_rng;   // [O] --norm_obs: network input = (obs - min) / range (actors.py:55-58,134-137); null = raw
+  int obs_u8;            // synthetic observations are uint8-valued (the -ram- envs: 128 bytes of console RAM), else ~N(0,1)
+  int export_trees;      // write the searched trees back to the global pool at the end of every move (tests / tree export)
   int32_t *action;       // [B]
   double *child_visits;  // [B][A]
   double *root_value, *error;   // [B]
@@ -77,9 +81,18 @@ __global__ void k_dirichlet(TreeView t, const uint8_t *legal, double alpha, uint
   }
 }
 
+// Experience record of one move: obs[O], child_visits[A] (float32), root_value and error as float64 (two float
+// slots each: the reference keeps both as Python floats, actors.py:147-148, game.py:112), reward (float32), then int32
+// bit patterns: action, done, step (pre-step), env_id, episode.
+#ifndef MZ_REC_EXTRA
+#define MZ_REC_EXTRA 10     // (include/mz_engine.h)
+#endif
+__device__ __forceinline__ void mz_rec_put_double(float *dst, double v) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  ((uint32_t *)dst)[0] = (uint32_t)u; ((uint32_t *)dst)[1] = (uint32_t)(u >> 32);
+}
+
 // Game.apply (game.py:79-104) on the synthetic env + the experience record of this move.
-// record: obs[O], child_visits[A] (float32), root_value, error, reward, then int32 bit patterns:
-// action, done, step (pre-step), env_id, episode.
 __global__ void k_env_step_record(TreeView tv, SelfplayState sp, int B, int O, int A, uint64_t seed) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
@@ -94,11 +107,15 @@ __global__ void k_env_step_record(TreeView tv, SelfplayState sp, int B, int O, i
   for (int a = 0; a < A; ++a) rec[O + a] = (float)sp.child_visits[(size_t)b * A + a];
   const float reward = mz_synth_reward(seed, (uint32_t)(sp.env_offset + b), (uint32_t)ep, (uint32_t)t);
   const int done = (t + 1 >= sp.episode_len) ? 1 : 0;
-  rec[O + A + 0] = (float)sp.root_value[b];
-  rec[O + A + 1] = (float)sp.error[b];
-  rec[O + A + 2] = reward;
-  int32_t *ri = (int32_t *)(rec + O + A + 3);
+  mz_rec_put_double(rec + O + A + 0, sp.root_value[b]);
+  mz_rec_put_double(rec + O + A + 2, sp.error[b]);
+  rec[O + A + 4] = reward;
+  int32_t *ri = (int32_t *)(rec + O + A + 5);
   ri[0] = sp.action[b]; ri[1] = done; ri[2] = t; ri[3] = sp.env_offset + b; ri[4] = ep;
-  if (done) { sp.t[b] = 0; sp.episode[b] = ep + 1; } else { sp.t[b] = t + 1; }
+  if (done) {      // the next game starts: its temperature is evaluated now (actors.py:128-129)
+    sp.t[b] = 0; sp.episode[b] = ep + 1; sp.temp[b] = *sp.temp_next;
+  } else {
+    sp.t[b] = t + 1;
+  }
 }
 

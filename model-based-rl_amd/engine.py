@@ -34,6 +34,22 @@ def flatten_weights(weights):
   return torch.cat(parts).contiguous()
 
 
+REC_EXTRA = 10      # include/mz_engine.h MZ_REC_EXTRA
+
+
+def records_view(rec, O, A):
+  """Named views into experience records [..., O + A + REC_EXTRA] (numpy float32, layout of include/mz_engine.h):
+  obs, child_visits, root_value / error (float64), reward, action / done / step / env_id / episode (int32)."""
+  rec = np.asarray(rec)
+  assert rec.dtype == np.float32 and rec.shape[-1] == O + A + REC_EXTRA, (rec.dtype, rec.shape)
+  ints = rec[..., O + A + 5:].view(np.int32)
+  return dict(obs=rec[..., :O], child_visits=rec[..., O:O + A],
+              root_value=np.ascontiguousarray(rec[..., O + A:O + A + 2]).view(np.float64)[..., 0],
+              error=np.ascontiguousarray(rec[..., O + A + 2:O + A + 4]).view(np.float64)[..., 0],
+              reward=rec[..., O + A + 4], action=ints[..., 0], done=ints[..., 1], step=ints[..., 2],
+              env_id=ints[..., 3], episode=ints[..., 4])
+
+
 def _ptr(t):
   return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -49,6 +65,8 @@ class Engine(object):
                          'there is no CPU path.')
     self.lib = _abi.load()
     self.device = torch.device(device if device is not None else 'cuda:0')
+    if self.device.index is None:
+      self.device = torch.device('cuda', torch.cuda.current_device())
     torch.cuda.set_device(self.device)
     lo, hi = known_bounds
     self.B, self.O, self.A, self.sims = int(num_envs), int(obs_dim), int(action_space), int(num_simulations)
@@ -214,7 +232,10 @@ class Engine(object):
                'mz_expand_backup')
 
   def finalize(self, temperature, uniform=None, move=0):
-    t = torch.as_tensor(np.broadcast_to(np.asarray(temperature, np.float64), (self.B,)).copy())
+    if torch.is_tensor(temperature):
+      t = temperature.to(self.device, torch.float64).expand(self.B)
+    else:
+      t = torch.as_tensor(np.broadcast_to(np.asarray(temperature, np.float64), (self.B,)).copy())
     t = self._dev(t, torch.float64)
     u = self._dev(uniform, torch.float64)
     action = torch.empty(self.B, dtype=torch.int32, device=self.device)
@@ -255,6 +276,24 @@ class Engine(object):
                'mz_selfplay_reset')
     self.rec_floats = self.lib.mz_selfplay_rec_floats(self._h)
     self.ring_moves = self.lib.mz_selfplay_ring_moves(self._h)
+
+  def selfplay_set_temperature(self, temperature):
+    """Temperature every environment's next game starts with (actors.py:128-129); games in progress keep theirs."""
+    _abi.check(self.lib.mz_selfplay_set_temperature(self._h, float(temperature), self.stream),
+               'mz_selfplay_set_temperature')
+
+  def selfplay_set_obs(self, uint8_obs=False, obs_min=None, obs_range=None):
+    """Synthetic observations as bytes (the -ram- envs) and / or --norm_obs (actors.py:55-58,134-137): obs_min and
+    obs_range are broadcast to obs_dim like numpy does in the reference's (obs - min) / range."""
+    mn = rg = None
+    if obs_min is not None:
+      mn = np.ascontiguousarray(np.broadcast_to(np.asarray(obs_min, np.float32).reshape(-1), (self.O,)))
+      rg = np.ascontiguousarray(np.broadcast_to(np.asarray(obs_range, np.float32).reshape(-1), (self.O,)))
+    p = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+    _abi.check(self.lib.mz_selfplay_set_obs(self._h, int(bool(uint8_obs)), p(mn), p(rg)), 'mz_selfplay_set_obs')
+
+  def selfplay_export_trees(self, keep=True):
+    _abi.check(self.lib.mz_selfplay_export_trees(self._h, int(bool(keep))), 'mz_selfplay_export_trees')
 
   def selfplay_steps(self, moves):
     _abi.check(self.lib.mz_selfplay_steps(self._h, int(moves), self.stream), 'mz_selfplay_steps')

@@ -1,8 +1,14 @@
-"""PyTorch definitions of the networks (training side + weight source).  Only FCNetwork's *definition*
-lives here; its inference inside the search is the fused HIP kernel in csrc/mz_net.hip.h.  Parameter names
-equal the reference's state_dict keys (networks.py:137-144) so checkpoints and the flat weight order
-(engine.WEIGHT_ORDER) are interchangeable.  Surface: initial_inference / recurrent_inference ->
-NetworkOutput(value, reward, policy_logits, hidden_state), load_weights / get_weights (networks.py:9-52).
+"""PyTorch definitions of the networks (training side + weight source).
+
+FCNetwork: only its *definition* lives here; its inference inside the search is the fused HIP kernel
+(csrc/mz_fused.hip.h, mz_root.hip.h).  MuZeroNetwork / TinyNetwork (the conv networks of BASELINE.json configs[4],
+reference networks.py:393-718): definitions AND inference are PyTorch-ROCm / MIOpen (SURVEY.md s2 row 11 -- no
+hand-written conv kernels); they serve the search through the batched external-inference path (torch_search.py).
+Parameter names and the order in which modules are constructed equal the reference's, so state_dicts, checkpoints and
+the flat weight order (engine.WEIGHT_ORDER) are interchangeable and a seeded default initialisation draws the same
+weights (tests/golden/g6_*).  Surface: initial_inference / recurrent_inference -> NetworkOutput(value, reward,
+policy_logits, hidden_state), load_weights / get_weights (networks.py:9-52); `action` may be a list (reference call
+style), a numpy array or a device tensor (batched search: no host round trip).
 """
 from collections import namedtuple
 
@@ -92,3 +98,250 @@ class FCNetwork(nn.Module):
 
   def get_weights(self):
     return {k: v.cpu() for k, v in self.state_dict().items()}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Conv networks (reference networks.py:393-718): residual tower MuZeroNetwork and TinyNetwork.
+
+class _Block(nn.Module):
+  """Two 3x3 convolutions around a skip connection; with BatchNorm it is the reference's ResidualBlock
+  (networks.py:393-410), without it the TinyBlock (networks.py:557-567): relu(n2(conv2(relu(n1(conv1(x))))) + x)."""
+
+  def __init__(self, channels, norm):
+    super().__init__()
+    self.conv1 = nn.Conv2d(channels, channels, kernel_size=3, stride=1, padding=1, bias=False)
+    if norm:
+      self.bn1 = nn.BatchNorm2d(channels)
+    self.conv2 = nn.Conv2d(channels, channels, kernel_size=3, stride=1, padding=1, bias=False)
+    if norm:
+      self.bn2 = nn.BatchNorm2d(channels)
+    self.norm = norm
+
+  def forward(self, x):
+    y = self.conv1(x)
+    y = torch.relu(self.bn1(y) if self.norm else y)
+    y = self.conv2(y)
+    y = self.bn2(y) if self.norm else y
+    return torch.relu(y + x)
+
+
+def _tower(n, channels, norm=True):
+  return nn.ModuleList([_Block(channels, norm) for _ in range(n)])
+
+
+def _through(blocks, x):
+  for b in blocks:
+    x = b(x)
+  return x
+
+
+class _MuZeroRepresentation(nn.Module):
+  """[B, C, 96, 96] -> [B, 128, 6, 6] (networks.py:413-446): stride-2 conv, 2 blocks @64, stride-2 conv, 3 blocks @128,
+  avg-pool, 3 blocks, avg-pool, 16 blocks."""
+
+  def __init__(self, input_channels):
+    super().__init__()
+    self.conv1 = nn.Conv2d(input_channels, 64, kernel_size=3, stride=2, padding=1)
+    self.resblocks1 = _tower(2, 64)
+    self.conv2 = nn.Conv2d(64, 128, kernel_size=3, stride=2, padding=1)
+    self.resblocks2 = _tower(3, 128)
+    self.avg_pool1 = nn.AvgPool2d(kernel_size=3, stride=2, padding=1)
+    self.resblocks3 = _tower(3, 128)
+    self.avg_pool2 = nn.AvgPool2d(kernel_size=3, stride=2, padding=1)
+    self.resblocks = _tower(16, 128)
+
+  def forward(self, x):
+    x = _through(self.resblocks1, self.conv1(x))
+    x = _through(self.resblocks2, self.conv2(x))
+    x = _through(self.resblocks3, self.avg_pool1(x))
+    return _through(self.resblocks, self.avg_pool2(x))
+
+
+class _MuZeroDynamics(nn.Module):
+  """[B, 128 + 1, 6, 6] -> (next state [B, 128, 6, 6], reward logits) (networks.py:449-471)."""
+
+  def __init__(self, reward_out):
+    super().__init__()
+    self.conv = nn.Conv2d(128 + 1, 128, kernel_size=3, stride=1, padding=1)
+    self.bn = nn.BatchNorm2d(128)
+    self.resblocks = _tower(16, 128)
+    self.fc1 = nn.Linear(6 * 6 * 128, 512)
+    self.fc2 = nn.Linear(512, reward_out)
+
+  def forward(self, x):
+    state = _through(self.resblocks, torch.relu(self.bn(self.conv(x))))
+    return state, self.fc2(torch.relu(self.fc1(state.flatten(1))))
+
+
+class _MuZeroPrediction(nn.Module):
+  """[B, 128, 6, 6] -> (policy logits, value logits) (networks.py:474-495)."""
+
+  def __init__(self, action_space, value_out):
+    super().__init__()
+    self.resblocks = _tower(16, 128)
+    self.fc_value = nn.Linear(6 * 6 * 128, 512)
+    self.fc_value_o = nn.Linear(512, value_out)
+    self.fc_policy = nn.Linear(6 * 6 * 128, 512)
+    self.fc_policy_o = nn.Linear(512, action_space)
+
+  def forward(self, x):
+    y = _through(self.resblocks, x).flatten(1)
+    return self.fc_policy_o(torch.relu(self.fc_policy(y))), self.fc_value_o(torch.relu(self.fc_value(y)))
+
+
+class _ConvNetBase(nn.Module):
+  """What MuZeroNetwork and TinyNetwork share (networks.py:498-555, 657-718): min-max scaling of hidden states over
+  the channel dimension, the action as one extra plane of value action / action_space, eval-mode support -> scalar."""
+
+  def _setup(self, action_space, device, config):
+    self.device = device
+    self.action_space = int(action_space)
+    self.no_support = bool(getattr(config, 'no_support', False))
+    self.no_target_transform = bool(getattr(config, 'no_target_transform', False))
+    vs = tuple(getattr(config, 'value_support', (-15, 15)))
+    rs = tuple(getattr(config, 'reward_support', (-15, 15)))
+    self.value_support_min, self.reward_support_min = vs[0], rs[0]
+    return (1 if self.no_support else vs[1] - vs[0] + 1), (1 if self.no_support else rs[1] - rs[0] + 1)
+
+  @staticmethod
+  def scale_state(state):
+    lo = state.min(dim=1, keepdim=True)[0]
+    hi = state.max(dim=1, keepdim=True)[0]
+    return (state - lo) / (hi - lo)
+
+  def attach_action(self, hidden_state, action):
+    n, _, h, w = hidden_state.shape
+    a = torch.as_tensor(action, device=hidden_state.device).reshape(n, 1, 1, 1).to(torch.float32)
+    plane = a * torch.ones((n, 1, h, w), dtype=torch.float32, device=hidden_state.device) / self.action_space
+    return torch.cat((hidden_state, plane), dim=1)
+
+  def _scalar(self, logits, support_min):
+    if self.training or self.no_support:
+      return logits
+    return support_to_scalar(logits, support_min, self.no_target_transform)
+
+  def initial_inference(self, observation):
+    hidden_state = self.representation(observation)
+    policy_logits, value = self.prediction(hidden_state)
+    return NetworkOutput(value, 0, policy_logits, hidden_state)
+
+  def recurrent_inference(self, hidden_state, action):
+    hidden_state, reward = self.dynamics(hidden_state, action)
+    policy_logits, value = self.prediction(hidden_state)
+    return NetworkOutput(value, reward, policy_logits, hidden_state)
+
+  def load_weights(self, weights):
+    self.load_state_dict(weights)
+
+  def get_weights(self):
+    return {k: v.cpu() for k, v in self.state_dict().items()}
+
+
+class MuZeroNetwork(_ConvNetBase):
+  """networks.py:498-555: 23.4 M parameters, hidden state [B, 128, 6, 6]."""
+
+  def __init__(self, input_channels, action_space, device, config):
+    super().__init__()
+    v_out, r_out = self._setup(action_space, device, config)
+    self.representation_head = _MuZeroRepresentation(int(input_channels))
+    self.prediction_head = _MuZeroPrediction(self.action_space, v_out)
+    self.dynamics_head = _MuZeroDynamics(r_out)
+    self.to(device)
+
+  def representation(self, observation):
+    return self.scale_state(self.representation_head(observation))
+
+  def prediction(self, hidden_state):
+    policy, value = self.prediction_head(hidden_state)
+    return policy, self._scalar(value, self.value_support_min)
+
+  def dynamics(self, hidden_state, action):
+    state, reward = self.dynamics_head(self.attach_action(hidden_state, action))
+    return self.scale_state(state), self._scalar(reward, self.reward_support_min)
+
+
+class _TinyRepresentation(nn.Module):
+  """[B, C, 96, 96] -> [B, 64, 6, 6] (networks.py:570-592)."""
+
+  def __init__(self, input_channels):
+    super().__init__()
+    self.conv1 = nn.Conv2d(input_channels, 32, kernel_size=3, stride=2, padding=1)
+    self.max_pool1 = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+    self.conv2 = nn.Conv2d(32, 64, kernel_size=3, stride=2, padding=1)
+    self.max_pool2 = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+    self.block2 = _Block(64, norm=False)
+    self.conv3 = nn.Conv2d(64, 64, kernel_size=3, stride=1, padding=1)
+
+  def forward(self, x):
+    x = self.max_pool1(torch.relu(self.conv1(x)))
+    x = self.max_pool2(torch.relu(self.conv2(x)))
+    return torch.tanh(self.conv3(self.block2(x)))
+
+
+class _TinyHead(nn.Module):
+  """block -> flatten -> Linear(512) -> ReLU -> Linear (networks.py:595-639); the two Linear layers carry the
+  reference's attribute names."""
+
+  def __init__(self, channels, n_out, fc_names):
+    super().__init__()
+    self.block1 = _Block(channels, norm=False)
+    setattr(self, fc_names[0], nn.Linear(6 * 6 * channels, 512))
+    setattr(self, fc_names[1], nn.Linear(512, n_out))
+    self._fc = fc_names
+
+  def forward(self, x):
+    y = self.block1(x).flatten(1)
+    return getattr(self, self._fc[1])(torch.relu(getattr(self, self._fc[0])(y)))
+
+
+class _TinyHidden(nn.Module):
+  """networks.py:642-654."""
+
+  def __init__(self):
+    super().__init__()
+    self.block1 = _Block(65, norm=False)
+    self.conv1 = nn.Conv2d(65, 64, kernel_size=3, stride=1, padding=1)
+
+  def forward(self, x):
+    return torch.tanh(self.conv1(self.block1(x)))
+
+
+class TinyNetwork(_ConvNetBase):
+  """networks.py:657-718: 4.06 M parameters, hidden state [B, 64, 6, 6]."""
+
+  def __init__(self, input_channels, action_space, device, config):
+    super().__init__()
+    v_out, r_out = self._setup(action_space, device, config)
+    self.representation_head = _TinyRepresentation(int(input_channels))
+    self.value_head = _TinyHead(64, v_out, ('fc_value', 'fc_value_o'))
+    self.reward_head = _TinyHead(64 + 1, r_out, ('fc1', 'fc2'))
+    self.policy_head = _TinyHead(64, self.action_space, ('fc_policy', 'fc_policy_o'))
+    self.transition_head = _TinyHidden()
+    self.to(device)
+
+  def representation(self, observation):
+    return self.scale_state(self.representation_head(observation))
+
+  def prediction(self, hidden_state):
+    return self.policy_head(hidden_state), self._scalar(self.value_head(hidden_state), self.value_support_min)
+
+  def dynamics(self, hidden_state, action):
+    x = self.attach_action(hidden_state, action)
+    reward = self._scalar(self.reward_head(x), self.reward_support_min)
+    return self.scale_state(self.transition_head(x)), reward
+
+
+def get_network(config, device=None):
+  """utils.get_network (utils.py:21-37) without the environment probe: action_space / obs_space come from the config
+  (train.py:66-68 injects them)."""
+  if device is None:
+    device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
+  arch = getattr(config, 'architecture', 'FCNetwork')
+  if arch == 'FCNetwork':
+    import numpy as np
+    return FCNetwork(int(np.prod(config.obs_space)), config.action_space, device, config)
+  if arch in ('MuZeroNetwork', 'TinyNetwork'):
+    channels = int(config.obs_space[0]) if len(tuple(config.obs_space)) == 3 else int(getattr(config, 'stack_obs', 1)) * (
+        2 if getattr(config, 'stack_actions', False) else 1)
+    return (MuZeroNetwork if arch == 'MuZeroNetwork' else TinyNetwork)(channels, config.action_space, device, config)
+  raise NotImplementedError('%s (the reference\'s AttentionNetwork / HopfieldNetwork do not run at HEAD, SURVEY.md s2 row 11)' % arch)

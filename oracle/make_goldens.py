@@ -210,11 +210,32 @@ def choice_uniform_and_action(ref_cfg, root, temperature):
   return int(action), u
 
 
+def margin_mcts(ref, cfg):
+  """The reference's MCTS with select_child wrapped (subclass in the generator, reference file untouched): before
+  delegating, it evaluates the children's scores the way select_child does (mcts.py:104-113) and keeps the smallest gap
+  between the best and the second-best score over all decisions of a search -- how close the move came to a tie that
+  float32 network noise could flip ('each record carries the min top-2 UCB margin')."""
+
+  class MarginMCTS(ref.mcts.MCTS):
+    min_margin = float('inf')
+
+    def select_child(self, node):
+      if len(node.children) > 1:
+        if node.visit_count == 0:
+          scores = sorted((c.prior for c in node.children.values()), reverse=True)
+        else:
+          scores = sorted((self.ucb_score(node, c) for c in node.children.values()), reverse=True)
+        self.min_margin = min(self.min_margin, scores[0] - scores[1])
+      return super().select_child(node)
+
+  return MarginMCTS(cfg)
+
+
 def play_and_record(ref, cfg, env, net, temperature, n_moves, recording=True):
   """The move loop of actors.py:131-173 around imported reference objects; returns per-move
   records plus the history flushes it would have sent to the replay buffer."""
   A, sims = cfg.action_space, cfg.num_simulations
-  mcts = ref.mcts.MCTS(cfg)
+  mcts = margin_mcts(ref, cfg)
   game = cfg.new_game(env)
   moves, flushes = [], []
   while not game.terminal and len(moves) < n_moves:
@@ -238,6 +259,7 @@ def play_and_record(ref, cfg, env, net, temperature, n_moves, recording=True):
     noise[legal] = noise_legal
 
     net.calls = []
+    mcts.min_margin = float('inf')
     with torch.inference_mode():
       paths = mcts.run(root, net)
     error = root.value() - init.value.item()
@@ -272,8 +294,7 @@ def play_and_record(ref, cfg, env, net, temperature, n_moves, recording=True):
     tree = dump_tree(root, paths, A, sims)
     for k, v in tree.items():
       rec['tree_' + k] = v
-    # minimum top-2 margin over all UCB decisions is not recoverable after the fact; the
-    # final-root margin is recorded as a cheap proxy for "is this move near a tie".
+    rec['min_margin'] = np.float64(mcts.min_margin)     # smallest top-2 score gap over all select_child decisions
     moves.append(rec)
 
     game.apply(action)
@@ -459,7 +480,64 @@ def gen_games(ref, outdir, nets):
     print('g3_game_ttt_%d' % gi, 'moves', len(all_moves), 'flushes', len(flush_meta))
 
 
+# ----------------------------------------------------------------------------- G6: conv networks (config 5)
+def perturb_norm_layers(net):
+  """Deterministic, non-trivial BatchNorm statistics / affine parameters (a fresh BatchNorm is the identity up to
+  eps): the same formulas are applied by the tests to the build's network, so nothing but the formulas travels."""
+  i = 0
+  with torch.no_grad():
+    for m in net.modules():
+      if isinstance(m, torch.nn.BatchNorm2d):
+        c = np.arange(m.num_features, dtype=np.float64)
+        m.running_mean.copy_(torch.from_numpy(0.05 * np.sin(c + i)).float())
+        m.running_var.copy_(torch.from_numpy(1.0 + 0.5 * np.cos(0.37 * c + i) ** 2).float())
+        m.weight.copy_(torch.from_numpy(1.0 + 0.1 * np.sin(0.11 * c - i)).float())
+        m.bias.copy_(torch.from_numpy(0.05 * np.cos(0.23 * c + 2 * i)).float())
+        i += 1
+  return net
+
+
+def gen_convnets(ref, outdir):
+  """MuZeroNetwork / TinyNetwork of the unmodified reference (networks.py:498-555, 657-718), default init under
+  torch.manual_seed(seed): the weights themselves (94 MB / 16 MB) do not travel -- the build's definitions construct
+  their modules in the reference's order, so the same seed draws the same weights; the fixture pins that with
+  per-tensor checksums and pins the forward passes with a small batch of inputs and outputs."""
+  for name, cls, C, A, seed in (('g6_net_muzero', 'MuZeroNetwork', 4, 4, 11), ('g6_net_tiny', 'TinyNetwork', 4, 4, 12),
+                                ('g6_net_tiny_a6', 'TinyNetwork', 2, 6, 13)):
+    cfg = make_ref_config(ref, ['--seed', str(seed)], A, (C, 96, 96))
+    torch.manual_seed(seed)
+    net = getattr(ref.networks, cls)(C, A, torch.device('cpu'), cfg).eval()
+    perturb_norm_layers(net)
+    rng = np.random.RandomState(seed)
+    rows = 3
+    obs = (rng.randint(0, 256, size=(rows, C, 96, 96)).astype(np.float32) / np.float32(255.0))
+    acts = np.array([1, A - 1, 0], np.int32)
+    with torch.inference_mode():
+      o = net.initial_inference(torch.from_numpy(obs))
+      r = net.recurrent_inference(o.hidden_state, [int(a) for a in acts])
+      r2 = net.recurrent_inference(r.hidden_state, [int(a) for a in acts[::-1]])
+    sd = net.state_dict()
+    keys = list(sd.keys())
+    out = dict(obs_u8=np.round(obs * 255).astype(np.uint8), actions=acts, seed=np.int32(seed), C=np.int32(C), A=np.int32(A),
+               arch=np.array(cls), keys=np.array(keys),
+               # (numpy's pairwise float64 sums: independent of torch's thread count)
+               key_sums=np.array([sd[k].numpy().astype(np.float64).sum() for k in keys]),
+               key_abs_sums=np.array([np.abs(sd[k].numpy().astype(np.float64)).sum() for k in keys]),
+               init_value=o.value.numpy().reshape(-1), init_logits=o.policy_logits.numpy(),
+               init_hidden=o.hidden_state.numpy(),
+               rec_value=r.value.numpy().reshape(-1), rec_reward=r.reward.numpy().reshape(-1),
+               rec_logits=r.policy_logits.numpy(), rec_hidden=r.hidden_state.numpy(),
+               rec2_value=r2.value.numpy().reshape(-1), rec2_reward=r2.reward.numpy().reshape(-1),
+               rec2_logits=r2.policy_logits.numpy(), rec2_hidden_sum=np.float64(r2.hidden_state.double().sum()))
+    np.savez_compressed(os.path.join(outdir, name), **out)
+    print(name, 'params', sum(p.numel() for p in net.parameters()), 'value', out['init_value'], out['rec_value'])
+
+
 def main():
+  if len(sys.argv) > 1 and sys.argv[1] == 'convnets':
+    torch.set_num_threads(1)
+    gen_convnets(_import_reference(), os.path.abspath(os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden')))
+    return
   outdir = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden')
   outdir = os.path.abspath(outdir)
   os.makedirs(outdir, exist_ok=True)
@@ -474,6 +552,7 @@ def main():
   gen_net(ref, outdir, 'g1_net_lunar_nosupport', ['--no_support'], 8, 4, 3)
   gen_tree_traces(ref, outdir, nets)
   gen_games(ref, outdir, nets)
+  gen_convnets(ref, outdir)
   total = sum(os.path.getsize(os.path.join(outdir, f)) for f in os.listdir(outdir) if f.endswith('.npz'))
   print('total fixture bytes', total)
 

@@ -1,0 +1,89 @@
+"""MuZeroNetwork / TinyNetwork definitions (BASELINE.json configs[4]) against goldens G6, generated from the imported,
+unmodified reference (oracle/make_goldens.py:gen_convnets; reference networks.py:393-718).  The weights themselves do
+not travel (94 MB / 16 MB): the definitions here construct their modules in the reference's order, so the same seed
+draws the same weights -- pinned by per-tensor checksums -- and the forward passes are pinned by inputs / outputs."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+G = os.path.join(os.path.dirname(__file__), 'golden')
+NAMES = ['g6_net_muzero', 'g6_net_tiny', 'g6_net_tiny_a6']
+
+
+def perturb_norm_layers(net):
+  """the generator's formulas for non-trivial BatchNorm statistics (oracle/make_goldens.py:perturb_norm_layers)"""
+  i = 0
+  with torch.no_grad():
+    for m in net.modules():
+      if isinstance(m, torch.nn.BatchNorm2d):
+        c = np.arange(m.num_features, dtype=np.float64)
+        m.running_mean.copy_(torch.from_numpy(0.05 * np.sin(c + i)).float())
+        m.running_var.copy_(torch.from_numpy(1.0 + 0.5 * np.cos(0.37 * c + i) ** 2).float())
+        m.weight.copy_(torch.from_numpy(1.0 + 0.1 * np.sin(0.11 * c - i)).float())
+        m.bias.copy_(torch.from_numpy(0.05 * np.cos(0.23 * c + 2 * i)).float())
+        i += 1
+  return net
+
+
+def build(g, device='cpu'):
+  from model_based_rl_amd import networks
+  torch.manual_seed(int(g['seed']))
+  net = getattr(networks, str(g['arch']))(int(g['C']), int(g['A']), torch.device('cpu'), types.SimpleNamespace())
+  perturb_norm_layers(net.eval())
+  return net.to(device)
+
+
+def forward(net, g, device='cpu'):
+  obs = torch.from_numpy(g['obs_u8'].astype(np.float32) / np.float32(255.0)).to(device)
+  acts = [int(a) for a in g['actions']]
+  with torch.inference_mode():
+    o = net.initial_inference(obs)
+    r = net.recurrent_inference(o.hidden_state, acts)
+    r2 = net.recurrent_inference(r.hidden_state, torch.tensor(acts[::-1], device=device, dtype=torch.int32))   # tensor actions
+  c = lambda t: t.detach().cpu().numpy()
+  return dict(init_value=c(o.value).reshape(-1), init_logits=c(o.policy_logits), init_hidden=c(o.hidden_state),
+              rec_value=c(r.value).reshape(-1), rec_reward=c(r.reward).reshape(-1), rec_logits=c(r.policy_logits),
+              rec_hidden=c(r.hidden_state), rec2_value=c(r2.value).reshape(-1), rec2_reward=c(r2.reward).reshape(-1),
+              rec2_logits=c(r2.policy_logits))
+
+
+@pytest.mark.parametrize('name', NAMES)
+def test_state_dict_keys_and_seeded_init_equal_the_reference(name):
+  g = np.load(os.path.join(G, name + '.npz'))
+  net = build(g)
+  sd = net.state_dict()
+  assert list(sd.keys()) == [str(k) for k in g['keys']]          # checkpoints are interchangeable (networks.py:36-40)
+  sums = np.array([v.numpy().astype(np.float64).sum() for v in sd.values()])
+  abs_sums = np.array([np.abs(v.numpy().astype(np.float64)).sum() for v in sd.values()])
+  assert np.array_equal(sums, g['key_sums']) and np.array_equal(abs_sums, g['key_abs_sums'])
+
+
+@pytest.mark.parametrize('name', NAMES)
+def test_forward_matches_reference_cpu(name):
+  """same weights, same PyTorch CPU kernels: the outputs agree to float32 round-off (measured: identical)"""
+  g = np.load(os.path.join(G, name + '.npz'))
+  got = forward(build(g), g)
+  for k, v in got.items():
+    assert np.abs(v - g[k]).max() <= 1e-6, (k, np.abs(v - g[k]).max())
+  assert np.isfinite(got['init_hidden']).all() and got['init_hidden'].min() == 0.0 and got['init_hidden'].max() == 1.0
+
+
+def test_get_network_factory_and_train_mode_outputs():
+  from model_based_rl_amd import networks
+  from model_based_rl_amd.config import make_config
+  cfg = make_config(['--architecture', 'TinyNetwork', '--environment', 'BreakoutNoFrameskip-v4'])
+  net = networks.get_network(cfg, torch.device('cpu'))
+  assert isinstance(net, networks.TinyNetwork) and cfg.obs_space == (4, 96, 96)
+  x = torch.rand(2, 4, 96, 96)
+  net.train()
+  out = net.initial_inference(x)
+  assert out.value.shape == (2, 31)                 # training mode returns the support logits (networks.py:153)
+  net.eval()
+  assert net.initial_inference(x).value.shape == (2, 1)
+  w = net.get_weights()
+  net.load_weights(w)
+  with pytest.raises(NotImplementedError):
+    networks.get_network(types.SimpleNamespace(architecture='AttentionNetwork', obs_space=(8,), action_space=4))

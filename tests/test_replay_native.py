@@ -83,10 +83,11 @@ def test_ingest_records_flush_rules(T, mhl):
   from model_based_rl_amd.replay_buffer import PrioritizedReplay
   O, A, B, moves = 3, 2, 5, 260
   rng = np.random.RandomState(T)
-  rec = np.zeros((moves, B, O + A + 8), np.float32)
+  rec = np.zeros((moves, B, O + A + 10), np.float32)
   rec[..., :O] = rng.standard_normal((moves, B, O))
-  rec[..., O + A + 1] = rng.standard_normal((moves, B))           # error
-  ints = rec[..., O + A + 3:].view(np.int32)
+  err = rng.standard_normal((moves, B))                           # error: a float64 in two float slots
+  rec[..., O + A + 2:O + A + 4] = err[..., None].view(np.float32)
+  ints = rec[..., O + A + 5:].view(np.int32)
   t0 = rng.randint(0, T, B)
   for b in range(B):
     t = t0[b]
@@ -99,8 +100,7 @@ def test_ingest_records_flush_rules(T, mhl):
   rep.ingest_records(rec[100:], moves - 100, B)
   # expected: the tree receives leaves in (move, env) arrival order of the flushes
   want, games = [], 0
-  per_env = [python_flush_rules(ints[:, b, 1].astype(bool), rec[:, b, O + A + 1].astype(np.float64), mhl, 15)
-             for b in range(B)]
+  per_env = [python_flush_rules(ints[:, b, 1].astype(bool), err[:, b], mhl, 15) for b in range(B)]
   frames = sum(len(p[0]) for p in per_env); games = sum(p[1] for p in per_env)
   assert rep.get_throughput() == {'frames': frames, 'games': games}
   assert rep.size() == min(frames, 4096)
@@ -108,7 +108,15 @@ def test_ingest_records_flush_rules(T, mhl):
   got = np.sort(rep.tree.leaves(min(frames, 4096)))
   exp = np.sort(np.concatenate([np.asarray(p[0]) for p in per_env]))
   if frames <= 4096:
-    assert np.array_equal(got, exp)
+    assert np.array_equal(got, exp)       # bit-identical: priorities come from the records' float64 errors
+  # one replay fed by two actor ranks (env_base): the same leaves as one actor with all the environments
+  rep2 = PrioritizedReplay(make_cfg(obs_space=(O,), action_space=A, max_history_length=mhl, window_size=4096))
+  for lo, hi in ((0, 100), (100, moves)):
+    rep2.ingest_records(np.ascontiguousarray(rec[lo:hi, :2]), hi - lo, 2, env_base=0)
+    rep2.ingest_records(np.ascontiguousarray(rec[lo:hi, 2:]), hi - lo, B - 2, env_base=2)
+  assert rep2.get_throughput() == {'frames': frames, 'games': games}
+  if frames <= 4096:
+    assert np.array_equal(np.sort(rep2.tree.leaves(frames)), exp)
 
 
 @pytest.mark.parametrize('path', FILES, ids=[os.path.basename(f)[:-4] for f in FILES])
