@@ -95,7 +95,11 @@ class Actor(object):
   # actors.py:75-79
   def _set_weights(self, weights):
     if self.torch_net:
-      self.network.load_weights(weights)            # networks.py:36-37
+      if torch.is_tensor(weights):                  # the flat buffer of the weight broadcast (distributed.RankStorage)
+        from .networks import load_flat
+        load_flat(self.network, weights)
+      else:
+        self.network.load_weights(weights)          # networks.py:36-37
     else:
       self.engine.set_weights(weights)
 

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from .actors import _call, set_all_seeds
-from .networks import FCNetwork, support_to_scalar
+from .networks import get_network, support_to_scalar
 
 
 def scalar_transform(x):
@@ -57,7 +57,7 @@ class Learner(object):
     self.storage, self.replay_buffer = storage, replay_buffer
     use_gpu = 'learner' in getattr(config, 'use_gpu_for', []) and torch.cuda.is_available()
     self.device = torch.device('cuda' if use_gpu else 'cpu')
-    self.network = FCNetwork(int(np.prod(config.obs_space)), config.action_space, self.device, config)
+    self.network = get_network(config, self.device)          # utils.get_network (utils.py:21-37)
     self.network.train()
     self.optimizer = make_optimizer(config, self.network.parameters())
     self.training_step = 0

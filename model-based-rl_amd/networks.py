@@ -345,3 +345,31 @@ def get_network(config, device=None):
         2 if getattr(config, 'stack_actions', False) else 1)
     return (MuZeroNetwork if arch == 'MuZeroNetwork' else TinyNetwork)(channels, config.action_space, device, config)
   raise NotImplementedError('%s (the reference\'s AttentionNetwork / HopfieldNetwork do not run at HEAD, SURVEY.md s2 row 11)' % arch)
+
+
+# ---- one flat float32 buffer per network: what the weight broadcast ships (distributed.RankStorage)
+def _float_items(sd):
+  return [(k, v) for k, v in sd.items() if torch.is_floating_point(v)]     # (BatchNorm's int64 batch counter stays local)
+
+
+def flat_size(network):
+  return int(sum(v.numel() for _, v in _float_items(network.state_dict())))
+
+
+def flatten_state(weights):
+  """state_dict (or network) -> one float32 vector, state_dict order: parameters and float buffers (BatchNorm running
+  statistics travel with the weights, as they do in the reference's pickled state_dict, networks.py:39-40)."""
+  sd = weights.state_dict() if isinstance(weights, nn.Module) else weights
+  return torch.cat([v.detach().reshape(-1).to(torch.float32).cpu() for _, v in _float_items(sd)]).contiguous()
+
+
+def load_flat(network, flat):
+  """inverse of flatten_state, device to device when `flat` lives where the network does (no host hop)"""
+  off = 0
+  with torch.no_grad():
+    for _, v in _float_items(network.state_dict()):
+      n = v.numel()
+      v.copy_(flat[off:off + n].view_as(v))
+      off += n
+  if off != flat.numel():
+    raise ValueError('flat weight buffer has %d floats, the network takes %d' % (flat.numel(), off))

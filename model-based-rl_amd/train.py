@@ -5,6 +5,7 @@ stands in for Learner.send_weights at start-up (learners.py:85-86,116).
   python -m model_based_rl_amd.train --environment LunarLander-v2 --num_envs 4096 --num_simulations 30 --seed 0 \
       --max_moves 64
 """
+import os
 import sys
 import time
 import types
@@ -22,8 +23,9 @@ from .shared_storage import SharedStorage
 
 
 def publish_initial_weights(config, storage):
+  from .networks import get_network
   torch.manual_seed(config.seed or 0)
-  net = FCNetwork(int(np.prod(config.obs_space)), config.action_space, torch.device('cpu'), config)
+  net = get_network(config, torch.device('cpu'))
   storage.store_weights.remote(net.get_weights(), 0).result()
 
 
@@ -48,17 +50,121 @@ def launch(config, max_moves, selfplay_only=False, learner_steps=None):
   return thr
 
 
+def launch_ranks(config, max_moves, selfplay_only=False, learner_steps=None):
+  """One process per GPU (this function runs in every rank; see distributed.py for what is exchanged where):
+  rank 0 = learner + storage + the one replay + actor 0, rank r = actor r.  train.py:62-78 on ranks instead of Ray."""
+  import json
+  import threading
+  from . import distributed as D
+  from .networks import flat_size, flatten_state, get_network
+  import torch.distributed as dist
+  rank, world, device, backend = D.init_process_group()
+  config.num_actors = world
+  config.actors_gpu_device_ids = None                 # every rank's actor runs on the rank's own current device
+  B = int(config.num_envs)
+  torch_net = config.architecture != 'FCNetwork'
+  O, A = int(np.prod(config.obs_space)), int(config.action_space)
+  rec, chunk = O + A + 10, (1 if torch_net else 8)
+  torch.manual_seed(config.seed or 0)
+  probe = get_network(config, torch.device('cpu'))
+  n_flat = flat_size(probe) if torch_net else sum(v.numel() for v in probe.state_dict().values())
+  run_id = 'mz_%s_%s' % (os.environ.get('MASTER_PORT', '0'), os.environ.get('TORCHELASTIC_RUN_ID', 'run'))
+  ray.init()
+  rings, storage, replay, learner, stop = {}, None, None, None, threading.Event()
+  if rank == 0:
+    storage = ray.remote(SharedStorage).remote(config)
+    replay = ray.remote(PrioritizedReplay).remote(config)
+    rings = {r: D.ShmRing('%s_%d' % (run_id, r), chunk, B, rec, slots=4, create=True) for r in range(1, world)}
+  dist.barrier()
+  from .actors import _call
+  if rank == 0:
+    actor_replay = replay
+    server = threading.Thread(target=D.serve_rings, args=(rings, lambda name, *a: _call(replay, name, *a), B, stop), daemon=True)
+    server.start()
+    workers = []
+    if selfplay_only:
+      storage.store_weights.remote(probe.get_weights(), 0).result()
+    else:
+      learner = ray.remote(Learner).remote(config, storage, replay)
+      workers.append(learner.launch.remote(learner_steps))
+  else:
+    ring = D.ShmRing('%s_%d' % (run_id, rank))
+    actor_replay = D.RingReplay(ring)
+  del probe
+  from .engine import flatten_weights
+  rstorage = D.RankStorage(rank, world, device, n_flat, storage=storage, storage_call=_call, backend=backend,
+                           flatten=flatten_state if torch_net else flatten_weights)
+  actor = Actor(rank, config, rstorage, actor_replay)
+  t0 = time.time()
+  actor.launch(max_moves)
+  if rank > 0:
+    ring.close_producer()
+  # what every rank's actor ended up with: the same broadcast buffer, the same training step
+  mine = torch.tensor([float(rstorage.flat.double().sum()), float(actor.training_step), float(actor.games_played)],
+                      dtype=torch.float64, device=rstorage.cdev)
+  every = [torch.zeros_like(mine) for _ in range(world)]
+  dist.all_gather(every, mine)
+  summary = None
+  if rank == 0:
+    server.join(timeout=120)
+    ray.get(workers)
+    dt = time.time() - t0
+    thr = ray.get(replay.get_throughput.remote())
+    stats = ray.get(storage.get_stats.remote())
+    summary = {'ranks': world, 'frames': thr['frames'], 'games': thr['games'], 'seconds': dt,
+               'env_steps_per_s': thr['frames'] / dt, 'training_step': stats['training_step'],
+               'actor_games': {int(k): int(v) for k, v in stats['actor_games'].items()},
+               'weight_broadcasts': rstorage.broadcasts, 'actor_training_step': actor.training_step,
+               'rank_weight_sums': [float(x[0]) for x in every], 'rank_training_steps': [int(x[1]) for x in every],
+               'rank_games': [int(x[2]) for x in every],
+               'replay_size': ray.get(replay.size.remote())}
+    print('MZ_TRAIN_SUMMARY ' + json.dumps(summary), flush=True)
+  dist.barrier()
+  stop.set()
+  for ring_ in list(rings.values()) + ([ring] if rank > 0 else []):
+    ring_.release()
+  if hasattr(actor, 'selfplay'):
+    actor.selfplay.close()
+  dist.destroy_process_group()
+  ray.shutdown()
+  return summary
+
+
+def _spawn_ranks(n, argv):
+  """`train --ranks N` without a launcher: start `python -m torch.distributed.run` as a child (before anything in
+  this process touches a GPU) and hand its exit code on."""
+  import socket
+  import subprocess
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+  env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''), MASTER_ADDR='127.0.0.1')
+  env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr',
+         '127.0.0.1', '--master-port', str(port), '-m', 'model_based_rl_amd.train'] + list(argv)
+  return subprocess.call(cmd, env=env)
+
+
 def main(argv=None):
+  argv = list(sys.argv[1:] if argv is None else argv)
   p = build_parser()
   p.add_argument('--max_moves', type=int, default=64)
   p.add_argument('--selfplay_only', action='store_true')
   p.add_argument('--learner_steps', type=int, default=None)
+  p.add_argument('--ranks', type=int, default=0,
+                 help='one process per GPU over torch.distributed: rank 0 = learner + storage + replay + actor 0')
   args = vars(p.parse_args(argv))
   max_moves, selfplay_only, learner_steps = args.pop('max_moves'), args.pop('selfplay_only'), args.pop('learner_steps')
+  ranks = args.pop('ranks')
+  if ranks and 'RANK' not in os.environ:
+    raise SystemExit(_spawn_ranks(ranks, argv))
+  if max_moves is not None and max_moves < 0:
+    max_moves = None              # run until the learner has reached --training_steps (actors.py:93)
   cfg = Config(args)
   cfg.action_space, cfg.obs_space = ENV_SHAPES[cfg.environment]
   if cfg.seed is None:
     cfg.seed = 0
+  if 'RANK' in os.environ and int(os.environ.get('WORLD_SIZE', '1')) >= 1 and ranks:
+    return launch_ranks(cfg, max_moves, selfplay_only, learner_steps)
   return launch(cfg, max_moves, selfplay_only, learner_steps)
 
 

@@ -40,3 +40,116 @@ def test_weight_broadcast_and_reductions_world2(tmp_path):
                        capture_output=True, text=True, timeout=300)
   assert out.returncode == 0, out.stderr[-2000:]
   assert out.stdout.count('ok') == 2
+
+
+RANK_WORKER = r'''
+import os, sys, threading, types
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+from model_based_rl_amd import distributed as D
+from model_based_rl_amd.engine import flatten_weights
+from model_based_rl_amd.networks import FCNetwork
+from model_based_rl_amd.replay_buffer import PrioritizedReplay
+from model_based_rl_amd.shared_storage import SharedStorage
+
+os.environ['MZ_DIST_BACKEND'] = 'gloo'
+rank, world, device, backend = D.init_process_group()
+assert device is None and backend == 'gloo'          # no GPU in this container: host logic only
+O, A, B, T, chunk, nchunks = 3, 2, 5, 7, 8, 4
+rec = O + A + 10
+
+
+def records(r):
+  """deterministic experience records of rank r: [moves][B][rec], episodes of T steps, staggered"""
+  rng = np.random.RandomState(100 + r)
+  moves = chunk * nchunks
+  x = np.zeros((moves, B, rec), np.float32)
+  x[..., :O] = rng.standard_normal((moves, B, O))
+  x[..., O + A + 2:O + A + 4] = rng.standard_normal((moves, B))[..., None].view(np.float32)     # error (float64)
+  ints = x[..., O + A + 5:].view(np.int32)
+  for b in range(B):
+    t = (r * B + b) %% T
+    for m in range(moves):
+      ints[m, b, 1] = int(t + 1 >= T); ints[m, b, 2] = t; ints[m, b, 3] = r * B + b
+      t = 0 if t + 1 >= T else t + 1
+  return x
+
+
+cfg = types.SimpleNamespace(batch_size=4, epsilon=0.01, alpha=1.0, beta=1.0, obs_space=(O,), action_space=A,
+                            window_size=4096, window_step=None, num_unroll_steps=5, td_steps=10, max_history_length=16,
+                            discount=0.997, seed=0, num_actors=world)
+torch.manual_seed(0)
+net = FCNetwork(8, 4, torch.device('cpu'), types.SimpleNamespace())
+w0 = net.get_weights()
+w1 = {k: v + 1.0 for k, v in w0.items()}
+call = lambda obj, name, *a: getattr(obj, name)(*a)
+storage = replay = None
+rings = {}
+if rank == 0:
+  storage, replay = SharedStorage(cfg), PrioritizedReplay(cfg)
+  storage.store_weights(w0, 0)
+  rings = {r: D.ShmRing('mzt_%%s_%%d' %% (os.environ['MASTER_PORT'], r), chunk, B, rec, slots=2, create=True) for r in range(1, world)}
+dist.barrier()
+stop = threading.Event()
+lock = threading.Lock()
+if rank == 0:
+  def replay_call(name, *a):
+    with lock:
+      return getattr(replay, name)(*a)
+  server = threading.Thread(target=D.serve_rings, args=(rings, replay_call, B, stop))
+  server.start()
+  sink = types.SimpleNamespace(ingest_records=lambda buf, n, B_, base=0: replay_call('ingest_records', buf, n, B_, base))
+else:
+  ring = D.ShmRing('mzt_%%s_%%d' %% (os.environ['MASTER_PORT'], rank))
+  sink = D.RingReplay(ring)
+rs = D.RankStorage(rank, world, 'cpu', flatten_weights(w0).numel(), storage=storage, storage_call=call, backend='gloo')
+assert rs.is_ready()
+mine = records(rank)
+games = 0
+for c in range(nchunks):
+  flat, step = rs.get_weights(games, rank)                # collective: every rank, same point of the loop
+  want_w, want_step = (w0, 0) if c < 2 else (w1, 7)
+  assert torch.equal(flat, flatten_weights(want_w)) and step == want_step, (rank, c, step)
+  sink.ingest_records(mine[c * chunk:(c + 1) * chunk], chunk, B, rank * B)
+  games += int(mine[c * chunk:(c + 1) * chunk, :, O + A + 6].view(np.int32).sum())
+  if rank == 0 and c == 1:
+    storage.store_weights(w1, 7)                          # the learner publishes (learners.py:85-86)
+rs.get_weights(games, rank)
+if rank > 0:
+  ring.close_producer()
+if rank == 0:
+  server.join(timeout=60)
+  assert not server.is_alive()
+  # the one replay now holds what a single process ingesting every rank's records holds
+  ref = PrioritizedReplay(cfg)
+  for r in range(world):
+    x = records(r)
+    for c in range(nchunks):
+      ref.ingest_records(np.ascontiguousarray(x[c * chunk:(c + 1) * chunk]), chunk, B, r * B)
+  assert replay.get_throughput() == ref.get_throughput() and replay.get_throughput()['frames'] > 0
+  n = replay.size()
+  assert n == ref.size() and np.array_equal(np.sort(replay.tree.leaves(n)), np.sort(ref.tree.leaves(n)))
+  tot = sum(int(records(r)[..., O + A + 6].view(np.int32).sum()) for r in range(world))
+  assert replay.get_throughput()['games'] == tot
+  assert storage.get_stats('actor_games') == {r: int(records(r)[..., O + A + 6].view(np.int32).sum()) for r in range(world)}
+dist.barrier()
+stop.set()
+for x in list(rings.values()) + ([ring] if rank > 0 else []):
+  x.release()
+dist.destroy_process_group()
+print('rank', rank, 'ok')
+''' % ROOT
+
+
+def test_rank_storage_and_experience_rings_world2(tmp_path):
+  """The multi-rank product wiring on CPU (gloo, world 2; distributed.py): the collective weight pull -- flat buffer +
+  training step from rank 0's SharedStorage, per-actor game counts back -- and the merge of every rank's experience
+  chunks into the ONE replay through shared-memory rings (train.py:62-78, actors.py:81-85,169 of the reference)."""
+  script = tmp_path / 'r.py'
+  script.write_text(RANK_WORKER)
+  env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+  out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                        '--master-addr', '127.0.0.1', '--master-port', '29541', str(script)], env=env,
+                       capture_output=True, text=True, timeout=300)
+  assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+  assert out.stdout.count('ok') == 2

@@ -1,0 +1,85 @@
+"""The multi-rank paths on ONE GPU (two ranks sharing it, collectives over gloo): what the driver's 8-GPU run executes
+over RCCL, proven before an 8-GPU node shows up.  The launchers are child processes."""
+import json
+import os
+import subprocess
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def launcher(n, port):
+  return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr',
+          '127.0.0.1', '--master-port', str(port)]
+
+
+def test_bench_two_ranks_shard_the_environments(tmp_path):
+  """bench.py --gpus 2 as the driver launches it: both ranks step their own B environments, the line reports 2 ranks and
+  2 x B x steps env-steps, the weight pull (broadcast + repack) fires inside the timed region, and rank 1's experience
+  records equal those a single engine produces for env ids [B, 2B) -- the sharding changes nothing but who computes."""
+  B, steps = 64, 16
+  dump = str(tmp_path / 'rec')
+  env = dict(os.environ, MZ_BENCH_BACKEND='gloo', MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+  out = subprocess.run(launcher(2, 29551) + [os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', str(steps), '--warmup',
+                       '4', '--no-cpu-baseline', '--envs', str(B), '--min-seconds', '0.2', '--dump-records', dump],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+  assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+  line = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+  assert line['n_gpus'] == 2 and line['steps'] == steps and line['config']['envs_per_gpu'] == B
+  executed = line['env_steps_executed_per_s'] * line['timed_seconds']
+  assert abs(executed - 2 * B * line['timed_steps']) < 1e-6 * executed
+  assert line['timed_steps'] == steps * line['repeats'] and line['timed_seconds'] >= 0.15
+  assert 'pulls inside the timed region' in line['config']['weight_sync'] and not line['config']['weight_sync'].startswith('0 ')
+  assert 0.5 * 2 * B * line['timed_steps'] < line['value'] * line['timed_seconds'] < 1.5 * 2 * B * line['timed_steps']
+  # rank 1's records vs one engine that owns env ids [B, 2B)
+  from model_based_rl_amd.engine import Engine, flatten_weights, records_view
+  from model_based_rl_amd.networks import FCNetwork
+  rec1 = np.load(dump + '.rank1.npy')
+  rec0 = np.load(dump + '.rank0.npy')
+  moves = rec1.shape[0]
+  assert moves >= 16 and rec1.shape[1:] == (B, 8 + 4 + 10)
+  torch.manual_seed(0)
+  flat = flatten_weights(FCNetwork(8, 4, torch.device('cpu'), types.SimpleNamespace()).state_dict())
+  eng = Engine(B, 8, 4, 30, seed=1234, env_id_offset=B)
+  eng.set_weights(flat)
+  eng.selfplay_reset(256, 1.0, stagger=True)
+  eng.selfplay_steps(moves)
+  buf, n = eng.selfplay_drain()
+  torch.cuda.synchronize()
+  one = buf[:n].numpy().copy()
+  eng.close()
+  assert np.array_equal(one.view(np.int32), rec1.view(np.int32))
+  assert np.array_equal(records_view(rec0, 8, 4)['env_id'][0], np.arange(B))
+  assert np.array_equal(records_view(rec1, 8, 4)['env_id'][0], np.arange(B, 2 * B))
+
+
+def test_train_two_ranks_learner_broadcast_and_one_replay():
+  """train --ranks 2: rank 0 = learner + storage + the one replay + actor 0, rank 1 = actor 1.  The actors run until the
+  learner has reached --training_steps: its published weights travel storage -> collective broadcast -> every rank's
+  engine, the training step reaches every actor, the experience of BOTH ranks lands in the one replay the learner
+  samples, and the per-actor game counts come back to the storage (reference train.py:62-78, learners.py:132-133,
+  actors.py:81-85,157-169)."""
+  env = dict(os.environ, MZ_DIST_BACKEND='gloo', PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''),
+             HSA_ENABLE_IPC_MODE_LEGACY='0')
+  out = subprocess.run([sys.executable, '-m', 'model_based_rl_amd.train', '--ranks', '2', '--environment', 'LunarLander-v2',
+                        '--num_envs', '64', '--num_simulations', '8', '--episode_length', '6', '--max_moves', '-1',
+                        '--window_size', '16384', '--stored_before_train', '1024', '--batch_size', '32',
+                        '--training_steps', '6', '--send_weights_frequency', '2', '--weight_sync_frequency', '8',
+                        '--seed', '3', '--use_gpu_for', 'actors', 'learner'],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+  assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+  s = json.loads([l for l in out.stdout.splitlines() if l.startswith('MZ_TRAIN_SUMMARY ')][-1][len('MZ_TRAIN_SUMMARY '):])
+  assert s['ranks'] == 2 and s['training_step'] == 6
+  assert s['rank_training_steps'] == [6, 6]                              # the learner's step reached every actor
+  assert s['rank_weight_sums'][0] == s['rank_weight_sums'][1]            # ... with the same weights
+  assert s['weight_broadcasts'] >= 3
+  assert all(g > 0 for g in s['rank_games']) and s['actor_games'] == {'0': s['rank_games'][0], '1': s['rank_games'][1]} \
+      or s['actor_games'] == {0: s['rank_games'][0], 1: s['rank_games'][1]}
+  assert s['games'] == sum(s['rank_games'])                              # both ranks' games were ingested by the one replay
+  assert s['frames'] >= 1024 and s['replay_size'] > 0
