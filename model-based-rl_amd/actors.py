@@ -18,8 +18,11 @@ from copy import deepcopy
 import numpy as np
 import torch
 
-from .engine import Engine, flatten_weights
+import os
+
+from .engine import Engine, flatten_weights, records_view
 from .envs import get_environment
+from .logger import Logger
 from .networks import get_network
 
 
@@ -42,12 +45,13 @@ def _call(obj, name, *args, **kwargs):
   return fn(*args, **kwargs)
 
 
-class Actor(object):
+class Actor(Logger):
 
   def __init__(self, actor_key, config, storage, replay_buffer, state=None):
     set_all_seeds(config.seed + actor_key if config.seed is not None else None)
     self.actor_key = actor_key
     self.config = deepcopy(config)
+    self.run_tag, self.group_tag = getattr(config, 'run_tag', None) or 'run', getattr(config, 'group_tag', None)
     self.storage, self.replay_buffer = storage, replay_buffer
     if not torch.cuda.is_available():
       raise RuntimeError('GPU was requested but torch.cuda.is_available() is False.')   # actors.py:41
@@ -78,8 +82,11 @@ class Actor(object):
       self.environments = [get_environment(config) for _ in range(self.num_envs)]
       for env in self.environments:
         env.seed(config.seed)
-    if config.fixed_temperatures:
+    if config.fixed_temperatures:                      # actors.py:49-53
       self.temperature = config.fixed_temperatures[actor_key]
+      self.worker_id = 'actors/temp={}'.format(round(self.temperature, 1))
+    else:
+      self.worker_id = 'actor-{}'.format(actor_key)
     if getattr(config, 'norm_obs', False):
       self.obs_min = np.array(config.obs_range[::2], dtype=np.float32)
       self.obs_range = np.array(config.obs_range[1::2], dtype=np.float32) - self.obs_min
@@ -89,8 +96,10 @@ class Actor(object):
     self.training_step = 0
     self.games_played = 0
     self.move_counter = 0
+    self._game_stats = None
     if state is not None:
       self.load_state(state)
+    Logger.__init__(self)
 
   # actors.py:75-79
   def _set_weights(self, weights):
@@ -104,6 +113,7 @@ class Actor(object):
       self.engine.set_weights(weights)
 
   def load_state(self, state):
+    self.run_tag = os.path.join(str(self.run_tag), 'resumed', '{}'.format(state['training_step']))
     self._set_weights(state['weights'])
     self.training_step = state['training_step']
     self.games_played = state['actor_games'][self.actor_key]
@@ -114,6 +124,27 @@ class Actor(object):
     if training_step != self.training_step or force:
       self._set_weights(weights)
       self.training_step = training_step
+
+  def _log_games(self, rv):
+    """games/{return,length,avg_value,max_value} (actors.py:99-117) from a chunk of experience records: one running
+    game per environment; the games that ended in a move are logged as one averaged point at i = games_played."""
+    B = rv['done'].shape[1]
+    if self._game_stats is None:
+      self._game_stats = {'ret': np.zeros(B), 'len': np.zeros(B), 'sumv': np.zeros(B), 'maxv': np.full(B, -np.inf)}
+    st = self._game_stats
+    for m in range(rv['done'].shape[0]):
+      st['ret'] += rv['reward'][m]; st['len'] += 1; st['sumv'] += rv['root_value'][m]
+      st['maxv'] = np.maximum(st['maxv'], rv['root_value'][m])
+      d = rv['done'][m] != 0
+      k = int(d.sum())
+      if k:
+        self.games_played += k
+        if self.games_played // max(1, self.config.actor_log_frequency) != (self.games_played - k) // max(1, self.config.actor_log_frequency):
+          self.log_scalar(tag='games/return', value=st['ret'][d].mean(), i=self.games_played)
+          self.log_scalar(tag='games/length', value=st['len'][d].mean(), i=self.games_played)
+          self.log_scalar(tag='games/avg_value', value=(st['sumv'][d] / st['len'][d]).mean(), i=self.games_played)
+          self.log_scalar(tag='games/max_value', value=st['maxv'][d].mean(), i=self.games_played)
+        st['ret'][d] = 0; st['len'][d] = 0; st['sumv'][d] = 0; st['maxv'][d] = -np.inf
 
   def _temperature(self):
     if self.config.fixed_temperatures:
@@ -188,7 +219,13 @@ class Actor(object):
       while self.training_step < cfg.training_steps and (max_moves is None or self.move_counter < max_moves):
         games = [cfg.new_game(env) for env in self.environments]
         self.play_game(games)
-        self.games_played += len(games)
+        for g in games:                                  # actors.py:99-117
+          self.games_played += 1
+          if self.games_played % max(1, cfg.actor_log_frequency) == 0:
+            self.log_scalar(tag='games/return', value=g.sum_rewards, i=self.games_played)
+            self.log_scalar(tag='games/length', value=g.step, i=self.games_played)
+            self.log_scalar(tag='games/avg_value', value=g.sum_values / max(1, g.history_idx), i=self.games_played)
+            self.log_scalar(tag='games/max_value', value=g.max_value, i=self.games_played)
       return
     if self.torch_net:
       return self._run_selfplay_torch(max_moves)
@@ -212,8 +249,8 @@ class Actor(object):
       buf, n, ev = p
       ev.synchronize()
       # games this actor finished (actors.py:94-99 counts one per play_game return; reported to the storage with the
-      # next weight pull, actors.py:82, shared_storage.py:12-14)
-      self.games_played += int(buf[:n].view(torch.int32)[..., done_col].sum())
+      # next weight pull, actors.py:82, shared_storage.py:12-14) and their logged statistics
+      self._log_games(records_view(buf[:n].numpy(), eng.O, eng.A))
       _call(self.replay_buffer, 'ingest_records', buf, n, eng.B, self.env_base)
 
     while self.training_step < cfg.training_steps and (max_moves is None or self.move_counter < max_moves):
@@ -256,7 +293,7 @@ class Actor(object):
     def hand_over(p):
       buf, ev = p
       ev.synchronize()
-      self.games_played += int(buf.view(torch.int32)[..., done_col].sum())
+      self._log_games(records_view(buf.numpy(), sp.O, sp.A))
       _call(self.replay_buffer, 'ingest_records', buf, 1, sp.B, self.env_base)
 
     while self.training_step < cfg.training_steps and (max_moves is None or self.move_counter < max_moves):

@@ -99,6 +99,14 @@ def build_parser():
   a('--weight_decay', type=float, default=1e-4)
   a('--momentum', type=float, default=0.9)
   a('--clip_grad', type=int, default=0)
+  a('--scalar_loss', type=str, default='MSE', choices=['MSE', 'Huber'])
+  a('--lr_scheduler', type=str, default=None, choices=['ExponentialLR', 'MuZeroLR', 'WarmUpLR'])
+  a('--lr_decay_rate', type=float, default=0.1)
+  a('--lr_decay_steps', type=int, default=100000)
+  a('--learner_gpu_device_id', type=int, default=None)
+  a('--learner_log_frequency', type=int, default=100)
+  a('--frames_before_fps_log', type=int, default=10000)
+  a('--runs_dir', type=str, default='runs', help='root of the run directories (the reference writes ./runs)')
   a('--save_state_frequency', type=int, default=1000)
   a('--use_gpu_for', nargs='+', type=str, default=['actors'], choices=['actors', 'learner'])
   a('--actors_gpu_device_ids', nargs='+', type=int, default=None)

@@ -12,6 +12,7 @@ import numpy as np
 import torch
 
 from .actors import _call, set_all_seeds
+from .logger import Logger
 from .networks import get_network, support_to_scalar
 
 
@@ -49,38 +50,103 @@ def make_optimizer(config, params):
   raise NotImplementedError(name)
 
 
-class Learner(object):
+class MuZeroLR(object):
+  """lr_init * decay_rate ** (step / decay_steps) (utils.py:85-99)"""
+
+  def __init__(self, optimizer, config):
+    self.optimizer, self.lr_init = optimizer, config.lr_init
+    self.rate, self.steps, self.lr_step, self.lr = config.lr_decay_rate, config.lr_decay_steps, 0, config.lr_init
+
+  def step(self):
+    self.lr_step += 1
+    self.lr = self.lr_init * self.rate ** (self.lr_step / self.steps)
+    for g in self.optimizer.param_groups:
+      g['lr'] = self.lr
+
+
+class WarmUpLR(object):
+  """linear ramp to lr_init over 5000 steps, then constant (utils.py:102-118)"""
+
+  def __init__(self, optimizer, config, warm_up_steps=5000):
+    self.optimizer, self.max_lr, self.n, self.lr_step = optimizer, config.lr_init, warm_up_steps, 0
+    self._set(1 / self.n * self.max_lr)
+
+  def _set(self, lr):
+    self.lr = lr
+    for g in self.optimizer.param_groups:
+      g['lr'] = lr
+
+  def step(self):
+    self.lr_step += 1
+    if self.lr_step <= self.n:
+      self._set(self.lr_step / self.n * self.max_lr)
+
+
+def make_lr_scheduler(config, optimizer):
+  """utils.get_lr_scheduler (utils.py:121-132)"""
+  name = getattr(config, 'lr_scheduler', None)
+  if name is None:
+    return None
+  if name == 'ExponentialLR':
+    sched = torch.optim.lr_scheduler.ExponentialLR(optimizer, config.lr_decay_rate)
+    sched.lr = config.lr_init
+    return sched
+  if name == 'MuZeroLR':
+    return MuZeroLR(optimizer, config)
+  if name == 'WarmUpLR':
+    return WarmUpLR(optimizer, config)
+  raise NotImplementedError(name)
+
+
+class Learner(Logger):
 
   def __init__(self, config, storage, replay_buffer, state=None):
     set_all_seeds(config.seed)
     self.config = deepcopy(config)
+    self.run_tag, self.group_tag = getattr(config, 'run_tag', None) or 'run', getattr(config, 'group_tag', None)
+    self.worker_id = 'learner'
     self.storage, self.replay_buffer = storage, replay_buffer
-    use_gpu = 'learner' in getattr(config, 'use_gpu_for', []) and torch.cuda.is_available()
-    self.device = torch.device('cuda' if use_gpu else 'cpu')
+    if 'learner' in getattr(config, 'use_gpu_for', []):          # learners.py:27-37
+      if not torch.cuda.is_available():
+        raise RuntimeError('GPU was requested but torch.cuda.is_available() is False.')
+      dev_id = getattr(config, 'learner_gpu_device_id', None)
+      self.device = torch.device('cuda', dev_id if dev_id is not None else torch.cuda.current_device())
+    else:
+      self.device = torch.device('cpu')
     self.network = get_network(config, self.device)          # utils.get_network (utils.py:21-37)
     self.network.train()
     self.optimizer = make_optimizer(config, self.network.parameters())
+    self.lr_scheduler = make_lr_scheduler(config, self.optimizer)
+    if getattr(config, 'scalar_loss', 'MSE') not in ('MSE', 'Huber'):
+      raise NotImplementedError(config.scalar_loss)
     self.training_step = 0
     self.losses_to_log = {'reward': 0., 'value': 0., 'policy': 0.}
-    self.throughput = {'total_frames': 0, 'total_games': 0}
+    self.throughput = {'total_frames': 0, 'total_games': 0, 'training_step': 0, 'time': {'ups': 0, 'fps': 0}}
+    self.last_throughput = {}
     if getattr(config, 'norm_obs', False):
       self.obs_min = np.array(config.obs_range[::2], dtype=np.float32)
       self.obs_range = np.array(config.obs_range[1::2], dtype=np.float32) - self.obs_min
-    self.saves_dir = os.path.join('runs', str(config.environment), str(config.group_tag), str(config.run_tag), 'saves')
     if state is not None:
       self.load_state(state)
+    Logger.__init__(self)
+    self.saves_dir = self.dirs['saves']
 
   # learners.py:62-70
   def load_state(self, state):
+    self.run_tag = os.path.join(str(self.run_tag), 'resumed', '{}'.format(state['training_step']))
     self.network.load_state_dict(state['weights'])
     self.optimizer.load_state_dict(state['optimizer'])
     _call(self.replay_buffer, 'add_initial_throughput', state['total_frames'], state['total_games'])
     self.throughput['total_frames'] = state['total_frames']
+    self.throughput['training_step'] = state['training_step']
     self.training_step = state['training_step']
 
   # learners.py:72-83 (same dictionary keys)
   def save_state(self, path=None):
-    state = {'dirs': {'saves': self.saves_dir}, 'config': self.config, 'weights': self.network.get_weights(),
+    thr = _call(self.replay_buffer, 'get_throughput')        # (the reference refreshes these in log_throughput)
+    self.throughput['total_games'] = thr['games']
+    self.throughput['total_frames'] = max(self.throughput['total_frames'], thr['frames'])
+    state = {'dirs': self.dirs, 'config': self.config, 'weights': self.network.get_weights(),
              'optimizer': self.optimizer.state_dict(), 'training_step': self.training_step,
              'total_games': self.throughput['total_games'], 'total_frames': self.throughput['total_frames'],
              'actor_games': _call(self.storage, 'get_stats', 'actor_games')}
@@ -115,7 +181,12 @@ class Learner(object):
       if not no_support:
         t_val = scalar_to_support(t_val, cfg.value_support_min, cfg.value_support_max)
         t_rew = scalar_to_support(t_rew, cfg.reward_support_min, cfg.reward_support_max)
-    scalar_loss = soft_cross_entropy if not no_support else (lambda a, b: (a - b) ** 2)
+    if not no_support:
+      scalar_loss = soft_cross_entropy
+    elif getattr(cfg, 'scalar_loss', 'MSE') == 'Huber':        # utils.py:62-70
+      scalar_loss = torch.nn.SmoothL1Loss(reduction='none')
+    else:
+      scalar_loss = torch.nn.MSELoss(reduction='none')
     reward_loss = 0
     value_loss = scalar_loss(value.squeeze(), t_val[:, 0])
     policy_loss = soft_cross_entropy(policy_logits.squeeze(), t_pol[:, 0])
@@ -133,17 +204,42 @@ class Learner(object):
     if getattr(cfg, 'clip_grad', 0):
       torch.nn.utils.clip_grad_norm_(self.network.parameters(), cfg.clip_grad)
     self.optimizer.step()
+    if self.lr_scheduler is not None:             # learners.py:225-226
+      self.lr_scheduler.step()
     self.losses_to_log['reward'] += reward_loss.item()
     self.losses_to_log['value'] += value_loss.item()
     self.losses_to_log['policy'] += policy_loss.item()
 
-  # learners.py:115-136 (logging left out)
+  # learners.py:88-113: the reference's own throughput scalars -- frames_per_second is its env-steps/sec metric
+  def log_throughput(self, force=False):
+    data = _call(self.replay_buffer, 'get_throughput')
+    self.throughput['total_games'] = data['games']
+    self.log_scalar(tag='games/finished', value=data['games'], i=self.training_step)
+    new_frames = data['frames'] - self.throughput['total_frames']
+    if new_frames > getattr(self.config, 'frames_before_fps_log', 10000) or (force and new_frames > 0):
+      now = time.time()
+      new_updates = self.training_step - self.throughput['training_step']
+      ups = new_updates / max(1e-9, now - self.throughput['time']['ups'])
+      fps = new_frames / max(1e-9, now - self.throughput['time']['fps'])
+      replay_ratio = ups / fps
+      self.throughput['total_frames'] = data['frames']
+      self.throughput['training_step'] = self.training_step
+      self.throughput['time']['ups'] = self.throughput['time']['fps'] = now
+      self.last_throughput = {'frames_per_second': fps, 'updates_per_second': ups, 'replay_ratio': replay_ratio,
+                              'sample_ratio': self.config.batch_size * replay_ratio, 'total_frames': data['frames']}
+      for k, v in self.last_throughput.items():
+        self.log_scalar(tag='throughput/' + k, value=v, i=self.training_step)
+
+  # learners.py:115-153
   def learn(self, max_steps=None):
     cfg = self.config
     self.send_weights()
+    self.throughput['time']['fps'] = time.time()
     while _call(self.replay_buffer, 'size') < cfg.stored_before_train:
       time.sleep(0.05)
+    self.throughput['time']['ups'] = time.time()
     last = cfg.training_steps if max_steps is None else min(cfg.training_steps, self.training_step + max_steps)
+    log_every = max(1, getattr(cfg, 'learner_log_frequency', 100))
     while self.training_step < last:
       self.update_weights(_call(self.replay_buffer, 'sample_batch'))
       self.training_step += 1
@@ -151,7 +247,18 @@ class Learner(object):
         self.send_weights()
       if self.training_step % getattr(cfg, 'save_state_frequency', 1000) == 0:
         self.save_state()
+      if self.training_step % log_every == 0:
+        for k in ('reward', 'value', 'policy'):
+          self.log_scalar(tag='loss/' + k, value=self.losses_to_log[k] / log_every, i=self.training_step)
+          self.losses_to_log[k] = 0
+        self.log_throughput()
+        if self.lr_scheduler is not None:
+          self.log_scalar(tag='loss/learning_rate', value=self.lr_scheduler.lr, i=self.training_step)
+    self.log_throughput(force=True)
     self.send_weights()
+
+  def get_last_throughput(self):
+    return dict(self.last_throughput)
 
   def launch(self, max_steps=None):
     print('Learner is online on {}.'.format(self.device))

@@ -46,6 +46,12 @@ def launch(config, max_moves, selfplay_only=False, learner_steps=None):
   thr = ray.get(replay.get_throughput.remote())
   print('frames accepted by replay: %d, games: %d, %.1f s -> %.0f env-steps/s' % (thr['frames'], thr['games'], dt,
                                                                                  thr['frames'] / dt))
+  if not selfplay_only:            # the reference's own throughput scalars (learners.py:88-113)
+    lt = ray.get(learner.get_last_throughput.remote())
+    if lt:
+      print('learner: %.0f frames/s, %.2f updates/s, replay_ratio %.3g, sample_ratio %.3g' %
+            (lt['frames_per_second'], lt['updates_per_second'], lt['replay_ratio'], lt['sample_ratio']))
+    thr = dict(thr, learner=lt)
   ray.shutdown()
   return thr
 
@@ -138,6 +144,7 @@ def _spawn_ranks(n, argv):
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
   s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
   env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''), MASTER_ADDR='127.0.0.1')
+  env.setdefault('MZ_RUN_TAG', time.strftime('%Y-%m-%d_%H-%M-%S'))      # one run directory for all ranks
   env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
   cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr',
          '127.0.0.1', '--master-port', str(port), '-m', 'model_based_rl_amd.train'] + list(argv)
@@ -163,6 +170,8 @@ def main(argv=None):
   cfg.action_space, cfg.obs_space = ENV_SHAPES[cfg.environment]
   if cfg.seed is None:
     cfg.seed = 0
+  if cfg.run_tag is None:           # train.py:83-90: a date-stamped run directory (the launcher's start time under --ranks)
+    cfg.run_tag = os.environ.get('MZ_RUN_TAG') or time.strftime('%Y-%m-%d_%H-%M-%S')
   if 'RANK' in os.environ and int(os.environ.get('WORLD_SIZE', '1')) >= 1 and ranks:
     return launch_ranks(cfg, max_moves, selfplay_only, learner_steps)
   return launch(cfg, max_moves, selfplay_only, learner_steps)

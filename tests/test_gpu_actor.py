@@ -43,33 +43,46 @@ def test_actor_reproduces_reference_games(gi, temp):
   moves = g['action'].shape[0]
   m = 0
   same_moves = 0
-  diverged = False
+  diverged_at = None
   for game_no in range(3):
     game = cfg.new_game(actor.environments[0])
     actor.play_game(game)
     h = game.history
     n = len(h.actions)
-    ga = g['action'][m:m + n]
-    if not diverged and np.array_equal(np.asarray(h.actions), ga):
-      assert np.array_equal(np.asarray(h.child_visits), g['child_visits'][m:m + n])
-      assert np.abs(np.asarray(h.root_values) - g['final_root_value'][m:m + n]).max() <= 5e-4
-      assert np.abs(np.asarray(h.errors) - g['error'][m:m + n]).max() <= 5e-4
-      same_moves += n
-    else:
-      diverged = True      # a flipped near-tie changes the game (and the numpy stream) from there on
+    if diverged_at is None:
+      for i in range(n):      # move by move: visit distribution and action are the reference's, bit for bit
+        if h.actions[i] != int(g['action'][m + i]) or not np.array_equal(np.asarray(h.child_visits[i]), g['child_visits'][m + i]):
+          diverged_at = m + i
+          break
+        same_moves += 1
+      if diverged_at is None:
+        # root values / errors: one step of the float32 inverse-transform staircase (tests/test_oracle_net.py)
+        assert np.abs(np.asarray(h.root_values) - g['final_root_value'][m:m + n]).max() <= 5e-4
+        assert np.abs(np.asarray(h.errors) - g['error'][m:m + n]).max() <= 5e-4
     m += n
     if m >= moves:
       break
-  # the engine's network agrees with PyTorch-CPU to ~1e-6, so whole games are reproduced; allow one late flip
-  assert same_moves >= 0.6 * moves, (same_moves, moves)
-  if not diverged:
+  print('g3_game_ttt_%d: %d of %d moves identical%s' % (gi, same_moves, moves, '' if diverged_at is None else
+        ', first difference at move %d (min top-2 margin there %.3g)' % (diverged_at, g['min_margin'][diverged_at])))
+  # The engine's network agrees with PyTorch-CPU to ~1e-6: a game can only leave the reference's at a decision whose two
+  # best scores were closer than that noise can bridge (a flipped near-tie changes the game and the numpy stream from
+  # there on).  The goldens carry the smallest top-2 score gap of every move (MCTS.select_child, mcts.py:104-113).
+  if diverged_at is not None:
+    assert g['min_margin'][diverged_at] < 1e-5, (diverged_at, g['min_margin'][diverged_at])      # (measured: no divergence at all)
+  safe_prefix = int(np.argmax(g['min_margin'] < 1e-4)) if np.any(g['min_margin'] < 1e-4) else moves
+  assert same_moves >= safe_prefix, (same_moves, safe_prefix)          # 100 % identity up to the first near-tie
+  if diverged_at is None:
+    assert same_moves == moves
     assert len(replay.calls) == int(g['n_flushes'])
     for k, (hist, ignore, terminal) in enumerate(replay.calls):
       meta = g['flush_meta'][k]
       assert (-1 if ignore is None else ignore) == int(meta[3]) and int(terminal) == int(meta[4])
       assert np.array_equal(np.asarray(hist.actions), g['flush%d_actions' % k])
     assert replay.inner.size() == int(g['flush_meta'][-1][5])
-    assert abs(replay.inner.tree.total_priority - float(g['replay_total'])) <= 1e-2
+    # total priority = sum(|error| + eps): every error may sit one staircase step (1.5e-4 (1 + |v|), twice: the root
+    # value and the initial value both come out of the float32 inverse transform) away from the reference's
+    bound = float(np.sum(2 * 1.5e-4 * (1 + np.abs(g['final_root_value']))))
+    assert abs(replay.inner.tree.total_priority - float(g['replay_total'])) <= bound, bound
   actor.engine.close()
 
 
@@ -420,6 +433,48 @@ def test_small_ring_drain_on_copy_stream_is_ordered():
     assert np.array_equal(x, y)
 
 
+def test_actor_load_state_metrics_and_run_dirs(tmp_path):
+  """Actor.load_state (actors.py:75-79): weights, training step and this actor's game count come back from a learner
+  checkpoint dictionary; the actor's scalars (actors.py:105-117) land in <run>/<worker>/metrics.csv and the game count is
+  reported to the storage with the weight pulls (actors.py:82, shared_storage.py:12-14)."""
+  import torch
+  from oracle import oracle as orc
+  from model_based_rl_amd.actors import Actor
+  from model_based_rl_amd.config import make_config
+  from model_based_rl_amd.logger import read_metrics
+  from model_based_rl_amd.replay_buffer import PrioritizedReplay
+  from model_based_rl_amd.shared_storage import SharedStorage
+  g = np.load(os.path.join(G, 'g1_net_lunar.npz'))
+  w = orc.load_weights(g)
+  cfg = make_config(['--environment', 'LunarLander-v2', '--num_envs', '32', '--num_simulations', '6', '--episode_length',
+                     '4', '--seed', '1', '--window_size', '4096', '--weight_sync_frequency', '8', '--runs_dir',
+                     str(tmp_path / 'runs'), '--run_tag', 'r', '--num_actors', '2'])
+  storage, replay = SharedStorage(cfg), PrioritizedReplay(cfg)
+  storage.store_weights({k: torch.from_numpy(v) for k, v in w.items()}, 3)
+  actor = Actor(1, cfg, storage, replay)
+  actor.launch(max_moves=16)
+  assert actor.training_step == 3 and actor.games_played == 32 * 4 == storage.get_stats('actor_games')[1]
+  base = tmp_path / 'runs' / 'LunarLander-v2' / 'r'
+  m = read_metrics(str(base / 'actor-1' / 'metrics.csv'))
+  assert set(m) == {'games/return', 'games/length', 'games/avg_value', 'games/max_value'}
+  # (staggered starts: the first game of an environment is partial, every later one has episode_length moves)
+  assert m['games/length'][-1][1] == 4.0 and all(v <= 4.0 for _, v in m['games/length'])
+  assert m['games/return'][-1][0] == actor.games_played
+  assert os.path.isfile(base / 'config' / 'config.json')
+  # resume: a checkpoint dictionary as Learner.save_state writes it
+  w2 = {k: torch.from_numpy(v * np.float32(0.5)) for k, v in w.items()}
+  state = {'weights': w2, 'training_step': 41, 'actor_games': {0: 7, 1: 19}}
+  resumed = Actor(1, cfg, storage, replay, state=state)
+  assert resumed.training_step == 41 and resumed.games_played == 19
+  assert resumed.dirs['base'] == str(base / 'resumed' / '41')
+  obs = np.random.RandomState(0).standard_normal((32, 8)).astype(np.float32)
+  resumed.engine.initial_inference(obs)
+  v, lg, h = [x.cpu().numpy() for x in resumed.engine.root_outputs()]
+  ho, vo, lgo = orc.FCNet({k: t.numpy() for k, t in w2.items()}, 8, 4).initial(obs)
+  assert np.abs(h - ho).max() < 1e-5 and np.abs(lg - lgo).max() < 1e-5
+  actor.engine.close(); resumed.engine.close()
+
+
 def test_train_driver_selfplay_only():
   from model_based_rl_amd import train
   thr = train.main(['--environment', 'LunarLander-v2', '--num_envs', '64', '--num_simulations', '8', '--seed', '3',
@@ -436,3 +491,6 @@ def test_train_driver_with_learner():
                     '--batch_size', '32', '--learner_steps', '5', '--send_weights_frequency', '2', '--use_gpu_for',
                     'actors', 'learner'])
   assert thr['frames'] >= 64 * 36
+  lt = thr['learner']                 # the reference's own throughput scalars (learners.py:88-113)
+  assert lt['frames_per_second'] > 0 and lt['updates_per_second'] > 0
+  assert abs(lt['replay_ratio'] - lt['updates_per_second'] / lt['frames_per_second']) < 1e-9

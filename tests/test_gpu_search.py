@@ -123,7 +123,7 @@ def test_full_game_goldens_end_to_end():
   Dirichlet draws / uniforms must reproduce the reference's visit distributions and actions."""
   from oracle import oracle as orc
   from model_based_rl_amd.engine import Engine
-  tot = same = 0
+  tot = same = safe = 0
   for gi in range(4):
     g = np.load(os.path.join(G, 'g3_game_ttt_%d.npz' % gi))
     w = orc.load_weights(g)
@@ -138,12 +138,17 @@ def test_full_game_goldens_end_to_end():
     u = np.where(g['uniform'] < 0, 0.0, g['uniform'])
     out = {k: v.cpu().numpy() for k, v in eng.finalize(g['temperature'], u).items()}
     eq = np.all(out['child_visits'] == g['child_visits'], axis=1)
-    tot += M; same += eq.sum()
+    # margin guard: wherever no decision of the reference's search came closer than 1e-4 to a tie, the
+    # visit distribution must be the reference's exactly; the moves below that margin are reported
+    wide = g['min_margin'] > 1e-4
+    assert np.all(eq[wide]), (gi, np.flatnonzero(wide & ~eq), g['min_margin'][wide & ~eq])
+    tot += M; same += eq.sum(); safe += wide.sum()
     sampled = (g['temperature'] != 0) & eq
     assert np.array_equal(out['action'][sampled], g['action'][sampled])
     assert np.abs(out['root_value'] - g['final_root_value'])[eq].max() <= 5e-4
     eng.close()
-  assert same / tot >= 0.97, (same, tot)
+  print('full-game goldens: %d of %d moves identical (%d with margin > 1e-4, all identical)' % (same, tot, safe))
+  assert same >= tot - 1, (same, tot)          # measured: 104 of 104; one near-tie flip is the slack
 
 
 def _run_variant(env_extra, tag):

@@ -3,7 +3,9 @@
 Tolerances (stated here, used by the GPU parity tests too):
   hidden state, policy logits : |d| <= 1e-5
   value / reward scalars       : with --no_target_transform (the support expectation itself): |d| <= 1e-5
-                                 on every row.  With the transform: |d| <= 1e-5 on >= 90 % of rows and
+                                 on every row.  With the transform: |d| <= 1e-5 on >= 97 % of rows (measured:
+                                 99.3 % of 4096 rows, scripts/value_err_stats.py; on the 64-row fixtures the
+                                 slack is three rows) and
                                  every row within ONE step of the reference's own float32 staircase:
                                  Config.inverse_transform (config.py:27-33) computes
                                  sqrt(1+0.004*(|x|+1.001))-1 in float32, a cancellation that quantises
@@ -30,7 +32,8 @@ def scalar_close(got, want, transformed=True):
     return
   step = 1.5e-4 * (1 + np.abs(want))
   assert np.all(d <= step), (d.max(), 'beyond one float32 staircase step')
-  assert np.mean(d <= TOL) >= 0.90, np.mean(d <= TOL)
+  off = int(np.sum(d > TOL))
+  assert off <= max(3, int(0.03 * d.size)), (off, d.size, 'rows beyond 1e-5')
 
 
 @pytest.mark.parametrize('name', ['g1_net_ttt', 'g1_net_lunar', 'g1_net_pong', 'g1_net_lunar_notransform',
