@@ -370,34 +370,41 @@ static int launch_root(mz_engine *e, const float *obs, bool selfplay, hipStream_
   return e->jtp == 1 ? launch_root_j<1>(e, obs, selfplay, s) : launch_root_j<2>(e, obs, selfplay, s);
 }
 
-template <int KS1, int JTP, int G, int LT>
-static int launch_fused_lt(mz_engine *e, int num_simulations, int sims_done, hipStream_t s) {
+template <int KS1, int JTP, int G, int LT, bool SP>
+static int launch_fused_sp(mz_engine *e, int num_simulations, int sims_done, hipStream_t s) {
   const size_t dyn = mz_fused_dyn_lds(e->sims, e->NN, LT);
   if (e->prof_buf) {
     if (!e->lds_attr_set_prof) {
-      HIPCHECK(hipFuncSetAttribute((const void *)k_search_fused<KS1, JTP, G, LT, true>,
+      HIPCHECK(hipFuncSetAttribute((const void *)k_search_fused<KS1, JTP, G, LT, true, SP>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)sizeof(float) * mz_fused_lds_floats(LT)));
       e->lds_attr_set_prof = true;
     }
-    hipLaunchKernelGGL((k_search_fused<KS1, JTP, G, LT, true>), dim3(e->Bp / MZ_ROWS), dim3(256), dyn, s, e->nv,
+    hipLaunchKernelGGL((k_search_fused<KS1, JTP, G, LT, true, SP>), dim3(e->Bp / MZ_ROWS), dim3(256), dyn, s, e->nv,
                        e->tv, e->wstream, num_simulations, sims_done, e->prof_buf, e->sp, 0, (uint64_t)e->cfg.seed);
   } else {
     if (!e->lds_attr_set) {
-      HIPCHECK(hipFuncSetAttribute((const void *)k_search_fused<KS1, JTP, G, LT, false>,
+      HIPCHECK(hipFuncSetAttribute((const void *)k_search_fused<KS1, JTP, G, LT, false, SP>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)sizeof(float) * mz_fused_lds_floats(LT)));
       e->lds_attr_set = true;
     }
     if (e->ev_start)      // timestamps of the dispatch itself (what rocprofv3's kernel trace reports), no launch gap inside
-      hipExtLaunchKernelGGL((k_search_fused<KS1, JTP, G, LT, false>), dim3(e->Bp / MZ_ROWS), dim3(256), dyn, s,
+      hipExtLaunchKernelGGL((k_search_fused<KS1, JTP, G, LT, false, SP>), dim3(e->Bp / MZ_ROWS), dim3(256), dyn, s,
                             e->ev_start, e->ev_stop, 0, e->nv, e->tv, e->wstream, num_simulations, sims_done,
                             (unsigned long long *)nullptr, e->sp, e->fuse_record ? 1 : 0, (uint64_t)e->cfg.seed);
     else
-    hipLaunchKernelGGL((k_search_fused<KS1, JTP, G, LT, false>), dim3(e->Bp / MZ_ROWS), dim3(256), dyn, s, e->nv,
+    hipLaunchKernelGGL((k_search_fused<KS1, JTP, G, LT, false, SP>), dim3(e->Bp / MZ_ROWS), dim3(256), dyn, s, e->nv,
                        e->tv, e->wstream, num_simulations, sims_done, (unsigned long long *)nullptr, e->sp,
                        e->fuse_record ? 1 : 0, (uint64_t)e->cfg.seed);
   }
   HIPCHECK(hipGetLastError());
   return 0;
+}
+
+// single-player games (every reference environment but TicTacToe) run the instantiation without to_play handling
+template <int KS1, int JTP, int G, int LT>
+static int launch_fused_lt(mz_engine *e, int num_simulations, int sims_done, hipStream_t s) {
+  return e->cfg.two_players ? launch_fused_sp<KS1, JTP, G, LT, false>(e, num_simulations, sims_done, s)
+                            : launch_fused_sp<KS1, JTP, G, LT, true>(e, num_simulations, sims_done, s);
 }
 
 // trees in LDS when 16 of them fit beside the kernel's static LDS (160 KiB per CU); if not, at least the fields the
@@ -418,6 +425,11 @@ static int fused_ks1(int A) { return A <= 5 ? 14 : (A <= 13 ? 16 : (A <= 21 ? 18
 
 static int launch_fused(mz_engine *e, int num_simulations, int sims_done, hipStream_t s) {
   const int A = e->A;
+#ifdef MZ_DEV_ONLY      // kernel development: only the two bench shapes are instantiated (a quarter of the build time)
+  if (A <= 4) return launch_fused_t<14, 1, 4>(e, num_simulations, sims_done, s);
+  if (A >= 6 && A <= 8) return launch_fused_t<16, 1, 8>(e, num_simulations, sims_done, s);
+  return fail("MZ_DEV_ONLY build: action_space %d not instantiated", A);
+#else
   if (A <= 4) return launch_fused_t<14, 1, 4>(e, num_simulations, sims_done, s);
   if (A <= 5) return launch_fused_t<14, 1, 8>(e, num_simulations, sims_done, s);
   if (A <= 8) return launch_fused_t<16, 1, 8>(e, num_simulations, sims_done, s);
@@ -425,6 +437,7 @@ static int launch_fused(mz_engine *e, int num_simulations, int sims_done, hipStr
   if (A <= 16) return launch_fused_t<18, 1, 16>(e, num_simulations, sims_done, s);
   if (A <= 21) return launch_fused_t<18, 2, 32>(e, num_simulations, sims_done, s);
   return launch_fused_t<21, 2, 32>(e, num_simulations, sims_done, s);
+#endif
 }
 
 static int launch_root_priors(mz_engine *e, const int8_t *to_play, const uint8_t *legal, const double *priors,

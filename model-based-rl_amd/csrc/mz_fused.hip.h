@@ -457,7 +457,7 @@ __device__ __forceinline__ float mz_support_to_scalar_q(const f32x4 &raw, int sm
 }
 
 #define MZ_FUSED_MAXPL 64   // search-path slots per tree kept in LDS: num_simulations + 2 <= 64
-#define MZ_FUSED_LDS_BASE (16 * MZ_HS + 4 * 6 * 256 + 16 + 16 + 16 * 32 + 96 + 64 + 64 + 64 + 2 * 16 * MZ_XE + 16 * MZ_FUSED_MAXPL)
+#define MZ_FUSED_LDS_BASE (16 * MZ_HS + 4 * 6 * 256 + 16 + 16 + 16 * 32 + 96 + 64 + 64 + 64 + 2 * 16 * MZ_XE + 16 * MZ_FUSED_MAXPL + 2 * MZ_FUSED_MAXPL)
 // + the tree step's own staging [16][96] doubles, except beside large trees (LT = 2), where it shares the partials' space
 __host__ __device__ constexpr int mz_fused_lds_floats(int lt) { return MZ_FUSED_LDS_BASE + (lt == 2 ? 0 : 16 * 96 * 2); }
 
@@ -529,7 +529,7 @@ __device__ __forceinline__ void mz_finalize_record(const TreeView &t, const Tree
   }
 }
 
-template <int KS1, int JTP, int G, int LT, bool PROF>
+template <int KS1, int JTP, int G, int LT, bool PROF, bool SP>
 __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, const f32x4 *wstream, int nsims,
                                                           int slot0, unsigned long long *prof, SelfplayState sp,
                                                           int record, uint64_t seed) {
@@ -564,9 +564,10 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
   float *xEd = s_lnb + 64;                // [16][MZ_XE] dynamics extension: one-hot(action), then 1 (bias column)
   float *xEp = xEd + 16 * MZ_XE;          // [16][MZ_XE] prediction extension: 1 (bias column), then 0
   int *s_path = (int *)(xEp + 16 * MZ_XE); // [16][MZ_FUSED_MAXPL] pending search path of every tree
+  double *s_rcp = (double *)(s_path + 16 * MZ_FUSED_MAXPL);      // [MZ_FUSED_MAXPL] 1 / n (mz_tree_backup_select_f)
   // [16][96] staging of the tree step: its own (the tree step of one wave overlaps other waves' epilogue), except
   // beside large trees, where it shares the partials' space and the tree step starts behind a barrier
-  double *s_stage = (LT == 2) ? (double *)red : (double *)(s_path + 16 * MZ_FUSED_MAXPL);
+  double *s_stage = (LT == 2) ? (double *)red : (double *)(s_rcp + MZ_FUSED_MAXPL);
 
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
   const int g4 = lane >> 4, m16 = lane & 15;
@@ -579,6 +580,7 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
   if (tid < 96) s_b2[tid] = (tid < 32 && tid >= n.Sr) ? MZ_PAD_BIN : n.b2[tid];
   if (tid < 32 + 16 * JTP) s_b4[tid] = (tid < 32 && tid >= n.Sv) ? MZ_PAD_BIN : n.b4[tid];
   if (tid < 64) { s_lnw[tid] = n.lnw[tid]; s_lnb[tid] = n.lnb[tid]; }
+  if (tid < MZ_FUSED_MAXPL) s_rcp[tid] = 1.0 / (double)(tid > 0 ? tid : 1);
   for (int i = tid; i < 16 * MZ_XE; i += 256) xEp[i] = (i % MZ_XE == 0) ? 1.f : 0.f;
   for (int i = tid; i < (t.sims + 2) * (t.sims + 2); i += 256) s_pbc[(i / (t.sims + 2)) * PBS + i % (t.sims + 2)] = t.pbctab[i];
 
@@ -937,12 +939,12 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
       STAMP(9)
       auto stampf = [&](int k) __attribute__((always_inline)) { STAMP(10 + k) };
       if (full || b0 + mt < t.B) {
-        mz_tree_expand_f<TL, G, LT>(t, tm[0], tl, slot0 + sim + 1, s_rew[mt], pr, s_path + mt * MZ_FUSED_MAXPL,
-                                 s_stage + mt * 96, tr[0]);
+        mz_tree_expand_f<TL, G, LT, SP>(t, tm[0], tl, slot0 + sim + 1, s_rew[mt], pr, s_path + mt * MZ_FUSED_MAXPL,
+                                        s_stage + mt * 96, tr[0]);
         stampf(0);
-        mz_tree_backup_select_f<TL, G, LT>(t, tm[0], tl, v, s_rew[mt], s_path + mt * MZ_FUSED_MAXPL, s_stage + mt * 96,
-                                           s_pbc, tr[0], sim + 1 < nsims, my_slot[0], my_act[0],
-                                           MzHiddenPrefetch{t.hpool, hoff[0], hv[0]}, stampf);
+        mz_tree_backup_select_f<TL, G, LT, SP>(t, tm[0], tl, v, s_rew[mt], s_path + mt * MZ_FUSED_MAXPL,
+                                               s_stage + mt * 96, s_pbc, s_rcp, tr[0], sim + 1 < nsims, my_slot[0],
+                                               my_act[0], MzHiddenPrefetch{t.hpool, hoff[0], hv[0]}, stampf);
       }
     } else {
       mz_bar();
@@ -954,9 +956,9 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
         const int b = b0 + mt;
         if (b < t.B) {
           auto stampf = [&](int k) __attribute__((always_inline)) { STAMP(10 + k) };
-          mz_tree_step_fused<TL, G, LT>(t, tm[i], tl, slot0 + sim + 1, s_val[mt], s_rew[mt], s_lg + mt * 32,
-                                     s_path + mt * MZ_FUSED_MAXPL, s_stage + mt * 96, s_pbc, tr[i],
-                                     sim + 1 < nsims, my_slot[i], my_act[i], t.hpool, hoff[i], hv[i], stampf);
+          mz_tree_step_fused<TL, G, LT, SP>(t, tm[i], tl, slot0 + sim + 1, s_val[mt], s_rew[mt], s_lg + mt * 32,
+                                            s_path + mt * MZ_FUSED_MAXPL, s_stage + mt * 96, s_pbc, s_rcp, tr[i],
+                                            sim + 1 < nsims, my_slot[i], my_act[i], t.hpool, hoff[i], hv[i], stampf);
         }
       }
     }

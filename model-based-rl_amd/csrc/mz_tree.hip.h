@@ -281,7 +281,9 @@ struct MzHiddenPrefetch {
 // ---- Node.expand (mcts.py:47-55) for the pending leaf: priors of the new children, leaf bookkeeping.
 // p = math.exp(logit of action `lane`) (0 for lane >= A), computed by the caller (so that it can be scheduled
 // beside other work)
-template <int TL, int G, int LT>
+// SP: single-player game known at compile time (every to_play is +1: no sign flips, no to_play loads or stores);
+// SP = false reads t.two_players at run time (both kinds of game).
+template <int TL, int G, int LT, bool SP = false>
 __device__ __forceinline__ void mz_tree_expand_f(const TreeView &t, const TreeMem<LT> &tm, int lane, int e_new,
                                                  float reward, double p, const int *s_path,
                                                  double *s_stage, const TreeRegs &tr) {
@@ -297,40 +299,48 @@ __device__ __forceinline__ void mz_tree_expand_f(const TreeView &t, const TreeMe
     if constexpr (LT != 1) { tm.N[ch] = 0; tm.W[ch] = 0.0; tm.R[ch] = 0.f; tm.E[ch] = -1; tm.TP[ch] = 1; }
     tm.P[ch] = p / sum;
   }
-  if (lane == 0) { tm.E[leafnode] = e_new; tm.TP[leafnode] = (int8_t)tr.tp; tm.R[leafnode] = reward; }
+  if (lane == 0) {
+    tm.E[leafnode] = e_new; tm.R[leafnode] = reward;
+    if constexpr (!SP) tm.TP[leafnode] = (int8_t)tr.tp;        // (single player: it was created with to_play 1 and stays so)
+  }
 }
 
-template <int TL, int G, int LT, class LEVELF, class STAMPF>
+template <int TL, int G, int LT, bool SP, class LEVELF, class STAMPF>
 __device__ __forceinline__ void mz_tree_backup_select_f(const TreeView &t, const TreeMem<LT> &tm, int lane,
                                                         float value, float reward, int *s_path, double *s_stage,
-                                                        const double *pbctab, TreeRegs &tr, bool do_select,
-                                                        int &slot_out, int &act_out, const LEVELF &levelf,
-                                                        STAMPF stampf);
+                                                        const double *pbctab, const double *rcptab, TreeRegs &tr,
+                                                        bool do_select, int &slot_out, int &act_out,
+                                                        const LEVELF &levelf, STAMPF stampf);
 
-template <int TL, int G, int LT, class STAMPF = MzNoStamp>
+template <int TL, int G, int LT, bool SP = false, class STAMPF = MzNoStamp>
 __device__ __forceinline__ void mz_tree_step_fused(const TreeView &t, const TreeMem<LT> &tm, int lane, int e_new,
                                                    float value, float reward, const float *logits, int *s_path,
-                                                   double *s_stage, const double *pbctab, TreeRegs &tr,
-                                                   bool do_select, int &slot_out, int &act_out,
+                                                   double *s_stage, const double *pbctab, const double *rcptab,
+                                                   TreeRegs &tr, bool do_select, int &slot_out, int &act_out,
                                                    const float *hpool, unsigned hoff, f32x4 &hv,
                                                    STAMPF stampf = STAMPF()) {
-  mz_tree_expand_f<TL, G, LT>(t, tm, lane, e_new, reward, (lane < t.A) ? exp((double)logits[lane]) : 0.0, s_path, s_stage, tr);
+  mz_tree_expand_f<TL, G, LT, SP>(t, tm, lane, e_new, reward, (lane < t.A) ? exp((double)logits[lane]) : 0.0, s_path, s_stage, tr);
   stampf(0);
-  mz_tree_backup_select_f<TL, G, LT>(t, tm, lane, value, reward, s_path, s_stage, pbctab, tr, do_select, slot_out,
-                                     act_out, MzHiddenPrefetch{hpool, hoff, hv}, stampf);
+  mz_tree_backup_select_f<TL, G, LT, SP>(t, tm, lane, value, reward, s_path, s_stage, pbctab, rcptab, tr, do_select,
+                                         slot_out, act_out, MzHiddenPrefetch{hpool, hoff, hv}, stampf);
 }
 
-// MCTS.backpropagate for the pending leaf, then (do_select) the next descent
-template <int TL, int G, int LT, class LEVELF, class STAMPF>
+// MCTS.backpropagate for the pending leaf, then (do_select) the next descent.
+// rcptab[n] = 1.0 / n (IEEE double, n = 1 .. num_simulations + 1): node.value() = value_sum / visit_count
+// (mcts.py:42-45) is taken as q0 = w * y, r = fma(-n, q0, w), q = fma(r, y, q0) with y = RN(1 / n) -- the correction
+// step of a correctly rounded division (Markstein): bit-identical to w / n for every finite w
+// (scripts/divcheck.c: 0 differences in 5e8 quotients), three dependent operations instead of the eleven of the
+// division's expansion.
+template <int TL, int G, int LT, bool SP, class LEVELF, class STAMPF>
 __device__ __forceinline__ void mz_tree_backup_select_f(const TreeView &t, const TreeMem<LT> &tm, int lane,
                                                         float value, float reward, int *s_path, double *s_stage,
-                                                        const double *pbctab, TreeRegs &tr, bool do_select,
-                                                        int &slot_out, int &act_out, const LEVELF &levelf,
-                                                        STAMPF stampf) {
+                                                        const double *pbctab, const double *rcptab, TreeRegs &tr,
+                                                        bool do_select, int &slot_out, int &act_out,
+                                                        const LEVELF &levelf, STAMPF stampf) {
   const int A = t.A;
   const int len = tr.len, tp = tr.tp;
   const double g = t.discount;
-  const bool two = t.two_players != 0;
+  const bool two = SP ? false : (t.two_players != 0);
 
   // ---- MCTS.backpropagate (mcts.py:126-143), TL path nodes per round
   double v_cur = (double)value;
@@ -349,7 +359,8 @@ __device__ __forceinline__ void mz_tree_backup_select_f(const TreeView &t, const
     const double Wn = tm.W[node];
     const int Nn = tm.N[node];
     const double r_node = (j == 0) ? (double)reward : (double)tm.R[node];
-    const int ntp = (j == 0) ? tp : (int)tm.TP[node];
+    int ntp = tp;
+    if constexpr (!SP) ntp = (j == 0) ? tp : (int)tm.TP[node];
     const double r_signed = (two && ntp == tp) ? -r_node : r_node;
     const int cnt = (len - base) < TL ? (len - base) : TL;
     double my_v = 0.0;
@@ -373,7 +384,9 @@ __device__ __forceinline__ void mz_tree_backup_select_f(const TreeView &t, const
     }
     const double w = Wn + ((ntp == tp) ? my_v : -my_v);
     const int n = Nn + 1;
-    const double q = w / (double)n;
+    const double yn = rcptab[n], dn = (double)n;
+    const double q0 = w * yn;
+    const double q = __builtin_fma(__builtin_fma(-dn, q0, w), yn, q0);     // = w / n, see above
     const double new_q = two ? r_node - g * q : r_node + g * q;     // = reward + discount * (two ? -Q : Q)
     if (act) {
       tm.W[node] = w;

@@ -1,18 +1,39 @@
-import sys, types, numpy as np, torch
-sys.path.insert(0,'.')
+"""In-kernel phase stamps of the fused search kernel (mz_search_phase_profile: a diagnostic build of k_search_fused with
+s_memtime stamps between its phases; never used for timing claims -- the stamps pin the schedule, the sum runs ~1 %
+above the production build).  Prints cycles per simulation per wave and writes profiles/phase_cycles_<tag>.json.
+
+  python scripts/phase_profile.py <obs> <actions> <sims> [tag]
+"""
+import json, os, sys, types
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 from model_based_rl_amd.engine import Engine, flatten_weights
 from model_based_rl_amd.networks import FCNetwork
 torch.manual_seed(0)
-O,A,SIMS=(int(sys.argv[1]),int(sys.argv[2]),int(sys.argv[3])) if len(sys.argv)>3 else (8,4,30)
-net=FCNetwork(O,A,torch.device('cpu'),types.SimpleNamespace()).eval()
-eng=Engine(4096,O,A,SIMS,seed=1)
+O, A, SIMS = (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (8, 4, 30)
+tag = sys.argv[4] if len(sys.argv) > 4 else None
+net = FCNetwork(O, A, torch.device('cpu'), types.SimpleNamespace()).eval()
+eng = Engine(4096, O, A, SIMS, seed=1)
 eng.set_weights(net.state_dict())
-obs=torch.randn(4096,O,device='cuda')
-names=['gather','bar','dyn_fc1','dyn_fc2','comb1','ln/rew','pred_fc1','pred_fc2','comb2','val/lg','t_expand','t_backup','t_select','t_rest']
+obs = torch.randn(4096, O, device='cuda')
+names = ['gather', 'bar', 'dyn_fc1', 'dyn_fc2', 'comb1', 'ln/rew', 'pred_fc1', 'pred_fc2', 'comb2', 'val/lg', 't_expand',
+         't_backup', 't_select', 't_rest']
 for it in range(3):
-    eng.initial_inference(obs); eng.root_prepare(None,None,None,device_rng=True,move=it)
-    c=eng.search_phase_profile()
+  eng.initial_inference(obs); eng.root_prepare(None, None, None, device_rng=True, move=it)
+  c = eng.search_phase_profile()
 print('cycles per sim (avg over WGs), per wave:')
 for p in range(14):
-    print('%-9s'%names[p], ' '.join('%8.0f'%(c[w,p]/SIMS) for w in range(4)))
-print('total    ', ' '.join('%8.0f'%(c[w].sum()/SIMS) for w in range(4)))
+  print('%-9s' % names[p], ' '.join('%8.0f' % (c[w, p] / SIMS) for w in range(4)))
+print('total    ', ' '.join('%8.0f' % (c[w].sum() / SIMS) for w in range(4)))
+if tag:
+  out = {'what': 'k_search_fused phase stamps (s_memtime, 100 MHz-independent shader clock cycles), cycles per simulation, '
+                 'averaged over the 256 workgroups, per wave; 4096 trees',
+         'obs': O, 'actions': A, 'sims': SIMS, 'phases': names,
+         'cycles_per_sim_per_wave': {names[p]: [float(c[w, p]) / SIMS for w in range(4)] for p in range(14)},
+         'total_per_wave': [float(c[w].sum()) / SIMS for w in range(4)],
+         'mfma_stage_cycles_wave0': float(sum(c[0, p] for p in (2, 3, 6, 7))) / SIMS,
+         'note': 'waves wait for each other at the four barriers of a simulation (end of gather, partials of the two out '
+                 'layers, LayerNorm): the time a wave spends waiting shows up in the phase that ENDS with the barrier '
+                 '(bar, comb1, ln/rew, comb2); per-wave differences inside t_* are the lock-step cost of unequal tree depths'}
+  json.dump(out, open(os.path.join(ROOT, 'profiles', 'phase_cycles_%s.json' % tag), 'w'), indent=1)
