@@ -143,6 +143,42 @@ def cpu_baseline_reference_shaped():
           'fidelity': 'profiles/r02_ref_shaped_ratio.json (timed beside the imported reference in the build container)'}
 
 
+def measure_split_f16(device, flat, chunk, moves=384):
+  """Short measurement of the opt-in split-f16 search kernel (mz_config.split_f16) on the headline workload: env-steps
+  executed per second over `moves` moves of the device loop (records drained, not ingested) and the search kernel's
+  launch duration."""
+  from model_based_rl_amd.engine import Engine
+  eng = Engine(B, O, A, SIMS, seed=1234, device=device, split_f16=True)
+  eng.set_weights(flat if flat.is_cuda else flat.to(device))
+  if '-ram' in WNAME:
+    eng.selfplay_set_obs(uint8_obs=True, obs_min=[0.0], obs_range=[255.0])
+  eng.selfplay_reset(EPISODE_LEN, 1.0, stagger=True)
+  pinned = torch.empty(chunk, B, eng.rec_floats, dtype=torch.float32).pin_memory()
+
+  def run(n):
+    for _ in range(n // chunk):
+      eng.selfplay_steps(chunk)
+      eng.selfplay_drain(pinned, chunk)
+  run(64)
+  torch.cuda.synchronize(device)
+  t0 = time.perf_counter()
+  run(moves)
+  torch.cuda.synchronize(device)
+  dt = time.perf_counter() - t0
+  durs = []
+  for _ in range(3):
+    durs += eng.selfplay_steps_timed(chunk)
+    eng.selfplay_drain(pinned, chunk)
+    torch.cuda.synchronize(device)
+  us = 1e3 * float(np.mean(durs[chunk:]))
+  eng.close()
+  return {'what': 'mz_config.split_f16 = 1: FCNetwork GEMMs as float16 high/low splits on v_mfma_f32_16x16x32_f16, f32 '
+                  'accumulation; float32-level accuracy (every parity test passes), not bit-identical to the exact-f32 path',
+          'env_steps_per_s': B * (moves // chunk) * chunk / dt, 'ms_per_step': 1e3 * dt / ((moves // chunk) * chunk),
+          'search_kernel_us_per_launch': us, 'moves': (moves // chunk) * chunk,
+          'algorithmic_tflops': SIMS * FLOP_PER_SIM * B / (us * 1e-6) / 1e12}
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
@@ -156,6 +192,9 @@ def main():
                   help='moves between weight pulls (the path\'s one exchange: broadcast + repack)')
   ap.add_argument('--min-seconds', type=float, default=1.2,
                   help='the --steps block is repeated back to back until the timed region is at least this long')
+  ap.add_argument('--split-f16', action='store_true',
+                  help='secondary line: the FCNetwork GEMMs as float16 high/low splits on the f16 matrix pipe '
+                       '(mz_config.split_f16; float32-level accuracy, not bit-identical to the exact-f32 default)')
   ap.add_argument('--dump-records', default=None,
                   help='(tests) save this rank\'s experience records of the first moves after reset to <path>.rank<r>.npy')
   args = ap.parse_args()
@@ -196,7 +235,7 @@ def main():
   flat = flatten_weights(net.state_dict()).to(coll_dev)
   if rank != 0:
     flat.zero_()
-  eng = Engine(B, O, A, SIMS, seed=1234, env_id_offset=rank * B, device=device)
+  eng = Engine(B, O, A, SIMS, seed=1234, env_id_offset=rank * B, device=device, split_f16=args.split_f16)
   n_syncs = [0]
 
   def sync_weights():
@@ -345,7 +384,8 @@ def main():
         'metric': 'env-steps/sec (self-play, whole node) at num_simulations=%d' % SIMS,
         'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': 1e3 * dt / total, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32', 'data': 'synthetic',
+        'dtype': 'f32' if not args.split_f16 else 'f16x2-split products, f32 accumulate (f32-level accuracy; secondary line)',
+        'data': 'synthetic',
         'repeats': repeats, 'timed_steps': total, 'timed_seconds': dt,
         'ms_per_step_blocks': {'median': float(np.median(block_ms)), 'std': float(np.std(block_ms)),
                                'min': float(np.min(block_ms)), 'max': float(np.max(block_ms)), 'n': len(block_ms),
@@ -371,6 +411,20 @@ def main():
                      'whole_path_frac': (env_steps / dt / world) * (SIMS * FLOP_PER_SIM + FLOP_PER_ROOT) / 1e12 /
                                         PEAK_F32_MFMA_TFLOPS},
     }
+    if args.split_f16:
+      out['secondary_line'] = True
+      out['roofline'].update({
+          'note': 'achieved = ALGORITHMIC float32 FLOP (the same count as the exact path) / time; every algorithmic product '
+                  'block is three v_mfma_f32_16x16x32_f16 (high x high, high x low, low x high), so the matrix pipe executes '
+                  '3x that (+ K padding to 64) against a dense f16 peak of 2516 TFLOP/s; the kernel is bound by the L2 -> CU '
+                  'weight stream (672 KB per CU and simulation, ~52 B/clk/CU of 64), see DESIGN.md',
+          'f16_mfma_peak': 2516.0})
+    elif world == 1 and O + 1 <= 64 and A <= 13:
+      # the opt-in split-f16 search kernel on the same workload, as a SECONDARY figure inside the same line (never `value`)
+      try:
+        out['split_f16_secondary'] = measure_split_f16(device, flat, chunk)
+      except Exception as exc:          # the headline must not depend on it
+        out['split_f16_secondary'] = {'error': str(exc)[:200]}
     if world == 1 and not args.no_cpu_baseline:
       out['cpu_baseline'] = cpu_baseline({k: v.numpy() for k, v in net.state_dict().items()})
       out['cpu_baseline']['reference_shaped'] = cpu_baseline_reference_shaped()

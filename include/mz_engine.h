@@ -58,6 +58,13 @@ typedef struct mz_config {
   int32_t env_id_offset;        /* global id of env 0 (rank * num_envs when actors are sharded over GPUs) */
   int32_t no_support;           /* --no_support: value / reward heads are single scalars (networks.py:135-136), returned
                                  * untransformed in eval mode (networks.py:153,161); the supports above are ignored */
+  int32_t split_f16;            /* 0 (default): the FCNetwork GEMMs of mz_search / the self-play loop run on
+                                 * v_mfma_f32_16x16x4_f32 -- exact float32, the reference's arithmetic type.
+                                 * 1: opt-in fast path (action_space <= 13): every float32 operand is split into two
+                                 * float16 parts and every product block is three v_mfma_f32_16x16x32_f16 with float32
+                                 * accumulation (csrc/mz_fused_h2.hip.h): float32-level accuracy (deviation from a float64
+                                 * evaluation 1-2x that of the exact path, inside the 1e-5 bound), NOT bit-identical to the
+                                 * exact path.  The environment variable MZ_SPLIT_F16=1 sets it for every engine. */
 } mz_config;
 
 const char *mz_last_error(void);

@@ -10,7 +10,7 @@ import subprocess
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 _SO = os.environ.get('MZ_HIP_LIB') or os.path.join(_CSRC, 'libmz_hip.so')      # (MZ_HIP_LIB: A/B runs of two builds on one box)
 _SOURCES = ['mz_engine.hip', 'mz_common.h', 'mz_net.hip.h', 'mz_tree.hip.h', 'mz_rng.h', 'mz_selfplay.hip.h',
-            'mz_selfplay_abi.inc', 'mz_fused.hip.h', 'mz_root.hip.h']
+            'mz_selfplay_abi.inc', 'mz_fused.hip.h', 'mz_root.hip.h', 'mz_fused_h2.hip.h']
 _lib = None
 
 HIPCC_FLAGS = ['-O3', '--offload-arch=gfx950', '-ffp-contract=off', '-std=c++17', '-fPIC', '-shared', '-Wno-unused-value',
@@ -26,7 +26,7 @@ class MzConfig(C.Structure):
               ('discount', C.c_double), ('pb_c_base', C.c_double), ('pb_c_init', C.c_double),
               ('init_value_score', C.c_double), ('root_dirichlet_alpha', C.c_double),
               ('root_exploration_fraction', C.c_double), ('seed', C.c_uint64), ('env_id_offset', C.c_int32),
-              ('no_support', C.c_int32)]
+              ('no_support', C.c_int32), ('split_f16', C.c_int32)]
 
 
 def stale():

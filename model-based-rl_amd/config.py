@@ -113,6 +113,9 @@ def build_parser():
   a('--group_tag', type=str, default=None)
   a('--run_tag', type=str, default=None)
   a('--actor_log_frequency', type=int, default=1)
+  a('--split_f16', action='store_true',
+    help='FCNetwork GEMMs of the search as float16 high/low splits on the f16 matrix pipe (float32-level accuracy, not '
+         'bit-identical to the exact-float32 default; include/mz_engine.h mz_config.split_f16)')
   a('--parity_rng', action='store_true',
     help="draw Dirichlet noise / action samples from numpy's global stream in the reference's order")
   return p

@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -22,6 +23,7 @@
 #include "mz_selfplay.hip.h"
 #include "mz_fused.hip.h"
 #include "mz_root.hip.h"
+#include "mz_fused_h2.hip.h"
 
 static thread_local std::string g_err;
 
@@ -81,6 +83,10 @@ struct mz_engine {
   hipStream_t drain_stream = nullptr;
   bool drain_pending = false;
   unsigned long long drained_ordered = 0;
+  bool split_f16 = false;           // FCNetwork GEMMs as float16 high/low splits (mz_fused_h2.hip.h)
+  int32_t *pack_idx_h2 = nullptr;   // gather table of the split-f16 weight stream (bit 30: low part)
+  uint16_t *packed_h2 = nullptr;    // [4 waves][NGROUPS][8 pieces][64 lanes][8] float16
+  size_t n_packed_h2 = 0;
   float *obs_norm = nullptr;        // [2][O] --norm_obs minimum and range (device)
   std::vector<float> obs_norm_host;
 };
@@ -183,6 +189,102 @@ static void fill_fc2(std::vector<int32_t> &idx, size_t wpos, int JT, size_t woff
 
 static void fill_vec(std::vector<int32_t> &idx, size_t pos, int padded, size_t off, int n) {
   for (int i = 0; i < padded; ++i) idx[pos + i] = i < n ? (int32_t)(off + i) : -1;
+}
+
+// ---- split-f16 weight stream (mz_fused_h2.hip.h): per wave [NGROUPS][8 pieces][64 lanes][8 halfs]; a group = the A
+// operands of four 16 x 32 blocks ("units"): pieces 0..3 their high parts, 4..7 their low parts.  Lane l of a piece holds
+// row l & 15, k = 8 (l >> 4) + j of the block.
+__global__ void k_pack_weights_h2(const float *flat, const int32_t *idx, _Float16 *packed, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int32_t s = idx[i];
+  float v = 0.f;
+  if (s >= 0) v = flat[s & 0x3fffffff];
+  const _Float16 h = (_Float16)v;                                  // round to nearest
+  packed[i] = (s >= 0 && (s & 0x40000000)) ? (_Float16)(v - (float)h) : h;
+}
+
+static int build_packing_h2(mz_engine *e, const FlatLayout &L, int Sv, int Sr) {
+  using SC = H2Sched;
+  const int A = e->A;
+  const size_t per_wave = (size_t)SC::NGROUPS * 8 * 512;
+  e->n_packed_h2 = 4 * per_wave;
+  std::vector<int32_t> idx(e->n_packed_h2, -1);
+  for (int w = 0; w < 4; ++w) {
+    size_t group = 0;
+    // unit: source index of (row 0..15, k 0..31) of one block, or -1
+    auto emit = [&](const std::function<int32_t(int, int)> (&unit)[4]) {
+      for (int part = 0; part < 2; ++part)
+        for (int u = 0; u < 4; ++u) {
+          const size_t base = (size_t)w * per_wave + (group * 8 + (size_t)part * 4 + u) * 512;
+          for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j) {
+              const int32_t sidx = unit[u](lane & 15, 8 * (lane >> 4) + j);
+              idx[base + (size_t)lane * 8 + j] = sidx < 0 ? -1 : (sidx | (part ? 0x40000000 : 0));
+            }
+        }
+      ++group;
+    };
+    // fc1 block: tile tt of this wave (head tt / 8, feature 128 w + 16 (tt % 8) + row), K chunk c; column K1 = bias
+    auto fc1_unit = [&](int tt, int c, const size_t *woff, const size_t *boff, int K1) {
+      return [=](int row, int kl) -> int32_t {
+        const int head = tt / 8, nf = 128 * w + 16 * (tt % 8) + row, k = 32 * c + kl;
+        if (k < K1) return (int32_t)(woff[head] + (size_t)nf * K1 + k);
+        if (k == K1) return (int32_t)(boff[head] + nf);
+        return -1;
+      };
+    };
+    // fc2 block: output rows 16 ot + row (< J) of the layer at woff, K pair p of this wave's eight tiles of the head:
+    // k = 8 g + j  <->  feature 128 w + 16 (2 p + (j >= 4)) + 4 g + (j & 3)   (the D fragments of tiles 2p, 2p+1)
+    auto fc2_unit = [&](size_t woff, int ot, int J, int p) {
+      return [=](int row, int kl) -> int32_t {
+        const int r = 16 * ot + row, g = kl / 8, j = kl % 8;
+        if (r >= J) return -1;
+        const int feat = 128 * w + 16 * (2 * p + (j >= 4 ? 1 : 0)) + 4 * g + (j & 3);
+        return (int32_t)(woff + (size_t)r * MZ_F + feat);
+      };
+    };
+    const size_t d1w[2] = {L.rew_w1, L.tr_w1}, d1b[2] = {L.rew_b1, L.tr_b1};
+    const size_t p1w[2] = {L.val_w1, L.pol_w1}, p1b[2] = {L.val_b1, L.pol_b1};
+    for (int tg = 0; tg < 4; ++tg)
+      for (int c = 0; c < 2; ++c) {
+        const std::function<int32_t(int, int)> u[4] = {fc1_unit(4 * tg, c, d1w, d1b, MZ_H + A), fc1_unit(4 * tg + 1, c, d1w, d1b, MZ_H + A),
+                                                         fc1_unit(4 * tg + 2, c, d1w, d1b, MZ_H + A), fc1_unit(4 * tg + 3, c, d1w, d1b, MZ_H + A)};
+        emit(u);
+      }
+    for (int half = 0; half < 2; ++half) {
+      for (int sub = 0; sub < 2; ++sub) {
+        const int p = 2 * half + sub;
+        const std::function<int32_t(int, int)> u[4] = {fc2_unit(L.rew_w2, 0, Sr, p), fc2_unit(L.rew_w2, 1, Sr, p),
+                                                         fc2_unit(L.tr_w2, 0, MZ_H, p), fc2_unit(L.tr_w2, 1, MZ_H, p)};
+        emit(u);
+      }
+      const std::function<int32_t(int, int)> u[4] = {fc2_unit(L.tr_w2, 2, MZ_H, 2 * half), fc2_unit(L.tr_w2, 3, MZ_H, 2 * half),
+                                                       fc2_unit(L.tr_w2, 2, MZ_H, 2 * half + 1), fc2_unit(L.tr_w2, 3, MZ_H, 2 * half + 1)};
+      emit(u);
+    }
+    for (int tg = 0; tg < 4; ++tg)
+      for (int c = 0; c < 2; ++c) {
+        const std::function<int32_t(int, int)> u[4] = {fc1_unit(4 * tg, c, p1w, p1b, MZ_H), fc1_unit(4 * tg + 1, c, p1w, p1b, MZ_H),
+                                                         fc1_unit(4 * tg + 2, c, p1w, p1b, MZ_H), fc1_unit(4 * tg + 3, c, p1w, p1b, MZ_H)};
+        emit(u);
+      }
+    for (int k = 0; k < 2; ++k) {
+      const std::function<int32_t(int, int)> u[4] = {fc2_unit(L.val_w2, 0, Sv, 2 * k), fc2_unit(L.val_w2, 1, Sv, 2 * k),
+                                                       fc2_unit(L.val_w2, 0, Sv, 2 * k + 1), fc2_unit(L.val_w2, 1, Sv, 2 * k + 1)};
+      emit(u);
+    }
+    {
+      const std::function<int32_t(int, int)> u[4] = {fc2_unit(L.pol_w2, 0, A, 0), fc2_unit(L.pol_w2, 0, A, 1),
+                                                       fc2_unit(L.pol_w2, 0, A, 2), fc2_unit(L.pol_w2, 0, A, 3)};
+      emit(u);
+    }
+    if ((int)group != SC::REAL) return fail("internal: split-f16 stream has %zu groups, expected %d", group, SC::REAL);
+  }
+  if (dmalloc(e, &e->pack_idx_h2, e->n_packed_h2)) return -1;
+  if (dmalloc(e, &e->packed_h2, e->n_packed_h2)) return -1;
+  HIPCHECK(hipMemcpy(e->pack_idx_h2, idx.data(), e->n_packed_h2 * sizeof(int32_t), hipMemcpyHostToDevice));
+  return 0;
 }
 
 static int build_packing(mz_engine *e) {
@@ -323,6 +425,7 @@ static int build_packing(mz_engine *e) {
   n.rmin = e->cfg.no_support ? 0 : e->cfg.reward_support_min;   // (0: mz_support_to_scalar_q adds the raw output to it)
   n.vmin = e->cfg.no_support ? 0 : e->cfg.value_support_min;
   n.no_transform = e->cfg.no_support ? 2 : (e->cfg.no_target_transform ? 1 : 0);
+  if (e->split_f16 && build_packing_h2(e, L, Sv, Sr)) return -1;
   return 0;
 }
 
@@ -400,6 +503,49 @@ static int launch_fused_sp(mz_engine *e, int num_simulations, int sims_done, hip
   return 0;
 }
 
+// the split-f16 variant (mz_fused_h2.hip.h): same arguments, its own weight stream and static LDS
+template <int G, int LT, bool SP>
+static int launch_h2_sp(mz_engine *e, int num_simulations, int sims_done, hipStream_t s) {
+  const size_t dyn = mz_fused_dyn_lds(e->sims, e->NN, LT);
+  const f32x4 *ws = (const f32x4 *)e->packed_h2;
+  const int maxdyn = 160 * 1024 - (int)sizeof(float) * mz_h2_lds_floats(LT);
+  if (e->prof_buf) {
+    if (!e->lds_attr_set_prof) {
+      HIPCHECK(hipFuncSetAttribute((const void *)k_search_h2<G, LT, true, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, maxdyn));
+      e->lds_attr_set_prof = true;
+    }
+    hipLaunchKernelGGL((k_search_h2<G, LT, true, SP>), dim3(e->Bp / MZ_ROWS), dim3(256), dyn, s, e->nv, e->tv, ws,
+                       num_simulations, sims_done, e->prof_buf, e->sp, 0, (uint64_t)e->cfg.seed);
+  } else {
+    if (!e->lds_attr_set) {
+      HIPCHECK(hipFuncSetAttribute((const void *)k_search_h2<G, LT, false, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, maxdyn));
+      e->lds_attr_set = true;
+    }
+    if (e->ev_start)
+      hipExtLaunchKernelGGL((k_search_h2<G, LT, false, SP>), dim3(e->Bp / MZ_ROWS), dim3(256), dyn, s, e->ev_start,
+                            e->ev_stop, 0, e->nv, e->tv, ws, num_simulations, sims_done, (unsigned long long *)nullptr,
+                            e->sp, e->fuse_record ? 1 : 0, (uint64_t)e->cfg.seed);
+    else
+      hipLaunchKernelGGL((k_search_h2<G, LT, false, SP>), dim3(e->Bp / MZ_ROWS), dim3(256), dyn, s, e->nv, e->tv, ws,
+                         num_simulations, sims_done, (unsigned long long *)nullptr, e->sp, e->fuse_record ? 1 : 0,
+                         (uint64_t)e->cfg.seed);
+  }
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
+
+// -1: the split-f16 kernel does not apply (trees fit neither LDS placement beside its larger static LDS)
+template <int G>
+static int launch_h2(mz_engine *e, int num_simulations, int sims_done, hipStream_t s) {
+  if (!e->use_lds_trees) return -2;
+  const bool two = e->cfg.two_players != 0;
+  if (sizeof(float) * mz_h2_lds_floats(1) + mz_fused_dyn_lds(e->sims, e->NN, 1) <= 160 * 1024)
+    return two ? launch_h2_sp<G, 1, false>(e, num_simulations, sims_done, s) : launch_h2_sp<G, 1, true>(e, num_simulations, sims_done, s);
+  if (e->use_lds_hybrid && sizeof(float) * mz_h2_lds_floats(2) + mz_fused_dyn_lds(e->sims, e->NN, 2) <= 160 * 1024)
+    return two ? launch_h2_sp<G, 2, false>(e, num_simulations, sims_done, s) : launch_h2_sp<G, 2, true>(e, num_simulations, sims_done, s);
+  return -2;
+}
+
 // single-player games (every reference environment but TicTacToe) run the instantiation without to_play handling
 template <int KS1, int JTP, int G, int LT>
 static int launch_fused_lt(mz_engine *e, int num_simulations, int sims_done, hipStream_t s) {
@@ -425,6 +571,15 @@ static int fused_ks1(int A) { return A <= 5 ? 14 : (A <= 13 ? 16 : (A <= 21 ? 18
 
 static int launch_fused(mz_engine *e, int num_simulations, int sims_done, hipStream_t s) {
   const int A = e->A;
+  if (e->split_f16) {
+    int rc = -2;
+    if (A <= 4) rc = launch_h2<4>(e, num_simulations, sims_done, s);
+    else if (A <= 8) rc = launch_h2<8>(e, num_simulations, sims_done, s);
+#ifndef MZ_DEV_ONLY
+    else rc = launch_h2<16>(e, num_simulations, sims_done, s);
+#endif
+    if (rc != -2) return rc;          // (-2: trees do not fit its LDS budget -> the exact-f32 kernel)
+  }
 #ifdef MZ_DEV_ONLY      // kernel development: only the two bench shapes are instantiated (a quarter of the build time)
   if (A <= 4) return launch_fused_t<14, 1, 4>(e, num_simulations, sims_done, s);
   if (A >= 6 && A <= 8) return launch_fused_t<16, 1, 8>(e, num_simulations, sims_done, s);
@@ -502,6 +657,15 @@ int mz_create(const mz_config *cfg, mz_engine **out) {
   e->use_fused = getenv("MZ_NO_FUSED") == nullptr;
   e->use_lds_trees = getenv("MZ_NO_LDS_TREES") == nullptr;
   e->use_lds_hybrid = getenv("MZ_NO_LDS_HYBRID") == nullptr;
+  {
+    const char *sf = getenv("MZ_SPLIT_F16");
+    const bool want = cfg->split_f16 != 0 || (sf && sf[0] == '1');
+    if (cfg->split_f16 != 0 && cfg->action_space > MZ_H2_MAXA) {
+      delete e;
+      return fail("mz_create: split_f16 supports action_space <= %d (got %d)", MZ_H2_MAXA, cfg->action_space);
+    }
+    e->split_f16 = want && cfg->action_space <= MZ_H2_MAXA;
+  }
   TreeView &t = e->tv;
   memset(&t, 0, sizeof t);
   const size_t nb = (size_t)e->Bp, nn = nb * e->NN;
@@ -585,6 +749,9 @@ int mz_set_weights(mz_engine *e, const float *flat, size_t n, int on_device, voi
   const int threads = 256;
   const unsigned blocks = (unsigned)((e->n_packed + threads - 1) / threads);
   hipLaunchKernelGGL(k_pack_weights, dim3(blocks), dim3(threads), 0, s, src, e->pack_idx, e->packed, e->n_packed);
+  if (e->split_f16)
+    hipLaunchKernelGGL(k_pack_weights_h2, dim3((unsigned)((e->n_packed_h2 + threads - 1) / threads)), dim3(threads), 0, s, src,
+                       e->pack_idx_h2, (_Float16 *)e->packed_h2, e->n_packed_h2);
   HIPCHECK(hipGetLastError());
   if (!on_device) HIPCHECK(hipStreamSynchronize(s));   // the host buffer may be freed by the caller
   e->weights_set = true;

@@ -337,6 +337,8 @@ __device__ __forceinline__ f32x4 mz_quad_sum(const MzQuad &o) {      // same ord
 // relu(LayerNorm) of output rows [row0,row0+50), column m -> row-major tile xR[m][0..51]; 8 lanes per column,
 // lane q owns the feature quads q and q+8.  Rows up to row0+63 exist and are exact zeros beyond 50 (zero
 // weights, bias and LayerNorm affine), so nothing is conditional but the variance term and the last store.
+// SMALLT: rows 48..51 come out of the small MFMA (as described below); false: they are an ordinary 16-row tile
+template <bool SMALLT = true>
 __device__ __forceinline__ void sln_relu8p(const float *red, const float *bias, float *xR, const float *lnw,
                                            const float *lnb, int row0, int m, int q) {
   MzQuad A, B;
@@ -348,9 +350,9 @@ __device__ __forceinline__ void sln_relu8p(const float *red, const float *bias, 
   // the four lane rows of wave q - 4 each, a quad reduction joins the waves, lane q = 4 keeps the sum (features >= 52
   // do not exist: exact zeros).  One address + one stride per lane serve both cases.
   const int jt5 = (row0 >> 4) + 3;
-  const unsigned pb = (q < 4) ? mz_quad_addr(red, row0 + 4 * q + 32, m)
-                              : mz_lds_addr((const f32x4 *)red + (((q - 4) * 6 + jt5) * 64 + m));
-  const unsigned st = (q < 4) ? 6u * 1024u : 256u;
+  const unsigned pb = (!SMALLT || q < 4) ? mz_quad_addr(red, row0 + 4 * q + 32, m)
+                                         : mz_lds_addr((const f32x4 *)red + (((q - 4) * 6 + jt5) * 64 + m));
+  const unsigned st = (!SMALLT || q < 4) ? 6u * 1024u : 256u;
   mz_lds128<128>(B.b, ba);
   mz_lds128<0>(B.p0, pb); mz_lds128<0>(B.p1, pb + st); mz_lds128<0>(B.p2, pb + 2 * st); mz_lds128<0>(B.p3, pb + 3 * st);
   asm volatile("s_waitcnt lgkmcnt(0)" : MZ_Q(A), MZ_Q(B));
@@ -364,7 +366,7 @@ __device__ __forceinline__ void sln_relu8p(const float *red, const float *bias, 
     for (int r = 0; r < 4; ++r) { float v = ps[r]; v += mz_dpp<0xB1>(v); v += mz_dpp<0x4E>(v); tot[r] = v; }   // over the quad q = 4..7
     const f32x4 big = B.b + ps, small = B.b + tot;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) xb[r] = (q < 4) ? big[r] : ((q == 4) ? small[r] : 0.f);
+    for (int r = 0; r < 4; ++r) xb[r] = (!SMALLT || q < 4) ? big[r] : ((q == 4) ? small[r] : 0.f);
   }
   // the affine parameters (lnb = lnw + 64 floats) arrive under the two reductions
   mz_lds128<0>(wA, wa); mz_lds128<128>(wB, wa);

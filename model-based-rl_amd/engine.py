@@ -59,7 +59,8 @@ class Engine(object):
   def __init__(self, num_envs, obs_dim, action_space, num_simulations, two_players=False,
                known_bounds=(None, None), value_support=(-15, 15), reward_support=(-15, 15),
                no_target_transform=False, no_support=False, discount=0.997, pb_c_base=19652, pb_c_init=1.25, init_value_score=0.0,
-               root_dirichlet_alpha=0.25, root_exploration_fraction=0.25, seed=0, env_id_offset=0, device=None):
+               root_dirichlet_alpha=0.25, root_exploration_fraction=0.25, seed=0, env_id_offset=0, device=None,
+               split_f16=False):
     if not torch.cuda.is_available():
       raise RuntimeError('model_based_rl_amd.Engine needs a HIP device (torch.cuda.is_available() is False); '
                          'there is no CPU path.')
@@ -75,7 +76,7 @@ class Engine(object):
         int(value_support[0]), int(value_support[1]), int(reward_support[0]), int(reward_support[1]),
         int(bool(no_target_transform)), 0.0 if lo is None else float(lo), 0.0 if hi is None else float(hi),
         float(discount), float(pb_c_base), float(pb_c_init), float(init_value_score), float(root_dirichlet_alpha),
-        float(root_exploration_fraction), int(seed), int(env_id_offset), int(bool(no_support)))
+        float(root_exploration_fraction), int(seed), int(env_id_offset), int(bool(no_support)), int(bool(split_f16)))
     h = C.c_void_p()
     _abi.check(self.lib.mz_create(C.byref(self.cfg), C.byref(h)), 'mz_create')
     self._h = h
@@ -98,7 +99,8 @@ class Engine(object):
                init_value_score=getattr(config, 'init_value_score', 0.0),
                root_dirichlet_alpha=config.root_dirichlet_alpha,
                root_exploration_fraction=config.root_exploration_fraction,
-               seed=(config.seed if seed is None else seed) or 0, env_id_offset=env_id_offset, device=device)
+               seed=(config.seed if seed is None else seed) or 0, env_id_offset=env_id_offset, device=device,
+               split_f16=getattr(config, 'split_f16', False))
 
   def close(self):
     if getattr(self, '_h', None):

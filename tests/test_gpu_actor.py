@@ -254,9 +254,11 @@ def test_timed_launches_are_the_same_moves():
     assert np.array_equal(trees[0][k], trees[1][k]), k
 
 
-@pytest.mark.parametrize('A,sims,T,temp,ns', [(4, 30, 5, 1.0, False), (6, 12, 4, 0.5, False), (3, 9, 3, 0.0, False),
-                                              (18, 8, 3, 1.0, False), (4, 30, 5, 1.0, True)])
-def test_selfplay_loop_equals_stepwise_abi(A, sims, T, temp, ns):
+@pytest.mark.parametrize('A,sims,T,temp,ns,split', [(4, 30, 5, 1.0, False, False), (6, 12, 4, 0.5, False, False),
+                                                    (3, 9, 3, 0.0, False, False), (18, 8, 3, 1.0, False, False),
+                                                    (4, 30, 5, 1.0, True, False), (4, 30, 5, 1.0, False, True),
+                                                    (6, 12, 4, 0.5, False, True)])
+def test_selfplay_loop_equals_stepwise_abi(A, sims, T, temp, ns, split):
   """The fused per-move kernels of the device loop (root kernel with in-kernel observation + Dirichlet + first
   descent; search kernel whose tail samples the action, steps the env and writes the record) against the
   stepwise C ABI on the same engine configuration: mz_initial_inference -> mz_root_prepare(device RNG) ->
@@ -272,7 +274,7 @@ def test_selfplay_loop_equals_stepwise_abi(A, sims, T, temp, ns):
                               no_target_transform=False)
   net = FCNetwork(O, A, torch.device('cpu'), cfg)
   flat = flatten_weights(net.state_dict())
-  loop = Engine(B, O, A, sims, seed=99, env_id_offset=7, no_support=ns)
+  loop = Engine(B, O, A, sims, seed=99, env_id_offset=7, no_support=ns, split_f16=split)
   loop.set_weights(flat)
   loop.selfplay_reset(T, temp, stagger=False)
   loop.selfplay_steps(moves)
@@ -282,7 +284,7 @@ def test_selfplay_loop_equals_stepwise_abi(A, sims, T, temp, ns):
   loop.close()
   rv = records_view(rec, O, A)
 
-  step = Engine(B, O, A, sims, seed=99, env_id_offset=7, no_support=ns)
+  step = Engine(B, O, A, sims, seed=99, env_id_offset=7, no_support=ns, split_f16=split)
   step.set_weights(flat)
   for m in range(moves):
     obs = np.stack([step.synth_obs(7 + b, m // T, m % T)[0] for b in range(B)])

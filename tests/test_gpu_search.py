@@ -208,3 +208,58 @@ def test_search_in_two_calls_equals_one_call():
     eng.close()
   for k in ('N', 'W', 'E', 'minmax'):
     assert np.array_equal(res[0][k], res[1][k]) and np.array_equal(res[0][k], res[2][k]), k
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# mz_config.split_f16: the opt-in search kernel with the FCNetwork GEMMs as float16 high/low splits on the f16 matrix pipe
+# (csrc/mz_fused_h2.hip.h).  Same oracle, same bounds as the exact-float32 kernel.
+
+@pytest.mark.parametrize('name,B,sims,two,bounds,discount,legal_p', [
+    ('g1_net_lunar', 4096, 30, False, (None, None), 0.997, 1.0),       # BASELINE config 2 shape
+    ('g1_net_ttt', 512, 30, True, (-1.0, 1.0), 1.0, 0.6),              # two players, A = 9 (16-lane groups), illegal moves
+    ('g1_net_pong', 256, 50, False, (None, None), 0.997, 1.0),         # config 4 shape
+    ((8, 5), 200, 30, False, (None, None), 0.997, 1.0),                # A = 5 (8-lane groups)
+    ((8, 13), 64, 12, False, (None, None), 0.997, 0.8),                # the widest supported action space
+    ((8, 4), 96, 60, False, (None, None), 0.997, 1.0),                 # trees too large for LDS: hybrid placement or f32 fallback
+    ('g1_net_lunar_nosupport', 1024, 30, False, (None, None), 0.997, 1.0),
+])
+def test_split_f16_search_vs_oracle(name, B, sims, two, bounds, discount, legal_p, monkeypatch):
+  monkeypatch.setenv('MZ_SPLIT_F16', '1')
+  out, ex, ref = run_both(name, B, sims, two, bounds, discount, legal_p)
+  same = np.all(out['visit_counts'] == ref['visit_counts'], axis=1)
+  assert same.mean() >= 0.99, same.mean()
+  assert np.abs(out['root_value'] - ref['root_value'])[same].max() <= 5e-4
+  assert np.array_equal(out['action'][same], ref['action'][same])
+  whole = np.all(ex['N'] == ref['tree']['N'], axis=1) & np.all(ex['E'] == ref['tree']['E'], axis=1)
+  assert whole.mean() >= 0.98, whole.mean()
+  assert np.abs(ex['hidden'][whole] - ref['hpool'][whole]).max() <= 5e-4
+
+
+def test_split_f16_network_error_and_config():
+  """One simulation, no compounding: the split-f16 network against the oracle's float32 recurrent inference on the
+  device's own root hidden state -- inside the same 1e-5 bound as the exact kernel (measured max: printed) -- and it IS
+  a different kernel (its bits differ from the exact path's somewhere); action spaces beyond 13 are refused."""
+  from model_based_rl_amd.engine import Engine
+  from oracle import oracle as orc
+  g = np.load(os.path.join(G, 'g1_net_lunar.npz'))
+  w = orc.load_weights(g)
+  B, O, A = 4096, 8, 4
+  obs = np.random.RandomState(9).standard_normal((B, O)).astype(np.float32) * 2
+  hid = {}
+  for split in (False, True):
+    eng = Engine(B, O, A, 4, seed=3, split_f16=split)
+    eng.set_weights(w)
+    eng.initial_inference(obs)
+    eng.root_prepare(None, None, None, device_rng=True, move=0)
+    eng.search(1)
+    t = eng.export_tree(hidden=True)
+    child = np.array([int(np.flatnonzero(t['N'][b, 1:1 + A])[0]) for b in range(B)], np.int32)
+    h1o, r1o, v1o, _ = orc.FCNet(w, O, A).recurrent(t['hidden'][:, 0, :], child)
+    err = np.abs(t['hidden'][:, 1, :] - h1o).max()
+    print('split_f16 =', split, ': max |hidden - oracle| %.2e' % err)
+    assert err <= 1e-5
+    hid[split] = t['hidden'][:, 1, :].copy()
+    eng.close()
+  assert not np.array_equal(hid[False], hid[True]) and np.abs(hid[False] - hid[True]).max() <= 1e-5
+  with pytest.raises(RuntimeError, match='split_f16 supports action_space'):
+    Engine(16, 8, 18, 4, split_f16=True)
