@@ -137,6 +137,9 @@ int mz_search_timed(mz_engine *e, int num_simulations, float *ms_out, void *stre
  * over workgroups.  Phases: 0 gather, 1 barrier, 2 dynamics fc1, 3 dynamics fc2, 4 combine, 5 LN/reward,
  * 6 store + prediction fc1, 7 prediction fc2, 8 combine, 9 value/logits, 10 expand, 11 backup, 12 descent, 13 rest of the tree step. */
 int mz_search_phase_profile(mz_engine *e, int num_simulations, unsigned long long *cycles_out, void *stream);
+/* of the last mz_search_phase_profile: out3 [host] = mean, minimum, maximum over the workgroups of a workgroup's total
+ * cycles (the launch lasts as long as its slowest workgroup) */
+int mz_search_phase_spread(const mz_engine *e, double *out3);
 
 /* The same loop opened up for an external network (MuZeroNetwork/TinyNetwork through PyTorch, or
  * recorded outputs in the parity tests):

@@ -67,6 +67,7 @@ SIGNATURES = {
     'mz_search_profiled': (_I, [_VP, _I, _VP, _VP]),
     'mz_search_timed': (_I, [_VP, _I, _VP, _VP]),
     'mz_search_phase_profile': (_I, [_VP, _I, _VP, _VP]),
+    'mz_search_phase_spread': (_I, [_VP, _VP]),
     'mz_select': (_I, [_VP, _VP, _VP, _VP, _VP, _VP]),
     'mz_gather_hidden': (_I, [_VP, _VP, _VP]),
     'mz_expand_backup': (_I, [_VP, _VP, _VP, _VP, _VP, _VP]),

@@ -83,6 +83,7 @@ struct mz_engine {
   hipStream_t drain_stream = nullptr;
   bool drain_pending = false;
   unsigned long long drained_ordered = 0;
+  double prof_spread[3] = {0, 0, 0};   // mean / min / max over workgroups of the last phase profile's total cycles
   bool split_f16 = false;           // FCNetwork GEMMs as float16 high/low splits (mz_fused_h2.hip.h)
   int32_t *pack_idx_h2 = nullptr;   // gather table of the split-f16 weight stream (bit 30: low part)
   uint16_t *packed_h2 = nullptr;    // [4 waves][NGROUPS][8 pieces][64 lanes][8] float16
@@ -957,6 +958,16 @@ int mz_search_phase_profile(mz_engine *e, int num_simulations, unsigned long lon
   std::vector<unsigned long long> h(n);
   HIPCHECK(hipMemcpy(h.data(), buf, n * 8, hipMemcpyDeviceToHost));
   hipFree(buf);
+  // spread of the workgroups' totals (wave 0): the launch lasts as long as its slowest workgroup
+  {
+    double mn = 1e300, mx = 0, sum = 0;
+    for (int g = 0; g < e->Bp / MZ_ROWS; ++g) {
+      double tot = 0;
+      for (int p2 = 0; p2 < MZ_NPHASE; ++p2) tot += (double)h[((size_t)g * 4) * MZ_NPHASE + p2];
+      mn = tot < mn ? tot : mn; mx = tot > mx ? tot : mx; sum += tot;
+    }
+    e->prof_spread[0] = sum / (e->Bp / MZ_ROWS); e->prof_spread[1] = mn; e->prof_spread[2] = mx;
+  }
   // average over workgroups, per wave and phase: cycles_out[4][MZ_NPHASE]
   for (int w = 0; w < 4; ++w)
     for (int p = 0; p < MZ_NPHASE; ++p) {
@@ -966,6 +977,12 @@ int mz_search_phase_profile(mz_engine *e, int num_simulations, unsigned long lon
     }
   e->sims_done = num_simulations;
   e->selection_valid = false;
+  return 0;
+}
+
+int mz_search_phase_spread(const mz_engine *e, double *out3) {
+  if (!e || !out3) return fail("mz_search_phase_spread: null argument");
+  out3[0] = e->prof_spread[0]; out3[1] = e->prof_spread[1]; out3[2] = e->prof_spread[2];
   return 0;
 }
 

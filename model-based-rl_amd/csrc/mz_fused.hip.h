@@ -337,10 +337,12 @@ __device__ __forceinline__ f32x4 mz_quad_sum(const MzQuad &o) {      // same ord
 // relu(LayerNorm) of output rows [row0,row0+50), column m -> row-major tile xR[m][0..51]; 8 lanes per column,
 // lane q owns the feature quads q and q+8.  Rows up to row0+63 exist and are exact zeros beyond 50 (zero
 // weights, bias and LayerNorm affine), so nothing is conditional but the variance term and the last store.
-// SMALLT: rows 48..51 come out of the small MFMA (as described below); false: they are an ordinary 16-row tile
-template <bool SMALLT = true>
+// SMALLT: rows 48..51 come out of the small MFMA (as described below); false: they are an ordinary 16-row tile.
+// SINK: gets the lane's two output quads as well (features 4q.. and 32 + 4q..), e.g. to keep a second copy of the tile.
+struct MzNoLnSink { __device__ __forceinline__ void operator()(int, int, const f32x4 &, const f32x4 &) const {} };
+template <bool SMALLT = true, class SINK = MzNoLnSink>
 __device__ __forceinline__ void sln_relu8p(const float *red, const float *bias, float *xR, const float *lnw,
-                                           const float *lnb, int row0, int m, int q) {
+                                           const float *lnb, int row0, int m, int q, const SINK &sink = SINK()) {
   MzQuad A, B;
   f32x4 wA, wB, bA, bB;
   const unsigned ba = mz_lds_addr(bias + row0 + 4 * q), wa = mz_lds_addr(lnw + 4 * q);
@@ -396,6 +398,7 @@ __device__ __forceinline__ void sln_relu8p(const float *red, const float *bias, 
   }
   *(f32x4 *)(xR + m * MZ_HS + 4 * q) = ya;
   if (4 * q + 32 < MZ_HS) *(f32x4 *)(xR + m * MZ_HS + 4 * q + 32) = yb;
+  sink(m, q, ya, yb);
 }
 
 // policy logits of a 4-action game out of the small MFMA (tile 2's slot of the prediction partials): lane tl of the

@@ -19,6 +19,9 @@
 //     of column lane & 15 -- the weights are packed in that k order), split into halves with v_cvt_pkrtz_f16_f32;
 //   * every accumulator is touched at most once per four consecutive MFMAs (the MFMAs are inline asm: no hazard
 //     recogniser), out tiles that would be hit more often are kept as two or four partial accumulators.
+// (Tried: refilling every piece in place, right behind the MFMA that reads it last, with the same piece of the group NBG
+// ahead -- a deeper prefetch from the same registers.  No gain (the stages are bound by bytes, not by latency), and the
+// 4 + 3 configuration computed wrong values; dropped.)
 // Supported: action_space <= 13 (dynamics fc1 K = 50 + A + 1 <= 64), 16 lanes per tree, one policy tile.
 #pragma once
 #include "mz_fused.hip.h"
@@ -91,6 +94,29 @@ __device__ __forceinline__ void h2_split_pair(const f32x4 &t0, const f32x4 &t1, 
   bh = f32x4{h[0], h[1], h[2], h[3]};
   bl = f32x4{l[0], l[1], l[2], l[3]};
 }
+
+// LayerNorm output -> the f16 x tile (high / low) of the prediction stage, written by the LayerNorm lanes themselves
+// (8 per column: lane q holds features 4q.. and 32 + 4q..): columns 0..49 the hidden state, 50 the bias column (1),
+// zero beyond
+struct H2LnSink {
+  mz_h16 *xH, *xL;
+  __device__ __forceinline__ void operator()(int m, int q, const f32x4 &ya, const f32x4 &yb) const {
+    float h0, l0, h1, l1;
+    h2_split2(ya[0], ya[1], h0, l0);
+    h2_split2(ya[2], ya[3], h1, l1);
+    float *dh = (float *)(xH + m * MZ_H2_XS + 4 * q), *dl = (float *)(xL + m * MZ_H2_XS + 4 * q);
+    dh[0] = h0; dh[1] = h1; dl[0] = l0; dl[1] = l1;
+    h2_split2(yb[0], yb[1], h0, l0);
+    h2_split2(yb[2], yb[3], h1, l1);
+    if (q < 4) { dh[16] = h0; dh[17] = h1; dl[16] = l0; dl[17] = l1; }
+    else if (q == 4) {                  // columns 48, 49, then the prediction's extension (the low parts there stay zero)
+      dh[16] = h0; dl[16] = l0;
+      dh[17] = __builtin_bit_cast(float, mz_h16x2{(mz_h16)1.f, (mz_h16)0.f});
+#pragma unroll
+      for (int z = 18; z < 24; ++z) dh[z] = 0.f;
+    }
+  }
+};
 
 // prefetch hook of a ring group: slot i requests piece i of the group NBG - 1 ahead (cyclic over the streamed groups)
 // into the buffer the previous group has released
@@ -362,7 +388,7 @@ __global__ __launch_bounds__(256, 1) void k_search_h2(NetView n, TreeView t, con
     {
       const int col = 8 * (w & 1) + (lane_e >> 3), q = lane_e & 7;
       if (w < 2) {
-        sln_relu8p<false>(red, s_b2, xR, s_lnw, s_lnb, 32, col, q);
+        sln_relu8p<false>(red, s_b2, xR, s_lnw, s_lnb, 32, col, q, H2LnSink{xH, xL});
       } else {
         MzQuad Q;
         mz_quad_issue<0>(Q, mz_quad_addr(red, 4 * q, col), mz_lds_addr(s_b2 + 4 * q));
@@ -373,24 +399,11 @@ __global__ __launch_bounds__(256, 1) void k_search_h2(NetView n, TreeView t, con
     }
     mz_bar();
     STAMP(5)
-    if (tid < 16 * (MZ_HS / 4)) {      // next hidden state -> pool slot of this expansion, and its f16 halves -> the prediction's x tile
+    if (tid < 16 * (MZ_HS / 4)) {      // next hidden state -> pool slot of this expansion
       const int m = tid / (MZ_HS / 4), c = tid % (MZ_HS / 4);
-      const f32x4 v = *(const f32x4 *)(xR + m * MZ_HS + 4 * c);
       f32x4 *dst = (f32x4 *)(t.hpool + (size_t)(b0 + m) * per_tree + (size_t)(slot0 + sim + 1) * MZ_HS);
-      dst[c] = v;
-      float h0, l0, h1, l1;
-      h2_split2(v[0], v[1], h0, l0);
-      h2_split2(v[2], v[3], h1, l1);
-      float *dh = (float *)(xH + m * XS + 4 * c), *dl = (float *)(xL + m * XS + 4 * c);
-      if (c < 12) { dh[0] = h0; dh[1] = h1; dl[0] = l0; dl[1] = l1; }
-      else {                                                            // columns 48, 49, then the prediction's extension:
-        dh[0] = h0; dl[0] = l0;                                         // 1 in the bias column (50), zero beyond
-        dh[1] = __builtin_bit_cast(float, mz_h16x2{(mz_h16)1.f, (mz_h16)0.f});
-#pragma unroll
-        for (int z = 2; z < 8; ++z) dh[z] = 0.f;
-      }
+      dst[c] = *(const f32x4 *)(xR + m * MZ_HS + 4 * c);
     }
-    mz_bar();
     // ---- prediction fc1
     load_x(xH, xL);
     mz_static_for<SC::P1>([&](auto G_) __attribute__((always_inline)) {

@@ -217,6 +217,12 @@ class Engine(object):
                'mz_search_phase_profile')
     return out
 
+  def search_phase_spread(self):
+    """(mean, min, max) over the workgroups of a workgroup's total cycles in the last search_phase_profile"""
+    out = (C.c_double * 3)()
+    _abi.check(self.lib.mz_search_phase_spread(self._h, out), 'mz_search_phase_spread')
+    return tuple(float(x) for x in out)
+
   def select(self):
     out = [torch.empty(self.B, dtype=torch.int32, device=self.device) for _ in range(4)]
     _abi.check(self.lib.mz_select(self._h, *[_ptr(o) for o in out], self.stream), 'mz_select')

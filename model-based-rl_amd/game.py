@@ -77,8 +77,15 @@ class Game(object):
     if self.two_players:
       self.to_play = -self.to_play
 
-  # game.py:106-115, from the engine's finalize outputs instead of Node objects
-  def store_search_statistics(self, child_visits, root_value):
+  # game.py:106-115.  Reference call style: store_search_statistics(root) with a searched Node; the batched actor passes
+  # what the engine's finalize step already computed: store_search_statistics(child_visits, root_value).
+  def store_search_statistics(self, root, root_value=None):
+    if root_value is None and hasattr(root, 'children'):
+      total = sum(child.visit_count for child in root.children.values())
+      child_visits = [root.children[a].visit_count / total if a in root.children else 0 for a in self.action_space]
+      root_value = root.value()
+    else:
+      child_visits = root
     self.history.child_visits.append(list(child_visits))
     self.history.root_values.append(root_value)
     self.sum_values += root_value

@@ -26,12 +26,16 @@ print('cycles per sim (avg over WGs), per wave:')
 for p in range(14):
   print('%-9s' % names[p], ' '.join('%8.0f' % (c[w, p] / SIMS) for w in range(4)))
 print('total    ', ' '.join('%8.0f' % (c[w].sum() / SIMS) for w in range(4)))
+spread = eng.search_phase_spread()
+print('workgroup totals per sim: mean %.0f  min %.0f  max %.0f  (max / mean %.3f)' %
+      (spread[0] / SIMS, spread[1] / SIMS, spread[2] / SIMS, spread[2] / spread[0]))
 if tag:
   out = {'what': 'k_search_fused phase stamps (s_memtime, 100 MHz-independent shader clock cycles), cycles per simulation, '
                  'averaged over the 256 workgroups, per wave; 4096 trees',
          'obs': O, 'actions': A, 'sims': SIMS, 'phases': names,
          'cycles_per_sim_per_wave': {names[p]: [float(c[w, p]) / SIMS for w in range(4)] for p in range(14)},
          'total_per_wave': [float(c[w].sum()) / SIMS for w in range(4)],
+         'workgroup_total_per_sim': {'mean': spread[0] / SIMS, 'min': spread[1] / SIMS, 'max': spread[2] / SIMS},
          'mfma_stage_cycles_wave0': float(sum(c[0, p] for p in (2, 3, 6, 7))) / SIMS,
          'note': 'waves wait for each other at the four barriers of a simulation (end of gather, partials of the two out '
                  'layers, LayerNorm): the time a wave spends waiting shows up in the phase that ENDS with the barrier '
