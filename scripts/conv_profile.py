@@ -1,0 +1,10 @@
+import sys, os, types, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from model_based_rl_amd.networks import MuZeroNetwork
+torch.manual_seed(0)
+net = MuZeroNetwork(4, 4, torch.device('cuda'), types.SimpleNamespace()).eval()
+h = torch.rand(512, 128, 6, 6, device='cuda'); a = torch.randint(0, 4, (512,), device='cuda', dtype=torch.int32)
+with torch.inference_mode():
+  for _ in range(8):
+    net.recurrent_inference(h, a)
+torch.cuda.synchronize()

@@ -21,4 +21,11 @@ python3 scripts/phase_profile.py 8 4 30 ${TAG}_lunar > $O/phase_${TAG}_lunar.txt
 python3 scripts/phase_profile.py 128 6 50 ${TAG}_pong > $O/phase_${TAG}_pong.txt 2>&1
 cp profiles/phase_cycles_${TAG}_*.json $O/ 2>/dev/null
 python3 bench.py --workload pong --no-cpu-baseline > $O/bench_pong_$TAG.json 2>> $O/bench_$TAG.err
+# secondary lines: the opt-in split-f16 search kernel on both shapes (+ its phase tables), MuZeroNetwork through PyTorch-ROCm
+python3 bench.py --split-f16 --no-cpu-baseline > $O/bench_split_$TAG.json 2>> $O/bench_$TAG.err
+python3 bench.py --workload pong --split-f16 --no-cpu-baseline > $O/bench_pong_split_$TAG.json 2>> $O/bench_$TAG.err
+MZ_SPLIT_F16=1 python3 scripts/phase_profile.py 8 4 30 ${TAG}_lunar_split > $O/phase_${TAG}_lunar_split.txt 2>&1
+MZ_SPLIT_F16=1 python3 scripts/phase_profile.py 128 6 50 ${TAG}_pong_split > $O/phase_${TAG}_pong_split.txt 2>&1
+cp profiles/phase_cycles_${TAG}_*split.json $O/ 2>/dev/null
+python3 bench.py --workload breakout > $O/bench_breakout_$TAG.json 2>> $O/bench_$TAG.err
 f=$(find $O/prof_$TAG -name "*kernel_stats.csv" | head -1); head -8 "$f"
