@@ -181,17 +181,20 @@ class _MuZeroDynamics(nn.Module):
     self.fc2 = nn.Linear(512, reward_out)
 
   def forward(self, x):
-    if self.training or not x.is_cuda:
-      y = self.conv(x)
-    else:
-      # inference on the GPU: the 129th input channel is the action plane, constant over the 6x6 positions of a sample.
-      # MIOpen has no fast kernel for 129 input channels (it falls back to a naive one: 3.4 ms per call on MI355X against
-      # 73 us for the 128-channel convolution), and a constant plane contributes action/A times the response of the
-      # layer to a plane of ones: conv(x) = conv_128(hidden) + plane value * conv_1(ones) + bias
-      hidden, plane = x[:, :128], x[:, 128:129, :1, :1]
-      ones = torch.ones((1, 1) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device)
-      response = nn.functional.conv2d(ones, self.conv.weight[:, 128:129], None, 1, 1)
-      y = nn.functional.conv2d(hidden, self.conv.weight[:, :128], self.conv.bias, 1, 1) + plane * response
+    return self._tail(self.conv(x))
+
+  def forward_action(self, hidden_state, plane_value):
+    """GPU inference: the 129th input channel is the action plane, constant over the 6x6 positions of a sample.  MIOpen
+    has no fast kernel for 129 input channels (it falls back to a naive one: 3.4 ms per call on MI355X against 73 us for
+    the 128-channel convolution), and a constant plane contributes its value times the layer's response to a plane of
+    ones: conv(cat(hidden, plane)) = conv_128(hidden) + plane value * conv_1(ones) + bias.  plane_value: [B, 1, 1, 1]."""
+    w = self.conv.weight
+    ones = torch.ones((1, 1) + tuple(hidden_state.shape[2:]), dtype=hidden_state.dtype, device=hidden_state.device)
+    response = nn.functional.conv2d(ones, w[:, 128:129].contiguous(), None, 1, 1)
+    y = nn.functional.conv2d(hidden_state, w[:, :128].contiguous(), self.conv.bias, 1, 1)
+    return self._tail(torch.addcmul(y, plane_value, response))
+
+  def _tail(self, y):
     state = _through(self.resblocks, torch.relu(_bn_infer(self.bn, y)))
     return state, self.fc2(torch.relu(self.fc1(state.flatten(1))))
 
@@ -279,7 +282,12 @@ class MuZeroNetwork(_ConvNetBase):
     return policy, self._scalar(value, self.value_support_min)
 
   def dynamics(self, hidden_state, action):
-    state, reward = self.dynamics_head(self.attach_action(hidden_state, action))
+    if self.training or not hidden_state.is_cuda:
+      state, reward = self.dynamics_head(self.attach_action(hidden_state, action))
+    else:
+      n = hidden_state.shape[0]
+      a = torch.as_tensor(action, device=hidden_state.device).reshape(n, 1, 1, 1).to(torch.float32)
+      state, reward = self.dynamics_head.forward_action(hidden_state, a * 1.0 / self.action_space)
     return self.scale_state(state), self._scalar(reward, self.reward_support_min)
 
 
