@@ -368,11 +368,18 @@ def main():
     eng.selfplay_drain(pinned[0], chunk)
     torch.cuda.synchronize(device)
   search_us = 1e3 * float(np.mean(durs[chunk:]))       # (first chunk = warm-up)
+  # single-player shapes with their trees in LDS: the loop is ONE kernel -- every launch plays `chunk` whole moves
+  # (root, simulations, end of move); mz_selfplay_steps_timed then reports every move as its share of its launch
+  persistent = eng.selfplay_moves_per_launch() > 0
+  moves_per_launch = min(chunk, eng.selfplay_moves_per_launch()) if persistent else 1
 
   if rank == 0:
     value = frames / dt
-    flops_per_launch = SIMS * FLOP_PER_SIM * B        # algorithmic: SURVEY.md s8(d) per-simulation figure x sims x trees
-    achieved = flops_per_launch / (search_us * 1e-6) / 1e12
+    # algorithmic: SURVEY.md s8(d) per-simulation figure x sims x trees (+ the per-root figure where the root runs
+    # inside the launch), x the moves one launch plays
+    flops_per_launch = moves_per_launch * (SIMS * FLOP_PER_SIM + (FLOP_PER_ROOT if persistent else 0)) * B
+    launch_us = search_us * moves_per_launch
+    achieved = flops_per_launch / (launch_us * 1e-6) / 1e12
     traffic, traffic_source = None, None
     tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
     if os.path.exists(tfile) and WNAME.startswith('Lunar') and B == 4096:
@@ -406,8 +413,12 @@ def main():
         'mcts_sims_per_s_per_gpu': env_steps * SIMS / dt / world,
         'roofline': {'bound': 'mfma', 'kernel': 'k_search_fused', 'achieved': achieved,
                      'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS,
-                     'traffic': traffic, 'traffic_source': traffic_source, 'us_per_launch': search_us,
-                     'flop_per_launch': flops_per_launch,
+                     'traffic': traffic, 'traffic_source': traffic_source, 'us_per_launch': launch_us,
+                     'flop_per_launch': flops_per_launch, 'moves_per_launch': moves_per_launch,
+                     'us_per_move': search_us,
+                     'launch': ('one launch = %d whole moves of all trees: root (observation, initial inference, Dirichlet '
+                                'noise, first descent), %d simulations, end of move' % (moves_per_launch, SIMS)) if persistent
+                               else 'one launch = all simulations of one move of all trees + the end of the move (root: k_root)',
                      'whole_path_frac': (env_steps / dt / world) * (SIMS * FLOP_PER_SIM + FLOP_PER_ROOT) / 1e12 /
                                         PEAK_F32_MFMA_TFLOPS},
     }

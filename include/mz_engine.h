@@ -198,7 +198,10 @@ int mz_padded_envs(const mz_engine *e);
  * (event): later moves then overlap the copy.  The ring normally keeps them in different slots; where it cannot
  * (records so large that the ring holds few moves), mz_selfplay_steps makes its stream wait for the event the
  * drain recorded behind its copy before it launches moves into slots the copy may still be reading.
- * mz_selfplay_steps issues up to 16 moves as one hipGraph launch (2 kernels per move: root, search + end of move).
+ * mz_selfplay_steps plays up to 16 moves per launch: single-player games with their trees in LDS run as whole moves
+ * inside ONE launch of the search kernel (root, simulations and end of every move; no launch, no grid-wide drain and
+ * no weight reload between moves); every other configuration as one hipGraph of 2 kernels per move (root, search +
+ * end of move).  Both produce the same records bit for bit (MZ_NO_PERSIST=1 at mz_create selects the graph).
  * stagger != 0: env i starts its first episode at t0 = hash(env id) % episode_len (uniform episode ends).
  * temperature: Config.visit_softmax_temperature at reset; mz_selfplay_set_temperature changes what every env's
  * NEXT game starts with (actors.py:128-129: evaluated once per game), games in progress keep theirs. */
@@ -219,6 +222,17 @@ int mz_selfplay_steps(mz_engine *e, int moves, void *stream);
  * with no synchronisation in between (the state of the timed loop); synchronous at the end.  ms_out [host][k] =
  * duration of each search launch in milliseconds.  bench.py's roofline figure is the mean of these. */
 int mz_selfplay_steps_timed(mz_engine *e, int k, float *ms_out, void *stream);
+/* Diagnostic: `moves` (<= 16) whole moves in ONE launch of the persistent self-play kernel with s_memtime stamps between
+ * the phases of a move; cycles_out [host][8] = shader cycles per move, mean over all waves, in the order of a move:
+ * root first stage (observation, obs_dim+1 -> 512), representation out + LayerNorm, prediction, root tree part (Dirichlet
+ * draw, root.expand, first descent), resident weight steps + tree set-up, ring priming + barrier, all simulations, end of
+ * the move (select_action, env step, record).  Synchronous; the moves' records land in the ring like any others.
+ * Fails where the self-play loop does not run as whole moves in one launch (two-player games, trees in the global pool,
+ * split_f16, MZ_NO_PERSIST). */
+int mz_selfplay_phase_profile(mz_engine *e, int moves, double *cycles_out, void *stream);
+/* 16 where mz_selfplay_steps plays whole moves inside one launch of the search kernel (at most that many per launch),
+ * 0 where a move is a hipGraph node pair (root kernel, search kernel). */
+int mz_selfplay_moves_per_launch(const mz_engine *e);
 int mz_selfplay_rec_floats(const mz_engine *e);
 int mz_selfplay_ring_moves(const mz_engine *e);
 int mz_selfplay_drain(mz_engine *e, float *out, int max_moves, int *n_moves, void *stream);

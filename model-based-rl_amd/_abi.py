@@ -82,6 +82,8 @@ SIGNATURES = {
     'mz_selfplay_export_trees': (_I, [_VP, _I]),
     'mz_selfplay_steps': (_I, [_VP, _I, _VP]),
     'mz_selfplay_steps_timed': (_I, [_VP, _I, _VP, _VP]),
+    'mz_selfplay_phase_profile': (_I, [_VP, _I, _VP, _VP]),
+    'mz_selfplay_moves_per_launch': (_I, [_VP]),
     'mz_selfplay_rec_floats': (_I, [_VP]),
     'mz_selfplay_ring_moves': (_I, [_VP]),
     'mz_selfplay_drain': (_I, [_VP, _VP, _I, C.POINTER(_I), _VP]),

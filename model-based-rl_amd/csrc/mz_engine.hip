@@ -77,6 +77,10 @@ struct mz_engine {
   unsigned long long *prof_buf = nullptr;   // non-null only inside mz_search_phase_profile
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;   // non-null only inside mz_search_timed: bracket the search kernel's dispatch
   bool lds_attr_set = false, lds_attr_set_prof = false;   // hipFuncAttributeMaxDynamicSharedMemorySize is per device: set once per engine
+  bool lds_attr_set_head = false;
+  bool use_persist = true;          // self-play loop: whole moves inside ONE launch of the search kernel (its HEAD instantiation)
+  int persist_moves = 0;            // > 0 only around that launch: moves it plays
+  unsigned long long *head_prof = nullptr;   // non-null only inside mz_selfplay_phase_profile
   // record drain on a copy stream (mz_selfplay_drain): event behind the last copy, and how far the compute stream
   // has been ordered behind the copies
   hipEvent_t drain_ev = nullptr;
@@ -474,9 +478,40 @@ static int launch_root(mz_engine *e, const float *obs, bool selfplay, hipStream_
   return e->jtp == 1 ? launch_root_j<1>(e, obs, selfplay, s) : launch_root_j<2>(e, obs, selfplay, s);
 }
 
+// dynamic LDS of a HEAD launch: the root's working set (mz_root_body) lies over the trees, behind the pb_c table
+static size_t fused_head_dyn_lds(int sims, int NN, int lt) {
+  const size_t table = ((size_t)(sims + 2) * (lt == 2 ? sims + 2 : 64) * 8 + 15) & ~(size_t)15;
+  const size_t root = table + sizeof(float) * MZ_ROOT_LDS_FLOATS, trees = mz_fused_dyn_lds(sims, NN, lt);
+  return root > trees ? root : trees;
+}
+
 template <int KS1, int JTP, int G, int LT, bool SP>
 static int launch_fused_sp(mz_engine *e, int num_simulations, int sims_done, hipStream_t s) {
   const size_t dyn = mz_fused_dyn_lds(e->sims, e->NN, LT);
+  const MzRootArgs ra0 = {nullptr, 0, 1, 0.0, 0.0};
+  if constexpr (LT != 0 && SP) {
+    if (e->persist_moves > 0) {      // the self-play loop: persist_moves whole moves in this launch
+      const size_t dynh = fused_head_dyn_lds(e->sims, e->NN, LT);
+      const MzRootArgs ra = {e->istream, e->nst0, e->persist_moves, e->cfg.root_dirichlet_alpha,
+                             e->cfg.root_exploration_fraction};
+      if (!e->lds_attr_set_head) {
+        HIPCHECK(hipFuncSetAttribute((const void *)k_search_fused<KS1, JTP, G, LT, false, SP, true>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)sizeof(float) * mz_fused_lds_floats(LT)));
+        e->lds_attr_set_head = true;
+      }
+      if (e->ev_start)
+        hipExtLaunchKernelGGL((k_search_fused<KS1, JTP, G, LT, false, SP, true>), dim3(e->Bp / MZ_ROWS), dim3(256), dynh, s,
+                              e->ev_start, e->ev_stop, 0, e->nv, e->tv, e->wstream, num_simulations, 0,
+                              (unsigned long long *)nullptr, e->sp, 1, (uint64_t)e->cfg.seed, ra);
+      else
+        hipLaunchKernelGGL((k_search_fused<KS1, JTP, G, LT, false, SP, true>), dim3(e->Bp / MZ_ROWS), dim3(256), dynh, s,
+                           e->nv, e->tv, e->wstream, num_simulations, 0, e->head_prof, e->sp, 1,
+                           (uint64_t)e->cfg.seed, ra);
+      HIPCHECK(hipGetLastError());
+      return 0;
+    }
+  }
+  if (e->persist_moves > 0) return fail("internal: no HEAD instantiation for this configuration");
   if (e->prof_buf) {
     if (!e->lds_attr_set_prof) {
       HIPCHECK(hipFuncSetAttribute((const void *)k_search_fused<KS1, JTP, G, LT, true, SP>,
@@ -484,7 +519,7 @@ static int launch_fused_sp(mz_engine *e, int num_simulations, int sims_done, hip
       e->lds_attr_set_prof = true;
     }
     hipLaunchKernelGGL((k_search_fused<KS1, JTP, G, LT, true, SP>), dim3(e->Bp / MZ_ROWS), dim3(256), dyn, s, e->nv,
-                       e->tv, e->wstream, num_simulations, sims_done, e->prof_buf, e->sp, 0, (uint64_t)e->cfg.seed);
+                       e->tv, e->wstream, num_simulations, sims_done, e->prof_buf, e->sp, 0, (uint64_t)e->cfg.seed, ra0);
   } else {
     if (!e->lds_attr_set) {
       HIPCHECK(hipFuncSetAttribute((const void *)k_search_fused<KS1, JTP, G, LT, false, SP>,
@@ -494,11 +529,11 @@ static int launch_fused_sp(mz_engine *e, int num_simulations, int sims_done, hip
     if (e->ev_start)      // timestamps of the dispatch itself (what rocprofv3's kernel trace reports), no launch gap inside
       hipExtLaunchKernelGGL((k_search_fused<KS1, JTP, G, LT, false, SP>), dim3(e->Bp / MZ_ROWS), dim3(256), dyn, s,
                             e->ev_start, e->ev_stop, 0, e->nv, e->tv, e->wstream, num_simulations, sims_done,
-                            (unsigned long long *)nullptr, e->sp, e->fuse_record ? 1 : 0, (uint64_t)e->cfg.seed);
+                            (unsigned long long *)nullptr, e->sp, e->fuse_record ? 1 : 0, (uint64_t)e->cfg.seed, ra0);
     else
     hipLaunchKernelGGL((k_search_fused<KS1, JTP, G, LT, false, SP>), dim3(e->Bp / MZ_ROWS), dim3(256), dyn, s, e->nv,
                        e->tv, e->wstream, num_simulations, sims_done, (unsigned long long *)nullptr, e->sp,
-                       e->fuse_record ? 1 : 0, (uint64_t)e->cfg.seed);
+                       e->fuse_record ? 1 : 0, (uint64_t)e->cfg.seed, ra0);
   }
   HIPCHECK(hipGetLastError());
   return 0;
@@ -596,6 +631,22 @@ static int launch_fused(mz_engine *e, int num_simulations, int sims_done, hipStr
 #endif
 }
 
+// LDS placement of the trees the exact-f32 fused kernel will choose (launch_fused_t)
+static int fused_lt(const mz_engine *e) {
+  if (e->use_lds_trees) {
+    if (sizeof(float) * mz_fused_lds_floats(1) + mz_fused_dyn_lds(e->sims, e->NN, 1) <= 160 * 1024) return 1;
+    if (e->use_lds_hybrid && sizeof(float) * mz_fused_lds_floats(2) + mz_fused_dyn_lds(e->sims, e->NN, 2) <= 160 * 1024) return 2;
+  }
+  return 0;
+}
+// Can the self-play loop run as whole moves inside one launch (HEAD instantiation of the fused kernel)?
+static bool selfplay_persist_ok(const mz_engine *e) {
+  if (!e->use_persist || !e->use_fused || e->sims + 2 > MZ_FUSED_MAXPL || e->cfg.two_players || e->split_f16 || e->prof_buf)
+    return false;
+  const int lt = fused_lt(e);
+  return lt != 0 && sizeof(float) * mz_fused_lds_floats(lt) + fused_head_dyn_lds(e->sims, e->NN, lt) <= 160 * 1024;
+}
+
 static int launch_root_priors(mz_engine *e, const int8_t *to_play, const uint8_t *legal, const double *priors,
                               hipStream_t s) {
   TREE_LAUNCH(k_tree_root_priors, s, e->tv, to_play, legal, priors);
@@ -656,6 +707,7 @@ int mz_create(const mz_config *cfg, mz_engine **out) {
   e->ks1sel = fused_ks1(e->A);
   e->use_graph = getenv("MZ_NO_GRAPH") == nullptr;
   e->use_fused = getenv("MZ_NO_FUSED") == nullptr;
+  e->use_persist = getenv("MZ_NO_PERSIST") == nullptr;
   e->use_lds_trees = getenv("MZ_NO_LDS_TREES") == nullptr;
   e->use_lds_hybrid = getenv("MZ_NO_LDS_HYBRID") == nullptr;
   {

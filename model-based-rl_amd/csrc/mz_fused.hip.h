@@ -534,10 +534,30 @@ __device__ __forceinline__ void mz_finalize_record(const TreeView &t, const Tree
   }
 }
 
-template <int KS1, int JTP, int G, int LT, bool PROF, bool SP>
+// (mz_root.hip.h) the root of a move for the 16 rows of a workgroup
+template <int JTP, int G, bool SELFPLAY, class STAMPF>
+__device__ __forceinline__ void mz_root_body(const NetView &n, const TreeView &t, const float *obs_in,
+                                             const f32x4 *istream, int nst0, const SelfplayState &sp, uint64_t seed,
+                                             double alpha, double frac, float *smem, int tid, double *root_stage,
+                                             STAMPF stampf);
+// HEAD instantiations: what the root needs, and how many moves the launch plays
+struct MzRootArgs {
+  const f32x4 *istream;      // the root network's weight stream (k_root's)
+  int nst0;                  // steps of its run-time first stage
+  int nmoves;                // moves per launch
+  double alpha, frac;        // root_dirichlet_alpha, root_exploration_fraction
+};
+
+// HEAD (self-play loop only): ONE launch plays ra.nmoves whole moves of its 16 environments -- observation, initial
+// inference, root expansion with Dirichlet noise and first descent (mz_root_body, on the LDS the trees are about to
+// occupy), all simulations, then the end of the move -- so a move costs no kernel launch, no grid-wide drain between
+// root and search, and the resident weight steps are loaded once per launch instead of once per move.  The
+// workgroups drift apart freely: nothing is exchanged between them.
+template <int KS1, int JTP, int G, int LT, bool PROF, bool SP, bool HEAD = false>
 __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, const f32x4 *wstream, int nsims,
                                                           int slot0, unsigned long long *prof, SelfplayState sp,
-                                                          int record, uint64_t seed) {
+                                                          int record, uint64_t seed, MzRootArgs ra) {
+  static_assert(!HEAD || (LT != 0 && !PROF), "HEAD: trees in LDS, no phase stamps");
   using SC = FusedSched<KS1, JTP>;
   constexpr int NB = MZ_NB, NSTEPS = SC::NSTEPS, RS = SC::RS, NRING = SC::NRING;
   static_assert(RS <= SC::FC1, "resident steps must be fc1 steps of the dynamics stage");
@@ -574,24 +594,60 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
   // beside large trees, where it shares the partials' space and the tree step starts behind a barrier
   double *s_stage = (LT == 2) ? (double *)red : (double *)(s_rcp + MZ_FUSED_MAXPL);
 
-  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-  const int g4 = lane >> 4, m16 = lane & 15;
+  const int tid0 = threadIdx.x;
   const int b0 = blockIdx.x * MZ_ROWS;
   const bool full = b0 + MZ_ROWS <= t.B;       // (wave-uniform) all 16 trees of this workgroup exist
   const size_t per_tree = (size_t)(t.sims + 1) * MZ_HS;
 
   // (the padding bins of the two 32-row support tiles get MZ_PAD_BIN as their bias: their softmax terms come out as
   // exact zeros in mz_support_to_scalar_q with no per-bin masking there)
-  if (tid < 96) s_b2[tid] = (tid < 32 && tid >= n.Sr) ? MZ_PAD_BIN : n.b2[tid];
-  if (tid < 32 + 16 * JTP) s_b4[tid] = (tid < 32 && tid >= n.Sv) ? MZ_PAD_BIN : n.b4[tid];
-  if (tid < 64) { s_lnw[tid] = n.lnw[tid]; s_lnb[tid] = n.lnb[tid]; }
-  if (tid < MZ_FUSED_MAXPL) s_rcp[tid] = 1.0 / (double)(tid > 0 ? tid : 1);
-  for (int i = tid; i < 16 * MZ_XE; i += 256) xEp[i] = (i % MZ_XE == 0) ? 1.f : 0.f;
-  for (int i = tid; i < (t.sims + 2) * (t.sims + 2); i += 256) s_pbc[(i / (t.sims + 2)) * PBS + i % (t.sims + 2)] = t.pbctab[i];
+  if (tid0 < 96) s_b2[tid0] = (tid0 < 32 && tid0 >= n.Sr) ? MZ_PAD_BIN : n.b2[tid0];
+  if (tid0 < 32 + 16 * JTP) s_b4[tid0] = (tid0 < 32 && tid0 >= n.Sv) ? MZ_PAD_BIN : n.b4[tid0];
+  if (tid0 < 64) { s_lnw[tid0] = n.lnw[tid0]; s_lnb[tid0] = n.lnb[tid0]; }
+  if (tid0 < MZ_FUSED_MAXPL) s_rcp[tid0] = 1.0 / (double)(tid0 > 0 ? tid0 : 1);
+  for (int i = tid0; i < 16 * MZ_XE; i += 256) xEp[i] = (i % MZ_XE == 0) ? 1.f : 0.f;
+  for (int i = tid0; i < (t.sims + 2) * (t.sims + 2); i += 256) s_pbc[(i / (t.sims + 2)) * PBS + i % (t.sims + 2)] = t.pbctab[i];
 
   // tree-lane mapping: TL lanes per tree (16, or 32 when A > 16), 256/TL trees per pass
   constexpr int TL = (G <= 16) ? 16 : 32;
   constexpr int NPASS = 16 * TL / 256;
+
+  unsigned long long pacc[MZ_NPHASE];
+  unsigned long long tlast = 0;
+  if (PROF) {
+    for (int i = 0; i < MZ_NPHASE; ++i) pacc[i] = 0;
+  }
+
+  const int nmoves = HEAD ? ra.nmoves : 1;
+  // HEAD launches: cycles per phase of a move (s_memtime), accumulated over the launch when `prof` is given
+  // (mz_selfplay_phase_profile): 0 root's tree part, 1 ring + barrier, 2 simulations, 3 end of move, 4 root first
+  // stage, 5 representation + LayerNorm, 6 prediction, 7 resident steps + tree set-up
+  unsigned long long hs_t = 0, hs_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define HSTAMP(k) if (HEAD && prof) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); hs_acc[k] += now_ - hs_t; hs_t = now_; }
+  if (HEAD && prof) hs_t = __builtin_amdgcn_s_memtime();
+  for (int mv = 0; mv < nmoves; ++mv) {
+  if constexpr (HEAD) {
+    // the root of this move (k_root's body) on the trees' LDS: the previous move's tail is done with it, this move's
+    // trees are built from what the root leaves in the pool (same workgroup, same L1: a barrier publishes it)
+    __syncthreads();
+    // (thread index laundered here and below: nothing derived from it is loop-invariant to the compiler, so the root's
+    // per-lane addresses are not kept in registers through the simulations, nor the search's through the root)
+    int tid_r = threadIdx.x;
+    asm volatile("" : "+v"(tid_r));
+    // (nst0 is never negative.  The branch is there for the compiler: with the call unconditional it treats the
+    // root's address arithmetic as invariants of the move loop and carries them through the simulations --
+    // 413.5 vs 410.5 us per move, A/B on one box)
+    if (ra.nst0 >= 0)
+    mz_root_body<JTP, G, true>(n, t, nullptr, ra.istream, ra.nst0, sp, seed, ra.alpha, ra.frac,
+                               (float *)(dyn_lds + (((t.sims + 2) * PBS * 8 + 15) & ~15)), tid_r, s_stage,
+                               [&](int k) __attribute__((always_inline)) { HSTAMP(4 + k) });
+    __syncthreads();
+    HSTAMP(0)
+  }
+  int tid = threadIdx.x;
+  if constexpr (HEAD) asm volatile("" : "+v"(tid));
+  const int w = tid >> 6, lane = tid & 63;
+  const int g4 = lane >> 4, m16 = lane & 15;
   const int tl = tid % TL;
   int my_slot[NPASS], my_act[NPASS];
   TreeRegs tr[NPASS];
@@ -613,8 +669,69 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
       const size_t o = (size_t)(b < t.B ? b : 0) * t.NN;
       tm[i].N = t.N + o; tm[i].W = t.W + o; tm[i].P = t.P + o; tm[i].R = t.R + o; tm[i].E = t.E + o; tm[i].TP = t.TP + o;
     }
+  }
+
+  // hidden state of the pending descent's parent, 16 bytes per lane (lanes 13.. of a tree duplicate column 12);
+  // refreshed by every descent (speculative gather, mz_tree_step_fused)
+  f32x4 hv[NPASS];
+  unsigned hoff[NPASS];
+#pragma unroll
+  for (int i = 0; i < NPASS; ++i) {
+    const int b = b0 + tid / TL + i * (256 / TL);
+    hoff[i] = (unsigned)(((size_t)(b < t.B ? b : 0) * per_tree) * 4) + (unsigned)((tl < MZ_HS / 4 ? tl : MZ_HS / 4 - 1) * 16);
+  }
+
+  // this wave's stream: [NSTEPS][4 pieces][64 lanes] f32x4.  Wave-uniform base in SGPRs + per-lane byte
+  // offset in one VGPR: every piece is then "s_base + const, v_off" (saddr form) and no per-piece 64-bit
+  // VGPR address exists that the compiler could hoist out of the simulation loop and spill.
+  // stream of one wave: [RS resident steps][NRING streamed steps], 4 pieces of 64 lanes x f32x4 each
+  // Buffer addressing: the wave's stream is one buffer resource (4 SGPRs), the lane offset one VGPR, the piece a
+  // scalar offset + immediate -- no VALU address arithmetic in the MFMA stream (with flat/global addressing the
+  // compiler kept base + lane offset as a 64-bit VGPR pair and spent two VALU adds per step on it; every
+  // non-MFMA instruction in a dense MFMA stream costs issue time, see DESIGN.md).
+  const char *wbase = (const char *)(wstream + (size_t)__builtin_amdgcn_readfirstlane(w) * NSTEPS * 256);
+  const __amdgpu_buffer_rsrc_t wrsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void *)wbase, 0, NSTEPS * 4096, 0x00020000);
+  const int lane_off = lane * 16;
+#define MZ_BLOAD(byteoff) __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane_off, (byteoff), 0))
+  // the resident steps (per move in a HEAD launch: the root needs the register file for its own ring, and 208 KB from
+  // L2 under the tree set-up below are cheaper than spilling around it)
+  f32x4 Rw[RS][4];
+#pragma unroll
+  for (int s = 0; s < RS; ++s) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) Rw[s][p] = MZ_BLOAD((s * 4 + p) * 1024);
+  }
+#pragma unroll
+  for (int i = 0; i < NPASS; ++i) {
+    const int mt = tid / TL + i * (256 / TL);
+    const int b = b0 + mt;
     my_slot[i] = 0; my_act[i] = 0;
     tr[i].len = 1; tr[i].tp = 1; tr[i].root_tp = 1; tr[i].legal = 0; tr[i].mn = 0.0; tr[i].mx = 0.0; tr[i].root_n = 0;
+    if constexpr (HEAD) {
+      // the root this launch has just made (mz_tree_root, single player): a fresh Node(0) with its A children, the
+      // first descent already taken -- everything but the priors and that descent's action is known without
+      // reading the pool back (mz_tree_root left those two in the staging area)
+      if (b < t.B) {
+        const double *st = s_stage + mt * 96;
+        const int best = (int)st[32];
+        my_act[i] = best;
+        tr[i].len = 2;
+        tr[i].legal = (t.A >= 32) ? 0xFFFFFFFFu : ((1u << t.A) - 1u);
+        tr[i].mn = t.has_min ? t.min_bound : __builtin_inf();
+        tr[i].mx = t.has_max ? t.max_bound : -__builtin_inf();
+        if (tl == 0) { s_path[mt * MZ_FUSED_MAXPL] = 0; s_path[mt * MZ_FUSED_MAXPL + 1] = 1 + best; }
+        const int have = 1 + t.A;
+        if constexpr (LT == 1) {
+          for (int k = tl; k < t.NN; k += TL) {
+            tm[i].N[k] = 0; tm[i].W[k] = 0.0; tm[i].R[k] = 0.f; tm[i].E[k] = (k == 0) ? 0 : -1; tm[i].TP[k] = 1;
+          }
+        } else {
+          for (int k = tl; k < have; k += TL) { tm[i].N[k] = 0; tm[i].E[k] = (k == 0) ? 0 : -1; }
+        }
+        for (int k = tl; k < have; k += TL) { tm[i].P[k] = (k == 0) ? 0.0 : st[k - 1]; tm[i].X[k] = 0.0; }
+      }
+    } else
     if (b < t.B) {
       my_slot[i] = t.slot[b];
       my_act[i] = t.act[b];
@@ -655,42 +772,17 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
     }
   }
 
-  // hidden state of the pending descent's parent, 16 bytes per lane (lanes 13.. of a tree duplicate column 12);
-  // refreshed by every descent (speculative gather, mz_tree_step_fused)
-  f32x4 hv[NPASS];
-  unsigned hoff[NPASS];
 #pragma unroll
-  for (int i = 0; i < NPASS; ++i) {
-    const int b = b0 + tid / TL + i * (256 / TL);
-    hoff[i] = (unsigned)(((size_t)(b < t.B ? b : 0) * per_tree) * 4) + (unsigned)((tl < MZ_HS / 4 ? tl : MZ_HS / 4 - 1) * 16);
+  for (int i = 0; i < NPASS; ++i)
     hv[i] = *(const f32x4 *)((const char *)t.hpool + hoff[i] + (size_t)my_slot[i] * (MZ_HS * 4));
-  }
 
-  // this wave's stream: [NSTEPS][4 pieces][64 lanes] f32x4.  Wave-uniform base in SGPRs + per-lane byte
-  // offset in one VGPR: every piece is then "s_base + const, v_off" (saddr form) and no per-piece 64-bit
-  // VGPR address exists that the compiler could hoist out of the simulation loop and spill.
-  // stream of one wave: [RS resident steps][NRING streamed steps], 4 pieces of 64 lanes x f32x4 each
-  // Buffer addressing: the wave's stream is one buffer resource (4 SGPRs), the lane offset one VGPR, the piece a
-  // scalar offset + immediate -- no VALU address arithmetic in the MFMA stream (with flat/global addressing the
-  // compiler kept base + lane offset as a 64-bit VGPR pair and spent two VALU adds per step on it; every
-  // non-MFMA instruction in a dense MFMA stream costs issue time, see DESIGN.md).
-  const char *wbase = (const char *)(wstream + (size_t)__builtin_amdgcn_readfirstlane(w) * NSTEPS * 256);
-  const __amdgpu_buffer_rsrc_t wrsrc =
-      __builtin_amdgcn_make_buffer_rsrc((void *)wbase, 0, NSTEPS * 4096, 0x00020000);
-  const int lane_off = lane * 16;
-#define MZ_BLOAD(byteoff) __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane_off, (byteoff), 0))
-  f32x4 Rw[RS][4];
-#pragma unroll
-  for (int s = 0; s < RS; ++s) {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) Rw[s][p] = MZ_BLOAD((s * 4 + p) * 1024);
-  }
   // the streamed part follows the resident one: ring step r at byte RS*4096 + r*4096
   // (piece offset as the instruction's immediate, step offset as the scalar offset: one s_mov per step instead of four)
 #define MZ_WLOAD(step, piece) __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane_off + (piece) * 1024, sbase + (step) * 4096, 0))
   // scalar offset of ring step 0.  Laundered through asm at the top of every simulation: as a known constant the
   // compiler materialises one SGPR per step of the unrolled schedule (33 of them), spills other scalars to make room
   // and pays v_readlane reloads inside the MFMA stream; as an opaque base a step costs one s_add
+  HSTAMP(7)
   int sbase = RS * 4096;
   f32x4 Bf[NB][4];
 #pragma unroll
@@ -699,13 +791,9 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
     for (int p = 0; p < 4; ++p) Bf[s][p] = MZ_WLOAD(s, p);
   }
 
-  unsigned long long pacc[MZ_NPHASE];
-  unsigned long long tlast = 0;
-  if (PROF) {
-    for (int i = 0; i < MZ_NPHASE; ++i) pacc[i] = 0;
-    tlast = __builtin_amdgcn_s_memtime();
-  }
+  if (PROF) tlast = __builtin_amdgcn_s_memtime();
   __syncthreads();
+  HSTAMP(1)
 
   for (int sim = 0; sim < nsims; ++sim) {
     asm volatile("" : "+s"(sbase));
@@ -969,6 +1057,7 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
     }
     STAMP(13)
   }
+  HSTAMP(2)
   if (record) {     // self-play loop: action, visit distribution, env step and experience record of this move
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
@@ -995,6 +1084,10 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
       }
     }
   }
-  if (PROF && lane == 0)
-    for (int i = 0; i < MZ_NPHASE; ++i) prof[((size_t)blockIdx.x * 4 + w) * MZ_NPHASE + i] = pacc[i];
+  HSTAMP(3)
+  }      // (moves of a HEAD launch)
+  if (HEAD && prof && (tid0 & 63) == 0)
+    for (int i = 0; i < 8; ++i) prof[((size_t)blockIdx.x * 4 + (tid0 >> 6)) * 8 + i] = hs_acc[i];
+  if (PROF && (tid0 & 63) == 0)
+    for (int i = 0; i < MZ_NPHASE; ++i) prof[((size_t)blockIdx.x * 4 + (tid0 >> 6)) * MZ_NPHASE + i] = pacc[i];
 }

@@ -30,14 +30,19 @@ __host__ __device__ inline int mz_root_nst0(int O) { return ((O + 1 + 3) / 4 + 1
 
 #define MZ_ROOT_LDS_FLOATS (16 * MZ_ROOT_XS + 16 * MZ_HS + 4 * 6 * 256 + 96 * 16 + 16 + 16 * 32 + 64 + 64 + 64 + 64 + 16 * MZ_XE)
 
-template <int JTP, int G, bool SELFPLAY>
-__global__ __launch_bounds__(256, 1) void k_root(NetView n, TreeView t, const float *obs_in, const f32x4 *istream,
-                                                  int nst0, SelfplayState sp, uint64_t seed, double alpha,
-                                                  double frac) {
+// The whole root of one move for the 16 rows of this workgroup (256 threads), on MZ_ROOT_LDS_FLOATS floats of LDS the
+// caller provides: the body of k_root, and the head of every move of the persistent self-play kernel (mz_fused.hip.h,
+// HEAD), which runs it on the space its trees are about to occupy.
+// stampf(k): phase hook (k = 0 first stage done, 1 representation + LayerNorm done, 2 prediction done); MzNoStamp outside
+// the profiled persistent kernel
+template <int JTP, int G, bool SELFPLAY, class STAMPF>
+__device__ __forceinline__ void mz_root_body(const NetView &n, const TreeView &t, const float *obs_in,
+                                             const f32x4 *istream, int nst0, const SelfplayState &sp, uint64_t seed,
+                                             double alpha, double frac, float *smem, int tid, double *root_stage,
+                                             STAMPF stampf) {
   using SC = RootSched<JTP>;
   constexpr int NB = MZ_ROOT_NB, NS = SC::NS, E_R2 = SC::R2, E_P1 = E_R2 + SC::P1, NJ2 = 2 + JTP;
   constexpr int XS = MZ_ROOT_XS;
-  __shared__ __attribute__((aligned(16))) float smem[MZ_ROOT_LDS_FLOATS];
   float *xO = smem;                       // [16][XS] observation chunk, row-major, column O = 1 (bias)
   float *xR = xO + 16 * XS;               // [16][MZ_HS] hidden tile
   float *red = xR + 16 * MZ_HS;           // split-K partials
@@ -50,7 +55,7 @@ __global__ __launch_bounds__(256, 1) void k_root(NetView n, TreeView t, const fl
   float *s_lnb = s_lnw + 64;
   float *xEp = s_lnb + 64;                // [16][MZ_XE] prediction extension: 1 (bias column), then 0
 
-  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+  const int w = tid >> 6, lane = tid & 63;
   const int g4 = lane >> 4, m16 = lane & 15;
   const int b0 = blockIdx.x * MZ_ROWS;
   const size_t per_tree = (size_t)(t.sims + 1) * MZ_HS;
@@ -136,6 +141,7 @@ __global__ __launch_bounds__(256, 1) void k_root(NetView n, TreeView t, const fl
     }
   }
   mz_mfma_fence16v(acc);
+  stampf(0);
 #pragma unroll
   for (int tt = 0; tt < 8; ++tt) {
     acc[tt][0] = fmaxf(acc[tt][0], 0.f); acc[tt][1] = fmaxf(acc[tt][1], 0.f);
@@ -174,6 +180,7 @@ __global__ __launch_bounds__(256, 1) void k_root(NetView n, TreeView t, const fl
           sln_relu16(fin, xR, s_lnw, s_lnb, 0, col, q);
         }
         mz_bar();
+        stampf(1);
         if (tid < 16 * (MZ_HS / 4)) {      // hidden state of the root -> pool slot 0
           const int m = tid / (MZ_HS / 4), c = tid % (MZ_HS / 4);
           if (b0 + m < t.B) {
@@ -240,6 +247,7 @@ __global__ __launch_bounds__(256, 1) void k_root(NetView n, TreeView t, const fl
     }
   });
 
+  stampf(2);
   if constexpr (SELFPLAY) {
     // Node(0), root.expand(all actions legal), add_exploration_noise (Dirichlet from the device RNG: lane a
     // draws Gamma(alpha) for action a, the group normalises), then the first descent of MCTS.run
@@ -259,9 +267,18 @@ __global__ __launch_bounds__(256, 1) void k_root(NetView n, TreeView t, const fl
         if (tl < A) t.noise[(size_t)b * A + tl] = sum > 0.0 ? gam / sum : 1.0 / A;
         __threadfence_block();
         const uint32_t mask = (A >= 32) ? 0xFFFFFFFFu : ((1u << A) - 1u);
-        mz_tree_root<G, true>(t, b, tl, 1, mask, s_lg + mt * 32, t.noise + (size_t)b * A, frac);
+        mz_tree_root<G, true>(t, b, tl, 1, mask, s_lg + mt * 32, t.noise + (size_t)b * A, frac,
+                              root_stage ? root_stage + mt * 96 : nullptr);
       }
     }
   }
 #undef MZ_RLOAD
+}
+
+template <int JTP, int G, bool SELFPLAY>
+__global__ __launch_bounds__(256, 1) void k_root(NetView n, TreeView t, const float *obs_in, const f32x4 *istream,
+                                                  int nst0, SelfplayState sp, uint64_t seed, double alpha,
+                                                  double frac) {
+  __shared__ __attribute__((aligned(16))) float smem[MZ_ROOT_LDS_FLOATS];
+  mz_root_body<JTP, G, SELFPLAY>(n, t, obs_in, istream, nst0, sp, seed, alpha, frac, smem, (int)threadIdx.x, nullptr, MzNoStamp());
 }

@@ -145,9 +145,12 @@ __device__ __forceinline__ void mz_tree_expand_backup(const TreeView &t, int b, 
 // SELECT: also perform the first descent of MCTS.run from the registers.  At a fresh root (N = 0) select_child
 // ranks the children by (prior, action) (mcts.py:105-108) and the chosen child is a leaf, so the descent needs
 // nothing from memory: path = [0, 1 + a*], parent slot 0.
+// stage (LDS, optional): the search kernel that continues in the same launch takes the root from there instead of
+// reading the pool back -- stage[a] = prior of child a (after the noise), stage[32] = the first descent's action.
 template <int G, bool SELECT = false>
 __device__ __forceinline__ void mz_tree_root(const TreeView &t, int b, int lane, int to_play, uint32_t legal,
-                                             const float *logits, const double *noise, double frac) {
+                                             const float *logits, const double *noise, double frac,
+                                             double *stage = nullptr) {
   const int A = t.A;
   const size_t o = (size_t)b * t.NN;
   const bool ok = lane < A && ((legal >> lane) & 1u);
@@ -160,6 +163,7 @@ __device__ __forceinline__ void mz_tree_root(const TreeView &t, int b, int lane,
     if (ok && noise) prior = prior * (1 - frac) + noise[lane] * frac;
     t.N[o + ch] = 0; t.W[o + ch] = 0.0; t.R[o + ch] = 0.f; t.E[o + ch] = -1; t.TP[o + ch] = ok ? 1 : 0;
     t.P[o + ch] = prior;
+    if (stage) stage[lane] = prior;
   }
   if (lane == 0) {
     t.N[o] = 0; t.W[o] = 0.0; t.R[o] = 0.f; t.E[o] = 0; t.TP[o] = (int8_t)to_play; t.P[o] = 0.0;
@@ -193,6 +197,7 @@ __device__ __forceinline__ void mz_tree_root(const TreeView &t, int b, int lane,
       t.slot[b] = 0;
       t.act[b] = best;
       t.depth[b] = 1;
+      if (stage) stage[32] = (double)best;
     }
   }
 }

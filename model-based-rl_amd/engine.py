@@ -313,6 +313,20 @@ class Engine(object):
     _abi.check(self.lib.mz_selfplay_steps_timed(self._h, int(moves), ms, self.stream), 'mz_selfplay_steps_timed')
     return [float(x) for x in ms]
 
+  def selfplay_moves_per_launch(self):
+    """16 where selfplay_steps plays whole moves inside one launch of the search kernel, 0 where every move is a root
+    kernel + a search kernel (two-player games, trees in the global pool, split_f16, MZ_NO_PERSIST)."""
+    return int(self.lib.mz_selfplay_moves_per_launch(self._h))
+
+  SELFPLAY_PHASES = ('root_stage0', 'root_rep_ln', 'root_prediction', 'root_tree', 'resident+tree_setup', 'ring+barrier',
+                     'simulations', 'end_of_move')
+
+  def selfplay_phase_profile(self, moves=16):
+    """Shader cycles per move and phase of the persistent self-play launch (diagnostic, synchronous): dict phase -> cycles."""
+    out = (C.c_double * 8)()
+    _abi.check(self.lib.mz_selfplay_phase_profile(self._h, int(moves), out, self.stream), 'mz_selfplay_phase_profile')
+    return dict(zip(self.SELFPLAY_PHASES, [float(x) for x in out]))
+
   def selfplay_drain(self, out=None, max_moves=None, copy_stream=None):
     """Asynchronous D2H of the records produced since the last drain into pinned memory; returns
     (host tensor [n_moves, B, rec_floats], n_moves).  Synchronise the stream before reading.

@@ -1,9 +1,8 @@
 #!/bin/bash
-# A/B of two builds of libmz_hip.so on ONE box (boxes of the pool differ by ~1 %): alternates the two libraries.
-#   scripts/ab_bench.sh <libA.so> <libB.so> [rounds]
-A=$1; B=$2; N=${3:-3}
+# several builds of libmz_hip.so alternating on ONE box:  scripts/ab_many.sh <rounds> lib1.so lib2.so ...
+N=$1; shift
 for i in $(seq $N); do
-  for L in $A $B; do
+  for L in "$@"; do
     MZ_HIP_LIB=$L python bench.py --no-cpu-baseline --steps 1024 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$L', round(d['value']), round(d['roofline'].get('us_per_move', d['roofline']['us_per_launch']), 2))"
   done
 done

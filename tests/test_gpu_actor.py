@@ -496,3 +496,60 @@ def test_train_driver_with_learner():
   lt = thr['learner']                 # the reference's own throughput scalars (learners.py:88-113)
   assert lt['frames_per_second'] > 0 and lt['updates_per_second'] > 0
   assert abs(lt['replay_ratio'] - lt['updates_per_second'] / lt['frames_per_second']) < 1e-9
+
+
+@pytest.mark.parametrize('O,A,sims,u8', [(8, 4, 30, False), (128, 6, 50, True), (5, 2, 6, False)])
+def test_persistent_selfplay_launch_equals_graph_of_kernels(O, A, sims, u8, monkeypatch):
+  """Single-player self-play runs as whole moves inside ONE launch of the search kernel (its HEAD instantiation: root,
+  simulations and end of every move, trees never leaving LDS between root and search); MZ_NO_PERSIST=1 keeps the
+  hipGraph of root + search kernels per move.  Same device functions, same keys: every record is bit-identical --
+  across launch boundaries, a weight update, a temperature change, ragged B, byte observations with --norm_obs, trees
+  in LDS (LunarLander shapes), descent fields only in LDS (Pong-ram shapes) and trees smaller than the root's working
+  set; with tree export on, the exported trees agree too."""
+  import torch
+  from model_based_rl_amd.engine import Engine, flatten_weights
+  from model_based_rl_amd.networks import FCNetwork
+  B = 40
+  torch.manual_seed(11)
+  cfg = types.SimpleNamespace(value_support=(-15, 15), reward_support=(-15, 15), no_support=False, no_target_transform=False)
+  w0 = flatten_weights(FCNetwork(O, A, torch.device('cpu'), cfg).state_dict())
+  w1 = flatten_weights(FCNetwork(O, A, torch.device('cpu'), cfg).state_dict())
+  out = []
+  for persist in (True, False):
+    if persist:
+      monkeypatch.delenv('MZ_NO_PERSIST', raising=False)
+    else:
+      monkeypatch.setenv('MZ_NO_PERSIST', '1')
+    eng = Engine(B, O, A, sims, seed=21, env_id_offset=3)
+    eng.set_weights(w0)
+    if u8:
+      eng.selfplay_set_obs(uint8_obs=True, obs_min=[0.0], obs_range=[255.0])
+    eng.selfplay_reset(9, 1.0, stagger=True)
+    recs = []
+    for chunk, k in enumerate((16, 5, 1, 20)):          # 20 > 16: two launches inside one call
+      if chunk == 1:
+        eng.selfplay_set_temperature(0.5)
+      if chunk == 2:
+        eng.set_weights(w1)
+      if chunk == 3:
+        eng.selfplay_export_trees(True)
+      eng.selfplay_steps(k)
+      buf, n = eng.selfplay_drain()
+      torch.cuda.synchronize()
+      assert n == k
+      recs.append(buf[:n].numpy().copy())
+    tree = eng.export_tree()
+    if persist:
+      ph = eng.selfplay_phase_profile(4)
+      assert set(ph) == set(Engine.SELFPLAY_PHASES) and all(v > 0 for v in ph.values()), ph
+      assert ph['simulations'] > 5 * ph['root_prediction']
+    else:
+      with pytest.raises(RuntimeError):
+        eng.selfplay_phase_profile(4)
+    eng.close()
+    out.append((np.concatenate(recs, 0), tree))
+  assert np.array_equal(out[0][0].view(np.int32), out[1][0].view(np.int32))
+  for k in ('N', 'W', 'E', 'R', 'EX', 'minmax'):
+    assert np.array_equal(out[0][1][k], out[1][1][k]), k
+  ex = out[0][1]['EX'].astype(bool)            # (priors exist only where a node does)
+  assert np.array_equal(out[0][1]['P'][ex], out[1][1]['P'][ex])
