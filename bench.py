@@ -171,12 +171,13 @@ def measure_split_f16(device, flat, chunk, moves=384):
     eng.selfplay_drain(pinned, chunk)
     torch.cuda.synchronize(device)
   us = 1e3 * float(np.mean(durs[chunk:]))
+  persistent = eng.selfplay_moves_per_launch() > 0      # whole moves inside the launch: `us` then includes the (f32) root
   eng.close()
   return {'what': 'mz_config.split_f16 = 1: FCNetwork GEMMs as float16 high/low splits on v_mfma_f32_16x16x32_f16, f32 '
                   'accumulation; float32-level accuracy (every parity test passes), not bit-identical to the exact-f32 path',
           'env_steps_per_s': B * (moves // chunk) * chunk / dt, 'ms_per_step': 1e3 * dt / ((moves // chunk) * chunk),
-          'search_kernel_us_per_launch': us, 'moves': (moves // chunk) * chunk,
-          'algorithmic_tflops': SIMS * FLOP_PER_SIM * B / (us * 1e-6) / 1e12}
+          'kernel_us_per_move': us, 'root_inside_the_launch': persistent, 'moves': (moves // chunk) * chunk,
+          'algorithmic_tflops': (SIMS * FLOP_PER_SIM + (FLOP_PER_ROOT if persistent else 0)) * B / (us * 1e-6) / 1e12}
 
 
 def main():
@@ -431,9 +432,10 @@ def main():
       out['roofline'] = {
           'bound': 'mfma', 'kernel': 'k_search_h2', 'achieved': exec_flop / (search_us * 1e-6) / 1e12, 'peak': 2516.0,
           'unit': 'TFLOP/s', 'frac': exec_flop / (search_us * 1e-6) / 1e12 / 2516.0, 'traffic': None,
-          'us_per_launch': search_us, 'flop_per_launch': exec_flop,
+          'us_per_launch': launch_us, 'flop_per_launch': exec_flop * moves_per_launch, 'moves_per_launch': moves_per_launch,
+          'us_per_move': search_us, 'root_inside_the_launch': persistent,
           'algorithmic_f32_tflops': achieved, 'algorithmic_frac_of_f32_mfma_peak': achieved / PEAK_F32_MFMA_TFLOPS,
-          'l2_weight_stream': {'bytes_per_launch': stream_bytes, 'achieved_TBps': stream_bytes / (search_us * 1e-6) / 1e12,
+          'l2_weight_stream': {'bytes_per_launch': stream_bytes * moves_per_launch, 'achieved_TBps': stream_bytes / (search_us * 1e-6) / 1e12,
                                'peak_TBps': 39.3, 'note': '21 streamed groups x 8 KiB x 4 waves per CU and simulation; inside the '
                                'matrix stages (12.8 k of 20.8 k cycles per simulation) the stream runs at ~52 of the 64 B/clk/CU '
                                'an XCD\'s L2 delivers: that, not the matrix pipe (0.22 busy), bounds the stages (DESIGN.md s3.4)'},

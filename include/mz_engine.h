@@ -227,8 +227,8 @@ int mz_selfplay_steps_timed(mz_engine *e, int k, float *ms_out, void *stream);
  * root first stage (observation, obs_dim+1 -> 512), representation out + LayerNorm, prediction, root tree part (Dirichlet
  * draw, root.expand, first descent), resident weight steps + tree set-up, ring priming + barrier, all simulations, end of
  * the move (select_action, env step, record).  Synchronous; the moves' records land in the ring like any others.
- * Fails where the self-play loop does not run as whole moves in one launch (two-player games, trees in the global pool,
- * split_f16, MZ_NO_PERSIST). */
+ * Exact-f32 kernel only; fails where the self-play loop does not run as whole moves in one launch (two-player games,
+ * trees in the global pool, MZ_NO_PERSIST) and for split_f16. */
 int mz_selfplay_phase_profile(mz_engine *e, int moves, double *cycles_out, void *stream);
 /* 16 where mz_selfplay_steps plays whole moves inside one launch of the search kernel (at most that many per launch),
  * 0 where a move is a hipGraph node pair (root kernel, search kernel). */

@@ -545,13 +545,35 @@ static int launch_h2_sp(mz_engine *e, int num_simulations, int sims_done, hipStr
   const size_t dyn = mz_fused_dyn_lds(e->sims, e->NN, LT);
   const f32x4 *ws = (const f32x4 *)e->packed_h2;
   const int maxdyn = 160 * 1024 - (int)sizeof(float) * mz_h2_lds_floats(LT);
+  const MzRootArgs ra0 = {nullptr, 0, 1, 0.0, 0.0};
+  if constexpr (SP) {
+    if (e->persist_moves > 0) {      // the self-play loop: persist_moves whole moves in this launch
+      const size_t dynh = fused_head_dyn_lds(e->sims, e->NN, LT);
+      const MzRootArgs ra = {e->istream, e->nst0, e->persist_moves, e->cfg.root_dirichlet_alpha,
+                             e->cfg.root_exploration_fraction};
+      if (!e->lds_attr_set_head) {
+        HIPCHECK(hipFuncSetAttribute((const void *)k_search_h2<G, LT, false, SP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, maxdyn));
+        e->lds_attr_set_head = true;
+      }
+      if (e->ev_start)
+        hipExtLaunchKernelGGL((k_search_h2<G, LT, false, SP, true>), dim3(e->Bp / MZ_ROWS), dim3(256), dynh, s, e->ev_start,
+                              e->ev_stop, 0, e->nv, e->tv, ws, num_simulations, 0, (unsigned long long *)nullptr, e->sp, 1,
+                              (uint64_t)e->cfg.seed, ra);
+      else
+        hipLaunchKernelGGL((k_search_h2<G, LT, false, SP, true>), dim3(e->Bp / MZ_ROWS), dim3(256), dynh, s, e->nv, e->tv, ws,
+                           num_simulations, 0, (unsigned long long *)nullptr, e->sp, 1, (uint64_t)e->cfg.seed, ra);
+      HIPCHECK(hipGetLastError());
+      return 0;
+    }
+  }
+  if (e->persist_moves > 0) return fail("internal: no HEAD instantiation for this configuration");
   if (e->prof_buf) {
     if (!e->lds_attr_set_prof) {
       HIPCHECK(hipFuncSetAttribute((const void *)k_search_h2<G, LT, true, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, maxdyn));
       e->lds_attr_set_prof = true;
     }
     hipLaunchKernelGGL((k_search_h2<G, LT, true, SP>), dim3(e->Bp / MZ_ROWS), dim3(256), dyn, s, e->nv, e->tv, ws,
-                       num_simulations, sims_done, e->prof_buf, e->sp, 0, (uint64_t)e->cfg.seed);
+                       num_simulations, sims_done, e->prof_buf, e->sp, 0, (uint64_t)e->cfg.seed, ra0);
   } else {
     if (!e->lds_attr_set) {
       HIPCHECK(hipFuncSetAttribute((const void *)k_search_h2<G, LT, false, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, maxdyn));
@@ -560,11 +582,11 @@ static int launch_h2_sp(mz_engine *e, int num_simulations, int sims_done, hipStr
     if (e->ev_start)
       hipExtLaunchKernelGGL((k_search_h2<G, LT, false, SP>), dim3(e->Bp / MZ_ROWS), dim3(256), dyn, s, e->ev_start,
                             e->ev_stop, 0, e->nv, e->tv, ws, num_simulations, sims_done, (unsigned long long *)nullptr,
-                            e->sp, e->fuse_record ? 1 : 0, (uint64_t)e->cfg.seed);
+                            e->sp, e->fuse_record ? 1 : 0, (uint64_t)e->cfg.seed, ra0);
     else
       hipLaunchKernelGGL((k_search_h2<G, LT, false, SP>), dim3(e->Bp / MZ_ROWS), dim3(256), dyn, s, e->nv, e->tv, ws,
                          num_simulations, sims_done, (unsigned long long *)nullptr, e->sp, e->fuse_record ? 1 : 0,
-                         (uint64_t)e->cfg.seed);
+                         (uint64_t)e->cfg.seed, ra0);
   }
   HIPCHECK(hipGetLastError());
   return 0;
@@ -641,8 +663,13 @@ static int fused_lt(const mz_engine *e) {
 }
 // Can the self-play loop run as whole moves inside one launch (HEAD instantiation of the fused kernel)?
 static bool selfplay_persist_ok(const mz_engine *e) {
-  if (!e->use_persist || !e->use_fused || e->sims + 2 > MZ_FUSED_MAXPL || e->cfg.two_players || e->split_f16 || e->prof_buf)
+  if (!e->use_persist || !e->use_fused || e->sims + 2 > MZ_FUSED_MAXPL || e->cfg.two_players || e->prof_buf)
     return false;
+  if (e->split_f16 && e->use_lds_trees) {      // the split-f16 kernel where it applies (launch_h2), else the exact one below
+    for (int lt = 1; lt <= (e->use_lds_hybrid ? 2 : 1); ++lt)
+      if (sizeof(float) * mz_h2_lds_floats(lt) + mz_fused_dyn_lds(e->sims, e->NN, lt) <= 160 * 1024)
+        return sizeof(float) * mz_h2_lds_floats(lt) + fused_head_dyn_lds(e->sims, e->NN, lt) <= 160 * 1024;
+  }
   const int lt = fused_lt(e);
   return lt != 0 && sizeof(float) * mz_fused_lds_floats(lt) + fused_head_dyn_lds(e->sims, e->NN, lt) <= 160 * 1024;
 }

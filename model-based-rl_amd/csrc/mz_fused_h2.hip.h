@@ -152,10 +152,13 @@ __device__ __forceinline__ void h2_group(f32x4 &c0, f32x4 &c1, f32x4 &c2, f32x4 
 #define MZ_H2_LDS_BASE (16 * MZ_HS + 4 * 6 * 256 + 16 + 16 + 16 * 32 + 96 + 64 + 64 + 64 + 16 * MZ_FUSED_MAXPL + 2 * MZ_FUSED_MAXPL + 2 * 16 * MZ_H2_XS / 2)
 __host__ __device__ constexpr int mz_h2_lds_floats(int lt) { return MZ_H2_LDS_BASE + (lt == 2 ? 0 : 16 * 96 * 2); }
 
-template <int G, int LT, bool PROF, bool SP>
+// HEAD: whole self-play moves inside the launch, as in k_search_fused (mz_fused.hip.h); the resident groups live in AGPRs
+// the compiler never allocates to the root, so here they do stay across the moves of a launch.
+template <int G, int LT, bool PROF, bool SP, bool HEAD = false>
 __global__ __launch_bounds__(256, 1) void k_search_h2(NetView n, TreeView t, const f32x4 *wstream, int nsims, int slot0,
                                                        unsigned long long *prof, SelfplayState sp, int record,
-                                                       uint64_t seed) {
+                                                       uint64_t seed, MzRootArgs ra) {
+  static_assert(!HEAD || (LT != 0 && !PROF && SP), "HEAD: single player, trees in LDS, no phase stamps");
   using SC = H2Sched;
   constexpr int NBG = SC::NBG, RSG = SC::RSG, NGROUPS = SC::NGROUPS, NRING = SC::NRING;
   static_assert(G <= 16, "16 lanes per tree");
@@ -190,20 +193,62 @@ __global__ __launch_bounds__(256, 1) void k_search_h2(NetView n, TreeView t, con
   mz_h16 *xL = xH + 16 * XS;
   double *s_stage = (LT == 2) ? (double *)red : (double *)(xL + 16 * XS);
 
-  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-  const int g4 = lane >> 4, m16 = lane & 15;
+  const int tid0 = threadIdx.x;
   const int b0 = blockIdx.x * MZ_ROWS;
   const bool full = b0 + MZ_ROWS <= t.B;
   const size_t per_tree = (size_t)(t.sims + 1) * MZ_HS;
 
-  if (tid < 96) s_b2[tid] = (tid < 32 && tid >= n.Sr) ? MZ_PAD_BIN : n.b2[tid];
-  if (tid < 48) s_b4[tid] = (tid < 32 && tid >= n.Sv) ? MZ_PAD_BIN : n.b4[tid];
-  if (tid < 64) { s_lnw[tid] = n.lnw[tid]; s_lnb[tid] = n.lnb[tid]; }
-  if (tid < MZ_FUSED_MAXPL) s_rcp[tid] = 1.0 / (double)(tid > 0 ? tid : 1);
-  for (int i = tid; i < 16 * XS; i += 256) { xH[i] = (mz_h16)0.f; xL[i] = (mz_h16)0.f; }
-  for (int i = tid; i < (t.sims + 2) * (t.sims + 2); i += 256) s_pbc[(i / (t.sims + 2)) * PBS + i % (t.sims + 2)] = t.pbctab[i];
+  if (tid0 < 96) s_b2[tid0] = (tid0 < 32 && tid0 >= n.Sr) ? MZ_PAD_BIN : n.b2[tid0];
+  if (tid0 < 48) s_b4[tid0] = (tid0 < 32 && tid0 >= n.Sv) ? MZ_PAD_BIN : n.b4[tid0];
+  if (tid0 < 64) { s_lnw[tid0] = n.lnw[tid0]; s_lnb[tid0] = n.lnb[tid0]; }
+  if (tid0 < MZ_FUSED_MAXPL) s_rcp[tid0] = 1.0 / (double)(tid0 > 0 ? tid0 : 1);
+  for (int i = tid0; i < 16 * XS; i += 256) { xH[i] = (mz_h16)0.f; xL[i] = (mz_h16)0.f; }
+  for (int i = tid0; i < (t.sims + 2) * (t.sims + 2); i += 256) s_pbc[(i / (t.sims + 2)) * PBS + i % (t.sims + 2)] = t.pbctab[i];
 
   constexpr int TL = 16;
+  // this wave's stream: [NGROUPS][8 pieces][64 lanes] f32x4 (8 KiB per group); the resident groups once per launch
+  f32x4 Rw[RSG][8];          // resident groups (AGPRs)
+#define H2_LOAD_GROUP(dst, byteoff)                                                                   \
+  do {                                                                                                \
+    h2_load<0>((dst)[0], wrsrc, lane_off, (byteoff)); h2_load<1024>((dst)[1], wrsrc, lane_off, (byteoff));          \
+    h2_load<2048>((dst)[2], wrsrc, lane_off, (byteoff)); h2_load<3072>((dst)[3], wrsrc, lane_off, (byteoff));       \
+    h2_load<0>((dst)[4], wrsrc, lane_off, (byteoff) + 4096); h2_load<1024>((dst)[5], wrsrc, lane_off, (byteoff) + 4096);   \
+    h2_load<2048>((dst)[6], wrsrc, lane_off, (byteoff) + 4096); h2_load<3072>((dst)[7], wrsrc, lane_off, (byteoff) + 4096); \
+  } while (0)
+  {
+    const char *wbase = (const char *)(wstream + (size_t)__builtin_amdgcn_readfirstlane(tid0 >> 6) * NGROUPS * 512);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)wbase, 0, NGROUPS * 8192, 0x00020000);
+    const int lane_off = (tid0 & 63) * 16;
+#pragma unroll
+    for (int s = 0; s < RSG; ++s) H2_LOAD_GROUP(Rw[s], s * 8192);
+    // the resident groups are never waited for again: have them in, with every register tied to the wait (the compiler
+    // does not know these are loads and must not touch the registers before the data has arrived)
+#pragma unroll
+    for (int s = 0; s < RSG; ++s) h2_wait<0>(Rw[s]);
+  }
+
+  unsigned long long pacc[MZ_NPHASE];
+  unsigned long long tlast = 0;
+  if (PROF) {
+    for (int i = 0; i < MZ_NPHASE; ++i) pacc[i] = 0;
+  }
+
+  const int nmoves = HEAD ? ra.nmoves : 1;
+  for (int mv = 0; mv < nmoves; ++mv) {
+  if constexpr (HEAD) {
+    // the root of this move on the trees' LDS (see k_search_fused)
+    __syncthreads();
+    int tid_r = threadIdx.x;
+    asm volatile("" : "+v"(tid_r));
+    if (ra.nst0 >= 0)
+    mz_root_body<1, G, true>(n, t, nullptr, ra.istream, ra.nst0, sp, seed, ra.alpha, ra.frac,
+                             (float *)(dyn_lds + (((t.sims + 2) * PBS * 8 + 15) & ~15)), tid_r, s_stage, MzNoStamp());
+    __syncthreads();
+  }
+  int tid = threadIdx.x;
+  if constexpr (HEAD) asm volatile("" : "+v"(tid));
+  const int w = tid >> 6, lane = tid & 63;
+  const int g4 = lane >> 4, m16 = lane & 15;
   const int tl = tid % TL;
   int my_slot = 0, my_act = 0;
   TreeRegs tr;
@@ -224,6 +269,27 @@ __global__ __launch_bounds__(256, 1) void k_search_h2(NetView n, TreeView t, con
       tm.N = t.N + o; tm.W = t.W + o; tm.P = t.P + o; tm.R = t.R + o; tm.E = t.E + o; tm.TP = t.TP + o;
     }
     tr.len = 1; tr.tp = 1; tr.root_tp = 1; tr.legal = 0; tr.mn = 0.0; tr.mx = 0.0; tr.root_n = 0;
+    if constexpr (HEAD) {      // the root this launch has just made: taken from LDS and from what is known (k_search_fused)
+      if (b < t.B) {
+        const double *st = s_stage + mt * 96;
+        const int best = (int)st[32];
+        my_act = best;
+        tr.len = 2;
+        tr.legal = (t.A >= 32) ? 0xFFFFFFFFu : ((1u << t.A) - 1u);
+        tr.mn = t.has_min ? t.min_bound : __builtin_inf();
+        tr.mx = t.has_max ? t.max_bound : -__builtin_inf();
+        if (tl == 0) { s_path[mt * MZ_FUSED_MAXPL] = 0; s_path[mt * MZ_FUSED_MAXPL + 1] = 1 + best; }
+        const int have = 1 + t.A;
+        if constexpr (LT == 1) {
+          for (int k = tl; k < t.NN; k += TL) {
+            tm.N[k] = 0; tm.W[k] = 0.0; tm.R[k] = 0.f; tm.E[k] = (k == 0) ? 0 : -1; tm.TP[k] = 1;
+          }
+        } else {
+          for (int k = tl; k < have; k += TL) { tm.N[k] = 0; tm.E[k] = (k == 0) ? 0 : -1; }
+        }
+        for (int k = tl; k < have; k += TL) { tm.P[k] = (k == 0) ? 0.0 : st[k - 1]; tm.X[k] = 0.0; }
+      }
+    } else
     if (b < t.B) {
       my_slot = t.slot[b];
       my_act = t.act[b];
@@ -270,35 +336,15 @@ __global__ __launch_bounds__(256, 1) void k_search_h2(NetView n, TreeView t, con
     hv = *(const f32x4 *)((const char *)t.hpool + hoff + (size_t)my_slot * (MZ_HS * 4));
   }
 
-  // this wave's stream: [NGROUPS][8 pieces][64 lanes] f32x4 (8 KiB per group)
   const char *wbase = (const char *)(wstream + (size_t)__builtin_amdgcn_readfirstlane(w) * NGROUPS * 512);
   const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)wbase, 0, NGROUPS * 8192, 0x00020000);
   const int lane_off = lane * 16;
-  f32x4 Rw[RSG][8];          // resident groups (AGPRs)
   f32x4 Bf[NBG][8];          // ring (AGPRs)
-#define H2_LOAD_GROUP(dst, byteoff)                                                                   \
-  do {                                                                                                \
-    h2_load<0>((dst)[0], wrsrc, lane_off, (byteoff)); h2_load<1024>((dst)[1], wrsrc, lane_off, (byteoff));          \
-    h2_load<2048>((dst)[2], wrsrc, lane_off, (byteoff)); h2_load<3072>((dst)[3], wrsrc, lane_off, (byteoff));       \
-    h2_load<0>((dst)[4], wrsrc, lane_off, (byteoff) + 4096); h2_load<1024>((dst)[5], wrsrc, lane_off, (byteoff) + 4096);   \
-    h2_load<2048>((dst)[6], wrsrc, lane_off, (byteoff) + 4096); h2_load<3072>((dst)[7], wrsrc, lane_off, (byteoff) + 4096); \
-  } while (0)
-#pragma unroll
-  for (int s = 0; s < RSG; ++s) H2_LOAD_GROUP(Rw[s], s * 8192);
-  // the resident groups are never waited for again: have them in, with every register tied to the wait (the compiler
-  // does not know these are loads and must not touch the registers before the data has arrived)
-#pragma unroll
-  for (int s = 0; s < RSG; ++s) h2_wait<0>(Rw[s]);
   int sbase = RSG * 8192;      // byte offset of ring group 0 (laundered per simulation, see mz_fused.hip.h)
 #pragma unroll
   for (int s = 0; s < NBG - 1; ++s) H2_LOAD_GROUP(Bf[s], sbase + s * 8192);
 
-  unsigned long long pacc[MZ_NPHASE];
-  unsigned long long tlast = 0;
-  if (PROF) {
-    for (int i = 0; i < MZ_NPHASE; ++i) pacc[i] = 0;
-    tlast = __builtin_amdgcn_s_memtime();
-  }
+  if (PROF) tlast = __builtin_amdgcn_s_memtime();
   __syncthreads();
 
   for (int sim = 0; sim < nsims; ++sim) {
@@ -506,7 +552,6 @@ __global__ __launch_bounds__(256, 1) void k_search_h2(NetView n, TreeView t, con
     STAMP(13)
   }
 #undef H2_GI
-#undef H2_LOAD_GROUP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the ring's requests in flight target registers of this wave
   if (record) {
     if (b0 + mt < t.B) mz_finalize_record<TL, LT>(t, tm, sp, b0 + mt, tl, tr.legal, seed, s_stage + mt * 96, n.O);
@@ -525,6 +570,8 @@ __global__ __launch_bounds__(256, 1) void k_search_h2(NetView n, TreeView t, con
       }
     }
   }
-  if (PROF && lane == 0)
-    for (int i = 0; i < MZ_NPHASE; ++i) prof[((size_t)blockIdx.x * 4 + w) * MZ_NPHASE + i] = pacc[i];
+  }      // (moves of a HEAD launch)
+#undef H2_LOAD_GROUP
+  if (PROF && (tid0 & 63) == 0)
+    for (int i = 0; i < MZ_NPHASE; ++i) prof[((size_t)blockIdx.x * 4 + (tid0 >> 6)) * MZ_NPHASE + i] = pacc[i];
 }

@@ -4,6 +4,7 @@ torch is used for device memory and streams only; every computation below is a H
 csrc/ reached through libmz_hip.so.  Mirrors, batched over B environments, what one reference Actor
 does per move (actors.py:131-153): initial inference, root expand + noise, MCTS.run, select_action."""
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -77,6 +78,8 @@ class Engine(object):
         int(bool(no_target_transform)), 0.0 if lo is None else float(lo), 0.0 if hi is None else float(hi),
         float(discount), float(pb_c_base), float(pb_c_init), float(init_value_score), float(root_dirichlet_alpha),
         float(root_exploration_fraction), int(seed), int(env_id_offset), int(bool(no_support)), int(bool(split_f16)))
+    # (the library also honours MZ_SPLIT_F16=1, for running the parity suite on that kernel)
+    self.split_f16 = bool(split_f16) or os.environ.get('MZ_SPLIT_F16', '0')[:1] == '1'
     h = C.c_void_p()
     _abi.check(self.lib.mz_create(C.byref(self.cfg), C.byref(h)), 'mz_create')
     self._h = h
@@ -315,7 +318,7 @@ class Engine(object):
 
   def selfplay_moves_per_launch(self):
     """16 where selfplay_steps plays whole moves inside one launch of the search kernel, 0 where every move is a root
-    kernel + a search kernel (two-player games, trees in the global pool, split_f16, MZ_NO_PERSIST)."""
+    kernel + a search kernel (two-player games, trees in the global pool, MZ_NO_PERSIST)."""
     return int(self.lib.mz_selfplay_moves_per_launch(self._h))
 
   SELFPLAY_PHASES = ('root_stage0', 'root_rep_ln', 'root_prediction', 'root_tree', 'resident+tree_setup', 'ring+barrier',

@@ -498,14 +498,15 @@ def test_train_driver_with_learner():
   assert abs(lt['replay_ratio'] - lt['updates_per_second'] / lt['frames_per_second']) < 1e-9
 
 
-@pytest.mark.parametrize('O,A,sims,u8', [(8, 4, 30, False), (128, 6, 50, True), (5, 2, 6, False)])
-def test_persistent_selfplay_launch_equals_graph_of_kernels(O, A, sims, u8, monkeypatch):
+@pytest.mark.parametrize('O,A,sims,u8,split', [(8, 4, 30, False, False), (128, 6, 50, True, False), (5, 2, 6, False, False),
+                                               (8, 4, 30, False, True), (60, 6, 50, True, True)])
+def test_persistent_selfplay_launch_equals_graph_of_kernels(O, A, sims, u8, split, monkeypatch):
   """Single-player self-play runs as whole moves inside ONE launch of the search kernel (its HEAD instantiation: root,
   simulations and end of every move, trees never leaving LDS between root and search); MZ_NO_PERSIST=1 keeps the
   hipGraph of root + search kernels per move.  Same device functions, same keys: every record is bit-identical --
   across launch boundaries, a weight update, a temperature change, ragged B, byte observations with --norm_obs, trees
   in LDS (LunarLander shapes), descent fields only in LDS (Pong-ram shapes) and trees smaller than the root's working
-  set; with tree export on, the exported trees agree too."""
+  set, the exact-f32 kernel and the split-f16 one; with tree export on, the exported trees agree too."""
   import torch
   from model_based_rl_amd.engine import Engine, flatten_weights
   from model_based_rl_amd.networks import FCNetwork
@@ -520,7 +521,8 @@ def test_persistent_selfplay_launch_equals_graph_of_kernels(O, A, sims, u8, monk
       monkeypatch.delenv('MZ_NO_PERSIST', raising=False)
     else:
       monkeypatch.setenv('MZ_NO_PERSIST', '1')
-    eng = Engine(B, O, A, sims, seed=21, env_id_offset=3)
+    eng = Engine(B, O, A, sims, seed=21, env_id_offset=3, split_f16=split)
+    assert (eng.selfplay_moves_per_launch() > 0) == persist
     eng.set_weights(w0)
     if u8:
       eng.selfplay_set_obs(uint8_obs=True, obs_min=[0.0], obs_range=[255.0])
@@ -539,7 +541,7 @@ def test_persistent_selfplay_launch_equals_graph_of_kernels(O, A, sims, u8, monk
       assert n == k
       recs.append(buf[:n].numpy().copy())
     tree = eng.export_tree()
-    if persist:
+    if persist and not eng.split_f16:
       ph = eng.selfplay_phase_profile(4)
       assert set(ph) == set(Engine.SELFPLAY_PHASES) and all(v > 0 for v in ph.values()), ph
       assert ph['simulations'] > 5 * ph['root_prediction']
