@@ -274,8 +274,11 @@ def main():
     k = 0
     for steps in blocks:
       done = 0
+      # the block in equal chunks of at most `chunk` moves (20 -> 10 + 10, not 16 + 4: every launch of the persistent
+      # self-play kernel pays its start-up once)
+      even = -(-steps // -(-steps // chunk))
       while done < steps:
-        m = min(chunk, steps - done)
+        m = min(even, steps - done)
         g0 = state['gmove']
         if g0 // state['sync_every'] != state['last_sync_q']:     # a multiple of sync_every was crossed
           state['last_sync_q'] = g0 // state['sync_every']
@@ -385,7 +388,12 @@ def main():
     tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
     if os.path.exists(tfile) and WNAME.startswith('Lunar') and B == 4096:
       tj = json.load(open(tfile))
-      traffic = tj.get('k_search_fused', {}).get('hbm_bytes_per_launch')
+      tk = tj.get('k_search_fused', {})
+      # (the PMC passes count per launch; a launch of the profiled command plays moves_per_launch moves)
+      if 'hbm_bytes_per_move' in tk:
+        traffic = tk['hbm_bytes_per_move'] * moves_per_launch
+      elif moves_per_launch == 1:
+        traffic = tk.get('hbm_bytes_per_launch')
       traffic_source = 'profiles/traffic.json (builder-run rocprofv3 --pmc passes of this command, %s; not re-measured ' \
                        'in this run)' % tj.get('tag', 'see file')
     out = {

@@ -29,6 +29,21 @@ print('total    ', ' '.join('%8.0f' % (c[w].sum() / SIMS) for w in range(4)))
 spread = eng.search_phase_spread()
 print('workgroup totals per sim: mean %.0f  min %.0f  max %.0f  (max / mean %.3f)' %
       (spread[0] / SIMS, spread[1] / SIMS, spread[2] / SIMS, spread[2] / spread[0]))
+# the persistent self-play launch (whole moves inside one launch of the exact-f32 kernel): cycles per phase of a MOVE
+move_phases = None
+if eng.selfplay_moves_per_launch() > 0 and not eng.split_f16:
+  if O > 64:
+    eng.selfplay_set_obs(uint8_obs=True, obs_min=[0.0], obs_range=[255.0])
+  eng.selfplay_reset(256, 1.0, stagger=True)
+  eng.selfplay_steps(32)
+  for it in range(3):
+    move_phases = eng.selfplay_phase_profile(16)
+    eng.selfplay_drain()
+  tot = sum(move_phases.values())
+  print('persistent self-play launch, cycles per move (mean over waves):')
+  for k in Engine.SELFPLAY_PHASES:
+    print('  %-20s %9.0f  %5.1f %%' % (k, move_phases[k], 100 * move_phases[k] / tot))
+  print('  %-20s %9.0f' % ('total', tot))
 if tag:
   out = {'what': 'k_search_fused phase stamps (s_memtime, 100 MHz-independent shader clock cycles), cycles per simulation, '
                  'averaged over the 256 workgroups, per wave; 4096 trees',
@@ -40,4 +55,8 @@ if tag:
          'note': 'waves wait for each other at the four barriers of a simulation (end of gather, partials of the two out '
                  'layers, LayerNorm): the time a wave spends waiting shows up in the phase that ENDS with the barrier '
                  '(bar, comb1, ln/rew, comb2); per-wave differences inside t_* are the lock-step cost of unequal tree depths'}
+  if move_phases is not None:
+    out['selfplay_move'] = {'what': 'mz_selfplay_phase_profile: shader cycles per phase of one MOVE inside the persistent '
+                                    'self-play launch (16 moves per launch), mean over all waves; the stamps pin the schedule',
+                            'cycles_per_move': move_phases, 'total': sum(move_phases.values())}
   json.dump(out, open(os.path.join(ROOT, 'profiles', 'phase_cycles_%s.json' % tag), 'w'), indent=1)
