@@ -1,3 +1,5 @@
+"""SHA-1 of the experience records of K self-play moves (env: K, B; MZ_HIP_LIB selects the library build, MZ_NO_PERSIST /
+MZ_SPLIT_F16 the kernel path): two builds or paths that must agree bit for bit print the same digest."""
 import sys, os
 sys.path.insert(0, '/root/repo')
 import torch, numpy as np
