@@ -29,5 +29,5 @@ for i, l in enumerate(body):
   if mm and mm.group(1) in labels and labels[mm.group(1)] < i:
     a = labels[mm.group(1)]
     c = collections.Counter(cls(x) for x in body[a:i] if x.startswith('\t') and not x.strip().startswith(('.', ';')) and x.strip())
-    if sum(c.values()) > 200:
+    if sum(c.values()) > int(sys.argv[3] if len(sys.argv) > 3 else 200):
       print('loop lines %d..%d  n=%d ' % (a, i, sum(c.values())), dict(c.most_common()))
