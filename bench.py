@@ -254,8 +254,9 @@ def main():
     eng.selfplay_set_obs(uint8_obs=True, obs_min=[0.0], obs_range=[255.0])
   eng.selfplay_reset(EPISODE_LEN, 1.0, stagger=True)
   rec = eng.rec_floats
-  pinned = [torch.empty(chunk, B, rec, dtype=torch.float32).pin_memory() for _ in range(2)]
-  events = [torch.cuda.Event(), torch.cuda.Event()]
+  NBUF = 4
+  pinned = [torch.empty(chunk, B, rec, dtype=torch.float32).pin_memory() for _ in range(NBUF)]
+  events = [torch.cuda.Event() for _ in range(NBUF)]
   copy_stream = torch.cuda.Stream(device)
   dump = [] if args.dump_records else None
   state = {'gmove': 0, 'sync_every': max(chunk, args.sync_every), 'last_sync_q': 0}
@@ -266,12 +267,39 @@ def main():
     while not ev.query():
       time.sleep(0.0002)
 
+  # host side of the pipeline: the main thread only launches (moves, copy); a worker waits for each chunk's copy and feeds
+  # the replay (native code, the GIL is released) -- up to NBUF - 1 chunks behind the GPU, so a slow ingest of one chunk
+  # (page faults, a busy host: its median is close to the 3.3 ms the GPU needs for a chunk) does not idle the GPU
+  import queue
+  import threading
+  free, work, failed = queue.Queue(), queue.Queue(), []
+  for i in range(NBUF):
+    free.put(i)
+
+  def ingest_worker():
+    torch.cuda.set_device(device)
+    while True:
+      item = work.get()
+      if item is None:
+        return
+      try:
+        i, n = item
+        wait(events[i])
+        if dump is not None and len(dump) < 4:
+          dump.append(pinned[i][:n].numpy().copy())
+        replay.ingest_records(pinned[i], n, B)
+      except Exception as exc:      # surfaced by run()
+        failed.append(exc)
+      finally:
+        free.put(item[0])
+        work.task_done()
+  threading.Thread(target=ingest_worker, daemon=True).start()
+
   def run(blocks, marks=None):
-    """blocks: list of step counts, run back to back in ONE pipelined stream of chunks (D2H + host ingest of chunk
-    i-1 overlap the GPU work of chunk i, across block boundaries too).  marks: list that receives one GPU event per
-    block boundary (recorded on the compute stream behind the block's last move)."""
-    pending = None
-    k = 0
+    """blocks: list of step counts, run back to back in ONE pipelined stream of chunks (D2H + host ingest of the
+    previous chunks overlap the GPU work of chunk i, across block boundaries too).  marks: list that receives one GPU
+    event per block boundary (recorded on the compute stream behind the block's last move).  Returns when every chunk
+    has been ingested."""
     for steps in blocks:
       done = 0
       # the block in equal chunks of at most `chunk` moves (20 -> 10 + 10, not 16 + 4: every launch of the persistent
@@ -283,29 +311,20 @@ def main():
         if g0 // state['sync_every'] != state['last_sync_q']:     # a multiple of sync_every was crossed
           state['last_sync_q'] = g0 // state['sync_every']
           sync_weights()     # Actor.sync_weights (actors.py:81-85): fresh weights from the storage rank, in stream order
+        i = free.get()       # (blocks while the worker is NBUF chunks behind)
         eng.selfplay_steps(m)
-        buf, n = eng.selfplay_drain(pinned[k & 1], m, copy_stream=copy_stream)   # overlaps the next chunk's moves
-        events[k & 1].record(copy_stream)
-        if pending is not None:
-          pb, pn, pe = pending
-          wait(pe)
-          if dump is not None and len(dump) < 4:
-            dump.append(pb[:pn].numpy().copy())
-          replay.ingest_records(pb, pn, B)
-        pending = (buf, n, events[k & 1])
+        _, n = eng.selfplay_drain(pinned[i], m, copy_stream=copy_stream)   # overlaps the next chunk's moves
+        events[i].record(copy_stream)
+        work.put((i, n))
         done += m
         state['gmove'] += m
-        k += 1
       if marks is not None:
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
         marks.append(ev)
-    if pending is not None:
-      pb, pn, pe = pending
-      wait(pe)
-      if dump is not None and len(dump) < 4:
-        dump.append(pb[:pn].numpy().copy())
-      replay.ingest_records(pb, pn, B)
+    work.join()
+    if failed:
+      raise failed[0]
 
   def barrier():
     torch.cuda.synchronize(device)

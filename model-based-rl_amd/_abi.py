@@ -9,12 +9,27 @@ import subprocess
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 _SO = os.environ.get('MZ_HIP_LIB') or os.path.join(_CSRC, 'libmz_hip.so')      # (MZ_HIP_LIB: A/B runs of two builds on one box)
-_SOURCES = ['mz_engine.hip', 'mz_common.h', 'mz_net.hip.h', 'mz_tree.hip.h', 'mz_rng.h', 'mz_selfplay.hip.h',
-            'mz_selfplay_abi.inc', 'mz_fused.hip.h', 'mz_root.hip.h', 'mz_fused_h2.hip.h']
+_SOURCES = ['mz_engine.hip', 'mz_inst.hip', 'mz_kernels.inc', 'mz_common.h', 'mz_net.hip.h', 'mz_tree.hip.h', 'mz_rng.h',
+            'mz_selfplay.hip.h', 'mz_selfplay_abi.inc', 'mz_fused.hip.h', 'mz_root.hip.h', 'mz_fused_h2.hip.h']
 _lib = None
 
-HIPCC_FLAGS = ['-O3', '--offload-arch=gfx950', '-ffp-contract=off', '-std=c++17', '-fPIC', '-shared', '-Wno-unused-value',
+HIPCC_FLAGS = ['-O3', '--offload-arch=gfx950', '-ffp-contract=off', '-std=c++17', '-fPIC', '-Wno-unused-value',
                '-Wno-unused-result']
+# translation units of libmz_hip.so: the host side + root / stepwise kernels, and one unit per shape of the two search
+# kernels (mz_kernels.inc; the same list as launch_fused / launch_h2 in mz_engine.hip dispatch to)
+FUSED_SHAPES = [(14, 1, 4), (14, 1, 8), (16, 1, 8), (16, 1, 16), (18, 1, 16), (18, 2, 32), (21, 2, 32)]
+H2_SHAPES = [4, 8, 16]
+DEV_FUSED_SHAPES, DEV_H2_SHAPES = [(14, 1, 4), (16, 1, 8)], [4, 8]      # -DMZ_DEV_ONLY: the two bench shapes
+
+
+def translation_units(extra=()):
+  dev = '-DMZ_DEV_ONLY' in extra
+  units = [('mz_engine', 'mz_engine.hip', [])]
+  for ks1, jtp, g in (DEV_FUSED_SHAPES if dev else FUSED_SHAPES):
+    units.append(('mz_inst_f_%d_%d_%d' % (ks1, jtp, g), 'mz_inst.hip', ['-DMZ_INST_F=%d,%d,%d' % (ks1, jtp, g)]))
+  for g in (DEV_H2_SHAPES if dev else H2_SHAPES):
+    units.append(('mz_inst_h_%d' % g, 'mz_inst.hip', ['-DMZ_INST_H=%d' % g]))
+  return units
 
 
 class MzConfig(C.Structure):
@@ -38,14 +53,34 @@ def stale():
   return any(os.path.exists(s) and os.path.getmtime(s) > t for s in srcs)
 
 
-def build(force=False, verbose=False):
-  """hipcc cross-compiles for gfx950 without a GPU; the .so stays in-tree (csrc/)."""
-  if force or stale():
-    cmd = ['hipcc'] + HIPCC_FLAGS + os.environ.get('MZ_HIPCC_EXTRA', '').split() + ['mz_engine.hip', '-o', 'libmz_hip.so']
+def build(force=False, verbose=False, out=None, extra=None, jobs=None):
+  """hipcc cross-compiles for gfx950 without a GPU; the .so stays in-tree (csrc/).  The translation units are compiled
+  in parallel (objects under csrc/obj/, git-ignored), then linked.  out / extra: another library name and extra hipcc
+  flags (kernel development: A/B builds under build/, -DMZ_DEV_ONLY)."""
+  target = out or os.path.join(_CSRC, 'libmz_hip.so')
+  if not (force or out or stale()):
+    return _SO
+  from concurrent.futures import ThreadPoolExecutor
+  extra = list(extra) if extra is not None else os.environ.get('MZ_HIPCC_EXTRA', '').split()
+  objdir = os.path.join(_CSRC, 'obj', os.path.splitext(os.path.basename(target))[0])
+  os.makedirs(objdir, exist_ok=True)
+
+  def compile_unit(unit):
+    name, src, defs = unit
+    obj = os.path.join(objdir, name + '.o')
+    cmd = ['hipcc'] + HIPCC_FLAGS + extra + defs + ['-c', src, '-o', obj]
     if verbose:
-      print(' '.join(cmd))
+      print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd, cwd=_CSRC)
-  return _SO
+    return obj
+  units = translation_units(extra)
+  with ThreadPoolExecutor(max_workers=jobs or min(len(units), os.cpu_count() or 1)) as pool:
+    objs = list(pool.map(compile_unit, units))
+  cmd = ['hipcc', '--offload-arch=gfx950', '-fPIC', '-shared'] + objs + ['-o', target]
+  if verbose:
+    print(' '.join(cmd), flush=True)
+  subprocess.check_call(cmd, cwd=_CSRC)
+  return target
 
 
 _VP, _I, _D, _U64, _SZ = C.c_void_p, C.c_int, C.c_double, C.c_uint64, C.c_size_t

@@ -24,6 +24,10 @@
 #include "mz_fused.hip.h"
 #include "mz_root.hip.h"
 #include "mz_fused_h2.hip.h"
+// the search kernels are compiled in their own translation units, one per shape (mz_inst.hip); here they are launched
+#include "mz_kernels.inc"
+MZ_ALL_FUSED(extern)
+MZ_ALL_H2(extern)
 
 static thread_local std::string g_err;
 

@@ -464,7 +464,7 @@ __device__ __forceinline__ float mz_support_to_scalar_q(const f32x4 &raw, int sm
 #define MZ_FUSED_MAXPL 64   // search-path slots per tree kept in LDS: num_simulations + 2 <= 64
 #define MZ_FUSED_LDS_BASE (16 * MZ_HS + 4 * 6 * 256 + 16 + 16 + 16 * 32 + 96 + 64 + 64 + 64 + 2 * 16 * MZ_XE + 16 * MZ_FUSED_MAXPL + 2 * MZ_FUSED_MAXPL)
 // + the tree step's own staging [16][96] doubles, except beside large trees (LT = 2), where it shares the partials' space
-__host__ __device__ constexpr int mz_fused_lds_floats(int lt) { return MZ_FUSED_LDS_BASE + (lt == 2 ? 0 : 16 * 96 * 2); }
+__host__ __device__ constexpr int mz_fused_lds_floats(int lt) { return MZ_FUSED_LDS_BASE + 16 * 96 * 2; }
 
 // PROF: diagnostic build only (mz_search_phase_profile): per-wave cycle totals of each phase of the loop.
 #define MZ_NPHASE 14
@@ -478,11 +478,11 @@ __host__ __device__ constexpr int mz_fused_lds_floats(int lt) { return MZ_FUSED_
   }
 
 // dynamic LDS of the fused kernel: pb_c table, then the 16 trees' node arrays (lt = 1: everything + Q cache, rows of the
-// table 64 apart; lt = 2: N, E, P, X only, rows sims + 2 apart; lt = 0: table only)
+// table 64 apart; lt = 2: N, E, P, to_play per node, W, R, X per expansion slot, rows sims + 2 apart; lt = 0: table only)
 __host__ __device__ inline size_t mz_fused_dyn_lds(int sims, int NN, int lt) {
   size_t b = (size_t)(sims + 2) * (lt == 2 ? sims + 2 : 64) * 8;
   if (lt == 1) b += (size_t)16 * NN * (8 + 8 + 8 + 4 + 2 + 2 + 1) + 64;
-  if (lt == 2) b += (size_t)16 * NN * (8 + 8 + 2 + 2) + 64;
+  if (lt == 2) b += (size_t)16 * NN * (8 + 2 + 2 + 1) + (size_t)16 * (sims + 2) * (8 + 8 + 4) + 64;
   return b;
 }
 
@@ -571,10 +571,12 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
   const int PBS = (LT == 2) ? t.sims + 2 : 64;
   // (LT = 1, 2) the workgroup's 16 trees live in LDS for the whole launch (LT = 2: the descent's fields only)
   double *l_P = s_pbc + (t.sims + 2) * PBS;
+  // LT = 1: every field per node; LT = 2: W, R and the X cache per expansion slot (mz_tree.hip.h, TreeMem)
+  const int NV = (LT == 2) ? t.sims + 2 : t.NN;      // entries per tree of the value arrays
   double *l_Q = l_P + 16 * t.NN;                     // X cache
-  double *l_W = l_Q + 16 * t.NN;                     // LT = 1 only from here on
-  float *l_R = (float *)(l_W + 16 * t.NN);
-  int16_t *l_N = (LT == 2) ? (int16_t *)l_W : (int16_t *)(l_R + 16 * t.NN);
+  double *l_W = l_Q + 16 * NV;
+  float *l_R = (float *)(l_W + 16 * NV);
+  int16_t *l_N = (int16_t *)(l_R + 16 * NV);
   int16_t *l_E = l_N + 16 * t.NN;
   int8_t *l_TP = (int8_t *)(l_E + 16 * t.NN);
   float *xR = smem;                       // [16][MZ_HS] x tile, row-major
@@ -592,7 +594,7 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
   double *s_rcp = (double *)(s_path + 16 * MZ_FUSED_MAXPL);      // [MZ_FUSED_MAXPL] 1 / n (mz_tree_backup_select_f)
   // [16][96] staging of the tree step: its own (the tree step of one wave overlaps other waves' epilogue), except
   // beside large trees, where it shares the partials' space and the tree step starts behind a barrier
-  double *s_stage = (LT == 2) ? (double *)red : (double *)(s_rcp + MZ_FUSED_MAXPL);
+  double *s_stage = (double *)(s_rcp + MZ_FUSED_MAXPL);
 
   const int tid0 = threadIdx.x;
   const int b0 = blockIdx.x * MZ_ROWS;
@@ -661,10 +663,9 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
       tm[i].N = l_N + o; tm[i].W = l_W + o; tm[i].P = l_P + o; tm[i].R = l_R + o; tm[i].E = l_E + o; tm[i].TP = l_TP + o;
       tm[i].X = l_Q + o;
     } else if constexpr (LT == 2) {
-      const int o = mt * t.NN;
-      const size_t og = (size_t)(b < t.B ? b : 0) * t.NN;
-      tm[i].N = l_N + o; tm[i].E = l_E + o; tm[i].P = l_P + o; tm[i].X = l_Q + o;
-      tm[i].W = t.W + og; tm[i].R = t.R + og; tm[i].TP = t.TP + og;
+      const int o = mt * t.NN, ov = mt * NV;
+      tm[i].N = l_N + o; tm[i].E = l_E + o; tm[i].P = l_P + o; tm[i].TP = l_TP + o;
+      tm[i].X = l_Q + ov; tm[i].W = l_W + ov; tm[i].R = l_R + ov;
     } else {
       const size_t o = (size_t)(b < t.B ? b : 0) * t.NN;
       tm[i].N = t.N + o; tm[i].W = t.W + o; tm[i].P = t.P + o; tm[i].R = t.R + o; tm[i].E = t.E + o; tm[i].TP = t.TP + o;
@@ -726,10 +727,12 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
           for (int k = tl; k < t.NN; k += TL) {
             tm[i].N[k] = 0; tm[i].W[k] = 0.0; tm[i].R[k] = 0.f; tm[i].E[k] = (k == 0) ? 0 : -1; tm[i].TP[k] = 1;
           }
+          for (int k = tl; k < have; k += TL) tm[i].X[k] = 0.0;
         } else {
-          for (int k = tl; k < have; k += TL) { tm[i].N[k] = 0; tm[i].E[k] = (k == 0) ? 0 : -1; }
+          for (int k = tl; k < have; k += TL) { tm[i].N[k] = 0; tm[i].E[k] = (k == 0) ? 0 : -1; tm[i].TP[k] = 1; }
+          if (tl == 0) { tm[i].W[0] = 0.0; tm[i].R[0] = 0.f; tm[i].X[0] = 0.0; }      // the root's expansion slot
         }
-        for (int k = tl; k < have; k += TL) { tm[i].P[k] = (k == 0) ? 0.0 : st[k - 1]; tm[i].X[k] = 0.0; }
+        for (int k = tl; k < have; k += TL) tm[i].P[k] = (k == 0) ? 0.0 : st[k - 1];
       }
     } else
     if (b < t.B) {
@@ -762,11 +765,14 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
         const size_t o = (size_t)b * t.NN;
         const int have = 1 + (slot0 + 1) * t.A;
         for (int k = tl; k < have; k += TL) {
-          const int nk = t.N[o + k];
-          tm[i].N[k] = (int16_t)nk; tm[i].P[k] = t.P[o + k]; tm[i].E[k] = (int16_t)t.E[o + k];
-          const double qk = nk > 0 ? t.W[o + k] / (double)nk : 0.0;      // a continued search: what the backup would have cached
-          const double rk = (double)t.R[o + k];
-          tm[i].X[k] = t.two_players ? rk - t.discount * qk : rk + t.discount * qk;
+          const int nk = t.N[o + k], ek = t.E[o + k];
+          tm[i].N[k] = (int16_t)nk; tm[i].P[k] = t.P[o + k]; tm[i].E[k] = (int16_t)ek; tm[i].TP[k] = t.TP[o + k];
+          if (ek >= 0) {       // an expanded node: its value fields live in its expansion slot
+            const double qk = nk > 0 ? t.W[o + k] / (double)nk : 0.0;      // a continued search: what the backup would have cached
+            const double rk = (double)t.R[o + k];
+            tm[i].W[ek] = t.W[o + k]; tm[i].R[ek] = t.R[o + k];
+            tm[i].X[ek] = t.two_players ? rk - t.discount * qk : rk + t.discount * qk;
+          }
         }
       }
     }
@@ -976,7 +982,7 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
           __builtin_amdgcn_s_waitcnt(MZ_VMCNT(4 * (NB - 1)));
           mz_partials_out<NJ2, P4 ? 1 << 2 : 0>(red, out4, tid);
           STAMP(8)
-          if constexpr (TL != 16 || LT == 2) {
+          if constexpr (TL != 16) {
               // every wave: value scalar + policy logits of 4 trees -> LDS; both halves of a tree's 16 lanes compute the
               // value (8 lanes x 4 bins), lane q < ceil(A/4) forwards 4 logits
             const int col = 4 * w + (lane_e >> 4), q = lane_e & 15, q8 = q & 7;
@@ -1000,7 +1006,7 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
       }
       // s >= E_P2: padding steps (prefetch only)
     });
-    if constexpr (TL == 16 && LT != 2) {
+    if constexpr (TL == 16) {
       // ---- value scalar, logits, then the tree step (expand + backup, mcts.py:97-99; next descent, mcts.py:83-92) of
       // the 4 trees this wave's lanes own, with no barrier in between: nothing here is exchanged across waves (the
       // wave that owns a tree reads its value and logits straight from the partials), and written as ONE straight
@@ -1080,6 +1086,10 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
         for (int k = tl; k < have; k += TL) {
           t.N[o + k] = tm[i].N[k]; t.P[o + k] = tm[i].P[k]; t.E[o + k] = tm[i].E[k];
           if constexpr (LT == 1) { t.W[o + k] = tm[i].W[k]; t.R[o + k] = tm[i].R[k]; t.TP[o + k] = tm[i].TP[k]; }
+          if constexpr (LT == 2) {
+            const int ek = tm[i].E[k];
+            t.W[o + k] = ek >= 0 ? tm[i].W[ek] : 0.0; t.R[o + k] = ek >= 0 ? tm[i].R[ek] : 0.f; t.TP[o + k] = tm[i].TP[k];
+          }
         }
       }
     }

@@ -150,7 +150,7 @@ __device__ __forceinline__ void h2_group(f32x4 &c0, f32x4 &c1, f32x4 &c2, f32x4 
 // 1 / n table, two f16 x tiles [16][XS] (high, low; shared by the dynamics and the prediction stage), and -- except beside
 // large trees (LT = 2), where it shares the partials' space -- the tree step's staging
 #define MZ_H2_LDS_BASE (16 * MZ_HS + 4 * 6 * 256 + 16 + 16 + 16 * 32 + 96 + 64 + 64 + 64 + 16 * MZ_FUSED_MAXPL + 2 * MZ_FUSED_MAXPL + 2 * 16 * MZ_H2_XS / 2)
-__host__ __device__ constexpr int mz_h2_lds_floats(int lt) { return MZ_H2_LDS_BASE + (lt == 2 ? 0 : 16 * 96 * 2); }
+__host__ __device__ constexpr int mz_h2_lds_floats(int lt) { return MZ_H2_LDS_BASE + 16 * 96 * 2; }
 
 // HEAD: whole self-play moves inside the launch, as in k_search_fused (mz_fused.hip.h); the resident groups live in AGPRs
 // the compiler never allocates to the root, so here they do stay across the moves of a launch.
@@ -169,10 +169,12 @@ __global__ __launch_bounds__(256, 1) void k_search_h2(NetView n, TreeView t, con
   double *s_pbc = (double *)dyn_lds;
   const int PBS = (LT == 2) ? t.sims + 2 : 64;
   double *l_P = s_pbc + (t.sims + 2) * PBS;
-  double *l_Q = l_P + 16 * t.NN;
-  double *l_W = l_Q + 16 * t.NN;
-  float *l_R = (float *)(l_W + 16 * t.NN);
-  int16_t *l_N = (LT == 2) ? (int16_t *)l_W : (int16_t *)(l_R + 16 * t.NN);
+  // LT = 1: every field per node; LT = 2: W, R and the X cache per expansion slot (mz_tree.hip.h, TreeMem)
+  const int NV = (LT == 2) ? t.sims + 2 : t.NN;      // entries per tree of the value arrays
+  double *l_Q = l_P + 16 * t.NN;                     // X cache
+  double *l_W = l_Q + 16 * NV;
+  float *l_R = (float *)(l_W + 16 * NV);
+  int16_t *l_N = (int16_t *)(l_R + 16 * NV);
   int16_t *l_E = l_N + 16 * t.NN;
   int8_t *l_TP = (int8_t *)(l_E + 16 * t.NN);
   float *xR = smem;                       // [16][MZ_HS] float32 hidden tile (LayerNorm output -> hidden-state pool)
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(256, 1) void k_search_h2(NetView n, TreeView t, con
   // extension columns (the low parts of those are always zero)
   mz_h16 *xH = (mz_h16 *)(s_rcp + MZ_FUSED_MAXPL);
   mz_h16 *xL = xH + 16 * XS;
-  double *s_stage = (LT == 2) ? (double *)red : (double *)(xL + 16 * XS);
+  double *s_stage = (double *)(xL + 16 * XS);
 
   const int tid0 = threadIdx.x;
   const int b0 = blockIdx.x * MZ_ROWS;
@@ -260,10 +262,9 @@ __global__ __launch_bounds__(256, 1) void k_search_h2(NetView n, TreeView t, con
       const int o = mt * t.NN;
       tm.N = l_N + o; tm.W = l_W + o; tm.P = l_P + o; tm.R = l_R + o; tm.E = l_E + o; tm.TP = l_TP + o; tm.X = l_Q + o;
     } else if constexpr (LT == 2) {
-      const int o = mt * t.NN;
-      const size_t og = (size_t)(b < t.B ? b : 0) * t.NN;
-      tm.N = l_N + o; tm.E = l_E + o; tm.P = l_P + o; tm.X = l_Q + o;
-      tm.W = t.W + og; tm.R = t.R + og; tm.TP = t.TP + og;
+      const int o = mt * t.NN, ov = mt * NV;
+      tm.N = l_N + o; tm.E = l_E + o; tm.P = l_P + o; tm.TP = l_TP + o;
+      tm.X = l_Q + ov; tm.W = l_W + ov; tm.R = l_R + ov;
     } else {
       const size_t o = (size_t)(b < t.B ? b : 0) * t.NN;
       tm.N = t.N + o; tm.W = t.W + o; tm.P = t.P + o; tm.R = t.R + o; tm.E = t.E + o; tm.TP = t.TP + o;
@@ -284,10 +285,12 @@ __global__ __launch_bounds__(256, 1) void k_search_h2(NetView n, TreeView t, con
           for (int k = tl; k < t.NN; k += TL) {
             tm.N[k] = 0; tm.W[k] = 0.0; tm.R[k] = 0.f; tm.E[k] = (k == 0) ? 0 : -1; tm.TP[k] = 1;
           }
+          for (int k = tl; k < have; k += TL) tm.X[k] = 0.0;
         } else {
-          for (int k = tl; k < have; k += TL) { tm.N[k] = 0; tm.E[k] = (k == 0) ? 0 : -1; }
+          for (int k = tl; k < have; k += TL) { tm.N[k] = 0; tm.E[k] = (k == 0) ? 0 : -1; tm.TP[k] = 1; }
+          if (tl == 0) { tm.W[0] = 0.0; tm.R[0] = 0.f; tm.X[0] = 0.0; }      // the root's expansion slot
         }
-        for (int k = tl; k < have; k += TL) { tm.P[k] = (k == 0) ? 0.0 : st[k - 1]; tm.X[k] = 0.0; }
+        for (int k = tl; k < have; k += TL) tm.P[k] = (k == 0) ? 0.0 : st[k - 1];
       }
     } else
     if (b < t.B) {
@@ -318,11 +321,14 @@ __global__ __launch_bounds__(256, 1) void k_search_h2(NetView n, TreeView t, con
         const size_t o = (size_t)b * t.NN;
         const int have = 1 + (slot0 + 1) * t.A;
         for (int k = tl; k < have; k += TL) {
-          const int nk = t.N[o + k];
-          tm.N[k] = (int16_t)nk; tm.P[k] = t.P[o + k]; tm.E[k] = (int16_t)t.E[o + k];
-          const double qk = nk > 0 ? t.W[o + k] / (double)nk : 0.0;
-          const double rk = (double)t.R[o + k];
-          tm.X[k] = t.two_players ? rk - t.discount * qk : rk + t.discount * qk;
+          const int nk = t.N[o + k], ek = t.E[o + k];
+          tm.N[k] = (int16_t)nk; tm.P[k] = t.P[o + k]; tm.E[k] = (int16_t)ek; tm.TP[k] = t.TP[o + k];
+          if (ek >= 0) {       // an expanded node: its value fields live in its expansion slot
+            const double qk = nk > 0 ? t.W[o + k] / (double)nk : 0.0;
+            const double rk = (double)t.R[o + k];
+            tm.W[ek] = t.W[o + k]; tm.R[ek] = t.R[o + k];
+            tm.X[ek] = t.two_players ? rk - t.discount * qk : rk + t.discount * qk;
+          }
         }
       }
     }
@@ -503,7 +509,7 @@ __global__ __launch_bounds__(256, 1) void k_search_h2(NetView n, TreeView t, con
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (NBG - 1)) : "memory");
     mz_partials_out<3, 0>(red, out4, tid);
     STAMP(8)
-    if constexpr (LT != 2) {
+    {
       const int q8 = tl & 7;
       MzQuad V, L;
       const unsigned ba = mz_lds_addr(s_b4 + 4 * q8);
@@ -526,28 +532,6 @@ __global__ __launch_bounds__(256, 1) void k_search_h2(NetView n, TreeView t, con
                                                s_pbc, s_rcp, tr, sim + 1 < nsims, my_slot, my_act,
                                                MzHiddenPrefetch{t.hpool, hoff, hv}, stampf);
       }
-    } else {
-      {
-        const int col = 4 * w + (lane_e >> 4), q = lane_e & 15, q8 = q & 7;
-        MzQuad V, L;
-        const unsigned ba = mz_lds_addr(s_b4 + 4 * q8);
-        mz_quad_issue<0>(V, mz_quad_addr(red, 4 * q8, col), ba);
-        asm volatile("s_waitcnt lgkmcnt(0)" : MZ_Q(V));
-        const f32x4 vs = mz_quad_sum(V);
-        mz_quad_issue<128>(L, mz_quad_addr(red, 32 + 4 * q8, col), ba);
-        const float v = mz_support_to_scalar_q(vs, n.vmin, n.no_transform, q8);
-        if (q == 0) s_val[col] = v;
-        asm volatile("s_waitcnt lgkmcnt(0)" : MZ_Q(L));
-        if (q < 8 && 4 * q < n.A) *(f32x4 *)(s_lg + col * 32 + 4 * q) = mz_quad_sum(L);
-      }
-      mz_bar();
-      STAMP(9)
-      if (b0 + mt < t.B) {
-        auto stampf = [&](int k) __attribute__((always_inline)) { STAMP(10 + k) };
-        mz_tree_step_fused<TL, G, LT, SP>(t, tm, tl, slot0 + sim + 1, s_val[mt], s_rew[mt], s_lg + mt * 32,
-                                          s_path + mt * MZ_FUSED_MAXPL, s_stage + mt * 96, s_pbc, s_rcp, tr,
-                                          sim + 1 < nsims, my_slot, my_act, t.hpool, hoff, hv, stampf);
-      }
     }
     STAMP(13)
   }
@@ -566,6 +550,10 @@ __global__ __launch_bounds__(256, 1) void k_search_h2(NetView n, TreeView t, con
         for (int k = tl; k < have; k += TL) {
           t.N[o + k] = tm.N[k]; t.P[o + k] = tm.P[k]; t.E[o + k] = tm.E[k];
           if constexpr (LT == 1) { t.W[o + k] = tm.W[k]; t.R[o + k] = tm.R[k]; t.TP[o + k] = tm.TP[k]; }
+          if constexpr (LT == 2) {
+            const int ek = tm.E[k];
+            t.W[o + k] = ek >= 0 ? tm.W[ek] : 0.0; t.R[o + k] = ek >= 0 ? tm.R[ek] : 0.f; t.TP[o + k] = tm.TP[k];
+          }
         }
       }
     }

@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256, 1) void k_net_recurrent_rows(NetView n, const 
 }
 
 // packed[i] = idx[i] >= 0 ? flat[idx[i]] : 0   (weights -> MFMA operand order)
-__global__ void k_pack_weights(const float *flat, const int32_t *idx, float *packed, size_t n) {
+static __global__ void k_pack_weights(const float *flat, const int32_t *idx, float *packed, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) packed[i] = idx[i] >= 0 ? flat[idx[i]] : 0.f;
 }

@@ -60,7 +60,7 @@ __device__ inline double mz_gamma(double alpha, uint64_t seed, uint32_t env, uin
 
 // noise[b] ~ Dirichlet(alpha * 1_legal)  (the draw of np.random.dirichlet in mcts.py:59, from the
 // device RNG instead of numpy's global stream; parity runs pass numpy's draw in instead)
-__global__ void k_dirichlet(TreeView t, const uint8_t *legal, double alpha, uint64_t seed, uint64_t move_val,
+static __global__ void k_dirichlet(TreeView t, const uint8_t *legal, double alpha, uint64_t seed, uint64_t move_val,
                             const unsigned long long *move_ptr, int env_offset) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= t.B) return;
@@ -93,7 +93,7 @@ __device__ __forceinline__ void mz_rec_put_double(float *dst, double v) {
 }
 
 // Game.apply (game.py:79-104) on the synthetic env + the experience record of this move.
-__global__ void k_env_step_record(TreeView tv, SelfplayState sp, int B, int O, int A, uint64_t seed) {
+static __global__ void k_env_step_record(TreeView tv, SelfplayState sp, int B, int O, int A, uint64_t seed) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   const unsigned long long move = sp.movecnt[b];

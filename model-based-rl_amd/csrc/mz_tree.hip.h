@@ -247,8 +247,12 @@ struct TreeRegs {
 //      16 bit), plus a cache X = reward + discount * (+-Q) of every visited node, the term MinMaxStats normalises: the
 //      backup computes it anyway for the MinMaxStats update (same operations, same order as the descent's own
 //      expression), so the descent reads one double instead of R and W/N and divides nothing;
-//   2  trees too large for (1): only what the DESCENT reads lives in LDS -- N, E, P and X -- while W, R and to_play,
-//      which only expand and backup touch (once per simulation, all path nodes in parallel), stay in the global pool.
+//   2  trees too large for (1): still everything in LDS, but compact -- per NODE only what exists for every node (visit
+//      count, expansion index, prior, to_play), per EXPANSION SLOT (num_simulations + 2 of them, not 1 + slots * A) what
+//      exists only for visited nodes, and a node is visited exactly when it is expanded: value_sum, reward and the X
+//      cache.  W[i], R[i], X[i] are therefore indexed by the expansion index E[node] here (root = slot 0); the descent
+//      fetches X[E[child]] beside its pb_c lookup (both hang on the first round trip), the backup E[node] first.
+//      Pong-ram shapes (307 nodes per tree): 97 KB instead of the 162 KB of placement (1).
 template <int LT> struct TreeMem;
 template <> struct TreeMem<0> { int32_t *N; double *W; double *P; float *R; int32_t *E; int8_t *TP; };
 template <> struct TreeMem<1> { int16_t *N; double *W; double *P; float *R; int16_t *E; int8_t *TP; double *X; };
@@ -301,11 +305,14 @@ __device__ __forceinline__ void mz_tree_expand_f(const TreeView &t, const TreeMe
   if (lane < A) {
     const int ch = 1 + __mul24(e_new, A) + lane;
     // (LT = 1: the kernel's prologue has written the fresh-Node fields of every node this launch can create)
-    if constexpr (LT != 1) { tm.N[ch] = 0; tm.W[ch] = 0.0; tm.R[ch] = 0.f; tm.E[ch] = -1; tm.TP[ch] = 1; }
+    if constexpr (LT == 0) { tm.N[ch] = 0; tm.W[ch] = 0.0; tm.R[ch] = 0.f; tm.E[ch] = -1; tm.TP[ch] = 1; }
+    if constexpr (LT == 2) { tm.N[ch] = 0; tm.E[ch] = -1; tm.TP[ch] = 1; }
     tm.P[ch] = p / sum;
   }
   if (lane == 0) {
-    tm.E[leafnode] = e_new; tm.R[leafnode] = reward;
+    tm.E[leafnode] = e_new;
+    if constexpr (LT == 2) { tm.W[e_new] = 0.0; tm.R[e_new] = reward; }      // (per expansion slot: a fresh Node's value_sum)
+    else tm.R[leafnode] = reward;
     if constexpr (!SP) tm.TP[leafnode] = (int8_t)tr.tp;        // (single player: it was created with to_play 1 and stays so)
   }
 }
@@ -361,9 +368,11 @@ __device__ __forceinline__ void mz_tree_backup_select_f(const TreeView &t, const
     const int j = base + lane;
     const bool act = j < len;
     const int node = s_path[act ? len - 1 - j : 0];
-    const double Wn = tm.W[node];
+    int vi = node;                                  // index of the node's value_sum / reward / X
+    if constexpr (LT == 2) vi = tm.E[node];         // (its expansion slot: every path node is expanded, the leaf just now)
+    const double Wn = tm.W[vi];
     const int Nn = tm.N[node];
-    const double r_node = (j == 0) ? (double)reward : (double)tm.R[node];
+    const double r_node = (j == 0) ? (double)reward : (double)tm.R[vi];
     int ntp = tp;
     if constexpr (!SP) ntp = (j == 0) ? tp : (int)tm.TP[node];
     const double r_signed = (two && ntp == tp) ? -r_node : r_node;
@@ -394,9 +403,9 @@ __device__ __forceinline__ void mz_tree_backup_select_f(const TreeView &t, const
     const double q = __builtin_fma(__builtin_fma(-dn, q0, w), yn, q0);     // = w / n, see above
     const double new_q = two ? r_node - g * q : r_node + g * q;     // = reward + discount * (two ? -Q : Q)
     if (act) {
-      tm.W[node] = w;
+      tm.W[vi] = w;
       tm.N[node] = n;
-      if constexpr (LT != 0) tm.X[node] = new_q;     // what the descent normalises (the root's is never read)
+      if constexpr (LT != 0) tm.X[vi] = new_q;       // what the descent normalises (the root's is never read)
     }
     const bool inner = act & (j < len - 1);          // MinMaxStats.update for every node but the root (mcts.py:136-141)
     mn_c = inner ? new_q : mn_c;
@@ -469,7 +478,9 @@ __device__ __forceinline__ void mz_tree_backup_select_f(const TreeView &t, const
     // pb_c table in LDS: rows 64 entries apart where it fits (a shift, no multiply), sims + 2 apart beside large trees
     const double prior_score = pbctab[(LT == 2 ? __mul24(Np, t.sims + 2) : (Np << 6)) + Nc] * p;
     double x;        // reward + discount * (+-Q) of the child; unused (may be stale or garbage) while Nc == 0
-    if constexpr (LT != 0) {
+    if constexpr (LT == 2) {
+      x = tm.X[Ec > 0 ? Ec : 0];                   // cached by the backup, per expansion slot
+    } else if constexpr (LT == 1) {
       x = tm.X[ch];                                // cached by the backup
     } else {
       const double q = tm.W[ch] / (double)(Nc > 0 ? Nc : 1);
@@ -690,7 +701,7 @@ __device__ __forceinline__ void mz_finalize_tree(const TreeView &t, int b, const
 }
 
 
-__global__ void k_tree_finalize(TreeView t, const double *temperature, const double *uniform, uint64_t seed,
+static __global__ void k_tree_finalize(TreeView t, const double *temperature, const double *uniform, uint64_t seed,
                                 uint64_t move_val, const unsigned long long *move_ptr, int env_offset,
                                 int32_t *action, double *child_visits, double *root_value, double *error,
                                 int32_t *visit_counts) {
@@ -702,7 +713,7 @@ __global__ void k_tree_finalize(TreeView t, const double *temperature, const dou
 }
 
 // hidden_out[b] = pool[b][slot[b]]  (what the reference hands to recurrent_inference, mcts.py:94-96)
-__global__ void k_gather_hidden(TreeView t, float *out) {
+static __global__ void k_gather_hidden(TreeView t, float *out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= t.B * MZ_H) return;
   const int b = i / MZ_H, k = i % MZ_H;
@@ -710,7 +721,7 @@ __global__ void k_gather_hidden(TreeView t, float *out) {
 }
 
 // store an externally computed hidden state into the slot the next expansion will own
-__global__ void k_scatter_hidden(TreeView t, const float *in, int root) {
+static __global__ void k_scatter_hidden(TreeView t, const float *in, int root) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= t.B * MZ_HS) return;
   const int b = i / MZ_HS, k = i % MZ_HS;

@@ -6,9 +6,15 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'
 import model_based_rl_amd  # noqa: F401  (import alias)
 from model_based_rl_amd import _abi
 src = os.path.join(os.path.dirname(_abi.__file__), 'csrc')
-cmd = ['hipcc'] + list(_abi.HIPCC_FLAGS) + ['-Rpass-analysis=kernel-resource-usage', 'mz_engine.hip', '-o', '/tmp/_mz_res.so']
-err = subprocess.run(cmd, cwd=src, capture_output=True, text=True).stderr
 flt = sys.argv[1] if len(sys.argv) > 1 else ''
+# every translation unit of the library (_abi.translation_units: the host unit and one unit per search-kernel shape)
+from concurrent.futures import ThreadPoolExecutor
+def remarks(unit):
+  name, source, defs = unit
+  cmd = ['hipcc'] + list(_abi.HIPCC_FLAGS) + defs + ['-Rpass-analysis=kernel-resource-usage', '-c', source, '-o', '/tmp/_mz_res_%s.o' % name]
+  return subprocess.run(cmd, cwd=src, capture_output=True, text=True).stderr
+with ThreadPoolExecutor(max_workers=os.cpu_count() or 1) as pool:
+  err = '\n'.join(pool.map(remarks, _abi.translation_units()))
 cur = None
 rows = {}
 for line in err.splitlines():
