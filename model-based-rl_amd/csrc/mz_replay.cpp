@@ -286,7 +286,14 @@ int mzr_ingest_records_from(mz_replay *r, const float *records, int n_moves, int
   std::vector<double> &pris = r->pend_pri;
   pend.clear();
   pris.clear();
-  for (int b = 0; b < B; ++b) {
+  const int PF = 6;       // envs ahead: an env's records lie n_moves strides of B * rec_floats apart (move-major ring),
+  for (int b = 0; b < B; ++b) {      // which no hardware prefetcher follows -- request them while the envs before are handled
+    if (b + PF < B)
+      for (int m = 0; m < n_moves; ++m) {
+        const char *q = (const char *)(records + ((size_t)m * B + b + PF) * rec_floats);
+        __builtin_prefetch(q, 0, 1);
+        __builtin_prefetch(q + 64, 0, 1);
+      }
     EnvGame &g = r->envs[(size_t)env_base + b];
     for (int m = 0; m < n_moves; ++m) {
       const float *rec = records + ((size_t)m * B + b) * rec_floats;

@@ -11,8 +11,8 @@ t = ((np.arange(B, dtype=np.uint32) * np.uint32(2654435761)) >> 8) % T
 ep = np.zeros(B, np.int32)
 ts = []
 for it in range(200):
-  rec = rng.standard_normal((8, B, O + A + 8)).astype(np.float32)
-  ints = rec[..., O + A + 3:].view(np.int32)
+  rec = rng.standard_normal((8, B, O + A + 10)).astype(np.float32)
+  ints = rec[..., O + A + 5:].view(np.int32)
   for m in range(8):
     ints[m, :, 0] = 1; ints[m, :, 1] = (t + 1 >= T); ints[m, :, 2] = t; ints[m, :, 3] = np.arange(B); ints[m, :, 4] = ep
     done = t + 1 >= T
