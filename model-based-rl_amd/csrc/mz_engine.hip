@@ -629,7 +629,8 @@ static int launch_fused_t(mz_engine *e, int num_simulations, int sims_done, hipS
 }
 
 // fused-kernel instantiations: (fc1 k-steps, policy tiles, lanes per tree) by action count
-static int fused_ks1(int A) { return A <= 5 ? 14 : (A <= 13 ? 16 : (A <= 21 ? 18 : 21)); }
+// (dynamics fc1: K = 50 + A + 1 columns in k-steps of 4)
+static int fused_ks1(int A) { return A <= 5 ? 14 : (A <= 8 ? 15 : (A <= 13 ? 16 : (A <= 21 ? 18 : 21))); }
 
 static int launch_fused(mz_engine *e, int num_simulations, int sims_done, hipStream_t s) {
   const int A = e->A;
@@ -644,12 +645,12 @@ static int launch_fused(mz_engine *e, int num_simulations, int sims_done, hipStr
   }
 #ifdef MZ_DEV_ONLY      // kernel development: only the two bench shapes are instantiated (a quarter of the build time)
   if (A <= 4) return launch_fused_t<14, 1, 4>(e, num_simulations, sims_done, s);
-  if (A >= 6 && A <= 8) return launch_fused_t<16, 1, 8>(e, num_simulations, sims_done, s);
+  if (A >= 6 && A <= 8) return launch_fused_t<15, 1, 8>(e, num_simulations, sims_done, s);
   return fail("MZ_DEV_ONLY build: action_space %d not instantiated", A);
 #else
   if (A <= 4) return launch_fused_t<14, 1, 4>(e, num_simulations, sims_done, s);
   if (A <= 5) return launch_fused_t<14, 1, 8>(e, num_simulations, sims_done, s);
-  if (A <= 8) return launch_fused_t<16, 1, 8>(e, num_simulations, sims_done, s);
+  if (A <= 8) return launch_fused_t<15, 1, 8>(e, num_simulations, sims_done, s);
   if (A <= 13) return launch_fused_t<16, 1, 16>(e, num_simulations, sims_done, s);
   if (A <= 16) return launch_fused_t<18, 1, 16>(e, num_simulations, sims_done, s);
   if (A <= 21) return launch_fused_t<18, 2, 32>(e, num_simulations, sims_done, s);
