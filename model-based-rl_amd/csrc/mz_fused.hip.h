@@ -1100,4 +1100,7 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
     for (int i = 0; i < 8; ++i) prof[((size_t)blockIdx.x * 4 + (tid0 >> 6)) * 8 + i] = hs_acc[i];
   if (PROF && (tid0 & 63) == 0)
     for (int i = 0; i < MZ_NPHASE; ++i) prof[((size_t)blockIdx.x * 4 + (tid0 >> 6)) * MZ_NPHASE + i] = pacc[i];
+#undef MZ_BLOAD
+#undef MZ_WLOAD
+#undef HSTAMP
 }
