@@ -1,6 +1,7 @@
 """Secondary bench line (never the headline): BASELINE.json configs[4] on one GPU -- Breakout image shapes
 ([4, 96, 96] uint8 frames, 4 actions), MuZeroNetwork (23.4 M parameters, reference networks.py:498-555) at
-num_simulations=50, batch of 512 self-play environments.  The network runs through PyTorch-ROCm / MIOpen in float32
+num_simulations=50, 4096 self-play environments per GPU (env-steps/s by env count, MI355X: 512: 1.49 k, 1024: 1.97 k,
+2048: 2.34 k, 4096: 2.47 k -- MIOpen's convolutions want the rows).  The network runs through PyTorch-ROCm / MIOpen in float32
 (no hand-written conv kernels); the search runs through the engine's external-inference entry
 points (mz_select / mz_expand_backup) with the hidden states in a device-resident pool -- no host synchronisation in
 the simulation loop (model-based-rl_amd/torch_search.py).  Called by bench.py --workload breakout.
@@ -41,7 +42,7 @@ def main(args):
   from model_based_rl_amd.replay_buffer import PrioritizedReplay
   from model_based_rl_amd.torch_search import TorchSelfplay
 
-  B = args.envs or 512
+  B = args.envs or 4096
   A, SIMS, T, OBS = 4, 50, 64, (4, 96, 96)
   steps = args.steps if args.steps != 512 else 6             # (bench.py's FC default would be ~4 minutes here)
   warmup = args.warmup if args.warmup != 64 else 2
