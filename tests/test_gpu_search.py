@@ -184,19 +184,24 @@ def test_all_search_paths_agree_bit_for_bit():
     assert np.abs(a[wk][same, 0] - c[wk][same, 0]).max() <= 1e-4 * (1 + np.abs(c[wk][same, 0]).max())
 
 
-def test_search_in_two_calls_equals_one_call():
-  """mz_search(10) + mz_search(20) continues the same trees (the fused kernel reloads the partial tree)."""
-  from oracle import oracle as orc
-  from model_based_rl_amd.engine import Engine
-  g = np.load(os.path.join(G, 'g1_net_lunar.npz'))
-  w = orc.load_weights(g)
+@pytest.mark.parametrize('A,sims', [(4, 30), (6, 50)])
+def test_search_in_two_calls_equals_one_call(A, sims):
+  """mz_search(10) + mz_search(20) continues the same trees (the fused kernel reloads the partial tree): trees entirely in
+  LDS per node (4 actions, 30 simulations) and in the compact per-node / per-expansion-slot layout (6 actions, 50
+  simulations: the continuation has to sort the pool's per-node value sums back into their slots)."""
+  import types
+  import torch
+  from model_based_rl_amd.engine import Engine, flatten_weights
+  from model_based_rl_amd.networks import FCNetwork
+  torch.manual_seed(3)
+  w = flatten_weights(FCNetwork(8, A, torch.device('cpu'), types.SimpleNamespace()).state_dict())
   rng = np.random.RandomState(5)
   B = 128
   obs = rng.standard_normal((B, 8)).astype(np.float32)
-  noise = rng.dirichlet([0.25] * 4, size=B)
+  noise = rng.dirichlet([0.25] * A, size=B)
   res = []
-  for split in ((30,), (10, 20), (1, 1, 28)):
-    eng = Engine(B, 8, 4, 30)
+  for split in ((sims,), (10, sims - 10), (1, 1, sims - 2)):
+    eng = Engine(B, 8, A, sims)
     eng.set_weights(w)
     eng.initial_inference(obs)
     eng.root_prepare(None, None, noise)
@@ -206,7 +211,7 @@ def test_search_in_two_calls_equals_one_call():
     with pytest.raises(RuntimeError, match='exceed'):
       eng.search(1)
     eng.close()
-  for k in ('N', 'W', 'E', 'minmax'):
+  for k in ('N', 'W', 'E', 'R', 'minmax'):
     assert np.array_equal(res[0][k], res[1][k]) and np.array_equal(res[0][k], res[2][k]), k
 
 
