@@ -216,6 +216,13 @@ int mz_selfplay_set_obs(mz_engine *e, int uint8_obs, const float *obs_min, const
 /* keep != 0: every move of the self-play loop also writes its searched tree back to the node pool (so that
  * mz_export_tree after mz_selfplay_steps shows the last move's tree).  Default 0: the loop never reads it. */
 int mz_selfplay_export_trees(mz_engine *e, int keep);
+/* keep != 0: every move also stores its Dirichlet draw (mcts.py:59; drawn on the device in this loop) in a per-move log
+ * as long as the experience ring; mz_selfplay_read_noise copies the draw of move `move` (0 = first move after
+ * mz_selfplay_reset, one of the last ring_moves moves) to out [host][B][A] float64, synchronously.  Test
+ * instrumentation: any move of a whole-moves launch can be replayed on the CPU by the parity tests with the device's own draw
+ * and the observation its record carries. */
+int mz_selfplay_noise_log(mz_engine *e, int keep);
+int mz_selfplay_read_noise(mz_engine *e, uint64_t move, double *out);
 int mz_selfplay_steps(mz_engine *e, int moves, void *stream);
 /* mz_selfplay_steps with one pair of HIP events around every search-kernel dispatch (hipExtLaunchKernelGGL start / stop
  * events on `stream`: the timestamps rocprofv3's kernel trace reports).  The k moves are launched eagerly, back to back,

@@ -115,6 +115,8 @@ SIGNATURES = {
     'mz_selfplay_set_temperature': (_I, [_VP, _D, _VP]),
     'mz_selfplay_set_obs': (_I, [_VP, _I, _VP, _VP]),
     'mz_selfplay_export_trees': (_I, [_VP, _I]),
+    'mz_selfplay_noise_log': (_I, [_VP, _I]),
+    'mz_selfplay_read_noise': (_I, [_VP, _U64, _VP]),
     'mz_selfplay_steps': (_I, [_VP, _I, _VP]),
     'mz_selfplay_steps_timed': (_I, [_VP, _I, _VP, _VP]),
     'mz_selfplay_phase_profile': (_I, [_VP, _I, _VP, _VP]),

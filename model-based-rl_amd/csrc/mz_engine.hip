@@ -97,6 +97,7 @@ struct mz_engine {
   uint16_t *packed_h2 = nullptr;    // [4 waves][NGROUPS][8 pieces][64 lanes][8] float16
   size_t n_packed_h2 = 0;
   float *obs_norm = nullptr;        // [2][O] --norm_obs minimum and range (device)
+  double *noise_log = nullptr;      // [ring_moves][B][A] per-move Dirichlet draws (mz_selfplay_noise_log), allocated on first use
   std::vector<float> obs_norm_host;
 };
 

@@ -264,7 +264,11 @@ __device__ __forceinline__ void mz_root_body(const NetView &n, const TreeView &t
         const double gam = tl < A ? mz_gamma(alpha, seed, (uint32_t)(sp.env_offset + b), move, (uint32_t)tl) : 0.0;
         double sum = 0.0;
         for (int a = 0; a < A; ++a) sum += __shfl(gam, a, G);
-        if (tl < A) t.noise[(size_t)b * A + tl] = sum > 0.0 ? gam / sum : 1.0 / A;
+        if (tl < A) {
+          const double nz = sum > 0.0 ? gam / sum : 1.0 / A;
+          t.noise[(size_t)b * A + tl] = nz;
+          if (sp.noise_log) sp.noise_log[((size_t)(move % (unsigned long long)sp.ring_moves) * t.B + b) * A + tl] = nz;
+        }
         __threadfence_block();
         const uint32_t mask = (A >= 32) ? 0xFFFFFFFFu : ((1u << A) - 1u);
         mz_tree_root<G, true>(t, b, tl, 1, mask, s_lg + mt * 32, t.noise + (size_t)b * A, frac,

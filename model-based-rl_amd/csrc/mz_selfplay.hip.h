@@ -17,6 +17,8 @@ struct SelfplayState {
   const float *obs_min, *obs_rng;   // [O] --norm_obs: network input = (obs - min) / range (actors.py:55-58,134-137); null = raw
   int obs_u8;            // synthetic observations are uint8-valued (the -ram- envs: 128 bytes of console RAM), else ~N(0,1)
   int export_trees;      // write the searched trees back to the global pool at the end of every move (tests / tree export)
+  double *noise_log;     // [ring_moves][B][A] or null: every move's Dirichlet draw, kept per move (mz_selfplay_noise_log: the
+                         // parity tests replay the moves of a whole-moves launch on the CPU with the device's own draws)
   int32_t *action;       // [B]
   double *child_visits;  // [B][A]
   double *root_value, *error;   // [B]

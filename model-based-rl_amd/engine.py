@@ -306,6 +306,15 @@ class Engine(object):
   def selfplay_export_trees(self, keep=True):
     _abi.check(self.lib.mz_selfplay_export_trees(self._h, int(bool(keep))), 'mz_selfplay_export_trees')
 
+  def selfplay_noise_log(self, keep=True):
+    """Keep every move's Dirichlet draw (test instrumentation; selfplay_noise(move) reads one move's draws)."""
+    _abi.check(self.lib.mz_selfplay_noise_log(self._h, int(bool(keep))), 'mz_selfplay_noise_log')
+
+  def selfplay_noise(self, move):
+    out = np.zeros((self.B, self.A), np.float64)
+    _abi.check(self.lib.mz_selfplay_read_noise(self._h, int(move), out.ctypes.data_as(C.c_void_p)), 'mz_selfplay_read_noise')
+    return out
+
   def selfplay_steps(self, moves):
     _abi.check(self.lib.mz_selfplay_steps(self._h, int(moves), self.stream), 'mz_selfplay_steps')
 

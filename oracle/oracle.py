@@ -111,6 +111,13 @@ class Trees(object):
     lib().orc_get_paths(self._h, _p(out))
     return out
 
+  def margin(self):
+    """per tree: the smallest gap between the best and the second-best score over all select_child decisions since
+    root_expand (mcts.py:104-113) -- what make_goldens.py records from the reference as `min_margin`."""
+    out = np.zeros(self.B, np.float64)
+    lib().orc_get_margin(self._h, _p(out))
+    return out
+
   def expand_backup(self, value, reward, logits):
     value = np.ascontiguousarray(value, np.float32)
     reward = np.ascontiguousarray(reward, np.float32)
@@ -145,6 +152,37 @@ class Trees(object):
     lib().orc_search_fc(self._h, C.byref(net.c), _p(obs), _p(to_play), _p(legal), _p(noise), C.c_double(frac),
                         _p(hpool), _p(v0))
     return hpool, v0
+
+
+def search_fc_threads(cfg, net, obs, to_play=None, legal=None, noise=None, frac=0.25, temperature=1.0, uniform=None,
+                      threads=None, tree=True):
+  """Trees.search_fc + finalize (+ export) for a large batch, the trees split over `threads` host threads (the
+  trees are independent and ctypes releases the GIL).  Returns a dict: action, child_visits, root_value, visit_counts,
+  margin, v0, hpool and, with tree=True, 'tree' = Trees.export()."""
+  from concurrent.futures import ThreadPoolExecutor
+  obs = np.ascontiguousarray(obs, np.float32)
+  B = obs.shape[0]
+  threads = max(1, min(threads or len(os.sched_getaffinity(0)), B))
+  to_play = np.ones(B, np.int8) if to_play is None else np.ascontiguousarray(to_play, np.int8)
+  temperature = np.ascontiguousarray(np.broadcast_to(temperature, (B,)), np.float64)
+  uniform = np.zeros(B) if uniform is None else np.ascontiguousarray(np.broadcast_to(uniform, (B,)), np.float64)
+  cuts = np.linspace(0, B, threads + 1).astype(int)
+
+  def part(i):
+    sl = slice(cuts[i], cuts[i + 1])
+    t = Trees(cfg, cuts[i + 1] - cuts[i])
+    hpool, v0 = t.search_fc(net, obs[sl], to_play[sl], None if legal is None else legal[sl],
+                            None if noise is None else noise[sl], frac)
+    action, cv, rv, vc = t.finalize(temperature[sl], uniform[sl])
+    return dict(action=action, child_visits=cv, root_value=rv, visit_counts=vc, margin=t.margin(), v0=v0, hpool=hpool,
+                tree=t.export() if tree else None)
+
+  with ThreadPoolExecutor(threads) as ex:
+    parts = list(ex.map(part, range(threads)))
+  out = {k: np.concatenate([p[k] for p in parts]) for k in parts[0] if k != 'tree'}
+  if tree:
+    out['tree'] = {k: np.concatenate([p['tree'][k] for p in parts]) for k in parts[0]['tree']}
+  return out
 
 
 class FCNet(object):

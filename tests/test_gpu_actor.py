@@ -176,9 +176,14 @@ def test_device_selfplay_records_and_sharding():
   t = orc.Trees(orc.tree_cfg(A, 30), 32)
   t.search_fc(orc.FCNet(w, O, A), rec[-1, :, :O], np.ones(32, np.int8), None, noise, 0.25)
   _, cvo, rvo, _ = t.finalize(1.0, np.zeros(32))
-  same = np.all(np.abs(cvo - cv[-1]) < 1e-6, axis=1)
-  assert same.mean() >= 0.9
-  assert np.abs(rvo - rv['root_value'][-1])[same].max() < 5e-4
+  # margin rule (tests/test_gpu_search.py): 100 % identity in every tree whose closest select_child decision was
+  # further than 1e-4 from a tie; the rest is counted
+  wide = t.margin() > 1e-4
+  same = np.all(cvo.astype(np.float32) == cv[-1], axis=1)
+  print('device self-play, last move vs oracle: %d of 32 trees above the margin, all identical: %s; below: %d of %d identical'
+        % (wide.sum(), bool(np.all(same[wide])), (same & ~wide).sum(), (~wide).sum()))
+  assert wide.sum() >= 16 and np.all(same[wide]), (np.flatnonzero(wide & ~same), t.margin()[wide & ~same])
+  assert np.abs(rvo - rv['root_value'][-1])[wide].max() < 5e-4
   eng.close()
   eng2, rec2 = run(16, 16)
   assert np.array_equal(rec2.view(np.int32), rec[:, 16:32].view(np.int32))      # (bit patterns: the float64 halves may read as NaN)

@@ -1,0 +1,129 @@
+"""The launch bench.py times, at the size bench.py times it, against the CPU oracle.
+
+BENCH_rNN's `value` is produced by the persistent HEAD instantiation of the search kernel (whole moves inside one launch,
+mz_selfplay_steps) on a full grid: 4096 environments = 256 workgroups, 8 moves per launch.  This test runs exactly that --
+three launches of 8 moves, a weight update before the third -- with the per-move Dirichlet log on
+(mz_selfplay_noise_log), takes the observation of a move from its experience record and the Dirichlet draw from the log,
+and replays single moves (the first, one in the middle of the second launch, one in the middle of the third, the last)
+through oracle/mz_oracle.c on all 4096 trees.
+
+Rule: the oracle reports, per tree, the smallest gap between the best and the second-best score over
+all select_child decisions of the search (mcts.py:104-113; pinned bit for bit against the reference's own number in
+tests/test_oracle_tree.py).  In EVERY tree whose margin is above MARGIN the device's visit vector, sampled action and --
+where the tree is exported -- every integer field must be the oracle's: 100 %, no percentage threshold.  Trees below the
+margin are counted and printed; a decision that close to a tie may legitimately resolve the other way, because the two
+float32 network evaluations differ in summation order (network outputs agree to 1e-5, tests/test_gpu_net.py).
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), 'golden')
+MARGIN = 1e-4
+
+
+def philox_action_uniform(seed, env, move):
+  """The uniform the device's select_action consumes for (env, move): Philox4x32-10 keyed by the engine seed, counter
+  (env, move lo, move hi, MZ_RNG_ACTION << 24), 53 bits of (x, y) (csrc/mz_rng.h, csrc/mz_tree.hip.h:mz_finalize_tree) --
+  integer arithmetic, restated here so that the oracle's Config.select_action gets the draw the device used."""
+  env = np.asarray(env, np.uint64)
+  c = [env & np.uint64(0xFFFFFFFF), np.full_like(env, move & 0xFFFFFFFF), np.full_like(env, move >> 32),
+       np.full_like(env, 4 << 24)]
+  k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+  M = np.uint64(0xFFFFFFFF)
+  for _ in range(10):
+    p0 = np.uint64(0xD2511F53) * c[0]
+    p1 = np.uint64(0xCD9E8D57) * c[2]
+    c = [(p1 >> np.uint64(32)) ^ c[1] ^ np.uint64(k0), p1 & M, (p0 >> np.uint64(32)) ^ c[3] ^ np.uint64(k1), p0 & M]
+    k0, k1 = (k0 + 0x9E3779B9) & 0xFFFFFFFF, (k1 + 0xBB67AE85) & 0xFFFFFFFF
+  v = ((c[0] << np.uint64(32)) | c[1]) >> np.uint64(11)
+  return v.astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+SHAPES = {
+    # BASELINE configs[1]: LunarLander-v2 shapes, 30 simulations  /  configs[3]: Pong-ram shapes, 50 simulations, bytes + norm_obs
+    'lunar': dict(gold='g1_net_lunar', O=8, A=4, sims=30, u8=False),
+    'pong': dict(gold='g1_net_pong', O=128, A=6, sims=50, u8=True),
+}
+
+
+def perturbed(w, seed):
+  """a second set of weights ('the learner published an update'): every tensor nudged by ~1 %"""
+  rng = np.random.RandomState(seed)
+  return {k: (v * (1 + 0.01 * rng.standard_normal(v.shape))).astype(np.float32) for k, v in w.items()}
+
+
+@pytest.mark.parametrize('shape,split', [('lunar', False), ('lunar', True), ('pong', False), ('pong', True)])
+def test_persistent_launch_on_a_full_grid_vs_oracle(shape, split):
+  import torch
+  from oracle import oracle as orc
+  from model_based_rl_amd.engine import Engine, records_view
+  sh = SHAPES[shape]
+  O, A, sims = sh['O'], sh['A'], sh['sims']
+  B, T, seed, chunk = 4096, 11, 1234, 8                  # bench.py: 4096 envs, 8 moves per launch
+  w0 = orc.load_weights(np.load(os.path.join(G, sh['gold'] + '.npz')))
+  w1 = perturbed(w0, 5)
+  eng = Engine(B, O, A, sims, seed=seed, split_f16=split)
+  assert eng.selfplay_moves_per_launch() == 16           # the whole-moves (HEAD) launch is what runs
+  assert eng.split_f16 == split
+  eng.set_weights(w0)
+  if sh['u8']:
+    eng.selfplay_set_obs(uint8_obs=True, obs_min=[0.0], obs_range=[255.0])
+  eng.selfplay_noise_log(True)
+  eng.selfplay_reset(T, 1.0, stagger=True)
+  eng.selfplay_steps(chunk)
+  eng.selfplay_steps(chunk)
+  eng.set_weights(w1)
+  eng.selfplay_export_trees(True)                        # (a run-time flag of the same instantiation: the last move's trees)
+  eng.selfplay_steps(chunk)
+  buf, n = eng.selfplay_drain()
+  torch.cuda.synchronize()
+  assert n == 3 * chunk
+  rec = buf[:n].numpy().copy()
+  rv = records_view(rec, O, A)
+  tree = eng.export_tree()
+  cfg = orc.tree_cfg(A, sims)
+  report = []
+  for m, w in ((0, w0), (chunk + 3, w0), (2 * chunk + 1, w1), (3 * chunk - 1, w1)):
+    raw = rec[m, :, :O]
+    for b in (0, 1777, B - 1):                           # the record's observation is the synthetic env's (env, episode, t)
+      assert np.array_equal(raw[b], eng.synth_obs(b, int(rv['episode'][m, b]), int(rv['step'][m, b]))[0])
+    obs = (raw - np.float32(0.0)) / np.float32(255.0) if sh['u8'] else raw       # actors.py:134-137 in float32
+    noise = eng.selfplay_noise(m)
+    assert np.abs(noise.sum(1) - 1).max() < 1e-12 and noise.min() >= 0
+    u = philox_action_uniform(seed, np.arange(B), m)
+    ref = orc.search_fc_threads(cfg, orc.FCNet(w, O, A), obs, noise=noise, temperature=1.0, uniform=u,
+                                tree=(m == 3 * chunk - 1))
+    wide = ref['margin'] > MARGIN
+    cv = rv['child_visits'][m]
+    same = np.all(cv == ref['child_visits'].astype(np.float32), axis=1)
+    same_act = rv['action'][m] == ref['action']
+    drv = np.abs(rv['root_value'][m] - ref['root_value'])
+    derr = np.abs(rv['error'][m] - (ref['root_value'] - ref['v0'].astype(np.float64)))
+    line = ('%s%s move %2d: %d of %d trees above margin %.0e; visit vectors identical in %d of them and in %d of the %d '
+            'below; max |root value - oracle| %.2e' % (shape, ' split-f16' if split else '', m, wide.sum(), B, MARGIN,
+                                                      (same & wide).sum(), (same & ~wide).sum(), (~wide).sum(),
+                                                      drv[wide].max()))
+    print(line)
+    report.append(line)
+    assert wide.mean() > 0.5                              # (the guard must not empty the test)
+    bad = np.flatnonzero(wide & ~same)
+    assert bad.size == 0, (m, bad[:8], ref['margin'][bad[:8]], cv[bad[:8]], ref['child_visits'][bad[:8]])
+    assert np.all(same_act[wide & same]), (m, np.flatnonzero(wide & ~same_act)[:8])
+    assert drv[wide].max() <= 5e-4 and derr[wide].max() <= 5e-4
+    assert drv.max() <= 5e-3                              # (a flipped near-tie, not a logic error)
+    assert np.all(np.take_along_axis(cv, rv['action'][m][:, None], -1) > 0)
+    if ref.get('tree') is not None:                       # the last move: every integer field of the exported trees
+      for k in ('N', 'E'):
+        eq = np.all(tree[k] == ref['tree'][k], axis=1)
+        assert np.all(eq[wide]), (k, np.flatnonzero(wide & ~eq)[:8])
+      whole = np.all(tree['N'] == ref['tree']['N'], axis=1) & np.all(tree['E'] == ref['tree']['E'], axis=1)
+      assert np.abs(tree['W'][whole] - ref['tree']['W'][whole]).max() <= 5e-3
+      assert np.array_equal(tree['noise'], noise)
+  eng.close()
+  out = os.environ.get('MZ_PARITY_REPORT')
+  if out:
+    with open(out, 'a') as f:
+      f.write('\n'.join(report) + '\n')

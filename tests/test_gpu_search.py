@@ -3,11 +3,13 @@ engine's own MFMA network in the loop) vs the CPU oracle running the same search
 full-game goldens.
 
 Network outputs agree only to ~1e-6 between the two, so a UCB near-tie can in principle resolve
-differently.  Bar: visit-count vectors identical in >= 99 % of the trees; in those trees
-the root values agree to 5e-4 (each leaf value/reward carries the reference's own float32 staircase of
-~1.2e-4*(1+|v|), see tests/test_oracle_net.py) and every integer field of the tree is identical; in a
-tree whose visit vector differs the root values still agree to 5e-3 (a flipped near-tie, not a logic
-error).
+differently.  The oracle reports, per tree, the smallest gap between the best and the second-best
+score over every select_child decision of the search (mcts.py:104-113; pinned bit for bit to the reference's own
+number in tests/test_oracle_tree.py).  Bar: in EVERY tree whose margin is above MARGIN the visit vector, the
+sampled action and every integer field of the tree are the oracle's -- 100 %, no percentage threshold -- and the
+root values agree to 5e-4 (each leaf value/reward carries the reference's own float32 staircase of
+~1.2e-4*(1+|v|), see tests/test_oracle_net.py); the trees below the margin are counted and printed, and their
+root values still agree to 5e-3 (a flipped near-tie, not a logic error).
 """
 import os
 
@@ -16,6 +18,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(__file__), 'golden')
+MARGIN = 1e-4
 
 
 def random_weights(O, A, seed):
@@ -70,7 +73,26 @@ def run_both(name, B, sims, two=False, bounds=(None, None), discount=0.997, lega
   hpool, v0 = t.search_fc(net, obs, tp, legal, noise, 0.25)
   action, cv, rv, vc = t.finalize(temp, u)
   return out, ex, dict(action=action, child_visits=cv, root_value=rv, visit_counts=vc, hpool=hpool, v0=v0,
-                       tree=t.export())
+                       tree=t.export(), margin=t.margin())
+
+
+def check_against_oracle(out, ex, ref, what):
+  """the margin rule of this module's docstring"""
+  wide = ref['margin'] > MARGIN
+  same = np.all(out['visit_counts'] == ref['visit_counts'], axis=1)
+  whole = np.all(ex['N'] == ref['tree']['N'], axis=1) & np.all(ex['E'] == ref['tree']['E'], axis=1)
+  print('%s: %d of %d trees above margin %.0e: visit vectors identical in %d, whole trees in %d; below the margin: %d of %d / %d'
+        % (what, wide.sum(), wide.size, MARGIN, (same & wide).sum(), (whole & wide).sum(), (same & ~wide).sum(),
+           (whole & ~wide).sum(), (~wide).sum()))
+  assert wide.mean() >= 0.5, wide.mean()                  # (the guard must not empty the test)
+  assert np.all(same[wide]), (np.flatnonzero(wide & ~same)[:8], ref['margin'][wide & ~same][:8])
+  assert np.all(whole[wide]), (np.flatnonzero(wide & ~whole)[:8], ref['margin'][wide & ~whole][:8])
+  assert np.array_equal(out['action'][wide], ref['action'][wide])
+  assert np.array_equal(ex['TP'][wide], ref['tree']['TP'][wide])
+  d = np.abs(out['root_value'] - ref['root_value'])
+  assert d[wide].max() <= 5e-4 and d.max() <= 5e-3, (d[wide].max(), d.max())
+  # identical decisions everywhere => hidden states agree to 5e-4 (1e-5 per inference, compounded over chains up to ~20 deep)
+  assert np.abs(ex['hidden'][wide] - ref['hpool'][wide]).max() <= 5e-4
 
 
 @pytest.mark.parametrize('name,B,sims,two,bounds,discount,legal_p', [
@@ -90,18 +112,7 @@ def run_both(name, B, sims, two=False, bounds=(None, None), discount=0.997, lega
 ])
 def test_search_vs_oracle(name, B, sims, two, bounds, discount, legal_p):
   out, ex, ref = run_both(name, B, sims, two, bounds, discount, legal_p)
-  same = np.all(out['visit_counts'] == ref['visit_counts'], axis=1)
-  assert same.mean() >= 0.99, same.mean()
-  assert np.abs(out['root_value'] - ref['root_value'])[~same].max(initial=0) <= 5e-3
-  assert np.abs(out['root_value'] - ref['root_value'])[same].max() <= 5e-4
-  assert np.array_equal(out['action'][same], ref['action'][same])
-  # trees that made identical decisions everywhere (whole N array equal) are identical in every integer
-  # field; their hidden states agree to 5e-4 (1e-5 per inference, compounded over chains up to ~20 deep)
-  # (a near-tie can also resolve in the other ORDER and end in the same N: such trees differ in E only)
-  whole = np.all(ex['N'] == ref['tree']['N'], axis=1) & np.all(ex['E'] == ref['tree']['E'], axis=1)
-  assert whole.mean() >= 0.98, whole.mean()
-  assert np.array_equal(ex['TP'][whole], ref['tree']['TP'][whole])
-  assert np.abs(ex['hidden'][whole] - ref['hpool'][whole]).max() <= 5e-4
+  check_against_oracle(out, ex, ref, 'exact f32 %s B=%d sims=%d' % (name, B, sims))
 
 
 def test_search_graph_and_eager_agree():
@@ -231,13 +242,7 @@ def test_search_in_two_calls_equals_one_call(A, sims):
 def test_split_f16_search_vs_oracle(name, B, sims, two, bounds, discount, legal_p, monkeypatch):
   monkeypatch.setenv('MZ_SPLIT_F16', '1')
   out, ex, ref = run_both(name, B, sims, two, bounds, discount, legal_p)
-  same = np.all(out['visit_counts'] == ref['visit_counts'], axis=1)
-  assert same.mean() >= 0.99, same.mean()
-  assert np.abs(out['root_value'] - ref['root_value'])[same].max() <= 5e-4
-  assert np.array_equal(out['action'][same], ref['action'][same])
-  whole = np.all(ex['N'] == ref['tree']['N'], axis=1) & np.all(ex['E'] == ref['tree']['E'], axis=1)
-  assert whole.mean() >= 0.98, whole.mean()
-  assert np.abs(ex['hidden'][whole] - ref['hpool'][whole]).max() <= 5e-4
+  check_against_oracle(out, ex, ref, 'split f16 %s B=%d sims=%d' % (name, B, sims))
 
 
 def test_split_f16_network_error_and_config():

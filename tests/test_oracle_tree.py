@@ -45,6 +45,9 @@ def replay_moves(g, batched):
     for k in ('N', 'W', 'P', 'R', 'E', 'TP', 'EX'):
       assert np.array_equal(ex[k], g['tree_' + k][idx]), k
     assert np.array_equal(ex['minmax'], g['minmax'][idx])
+    # the smallest top-2 score gap over all select_child decisions of the move: the reference's own number, bit for bit
+    # (the GPU parity tests demand 100 % identity in every tree whose margin is above the network's float32 noise)
+    assert np.array_equal(t.margin(), g['min_margin'][idx])
     temp = g['temperature'][idx]
     u = np.where(g['uniform'][idx] < 0, 0.0, g['uniform'][idx])
     action, cv, rv, vc = t.finalize(temp, u)
@@ -63,6 +66,30 @@ def replay_moves(g, batched):
 @pytest.mark.parametrize('batched', [False, True], ids=['b1', 'batched'])
 def test_tree_bit_exact(path, batched):
   replay_moves(np.load(path), batched)
+
+
+def test_threaded_search_equals_one_batch():
+  """oracle.search_fc_threads (what the large GPU parity tests run) splits the batch over host threads: same trees,
+  same margins as one Trees object over the whole batch."""
+  g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'g1_net_lunar.npz'))
+  w = orc.load_weights(g)
+  B, O, A, sims = 37, 8, 4, 12
+  rng = np.random.RandomState(1)
+  obs = rng.standard_normal((B, O)).astype(np.float32)
+  noise = rng.dirichlet([0.25] * A, size=B)
+  u = rng.uniform(size=B)
+  cfg = orc.tree_cfg(A, sims)
+  net = orc.FCNet(w, O, A)
+  t = orc.Trees(cfg, B)
+  hpool, v0 = t.search_fc(net, obs, np.ones(B, np.int8), None, noise, 0.25)
+  action, cv, rv, vc = t.finalize(1.0, u)
+  r = orc.search_fc_threads(cfg, net, obs, noise=noise, uniform=u, threads=3)
+  assert np.array_equal(r['action'], action) and np.array_equal(r['visit_counts'], vc) and np.array_equal(r['root_value'], rv)
+  assert np.array_equal(r['margin'], t.margin()) and np.array_equal(r['hpool'], hpool) and np.array_equal(r['v0'], v0)
+  ex = t.export()
+  for k in ex:
+    assert np.array_equal(r['tree'][k], ex[k]), k
+  assert np.all(r['margin'] >= 0) and np.isfinite(r['margin']).all()
 
 
 def test_slot_is_parent_hidden():
