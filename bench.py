@@ -143,28 +143,117 @@ def cpu_baseline_reference_shaped():
           'fidelity': 'profiles/r02_ref_shaped_ratio.json (timed beside the imported reference in the build container)'}
 
 
+class Pipeline(object):
+  """Host side of the self-play loop, the same for the headline and for every secondary figure: the main thread only
+  launches (moves, D2H copy on a copy stream); a worker thread waits for each chunk's copy and feeds the native replay
+  (PrioritizedReplay.ingest_records: the GIL is released, the environments of a chunk are split over the replay's ingest
+  threads) -- up to NBUF - 1 chunks behind the GPU, so one slow ingest does not idle the GPU.  run() returns when every
+  chunk has been ingested: `frames accepted by the replay` is what every rate below counts."""
+  NBUF = 4
+
+  def __init__(self, eng, replay, chunk, device, sync_weights=None, sync_every=1 << 30, dump=None):
+    import queue
+    import threading
+    self.eng, self.replay, self.chunk, self.device, self.sync_weights, self.dump = eng, replay, chunk, device, sync_weights, dump
+    self.pinned = [torch.empty(chunk, eng.B, eng.rec_floats, dtype=torch.float32).pin_memory() for _ in range(self.NBUF)]
+    self.events = [torch.cuda.Event() for _ in range(self.NBUF)]
+    self.copy_stream = torch.cuda.Stream(device)
+    self.state = {'gmove': 0, 'sync_every': sync_every, 'last_sync_q': 0}
+    self.free, self.work, self.failed = queue.Queue(), queue.Queue(), []
+    for i in range(self.NBUF):
+      self.free.put(i)
+    threading.Thread(target=self._ingest_worker, daemon=True).start()
+
+  @staticmethod
+  def _wait(ev):
+    # the chunk's copy is a few milliseconds out: sleep-poll instead of spinning a core on hipEventSynchronize (one
+    # process per GPU shares the host's cores with seven others)
+    while not ev.query():
+      time.sleep(0.0002)
+
+  def _ingest_worker(self):
+    torch.cuda.set_device(self.device)
+    while True:
+      item = self.work.get()
+      if item is None:
+        return
+      try:
+        i, n = item
+        self._wait(self.events[i])
+        if self.dump is not None and len(self.dump) < 4:
+          self.dump.append(self.pinned[i][:n].numpy().copy())
+        self.replay.ingest_records(self.pinned[i], n, self.eng.B)
+      except Exception as exc:      # surfaced by run()
+        self.failed.append(exc)
+      finally:
+        self.free.put(item[0])
+        self.work.task_done()
+
+  def run(self, blocks, marks=None):
+    """blocks: list of step counts, run back to back in ONE pipelined stream of chunks (D2H + host ingest of the
+    previous chunks overlap the GPU work of chunk i, across block boundaries too).  marks: list that receives one GPU
+    event per block boundary (recorded on the compute stream behind the block's last move).  Returns when every chunk
+    has been ingested."""
+    eng, state, chunk = self.eng, self.state, self.chunk
+    for steps in blocks:
+      done = 0
+      # the block in equal chunks of at most `chunk` moves (20 -> 10 + 10, not 16 + 4: every launch of the persistent
+      # self-play kernel pays its start-up once)
+      even = -(-steps // -(-steps // chunk))
+      while done < steps:
+        m = min(even, steps - done)
+        g0 = state['gmove']
+        if self.sync_weights is not None and g0 // state['sync_every'] != state['last_sync_q']:   # a multiple of sync_every was crossed
+          state['last_sync_q'] = g0 // state['sync_every']
+          self.sync_weights()     # Actor.sync_weights (actors.py:81-85): fresh weights from the storage rank, in stream order
+        i = self.free.get()       # (blocks while the worker is NBUF chunks behind)
+        eng.selfplay_steps(m)
+        _, n = eng.selfplay_drain(self.pinned[i], m, copy_stream=self.copy_stream)   # overlaps the next chunk's moves
+        self.events[i].record(self.copy_stream)
+        self.work.put((i, n))
+        done += m
+        state['gmove'] += m
+      if marks is not None:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        marks.append(ev)
+    self.work.join()
+    if self.failed:
+      raise self.failed[0]
+
+  def close(self):
+    self.work.put(None)
+
+
+def replay_config():
+  return types.SimpleNamespace(batch_size=256, epsilon=0.01, alpha=1.0, beta=1.0, obs_space=(O,), action_space=A,
+                               window_size=1 << 21, window_step=None, num_unroll_steps=5, td_steps=10,
+                               max_history_length=500, discount=0.997, seed=0)
+
+
 def measure_split_f16(device, flat, chunk, moves=384):
-  """Short measurement of the opt-in split-f16 search kernel (mz_config.split_f16) on the headline workload: env-steps
-  executed per second over `moves` moves of the device loop (records drained, not ingested) and the search kernel's
-  launch duration."""
+  """Short measurement of the opt-in split-f16 search kernel (mz_config.split_f16) on the headline workload, through the
+  SAME host pipeline as `value` (records drained to pinned memory and ingested by a native replay of its own): frames
+  accepted by the replay per second over `moves` moves of the device loop, and the search kernel's launch duration."""
   from model_based_rl_amd.engine import Engine
+  from model_based_rl_amd.replay_buffer import PrioritizedReplay
   eng = Engine(B, O, A, SIMS, seed=1234, device=device, split_f16=True)
   eng.set_weights(flat if flat.is_cuda else flat.to(device))
   if '-ram' in WNAME:
     eng.selfplay_set_obs(uint8_obs=True, obs_min=[0.0], obs_range=[255.0])
   eng.selfplay_reset(EPISODE_LEN, 1.0, stagger=True)
-  pinned = torch.empty(chunk, B, eng.rec_floats, dtype=torch.float32).pin_memory()
-
-  def run(n):
-    for _ in range(n // chunk):
-      eng.selfplay_steps(chunk)
-      eng.selfplay_drain(pinned, chunk)
-  run(64)
+  replay = PrioritizedReplay(replay_config())
+  pipe = Pipeline(eng, replay, chunk, device)
+  moves = (moves // chunk) * chunk
+  pipe.run([EPISODE_LEN, 64])            # priming (every env past its first, partial episode) + warm-up
   torch.cuda.synchronize(device)
+  f0 = replay.get_throughput()['frames']
   t0 = time.perf_counter()
-  run(moves)
+  pipe.run([moves])
   torch.cuda.synchronize(device)
   dt = time.perf_counter() - t0
+  frames = replay.get_throughput()['frames'] - f0
+  pinned = pipe.pinned[0]
   durs = []
   for _ in range(3):
     durs += eng.selfplay_steps_timed(chunk)
@@ -172,11 +261,13 @@ def measure_split_f16(device, flat, chunk, moves=384):
     torch.cuda.synchronize(device)
   us = 1e3 * float(np.mean(durs[chunk:]))
   persistent = eng.selfplay_moves_per_launch() > 0      # whole moves inside the launch: `us` then includes the (f32) root
+  pipe.close()
   eng.close()
   return {'what': 'mz_config.split_f16 = 1: FCNetwork GEMMs as float16 high/low splits on v_mfma_f32_16x16x32_f16, f32 '
                   'accumulation; float32-level accuracy (every parity test passes), not bit-identical to the exact-f32 path',
-          'env_steps_per_s': B * (moves // chunk) * chunk / dt, 'ms_per_step': 1e3 * dt / ((moves // chunk) * chunk),
-          'kernel_us_per_move': us, 'root_inside_the_launch': persistent, 'moves': (moves // chunk) * chunk,
+          'env_steps_per_s': frames / dt, 'counted': 'frames accepted by the replay (same drain + ingest pipeline as `value`)',
+          'env_steps_executed_per_s': B * moves / dt, 'ms_per_step': 1e3 * dt / moves,
+          'kernel_us_per_move': us, 'root_inside_the_launch': persistent, 'moves': moves,
           'algorithmic_tflops': (SIMS * FLOP_PER_SIM + (FLOP_PER_ROOT if persistent else 0)) * B / (us * 1e-6) / 1e12}
 
 
@@ -209,7 +300,11 @@ def main():
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
   dist = None
   backend = None
-  if world > 1:
+  # MZ_BENCH_FORCE_DIST=1: take the multi-rank branch at ANY world size (launched by torch.distributed.run with one
+  # process it runs the whole collective path -- process group over RCCL, broadcast of the weights into device memory,
+  # the MAX / SUM all-reduces, barriers -- on a single GPU)
+  force_dist = os.environ.get('MZ_BENCH_FORCE_DIST', '0')[:1] == '1' and 'RANK' in os.environ
+  if world > 1 or force_dist:
     import torch.distributed as dist
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     local_rank = local_rank % max(1, torch.cuda.device_count())   # (several ranks on one GPU only in the gloo self-test)
@@ -229,6 +324,7 @@ def main():
   from model_based_rl_amd.networks import FCNetwork
   from model_based_rl_amd.replay_buffer import PrioritizedReplay
   from model_based_rl_amd.shared_storage import broadcast_flat
+  from model_based_rl_amd.distributed import rccl_mapped
 
   # random-init FCNetwork, torch.manual_seed(0) default init; rank 0 owns the weights
   torch.manual_seed(0)
@@ -245,86 +341,13 @@ def main():
     n_syncs[0] += 1
 
   sync_weights()
-  cfg = types.SimpleNamespace(batch_size=256, epsilon=0.01, alpha=1.0, beta=1.0, obs_space=(O,), action_space=A,
-                              window_size=1 << 21, window_step=None, num_unroll_steps=5, td_steps=10,
-                              max_history_length=500, discount=0.997, seed=0)
-  replay = PrioritizedReplay(cfg)
+  replay = PrioritizedReplay(replay_config())
   ram = '-ram' in WNAME
   if ram:        # the -ram- envs: byte observations, --norm_obs --obs_range 0 255 inside the root kernel (actors.py:134-137)
     eng.selfplay_set_obs(uint8_obs=True, obs_min=[0.0], obs_range=[255.0])
   eng.selfplay_reset(EPISODE_LEN, 1.0, stagger=True)
-  rec = eng.rec_floats
-  NBUF = 4
-  pinned = [torch.empty(chunk, B, rec, dtype=torch.float32).pin_memory() for _ in range(NBUF)]
-  events = [torch.cuda.Event() for _ in range(NBUF)]
-  copy_stream = torch.cuda.Stream(device)
-  dump = [] if args.dump_records else None
-  state = {'gmove': 0, 'sync_every': max(chunk, args.sync_every), 'last_sync_q': 0}
-
-  def wait(ev):
-    # the chunk's copy is a few milliseconds out: sleep-poll instead of spinning a core on hipEventSynchronize (one
-    # process per GPU shares the host's cores with seven others)
-    while not ev.query():
-      time.sleep(0.0002)
-
-  # host side of the pipeline: the main thread only launches (moves, copy); a worker waits for each chunk's copy and feeds
-  # the replay (native code, the GIL is released) -- up to NBUF - 1 chunks behind the GPU, so a slow ingest of one chunk
-  # (page faults, a busy host: its median is close to the 3.3 ms the GPU needs for a chunk) does not idle the GPU
-  import queue
-  import threading
-  free, work, failed = queue.Queue(), queue.Queue(), []
-  for i in range(NBUF):
-    free.put(i)
-
-  def ingest_worker():
-    torch.cuda.set_device(device)
-    while True:
-      item = work.get()
-      if item is None:
-        return
-      try:
-        i, n = item
-        wait(events[i])
-        if dump is not None and len(dump) < 4:
-          dump.append(pinned[i][:n].numpy().copy())
-        replay.ingest_records(pinned[i], n, B)
-      except Exception as exc:      # surfaced by run()
-        failed.append(exc)
-      finally:
-        free.put(item[0])
-        work.task_done()
-  threading.Thread(target=ingest_worker, daemon=True).start()
-
-  def run(blocks, marks=None):
-    """blocks: list of step counts, run back to back in ONE pipelined stream of chunks (D2H + host ingest of the
-    previous chunks overlap the GPU work of chunk i, across block boundaries too).  marks: list that receives one GPU
-    event per block boundary (recorded on the compute stream behind the block's last move).  Returns when every chunk
-    has been ingested."""
-    for steps in blocks:
-      done = 0
-      # the block in equal chunks of at most `chunk` moves (20 -> 10 + 10, not 16 + 4: every launch of the persistent
-      # self-play kernel pays its start-up once)
-      even = -(-steps // -(-steps // chunk))
-      while done < steps:
-        m = min(even, steps - done)
-        g0 = state['gmove']
-        if g0 // state['sync_every'] != state['last_sync_q']:     # a multiple of sync_every was crossed
-          state['last_sync_q'] = g0 // state['sync_every']
-          sync_weights()     # Actor.sync_weights (actors.py:81-85): fresh weights from the storage rank, in stream order
-        i = free.get()       # (blocks while the worker is NBUF chunks behind)
-        eng.selfplay_steps(m)
-        _, n = eng.selfplay_drain(pinned[i], m, copy_stream=copy_stream)   # overlaps the next chunk's moves
-        events[i].record(copy_stream)
-        work.put((i, n))
-        done += m
-        state['gmove'] += m
-      if marks is not None:
-        ev = torch.cuda.Event(enable_timing=True)
-        ev.record()
-        marks.append(ev)
-    work.join()
-    if failed:
-      raise failed[0]
+  pipe = Pipeline(eng, replay, chunk, device, sync_weights, max(chunk, args.sync_every), dump=[] if args.dump_records else None)
+  state, run, pinned, dump = pipe.state, pipe.run, pipe.pinned, pipe.dump
 
   def barrier():
     torch.cuda.synchronize(device)
@@ -338,7 +361,7 @@ def main():
   run([EPISODE_LEN])
   if dump is not None:
     np.save('%s.rank%d.npy' % (args.dump_records, rank), np.concatenate(dump, 0))
-    dump = None
+    dump = pipe.dump = None
   run([args.steps])             # one untimed block: builds the hipGraphs of every chunk size a block uses
   # calibration: how many --steps blocks make a timed region of >= --min-seconds (same count on every rank)
   torch.cuda.synchronize(device)
@@ -433,11 +456,17 @@ def main():
                    'priming': '%d untimed moves before warm-up so episode ends are in steady state' % EPISODE_LEN,
                    'timed_region': 'the --steps block repeated %d times back to back in one pipelined region of %.2f s '
                                    '(barrier + synchronize on both sides)' % (repeats, dt),
-                   'sharding': 'env-id sharded, %d rank(s), RCCL weight broadcast' % world,
+                   'sharding': 'env-id sharded, %d rank(s), weight broadcast over %s' % (world, {'nccl': 'RCCL (torch.distributed nccl backend)', None: 'nothing (one rank, no process group)'}.get(backend, backend)),
+                   'replay': 'one native replay per rank (bench layout: the metric counts frames accepted; `train --ranks N` merges '
+                             'all ranks into ONE replay on rank 0, DESIGN.md s6), %d ingest threads' % replay.ingest_threads,
                    'weight_sync': 'flat f32 buffer broadcast from rank 0 + repack every %d moves: %d pulls inside the '
                                   'timed region' % (state['sync_every'], syncs_in_region)},
         'env_steps_executed_per_s': env_steps / dt,
         'host_cores_busy_per_rank': host_cores_busy,
+        'collectives': {'backend': backend, 'world': world, 'forced_at_world_1': bool(force_dist and world == 1),
+                        'rccl_mapped': rccl_mapped(), 'weights_on_device': bool(flat.is_cuda),
+                        'what': 'broadcast of the flat f32 weights (%d floats) per pull, MAX / SUM all-reduces of the timing, '
+                                'barriers' % flat.numel()} if dist is not None else None,
         'mcts_sims_per_s_per_gpu': env_steps * SIMS / dt / world,
         'roofline': {'bound': 'mfma', 'kernel': 'k_search_fused', 'achieved': achieved,
                      'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS,

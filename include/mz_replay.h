@@ -8,7 +8,9 @@
  * propagates `change` leaf-to-root one leaf at a time in arrival order, so tree sums are bit-identical to the
  * reference's for the same sequence of histories.
  *
- * Returns 0 on success, <0 on error (message: mzr_last_error()).  Not thread-safe per handle.
+ * Returns 0 on success, <0 on error (message: mzr_last_error()).  Not thread-safe per handle: one caller at a time
+ * (the reference's replay is a Ray actor, replay_buffer.py:69: calls are serialised); mzr_ingest_records* fans the
+ * environments of ONE call out over the handle's own ingest threads and joins them before it returns.
  */
 #ifndef MZ_REPLAY_H
 #define MZ_REPLAY_H
@@ -33,6 +35,10 @@ typedef struct mzr_config {
   double epsilon, alpha, beta, beta_increment_per_sampling;   /* replay_buffer.py:73-77 */
   double discount;
   uint64_t seed;
+  int32_t two_players;        /* --two_players: histories carry to_play = +-1 and targets flip signs (replay_buffer.py:187-189) */
+  int32_t episode_life;       /* --episode_life: `terminal` (end of game) differs from `done` (game.py:90) */
+  int32_t ingest_threads;     /* threads mzr_ingest_records* splits the environments of a call over (0 or 1: the caller only) */
+  int32_t reserved;
 } mzr_config;
 
 const char *mzr_last_error(void);
@@ -68,8 +74,13 @@ int mzr_save_history(mz_replay *r, int64_t n, const double *errors, int64_t igno
  * Re-creates per environment what Actor.play_game does after each move (actors.py:160-173): histories are
  * accumulated per env and flushed to save_history when max_history_length steps were collected (with the
  * overlap/ignore rules) or the episode is done.  frames/games: PrioritizedReplay.throughput.
- * Records describe single-player synthetic episodes: to_play = +1 and `done` ends the game (terminal == done;
- * --two_players / --episode_life histories go through mzr_save_history).
+ * Records describe single-player episodes: to_play = +1 and `done` ends the game (terminal == done).  A replay
+ * created with two_players or episode_life REFUSES records (-1, mzr_last_error): such histories go through
+ * mzr_save_history, which takes to_play and `terminal` explicitly.
+ * Threads: the environments of a call are split into contiguous ranges over mzr_config.ingest_threads threads (history
+ * assembly and priorities are per environment, actors.py:160-173); the finished slices enter the one sum tree on the
+ * calling thread in (move, environment) order -- leaves, sums, counters and sample batches are bit-identical for every
+ * thread count (replay_buffer.py:19-40 adds in arrival order).
  * mzr_ingest_records_from: the B environments of this call are the replay's environments env_base .. env_base+B-1
  * (one replay fed by several actor ranks: rank r passes env_base = r * B; actors.py:169 -- every reference actor
  * sends to the ONE replay buffer, train.py:71-72). */
@@ -88,6 +99,10 @@ int mzr_ingest_records_from(mz_replay *r, const float *records, int n_moves, int
 int mzr_sample_batch(const mz_replay *r, const double *draws, int bs, float *obs, int32_t *actions,
                      float *target_rewards, float *target_values, float *target_policies, int64_t *idxs,
                      double *priorities);
+
+/* number of ingest threads of the handle (mzr_config.ingest_threads at creation; the setter re-creates the pool) */
+int mzr_set_ingest_threads(mz_replay *r, int threads);
+int mzr_ingest_threads(const mz_replay *r);
 
 int64_t mzr_frames(const mz_replay *r);   /* throughput['frames'] (replay_buffer.py:121) */
 int64_t mzr_games(const mz_replay *r);    /* throughput['games'] */

@@ -157,7 +157,8 @@ class MzrConfig(C.Structure):
   _fields_ = [('window_size', _I64), ('window_step', _I64), ('obs_dim', C.c_int32), ('action_space', C.c_int32),
               ('num_unroll_steps', C.c_int32), ('td_steps', C.c_int32), ('max_history_length', C.c_int32),
               ('batch_size', C.c_int32), ('epsilon', _D), ('alpha', _D), ('beta', _D),
-              ('beta_increment_per_sampling', _D), ('discount', _D), ('seed', _U64)]
+              ('beta_increment_per_sampling', _D), ('discount', _D), ('seed', _U64), ('two_players', C.c_int32),
+              ('episode_life', C.c_int32), ('ingest_threads', C.c_int32), ('reserved', C.c_int32)]
 
 
 REPLAY_SIGNATURES = {
@@ -175,6 +176,8 @@ REPLAY_SIGNATURES = {
     'mzr_ingest_records': (_I, [_VP, _VP, _I, _I, _I]),
     'mzr_ingest_records_from': (_I, [_VP, _VP, _I, _I, _I, _I]),
     'mzr_sample_batch': (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    'mzr_set_ingest_threads': (_I, [_VP, _I]),
+    'mzr_ingest_threads': (_I, [_VP]),
     'mzr_frames': (_I64, [_VP]),
     'mzr_games': (_I64, [_VP]),
     'mzr_add_initial_throughput': (_I, [_VP, _I64, _I64]),
@@ -185,7 +188,7 @@ def build_replay(force=False, verbose=False):
   src = os.path.join(_CSRC, 'mz_replay.cpp')
   hdr = os.path.join(_CSRC, '..', '..', 'include', 'mz_replay.h')
   if force or not os.path.exists(_RSO) or os.path.getmtime(_RSO) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
-    cmd = ['g++', '-O2', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared', 'mz_replay.cpp', '-o',
+    cmd = ['g++', '-O2', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared', '-pthread', 'mz_replay.cpp', '-o',
            'libmz_replay.so']
     if verbose:
       print(' '.join(cmd))

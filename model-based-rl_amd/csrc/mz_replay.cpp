@@ -1,6 +1,15 @@
 // mz_replay.cpp -- libmz_replay.so: host-side prioritized replay ingest (include/mz_replay.h).
 // Plain C++17, no GPU code.  Arithmetic and update order follow the reference's SumTree /
 // PrioritizedReplay (replay_buffer.py) exactly; see the header for the citations.
+//
+// Layout.  A history slice (HistorySlice, game.py:5-16) is kept as the experience records it was made from: one row
+// of rec_floats = O + A + MZR_REC_EXTRA float32 per step, exactly the device's record (include/mz_engine.h).  The bulk
+// ingest therefore moves every record ONCE -- appended to its environment's open buffer, which becomes the slice when
+// the game ends -- and sample_batch reads its fields straight from the rows.
+// Threads.  mzr_ingest_records* splits the environments of a call over the handle's ingest threads (per-environment
+// bookkeeping is independent, actors.py:160-173 runs per actor); the slices they build enter the ONE sum tree
+// afterwards in (move, environment) order on the calling thread, so leaves, sums and counters are those of a
+// single-threaded walk, bit for bit (replay_buffer.py:19-40 is order dependent in float64).
 #include "../../include/mz_replay.h"
 
 #include <math.h>
@@ -9,8 +18,12 @@
 #include <string.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <functional>
 #include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 static thread_local std::string g_err;
@@ -24,31 +37,100 @@ static int fail(const char *fmt, ...) {
   return -1;
 }
 
-// one HistorySlice (game.py:5-16) as flat arrays; leaves point into it as (history, step)
+// One HistorySlice as record rows; leaves point into it as (history, step).  Row layout (R = O + A + MZR_REC_EXTRA floats):
+// obs[O], child_visits[A], root_value (float64, 2 slots), error (float64, 2 slots), reward, then int32 bits: action,
+// flags (bit 0 done, bit 1 to_play == -1), step, env_id, episode.
 struct Hist {
-  int64_t n = 0;
-  int64_t refs = 0;             // leaves pointing at this slice (single-threaded handle: plain counter)
-  std::vector<float> obs, child_visits, rewards;
-  std::vector<double> root_values;
-  std::vector<int32_t> actions;
-  std::vector<uint8_t> dones;
-  std::vector<int8_t> to_play;
+  int64_t n = 0;                // steps of the slice
+  int64_t off = 0;              // first row of the slice inside `rows` (a finished game hands its whole buffer over)
+  int64_t refs = 0;             // leaves pointing at this slice (touched by the inserting thread only)
+  bool payload = false;         // rows carry observations / policies / values (mzr_save_history may omit them)
+  std::vector<float> rows;
 };
+
+#define MZR_FLAG_DONE 1
+#define MZR_FLAG_P2 2           // to_play == -1 (two-player games; single-player records leave it clear: to_play = +1)
 
 // what Game/Actor keep per environment between flushes (game.py:54-77, actors.py:160-169)
 struct EnvGame {
-  std::vector<float> recs;      // records from absolute history index `base` on
+  std::vector<float> recs;      // rows from absolute history index `base` on
   int64_t base = 0;             // history index of recs[0]
   int64_t history_idx = 0;      // game.history_idx
   int64_t previous_collect_to = 0;
   bool done_at_last_flush = false;
 };
 
-// a history slice built during an env-major ingest pass, waiting for its (move, env)-ordered tree insertion
-struct Pending { int m, b; struct Hist *h; int64_t keep; size_t pri_off; bool done; };
+// a history slice built by an ingest thread, waiting for its (move, env)-ordered tree insertion
+struct Pending { int m, b; Hist *h; int64_t keep; const double *pri; bool done; };
+
+struct Scratch {                // per ingest thread
+  std::vector<Pending> pend;
+  std::vector<double> pris;
+  std::vector<size_t> pri_off;  // pris may reallocate while a thread works: offsets first, pointers after
+};
+
+// A fixed set of worker threads that run one job(tid) per call of run(); the caller is thread 0.
+struct Pool {
+  int T = 1;
+  std::vector<std::thread> th;
+  std::mutex mu;
+  std::condition_variable go, done_cv;
+  unsigned long long gen = 0;
+  int left = 0;
+  bool quit = false;
+  std::function<void(int)> job;
+
+  void start(int threads) {
+    stop();
+    T = threads < 1 ? 1 : threads;
+    quit = false;
+    for (int i = 1; i < T; ++i)
+      th.emplace_back([this, i] {
+        unsigned long long seen = 0;
+        for (;;) {
+          {
+            std::unique_lock<std::mutex> lk(mu);
+            go.wait(lk, [&] { return quit || gen != seen; });
+            if (quit) return;
+            seen = gen;
+          }
+          job(i);
+          {
+            std::lock_guard<std::mutex> lk(mu);
+            if (--left == 0) done_cv.notify_one();
+          }
+        }
+      });
+  }
+  void stop() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      quit = true;
+    }
+    go.notify_all();
+    for (auto &t : th) t.join();
+    th.clear();
+    T = 1;
+  }
+  void run(const std::function<void(int)> &f) {
+    if (T == 1) { f(0); return; }
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      job = f;
+      left = T - 1;
+      ++gen;
+    }
+    go.notify_all();
+    f(0);
+    std::unique_lock<std::mutex> lk(mu);
+    done_cv.wait(lk, [&] { return left == 0; });
+  }
+  ~Pool() { stop(); }
+};
 
 struct mz_replay {
   mzr_config c;
+  int R = 0;                       // floats per row
   // SumTree (replay_buffer.py:8-17)
   int64_t max_capacity, capacity_step, capacity, prev_capacity = 0, num_memories = 0, position = 0;
   std::vector<double> tree;
@@ -57,12 +139,10 @@ struct mz_replay {
   int64_t frames = 0, games = 0;
   std::vector<EnvGame> envs;
   // scratch
-  std::vector<double> errs, pri, rootv, chg, pend_pri;
-  std::vector<struct Pending> pend;
-  std::vector<float> obs, cv, rew;
-  std::vector<int32_t> act;
-  std::vector<uint8_t> done;
-  std::vector<int8_t> tp;
+  std::vector<double> pri, chg;
+  std::vector<Scratch> scratch;
+  std::vector<Pending> merged;
+  Pool pool;
 };
 
 // SumTree.update, replay_buffer.py:34-40
@@ -122,32 +202,50 @@ static void tree_update_run(mz_replay *r, int64_t first_idx, const double *prior
   }
 }
 
-// SumTree.add, replay_buffer.py:19-32
-static void tree_add(mz_replay *r, const double *priorities, int64_t n, Hist *h,
-                     int64_t *positions_out) {
-  int64_t run_start = 0;                       // [run_start, step) = leaves at consecutive positions, not yet summed
-  int64_t run_idx = r->position + r->max_capacity - 1;
-  for (int64_t step = 0; step < n; ++step) {
-    {
-      Hist *&slot = r->leaf_hist[r->position];
-      if (slot && --slot->refs == 0) delete slot;
-      slot = h;
-      if (h) ++h->refs;
+// SumTree.add, replay_buffer.py:19-32, for n leaves of one history: the leaves up to the end of the current capacity
+// are consecutive slots -- payload pointers, steps and the memory count are set per run instead of per leaf (the
+// reference's `position = (position + 1) % capacity` and its capacity growth at the wrap, run by run).
+static void tree_add(mz_replay *r, const double *priorities, int64_t n, Hist *h, int64_t *positions_out) {
+  int64_t step = 0;
+  while (step < n) {
+    const int64_t pos = r->position;
+    int64_t seg = r->capacity - pos;
+    if (seg > n - step) seg = n - step;
+    Hist **slot = r->leaf_hist.data() + pos;
+    int32_t *ls = r->leaf_step.data() + pos;
+    for (int64_t i = 0; i < seg;) {             // evicted payloads: consecutive slots mostly share one history
+      Hist *old = slot[i];
+      int64_t j = i + 1;
+      while (j < seg && slot[j] == old) ++j;
+      if (old && (old->refs -= (j - i)) == 0) delete old;
+      i = j;
     }
-    r->leaf_step[r->position] = (int32_t)step;
-    if (positions_out) positions_out[step] = r->position;
-    if (r->position >= r->prev_capacity) r->num_memories += 1;
-    r->position = (r->position + 1) % r->capacity;
-    if (r->position == 0) {
-      tree_update_run(r, run_idx, priorities + run_start, step + 1 - run_start);
-      run_start = step + 1;
-      run_idx = r->max_capacity - 1;
+    for (int64_t i = 0; i < seg; ++i) { slot[i] = h; ls[i] = (int32_t)(step + i); }
+    if (h) h->refs += seg;
+    if (positions_out)
+      for (int64_t i = 0; i < seg; ++i) positions_out[step + i] = pos + i;
+    // `if self.position >= self.prev_capacity: self.num_memories += 1`, replay_buffer.py:26-27
+    {
+      const int64_t lo = pos > r->prev_capacity ? pos : r->prev_capacity;
+      if (pos + seg > lo) r->num_memories += pos + seg - lo;
+    }
+    tree_update_run(r, pos + r->max_capacity - 1, priorities + step, seg);
+    step += seg;
+    r->position = pos + seg;
+    if (r->position == r->capacity) {           // replay_buffer.py:29-32
+      r->position = 0;
       r->prev_capacity = r->capacity;
       const int64_t next = r->capacity + r->capacity_step;
       r->capacity = next < r->max_capacity ? next : r->max_capacity;
     }
   }
-  if (run_start < n) tree_update_run(r, run_idx, priorities + run_start, n - run_start);
+}
+
+static inline void row_put_double(float *dst, double v) { memcpy(dst, &v, sizeof v); }
+static inline double row_double(const float *p) {     // a float64 stored in two float slots (4-byte aligned)
+  double v;
+  memcpy(&v, p, sizeof v);
+  return v;
 }
 
 static int save_history(mz_replay *r, int64_t n, const double *errors, int64_t ignore, int terminal,
@@ -160,14 +258,21 @@ static int save_history(mz_replay *r, int64_t n, const double *errors, int64_t i
   if (obs || child_visits || root_values || rewards || actions || dones || to_play) {
     h = new Hist();
     h->n = n;
-    const int O = r->c.obs_dim, A = r->c.action_space;
-    if (obs) h->obs.assign(obs, obs + n * O);
-    if (child_visits) h->child_visits.assign(child_visits, child_visits + n * A);
-    if (root_values) h->root_values.assign(root_values, root_values + n);
-    if (rewards) h->rewards.assign(rewards, rewards + n);
-    if (actions) h->actions.assign(actions, actions + n);
-    if (dones) h->dones.assign(dones, dones + n);
-    if (to_play) h->to_play.assign(to_play, to_play + n);
+    h->payload = obs && child_visits && root_values;
+    const int O = r->c.obs_dim, A = r->c.action_space, R = r->R;
+    h->rows.assign((size_t)n * R, 0.f);
+    for (int64_t i = 0; i < n; ++i) {
+      float *q = h->rows.data() + (size_t)i * R;
+      int32_t *qi = (int32_t *)(q + O + A + 5);
+      if (obs) memcpy(q, obs + i * O, O * sizeof(float));
+      if (child_visits) memcpy(q + O, child_visits + i * A, A * sizeof(float));
+      if (root_values) row_put_double(q + O + A, root_values[i]);
+      row_put_double(q + O + A + 2, errors[i]);
+      if (rewards) q[O + A + 4] = rewards[i];
+      qi[0] = actions ? actions[i] : 0;
+      qi[1] = ((dones && dones[i]) ? MZR_FLAG_DONE : 0) | ((to_play && to_play[i] < 0) ? MZR_FLAG_P2 : 0);
+      qi[2] = (int32_t)i;
+    }
   }
   if ((int64_t)r->pri.size() < keep) r->pri.resize(keep);
   if (r->c.alpha == 1.0)      // pow(x, 1.0) == x exactly: skip the libm call
@@ -190,25 +295,45 @@ int mzr_create(const mzr_config *cfg, mz_replay **out) {
   if (cfg->window_size < 1 || cfg->window_step < 1 || cfg->window_step > cfg->window_size)
     return fail("mzr_create: need 1 <= window_step <= window_size");
   if (cfg->obs_dim < 1 || cfg->action_space < 1) return fail("mzr_create: bad obs_dim/action_space");
+  if (cfg->ingest_threads < 0 || cfg->ingest_threads > 64) return fail("mzr_create: ingest_threads must be in [0, 64]");
   mz_replay *r = new mz_replay();
   r->c = *cfg;
+  r->R = cfg->obs_dim + cfg->action_space + MZR_REC_EXTRA;
   r->max_capacity = cfg->window_size;
   r->capacity_step = cfg->window_step;
   r->capacity = cfg->window_step;
   r->tree.assign((size_t)(2 * cfg->window_size - 1), 0.0);
   r->leaf_hist.assign((size_t)cfg->window_size, nullptr);
   r->leaf_step.assign((size_t)cfg->window_size, 0);
+  r->pool.start(cfg->ingest_threads > 1 ? cfg->ingest_threads : 1);
+  r->scratch.resize((size_t)r->pool.T);
   *out = r;
   return 0;
 }
 
 int mzr_destroy(mz_replay *r) {
-  if (r)
-    for (Hist *&h : r->leaf_hist)
-      if (h) { if (--h->refs == 0) delete h; h = nullptr; }
+  if (r) {
+    r->pool.stop();
+    for (int64_t i = 0; i < (int64_t)r->leaf_hist.size();) {
+      Hist *h = r->leaf_hist[(size_t)i];
+      int64_t j = i + 1;
+      while (j < (int64_t)r->leaf_hist.size() && r->leaf_hist[(size_t)j] == h) ++j;
+      if (h && (h->refs -= (j - i)) == 0) delete h;
+      i = j;
+    }
+  }
   delete r;
   return 0;
 }
+
+int mzr_set_ingest_threads(mz_replay *r, int threads) {
+  if (!r) return fail("mzr_set_ingest_threads: null");
+  if (threads < 1 || threads > 64) return fail("mzr_set_ingest_threads: threads must be in [1, 64]");
+  r->pool.start(threads);
+  r->scratch.resize((size_t)r->pool.T);
+  return 0;
+}
+int mzr_ingest_threads(const mz_replay *r) { return r ? r->pool.T : -1; }
 
 int mzr_priorities(const mz_replay *r, const double *errors, int64_t n, double *out) {
   if (!r || !errors || !out) return fail("mzr_priorities: null argument");
@@ -260,95 +385,116 @@ int mzr_save_history(mz_replay *r, int64_t n, const double *errors, int64_t igno
   return save_history(r, n, errors, ignore, terminal, obs, child_visits, root_values, rewards, actions, dones, to_play);
 }
 
-static inline double rec_double(const float *p) {     // a float64 stored in two float slots (4-byte aligned)
-  double v;
-  memcpy(&v, p, sizeof v);
-  return v;
-}
-
 int mzr_ingest_records(mz_replay *r, const float *records, int n_moves, int B, int rec_floats) {
   return mzr_ingest_records_from(r, records, n_moves, B, rec_floats, 0);
 }
 
-int mzr_ingest_records_from(mz_replay *r, const float *records, int n_moves, int B, int rec_floats, int env_base) {
-  if (!r || !records) return fail("mzr_ingest_records: null argument");
-  if (n_moves < 0 || B < 1 || env_base < 0) return fail("mzr_ingest_records: bad shape (n_moves %d, B %d, env_base %d)", n_moves, B, env_base);
-  const int O = r->c.obs_dim, A = r->c.action_space;
-  if (rec_floats != O + A + MZR_REC_EXTRA)
-    return fail("mzr_ingest_records: rec_floats %d != obs_dim+action_space+%d = %d", rec_floats, MZR_REC_EXTRA, O + A + MZR_REC_EXTRA);
-  if ((int)r->envs.size() < env_base + B) r->envs.resize((size_t)env_base + B);
+// actors.py:160-173 for the environments [b_lo, b_hi) of one call, environment-major: an env's bookkeeping and the
+// tail of its open buffer are touched once per call instead of once per move.  The slices that fall due are built
+// here (their priorities too); their insertion into the sum tree is deferred (Pending).
+static void ingest_range(mz_replay *r, Scratch &sc, const float *records, int n_moves, int B, int env_base, int b_lo,
+                         int b_hi) {
+  const int O = r->c.obs_dim, A = r->c.action_space, R = r->R;
   const int64_t overlap = r->c.num_unroll_steps + r->c.td_steps;
-  // Environment-major: an env's bookkeeping and the tail of its record buffer are touched once per call
-  // instead of once per move (4096 envs x 3 cold cache lines per record were the bulk of the ingest time).  The
-  // history slices are built as they fall due; their insertion into the sum tree is deferred and replayed in
-  // (move, env) order, i.e. exactly the arrival order of a move-major walk.
-  std::vector<Pending> &pend = r->pend;
-  std::vector<double> &pris = r->pend_pri;
-  pend.clear();
-  pris.clear();
+  sc.pend.clear(); sc.pris.clear(); sc.pri_off.clear();
   const int PF = 6;       // envs ahead: an env's records lie n_moves strides of B * rec_floats apart (move-major ring),
-  for (int b = 0; b < B; ++b) {      // which no hardware prefetcher follows -- request them while the envs before are handled
-    if (b + PF < B)
+  for (int b = b_lo; b < b_hi; ++b) {      // which no hardware prefetcher follows -- request them while the envs before are handled
+    if (b + PF < b_hi) {
       for (int m = 0; m < n_moves; ++m) {
-        const char *q = (const char *)(records + ((size_t)m * B + b + PF) * rec_floats);
+        const char *q = (const char *)(records + ((size_t)m * B + b + PF) * R);
         __builtin_prefetch(q, 0, 1);
         __builtin_prefetch(q + 64, 0, 1);
       }
+      const EnvGame &gn = r->envs[(size_t)env_base + b + PF];      // and the tail of the open buffer the rows go to
+      if (!gn.recs.empty()) {
+        const char *q = (const char *)(gn.recs.data() + gn.recs.size());
+        for (int k = 0; k < n_moves * R * 4; k += 64) __builtin_prefetch(q + k, 1, 1);
+      }
+    }
     EnvGame &g = r->envs[(size_t)env_base + b];
+    if (g.recs.capacity() == 0) g.recs.reserve((size_t)64 * R);
     for (int m = 0; m < n_moves; ++m) {
-      const float *rec = records + ((size_t)m * B + b) * rec_floats;
+      const float *rec = records + ((size_t)m * B + b) * R;
       const int32_t *ri = (const int32_t *)(rec + O + A + 5);
-      const bool done = ri[1] != 0;
-      g.recs.insert(g.recs.end(), rec, rec + rec_floats);
+      const bool done = (ri[1] & MZR_FLAG_DONE) != 0;
+      g.recs.insert(g.recs.end(), rec, rec + R);
       g.history_idx += 1;
       // actors.py:160-169
       const bool save = (g.history_idx - g.previous_collect_to) == r->c.max_history_length;
       if (!(save || done)) continue;
       const bool d_prev = g.previous_collect_to == 0 ? done : g.done_at_last_flush;   // dones[prev-1] (index -1 when prev == 0)
-      int64_t collect_from = d_prev ? g.previous_collect_to
-                                    : (g.previous_collect_to - overlap > 0 ? g.previous_collect_to - overlap : 0);
+      const int64_t collect_from = d_prev ? g.previous_collect_to
+                                          : (g.previous_collect_to - overlap > 0 ? g.previous_collect_to - overlap : 0);
       const int64_t n = g.history_idx - collect_from;
       const int64_t ignore = done ? -1 : overlap;
-      // PrioritizedReplay.save_history (replay_buffer.py:113-122) with the HistorySlice built straight from the
-      // env's records (same arithmetic as save_history() above, one copy less)
-      {
-        Hist *h = new Hist();
-        h->n = n;
-        h->obs.resize((size_t)n * O); h->child_visits.resize((size_t)n * A); h->root_values.resize((size_t)n);
-        h->rewards.resize((size_t)n); h->actions.resize((size_t)n); h->dones.resize((size_t)n); h->to_play.assign((size_t)n, 1);
-        int64_t keep = n;
-        if (ignore >= 0) keep = ignore == 0 ? 0 : (n - ignore > 0 ? n - ignore : 0);
-        const size_t off = pris.size();
-        pris.resize(off + (size_t)n);
-        double *pri = pris.data() + off;
-        const float *q = g.recs.data() + (size_t)(collect_from - g.base) * rec_floats;
-        for (int64_t i = 0; i < n; ++i, q += rec_floats) {
-          const int32_t *qi = (const int32_t *)(q + O + A + 5);
-          memcpy(h->obs.data() + i * O, q, O * sizeof(float));
-          memcpy(h->child_visits.data() + i * A, q + O, A * sizeof(float));
-          h->root_values[i] = rec_double(q + O + A); h->rewards[i] = q[O + A + 4];
-          h->actions[i] = qi[0]; h->dones[i] = (uint8_t)(qi[1] != 0);
-          const double e = fabs(rec_double(q + O + A + 2)) + r->c.epsilon;
-          pri[i] = r->c.alpha == 1.0 ? e : pow(e, r->c.alpha);
-        }
-        pend.push_back(Pending{m, b, h, keep, off, done});
+      // PrioritizedReplay.save_history (replay_buffer.py:113-122): the slice IS the env's rows
+      Hist *h = new Hist();
+      h->n = n;
+      h->payload = true;
+      int64_t keep = n;
+      if (ignore >= 0) keep = ignore == 0 ? 0 : (n - ignore > 0 ? n - ignore : 0);
+      const size_t off = sc.pris.size();
+      sc.pris.resize(off + (size_t)n);
+      double *pri = sc.pris.data() + off;
+      const float *q = g.recs.data() + (size_t)(collect_from - g.base) * R;
+      for (int64_t i = 0; i < n; ++i, q += R) {
+        const double e = fabs(row_double(q + O + A + 2)) + r->c.epsilon;
+        pri[i] = r->c.alpha == 1.0 ? e : pow(e, r->c.alpha);
       }
-      g.previous_collect_to = g.history_idx;
-      g.done_at_last_flush = done;
-      if (done) {           // terminal: run_selfplay starts a new Game (actors.py:94-97)
+      if (done) {           // the game is over: its buffer becomes the slice (run_selfplay starts a new Game, actors.py:94-97)
+        h->off = collect_from - g.base;
+        h->rows.swap(g.recs);
         g.recs.clear(); g.base = 0; g.history_idx = 0; g.previous_collect_to = 0; g.done_at_last_flush = false;
-      } else {              // keep only what the next slice can still reach back to
+      } else {              // the game goes on: copy the slice, keep only what the next slice can still reach back to
+        const float *src = g.recs.data() + (size_t)(collect_from - g.base) * R;
+        h->rows.assign(src, src + (size_t)n * R);
+        g.previous_collect_to = g.history_idx;
+        g.done_at_last_flush = done;
         const int64_t nb = g.history_idx - overlap > 0 ? g.history_idx - overlap : 0;
         if (nb > g.base) {
-          g.recs.erase(g.recs.begin(), g.recs.begin() + (size_t)(nb - g.base) * rec_floats);
+          g.recs.erase(g.recs.begin(), g.recs.begin() + (size_t)(nb - g.base) * R);
           g.base = nb;
         }
       }
+      sc.pend.push_back(Pending{m, b, h, keep, nullptr, done});
+      sc.pri_off.push_back(off);
     }
   }
-  std::stable_sort(pend.begin(), pend.end(), [](const Pending &x, const Pending &y) { return x.m < y.m; });   // b already ascending
-  for (const Pending &p : pend) {
-    tree_add(r, pris.data() + p.pri_off, p.keep, p.h, nullptr);
+  for (size_t i = 0; i < sc.pend.size(); ++i) sc.pend[i].pri = sc.pris.data() + sc.pri_off[i];
+}
+
+int mzr_ingest_records_from(mz_replay *r, const float *records, int n_moves, int B, int rec_floats, int env_base) {
+  if (!r || !records) return fail("mzr_ingest_records: null argument");
+  if (n_moves < 0 || B < 1 || env_base < 0) return fail("mzr_ingest_records: bad shape (n_moves %d, B %d, env_base %d)", n_moves, B, env_base);
+  if (rec_floats != r->R)
+    return fail("mzr_ingest_records: rec_floats %d != obs_dim+action_space+%d = %d", rec_floats, MZR_REC_EXTRA, r->R);
+  // what the records cannot express (include/mz_replay.h): `terminal` separate from `done`
+  if (r->c.episode_life)
+    return fail("mzr_ingest_records: this replay is configured with episode_life (terminal != done, game.py:90): records "
+                "carry one end-of-game flag; feed such histories through mzr_save_history");
+  if (r->c.two_players)
+    return fail("mzr_ingest_records: this replay is configured with two_players: device records carry no to_play yet "
+                "(targets flip signs by it, replay_buffer.py:187-189); feed such histories through mzr_save_history");
+  if ((int)r->envs.size() < env_base + B) r->envs.resize((size_t)env_base + B);
+  // contiguous environment ranges per thread: concatenated in thread order the slices are in environment order, and a
+  // stable sort by move restores (move, env) -- the arrival order of a move-major walk, the order the reference's one
+  // replay would see with actors flushing in lock-step
+  const int T = r->pool.T < B ? r->pool.T : B;
+  if (T <= 1) {
+    ingest_range(r, r->scratch[0], records, n_moves, B, env_base, 0, B);
+  } else {
+    r->pool.run([&](int tid) {
+      if (tid >= T) return;
+      const int lo = (int)((int64_t)B * tid / T), hi = (int)((int64_t)B * (tid + 1) / T);
+      ingest_range(r, r->scratch[(size_t)tid], records, n_moves, B, env_base, lo, hi);
+    });
+  }
+  std::vector<Pending> &all = r->merged;
+  all.clear();
+  for (int t = 0; t < (T < 1 ? 1 : T); ++t) all.insert(all.end(), r->scratch[(size_t)t].pend.begin(), r->scratch[(size_t)t].pend.end());
+  std::stable_sort(all.begin(), all.end(), [](const Pending &x, const Pending &y) { return x.m < y.m; });   // b already ascending
+  for (const Pending &p : all) {
+    tree_add(r, p.pri, p.keep, p.h, nullptr);
     if (p.h->refs == 0) delete p.h;
     r->frames += p.keep;
     if (p.done) r->games += 1;
@@ -361,7 +507,7 @@ int mzr_sample_batch(const mz_replay *r, const double *draws, int bs, float *obs
                      double *priorities) {
   if (!r || !draws || !obs || !actions || !target_rewards || !target_values || !target_policies || !idxs || !priorities)
     return fail("mzr_sample_batch: null argument");
-  const int O = r->c.obs_dim, A = r->c.action_space, K = r->c.num_unroll_steps, td = r->c.td_steps;
+  const int O = r->c.obs_dim, A = r->c.action_space, K = r->c.num_unroll_steps, td = r->c.td_steps, R = r->R;
   const int TL = K + 1;
   // replay_buffer.py:81-82: discounts as float32, discount**td as a Python float
   float disc[256];
@@ -376,32 +522,35 @@ int mzr_sample_batch(const mz_replay *r, const double *draws, int bs, float *obs
     const int64_t step = r->leaf_step[(size_t)pos];
     idxs[i] = idx;
     priorities[i] = r->tree[(size_t)idx];
-    if (h->obs.empty() || h->child_visits.empty() || h->root_values.empty())
-      return fail("mzr_sample_batch: history was ingested without payload");
-    memcpy(obs + (size_t)i * O, h->obs.data() + (size_t)step * O, O * sizeof(float));   // 147
+    if (!h->payload) return fail("mzr_sample_batch: history was ingested without payload");
+    const float *rows = h->rows.data() + (size_t)h->off * R;
+    auto row = [&](int64_t s) { return rows + (size_t)s * R; };
+    auto reward = [&](int64_t s) { return row(s)[O + A + 4]; };
+    auto flags = [&](int64_t s) { return ((const int32_t *)(row(s) + O + A + 5))[1]; };
+    memcpy(obs + (size_t)i * O, row(step), O * sizeof(float));                                // 147
+    // (History: observations has one entry more than the other lists, game.py:93-96; every other list has h->n entries)
+    const int64_t end_index = h->n, n_rewards = h->n;
     for (int k = 0; k < K; ++k)                                                        // 149-152
-      actions[(size_t)i * K + k] = (step + k < (int64_t)h->actions.size()) ? h->actions[(size_t)(step + k)] : -1;
+      actions[(size_t)i * K + k] = (step + k < end_index) ? ((const int32_t *)(row(step + k) + O + A + 5))[0] : -1;
     // insert_target, replay_buffer.py:165-198
-    const int64_t end_index = (int64_t)h->root_values.size();
-    const int64_t n_rewards = (int64_t)h->rewards.size();
     for (int j = 0; j < TL; ++j) {
       const int64_t cur = step + j;
-      const float last_reward = (cur > 0 && cur <= n_rewards) ? h->rewards[(size_t)(cur - 1)] : 0.f;
+      const float last_reward = (cur > 0 && cur <= n_rewards) ? reward(cur - 1) : 0.f;
       float *pol = target_policies + ((size_t)i * TL + j) * A;
       if (cur < end_index) {
-        const int tp = h->to_play[(size_t)cur];
+        const int tp = flags(cur) & MZR_FLAG_P2;
         const int64_t boot = cur + td;
-        double value = boot < end_index ? h->root_values[(size_t)boot] * disc_td : 0.0;
+        double value = boot < end_index ? row_double(row(boot) + O + A) * disc_td : 0.0;
         const int64_t hi = boot < n_rewards ? boot : n_rewards;
         if (hi > cur) {
           float acc = 0.f;
           for (int64_t q = cur; q < hi; ++q) {
-            const float rw = (h->to_play[(size_t)q] != tp) ? -h->rewards[(size_t)q] : h->rewards[(size_t)q];
+            const float rw = ((flags(q) & MZR_FLAG_P2) != tp) ? -reward(q) : reward(q);      // 187-189
             acc += rw * disc[q - cur];
           }
           value += (double)acc;
         }
-        memcpy(pol, h->child_visits.data() + (size_t)cur * A, A * sizeof(float));
+        memcpy(pol, row(cur) + O, A * sizeof(float));
         target_rewards[(size_t)i * TL + j] = last_reward;
         target_values[(size_t)i * TL + j] = (float)value;
       } else {

@@ -74,7 +74,10 @@ class ShmRing(object):
     src = records.numpy() if torch.is_tensor(records) else np.asarray(records)
     data[:n_moves] = src[:n_moves]
     n[0] = n_moves
-    self.hdr[0] += 1          # published after the payload (x86 stores are not reordered; numpy's copy has completed)
+    # Published after the payload.  This relies on x86-64's store ordering (stores become visible in program order; the
+    # consumer's loads are not reordered with older loads) and on numpy having completed the copy before this statement
+    # runs: the ring is for ONE node of x86-64 hosts (the MI355X boxes are EPYC), not a portable lock-free queue.
+    self.hdr[0] += 1
 
   def close_producer(self):
     self.hdr[2] = 1
@@ -176,6 +179,14 @@ class RankStorage(object):
         self.call(self.storage, 'get_weights', int(gathered[r][1]), r)
     self.broadcasts += 1
     return (self.flat if self.flat.device == self.device else self.flat.to(self.device)), self.training_step
+
+
+def rccl_mapped():
+  """is librccl mapped into this process? (the evidence that backend 'nccl' really is RCCL here)"""
+  try:
+    return any('librccl' in line for line in open('/proc/self/maps'))
+  except OSError:
+    return False
 
 
 def init_process_group():

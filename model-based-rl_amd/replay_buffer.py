@@ -67,6 +67,19 @@ class SumTree(object):
     return out
 
 
+def default_ingest_threads(config=None):
+  """--ingest_threads, else 4 bounded by the CPUs this process may run on (one is left to the launching thread)"""
+  import os
+  n = getattr(config, 'ingest_threads', None)
+  if n:
+    return max(1, int(n))
+  try:
+    cpus = len(os.sched_getaffinity(0))
+  except AttributeError:
+    cpus = os.cpu_count() or 1
+  return max(1, min(4, cpus - 1))
+
+
 class PrioritizedReplay(object):
 
   def __init__(self, config):
@@ -82,7 +95,8 @@ class PrioritizedReplay(object):
                          int(config.td_steps), int(getattr(config, 'max_history_length', 500)), int(config.batch_size),
                          float(config.epsilon), float(config.alpha), float(config.beta),
                          float(getattr(config, 'beta_increment_per_sampling', 0.001)), float(config.discount),
-                         int(config.seed or 0))
+                         int(config.seed or 0), int(bool(getattr(config, 'two_players', False))),
+                         int(bool(getattr(config, 'episode_life', False))), default_ingest_threads(config), 0)
     h = C.c_void_p()
     _abi.check_replay(self.lib.mzr_create(C.byref(cfg), C.byref(h)), 'mzr_create')
     self._h = h
@@ -160,6 +174,16 @@ class PrioritizedReplay(object):
   # replay_buffer.py:200-203
   def update(self, idxs, errors):
     self.tree.update(np.asarray(idxs, np.int64), self.get_priorities(errors))
+
+  def set_ingest_threads(self, threads):
+    _abi.check_replay(self.lib.mzr_set_ingest_threads(self._h, int(threads)), 'mzr_set_ingest_threads')
+
+  @property
+  def ingest_threads(self):
+    return int(self.lib.mzr_ingest_threads(self._h))
+
+  def get_ingest_threads(self):
+    return self.ingest_threads
 
   def size(self):
     return int(self.lib.mzr_size(self._h))

@@ -30,6 +30,6 @@ def broadcast_flat(flat, src=0):
   """One collective: the flattened weights (engine.flatten_weights order) from rank `src` to all ranks.
   0.79 MB for the LunarLander FCNetwork -- latency-bound, so a single un-bucketed broadcast."""
   import torch.distributed as dist
-  if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+  if dist.is_available() and dist.is_initialized():      # (also at world size 1: the single-GPU RCCL self-test runs the collective)
     dist.broadcast(flat, src=src)
   return flat

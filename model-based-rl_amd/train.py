@@ -112,7 +112,7 @@ def launch_ranks(config, max_moves, selfplay_only=False, learner_steps=None):
   dist.all_gather(every, mine)
   summary = None
   if rank == 0:
-    server.join(timeout=120)
+    server.join(timeout=120)        # (`drained` in the summary says whether the rings were emptied in time)
     ray.get(workers)
     dt = time.time() - t0
     thr = ray.get(replay.get_throughput.remote())
@@ -123,7 +123,9 @@ def launch_ranks(config, max_moves, selfplay_only=False, learner_steps=None):
                'weight_broadcasts': rstorage.broadcasts, 'actor_training_step': actor.training_step,
                'rank_weight_sums': [float(x[0]) for x in every], 'rank_training_steps': [int(x[1]) for x in every],
                'rank_games': [int(x[2]) for x in every],
-               'replay_size': ray.get(replay.size.remote())}
+               'replay_size': ray.get(replay.size.remote()), 'backend': backend, 'rccl_mapped': D.rccl_mapped(),
+               'weights_on_device': bool(rstorage.flat.is_cuda), 'ingest_threads': ray.get(replay.get_ingest_threads.remote()),
+               'drained': not server.is_alive()}
     print('MZ_TRAIN_SUMMARY ' + json.dumps(summary), flush=True)
   dist.barrier()
   stop.set()

@@ -503,6 +503,81 @@ def test_train_driver_with_learner():
   assert abs(lt['replay_ratio'] - lt['updates_per_second'] / lt['frames_per_second']) < 1e-9
 
 
+def test_device_records_to_sampled_batch():
+  """Device loop -> drain -> native ingest -> PrioritizedReplay.sample_batch: every sampled position is traced back to the
+  experience record it came from (observations are unique) and its targets are recomputed from the raw records with
+  replay_buffer.py:124-198 written out in numpy -- policy = the stored visit distribution or zeros past the end of the
+  game (absorbing, 195-198), reward = the previous step's, value = discounted float32 reward sum + discount^td * root
+  value at the bootstrap step (176-189), actions padded with draws past the end (150-151), IS weights
+  (N * p / total)^-beta / max (157-160)."""
+  import random
+  import torch
+  from oracle import oracle as orc
+  from model_based_rl_amd.engine import Engine, records_view
+  from model_based_rl_amd.replay_buffer import PrioritizedReplay
+  g = np.load(os.path.join(G, 'g1_net_lunar.npz'))
+  O, A, B, T, moves, K, td, disc = 8, 4, 48, 7, 40, 5, 10, 0.997
+  eng = Engine(B, O, A, 12, seed=31)
+  eng.set_weights(orc.load_weights(g))
+  eng.selfplay_reset(T, 1.0, stagger=True)
+  cfg = types.SimpleNamespace(batch_size=64, epsilon=0.01, alpha=1.0, beta=0.7, obs_space=(O,), action_space=A, window_size=4096,
+                              window_step=None, num_unroll_steps=K, td_steps=td, max_history_length=500, discount=disc, seed=2)
+  rep = PrioritizedReplay(cfg)
+  recs = []
+  for _ in range(moves // 8):
+    eng.selfplay_steps(8)
+    buf, n = eng.selfplay_drain()
+    torch.cuda.synchronize()
+    recs.append(buf[:n].numpy().copy())
+    rep.ingest_records(recs[-1], n, B)
+  eng.close()
+  rec = np.concatenate(recs, 0)
+  rv = records_view(rec, O, A)
+  random.seed(9); np.random.seed(10)
+  total, size, beta = rep.tree.total_priority, rep.size(), min(1.0, 0.7 + 0.001)
+  (obs, actions, (t_rew, t_val, t_pol)), idxs, isw = rep.sample_batch()
+  actions = np.asarray(actions)
+  pri = rep.tree.leaves()[np.asarray(idxs) - (4096 - 1)]
+  w = np.power(size * pri / total, -beta)
+  assert np.allclose(isw, w / w.max(), rtol=0, atol=1e-15)
+  key = {rec[m, b, :O].tobytes(): (m, b) for m in range(moves) for b in range(B)}
+  discf = np.array([disc ** n for n in range(K + td)], np.float32)
+  checked_absorbing = 0
+  for i in range(64):
+    m, b = key[obs[i].tobytes()]
+    # the game this step belongs to: from the step after the previous done to the next done (histories are whole games here)
+    end = m
+    while not rv['done'][end, b]:
+      end += 1                                  # (a sampled step always belongs to a finished, flushed game)
+    n_game = end + 1                            # exclusive end, in move indices
+    start = m
+    while start > 0 and not rv['done'][start - 1, b]:
+      start -= 1                                # first recorded move of that game = step 0 of its history slice
+    assert abs(pri[i] - (abs(rv['error'][m, b]) + 0.01)) == 0
+    for k in range(K):
+      if m + k < n_game:
+        assert actions[i, k] == rv['action'][m + k, b]
+      else:
+        assert 0 <= actions[i, k] < A
+    for j in range(K + 1):
+      cur = m + j
+      last_reward = rv['reward'][cur - 1, b] if start < cur <= n_game else np.float32(0)      # replay_buffer.py:170-173
+      assert t_rew[i, j] == last_reward, (i, j)
+      if cur < n_game:
+        boot = cur + td
+        value = rv['root_value'][boot, b] * disc ** td if boot < n_game else 0.0
+        hi = min(boot, n_game)
+        acc = np.float32(0)
+        for q in range(cur, hi):
+          acc = np.float32(acc + np.float32(rv['reward'][q, b] * discf[q - cur]))
+        assert abs(t_val[i, j] - np.float32(value + float(acc))) <= 1e-6
+        assert np.array_equal(t_pol[i, j], rv['child_visits'][cur, b])
+      else:
+        checked_absorbing += 1
+        assert t_val[i, j] == 0 and not t_pol[i, j].any()
+  assert checked_absorbing > 0
+
+
 @pytest.mark.parametrize('O,A,sims,u8,split', [(8, 4, 30, False, False), (128, 6, 50, True, False), (5, 2, 6, False, False),
                                                (8, 4, 30, False, True), (60, 6, 50, True, True)])
 def test_persistent_selfplay_launch_equals_graph_of_kernels(O, A, sims, u8, split, monkeypatch):

@@ -1,5 +1,8 @@
-"""The multi-rank paths on ONE GPU (two ranks sharing it, collectives over gloo): what the driver's 8-GPU run executes
-over RCCL, proven before an 8-GPU node shows up.  The launchers are child processes."""
+"""The multi-rank paths on ONE GPU: two ranks sharing it with collectives over gloo (sharding, one replay fed by two
+ranks), and ONE rank with the process group over RCCL (backend "nccl", world size 1: the library is loaded, the group is
+created on the device, the weights are broadcast into device memory, the all-reduces and barriers run) -- what the
+driver's 8-GPU run executes, proven before an 8-GPU node shows up.  The launchers are child processes, started before
+anything in them touches the GPU."""
 import json
 import os
 import subprocess
@@ -37,6 +40,8 @@ def test_bench_two_ranks_shard_the_environments(tmp_path):
   assert line['timed_steps'] == steps * line['repeats'] and line['timed_seconds'] >= 0.15
   assert 'pulls inside the timed region' in line['config']['weight_sync'] and not line['config']['weight_sync'].startswith('0 ')
   assert 0.5 * 2 * B * line['timed_steps'] < line['value'] * line['timed_seconds'] < 1.5 * 2 * B * line['timed_steps']
+  assert line['collectives']['backend'] == 'gloo' and line['collectives']['world'] == 2
+  assert line['host_cores_busy_per_rank'] <= 2.0, line['host_cores_busy_per_rank']       # (8 ranks fit a 16-CPU quota)
   # rank 1's records vs one engine that owns env ids [B, 2B)
   from model_based_rl_amd.engine import Engine, flatten_weights, records_view
   from model_based_rl_amd.networks import FCNetwork
@@ -83,3 +88,43 @@ def test_train_two_ranks_learner_broadcast_and_one_replay():
       or s['actor_games'] == {0: s['rank_games'][0], 1: s['rank_games'][1]}
   assert s['games'] == sum(s['rank_games'])                              # both ranks' games were ingested by the one replay
   assert s['frames'] >= 1024 and s['replay_size'] > 0
+
+
+def test_bench_over_rccl_at_world_size_1():
+  """MZ_BENCH_FORCE_DIST=1 under the launcher with ONE process: bench.py takes its multi-rank branch over backend "nccl"
+  (= RCCL on ROCm): init_process_group on the device, broadcast_flat of the weights INTO DEVICE MEMORY at every pull, the
+  MAX / SUM all-reduces, barriers, destroy_process_group.  librccl must be mapped in the rank's process."""
+  B, steps = 256, 16
+  env = dict(os.environ, MZ_BENCH_FORCE_DIST='1', MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+  env.pop('MZ_BENCH_BACKEND', None)
+  out = subprocess.run(launcher(1, 29561) + [os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', str(steps), '--warmup',
+                       '4', '--no-cpu-baseline', '--envs', str(B), '--min-seconds', '0.3', '--sync-every', '16'],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+  assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+  line = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+  c = line['collectives']
+  assert c['backend'] == 'nccl' and c['world'] == 1 and c['forced_at_world_1'] and c['rccl_mapped'] and c['weights_on_device']
+  assert line['n_gpus'] == 1 and line['metric'].startswith('env-steps/sec') and line['value'] > 0
+  pulls = int(line['config']['weight_sync'].split(':')[1].split()[0])
+  assert pulls >= 2, line['config']['weight_sync']                     # broadcasts of device buffers inside the timed region
+  for key in ('roofline', 'ms_per_step', 'steps', 'warmup', 'scaling', 'dtype', 'config'):
+    assert key in line
+  assert 0.5 * B * line['timed_steps'] < line['value'] * line['timed_seconds'] < 1.5 * B * line['timed_steps']
+
+
+def test_train_over_rccl_at_world_size_1():
+  """train --ranks 1 with the default backend: RankStorage.get_weights does its broadcast + all-gather over RCCL on device
+  memory, the learner's weights and step reach the actor, the experience lands in the replay."""
+  env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''), HSA_ENABLE_IPC_MODE_LEGACY='0')
+  env.pop('MZ_DIST_BACKEND', None)
+  out = subprocess.run([sys.executable, '-m', 'model_based_rl_amd.train', '--ranks', '1', '--environment', 'LunarLander-v2',
+                        '--num_envs', '64', '--num_simulations', '8', '--episode_length', '6', '--max_moves', '-1',
+                        '--window_size', '16384', '--stored_before_train', '512', '--batch_size', '32',
+                        '--training_steps', '4', '--send_weights_frequency', '2', '--weight_sync_frequency', '8',
+                        '--seed', '3', '--use_gpu_for', 'actors', 'learner'],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+  assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+  s = json.loads([l for l in out.stdout.splitlines() if l.startswith('MZ_TRAIN_SUMMARY ')][-1][len('MZ_TRAIN_SUMMARY '):])
+  assert s['backend'] == 'nccl' and s['rccl_mapped'] and s['weights_on_device'] and s['drained']
+  assert s['ranks'] == 1 and s['training_step'] == 4 and s['rank_training_steps'] == [4]
+  assert s['weight_broadcasts'] >= 2 and s['frames'] >= 512 and s['games'] == s['rank_games'][0]

@@ -148,3 +148,66 @@ def test_sample_batch_matches_reference(path):
   # priority refresh (replay_buffer.py:200-203)
   rep.update(idxs, np.full(16, 0.5))
   assert abs(rep.tree.leaves()[idxs[0] - (int(g['max_capacity']) - 1)] - 0.51) < 1e-15
+
+
+def _bulk_records(rng, moves, B, O, A, T, two_player_bit=False):
+  rec = np.zeros((moves, B, O + A + 10), np.float32)
+  rec[..., :O + A] = rng.standard_normal((moves, B, O + A))
+  rec[..., O + A:O + A + 2] = rng.standard_normal((moves, B))[..., None].view(np.float32)        # root value (float64)
+  rec[..., O + A + 2:O + A + 4] = rng.standard_normal((moves, B))[..., None].view(np.float32)    # error (float64)
+  rec[..., O + A + 4] = rng.uniform(-1, 1, (moves, B))
+  ints = rec[..., O + A + 5:].view(np.int32)
+  t = rng.randint(0, T, B)
+  for m in range(moves):
+    ints[m, :, 0] = rng.randint(0, A, B); ints[m, :, 1] = t + 1 >= T; ints[m, :, 2] = t; ints[m, :, 3] = np.arange(B)
+    t = np.where(t + 1 >= T, 0, t + 1)
+  return rec
+
+
+@pytest.mark.parametrize('T,mhl,window', [(40, 500, 1 << 15), (23, 16, 1 << 15), (40, 500, 3000)])
+def test_parallel_ingest_is_bit_identical_to_one_thread(T, mhl, window):
+  """mzr_config.ingest_threads: the environments of a chunk are split over threads, the finished slices enter the one
+  sum tree in (move, env) order -- leaves, sums, counters and a sampled batch must not depend on the thread count
+  (replay_buffer.py:19-40 adds in arrival order; window 3000: the ring wraps and evicts while ingesting)."""
+  import random
+  from model_based_rl_amd.replay_buffer import PrioritizedReplay
+  O, A, B, moves = 5, 3, 203, 96
+  rec = _bulk_records(np.random.RandomState(7), moves, B, O, A, T)
+  results = []
+  for threads in (1, 4, 7):
+    rep = PrioritizedReplay(make_cfg(obs_space=(O,), action_space=A, max_history_length=mhl, window_size=window,
+                                     discount=0.997, ingest_threads=threads))
+    assert rep.ingest_threads == threads
+    for lo in range(0, moves, 8):
+      rep.ingest_records(rec[lo:lo + 8], 8, B)
+    random.seed(5); np.random.seed(6)
+    (obs, actions, (t_rew, t_val, t_pol)), idxs, isw = rep.sample_batch()
+    n = rep.size()
+    results.append(dict(total=rep.tree.total_priority, size=n, thr=rep.get_throughput(), leaves=rep.tree.leaves(n), obs=obs,
+                        actions=np.asarray(actions), t_rew=t_rew, t_val=t_val, t_pol=t_pol, idxs=np.asarray(idxs), isw=isw))
+  assert results[0]['thr']['frames'] > B * moves // 2 and results[0]['size'] == min(window, results[0]['thr']['frames'])
+  for other in results[1:]:
+    for k, v in results[0].items():
+      assert np.array_equal(np.asarray(v), np.asarray(other[k])) if not isinstance(v, dict) else v == other[k], k
+
+
+def test_ingest_records_refuses_what_records_cannot_express():
+  """Device records carry one end-of-game flag and no to_play: a replay configured with --two_players or --episode_life
+  (terminal != done, game.py:90; sign-flipped targets, replay_buffer.py:187-189) must refuse them loudly instead of
+  building wrong targets; save_history, which takes to_play and `terminal` explicitly, still works."""
+  from model_based_rl_amd.replay_buffer import PrioritizedReplay
+  O, A, B = 3, 2, 4
+  rec = _bulk_records(np.random.RandomState(1), 8, B, O, A, 5)
+  for flag in ('two_players', 'episode_life'):
+    rep = PrioritizedReplay(make_cfg(obs_space=(O,), action_space=A, window_size=256, **{flag: True}))
+    with pytest.raises(RuntimeError, match=flag):
+      rep.ingest_records(rec, 8, B)
+    assert rep.size() == 0 and rep.get_throughput() == {'frames': 0, 'games': 0}
+    h = types.SimpleNamespace(observations=np.zeros((4, O), np.float32), child_visits=np.full((3, A), 0.5, np.float32),
+                              root_values=[0.1, 0.2, 0.3], actions=[0, 1, 0], rewards=[1.0, 0.0, -1.0],
+                              errors=[0.5, 0.25, 0.125], dones=[0, 0, 1], to_play=[1, -1, 1])
+    rep.save_history(h, ignore=None, terminal=True)
+    assert rep.size() == 3 and rep.get_throughput() == {'frames': 3, 'games': 1}
+  ok = PrioritizedReplay(make_cfg(obs_space=(O,), action_space=A, window_size=256))
+  ok.ingest_records(rec, 8, B)
+  assert ok.get_throughput()['frames'] > 0
