@@ -44,12 +44,12 @@ def main(args):
 
   B = args.envs or 4096
   A, SIMS, T, OBS = 4, 50, 64, (4, 96, 96)
-  steps = args.steps if args.steps != 512 else 6             # (bench.py's FC default would be ~4 minutes here)
+  steps = args.steps if args.steps != 512 else 20            # (bench.py's FC default would be ~14 minutes here)
   warmup = args.warmup if args.warmup != 64 else 2
   cfg = types.SimpleNamespace(action_space=A, num_simulations=SIMS, two_players=False, known_bounds=(None, None),
                               discount=0.997, pb_c_base=19652, pb_c_init=1.25, init_value_score=0.0,
                               root_dirichlet_alpha=0.25, root_exploration_fraction=0.25, obs_space=OBS, episode_length=T,
-                              seed=0, batch_size=512, epsilon=0.01, alpha=1.0, beta=1.0, window_size=4096,
+                              seed=0, batch_size=512, obs_u8=True, epsilon=0.01, alpha=1.0, beta=1.0, window_size=4096,
                               window_step=None, num_unroll_steps=5, td_steps=10, max_history_length=500)
   torch.manual_seed(0)
   net = MuZeroNetwork(OBS[0], A, device, types.SimpleNamespace()).eval()
@@ -111,9 +111,18 @@ def main(args):
                  'note': 'env-steps executed per second; the replay accepted %d frames in the region (episodes of %d '
                          'moves are longer than the region)' % (frames, T)},
       'mcts_sims_per_s_per_gpu': B * steps * SIMS / dt,
-      'roofline': {'bound': 'mfma', 'kernel': 'MIOpen f32 convolutions of recurrent_inference (whole path, no per-kernel clock)',
+      'roofline': {'bound': 'mfma', 'kernel': 'MIOpen f32 convolutions of recurrent_inference (achieved = whole-path FLOP / wall time)',
                    'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                    'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': None, 'flop_per_move': flop_per_move},
+      'record_bytes_per_env_step': 4 * sp.rec_floats,
   }
+  # kernel-level view of this command: rocprofv3 --kernel-trace --stats summary committed under profiles/ (the builder's run;
+  # scripts/breakout_shares.py): dominant kernel with its average duration and share, GPU-time share by category
+  shares = os.path.join(ROOT, 'profiles', 'r03_breakout_kernel_shares.json')
+  if os.path.exists(shares) and B == 4096:
+    sj = json.load(open(shares))
+    out['roofline']['dominant_kernel'] = sj['dominant_kernel']
+    out['roofline']['gpu_time_share_by_category'] = {k: round(v['share'], 4) for k, v in sj['share_by_category'].items()}
+    out['roofline']['kernel_trace'] = 'profiles/r03_breakout_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this command, builder-run; not re-measured here)'
   print(json.dumps(out), flush=True)
   sp.close()

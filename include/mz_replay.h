@@ -38,7 +38,9 @@ typedef struct mzr_config {
   int32_t two_players;        /* --two_players: histories carry to_play = +-1 and targets flip signs (replay_buffer.py:187-189) */
   int32_t episode_life;       /* --episode_life: `terminal` (end of game) differs from `done` (game.py:90) */
   int32_t ingest_threads;     /* threads mzr_ingest_records* splits the environments of a call over (0 or 1: the caller only) */
-  int32_t reserved;
+  int32_t obs_u8;             /* observations are bytes (image / -ram- frames, game.py:93-96 keeps the raw uint8 observation): a record
+                               * carries them packed, 4 per float slot -- rec_floats = ceil(obs_dim / 4) + action_space + MZR_REC_EXTRA;
+                               * mzr_save_history still takes float32 observations (values 0..255), mzr_sample_batch returns float32 */
 } mzr_config;
 
 const char *mzr_last_error(void);

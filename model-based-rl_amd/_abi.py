@@ -158,7 +158,7 @@ class MzrConfig(C.Structure):
               ('num_unroll_steps', C.c_int32), ('td_steps', C.c_int32), ('max_history_length', C.c_int32),
               ('batch_size', C.c_int32), ('epsilon', _D), ('alpha', _D), ('beta', _D),
               ('beta_increment_per_sampling', _D), ('discount', _D), ('seed', _U64), ('two_players', C.c_int32),
-              ('episode_life', C.c_int32), ('ingest_threads', C.c_int32), ('reserved', C.c_int32)]
+              ('episode_life', C.c_int32), ('ingest_threads', C.c_int32), ('obs_u8', C.c_int32)]
 
 
 REPLAY_SIGNATURES = {

@@ -287,13 +287,12 @@ class Actor(Logger):
     events = [torch.cuda.Event(), torch.cuda.Event()]
     copy_stream = torch.cuda.Stream(self.device)
     sync_every = max(1, cfg.weight_sync_frequency)
-    done_col = sp.O + sp.A + 6
     pending, k = None, 0
 
     def hand_over(p):
       buf, ev = p
       ev.synchronize()
-      self._log_games(records_view(buf.numpy(), sp.O, sp.A))
+      self._log_games(records_view(buf.numpy(), sp.O, sp.A, obs_u8=sp.obs_u8))
       _call(self.replay_buffer, 'ingest_records', buf, 1, sp.B, self.env_base)
 
     while self.training_step < cfg.training_steps and (max_moves is None or self.move_counter < max_moves):

@@ -126,10 +126,23 @@ def build_parser():
 ENV_SHAPES = {   # (action_space, obs_space) of the environments the reference's README runs
     'TicTacToe': (9, (9,)), 'LunarLander-v2': (4, (8,)), 'Pong-ramNoFrameskip-v4': (6, (128,)),
     'Breakout-ramNoFrameskip-v4': (4, (128,)),
-    # image observations of the Atari wrappers (wrappers.py:422-444: 96x96 frames, stack_obs channels) -- what
-    # MuZeroNetwork / TinyNetwork take (SURVEY.md s7 on BASELINE configs[4])
-    'BreakoutNoFrameskip-v4': (4, (4, 96, 96)), 'PongNoFrameskip-v4': (6, (4, 96, 96)),
+    # image observations of the Atari wrappers (wrappers.py:422-444: 96x96 uint8 frames) -- what MuZeroNetwork /
+    # TinyNetwork take (SURVEY.md s7 on BASELINE configs[4]).  The channel count is NOT a property of the environment:
+    # utils.py:27-35 builds the network with input_channels = stack_obs, doubled with --stack_actions (None below;
+    # env_shapes() fills it in from the flags, so the same flags build the same conv1 as the reference's)
+    'BreakoutNoFrameskip-v4': (4, (None, 96, 96)), 'PongNoFrameskip-v4': (6, (None, 96, 96)),
 }
+
+
+def env_shapes(config):
+  """(action_space, obs_space) of config.environment (train.py:66-68 probes the environment for these).  Image
+  environments: channels = stack_obs * (2 if stack_actions else 1), as utils.get_network does (utils.py:27-35);
+  their frames are bytes (config.obs_u8: the experience records and the replay keep them as bytes, game.py:93-96)."""
+  A, obs = ENV_SHAPES[config.environment]
+  if obs[0] is None:
+    ch = int(getattr(config, 'stack_obs', 1)) * (2 if getattr(config, 'stack_actions', False) else 1)
+    obs = (ch,) + tuple(obs[1:])
+  return A, tuple(obs)
 
 
 def make_config(argv=None, **overrides):
@@ -137,5 +150,7 @@ def make_config(argv=None, **overrides):
   args.update(overrides)
   cfg = Config(args)
   if cfg.environment in ENV_SHAPES and not hasattr(cfg, 'action_space'):
-    cfg.action_space, cfg.obs_space = ENV_SHAPES[cfg.environment]   # train.py:66-68 probes the env for these
+    cfg.action_space, cfg.obs_space = env_shapes(cfg)   # train.py:66-68 probes the env for these
+  if not hasattr(cfg, 'obs_u8'):
+    cfg.obs_u8 = len(tuple(getattr(cfg, 'obs_space', ()))) == 3      # image frames travel as bytes
   return cfg

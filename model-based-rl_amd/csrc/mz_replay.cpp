@@ -37,8 +37,8 @@ static int fail(const char *fmt, ...) {
   return -1;
 }
 
-// One HistorySlice as record rows; leaves point into it as (history, step).  Row layout (R = O + A + MZR_REC_EXTRA floats):
-// obs[O], child_visits[A], root_value (float64, 2 slots), error (float64, 2 slots), reward, then int32 bits: action,
+// One HistorySlice as record rows; leaves point into it as (history, step).  Row layout (R = OS + A + MZR_REC_EXTRA floats,
+// OS = O float32 slots, or ceil(O / 4) when the observations are bytes -- mzr_config.obs_u8): obs, child_visits[A], root_value (float64, 2 slots), error (float64, 2 slots), reward, then int32 bits: action,
 // flags (bit 0 done, bit 1 to_play == -1), step, env_id, episode.
 struct Hist {
   int64_t n = 0;                // steps of the slice
@@ -130,6 +130,7 @@ struct Pool {
 
 struct mz_replay {
   mzr_config c;
+  int OS = 0;                      // float slots the observation takes in a row: O, or ceil(O / 4) for byte observations
   int R = 0;                       // floats per row
   // SumTree (replay_buffer.py:8-17)
   int64_t max_capacity, capacity_step, capacity, prev_capacity = 0, num_memories = 0, position = 0;
@@ -259,16 +260,19 @@ static int save_history(mz_replay *r, int64_t n, const double *errors, int64_t i
     h = new Hist();
     h->n = n;
     h->payload = obs && child_visits && root_values;
-    const int O = r->c.obs_dim, A = r->c.action_space, R = r->R;
+    const int O = r->c.obs_dim, OS = r->OS, A = r->c.action_space, R = r->R;
     h->rows.assign((size_t)n * R, 0.f);
     for (int64_t i = 0; i < n; ++i) {
       float *q = h->rows.data() + (size_t)i * R;
-      int32_t *qi = (int32_t *)(q + O + A + 5);
-      if (obs) memcpy(q, obs + i * O, O * sizeof(float));
-      if (child_visits) memcpy(q + O, child_visits + i * A, A * sizeof(float));
-      if (root_values) row_put_double(q + O + A, root_values[i]);
-      row_put_double(q + O + A + 2, errors[i]);
-      if (rewards) q[O + A + 4] = rewards[i];
+      int32_t *qi = (int32_t *)(q + OS + A + 5);
+      if (obs) {
+        if (r->c.obs_u8) { uint8_t *qb = (uint8_t *)q; for (int k = 0; k < O; ++k) qb[k] = (uint8_t)obs[i * O + k]; }
+        else memcpy(q, obs + i * O, O * sizeof(float));
+      }
+      if (child_visits) memcpy(q + OS, child_visits + i * A, A * sizeof(float));
+      if (root_values) row_put_double(q + OS + A, root_values[i]);
+      row_put_double(q + OS + A + 2, errors[i]);
+      if (rewards) q[OS + A + 4] = rewards[i];
       qi[0] = actions ? actions[i] : 0;
       qi[1] = ((dones && dones[i]) ? MZR_FLAG_DONE : 0) | ((to_play && to_play[i] < 0) ? MZR_FLAG_P2 : 0);
       qi[2] = (int32_t)i;
@@ -298,7 +302,8 @@ int mzr_create(const mzr_config *cfg, mz_replay **out) {
   if (cfg->ingest_threads < 0 || cfg->ingest_threads > 64) return fail("mzr_create: ingest_threads must be in [0, 64]");
   mz_replay *r = new mz_replay();
   r->c = *cfg;
-  r->R = cfg->obs_dim + cfg->action_space + MZR_REC_EXTRA;
+  r->OS = cfg->obs_u8 ? (cfg->obs_dim + 3) / 4 : cfg->obs_dim;
+  r->R = r->OS + cfg->action_space + MZR_REC_EXTRA;
   r->max_capacity = cfg->window_size;
   r->capacity_step = cfg->window_step;
   r->capacity = cfg->window_step;
@@ -394,7 +399,7 @@ int mzr_ingest_records(mz_replay *r, const float *records, int n_moves, int B, i
 // here (their priorities too); their insertion into the sum tree is deferred (Pending).
 static void ingest_range(mz_replay *r, Scratch &sc, const float *records, int n_moves, int B, int env_base, int b_lo,
                          int b_hi) {
-  const int O = r->c.obs_dim, A = r->c.action_space, R = r->R;
+  const int OS = r->OS, A = r->c.action_space, R = r->R;
   const int64_t overlap = r->c.num_unroll_steps + r->c.td_steps;
   sc.pend.clear(); sc.pris.clear(); sc.pri_off.clear();
   const int PF = 6;       // envs ahead: an env's records lie n_moves strides of B * rec_floats apart (move-major ring),
@@ -415,7 +420,7 @@ static void ingest_range(mz_replay *r, Scratch &sc, const float *records, int n_
     if (g.recs.capacity() == 0) g.recs.reserve((size_t)64 * R);
     for (int m = 0; m < n_moves; ++m) {
       const float *rec = records + ((size_t)m * B + b) * R;
-      const int32_t *ri = (const int32_t *)(rec + O + A + 5);
+      const int32_t *ri = (const int32_t *)(rec + OS + A + 5);
       const bool done = (ri[1] & MZR_FLAG_DONE) != 0;
       g.recs.insert(g.recs.end(), rec, rec + R);
       g.history_idx += 1;
@@ -438,7 +443,7 @@ static void ingest_range(mz_replay *r, Scratch &sc, const float *records, int n_
       double *pri = sc.pris.data() + off;
       const float *q = g.recs.data() + (size_t)(collect_from - g.base) * R;
       for (int64_t i = 0; i < n; ++i, q += R) {
-        const double e = fabs(row_double(q + O + A + 2)) + r->c.epsilon;
+        const double e = fabs(row_double(q + OS + A + 2)) + r->c.epsilon;
         pri[i] = r->c.alpha == 1.0 ? e : pow(e, r->c.alpha);
       }
       if (done) {           // the game is over: its buffer becomes the slice (run_selfplay starts a new Game, actors.py:94-97)
@@ -467,7 +472,7 @@ int mzr_ingest_records_from(mz_replay *r, const float *records, int n_moves, int
   if (!r || !records) return fail("mzr_ingest_records: null argument");
   if (n_moves < 0 || B < 1 || env_base < 0) return fail("mzr_ingest_records: bad shape (n_moves %d, B %d, env_base %d)", n_moves, B, env_base);
   if (rec_floats != r->R)
-    return fail("mzr_ingest_records: rec_floats %d != obs_dim+action_space+%d = %d", rec_floats, MZR_REC_EXTRA, r->R);
+    return fail("mzr_ingest_records: rec_floats %d != obs slots (%d) + action_space + %d = %d", rec_floats, r->OS, MZR_REC_EXTRA, r->R);
   // what the records cannot express (include/mz_replay.h): `terminal` separate from `done`
   if (r->c.episode_life)
     return fail("mzr_ingest_records: this replay is configured with episode_life (terminal != done, game.py:90): records "
@@ -507,7 +512,7 @@ int mzr_sample_batch(const mz_replay *r, const double *draws, int bs, float *obs
                      double *priorities) {
   if (!r || !draws || !obs || !actions || !target_rewards || !target_values || !target_policies || !idxs || !priorities)
     return fail("mzr_sample_batch: null argument");
-  const int O = r->c.obs_dim, A = r->c.action_space, K = r->c.num_unroll_steps, td = r->c.td_steps, R = r->R;
+  const int O = r->c.obs_dim, OS = r->OS, A = r->c.action_space, K = r->c.num_unroll_steps, td = r->c.td_steps, R = r->R;
   const int TL = K + 1;
   // replay_buffer.py:81-82: discounts as float32, discount**td as a Python float
   float disc[256];
@@ -525,13 +530,18 @@ int mzr_sample_batch(const mz_replay *r, const double *draws, int bs, float *obs
     if (!h->payload) return fail("mzr_sample_batch: history was ingested without payload");
     const float *rows = h->rows.data() + (size_t)h->off * R;
     auto row = [&](int64_t s) { return rows + (size_t)s * R; };
-    auto reward = [&](int64_t s) { return row(s)[O + A + 4]; };
-    auto flags = [&](int64_t s) { return ((const int32_t *)(row(s) + O + A + 5))[1]; };
-    memcpy(obs + (size_t)i * O, row(step), O * sizeof(float));                                // 147
+    auto reward = [&](int64_t s) { return row(s)[OS + A + 4]; };
+    auto flags = [&](int64_t s) { return ((const int32_t *)(row(s) + OS + A + 5))[1]; };
+    if (r->c.obs_u8) {                                                                        // 147 (bytes -> float32, as np.float32(obs))
+      const uint8_t *ob = (const uint8_t *)row(step);
+      for (int k = 0; k < O; ++k) obs[(size_t)i * O + k] = (float)ob[k];
+    } else {
+      memcpy(obs + (size_t)i * O, row(step), O * sizeof(float));
+    }
     // (History: observations has one entry more than the other lists, game.py:93-96; every other list has h->n entries)
     const int64_t end_index = h->n, n_rewards = h->n;
     for (int k = 0; k < K; ++k)                                                        // 149-152
-      actions[(size_t)i * K + k] = (step + k < end_index) ? ((const int32_t *)(row(step + k) + O + A + 5))[0] : -1;
+      actions[(size_t)i * K + k] = (step + k < end_index) ? ((const int32_t *)(row(step + k) + OS + A + 5))[0] : -1;
     // insert_target, replay_buffer.py:165-198
     for (int j = 0; j < TL; ++j) {
       const int64_t cur = step + j;
@@ -540,7 +550,7 @@ int mzr_sample_batch(const mz_replay *r, const double *draws, int bs, float *obs
       if (cur < end_index) {
         const int tp = flags(cur) & MZR_FLAG_P2;
         const int64_t boot = cur + td;
-        double value = boot < end_index ? row_double(row(boot) + O + A) * disc_td : 0.0;
+        double value = boot < end_index ? row_double(row(boot) + OS + A) * disc_td : 0.0;
         const int64_t hi = boot < n_rewards ? boot : n_rewards;
         if (hi > cur) {
           float acc = 0.f;
@@ -550,7 +560,7 @@ int mzr_sample_batch(const mz_replay *r, const double *draws, int bs, float *obs
           }
           value += (double)acc;
         }
-        memcpy(pol, row(cur) + O, A * sizeof(float));
+        memcpy(pol, row(cur) + OS, A * sizeof(float));
         target_rewards[(size_t)i * TL + j] = last_reward;
         target_values[(size_t)i * TL + j] = (float)value;
       } else {

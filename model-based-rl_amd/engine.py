@@ -38,16 +38,19 @@ def flatten_weights(weights):
 REC_EXTRA = 10      # include/mz_engine.h MZ_REC_EXTRA
 
 
-def records_view(rec, O, A):
-  """Named views into experience records [..., O + A + REC_EXTRA] (numpy float32, layout of include/mz_engine.h):
-  obs, child_visits, root_value / error (float64), reward, action / done / step / env_id / episode (int32)."""
+def records_view(rec, O, A, obs_u8=False):
+  """Named views into experience records (numpy float32, layout of include/mz_engine.h / include/mz_replay.h):
+  obs, child_visits, root_value / error (float64), reward, action / done / step / env_id / episode (int32).
+  obs_u8: the observation is O bytes packed into ceil(O / 4) float slots (image frames, torch_search.TorchSelfplay)."""
   rec = np.asarray(rec)
-  assert rec.dtype == np.float32 and rec.shape[-1] == O + A + REC_EXTRA, (rec.dtype, rec.shape)
-  ints = rec[..., O + A + 5:].view(np.int32)
-  return dict(obs=rec[..., :O], child_visits=rec[..., O:O + A],
-              root_value=np.ascontiguousarray(rec[..., O + A:O + A + 2]).view(np.float64)[..., 0],
-              error=np.ascontiguousarray(rec[..., O + A + 2:O + A + 4]).view(np.float64)[..., 0],
-              reward=rec[..., O + A + 4], action=ints[..., 0], done=ints[..., 1], step=ints[..., 2],
+  OS = (O + 3) // 4 if obs_u8 else O
+  assert rec.dtype == np.float32 and rec.shape[-1] == OS + A + REC_EXTRA, (rec.dtype, rec.shape)
+  ints = rec[..., OS + A + 5:].view(np.int32)
+  obs = np.ascontiguousarray(rec[..., :OS]).view(np.uint8)[..., :O] if obs_u8 else rec[..., :O]
+  return dict(obs=obs, child_visits=rec[..., OS:OS + A],
+              root_value=np.ascontiguousarray(rec[..., OS + A:OS + A + 2]).view(np.float64)[..., 0],
+              error=np.ascontiguousarray(rec[..., OS + A + 2:OS + A + 4]).view(np.float64)[..., 0],
+              reward=rec[..., OS + A + 4], action=ints[..., 0], done=ints[..., 1], step=ints[..., 2],
               env_id=ints[..., 3], episode=ints[..., 4])
 
 

@@ -372,6 +372,8 @@ def get_network(config, device=None):
     import numpy as np
     return FCNetwork(int(np.prod(config.obs_space)), config.action_space, device, config)
   if arch in ('MuZeroNetwork', 'TinyNetwork'):
+    # utils.py:27-35: input_channels = stack_obs, doubled with stack_actions; config.env_shapes() derives the image
+    # environments' obs_space[0] from the same two flags, and a hand-built config may give obs_space directly
     channels = int(config.obs_space[0]) if len(tuple(config.obs_space)) == 3 else int(getattr(config, 'stack_obs', 1)) * (
         2 if getattr(config, 'stack_actions', False) else 1)
     return (MuZeroNetwork if arch == 'MuZeroNetwork' else TinyNetwork)(channels, config.action_space, device, config)

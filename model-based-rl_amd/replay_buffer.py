@@ -96,7 +96,8 @@ class PrioritizedReplay(object):
                          float(config.epsilon), float(config.alpha), float(config.beta),
                          float(getattr(config, 'beta_increment_per_sampling', 0.001)), float(config.discount),
                          int(config.seed or 0), int(bool(getattr(config, 'two_players', False))),
-                         int(bool(getattr(config, 'episode_life', False))), default_ingest_threads(config), 0)
+                         int(bool(getattr(config, 'episode_life', False))), default_ingest_threads(config),
+                         int(bool(getattr(config, 'obs_u8', False))))
     h = C.c_void_p()
     _abi.check_replay(self.lib.mzr_create(C.byref(cfg), C.byref(h)), 'mzr_create')
     self._h = h

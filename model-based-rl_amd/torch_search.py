@@ -117,7 +117,11 @@ class TorchSelfplay(object):
     self.envs = SyntheticImageEnvs(num_envs, tuple(config.obs_space), int(config.episode_length), device, seed=seed,
                                    env_id_offset=env_id_offset)
     self.O = int(np.prod(config.obs_space))
-    self.rec_floats = self.O + self.A + REC_EXTRA
+    # the frames are bytes and stay bytes in the experience record (game.py:93-96 keeps the raw observation): O bytes in
+    # ceil(O / 4) float slots -- a quarter of the D2H traffic and of the replay's memory (include/mz_replay.h obs_u8)
+    self.obs_u8 = self.envs.obs.dtype == torch.uint8
+    self.OS = (self.O + 3) // 4 if self.obs_u8 else self.O
+    self.rec_floats = self.OS + self.A + REC_EXTRA
     self.norm = norm                   # (obs_min, obs_range) device tensors or None (actors.py:134-137)
     self.move = 0
     self.temperature = torch.full((self.B,), 1.0, dtype=torch.float64, device=self.device)
@@ -133,7 +137,7 @@ class TorchSelfplay(object):
   @torch.inference_mode()
   def play_move(self, out):
     """One move of every environment; the experience records go to out [B, rec_floats] (device float32 tensor)."""
-    envs, B, O, A = self.envs, self.B, self.O, self.A
+    envs, B, O, A = self.envs, self.B, self.OS, self.A
     raw = envs.obs
     obs = raw.to(torch.float32)                                     # actors.py:134
     if self.norm is not None:
@@ -141,7 +145,10 @@ class TorchSelfplay(object):
     self.search.run(obs, move=self.move)
     fin = self.search.finalize(self.temperature, None, move=self.move)
     reward, done, step, episode = envs.step()
-    out[:, :O].copy_(raw.reshape(B, O))                             # History keeps the raw observation (game.py:93-96)
+    if self.obs_u8:                                                 # History keeps the raw observation (game.py:93-96)
+      out.view(torch.uint8)[:, :self.O].copy_(raw.reshape(B, self.O))
+    else:
+      out[:, :O].copy_(raw.reshape(B, self.O))
     out[:, O:O + A].copy_(fin['child_visits'])
     out[:, O + A:O + A + 4].copy_(torch.stack((fin['root_value'], fin['error']), 1).view(torch.float32))
     out[:, O + A + 4].copy_(reward)

@@ -15,7 +15,7 @@ import torch
 
 from . import rayshim as ray
 from .actors import Actor
-from .config import build_parser, Config, ENV_SHAPES
+from .config import build_parser, Config, env_shapes
 from .learners import Learner
 from .networks import FCNetwork
 from .replay_buffer import PrioritizedReplay
@@ -70,7 +70,7 @@ def launch_ranks(config, max_moves, selfplay_only=False, learner_steps=None):
   B = int(config.num_envs)
   torch_net = config.architecture != 'FCNetwork'
   O, A = int(np.prod(config.obs_space)), int(config.action_space)
-  rec, chunk = O + A + 10, (1 if torch_net else 8)
+  rec, chunk = ((O + 3) // 4 if getattr(config, 'obs_u8', False) else O) + A + 10, (1 if torch_net else 8)
   torch.manual_seed(config.seed or 0)
   probe = get_network(config, torch.device('cpu'))
   n_flat = flat_size(probe) if torch_net else sum(v.numel() for v in probe.state_dict().values())
@@ -169,7 +169,8 @@ def main(argv=None):
   if max_moves is not None and max_moves < 0:
     max_moves = None              # run until the learner has reached --training_steps (actors.py:93)
   cfg = Config(args)
-  cfg.action_space, cfg.obs_space = ENV_SHAPES[cfg.environment]
+  cfg.action_space, cfg.obs_space = env_shapes(cfg)
+  cfg.obs_u8 = len(cfg.obs_space) == 3               # image frames travel as bytes (records, replay)
   if cfg.seed is None:
     cfg.seed = 0
   if cfg.run_tag is None:           # train.py:83-90: a date-stamped run directory (the launcher's start time under --ranks)

@@ -114,7 +114,7 @@ def test_torch_selfplay_records_and_actor_loop():
   from model_based_rl_amd.networks import get_network
   from model_based_rl_amd.replay_buffer import PrioritizedReplay
   from model_based_rl_amd.shared_storage import SharedStorage
-  cfg = make_config(['--architecture', 'TinyNetwork', '--environment', 'BreakoutNoFrameskip-v4', '--num_envs', '24',
+  cfg = make_config(['--architecture', 'TinyNetwork', '--environment', 'BreakoutNoFrameskip-v4', '--stack_obs', '4', '--num_envs', '24',
                      '--num_simulations', '6', '--episode_length', '5', '--seed', '2', '--window_size', '2048',
                      '--weight_sync_frequency', '4', '--training_steps', '100'])
   storage, replay = SharedStorage(cfg), PrioritizedReplay(cfg)
@@ -127,9 +127,17 @@ def test_torch_selfplay_records_and_actor_loop():
   actor.launch(max_moves=12)
   rec = np.concatenate(seen, 0)
   O, A = 4 * 96 * 96, 4
-  assert rec.shape == (12, 24, O + A + 10)
-  rv = records_view(rec, O, A)
-  assert np.array_equal(rv['obs'], np.round(rv['obs'])) and rv['obs'].max() == 255 and rv['obs'].min() == 0
+  assert cfg.obs_space == (4, 96, 96) and cfg.obs_u8          # channels = --stack_obs (utils.py:27-35); frames travel as bytes
+  assert rec.shape == (12, 24, O // 4 + A + 10)               # ... 4 per float slot: a quarter of the float32 record
+  rv = records_view(rec, O, A, obs_u8=True)
+  assert rv['obs'].dtype == np.uint8 and rv['obs'].shape == (12, 24, O) and rv['obs'].max() == 255 and rv['obs'].min() == 0
+  assert abs(float(rv['obs'].mean()) - 127.5) < 1.0
+  # what the learner gets back out of the replay: the same frames as float32 (np.float32(obs), learners.py:167-168 normalises)
+  replay.batch_size = 4
+  (bobs, _, _), _, _ = replay.sample_batch()
+  assert bobs.shape == (4, 4, 96, 96) and bobs.dtype == np.float32
+  frames = {rv['obs'][m, b].tobytes() for m in range(12) for b in range(24)}
+  assert all(bobs[i].astype(np.uint8).tobytes() in frames and np.array_equal(bobs[i], np.round(bobs[i])) for i in range(4))
   assert np.allclose(rv['child_visits'].sum(-1), 1.0, atol=1e-6)
   assert np.all(np.take_along_axis(rv['child_visits'], rv['action'][..., None], -1) > 0)
   assert np.array_equal(rv['env_id'][0], np.arange(24)) and set(np.unique(rv['done'])) == {0, 1}
@@ -150,7 +158,8 @@ def test_train_driver_with_conv_network_and_learner():
   the actor searches with TinyNetwork behind the batched external-inference path, its records (image observations)
   reach the replay, the learner trains on sampled batches on the GPU and publishes weights the actor adopts."""
   from model_based_rl_amd import train
-  thr = train.main(['--architecture', 'TinyNetwork', '--environment', 'BreakoutNoFrameskip-v4', '--num_envs', '16',
+  thr = train.main(['--architecture', 'TinyNetwork', '--environment', 'BreakoutNoFrameskip-v4', '--stack_obs', '2', '--stack_actions',
+                    '--num_envs', '16',
                     '--num_simulations', '4', '--seed', '1', '--episode_length', '6', '--max_moves', '40', '--window_size',
                     '1024', '--stored_before_train', '128', '--batch_size', '8', '--learner_steps', '3',
                     '--send_weights_frequency', '1', '--weight_sync_frequency', '4', '--norm_obs', '--obs_range', '0', '255',
