@@ -51,6 +51,8 @@ def main(args):
                               root_dirichlet_alpha=0.25, root_exploration_fraction=0.25, obs_space=OBS, episode_length=T,
                               seed=0, batch_size=512, obs_u8=True, epsilon=0.01, alpha=1.0, beta=1.0, window_size=4096,
                               window_step=None, num_unroll_steps=5, td_steps=10, max_history_length=500)
+  if os.environ.get('MZ_MIOPEN_FIND', '0')[:1] == '1':
+    torch.backends.cudnn.benchmark = True
   torch.manual_seed(0)
   net = MuZeroNetwork(OBS[0], A, device, types.SimpleNamespace()).eval()
   norm = (torch.zeros(1, device=device), torch.full((1,), 255.0, device=device))      # --norm_obs --obs_range 0 255
@@ -94,6 +96,22 @@ def main(args):
   torch.cuda.synchronize(device)
   dt = time.perf_counter() - t0
   frames = replay.get_throughput()['frames'] - frames0
+  # the two network calls of a move on their own (events on the current stream, outside the timed region)
+  def gpu_ms(fn, n):
+    fn(); torch.cuda.synchronize(device)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+      fn()
+    b.record(); torch.cuda.synchronize(device)
+    return a.elapsed_time(b) / n
+  with torch.inference_mode():
+    obs_f = (sp.envs.obs.to(torch.float32) - norm[0]) / norm[1]
+    hid = net.representation(obs_f)
+    act = torch.zeros(B, dtype=torch.int32, device=device)
+    init_ms = gpu_ms(lambda: net.initial_inference(obs_f), 2)
+    rec_ms = gpu_ms(lambda: net.recurrent_inference(hid, act), 5)
+    del obs_f, hid
   f_rec, f_init = muzero_flops(A)
   flop_per_move = B * (SIMS * f_rec + f_init)
   achieved = flop_per_move * steps / dt / 1e12
@@ -115,6 +133,10 @@ def main(args):
                    'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                    'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': None, 'flop_per_move': flop_per_move},
       'record_bytes_per_env_step': 4 * sp.rec_floats,
+      'network_calls': {'initial_inference_ms': init_ms, 'recurrent_inference_ms': rec_ms,
+                        'recurrent_tflops': B * f_rec / (rec_ms * 1e-3) / 1e12,
+                        'share_of_move': (init_ms + SIMS * rec_ms) / (1e3 * dt / steps),
+                        'clock': 'HIP events around back-to-back calls at %d rows, outside the timed region' % B},
   }
   # kernel-level view of this command: rocprofv3 --kernel-trace --stats summary committed under profiles/ (the builder's run;
   # scripts/breakout_shares.py): dominant kernel with its average duration and share, GPU-time share by category

@@ -177,6 +177,14 @@ int mz_finalize(mz_engine *e, const double *temperature, const double *uniform, 
 int mz_export_tree(mz_engine *e, int32_t *N, double *W, double *P, float *R, int32_t *E, int8_t *TP,
                    uint32_t *legal_mask, double *minmax, double *noise, float *hidden_pool);
 
+/* Epilogue of a residual block of the conv networks in GPU inference (reference networks.py:393-410: BatchNorm2d in eval
+ * mode, the skip connection, ReLU), for the torch-network path (BASELINE configs[4]; the convolutions themselves stay
+ * MIOpen's): in place over a contiguous NCHW float32 tensor y [dev][n] = [N][channels][hw], hw % 4 == 0,
+ *   y = relu(y * scale[c] + shift[c] (+ residual)),   scale = weight / sqrt(running_var + eps), shift = bias - mean * scale
+ * (scale, shift [dev][channels]; residual [dev][n] or NULL).  One pass instead of PyTorch's 2-3 elementwise kernels. */
+int mz_affine_relu(float *y, const float *scale, const float *shift, const float *residual, size_t n, int channels,
+                   int hw, void *stream);
+
 /* Introspection for tests/bench. */
 int mz_nodes_per_tree(const mz_engine *e);
 int mz_padded_envs(const mz_engine *e);

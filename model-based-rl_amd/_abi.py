@@ -109,6 +109,7 @@ SIGNATURES = {
     'mz_recurrent_inference': (_I, [_VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP]),
     'mz_finalize': (_I, [_VP, _VP, _VP, _U64, _VP, _VP, _VP, _VP, _VP, _VP]),
     'mz_export_tree': (_I, [_VP] * 11),
+    'mz_affine_relu': (_I, [_VP, _VP, _VP, _VP, _SZ, _I, _I, _VP]),
     'mz_nodes_per_tree': (_I, [_VP]),
     'mz_padded_envs': (_I, [_VP]),
     'mz_selfplay_reset': (_I, [_VP, _I, _D, _I, _VP]),

@@ -111,6 +111,23 @@ struct mz_engine {
 
 __global__ void k_store_double(double *dst, double v) { *dst = v; }
 
+// y = relu(y * scale[c] + shift[c] (+ residual)) in place over an NCHW float32 tensor, HW a multiple of 4: one 16-byte
+// access per thread and operand (a float4 never straddles a channel), grid-stride.  HBM-bound: 2 or 3 tensor passes.
+template <bool RES>
+__global__ __launch_bounds__(256) void k_affine_relu(float4 *__restrict__ y, const float *__restrict__ scale,
+                                                      const float *__restrict__ shift, const float4 *__restrict__ res,
+                                                      size_t n4, int C, int hw4) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const int c = (int)((i / (size_t)hw4) % (size_t)C);
+    const float a = scale[c], b = shift[c];
+    float4 v = y[i];
+    v.x = v.x * a + b; v.y = v.y * a + b; v.z = v.z * a + b; v.w = v.w * a + b;
+    if constexpr (RES) { const float4 r = res[i]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    y[i] = v;
+  }
+}
+
 template <typename T>
 static int dmalloc(mz_engine *e, T **p, size_t n) {
   void *q = nullptr;
@@ -815,6 +832,24 @@ int mz_destroy(mz_engine *e) {
   for (void *p : e->allocs) hipFree(p);
   if (e->sp.host_ring) hipHostFree(e->sp.host_ring);
   delete e;
+  return 0;
+}
+
+int mz_affine_relu(float *y, const float *scale, const float *shift, const float *residual, size_t n, int channels,
+                   int hw, void *stream) {
+  if (!y || !scale || !shift) return fail("mz_affine_relu: null argument");
+  if (channels < 1 || hw < 4 || (hw & 3) || n % ((size_t)channels * hw)) return fail("mz_affine_relu: n %zu is not [N][%d][%d] with hw %% 4 == 0", n, channels, hw);
+  if (((uintptr_t)y | (uintptr_t)residual) & 15) return fail("mz_affine_relu: tensors must be 16-byte aligned");
+  const size_t n4 = n / 4;
+  size_t blocks = (n4 + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  if (residual)
+    hipLaunchKernelGGL(k_affine_relu<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float4 *)y, scale, shift,
+                       (const float4 *)residual, n4, channels, hw / 4);
+  else
+    hipLaunchKernelGGL(k_affine_relu<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float4 *)y, scale, shift,
+                       (const float4 *)nullptr, n4, channels, hw / 4);
+  HIPCHECK(hipGetLastError());
   return 0;
 }
 

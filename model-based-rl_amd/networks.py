@@ -103,6 +103,38 @@ class FCNetwork(nn.Module):
 # ---------------------------------------------------------------------------------------------------------------
 # Conv networks (reference networks.py:393-718): residual tower MuZeroNetwork and TinyNetwork.
 
+def _bn_affine(bn):
+  """BatchNorm2d in inference mode is x * scale + shift per channel; the pair is cached on the module and recomputed when
+  any of its four tensors has been written (load_state_dict / load_flat copy in place: the version counters move)."""
+  key = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version, bn.weight.device)
+  cache = getattr(bn, '_mz_affine', None)
+  if cache is None or cache[0] != key:
+    with torch.no_grad():
+      scale = (bn.weight * torch.rsqrt(bn.running_var + bn.eps)).contiguous()
+      shift = (bn.bias - bn.running_mean * scale).contiguous()
+    cache = (key, scale, shift)
+    bn._mz_affine = cache
+  return cache[1], cache[2]
+
+
+def _fused_ok(y):
+  return y.is_cuda and y.dtype == torch.float32 and y.dim() == 4 and y.is_contiguous() and (y.shape[2] * y.shape[3]) % 4 == 0
+
+
+def _affine_relu_(y, scale, shift, residual=None):
+  """y <- relu(y * scale[c] + shift[c] (+ residual)) in place, one HIP kernel (mz_affine_relu, include/mz_engine.h): the
+  BatchNorm + skip + ReLU epilogue of a residual block.  PyTorch's own three elementwise kernels (addcmul, add, clamp) were
+  15.7 % of the GPU time of `bench.py --workload breakout` (profiles/r03_breakout_kernel_stats.csv, before)."""
+  from . import _abi
+  import ctypes as C
+  lib = _abi.load()
+  _abi.check(lib.mz_affine_relu(C.c_void_p(y.data_ptr()), C.c_void_p(scale.data_ptr()), C.c_void_p(shift.data_ptr()),
+                                None if residual is None else C.c_void_p(residual.data_ptr()), y.numel(), int(y.shape[1]),
+                                int(y.shape[2] * y.shape[3]), C.c_void_p(torch.cuda.current_stream(y.device).cuda_stream)),
+             'mz_affine_relu')
+  return y
+
+
 def _bn_infer(bn, x):
   """BatchNorm2d in inference mode as one fused multiply-add per element on the GPU: MIOpen's inference kernel
   (MIOpenBatchNormFwdInferSpatialEst) takes 144 us for a [512, 128, 6, 6] tensor on MI355X -- twice the 3x3 convolution
@@ -110,14 +142,15 @@ def _bn_infer(bn, x):
   CPU tensors and training mode go through the module itself."""
   if bn.training or not x.is_cuda:
     return bn(x)
-  scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
-  shift = bn.bias - bn.running_mean * scale
+  scale, shift = _bn_affine(bn)
   return torch.addcmul(shift.view(1, -1, 1, 1), x, scale.view(1, -1, 1, 1))
 
 
 class _Block(nn.Module):
   """Two 3x3 convolutions around a skip connection; with BatchNorm it is the reference's ResidualBlock
-  (networks.py:393-410), without it the TinyBlock (networks.py:557-567): relu(n2(conv2(relu(n1(conv1(x))))) + x)."""
+  (networks.py:393-410), without it the TinyBlock (networks.py:557-567): relu(n2(conv2(relu(n1(conv1(x))))) + x).
+  GPU inference with BatchNorm: each convolution's output gets its whole epilogue (BatchNorm, skip, ReLU) in one
+  in-place pass (_affine_relu_)."""
 
   def __init__(self, channels, norm):
     super().__init__()
@@ -130,6 +163,10 @@ class _Block(nn.Module):
     self.norm = norm
 
   def forward(self, x):
+    if self.norm and not self.training and _fused_ok(x):
+      x = x if x.is_contiguous() else x.contiguous()
+      y = _affine_relu_(self.conv1(x), *_bn_affine(self.bn1))
+      return _affine_relu_(self.conv2(y), *_bn_affine(self.bn2), residual=x)
     y = self.conv1(x)
     y = torch.relu(_bn_infer(self.bn1, y) if self.norm else y)
     y = self.conv2(y)
@@ -195,6 +232,9 @@ class _MuZeroDynamics(nn.Module):
     return self._tail(torch.addcmul(y, plane_value, response))
 
   def _tail(self, y):
+    if not self.training and _fused_ok(y):
+      state = _through(self.resblocks, _affine_relu_(y, *_bn_affine(self.bn)))
+      return state, self.fc2(torch.relu(self.fc1(state.flatten(1))))
     state = _through(self.resblocks, torch.relu(_bn_infer(self.bn, y)))
     return state, self.fc2(torch.relu(self.fc1(state.flatten(1))))
 
