@@ -8,6 +8,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 tot = sum(float(r['TotalDurationNs']) for r in rows)
 CATS = [
     ('tree kernels (mz_select / mz_expand_backup / root / finalize)', r'k_tree_|k_dirichlet|k_env_step|k_gather_hidden|k_scatter_hidden|k_store'),
+    ('BatchNorm + skip + ReLU epilogues (mz_affine_relu)', r'k_affine_relu'),
     ('convolution (MIOpen)', r'[Cc]onv|igemm|Igemm|gfx9.*_fwd|miopen.*(Fwd|fwd)|naive_conv|Winograd|winograd|sp3|Sp3|ConvBin|gridwise_convolution|implicit_gemm'),
     ('GEMM (rocBLAS / hipBLASLt: the fully connected heads)', r'Cijk_|gemm|Gemm|GEMM'),
     ('copies / gathers (index_select, hidden pool, records)', r'copyBuffer|index_select|indexSelect|gather|CatArrayBatchedCopy|copy_kernel|direct_copy|fillBuffer|memcpy|Memcpy'),
