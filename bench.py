@@ -30,7 +30,8 @@ if ROOT not in sys.path:
 # BASELINE.json configs[1] (the headline, default): LunarLander-v2 shapes, FCNetwork, 30 simulations, 4096 parallel
 # envs per GPU.  Secondary lines for profiles/, never the headline: --workload pong = configs[3]'s shapes on one GPU
 # (Pong-ram: 128 uint8 observations with --norm_obs 0 255, 6 actions, 50 simulations); --workload breakout =
-# configs[4] (MuZeroNetwork through PyTorch-ROCm behind the external-inference entry points, bench_torch.py).
+# configs[4] (MuZeroNetwork through PyTorch-ROCm behind the external-inference entry points, bench_torch.py);
+# --workload tree = the stand-alone tree kernels of that path against the HBM / cache rooflines (bench_tree.py).
 WORKLOADS = {'lunar': ('LunarLander-v2', 4096, 8, 4, 30, 256), 'pong': ('Pong-ramNoFrameskip-v4', 4096, 128, 6, 50, 1024)}
 WNAME, B, O, A, SIMS, EPISODE_LEN = WORKLOADS['lunar']
 for _i, _a in enumerate(sys.argv):
@@ -277,7 +278,7 @@ def main():
   ap.add_argument('--steps', type=int, default=512)
   ap.add_argument('--warmup', type=int, default=64)
   ap.add_argument('--no-cpu-baseline', action='store_true')
-  ap.add_argument('--workload', choices=sorted(WORKLOADS) + ['breakout'], default='lunar')
+  ap.add_argument('--workload', choices=sorted(WORKLOADS) + ['breakout', 'tree'], default='lunar')
   ap.add_argument('--envs', type=int, default=None, help='override the number of environments per GPU (tests)')
   ap.add_argument('--chunk', type=int, default=CHUNK, help='moves per drain / ingest chunk')
   ap.add_argument('--sync-every', type=int, default=128,
@@ -293,6 +294,9 @@ def main():
   if args.workload == 'breakout':
     import bench_torch             # secondary line: MuZeroNetwork through PyTorch-ROCm (BASELINE.json configs[4])
     return bench_torch.main(args)
+  if args.workload == 'tree':
+    import bench_tree              # secondary line: the stand-alone tree kernels against the HBM / cache rooflines (SURVEY.md s8d ii)
+    return bench_tree.main(args)
   chunk = max(1, args.chunk)
 
   world = int(os.environ.get('WORLD_SIZE', '1'))
