@@ -49,16 +49,9 @@ def main(args):
     eng.root_load(val[SIMS], lg[SIMS])
     eng.root_prepare(None, None, None, device_rng=True, move=m)
     for s in range(SIMS):
-      if timing is not None:
-        e0, e1, e2 = ev(), ev(), ev()
-        e0.record()
       leaf, slot, action, depth = eng.select()
-      if timing is not None:
-        e1.record()
       eng.expand_backup(val[s], rew[s], lg[s])
       if timing is not None:
-        e2.record()
-        timing.append((e0, e1, e2))
         depth_sum.add_(depth.long())
 
   for m in range(warmup):
@@ -69,13 +62,19 @@ def main(args):
     move(warmup + m)
   torch.cuda.synchronize(device)
   dt = time.perf_counter() - t0
-  # per-kernel clock: HIP events on the stream the kernels are launched on, around every launch of a few moves
+  # per-kernel clock: start / stop events on each kernel's own dispatch (mz_tree_pair_timed), every launch of 4 moves;
+  # the leaf depths of the same simulations come from a replay of those moves through mz_select (same seeds, same trees)
   timing = []
   for m in range(4):
-    move(warmup + moves + m, timing)
+    eng.root_load(val[SIMS], lg[SIMS])
+    eng.root_prepare(None, None, None, device_rng=True, move=warmup + moves + m)
+    for s in range(SIMS):
+      timing.append(eng.tree_pair_timed(val[s], rew[s], lg[s]))
+  for m in range(4):
+    move(warmup + moves + m, [])
   torch.cuda.synchronize(device)
-  sel_us = 1e3 * float(np.mean([a.elapsed_time(b) for a, b, _ in timing]))
-  exb_us = 1e3 * float(np.mean([b.elapsed_time(c) for _, b, c in timing]))
+  sel_us = 1e3 * float(np.mean([a for a, _ in timing]))
+  exb_us = 1e3 * float(np.mean([b for _, b in timing]))
   d_mean = float(depth_sum.sum().item()) / (B * len(timing))
   bytes_sel = B * d_mean * (4 + 24 * A)
   bytes_exb = B * (29 * (d_mean + 1) + 24 * A + 4 * A + 8)
@@ -113,7 +112,9 @@ def main(args):
                               'each (one 16-lane group per tree), %.0f KB of algorithmic traffic per launch in %.1f us; what '
                               'bounds them is the chain of dependent cache round trips and the %.1f us launch floor, not bytes' %
                               (bytes_sel / 1e3, sel_us, 1.5),
-                   'clock': 'HIP events on the launch stream around every launch of 4 moves (%d launches of each kernel)' % len(timing)},
+                   'hbm_side_traffic': 'profiles/r03_tree_traffic.json: FETCH_SIZE / WRITE_SIZE passes of this command' if traffic else None,
+                   'clock': 'start / stop events on each kernel\'s own dispatch (hipExtLaunchKernelGGL, mz_tree_pair_timed), every '
+                            'launch of 4 moves (%d launches of each kernel)' % len(timing)},
   }
   print(json.dumps(out), flush=True)
   eng.close()

@@ -151,6 +151,12 @@ int mz_search_phase_spread(const mz_engine *e, double *out3);
 int mz_select(mz_engine *e, int32_t *leaf_node, int32_t *parent_slot, int32_t *action, int32_t *depth,
               void *stream);
 int mz_gather_hidden(mz_engine *e, float *hidden_out, void *stream);
+/* One simulation's tree work with a clock on each kernel: mz_select (no outputs) + mz_expand_backup (no hidden state),
+ * hipExtLaunchKernelGGL start / stop events around each of the two dispatches (the timestamps rocprofv3's kernel trace
+ * reports); synchronous.  ms_out [host][2] = duration of k_tree_select, of k_tree_expand_backup, in milliseconds.
+ * The roofline clock of `bench.py --workload tree` (the tree kernels against HBM / cache bandwidth). */
+int mz_tree_pair_timed(mz_engine *e, const float *value, const float *reward, const float *logits, float *ms_out,
+                       void *stream);
 int mz_expand_backup(mz_engine *e, const float *value, const float *reward, const float *logits,
                      const float *hidden, void *stream);
 

@@ -105,6 +105,7 @@ SIGNATURES = {
     'mz_search_phase_spread': (_I, [_VP, _VP]),
     'mz_select': (_I, [_VP, _VP, _VP, _VP, _VP, _VP]),
     'mz_gather_hidden': (_I, [_VP, _VP, _VP]),
+    'mz_tree_pair_timed': (_I, [_VP, _VP, _VP, _VP, _VP, _VP]),
     'mz_expand_backup': (_I, [_VP, _VP, _VP, _VP, _VP, _VP]),
     'mz_recurrent_inference': (_I, [_VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP]),
     'mz_finalize': (_I, [_VP, _VP, _VP, _U64, _VP, _VP, _VP, _VP, _VP, _VP]),

@@ -111,6 +111,16 @@ struct mz_engine {
 
 __global__ void k_store_double(double *dst, double v) { *dst = v; }
 
+// what mz_select hands back, in one launch: any of the four outputs may be null
+__global__ void k_export_selection(TreeView t, int32_t *leaf, int32_t *slot, int32_t *act, int32_t *depth) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= t.B) return;
+  if (leaf) leaf[b] = t.leaf[b];
+  if (slot) slot[b] = t.slot[b];
+  if (act) act[b] = t.act[b];
+  if (depth) depth[b] = t.depth[b];
+}
+
 // y = relu(y * scale[c] + shift[c] (+ residual)) in place over an NCHW float32 tensor, HW a multiple of 4: one 16-byte
 // access per thread and operand (a float4 never straddles a channel), grid-stride.  HBM-bound: 2 or 3 tensor passes.
 template <bool RES>
@@ -462,16 +472,22 @@ static int build_packing(mz_engine *e) {
     else hipLaunchKernelGGL(kern<2>, dim3(grid), dim3(256), 0, s, __VA_ARGS__);                \
   } while (0)
 
+// (e->ev_start set: the dispatch carries start / stop events -- mz_tree_pair_timed, the clock of bench.py --workload tree)
+#define TREE_GO_(kern, G_, s, ...)                                                                                \
+  do {                                                                                                            \
+    if (e->ev_start) hipExtLaunchKernelGGL(kern<G_>, dim3(blocks_), dim3(threads_), 0, s, e->ev_start, e->ev_stop, 0, __VA_ARGS__); \
+    else hipLaunchKernelGGL(kern<G_>, dim3(blocks_), dim3(threads_), 0, s, __VA_ARGS__);                          \
+  } while (0)
 #define TREE_LAUNCH(kern, s, ...)                                                             \
   do {                                                                                        \
     const int threads_ = 256;                                                                 \
     const int total_ = e->B * e->G;                                                           \
     const int blocks_ = (total_ + threads_ - 1) / threads_;                                   \
     switch (e->G) {                                                                           \
-      case 4: hipLaunchKernelGGL(kern<4>, dim3(blocks_), dim3(threads_), 0, s, __VA_ARGS__); break;   \
-      case 8: hipLaunchKernelGGL(kern<8>, dim3(blocks_), dim3(threads_), 0, s, __VA_ARGS__); break;   \
-      case 16: hipLaunchKernelGGL(kern<16>, dim3(blocks_), dim3(threads_), 0, s, __VA_ARGS__); break; \
-      default: hipLaunchKernelGGL(kern<32>, dim3(blocks_), dim3(threads_), 0, s, __VA_ARGS__); break; \
+      case 4: TREE_GO_(kern, 4, s, __VA_ARGS__); break;                                       \
+      case 8: TREE_GO_(kern, 8, s, __VA_ARGS__); break;                                       \
+      case 16: TREE_GO_(kern, 16, s, __VA_ARGS__); break;                                     \
+      default: TREE_GO_(kern, 32, s, __VA_ARGS__); break;                                     \
     }                                                                                         \
   } while (0)
 
@@ -1117,11 +1133,36 @@ int mz_select(mz_engine *e, int32_t *leaf_node, int32_t *parent_slot, int32_t *a
     HIPCHECK(hipGetLastError());
     e->selection_valid = true;
   }
-  const size_t nb = (size_t)e->B * sizeof(int32_t);
-  if (leaf_node) HIPCHECK(hipMemcpyAsync(leaf_node, e->tv.leaf, nb, hipMemcpyDeviceToDevice, s));
-  if (parent_slot) HIPCHECK(hipMemcpyAsync(parent_slot, e->tv.slot, nb, hipMemcpyDeviceToDevice, s));
-  if (action) HIPCHECK(hipMemcpyAsync(action, e->tv.act, nb, hipMemcpyDeviceToDevice, s));
-  if (depth) HIPCHECK(hipMemcpyAsync(depth, e->tv.depth, nb, hipMemcpyDeviceToDevice, s));
+  if (leaf_node || parent_slot || action || depth) {      // one launch (four D2D blits cost 4 x 4 us per simulation)
+    hipLaunchKernelGGL(k_export_selection, dim3((e->B + 255) / 256), dim3(256), 0, s, e->tv, leaf_node, parent_slot, action, depth);
+    HIPCHECK(hipGetLastError());
+  }
+  return 0;
+}
+
+int mz_tree_pair_timed(mz_engine *e, const float *value, const float *reward, const float *logits, float *ms_out, void *stream) {
+  if (!e || !value || !reward || !logits || !ms_out) return fail("mz_tree_pair_timed: null argument");
+  MZ_ENTER(e);
+  if (!e->root_ready) return fail("mz_tree_pair_timed: call mz_root_prepare first");
+  if (e->sims_done >= e->sims) return fail("mz_tree_pair_timed: all %d simulations already done", e->sims);
+  if (e->selection_valid) return fail("mz_tree_pair_timed: a selection is pending (mz_expand_backup it first)");
+  hipStream_t s = (hipStream_t)stream;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  for (auto &x : ev) HIPCHECK(hipEventCreate(&x));
+  e->ev_start = ev[0]; e->ev_stop = ev[1];
+  TREE_LAUNCH(k_tree_select, s, e->tv);
+  e->ev_start = ev[2]; e->ev_stop = ev[3];
+  TREE_LAUNCH(k_tree_expand_backup, s, e->tv, value, reward, logits);
+  e->ev_start = e->ev_stop = nullptr;
+  hipError_t le = hipGetLastError(), se = hipStreamSynchronize(s);
+  int rc = 0;
+  if (le != hipSuccess || se != hipSuccess) rc = fail("mz_tree_pair_timed: %s", hipGetErrorString(le != hipSuccess ? le : se));
+  else if (hipEventElapsedTime(&ms_out[0], ev[0], ev[1]) != hipSuccess || hipEventElapsedTime(&ms_out[1], ev[2], ev[3]) != hipSuccess)
+    rc = fail("mz_tree_pair_timed: event timing failed");
+  for (auto &x : ev) hipEventDestroy(x);
+  if (rc) return rc;
+  e->sims_done += 1;
+  e->selection_valid = false;
   return 0;
 }
 

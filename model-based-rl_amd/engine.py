@@ -234,6 +234,13 @@ class Engine(object):
     _abi.check(self.lib.mz_select(self._h, *[_ptr(o) for o in out], self.stream), 'mz_select')
     return out   # leaf_node, parent_slot, action, depth
 
+  def tree_pair_timed(self, value, reward, logits):
+    """one simulation's select + expand_backup with events around each kernel's own dispatch; returns (ms, ms), synchronous"""
+    value = self._dev(value, torch.float32); reward = self._dev(reward, torch.float32); logits = self._dev(logits, torch.float32)
+    ms = (C.c_float * 2)()
+    _abi.check(self.lib.mz_tree_pair_timed(self._h, _ptr(value), _ptr(reward), _ptr(logits), ms, self.stream), 'mz_tree_pair_timed')
+    return float(ms[0]), float(ms[1])
+
   def gather_hidden(self):
     h = torch.empty(self.B, H, dtype=torch.float32, device=self.device)
     _abi.check(self.lib.mz_gather_hidden(self._h, _ptr(h), self.stream), 'mz_gather_hidden')
