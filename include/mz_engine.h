@@ -153,7 +153,8 @@ int mz_select(mz_engine *e, int32_t *leaf_node, int32_t *parent_slot, int32_t *a
 int mz_gather_hidden(mz_engine *e, float *hidden_out, void *stream);
 /* One simulation's tree work with a clock on each kernel: mz_select (no outputs) + mz_expand_backup (no hidden state),
  * hipExtLaunchKernelGGL start / stop events around each of the two dispatches (the timestamps rocprofv3's kernel trace
- * reports); synchronous.  ms_out [host][2] = duration of k_tree_select, of k_tree_expand_backup, in milliseconds.
+ * reports); synchronous.  ms_out [host][2] = duration of k_tree_select (-1 where the descent was already pending: the
+ * first simulation after mz_root_prepare, which selects inside the root kernel), of k_tree_expand_backup, in milliseconds.
  * The roofline clock of `bench.py --workload tree` (the tree kernels against HBM / cache bandwidth). */
 int mz_tree_pair_timed(mz_engine *e, const float *value, const float *reward, const float *logits, float *ms_out,
                        void *stream);

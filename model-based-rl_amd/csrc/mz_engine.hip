@@ -1145,20 +1145,21 @@ int mz_tree_pair_timed(mz_engine *e, const float *value, const float *reward, co
   MZ_ENTER(e);
   if (!e->root_ready) return fail("mz_tree_pair_timed: call mz_root_prepare first");
   if (e->sims_done >= e->sims) return fail("mz_tree_pair_timed: all %d simulations already done", e->sims);
-  if (e->selection_valid) return fail("mz_tree_pair_timed: a selection is pending (mz_expand_backup it first)");
   hipStream_t s = (hipStream_t)stream;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   for (auto &x : ev) HIPCHECK(hipEventCreate(&x));
+  const bool pending = e->selection_valid;      // (the root's own first descent: mz_root_prepare leaves it selected)
   e->ev_start = ev[0]; e->ev_stop = ev[1];
-  TREE_LAUNCH(k_tree_select, s, e->tv);
+  if (!pending) TREE_LAUNCH(k_tree_select, s, e->tv);
   e->ev_start = ev[2]; e->ev_stop = ev[3];
   TREE_LAUNCH(k_tree_expand_backup, s, e->tv, value, reward, logits);
   e->ev_start = e->ev_stop = nullptr;
   hipError_t le = hipGetLastError(), se = hipStreamSynchronize(s);
   int rc = 0;
   if (le != hipSuccess || se != hipSuccess) rc = fail("mz_tree_pair_timed: %s", hipGetErrorString(le != hipSuccess ? le : se));
-  else if (hipEventElapsedTime(&ms_out[0], ev[0], ev[1]) != hipSuccess || hipEventElapsedTime(&ms_out[1], ev[2], ev[3]) != hipSuccess)
+  else if ((!pending && hipEventElapsedTime(&ms_out[0], ev[0], ev[1]) != hipSuccess) || hipEventElapsedTime(&ms_out[1], ev[2], ev[3]) != hipSuccess)
     rc = fail("mz_tree_pair_timed: event timing failed");
+  if (pending) ms_out[0] = -1.f;
   for (auto &x : ev) hipEventDestroy(x);
   if (rc) return rc;
   e->sims_done += 1;
