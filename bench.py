@@ -32,7 +32,10 @@ if ROOT not in sys.path:
 # (Pong-ram: 128 uint8 observations with --norm_obs 0 255, 6 actions, 50 simulations); --workload breakout =
 # configs[4] (MuZeroNetwork through PyTorch-ROCm behind the external-inference entry points, bench_torch.py);
 # --workload tree = the stand-alone tree kernels of that path against the HBM / cache rooflines (bench_tree.py).
-WORKLOADS = {'lunar': ('LunarLander-v2', 4096, 8, 4, 30, 256), 'pong': ('Pong-ramNoFrameskip-v4', 4096, 128, 6, 50, 1024)}
+WORKLOADS = {'lunar': ('LunarLander-v2', 4096, 8, 4, 30, 256), 'pong': ('Pong-ramNoFrameskip-v4', 4096, 128, 6, 50, 1024),
+             # configs[0]'s game at throughput size (SURVEY.md s8d Config 1): TicTacToe with the reference's rules ON THE DEVICE,
+             # two players, known bounds (-1, 1), discount 1; games last 5-9 moves
+             'tictactoe': ('TicTacToe', 4096, 9, 9, 30, 9)}
 WNAME, B, O, A, SIMS, EPISODE_LEN = WORKLOADS['lunar']
 for _i, _a in enumerate(sys.argv):
   if _a == '--workload' and _i + 1 < len(sys.argv) and sys.argv[_i + 1] in WORKLOADS:
@@ -229,7 +232,8 @@ class Pipeline(object):
 def replay_config():
   return types.SimpleNamespace(batch_size=256, epsilon=0.01, alpha=1.0, beta=1.0, obs_space=(O,), action_space=A,
                                window_size=1 << 21, window_step=None, num_unroll_steps=5, td_steps=10,
-                               max_history_length=500, discount=0.997, seed=0)
+                               max_history_length=500, discount=1.0 if WNAME == 'TicTacToe' else 0.997, seed=0,
+                               two_players=WNAME == 'TicTacToe')
 
 
 def measure_split_f16(device, flat, chunk, moves=384):
@@ -336,7 +340,11 @@ def main():
   flat = flatten_weights(net.state_dict()).to(coll_dev)
   if rank != 0:
     flat.zero_()
-  eng = Engine(B, O, A, SIMS, seed=1234, env_id_offset=rank * B, device=device, split_f16=args.split_f16)
+  game = WNAME == 'TicTacToe'
+  eng = Engine(B, O, A, SIMS, seed=1234, env_id_offset=rank * B, device=device, split_f16=args.split_f16,
+               **(dict(two_players=True, known_bounds=(-1.0, 1.0), discount=1.0) if game else {}))
+  if game:
+    eng.selfplay_set_env('tictactoe')
   n_syncs = [0]
 
   def sync_weights():
@@ -457,6 +465,9 @@ def main():
                                'random-init weights (torch.manual_seed(0))'
                                % (WNAME, O, ' uint8 + norm_obs 0 255' if ram else '', A, SIMS, B, EPISODE_LEN),
                    'envs_per_gpu': B, 'num_simulations': SIMS, 'episode_len': EPISODE_LEN,
+                   'environment': 'TicTacToe on the device (custom_environments/tic_tac_toe.py rules; two players, known bounds '
+                                  '(-1, 1), discount 1; one launch per step of a move, 16 moves per hipGraph)' if game else
+                                  'synthetic fixed-length episodes on the device',
                    'priming': '%d untimed moves before warm-up so episode ends are in steady state' % EPISODE_LEN,
                    'timed_region': 'the --steps block repeated %d times back to back in one pipelined region of %.2f s '
                                    '(barrier + synchronize on both sides)' % (repeats, dt),
@@ -501,7 +512,7 @@ def main():
                                'an XCD\'s L2 delivers: that, not the matrix pipe (0.22 busy), bounds the stages (DESIGN.md s3.4)'},
           'note': 'achieved / peak = EXECUTED float16 MFMA FLOP against the dense f16 peak; the algorithmic float32 FLOP of the '
                   'same work are a third of that minus the K padding'}
-    elif world == 1 and O + 1 <= 64 and A <= 13:
+    elif world == 1 and O + 1 <= 64 and A <= 13 and not game:
       # the opt-in split-f16 search kernel on the same workload, as a SECONDARY figure inside the same line (never `value`)
       try:
         out['split_f16_secondary'] = measure_split_f16(device, flat, chunk)

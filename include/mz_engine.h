@@ -205,7 +205,8 @@ int mz_padded_envs(const mz_engine *e);
  * select_action -> env.step -> experience record appended to a device ring.
  * Each record is rec_floats() = obs_dim + action_space + MZ_REC_EXTRA float32 slots: obs[O] (raw, as History keeps
  * it), child_visits[A], root_value and error as float64 in two slots each (the reference's Python floats,
- * actors.py:147-148, game.py:112), reward, then as int32 bit patterns: action, done, step, env_id, episode.
+ * actors.py:147-148, game.py:112), reward, then as int32 bit patterns: action, flags (bit 0 = done, bit 1 = the mover was
+ * player -1: History.to_play, game.py:100-101; always clear for the single-player environments), step, env_id, episode.
  * mz_selfplay_drain copies the records produced since the last drain into `out` [host, pinned
  * preferred] asynchronously on `stream` and returns their count through *n_records after the
  * stream is synchronised by the caller (records are laid out move-major: [moves][B]).  `stream` may be a
@@ -223,6 +224,15 @@ int mz_padded_envs(const mz_engine *e);
 #define MZ_REC_EXTRA 10
 int mz_selfplay_reset(mz_engine *e, int episode_len, double temperature, int stagger, void *stream);
 int mz_selfplay_set_temperature(mz_engine *e, double temperature, void *stream);
+/* The environment the loop plays (call before mz_selfplay_reset).  0 (default): the synthetic fixed-length episodes above.
+ * 1: TicTacToe with the reference's rules (custom_environments/tic_tac_toe.py:5-76: observation turn * board, legal =
+ * empty cells, reward 1 for the winning move, done on a win or after nine moves, players alternate) entirely on the device;
+ * needs obs_dim 9, action_space 9, two_players.  mz_selfplay_reset's episode_len / stagger are ignored (real games).
+ * mz_selfplay_set_draws (game environments only): the Dirichlet draw (noise [dev][B][A] float64 at the legal positions,
+ * mcts.py:59) and / or the uniform of select_action (uniform [dev][B] float64, config.py:77) of the following moves come
+ * from the caller -- numpy's stream in the reference's order -- instead of the device RNG; NULL, NULL switches back. */
+int mz_selfplay_set_env(mz_engine *e, int kind);
+int mz_selfplay_set_draws(mz_engine *e, const double *noise, const double *uniform, void *stream);
 /* Observation format of the synthetic env (call before mz_selfplay_reset; synchronous).  uint8_obs != 0: observations
  * are bytes 0..255 (the -ram- envs).  obs_min / obs_range [host][obs_dim], both or neither: --norm_obs
  * (actors.py:55-58,134-137): the network input is (obs - obs_min) / obs_range in float32, the record keeps the raw

@@ -71,14 +71,16 @@ int mzr_save_history(mz_replay *r, int64_t n, const double *errors, int64_t igno
 /* Bulk ingest of device records (layout of mz_selfplay_drain: [n_moves][B][rec_floats], rec = obs[O],
  * child_visits[A] (float32), root_value and error as float64 in two float slots each (the reference keeps both as
  * Python floats: actors.py:147-148, game.py:112 -- priorities and value targets built from records are therefore
- * the reference's doubles), reward (float32), then int32 bits action, done, step, env_id, episode:
+ * the reference's doubles), reward (float32), then int32 bits action, flags, step, env_id, episode:
  * rec_floats = obs_dim + action_space + MZR_REC_EXTRA.
  * Re-creates per environment what Actor.play_game does after each move (actors.py:160-173): histories are
  * accumulated per env and flushed to save_history when max_history_length steps were collected (with the
  * overlap/ignore rules) or the episode is done.  frames/games: PrioritizedReplay.throughput.
- * Records describe single-player episodes: to_play = +1 and `done` ends the game (terminal == done).  A replay
- * created with two_players or episode_life REFUSES records (-1, mzr_last_error): such histories go through
- * mzr_save_history, which takes to_play and `terminal` explicitly.
+ * The flags word of a record carries `done` (bit 0) and the mover (bit 1 set = to_play -1; History.to_play,
+ * game.py:100-101 -- n-step targets flip the sign of the other player's rewards by it, replay_buffer.py:187-189); the
+ * single-player device loops leave bit 1 clear (to_play = +1), the device TicTacToe loop sets it.  `done` ends the game
+ * (terminal == done): a replay created with episode_life (terminal != done, game.py:90) REFUSES records (-1,
+ * mzr_last_error) -- such histories go through mzr_save_history, which takes `terminal` explicitly.
  * Threads: the environments of a call are split into contiguous ranges over mzr_config.ingest_threads threads (history
  * assembly and priorities are per environment, actors.py:160-173); the finished slices enter the one sum tree on the
  * calling thread in (move, environment) order -- leaves, sums, counters and sample batches are bit-identical for every

@@ -116,6 +116,8 @@ SIGNATURES = {
     'mz_selfplay_reset': (_I, [_VP, _I, _D, _I, _VP]),
     'mz_selfplay_set_temperature': (_I, [_VP, _D, _VP]),
     'mz_selfplay_set_obs': (_I, [_VP, _I, _VP, _VP]),
+    'mz_selfplay_set_env': (_I, [_VP, _I]),
+    'mz_selfplay_set_draws': (_I, [_VP, _VP, _VP, _VP]),
     'mz_selfplay_export_trees': (_I, [_VP, _I]),
     'mz_selfplay_noise_log': (_I, [_VP, _I]),
     'mz_selfplay_read_noise': (_I, [_VP, _U64, _VP]),

@@ -98,6 +98,8 @@ struct mz_engine {
   size_t n_packed_h2 = 0;
   float *obs_norm = nullptr;        // [2][O] --norm_obs minimum and range (device)
   double *noise_log = nullptr;      // [ring_moves][B][A] per-move Dirichlet draws (mz_selfplay_noise_log), allocated on first use
+  double *draw_uniform = nullptr;   // [B] host-given uniforms of a game environment's parity run (mz_selfplay_set_draws)
+  bool draws_noise = false, draws_set = false;
   std::vector<float> obs_norm_host;
 };
 
@@ -702,7 +704,7 @@ static int fused_lt(const mz_engine *e) {
 }
 // Can the self-play loop run as whole moves inside one launch (HEAD instantiation of the fused kernel)?
 static bool selfplay_persist_ok(const mz_engine *e) {
-  if (!e->use_persist || !e->use_fused || e->sims + 2 > MZ_FUSED_MAXPL || e->cfg.two_players || e->prof_buf)
+  if (!e->use_persist || !e->use_fused || e->sims + 2 > MZ_FUSED_MAXPL || e->cfg.two_players || e->prof_buf || e->sp.env_kind)
     return false;
   if (e->split_f16 && e->use_lds_trees) {      // the split-f16 kernel where it applies (launch_h2), else the exact one below
     for (int lt = 1; lt <= (e->use_lds_hybrid ? 2 : 1); ++lt)

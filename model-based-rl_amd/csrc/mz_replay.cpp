@@ -477,9 +477,6 @@ int mzr_ingest_records_from(mz_replay *r, const float *records, int n_moves, int
   if (r->c.episode_life)
     return fail("mzr_ingest_records: this replay is configured with episode_life (terminal != done, game.py:90): records "
                 "carry one end-of-game flag; feed such histories through mzr_save_history");
-  if (r->c.two_players)
-    return fail("mzr_ingest_records: this replay is configured with two_players: device records carry no to_play yet "
-                "(targets flip signs by it, replay_buffer.py:187-189); feed such histories through mzr_save_history");
   if ((int)r->envs.size() < env_base + B) r->envs.resize((size_t)env_base + B);
   // contiguous environment ranges per thread: concatenated in thread order the slices are in environment order, and a
   // stable sort by move restores (move, env) -- the arrival order of a move-major walk, the order the reference's one

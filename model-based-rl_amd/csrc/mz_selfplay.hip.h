@@ -24,6 +24,14 @@ struct SelfplayState {
   double *root_value, *error;   // [B]
   unsigned long long *movecnt;   // [B] moves completed by env b (all equal; per-env so that every thread reads and
                                  // advances only its own counter): keys the RNG and the ring slot
+  // ---- a real game as the environment (mz_selfplay_set_env): TicTacToe, custom_environments/tic_tac_toe.py:5-76
+  int env_kind;          // 0 = synthetic fixed-length episodes (above), 1 = TicTacToe (two players, 9 cells, 9 actions)
+  int8_t *board;         // [B][9] env.board: 0 empty, +1 / -1 the two players' marks
+  int8_t *turn;          // [B] env.turn == game.to_play: +1 or -1, the player about to move
+  uint8_t *legal;        // [B][A] legal_actions() of the current position as a mask (actors.py:141)
+  int8_t *to_play;       // [B] game.to_play of the current move (root.expand's to_play, actors.py:142)
+  const double *draw_uniform;   // [B] or null: the uniform select_action consumes, given by the host (parity runs,
+                                // mz_selfplay_set_draws); null = the device RNG keyed (seed, env, move)
   float *ring;           // [ring_moves][B][rec_floats]
   float *host_ring;      // pinned staging for drains (optional)
   unsigned long long moves_host, drained;
@@ -85,7 +93,8 @@ static __global__ void k_dirichlet(TreeView t, const uint8_t *legal, double alph
 
 // Experience record of one move: obs[O], child_visits[A] (float32), root_value and error as float64 (two float
 // slots each: the reference keeps both as Python floats, actors.py:147-148, game.py:112), reward (float32), then int32
-// bit patterns: action, done, step (pre-step), env_id, episode.
+// bit patterns: action, flags (bit 0 done, bit 1 to_play == -1: game.py:100-101 appends the mover), step (pre-step),
+// env_id, episode.
 #ifndef MZ_REC_EXTRA
 #define MZ_REC_EXTRA 10     // (include/mz_engine.h)
 #endif
@@ -121,3 +130,54 @@ static __global__ void k_env_step_record(TreeView tv, SelfplayState sp, int B, i
   }
 }
 
+
+// ---- TicTacToe on the device (custom_environments/tic_tac_toe.py:5-76; the reference's only two-player environment)
+// What Actor.play_game reads before a move (actors.py:134-142): observation = turn * board as float32
+// (tic_tac_toe.py:24,50 + actors.py:134), the legal actions (tic_tac_toe.py:27-28) and game.to_play.
+static __global__ void k_ttt_observe(SelfplayState sp, int B, int A) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int turn = sp.turn[b];
+  for (int k = 0; k < 9; ++k) {
+    const int c = sp.board[(size_t)b * 9 + k];
+    sp.obs[(size_t)b * 9 + k] = (float)(turn * c);
+    sp.legal[(size_t)b * A + k] = c == 0 ? 1 : 0;
+  }
+  sp.to_play[b] = (int8_t)turn;
+}
+
+// End of a move: Config.select_action + store_search_statistics + root error (mz_finalize_tree), then Game.apply
+// (game.py:79-104) on env.step (tic_tac_toe.py:30-51): the mover's mark goes on the board; the move wins if a line
+// through it sums to +-3 (reward 1 for the mover), the game is done on a win or after the ninth move; the turn flips.
+// The record carries the mover in its flags word (to_play), as History.to_play does.
+static __global__ void k_ttt_step_record(TreeView tv, SelfplayState sp, int B, int A, uint64_t seed) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const unsigned long long move = sp.movecnt[b];
+  sp.movecnt[b] = move + 1ull;
+  mz_finalize_tree(tv, b, sp.temp, sp.draw_uniform, seed, move, sp.env_offset, sp.action, sp.child_visits, sp.root_value,
+                   sp.error, nullptr);
+  const int O = 9;
+  float *rec = sp.ring + ((size_t)(move % (unsigned long long)sp.ring_moves) * B + b) * sp.rec_floats;
+  for (int k = 0; k < O; ++k) rec[k] = sp.obs[(size_t)b * O + k];
+  for (int a = 0; a < A; ++a) rec[O + a] = (float)sp.child_visits[(size_t)b * A + a];
+  const int action = sp.action[b], turn = sp.turn[b], t = sp.t[b], ep = sp.episode[b];
+  int8_t *bd = sp.board + (size_t)b * 9;
+  bd[action] = (int8_t)turn;
+  const int r0 = 3 * (action / 3), c0 = action % 3;
+  bool won = (bd[r0] + bd[r0 + 1] + bd[r0 + 2] == 3 * turn) || (bd[c0] + bd[c0 + 3] + bd[c0 + 6] == 3 * turn);
+  if (action % 4 == 0) won = won || (bd[0] + bd[4] + bd[8] == 3 * turn);
+  if (action == 2 || action == 4 || action == 6) won = won || (bd[2] + bd[4] + bd[6] == 3 * turn);
+  const int done = (won || t == 8) ? 1 : 0;           // tic_tac_toe.py:37 (elapsed steps before this move)
+  mz_rec_put_double(rec + O + A + 0, sp.root_value[b]);
+  mz_rec_put_double(rec + O + A + 2, sp.error[b]);
+  rec[O + A + 4] = won ? 1.f : 0.f;
+  int32_t *ri = (int32_t *)(rec + O + A + 5);
+  ri[0] = action; ri[1] = done | (turn < 0 ? 2 : 0); ri[2] = t; ri[3] = sp.env_offset + b; ri[4] = ep;
+  if (done) {      // run_selfplay starts a new Game: env.reset (tic_tac_toe.py:20-25), its temperature evaluated now
+    for (int k = 0; k < 9; ++k) bd[k] = 0;
+    sp.turn[b] = 1; sp.t[b] = 0; sp.episode[b] = ep + 1; sp.temp[b] = *sp.temp_next;
+  } else {
+    sp.turn[b] = (int8_t)(-turn); sp.t[b] = t + 1;
+  }
+}

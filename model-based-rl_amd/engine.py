@@ -46,11 +46,12 @@ def records_view(rec, O, A, obs_u8=False):
   OS = (O + 3) // 4 if obs_u8 else O
   assert rec.dtype == np.float32 and rec.shape[-1] == OS + A + REC_EXTRA, (rec.dtype, rec.shape)
   ints = rec[..., OS + A + 5:].view(np.int32)
+  flags = ints[..., 1]                   # bit 0 done, bit 1 the mover was player -1 (History.to_play, game.py:100-101)
   obs = np.ascontiguousarray(rec[..., :OS]).view(np.uint8)[..., :O] if obs_u8 else rec[..., :O]
   return dict(obs=obs, child_visits=rec[..., OS:OS + A],
               root_value=np.ascontiguousarray(rec[..., OS + A:OS + A + 2]).view(np.float64)[..., 0],
               error=np.ascontiguousarray(rec[..., OS + A + 2:OS + A + 4]).view(np.float64)[..., 0],
-              reward=rec[..., OS + A + 4], action=ints[..., 0], done=ints[..., 1], step=ints[..., 2],
+              reward=rec[..., OS + A + 4], action=ints[..., 0], done=flags & 1, to_play=1 - (flags & 2), step=ints[..., 2],
               env_id=ints[..., 3], episode=ints[..., 4])
 
 
@@ -312,6 +313,17 @@ class Engine(object):
       rg = np.ascontiguousarray(np.broadcast_to(np.asarray(obs_range, np.float32).reshape(-1), (self.O,)))
     p = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
     _abi.check(self.lib.mz_selfplay_set_obs(self._h, int(bool(uint8_obs)), p(mn), p(rg)), 'mz_selfplay_set_obs')
+
+  ENVS = {'synthetic': 0, 'tictactoe': 1}
+
+  def selfplay_set_env(self, kind):
+    """'synthetic' (default) or 'tictactoe' (the reference's custom_environments/tic_tac_toe.py on the device); before selfplay_reset"""
+    _abi.check(self.lib.mz_selfplay_set_env(self._h, self.ENVS[kind] if isinstance(kind, str) else int(kind)), 'mz_selfplay_set_env')
+
+  def selfplay_set_draws(self, noise=None, uniform=None):
+    """parity runs of a game environment: the next moves use these Dirichlet draws [B, A] / select_action uniforms [B]"""
+    noise = self._dev(noise, torch.float64); uniform = self._dev(uniform, torch.float64)
+    _abi.check(self.lib.mz_selfplay_set_draws(self._h, _ptr(noise), _ptr(uniform), self.stream), 'mz_selfplay_set_draws')
 
   def selfplay_export_trees(self, keep=True):
     _abi.check(self.lib.mz_selfplay_export_trees(self._h, int(bool(keep))), 'mz_selfplay_export_trees')

@@ -192,22 +192,63 @@ def test_parallel_ingest_is_bit_identical_to_one_thread(T, mhl, window):
 
 
 def test_ingest_records_refuses_what_records_cannot_express():
-  """Device records carry one end-of-game flag and no to_play: a replay configured with --two_players or --episode_life
-  (terminal != done, game.py:90; sign-flipped targets, replay_buffer.py:187-189) must refuse them loudly instead of
-  building wrong targets; save_history, which takes to_play and `terminal` explicitly, still works."""
+  """Device records carry ONE end-of-game flag: a replay configured with --episode_life (terminal != done, game.py:90)
+  must refuse them loudly instead of miscounting games; save_history, which takes `terminal` explicitly, still works.
+  (--two_players records are fine: the flags word carries the mover, see the next test.)"""
   from model_based_rl_amd.replay_buffer import PrioritizedReplay
   O, A, B = 3, 2, 4
   rec = _bulk_records(np.random.RandomState(1), 8, B, O, A, 5)
-  for flag in ('two_players', 'episode_life'):
-    rep = PrioritizedReplay(make_cfg(obs_space=(O,), action_space=A, window_size=256, **{flag: True}))
-    with pytest.raises(RuntimeError, match=flag):
-      rep.ingest_records(rec, 8, B)
-    assert rep.size() == 0 and rep.get_throughput() == {'frames': 0, 'games': 0}
-    h = types.SimpleNamespace(observations=np.zeros((4, O), np.float32), child_visits=np.full((3, A), 0.5, np.float32),
-                              root_values=[0.1, 0.2, 0.3], actions=[0, 1, 0], rewards=[1.0, 0.0, -1.0],
-                              errors=[0.5, 0.25, 0.125], dones=[0, 0, 1], to_play=[1, -1, 1])
-    rep.save_history(h, ignore=None, terminal=True)
-    assert rep.size() == 3 and rep.get_throughput() == {'frames': 3, 'games': 1}
+  rep = PrioritizedReplay(make_cfg(obs_space=(O,), action_space=A, window_size=256, episode_life=True))
+  with pytest.raises(RuntimeError, match='episode_life'):
+    rep.ingest_records(rec, 8, B)
+  assert rep.size() == 0 and rep.get_throughput() == {'frames': 0, 'games': 0}
+  h = types.SimpleNamespace(observations=np.zeros((4, O), np.float32), child_visits=np.full((3, A), 0.5, np.float32),
+                            root_values=[0.1, 0.2, 0.3], actions=[0, 1, 0], rewards=[1.0, 0.0, -1.0],
+                            errors=[0.5, 0.25, 0.125], dones=[0, 0, 1], to_play=[1, -1, 1])
+  rep.save_history(h, ignore=None, terminal=True)
+  assert rep.size() == 3 and rep.get_throughput() == {'frames': 3, 'games': 1}
   ok = PrioritizedReplay(make_cfg(obs_space=(O,), action_space=A, window_size=256))
   ok.ingest_records(rec, 8, B)
   assert ok.get_throughput()['frames'] > 0
+
+
+def test_records_with_to_play_equal_save_history():
+  """Two-player records: the mover travels in bit 1 of the flags word.  One game ingested as device records must leave
+  the replay in the state save_history leaves it in for the same game as a HistorySlice with to_play = +-1 -- same
+  leaves, and the same sampled targets incl. the sign flips of replay_buffer.py:187-189."""
+  import random
+  from model_based_rl_amd.replay_buffer import PrioritizedReplay
+  O, A, n = 9, 9, 7
+  rng = np.random.RandomState(3)
+  obs = rng.randint(-1, 2, (n, O)).astype(np.float32)
+  cv = rng.dirichlet([1.0] * A, n).astype(np.float32)
+  rootv, err = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+  rew = np.zeros(n, np.float32); rew[-1] = 1.0; rew[2] = 0.5       # (a mid-game reward makes the flips visible)
+  act = rng.randint(0, A, n).astype(np.int32)
+  tp = np.array([1, -1, 1, -1, 1, -1, 1], np.int8)
+  rec = np.zeros((n, 1, O + A + 10), np.float32)
+  rec[:, 0, :O] = obs; rec[:, 0, O:O + A] = cv
+  rec[:, 0, O + A:O + A + 2] = rootv[:, None].view(np.float32); rec[:, 0, O + A + 2:O + A + 4] = err[:, None].view(np.float32)
+  rec[:, 0, O + A + 4] = rew
+  ints = rec[..., O + A + 5:].view(np.int32)
+  ints[:, 0, 0] = act; ints[:, 0, 1] = (np.arange(n) == n - 1) | ((tp < 0) << 1); ints[:, 0, 2] = np.arange(n)
+  out = []
+  for via_records in (True, False):
+    rep = PrioritizedReplay(make_cfg(window_size=64, two_players=True, batch_size=8, td_steps=3, seed=None))
+    if via_records:
+      rep.ingest_records(rec, n, 1)
+    else:
+      h = types.SimpleNamespace(observations=obs, child_visits=cv, root_values=rootv, actions=act, rewards=rew, errors=err,
+                                dones=(np.arange(n) == n - 1), to_play=tp)
+      rep.save_history(h, ignore=None, terminal=True)
+    random.seed(1); np.random.seed(2)
+    (bobs, bact, (t_rew, t_val, t_pol)), idxs, isw = rep.sample_batch()
+    out.append((rep.tree.leaves(), bobs, np.asarray(bact), t_rew, t_val, t_pol, np.asarray(idxs), isw, rep.get_throughput()))
+  for a, b in zip(*out):
+    assert np.array_equal(np.asarray(a), np.asarray(b)) if not isinstance(a, dict) else a == b
+  # and the flips are real: with every to_play = +1 the value targets differ
+  rec1 = rec.copy(); rec1[..., O + A + 5:].view(np.int32)[:, 0, 1] &= 1
+  rep = PrioritizedReplay(make_cfg(window_size=64, two_players=True, batch_size=8, td_steps=3, seed=None))
+  rep.ingest_records(rec1, n, 1)
+  random.seed(1); np.random.seed(2)
+  assert not np.array_equal(rep.sample_batch()[0][2][1], out[0][4])
