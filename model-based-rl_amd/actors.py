@@ -57,8 +57,10 @@ class Actor(Logger):
       raise RuntimeError('GPU was requested but torch.cuda.is_available() is False.')   # actors.py:41
     ids = getattr(config, 'actors_gpu_device_ids', None)
     self.device = torch.device('cuda', ids[actor_key] if ids else torch.cuda.current_device())
-    self.host_env = config.environment == 'TicTacToe'
     self.num_envs = int(getattr(config, 'num_envs', 1))
+    # TicTacToe: the reference's environment object on the host for parity runs (numpy's global stream) and single games;
+    # a pool of games runs the same rules on the device (mz_selfplay_set_env, csrc/mz_selfplay.hip.h)
+    self.host_env = config.environment == 'TicTacToe' and (bool(getattr(config, 'parity_rng', False)) or self.num_envs == 1)
     # FCNetwork: the engine's own fused HIP kernels.  Any other architecture (MuZeroNetwork / TinyNetwork): the torch
     # network stays in the loop behind the batched external-inference path (actors.py:45-47 is network-agnostic)
     self.torch_net = getattr(config, 'architecture', 'FCNetwork') != 'FCNetwork'
@@ -237,13 +239,14 @@ class Actor(Logger):
       eng.selfplay_set_obs(uint8_obs='-ram' in str(cfg.environment), obs_min=self.obs_min if norm else None,
                            obs_range=self.obs_range if norm else None)
     temperature = self._temperature()
+    if cfg.environment == 'TicTacToe':
+      eng.selfplay_set_env('tictactoe')
     eng.selfplay_reset(cfg.episode_length, temperature, stagger=True)
     pinned = [torch.empty(chunk, eng.B, eng.rec_floats, dtype=torch.float32).pin_memory() for _ in range(2)]
     events = [torch.cuda.Event(), torch.cuda.Event()]
     copy_stream = torch.cuda.Stream(self.device)        # D2H of chunk i overlaps the moves of chunk i+1
     pending, k = None, 0
     sync_every = max(1, cfg.weight_sync_frequency)      # experiences per environment between weight pulls
-    done_col = eng.O + eng.A + 6                        # int32 `done` slot of a record (include/mz_engine.h)
 
     def hand_over(p):
       buf, n, ev = p

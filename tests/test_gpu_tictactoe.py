@@ -116,3 +116,30 @@ def test_device_tictactoe_rules_at_4096_envs():
     turn = np.where(done, 1, -turn); t = np.where(done, 0, t + 1)
   assert wins > B and draws > 0                  # ~2.7 games per environment, both endings occur
   assert np.array_equal(rv['episode'][-1], np.cumsum(rv['done'], 0)[-1] - rv['done'][-1])
+
+
+def test_actor_plays_tictactoe_on_the_device_and_feeds_the_replay():
+  """Actor with --environment TicTacToe and a pool of environments: the games run on the device, the records (with the
+  mover) reach the two-player replay, games are counted, and a sampled batch carries sign-flipped n-step targets."""
+  import torch
+  from oracle import oracle as orc
+  from model_based_rl_amd.actors import Actor
+  from model_based_rl_amd.config import make_config
+  from model_based_rl_amd.replay_buffer import PrioritizedReplay
+  from model_based_rl_amd.shared_storage import SharedStorage
+  g = np.load(os.path.join(G, 'g1_net_ttt.npz'))
+  cfg = make_config(['--environment', 'TicTacToe', '--two_players', '--known_bounds', '-1', '1', '--discount', '1',
+                     '--num_simulations', '30', '--seed', '4', '--num_envs', '256', '--window_size', '16384',
+                     '--weight_sync_frequency', '8', '--batch_size', '64', '--td_steps', '3'])
+  storage, replay = SharedStorage(cfg), PrioritizedReplay(cfg)
+  storage.store_weights({k: torch.from_numpy(v) for k, v in orc.load_weights(g).items()}, 0)
+  actor = Actor(0, cfg, storage, replay)
+  assert not actor.host_env
+  actor.launch(max_moves=32)
+  thr = replay.get_throughput()
+  assert actor.games_played == thr['games'] and thr['games'] >= 256 * 3 and thr['frames'] >= 256 * 20
+  (obs, actions, (t_rew, t_val, t_pol)), idxs, isw = replay.sample_batch()
+  assert obs.shape == (64, 9) and set(np.unique(obs)) <= {-1.0, 0.0, 1.0}
+  assert set(np.unique(t_rew)) <= {0.0, 1.0} and (t_rew == 1).any()
+  assert (t_val < 0).any() and (t_val > 0).any()          # a win two plies ahead is a loss for the player to move (replay_buffer.py:187-189)
+  actor.engine.close()
