@@ -90,6 +90,8 @@ def main(args):
   finally:
     torch.cuda.set_sync_debug_mode('default')
   torch.cuda.synchronize(device)
+  pinned[0][0].copy_(dev[0])               # that move advanced the environments: its records belong to their histories too
+  replay.ingest_records(pinned[0], 1, B)
   frames0 = replay.get_throughput()['frames']
   t0 = time.perf_counter()
   run(steps)

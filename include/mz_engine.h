@@ -64,7 +64,13 @@ typedef struct mz_config {
                                  * float16 parts and every product block is three v_mfma_f32_16x16x32_f16 with float32
                                  * accumulation (csrc/mz_fused_h2.hip.h): float32-level accuracy (deviation from a float64
                                  * evaluation 1-2x that of the exact path, inside the 1e-5 bound), NOT bit-identical to the
-                                 * exact path.  The environment variable MZ_SPLIT_F16=1 sets it for every engine. */
+                                 * exact path.  The environment variable MZ_SPLIT_F16=1 sets it for every engine.
+                                 * Range: the high part of a split value is its float16 rounding, so mz_set_weights FAILS for
+                                 * weights that are not finite or exceed 65504 in magnitude; weights below 6.1e-5 in magnitude
+                                 * are carried with an absolute error of ~3e-8 (float16 subnormals) instead of a relative one --
+                                 * far inside the 1e-5 bound on outputs.  Activations are split at run time the same way: hidden
+                                 * states are min-max free here (ReLU(LayerNorm), |x| < ~10), head pre-activations are sums of
+                                 * 512 products of such values and PyTorch-initialised weights. */
 } mz_config;
 
 const char *mz_last_error(void);

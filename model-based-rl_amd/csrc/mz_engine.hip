@@ -98,6 +98,7 @@ struct mz_engine {
   size_t n_packed_h2 = 0;
   float *obs_norm = nullptr;        // [2][O] --norm_obs minimum and range (device)
   double *noise_log = nullptr;      // [ring_moves][B][A] per-move Dirichlet draws (mz_selfplay_noise_log), allocated on first use
+  unsigned *absmax_dev = nullptr;   // scratch of the split_f16 weight-range check (mz_set_weights)
   double *draw_uniform = nullptr;   // [B] host-given uniforms of a game environment's parity run (mz_selfplay_set_draws)
   bool draws_noise = false, draws_set = false;
   std::vector<float> obs_norm_host;
@@ -241,6 +242,16 @@ __global__ void k_pack_weights_h2(const float *flat, const int32_t *idx, _Float1
   if (s >= 0) v = flat[s & 0x3fffffff];
   const _Float16 h = (_Float16)v;                                  // round to nearest
   packed[i] = (s >= 0 && (s & 0x40000000)) ? (_Float16)(v - (float)h) : h;
+}
+
+// max |w| over the flat weights, or +inf if any is not finite (bit pattern compare: non-negative floats order like uints)
+__global__ void k_absmax(const float *w, size_t n, unsigned *out) {
+  unsigned m = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const unsigned u = __float_as_uint(w[i]) & 0x7fffffffu;
+    m = u > m ? u : m;
+  }
+  atomicMax(out, m);
 }
 
 static int build_packing_h2(mz_engine *e, const FlatLayout &L, int Sv, int Sr) {
@@ -887,6 +898,21 @@ int mz_set_weights(mz_engine *e, const float *flat, size_t n, int on_device, voi
   }
   const int threads = 256;
   const unsigned blocks = (unsigned)((e->n_packed + threads - 1) / threads);
+  if (e->split_f16) {
+    // the high part of a split weight is its float16 rounding: beyond the float16 range it would be inf and poison every
+    // search silently.  Checked here, loudly (one small reduction + a 4-byte read back; split_f16 is opt-in).
+    if (!e->absmax_dev && dmalloc(e, &e->absmax_dev, (size_t)1)) return -1;
+    HIPCHECK(hipMemsetAsync(e->absmax_dev, 0, 4, s));
+    hipLaunchKernelGGL(k_absmax, dim3(64), dim3(256), 0, s, src, n, e->absmax_dev);
+    unsigned bits = 0;
+    HIPCHECK(hipMemcpyAsync(&bits, e->absmax_dev, 4, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    float mx;
+    memcpy(&mx, &bits, 4);
+    if (!(mx <= 65504.f))
+      return fail("mz_set_weights: split_f16 needs every weight finite and |w| <= 65504 (the float16 range of the high part); "
+                  "max |w| = %g.  Use the exact-float32 kernel (split_f16 = 0) for these weights", (double)mx);
+  }
   hipLaunchKernelGGL(k_pack_weights, dim3(blocks), dim3(threads), 0, s, src, e->pack_idx, e->packed, e->n_packed);
   if (e->split_f16)
     hipLaunchKernelGGL(k_pack_weights_h2, dim3((unsigned)((e->n_packed_h2 + threads - 1) / threads)), dim3(threads), 0, s, src,

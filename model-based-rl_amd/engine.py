@@ -147,8 +147,7 @@ class Engine(object):
     on_dev = weights.is_cuda
     w = weights.to(torch.float32).contiguous()
     _abi.check(self.lib.mz_set_weights(self._h, _ptr(w), w.numel(), int(on_dev), self.stream), 'mz_set_weights')
-    if on_dev:
-      self._keep.append(w)
+    self._weights_dev = w if on_dev else None      # (the one device buffer of the last pull stays alive; nothing accumulates)
 
   # ---- network
   def initial_inference(self, obs):

@@ -253,7 +253,7 @@ class Learner(Logger):
           self.losses_to_log[k] = 0
         self.log_throughput()
         if self.lr_scheduler is not None:
-          self.log_scalar(tag='loss/learning_rate', value=self.lr_scheduler.lr, i=self.training_step)
+          self.log_scalar(tag='loss/learning_rate', value=self.optimizer.param_groups[0]['lr'], i=self.training_step)      # (what the optimizer really uses, every scheduler)
     self.log_throughput(force=True)
     self.send_weights()
 

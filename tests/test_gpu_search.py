@@ -273,3 +273,25 @@ def test_split_f16_network_error_and_config():
   assert not np.array_equal(hid[False], hid[True]) and np.abs(hid[False] - hid[True]).max() <= 1e-5
   with pytest.raises(RuntimeError, match='split_f16 supports action_space'):
     Engine(16, 8, 18, 4, split_f16=True)
+
+
+def test_split_f16_refuses_weights_outside_the_float16_range():
+  """The high part of a split weight is its float16 rounding: a weight beyond 65504 (or a NaN) would turn into inf and
+  poison every search silently -- mz_set_weights must fail loudly instead; the exact-float32 engine takes the same weights."""
+  from model_based_rl_amd.engine import Engine
+  from oracle import oracle as orc
+  w = orc.load_weights(np.load(os.path.join(G, 'g1_net_lunar.npz')))
+  bad = {k: v.copy() for k, v in w.items()}
+  bad['value_head.fc1.weight'][3, 7] = 1e5
+  split = Engine(32, 8, 4, 8, split_f16=True)
+  split.set_weights(w)
+  with pytest.raises(RuntimeError, match='65504'):
+    split.set_weights(bad)
+  bad['value_head.fc1.weight'][3, 7] = np.nan
+  with pytest.raises(RuntimeError, match='65504'):
+    split.set_weights(bad)
+  split.close()
+  exact = Engine(32, 8, 4, 8)
+  bad['value_head.fc1.weight'][3, 7] = 1e5
+  exact.set_weights(bad)
+  exact.close()
