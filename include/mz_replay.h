@@ -84,7 +84,10 @@ int mzr_save_history(mz_replay *r, int64_t n, const double *errors, int64_t igno
  * Threads: the environments of a call are split into contiguous ranges over mzr_config.ingest_threads threads (history
  * assembly and priorities are per environment, actors.py:160-173); the finished slices enter the one sum tree on the
  * calling thread in (move, environment) order -- leaves, sums, counters and sample batches are bit-identical for every
- * thread count (replay_buffer.py:19-40 adds in arrival order).
+ * thread count (replay_buffer.py:19-40 adds in arrival order).  With more than one ingest thread that insertion is
+ * DEFERRED to the handle's inserter thread (jobs in call order): a call returns once its records are copied into the
+ * environments' histories -- the record buffer may be reused -- and the next chunk's assembly overlaps this chunk's
+ * insertion; every other entry point first waits for the pending insertions, so nothing observable changes.
  * mzr_ingest_records_from: the B environments of this call are the replay's environments env_base .. env_base+B-1
  * (one replay fed by several actor ranks: rank r passes env_base = r * B; actors.py:169 -- every reference actor
  * sends to the ONE replay buffer, train.py:71-72). */

@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <condition_variable>
+#include <deque>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -67,6 +68,12 @@ struct Scratch {                // per ingest thread
   std::vector<Pending> pend;
   std::vector<double> pris;
   std::vector<size_t> pri_off;  // pris may reallocate while a thread works: offsets first, pointers after
+};
+
+// the slices of one ingest call in (move, env) order, with the priority buffers their Pending::pri point into
+struct Job {
+  std::vector<Pending> items;
+  std::vector<std::vector<double>> pris;
 };
 
 // A fixed set of worker threads that run one job(tid) per call of run(); the caller is thread 0.
@@ -142,9 +149,77 @@ struct mz_replay {
   // scratch
   std::vector<double> pri, chg;
   std::vector<Scratch> scratch;
-  std::vector<Pending> merged;
   Pool pool;
+  // Deferred insertion (handles with more than one ingest thread): the sum-tree insertion of a call's slices -- the serial
+  // part, replay_buffer.py:19-40 in arrival order -- runs on an inserter thread while the caller already assembles the next
+  // chunk; jobs are inserted in call order, every other entry point waits for the queue to drain first, so the handle
+  // behaves exactly as with immediate insertion.
+  std::thread inserter;
+  std::mutex qmu;
+  std::condition_variable qcv, idle_cv;
+  std::deque<Job> queue;
+  std::vector<std::vector<double>> spare;      // recycled priority buffers
+  bool inserting = false, qquit = false;
 };
+
+static void tree_add(mz_replay *r, const double *priorities, int64_t n, Hist *h, int64_t *positions_out);
+
+static void insert_job(mz_replay *r, Job &job) {
+  for (const Pending &p : job.items) {
+    tree_add(r, p.pri, p.keep, p.h, nullptr);
+    if (p.h->refs == 0) delete p.h;
+    r->frames += p.keep;
+    if (p.done) r->games += 1;
+  }
+}
+
+static void inserter_loop(mz_replay *r) {
+  for (;;) {
+    Job job;
+    {
+      std::unique_lock<std::mutex> lk(r->qmu);
+      r->qcv.wait(lk, [&] { return r->qquit || !r->queue.empty(); });
+      if (r->queue.empty()) return;            // quit with nothing left to insert
+      job = std::move(r->queue.front());
+      r->queue.pop_front();
+      r->inserting = true;
+    }
+    insert_job(r, job);
+    {
+      std::lock_guard<std::mutex> lk(r->qmu);
+      for (auto &v : job.pris) { v.clear(); if (r->spare.size() < 64) r->spare.push_back(std::move(v)); }
+      r->inserting = false;
+      if (r->queue.empty()) r->idle_cv.notify_all();
+    }
+  }
+}
+
+// every entry point but the bulk ingest: wait until all deferred insertions have happened
+static void drain(const mz_replay *cr) {
+  mz_replay *r = const_cast<mz_replay *>(cr);
+  if (!r->inserter.joinable()) return;
+  std::unique_lock<std::mutex> lk(r->qmu);
+  r->idle_cv.wait(lk, [&] { return r->queue.empty() && !r->inserting; });
+}
+
+static void stop_inserter(mz_replay *r) {
+  if (!r->inserter.joinable()) return;
+  drain(r);
+  {
+    std::lock_guard<std::mutex> lk(r->qmu);
+    r->qquit = true;
+  }
+  r->qcv.notify_all();
+  r->inserter.join();
+  r->qquit = false;
+}
+
+static void start_threads(mz_replay *r, int threads) {
+  stop_inserter(r);
+  r->pool.start(threads);
+  r->scratch.resize((size_t)r->pool.T);
+  if (r->pool.T > 1) r->inserter = std::thread(inserter_loop, r);
+}
 
 // SumTree.update, replay_buffer.py:34-40
 static inline void tree_update(mz_replay *r, int64_t idx, double priority) {
@@ -310,14 +385,14 @@ int mzr_create(const mzr_config *cfg, mz_replay **out) {
   r->tree.assign((size_t)(2 * cfg->window_size - 1), 0.0);
   r->leaf_hist.assign((size_t)cfg->window_size, nullptr);
   r->leaf_step.assign((size_t)cfg->window_size, 0);
-  r->pool.start(cfg->ingest_threads > 1 ? cfg->ingest_threads : 1);
-  r->scratch.resize((size_t)r->pool.T);
+  start_threads(r, cfg->ingest_threads > 1 ? cfg->ingest_threads : 1);
   *out = r;
   return 0;
 }
 
 int mzr_destroy(mz_replay *r) {
   if (r) {
+    stop_inserter(r);
     r->pool.stop();
     for (int64_t i = 0; i < (int64_t)r->leaf_hist.size();) {
       Hist *h = r->leaf_hist[(size_t)i];
@@ -334,8 +409,7 @@ int mzr_destroy(mz_replay *r) {
 int mzr_set_ingest_threads(mz_replay *r, int threads) {
   if (!r) return fail("mzr_set_ingest_threads: null");
   if (threads < 1 || threads > 64) return fail("mzr_set_ingest_threads: threads must be in [1, 64]");
-  r->pool.start(threads);
-  r->scratch.resize((size_t)r->pool.T);
+  start_threads(r, threads);
   return 0;
 }
 int mzr_ingest_threads(const mz_replay *r) { return r ? r->pool.T : -1; }
@@ -348,12 +422,14 @@ int mzr_priorities(const mz_replay *r, const double *errors, int64_t n, double *
 
 int mzr_tree_add(mz_replay *r, const double *priorities, int64_t n, int64_t *positions_out) {
   if (!r || !priorities) return fail("mzr_tree_add: null argument");
+  drain(r);
   tree_add(r, priorities, n, nullptr, positions_out);
   return 0;
 }
 
 int mzr_tree_update(mz_replay *r, const int64_t *idxs, const double *priorities, int64_t n) {
   if (!r || !idxs || !priorities) return fail("mzr_tree_update: null argument");
+  drain(r);
   const int64_t len = 2 * r->max_capacity - 1;
   for (int64_t i = 0; i < n; ++i) {
     if (idxs[i] < 0 || idxs[i] >= len) return fail("mzr_tree_update: index %lld out of range", (long long)idxs[i]);
@@ -363,7 +439,12 @@ int mzr_tree_update(mz_replay *r, const int64_t *idxs, const double *priorities,
 }
 
 // SumTree.get_leaf, replay_buffer.py:42-62 (returns the tree index of the leaf)
+static int64_t get_leaf(const mz_replay *r, double value);
 int64_t mzr_tree_get_leaf(const mz_replay *r, double value) {
+  drain(r);
+  return get_leaf(r, value);
+}
+static int64_t get_leaf(const mz_replay *r, double value) {
   const int64_t len = 2 * r->max_capacity - 1;
   const double *t = r->tree.data();
   int64_t parent = 0;
@@ -375,10 +456,11 @@ int64_t mzr_tree_get_leaf(const mz_replay *r, double value) {
   }
 }
 
-double mzr_total_priority(const mz_replay *r) { return r->tree[0]; }
-int64_t mzr_size(const mz_replay *r) { return r->num_memories; }
+double mzr_total_priority(const mz_replay *r) { drain(r); return r->tree[0]; }
+int64_t mzr_size(const mz_replay *r) { drain(r); return r->num_memories; }
 int mzr_tree_leaves(const mz_replay *r, int64_t n, double *out) {
   if (!r || !out || n > r->max_capacity) return fail("mzr_tree_leaves: bad argument");
+  drain(r);
   memcpy(out, r->tree.data() + r->max_capacity - 1, (size_t)n * sizeof(double));
   return 0;
 }
@@ -387,6 +469,7 @@ int mzr_save_history(mz_replay *r, int64_t n, const double *errors, int64_t igno
                      const float *child_visits, const double *root_values, const float *rewards,
                      const int32_t *actions, const uint8_t *dones, const int8_t *to_play) {
   if (!r || (n > 0 && !errors)) return fail("mzr_save_history: null argument");
+  drain(r);
   return save_history(r, n, errors, ignore, terminal, obs, child_visits, root_values, rewards, actions, dones, to_play);
 }
 
@@ -491,16 +574,28 @@ int mzr_ingest_records_from(mz_replay *r, const float *records, int n_moves, int
       ingest_range(r, r->scratch[(size_t)tid], records, n_moves, B, env_base, lo, hi);
     });
   }
-  std::vector<Pending> &all = r->merged;
-  all.clear();
-  for (int t = 0; t < (T < 1 ? 1 : T); ++t) all.insert(all.end(), r->scratch[(size_t)t].pend.begin(), r->scratch[(size_t)t].pend.end());
-  std::stable_sort(all.begin(), all.end(), [](const Pending &x, const Pending &y) { return x.m < y.m; });   // b already ascending
-  for (const Pending &p : all) {
-    tree_add(r, p.pri, p.keep, p.h, nullptr);
-    if (p.h->refs == 0) delete p.h;
-    r->frames += p.keep;
-    if (p.done) r->games += 1;
+  Job job;
+  for (int t = 0; t < (T < 1 ? 1 : T); ++t) {
+    Scratch &sc = r->scratch[(size_t)t];
+    job.items.insert(job.items.end(), sc.pend.begin(), sc.pend.end());
+    job.pris.push_back(std::move(sc.pris));     // the Pending::pri pointers stay valid: the buffer moves, its storage does not
+    sc.pris = std::vector<double>();
   }
+  std::stable_sort(job.items.begin(), job.items.end(), [](const Pending &x, const Pending &y) { return x.m < y.m; });   // b already ascending
+  if (!r->inserter.joinable()) {
+    insert_job(r, job);
+    for (int t = 0; t < (int)job.pris.size(); ++t) { job.pris[(size_t)t].clear(); r->scratch[(size_t)t].pris = std::move(job.pris[(size_t)t]); }
+    return 0;
+  }
+  {
+    std::lock_guard<std::mutex> lk(r->qmu);
+    for (int t = 0; t < (T < 1 ? 1 : T) && !r->spare.empty(); ++t) {      // hand the ingest threads recycled buffers
+      r->scratch[(size_t)t].pris = std::move(r->spare.back());
+      r->spare.pop_back();
+    }
+    r->queue.push_back(std::move(job));
+  }
+  r->qcv.notify_one();
   return 0;
 }
 
@@ -509,6 +604,7 @@ int mzr_sample_batch(const mz_replay *r, const double *draws, int bs, float *obs
                      double *priorities) {
   if (!r || !draws || !obs || !actions || !target_rewards || !target_values || !target_policies || !idxs || !priorities)
     return fail("mzr_sample_batch: null argument");
+  drain(r);
   const int O = r->c.obs_dim, OS = r->OS, A = r->c.action_space, K = r->c.num_unroll_steps, td = r->c.td_steps, R = r->R;
   const int TL = K + 1;
   // replay_buffer.py:81-82: discounts as float32, discount**td as a Python float
@@ -517,7 +613,7 @@ int mzr_sample_batch(const mz_replay *r, const double *draws, int bs, float *obs
   for (int n = 0; n < K + td; ++n) disc[n] = (float)pow(r->c.discount, (double)n);
   const double disc_td = pow(r->c.discount, (double)td);
   for (int i = 0; i < bs; ++i) {
-    const int64_t idx = mzr_tree_get_leaf(r, draws[i]);                       // replay_buffer.py:142
+    const int64_t idx = get_leaf(r, draws[i]);                       // replay_buffer.py:142
     const int64_t pos = idx - r->max_capacity + 1;
     const Hist *h = r->leaf_hist[(size_t)pos];
     if (!h) return fail("mzr_sample_batch: draw %d hit an empty leaf (buffer smaller than the draw range?)", i);
@@ -570,10 +666,11 @@ int mzr_sample_batch(const mz_replay *r, const double *draws, int bs, float *obs
   return 0;
 }
 
-int64_t mzr_frames(const mz_replay *r) { return r->frames; }
-int64_t mzr_games(const mz_replay *r) { return r->games; }
+int64_t mzr_frames(const mz_replay *r) { drain(r); return r->frames; }
+int64_t mzr_games(const mz_replay *r) { drain(r); return r->games; }
 int mzr_add_initial_throughput(mz_replay *r, int64_t frames, int64_t games) {
   if (!r) return fail("mzr_add_initial_throughput: null");
+  drain(r);
   r->frames += frames; r->games += games;
   return 0;
 }

@@ -252,3 +252,46 @@ def test_records_with_to_play_equal_save_history():
   rep.ingest_records(rec1, n, 1)
   random.seed(1); np.random.seed(2)
   assert not np.array_equal(rep.sample_batch()[0][2][1], out[0][4])
+
+
+def test_deferred_insertion_is_invisible():
+  """With more than one ingest thread the sum-tree insertion of a chunk is deferred to the handle's inserter thread; every
+  other entry point waits for it first.  Calls interleaved in every order -- size / frames / total / sample / update /
+  save_history right behind an ingest, a thread-count change and a destroy with insertions pending -- give what the
+  one-thread handle gives."""
+  import random
+  from model_based_rl_amd.replay_buffer import PrioritizedReplay
+  O, A, B, moves, T = 4, 3, 64, 64, 9
+  rec = _bulk_records(np.random.RandomState(11), moves, B, O, A, T)
+  logs = []
+  for threads in (1, 3):
+    rep = PrioritizedReplay(make_cfg(obs_space=(O,), action_space=A, window_size=2048, discount=0.997, ingest_threads=threads,
+                                     batch_size=8))
+    log = []
+    random.seed(3); np.random.seed(4)
+    for k, lo in enumerate(range(0, moves, 8)):
+      rep.ingest_records(rec[lo:lo + 8], 8, B)
+      if k % 4 == 0:
+        log.append(('size', rep.size(), rep.get_throughput()))
+      elif k % 4 == 1:
+        log.append(('total', rep.tree.total_priority))
+      elif k % 4 == 2:
+        (obs, act, (tr, tv, tp)), idxs, isw = rep.sample_batch()
+        rep.update(idxs, np.linspace(0.1, 0.9, 8))
+        log.append(('batch', obs.copy(), tv.copy(), list(idxs), rep.tree.total_priority))
+      else:
+        h = types.SimpleNamespace(observations=np.ones((3, O), np.float32), child_visits=np.full((2, A), 1 / A, np.float32),
+                                  root_values=[0.5, 0.25], actions=[0, 1], rewards=[0.0, 1.0], errors=[0.3, 0.2], dones=[0, 1],
+                                  to_play=[1, 1])
+        rep.save_history(h, ignore=None, terminal=True)
+        if threads > 1:
+          rep.set_ingest_threads(2 if rep.ingest_threads != 2 else 3)      # re-creates the pool behind pending insertions
+    rep.ingest_records(rec[:8], 8, B)      # ... and the handle is destroyed with this chunk's insertion possibly pending
+    log.append(('leaves', rep.tree.leaves(rep.size()).copy()))
+    logs.append(log)
+    del rep
+  assert len(logs[0]) == len(logs[1])
+  for a, b in zip(*logs):
+    assert a[0] == b[0]
+    for x, y in zip(a[1:], b[1:]):
+      assert np.array_equal(np.asarray(x), np.asarray(y)) if not isinstance(x, dict) else x == y, a[0]
