@@ -91,9 +91,10 @@ struct Pool {
     stop();
     T = threads < 1 ? 1 : threads;
     quit = false;
+    const unsigned long long gen0 = gen;      // (a pool restarted after earlier runs: the new workers wait for the NEXT job)
     for (int i = 1; i < T; ++i)
-      th.emplace_back([this, i] {
-        unsigned long long seen = 0;
+      th.emplace_back([this, i, gen0] {
+        unsigned long long seen = gen0;
         for (;;) {
           {
             std::unique_lock<std::mutex> lk(mu);
