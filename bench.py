@@ -292,6 +292,9 @@ def main():
   ap.add_argument('--split-f16', action='store_true',
                   help='secondary line: the FCNetwork GEMMs as float16 high/low splits on the f16 matrix pipe '
                        '(mz_config.split_f16; float32-level accuracy, not bit-identical to the exact-f32 default)')
+  ap.add_argument('--one-replay', action='store_true',
+                  help='N > 1: the topology of `train --ranks N` -- every rank ships its record chunks through a shared-memory ring '
+                       'to rank 0, whose ONE native replay ingests them all (default: one replay per rank; DESIGN.md s6)')
   ap.add_argument('--dump-records', default=None,
                   help='(tests) save this rank\'s experience records of the first moves after reset to <path>.rank<r>.npy')
   args = ap.parse_args()
@@ -354,10 +357,38 @@ def main():
 
   sync_weights()
   replay = PrioritizedReplay(replay_config())
+  n_ingest = replay.ingest_threads
   ram = '-ram' in WNAME
   if ram:        # the -ram- envs: byte observations, --norm_obs --obs_range 0 255 inside the root kernel (actors.py:134-137)
     eng.selfplay_set_obs(uint8_obs=True, obs_min=[0.0], obs_range=[255.0])
   eng.selfplay_reset(EPISODE_LEN, 1.0, stagger=True)
+  one_replay = bool(args.one_replay) and dist is not None and world > 1
+  rings, ring_stop = {}, None
+  if one_replay:
+    # train.launch_ranks' wiring (reference train.py:71-72: ONE replay buffer for all actors): rank r > 0 owns a ring in
+    # shared memory, a thread on rank 0 drains the rings into the one replay with env_base = r * B
+    import threading
+    from model_based_rl_amd import distributed as D
+    run_id = 'mzb_%s' % os.environ.get('MASTER_PORT', '0')
+    if rank == 0:
+      rings = {r: D.ShmRing('%s_%d' % (run_id, r), chunk, B, eng.rec_floats, slots=4, create=True) for r in range(1, world)}
+    dist.barrier()
+    if rank == 0:
+      lock, inner = threading.Lock(), replay
+
+      class Locked(object):              # two callers on rank 0: its own pipeline worker and the ring server
+        def __getattr__(self, name):
+          def call(*a, **k):
+            with lock:
+              return getattr(inner, name)(*a, **k)
+          return call
+      replay = Locked()
+      ring_stop = threading.Event()
+      threading.Thread(target=D.serve_rings, args=(rings, lambda name, *a: getattr(replay, name)(*a), B, ring_stop), daemon=True).start()
+    else:
+      my_ring = D.ShmRing('%s_%d' % (run_id, rank))
+      replay = D.RingReplay(my_ring)
+      replay.get_throughput = lambda: {'frames': 0, 'games': 0}      # (counted where they are accepted: rank 0's replay)
   pipe = Pipeline(eng, replay, chunk, device, sync_weights, max(chunk, args.sync_every), dump=[] if args.dump_records else None)
   state, run, pinned, dump = pipe.state, pipe.run, pipe.pinned, pipe.dump
 
@@ -365,6 +396,12 @@ def main():
     torch.cuda.synchronize(device)
     if dist is not None:
       dist.barrier()
+      if one_replay:        # every producer has put its last chunk: the region ends when the one replay has accepted them all
+        if rank == 0:
+          while any(int(r.hdr[1]) < int(r.hdr[0]) for r in rings.values()):
+            time.sleep(0.0002)
+          replay.size()     # (takes the lock behind an ingest in flight, and waits for the deferred insertions)
+        dist.barrier()
       torch.cuda.synchronize(device)
 
   # priming (untimed, not part of --warmup): every env finishes its first, partial (staggered) episode, so
@@ -472,8 +509,10 @@ def main():
                    'timed_region': 'the --steps block repeated %d times back to back in one pipelined region of %.2f s '
                                    '(barrier + synchronize on both sides)' % (repeats, dt),
                    'sharding': 'env-id sharded, %d rank(s), weight broadcast over %s' % (world, {'nccl': 'RCCL (torch.distributed nccl backend)', None: 'nothing (one rank, no process group)'}.get(backend, backend)),
-                   'replay': 'one native replay per rank (bench layout: the metric counts frames accepted; `train --ranks N` merges '
-                             'all ranks into ONE replay on rank 0, DESIGN.md s6), %d ingest threads' % replay.ingest_threads,
+                   'replay': ('ONE native replay on rank 0 fed by every rank through shared-memory rings (--one-replay: the layout of '
+                              '`train --ranks N`, reference train.py:71-72), %d ingest threads' if one_replay else
+                              'one native replay per rank (bench layout: the metric counts frames accepted; `train --ranks N` and '
+                              '--one-replay merge all ranks into ONE replay on rank 0, DESIGN.md s6), %d ingest threads') % n_ingest,
                    'weight_sync': 'flat f32 buffer broadcast from rank 0 + repack every %d moves: %d pulls inside the '
                                   'timed region' % (state['sync_every'], syncs_in_region)},
         'env_steps_executed_per_s': env_steps / dt,
@@ -524,6 +563,11 @@ def main():
     print(json.dumps(out), flush=True)
   if dist is not None:
     dist.barrier()
+    if one_replay:
+      if ring_stop is not None:
+        ring_stop.set()
+      for r_ in list(rings.values()) + ([my_ring] if rank > 0 else []):
+        r_.release()
     dist.destroy_process_group()
 
 

@@ -128,3 +128,21 @@ def test_train_over_rccl_at_world_size_1():
   assert s['backend'] == 'nccl' and s['rccl_mapped'] and s['weights_on_device'] and s['drained']
   assert s['ranks'] == 1 and s['training_step'] == 4 and s['rank_training_steps'] == [4]
   assert s['weight_broadcasts'] >= 2 and s['frames'] >= 512 and s['games'] == s['rank_games'][0]
+
+
+def test_bench_two_ranks_into_one_replay():
+  """bench.py --gpus 2 --one-replay: the topology of `train --ranks N` (reference train.py:71-72: ONE replay buffer) under
+  the bench's clock -- rank 1 ships its record chunks through its shared-memory ring, rank 0's drain thread ingests them
+  with env_base = B beside rank 0's own; the one replay accepts both ranks' frames."""
+  B, steps = 64, 16
+  env = dict(os.environ, MZ_BENCH_BACKEND='gloo', MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+  out = subprocess.run(launcher(2, 29571) + [os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', str(steps), '--warmup',
+                       '4', '--no-cpu-baseline', '--envs', str(B), '--min-seconds', '0.2', '--one-replay'],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+  assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+  line = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+  assert line['n_gpus'] == 2 and 'ONE native replay on rank 0' in line['config']['replay']
+  executed = line['env_steps_executed_per_s'] * line['timed_seconds']
+  assert abs(executed - 2 * B * line['timed_steps']) < 1e-6 * executed
+  # frames accepted by the ONE replay = both ranks' (steady state: ~B frames per move and rank)
+  assert 0.6 * 2 * B * line['timed_steps'] < line['value'] * line['timed_seconds'] < 1.4 * 2 * B * line['timed_steps']
