@@ -48,7 +48,8 @@ def test_forward_matches_reference_gpu(name):
     assert v <= TOL[kind], (k, v)
 
 
-@pytest.mark.parametrize('arch,B,A,sims', [('TinyNetwork', 256, 4, 50), ('MuZeroNetwork', 24, 4, 12), ('TinyNetwork', 40, 6, 20)])
+@pytest.mark.parametrize('arch,B,A,sims', [('TinyNetwork', 256, 4, 50), ('MuZeroNetwork', 24, 4, 12), ('TinyNetwork', 40, 6, 20),
+                                             ('MuZeroNetwork', 512, 4, 50)])       # BASELINE configs[4]'s network and simulation count
 def test_batched_search_tree_is_bit_exact_given_the_torch_outputs(arch, B, A, sims):
   """(i) the tree the device builds around a torch network equals, field for field, the tree the CPU oracle builds
   when it is fed the very same network outputs: descents (leaf, parent slot, action, depth) of every simulation, N, E,
