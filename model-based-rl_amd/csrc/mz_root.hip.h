@@ -264,15 +264,17 @@ __device__ __forceinline__ void mz_root_body(const NetView &n, const TreeView &t
         const double gam = tl < A ? mz_gamma(alpha, seed, (uint32_t)(sp.env_offset + b), move, (uint32_t)tl) : 0.0;
         double sum = 0.0;
         for (int a = 0; a < A; ++a) sum += __shfl(gam, a, G);
-        if (tl < A) {
-          const double nz = sum > 0.0 ? gam / sum : 1.0 / A;
-          t.noise[(size_t)b * A + tl] = nz;
-          if (sp.noise_log) sp.noise_log[((size_t)(move % (unsigned long long)sp.ring_moves) * t.B + b) * A + tl] = nz;
-        }
+        const double nz = sum > 0.0 ? gam / sum : 1.0 / A;
+        if (tl < A) t.noise[(size_t)b * A + tl] = nz;
         __threadfence_block();
         const uint32_t mask = (A >= 32) ? 0xFFFFFFFFu : ((1u << A) - 1u);
         mz_tree_root<G, true>(t, b, tl, 1, mask, s_lg + mt * 32, t.noise + (size_t)b * A, frac,
                               root_stage ? root_stage + mt * 96 : nullptr);
+        // test instrumentation (mz_selfplay_noise_log), off in production.  AFTER the root: a second, possibly aliasing
+        // store between the one above and mz_tree_root's read of it keeps the compiler from forwarding the value in
+        // registers and costs a whole store -> load round trip per move (A/B on one box: 0.3 % of the move)
+        if (sp.noise_log && tl < A)
+          sp.noise_log[((size_t)((uint32_t)move % (uint32_t)sp.ring_moves) * (uint32_t)t.B + (uint32_t)b) * (uint32_t)A + (uint32_t)tl] = nz;
       }
     }
   }

@@ -28,4 +28,13 @@ MZ_SPLIT_F16=1 python3 scripts/phase_profile.py 8 4 30 ${TAG}_lunar_split > $O/p
 MZ_SPLIT_F16=1 python3 scripts/phase_profile.py 128 6 50 ${TAG}_pong_split > $O/phase_${TAG}_pong_split.txt 2>&1
 cp profiles/phase_cycles_${TAG}_*split.json $O/ 2>/dev/null
 python3 bench.py --workload breakout > $O/bench_breakout_$TAG.json 2>> $O/bench_$TAG.err
+# two-player games on the device (TicTacToe, reference rules), and the stand-alone tree kernels against the HBM / cache roofs
+python3 bench.py --workload tictactoe --no-cpu-baseline > $O/bench_tictactoe_$TAG.json 2>> $O/bench_$TAG.err
+python3 bench.py --workload tree > $O/bench_tree_$TAG.json 2>> $O/bench_$TAG.err
+# the world-size-1 RCCL branch of the bench (process group over nccl, device-side weight broadcasts)
+MZ_BENCH_FORCE_DIST=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29591 bench.py --gpus 1 --no-cpu-baseline > $O/bench_rccl_world1_$TAG.json 2>> $O/bench_$TAG.err
+# host side: ingest thread scaling, the one-replay path of train --ranks 8 with synthetic producers
+python3 scripts/ingest_bench.py --json $O/ingest_bench_$TAG.json > $O/ingest_bench_$TAG.txt 2>&1
+python3 scripts/one_replay_bench.py --ranks 8 --chunks 200 --threads 4 --json $O/one_replay_8ranks_4threads_$TAG.json > /dev/null 2>&1
+python3 scripts/one_replay_bench.py --ranks 8 --chunks 200 --threads 8 --json $O/one_replay_8ranks_8threads_$TAG.json > /dev/null 2>&1
 f=$(find $O/prof_$TAG -name "*kernel_stats.csv" | head -1); head -8 "$f"
