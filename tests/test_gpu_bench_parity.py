@@ -126,3 +126,45 @@ def test_persistent_launch_on_a_full_grid_vs_oracle(shape, split):
   if out:
     with open(out, 'a') as f:
       f.write('\n'.join(report) + '\n')
+
+
+def _selfplay_digest(shape, persist, split=False):
+  """records of 3 chunks x 8 moves at 4096 envs (bench.py's launch shape) as one sha256, in a child process (the launch
+  structure is chosen at mz_create from MZ_NO_PERSIST)"""
+  import subprocess, sys
+  sh = SHAPES[shape]
+  code = '''
+import hashlib, os, sys, numpy as np, torch
+sys.path.insert(0, %r)
+from oracle import oracle as orc
+from model_based_rl_amd.engine import Engine
+w = orc.load_weights(np.load(%r))
+eng = Engine(4096, %d, %d, %d, seed=77, split_f16=%r)
+assert (eng.selfplay_moves_per_launch() > 0) == %r
+eng.set_weights(w)
+if %r:
+  eng.selfplay_set_obs(uint8_obs=True, obs_min=[0.0], obs_range=[255.0])
+eng.selfplay_reset(11, 1.0, stagger=True)
+h = hashlib.sha256()
+for k in range(3):
+  eng.selfplay_steps(8)
+  buf, n = eng.selfplay_drain()
+  torch.cuda.synchronize()
+  h.update(buf[:n].numpy().tobytes())
+print('DIGEST', h.hexdigest())
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(G, sh['gold'] + '.npz'), sh['O'], sh['A'],
+       sh['sims'], split, persist, sh['u8'])
+  env = dict(os.environ)
+  env.pop('MZ_NO_PERSIST', None)
+  if not persist:
+    env['MZ_NO_PERSIST'] = '1'
+  out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
+  assert out.returncode == 0, out.stderr[-2000:]
+  return [l for l in out.stdout.splitlines() if l.startswith('DIGEST')][-1]
+
+
+@pytest.mark.parametrize('shape,split', [('lunar', False), ('pong', False), ('lunar', True)])
+def test_persistent_launch_equals_kernel_per_phase_on_a_full_grid(shape, split):
+  """The whole-moves launch on 256 workgroups against the hipGraph of root + search kernels per move (MZ_NO_PERSIST=1):
+  24 moves of 4096 environments, every byte of every record identical (same device functions, same keys)."""
+  assert _selfplay_digest(shape, True, split) == _selfplay_digest(shape, False, split)
