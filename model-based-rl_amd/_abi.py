@@ -26,7 +26,8 @@ def translation_units(extra=()):
   dev = '-DMZ_DEV_ONLY' in extra
   units = [('mz_engine', 'mz_engine.hip', [])]
   for ks1, jtp, g in (DEV_FUSED_SHAPES if dev else FUSED_SHAPES):
-    units.append(('mz_inst_f_%d_%d_%d' % (ks1, jtp, g), 'mz_inst.hip', ['-DMZ_INST_F=%d,%d,%d' % (ks1, jtp, g)]))
+    units.append(('mz_inst_f_%d_%d_%d' % (ks1, jtp, g), 'mz_inst.hip', ['-DMZ_INST_F=%d,%d,%d' % (ks1, jtp, g)] +
+                  (['-DMZ_INST_GAME=1'] if (ks1, jtp, g) == (16, 1, 16) else [])))
   for g in (DEV_H2_SHAPES if dev else H2_SHAPES):
     units.append(('mz_inst_h_%d' % g, 'mz_inst.hip', ['-DMZ_INST_H=%d' % g]))
   return units

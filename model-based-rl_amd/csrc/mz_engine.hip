@@ -28,6 +28,10 @@
 #include "mz_kernels.inc"
 MZ_ALL_FUSED(extern)
 MZ_ALL_H2(extern)
+#ifndef MZ_DEV_ONLY
+// whole moves of the device TicTacToe environment (two players, 9 actions: the <16, 1, 16> shape, compact LDS trees)
+extern template __global__ void k_search_fused<16, 1, 16, 2, false, false, true, true> MZ_KARGS;
+#endif
 
 static thread_local std::string g_err;
 
@@ -562,6 +566,30 @@ static int launch_fused_sp(mz_engine *e, int num_simulations, int sims_done, hip
       return 0;
     }
   }
+#ifndef MZ_DEV_ONLY
+  if constexpr (KS1 == 16 && JTP == 1 && G == 16 && LT == 2 && !SP) {
+    if (e->persist_moves > 0 && e->sp.env_kind == 1) {      // whole moves of the device TicTacToe environment in this launch
+      const size_t dynh = fused_head_dyn_lds(e->sims, e->NN, LT);
+      const MzRootArgs ra = {e->istream, e->nst0, e->persist_moves, e->cfg.root_dirichlet_alpha,
+                             e->cfg.root_exploration_fraction};
+      if (!e->lds_attr_set_head) {
+        HIPCHECK(hipFuncSetAttribute((const void *)k_search_fused<16, 1, 16, 2, false, false, true, true>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)sizeof(float) * mz_fused_lds_floats(LT)));
+        e->lds_attr_set_head = true;
+      }
+      if (e->ev_start)
+        hipExtLaunchKernelGGL((k_search_fused<16, 1, 16, 2, false, false, true, true>), dim3(e->Bp / MZ_ROWS), dim3(256), dynh, s,
+                              e->ev_start, e->ev_stop, 0, e->nv, e->tv, e->wstream, num_simulations, 0,
+                              (unsigned long long *)nullptr, e->sp, 1, (uint64_t)e->cfg.seed, ra);
+      else
+        hipLaunchKernelGGL((k_search_fused<16, 1, 16, 2, false, false, true, true>), dim3(e->Bp / MZ_ROWS), dim3(256), dynh, s,
+                           e->nv, e->tv, e->wstream, num_simulations, 0, (unsigned long long *)nullptr, e->sp, 1,
+                           (uint64_t)e->cfg.seed, ra);
+      HIPCHECK(hipGetLastError());
+      return 0;
+    }
+  }
+#endif
   if (e->persist_moves > 0) return fail("internal: no HEAD instantiation for this configuration");
   if (e->prof_buf) {
     if (!e->lds_attr_set_prof) {
@@ -715,8 +743,18 @@ static int fused_lt(const mz_engine *e) {
 }
 // Can the self-play loop run as whole moves inside one launch (HEAD instantiation of the fused kernel)?
 static bool selfplay_persist_ok(const mz_engine *e) {
-  if (!e->use_persist || !e->use_fused || e->sims + 2 > MZ_FUSED_MAXPL || e->cfg.two_players || e->prof_buf || e->sp.env_kind)
+  if (!e->use_persist || !e->use_fused || e->sims + 2 > MZ_FUSED_MAXPL || e->prof_buf) return false;
+  if (e->sp.env_kind == 1) {
+    // the device TicTacToe environment: whole moves inside the launch of the two-player <16, 1, 16> instantiation with
+    // its trees compact in LDS (the exact-f32 kernel; host-given uniforms / draws work there too)
+#ifdef MZ_DEV_ONLY
     return false;
+#else
+    return !e->split_f16 && e->cfg.two_players && e->A > 8 && e->A <= 13 && fused_lt(e) == 2 &&
+           sizeof(float) * mz_fused_lds_floats(2) + fused_head_dyn_lds(e->sims, e->NN, 2) <= 160 * 1024;
+#endif
+  }
+  if (e->cfg.two_players || e->sp.env_kind) return false;
   if (e->split_f16 && e->use_lds_trees) {      // the split-f16 kernel where it applies (launch_h2), else the exact one below
     for (int lt = 1; lt <= (e->use_lds_hybrid ? 2 : 1); ++lt)
       if (sizeof(float) * mz_h2_lds_floats(lt) + mz_fused_dyn_lds(e->sims, e->NN, lt) <= 160 * 1024)

@@ -491,7 +491,8 @@ __host__ __device__ inline size_t mz_fused_dyn_lds(int sims, int NN, int lt) {
 // Game.store_search_statistics, root error, Game.apply on the synthetic env and the experience record
 // (the stand-alone k_env_step_record does the same from the global pool).  Lane a stages child a's visit count
 // in LDS, lane 0 then runs the reference's sequential arithmetic (mz_sample_index) on the staged vector.
-template <int TL, int LT>
+// GAME: the environment is the device TicTacToe (mz_ttt_apply) instead of the synthetic one; the uniform may be the host's.
+template <int TL, int LT, bool GAME = false>
 __device__ __forceinline__ void mz_finalize_record(const TreeView &t, const TreeMem<LT> &tm, const SelfplayState &sp,
                                                    int b, int lane, uint32_t legal, uint64_t seed, double *stage,
                                                    int O) {
@@ -516,8 +517,15 @@ __device__ __forceinline__ void mz_finalize_record(const TreeView &t, const Tree
     const double err = rv - (double)t.root_value[b];
     const uint32_t env = (uint32_t)(sp.env_offset + b);
     const mz_u4 r = mz_philox(seed, env, (uint32_t)move, (uint32_t)(move >> 32), MZ_RNG_ACTION << 24);
-    const int idx = mz_sample_index(d, n, sp.temp[b], mz_u01(r.x, r.y));
+    double u = mz_u01(r.x, r.y);
+    if constexpr (GAME) { if (sp.draw_uniform) u = sp.draw_uniform[b]; }
+    const int idx = mz_sample_index(d, n, sp.temp[b], u);
     const int action = acts[idx];
+    if constexpr (GAME) {
+      mz_ttt_apply(sp, b, action, rv, err, rec, A);
+      sp.movecnt[b] = move + 1ull;
+      return;
+    }
     const int tt = sp.t[b], ep = sp.episode[b];
     const int done = (tt + 1 >= sp.episode_len) ? 1 : 0;
     mz_rec_put_double(rec + O + A + 0, rv);
@@ -535,7 +543,7 @@ __device__ __forceinline__ void mz_finalize_record(const TreeView &t, const Tree
 }
 
 // (mz_root.hip.h) the root of a move for the 16 rows of a workgroup
-template <int JTP, int G, bool SELFPLAY, class STAMPF>
+template <int JTP, int G, bool SELFPLAY, bool GAME, class STAMPF>
 __device__ __forceinline__ void mz_root_body(const NetView &n, const TreeView &t, const float *obs_in,
                                              const f32x4 *istream, int nst0, const SelfplayState &sp, uint64_t seed,
                                              double alpha, double frac, float *smem, int tid, double *root_stage,
@@ -553,11 +561,13 @@ struct MzRootArgs {
 // occupy), all simulations, then the end of the move -- so a move costs no kernel launch, no grid-wide drain between
 // root and search, and the resident weight steps are loaded once per launch instead of once per move.  The
 // workgroups drift apart freely: nothing is exchanged between them.
-template <int KS1, int JTP, int G, int LT, bool PROF, bool SP, bool HEAD = false>
+// GAME (HEAD, two players): the moves are those of the device TicTacToe environment (mz_root_body<.., GAME>, mz_ttt_apply).
+template <int KS1, int JTP, int G, int LT, bool PROF, bool SP, bool HEAD = false, bool GAME = false>
 __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, const f32x4 *wstream, int nsims,
                                                           int slot0, unsigned long long *prof, SelfplayState sp,
                                                           int record, uint64_t seed, MzRootArgs ra) {
   static_assert(!HEAD || (LT != 0 && !PROF), "HEAD: trees in LDS, no phase stamps");
+  static_assert(!GAME || (HEAD && !SP), "GAME: whole moves of a two-player game environment");
   using SC = FusedSched<KS1, JTP>;
   constexpr int NB = MZ_NB, NSTEPS = SC::NSTEPS, RS = SC::RS, NRING = SC::NRING;
   static_assert(RS <= SC::FC1, "resident steps must be fc1 steps of the dynamics stage");
@@ -640,7 +650,7 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
     // root's address arithmetic as invariants of the move loop and carries them through the simulations --
     // 413.5 vs 410.5 us per move, A/B on one box)
     if (ra.nst0 >= 0)
-    mz_root_body<JTP, G, true>(n, t, nullptr, ra.istream, ra.nst0, sp, seed, ra.alpha, ra.frac,
+    mz_root_body<JTP, G, true, GAME>(n, t, nullptr, ra.istream, ra.nst0, sp, seed, ra.alpha, ra.frac,
                                (float *)(dyn_lds + (((t.sims + 2) * PBS * 8 + 15) & ~15)), tid_r, s_stage,
                                [&](int k) __attribute__((always_inline)) { HSTAMP(4 + k) });
     __syncthreads();
@@ -719,6 +729,11 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
         my_act[i] = best;
         tr[i].len = 2;
         tr[i].legal = (t.A >= 32) ? 0xFFFFFFFFu : ((1u << t.A) - 1u);
+        if constexpr (GAME) {         // the root's mover and legal moves (mz_root_body left them in the staging area)
+          tr[i].root_tp = (int)st[33];
+          tr[i].tp = -tr[i].root_tp;                 // to_play at the leaf of the first descent (mcts.py:90-92)
+          tr[i].legal = (uint32_t)st[34];
+        }
         tr[i].mn = t.has_min ? t.min_bound : __builtin_inf();
         tr[i].mx = t.has_max ? t.max_bound : -__builtin_inf();
         if (tl == 0) { s_path[mt * MZ_FUSED_MAXPL] = 0; s_path[mt * MZ_FUSED_MAXPL + 1] = 1 + best; }
@@ -729,7 +744,7 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
           }
           for (int k = tl; k < have; k += TL) tm[i].X[k] = 0.0;
         } else {
-          for (int k = tl; k < have; k += TL) { tm[i].N[k] = 0; tm[i].E[k] = (k == 0) ? 0 : -1; tm[i].TP[k] = 1; }
+          for (int k = tl; k < have; k += TL) { tm[i].N[k] = 0; tm[i].E[k] = (k == 0) ? 0 : -1; tm[i].TP[k] = (GAME && k == 0) ? (int8_t)tr[i].root_tp : (int8_t)1; }
           if (tl == 0) { tm[i].W[0] = 0.0; tm[i].R[0] = 0.f; tm[i].X[0] = 0.0; }      // the root's expansion slot
         }
         for (int k = tl; k < have; k += TL) tm[i].P[k] = (k == 0) ? 0.0 : st[k - 1];
@@ -1068,7 +1083,7 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
       const int mt = tid / TL + i * (256 / TL);
-      if (b0 + mt < t.B) mz_finalize_record<TL, LT>(t, tm[i], sp, b0 + mt, tl, tr[i].legal, seed, s_stage + mt * 96, n.O);
+      if (b0 + mt < t.B) mz_finalize_record<TL, LT, GAME>(t, tm[i], sp, b0 + mt, tl, tr[i].legal, seed, s_stage + mt * 96, n.O);
     }
   }
   // per-tree scalars back to the pool (what export / a later mz_select continue from)

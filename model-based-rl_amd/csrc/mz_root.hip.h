@@ -35,7 +35,11 @@ __host__ __device__ inline int mz_root_nst0(int O) { return ((O + 1 + 3) / 4 + 1
 // HEAD), which runs it on the space its trees are about to occupy.
 // stampf(k): phase hook (k = 0 first stage done, 1 representation + LayerNorm done, 2 prediction done); MzNoStamp outside
 // the profiled persistent kernel
-template <int JTP, int G, bool SELFPLAY, class STAMPF>
+// GAME (whole-moves launch of a game environment, mz_selfplay_set_env; SELFPLAY only): the observation is turn * board of
+// the TicTacToe state (custom_environments/tic_tac_toe.py:24,50), the root is expanded over the legal moves for the player
+// to move (actors.py:141-142), the Dirichlet draw covers the legal actions only (mcts.py:58-59) or is the host's
+// (parity runs); root_stage additionally receives to_play (slot 33) and the legal mask (slot 34).
+template <int JTP, int G, bool SELFPLAY, bool GAME = false, class STAMPF>
 __device__ __forceinline__ void mz_root_body(const NetView &n, const TreeView &t, const float *obs_in,
                                              const f32x4 *istream, int nst0, const SelfplayState &sp, uint64_t seed,
                                              double alpha, double frac, float *smem, int tid, double *root_stage,
@@ -110,6 +114,10 @@ __device__ __forceinline__ void mz_root_body(const NetView &n, const TreeView &t
       float v = 0.f;
       if (k < O) {
         if (b < t.B) {
+          if constexpr (GAME) {       // tic_tac_toe.py:24,50: observation = turn * board, np.float32 (actors.py:134)
+            v = (float)((int)sp.turn[b] * (int)sp.board[(size_t)b * 9 + k]);
+            sp.obs[(size_t)b * O + k] = v;
+          } else
           if constexpr (SELFPLAY) {   // Game.get_observation(-1) of the synthetic env (game.py:117-121)
             const uint32_t env = (uint32_t)(sp.env_offset + b), ep = (uint32_t)sp.episode[b], tt = (uint32_t)sp.t[b];
             v = sp.obs_u8 ? mz_synth_obs_u8(seed, env, ep, tt, (uint32_t)k) : mz_synth_obs_elem(seed, env, ep, tt, (uint32_t)k);
@@ -261,15 +269,37 @@ __device__ __forceinline__ void mz_root_body(const NetView &n, const TreeView &t
       const int b = b0 + mt;
       if (b < t.B && tl < G) {
         const uint64_t move = (uint64_t)sp.movecnt[b];
-        const double gam = tl < A ? mz_gamma(alpha, seed, (uint32_t)(sp.env_offset + b), move, (uint32_t)tl) : 0.0;
-        double sum = 0.0;
-        for (int a = 0; a < A; ++a) sum += __shfl(gam, a, G);
-        const double nz = sum > 0.0 ? gam / sum : 1.0 / A;
-        if (tl < A) t.noise[(size_t)b * A + tl] = nz;
-        __threadfence_block();
-        const uint32_t mask = (A >= 32) ? 0xFFFFFFFFu : ((1u << A) - 1u);
-        mz_tree_root<G, true>(t, b, tl, 1, mask, s_lg + mt * 32, t.noise + (size_t)b * A, frac,
-                              root_stage ? root_stage + mt * 96 : nullptr);
+        double nz;
+        if constexpr (GAME) {
+          // legal_actions() = the empty cells (tic_tac_toe.py:27-28), game.to_play = env.turn
+          const int to_play = (int)sp.turn[b];
+          const bool ok = tl < A && sp.board[(size_t)b * 9 + (tl < 9 ? tl : 0)] == 0;
+          uint32_t mask = 0;
+          for (int a = 0; a < A; ++a) mask |= (__shfl((int)ok, a, G) ? 1u : 0u) << a;
+          if (sp.draws_noise) {
+            nz = tl < A ? t.noise[(size_t)b * A + tl] : 0.0;      // the host's draw, at the legal positions (mz_selfplay_set_draws)
+          } else {
+            const double gam = ok ? mz_gamma(alpha, seed, (uint32_t)(sp.env_offset + b), move, (uint32_t)tl) : 0.0;
+            double sum = 0.0;
+            for (int a = 0; a < A; ++a) sum += __shfl(gam, a, G);
+            nz = ok ? (sum > 0.0 ? gam / sum : 1.0 / (double)__popc(mask)) : 0.0;
+            if (tl < A) t.noise[(size_t)b * A + tl] = nz;
+          }
+          __threadfence_block();
+          mz_tree_root<G, true>(t, b, tl, to_play, mask, s_lg + mt * 32, t.noise + (size_t)b * A, frac,
+                                root_stage ? root_stage + mt * 96 : nullptr);
+          if (tl == 0 && root_stage) { root_stage[mt * 96 + 33] = (double)to_play; root_stage[mt * 96 + 34] = (double)mask; }
+        } else {
+          const double gam = tl < A ? mz_gamma(alpha, seed, (uint32_t)(sp.env_offset + b), move, (uint32_t)tl) : 0.0;
+          double sum = 0.0;
+          for (int a = 0; a < A; ++a) sum += __shfl(gam, a, G);
+          nz = sum > 0.0 ? gam / sum : 1.0 / A;
+          if (tl < A) t.noise[(size_t)b * A + tl] = nz;
+          __threadfence_block();
+          const uint32_t mask = (A >= 32) ? 0xFFFFFFFFu : ((1u << A) - 1u);
+          mz_tree_root<G, true>(t, b, tl, 1, mask, s_lg + mt * 32, t.noise + (size_t)b * A, frac,
+                                root_stage ? root_stage + mt * 96 : nullptr);
+        }
         // test instrumentation (mz_selfplay_noise_log), off in production.  AFTER the root: a second, possibly aliasing
         // store between the one above and mz_tree_root's read of it keeps the compiler from forwarding the value in
         // registers and costs a whole store -> load round trip per move (A/B on one box: 0.3 % of the move)
@@ -286,5 +316,5 @@ __global__ __launch_bounds__(256, 1) void k_root(NetView n, TreeView t, const fl
                                                   int nst0, SelfplayState sp, uint64_t seed, double alpha,
                                                   double frac) {
   __shared__ __attribute__((aligned(16))) float smem[MZ_ROOT_LDS_FLOATS];
-  mz_root_body<JTP, G, SELFPLAY>(n, t, obs_in, istream, nst0, sp, seed, alpha, frac, smem, (int)threadIdx.x, nullptr, MzNoStamp());
+  mz_root_body<JTP, G, SELFPLAY, false>(n, t, obs_in, istream, nst0, sp, seed, alpha, frac, smem, (int)threadIdx.x, nullptr, MzNoStamp());
 }

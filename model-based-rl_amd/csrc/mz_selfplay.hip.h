@@ -32,6 +32,7 @@ struct SelfplayState {
   int8_t *to_play;       // [B] game.to_play of the current move (root.expand's to_play, actors.py:142)
   const double *draw_uniform;   // [B] or null: the uniform select_action consumes, given by the host (parity runs,
                                 // mz_selfplay_set_draws); null = the device RNG keyed (seed, env, move)
+  int draws_noise;       // != 0: the Dirichlet draw of the coming moves is the one the host put into TreeView::noise
   float *ring;           // [ring_moves][B][rec_floats]
   float *host_ring;      // pinned staging for drains (optional)
   unsigned long long moves_host, drained;
@@ -146,6 +147,32 @@ static __global__ void k_ttt_observe(SelfplayState sp, int B, int A) {
   sp.to_play[b] = (int8_t)turn;
 }
 
+// Game.apply (game.py:79-104) on env.step (tic_tac_toe.py:30-51) for environment b, by ONE lane, and the tail of its
+// experience record (root value, error, reward, action, flags with the mover, step, env id, episode).
+__device__ __forceinline__ void mz_ttt_apply(const SelfplayState &sp, int b, int action, double root_value, double error,
+                                             float *rec, int A) {
+  const int O = 9;
+  const int turn = sp.turn[b], t = sp.t[b], ep = sp.episode[b];
+  int8_t *bd = sp.board + (size_t)b * 9;
+  bd[action] = (int8_t)turn;
+  const int r0 = 3 * (action / 3), c0 = action % 3;
+  bool won = (bd[r0] + bd[r0 + 1] + bd[r0 + 2] == 3 * turn) || (bd[c0] + bd[c0 + 3] + bd[c0 + 6] == 3 * turn);
+  if (action % 4 == 0) won = won || (bd[0] + bd[4] + bd[8] == 3 * turn);
+  if (action == 2 || action == 4 || action == 6) won = won || (bd[2] + bd[4] + bd[6] == 3 * turn);
+  const int done = (won || t == 8) ? 1 : 0;           // tic_tac_toe.py:37 (elapsed steps before this move)
+  mz_rec_put_double(rec + O + A + 0, root_value);
+  mz_rec_put_double(rec + O + A + 2, error);
+  rec[O + A + 4] = won ? 1.f : 0.f;
+  int32_t *ri = (int32_t *)(rec + O + A + 5);
+  ri[0] = action; ri[1] = done | (turn < 0 ? 2 : 0); ri[2] = t; ri[3] = sp.env_offset + b; ri[4] = ep;
+  if (done) {      // run_selfplay starts a new Game: env.reset (tic_tac_toe.py:20-25), its temperature evaluated now
+    for (int k = 0; k < 9; ++k) bd[k] = 0;
+    sp.turn[b] = 1; sp.t[b] = 0; sp.episode[b] = ep + 1; sp.temp[b] = *sp.temp_next;
+  } else {
+    sp.turn[b] = (int8_t)(-turn); sp.t[b] = t + 1;
+  }
+}
+
 // End of a move: Config.select_action + store_search_statistics + root error (mz_finalize_tree), then Game.apply
 // (game.py:79-104) on env.step (tic_tac_toe.py:30-51): the mover's mark goes on the board; the move wins if a line
 // through it sums to +-3 (reward 1 for the mover), the game is done on a win or after the ninth move; the turn flips.
@@ -161,23 +188,5 @@ static __global__ void k_ttt_step_record(TreeView tv, SelfplayState sp, int B, i
   float *rec = sp.ring + ((size_t)(move % (unsigned long long)sp.ring_moves) * B + b) * sp.rec_floats;
   for (int k = 0; k < O; ++k) rec[k] = sp.obs[(size_t)b * O + k];
   for (int a = 0; a < A; ++a) rec[O + a] = (float)sp.child_visits[(size_t)b * A + a];
-  const int action = sp.action[b], turn = sp.turn[b], t = sp.t[b], ep = sp.episode[b];
-  int8_t *bd = sp.board + (size_t)b * 9;
-  bd[action] = (int8_t)turn;
-  const int r0 = 3 * (action / 3), c0 = action % 3;
-  bool won = (bd[r0] + bd[r0 + 1] + bd[r0 + 2] == 3 * turn) || (bd[c0] + bd[c0 + 3] + bd[c0 + 6] == 3 * turn);
-  if (action % 4 == 0) won = won || (bd[0] + bd[4] + bd[8] == 3 * turn);
-  if (action == 2 || action == 4 || action == 6) won = won || (bd[2] + bd[4] + bd[6] == 3 * turn);
-  const int done = (won || t == 8) ? 1 : 0;           // tic_tac_toe.py:37 (elapsed steps before this move)
-  mz_rec_put_double(rec + O + A + 0, sp.root_value[b]);
-  mz_rec_put_double(rec + O + A + 2, sp.error[b]);
-  rec[O + A + 4] = won ? 1.f : 0.f;
-  int32_t *ri = (int32_t *)(rec + O + A + 5);
-  ri[0] = action; ri[1] = done | (turn < 0 ? 2 : 0); ri[2] = t; ri[3] = sp.env_offset + b; ri[4] = ep;
-  if (done) {      // run_selfplay starts a new Game: env.reset (tic_tac_toe.py:20-25), its temperature evaluated now
-    for (int k = 0; k < 9; ++k) bd[k] = 0;
-    sp.turn[b] = 1; sp.t[b] = 0; sp.episode[b] = ep + 1; sp.temp[b] = *sp.temp_next;
-  } else {
-    sp.turn[b] = (int8_t)(-turn); sp.t[b] = t + 1;
-  }
+  mz_ttt_apply(sp, b, sp.action[b], sp.root_value[b], sp.error[b], rec, A);
 }
