@@ -190,7 +190,7 @@ static void inserter_loop(mz_replay *r) {
       std::lock_guard<std::mutex> lk(r->qmu);
       for (auto &v : job.pris) { v.clear(); if (r->spare.size() < 64) r->spare.push_back(std::move(v)); }
       r->inserting = false;
-      if (r->queue.empty()) r->idle_cv.notify_all();
+      r->idle_cv.notify_all();
     }
   }
 }
@@ -589,7 +589,10 @@ int mzr_ingest_records_from(mz_replay *r, const float *records, int n_moves, int
     return 0;
   }
   {
-    std::lock_guard<std::mutex> lk(r->qmu);
+    std::unique_lock<std::mutex> lk(r->qmu);
+    // back-pressure: at most a few chunks' insertions pending (their slices and priorities are memory; a caller that
+    // assembles faster than the tree takes them then runs at the tree's rate)
+    r->idle_cv.wait(lk, [&] { return r->queue.size() < 4; });
     for (int t = 0; t < (T < 1 ? 1 : T) && !r->spare.empty(); ++t) {      // hand the ingest threads recycled buffers
       r->scratch[(size_t)t].pris = std::move(r->spare.back());
       r->spare.pop_back();
