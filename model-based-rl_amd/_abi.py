@@ -193,7 +193,9 @@ def build_replay(force=False, verbose=False):
   src = os.path.join(_CSRC, 'mz_replay.cpp')
   hdr = os.path.join(_CSRC, '..', '..', 'include', 'mz_replay.h')
   if force or not os.path.exists(_RSO) or os.path.getmtime(_RSO) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
-    cmd = ['g++', '-O2', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared', '-pthread', 'mz_replay.cpp', '-o',
+    # -mavx2: the sum tree's per-level running sums are 4-wide double vectors (every x86-64 host of an MI355X box has
+    # AVX2; no FMA is enabled and contraction stays off: the sums are the reference's, term by term)
+    cmd = ['g++', '-O3', '-mavx2', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared', '-pthread', 'mz_replay.cpp', '-o',
            'libmz_replay.so']
     if verbose:
       print(' '.join(cmd))

@@ -235,46 +235,78 @@ static inline void tree_update(mz_replay *r, int64_t idx, double priority) {
 
 // SumTree.update (replay_buffer.py:34-40) for a run of leaves at consecutive tree indices, in arrival order.
 // Every node must receive its `change` terms in arrival order for the float64 sums to equal the reference's
-// one-leaf-at-a-time walk; the order between different nodes is free.  The upper levels, where the whole run
-// sits under one node, are therefore summed in ONE pass over the leaves with one running sum per level
-// (independent add chains instead of a store-to-load dependent walk per leaf); the lower levels walk runs of
-// leaves that share a node with the sum in a register.
+// one-leaf-at-a-time walk; the order between different nodes is free.  So the run is walked ONCE with one running sum
+// per LEVEL: a leaf adds its change to all of them (independent add chains, one per level -- a vector add, instead of
+// a store-to-load dependent walk to the root per leaf), and a level's sum is written back and re-read exactly when
+// the walk leaves one of that level's nodes for the next (level L every 2^L leaves: one write-back per leaf in total).
 static void tree_update_run(mz_replay *r, int64_t first_idx, const double *priorities, int64_t n) {
   double *t = r->tree.data();
-  if ((int64_t)r->chg.size() < n) r->chg.resize(n);
-  double *chg = r->chg.data();
-  for (int64_t i = 0; i < n; ++i) {
-    chg[i] = priorities[i] - t[first_idx + i];
-    t[first_idx + i] = priorities[i];
-  }
   // 1-based heap numbering: node j has parent j >> 1.  Split where the leaf depth changes (j crosses a power of 2).
   for (int64_t a = 0; a < n;) {
     const uint64_t j0 = (uint64_t)(first_idx + a) + 1;
-    const int depth = 63 - __builtin_clzll(j0);
+    const int depth = 63 - __builtin_clzll(j0);      // (<= 48: a window of 2^48 leaves does not fit any memory)
     int64_t b = n;
     const uint64_t next_pow = (uint64_t)1 << (depth + 1);
     if (j0 + (uint64_t)(n - a) > next_pow) b = a + (int64_t)(next_pow - j0);
-    const uint64_t j1 = (uint64_t)(first_idx + b - 1) + 1;      // last leaf of this sub-run
-    int L = 1;
-    for (; L <= depth && (j0 >> L) != (j1 >> L); ++L) {          // levels with several nodes under the run
-      int64_t i = a;
-      while (i < b) {
-        const uint64_t node = ((uint64_t)(first_idx + i) + 1) >> L;
-        double acc = t[node - 1];
-        do { acc += chg[i]; ++i; } while (i < b && ((((uint64_t)(first_idx + i) + 1) >> L) == node));
-        t[node - 1] = acc;
+    // acc[L - 1] = running sum of the level-L ancestor, L = 1 .. depth, as vectors of four levels (GCC vector extension:
+    // two SSE2 or one AVX2 add per vector; the lanes beyond `depth` compute on zeros and are never stored)
+    typedef double v4d __attribute__((vector_size(32)));
+    v4d acc4[12];                                                // depth <= 48
+    double *acc = (double *)acc4;
+    const int nv = (depth + 3) / 4;
+    for (int L = 1; L <= 4 * nv; ++L) acc[L - 1] = L <= depth ? t[(j0 >> L) - 1] : 0.0;
+    // one leaf: add its change to every level's running sum, write back / re-read the levels whose node ends with it
+    auto one_leaf = [&](int64_t i) {
+      const uint64_t j = (uint64_t)(first_idx + i) + 1;
+      const double c = priorities[i] - t[j - 1];
+      t[j - 1] = priorities[i];
+      const v4d c4 = {c, c, c, c};
+      for (int v = 0; v < nv; ++v) acc4[v] += c4;
+      // the ancestors this leaf is the LAST leaf of (within the run or at all): levels 1 .. number of trailing one bits of j
+      int last = (i + 1 < b) ? __builtin_ctzll(~j) : depth;
+      if (last > depth) last = depth;
+      for (int L = 1; L <= last; ++L) {
+        t[(j >> L) - 1] = acc[L - 1];
+        if (i + 1 < b) acc[L - 1] = t[((j + 1) >> L) - 1];
+      }
+    };
+    int64_t i = a;
+    if (depth >= 4) {
+      while (i < b && (((uint64_t)(first_idx + i) + 1) & 7)) one_leaf(i++);        // up to an 8-aligned leaf
+      // aligned blocks of 8 leaves: the 4 + 2 + 1 nodes of levels 1..3 lie entirely inside a block and get their 2 / 4 / 8
+      // terms straight in memory; the levels above take the block's 8 terms in order and are written back once per
+      // block where a node ends -- no per-leaf branch on the (geometrically distributed) number of finished levels
+      for (; i + 8 <= b; i += 8) {
+        const uint64_t j = (uint64_t)(first_idx + i) + 1;                           // j % 8 == 0
+        double c[8];
+        for (int k = 0; k < 8; ++k) { c[k] = priorities[i + k] - t[j - 1 + k]; t[j - 1 + k] = priorities[i + k]; }
+        double *l1 = t + (j >> 1) - 1, *l2 = t + (j >> 2) - 1, *l3 = t + (j >> 3) - 1;
+        for (int k = 0; k < 4; ++k) l1[k] = (l1[k] + c[2 * k]) + c[2 * k + 1];
+        for (int k = 0; k < 2; ++k) l2[k] = (((l2[k] + c[4 * k]) + c[4 * k + 1]) + c[4 * k + 2]) + c[4 * k + 3];
+        double s3 = l3[0];
+        for (int k = 0; k < 8; ++k) s3 += c[k];
+        l3[0] = s3;
+        {      // the levels above: eight terms in order per level, the running sums in registers (lanes of levels 1..3: unused here)
+          v4d cb[8];
+          for (int k = 0; k < 8; ++k) cb[k] = v4d{c[k], c[k], c[k], c[k]};
+          for (int v = 0; v < nv; ++v) {
+            v4d x = acc4[v];
+            x += cb[0]; x += cb[1]; x += cb[2]; x += cb[3]; x += cb[4]; x += cb[5]; x += cb[6]; x += cb[7];
+            acc4[v] = x;
+          }
+        }
+        const uint64_t je = j + 7;                                                  // the block's last leaf: low 3 bits set
+        const bool more = i + 8 < b;
+        int last = more ? __builtin_ctzll(~je) : depth;
+        if (last > depth) last = depth;
+        for (int L = 4; L <= last; ++L) {
+          t[(je >> L) - 1] = acc[L - 1];
+          if (more) acc[L - 1] = t[((je + 1) >> L) - 1];
+        }
+        if (more) for (int L = 1; L <= 3; ++L) acc[L - 1] = t[((je + 1) >> L) - 1];   // for the leaf-by-leaf tail
       }
     }
-    if (L <= depth) {                                            // levels L..depth: one node each
-      double acc[64];
-      const int nl = depth - L + 1;
-      for (int k = 0; k < nl; ++k) acc[k] = t[(j0 >> (L + k)) - 1];
-      for (int64_t i = a; i < b; ++i) {
-        const double c = chg[i];
-        for (int k = 0; k < nl; ++k) acc[k] += c;
-      }
-      for (int k = 0; k < nl; ++k) t[(j0 >> (L + k)) - 1] = acc[k];
-    }
+    for (; i < b; ++i) one_leaf(i);
     a = b;
   }
 }
