@@ -92,6 +92,7 @@ def main():
         time.sleep(dt)
     locked_call('ingest_records', own[i % len(own)], CH, B, 0)
   server.join(timeout=600)
+  replay.size()                                      # (waits for the deferred insertions: the region ends when the tree has them)
   dt = time.perf_counter() - t0
   frames = replay.get_throughput()['frames'] - f0
   waits = dict(result.get(timeout=60) for _ in procs)
