@@ -1,0 +1,55 @@
+"""The secondary modes of bench.py at toy sizes: each prints one well-formed JSON line with the contract's keys and a
+`roofline` object (so that the lines committed under profiles/ cannot rot unnoticed).  Child processes."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+        'dtype', 'data', 'config', 'roofline')
+
+
+def line_of(args):
+  out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, capture_output=True, text=True, timeout=900, cwd=ROOT)
+  assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-3000:])
+  rows = [l for l in out.stdout.splitlines() if l.startswith('{')]
+  assert len(rows) == 1, out.stdout[-2000:]
+  line = json.loads(rows[0])
+  for k in KEYS:
+    assert k in line, k
+  r = line['roofline']
+  for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+    assert k in r, k
+  assert line['value'] > 0 and r['achieved'] > 0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
+  assert 'workload' in line['config'] and line['n_gpus'] == 1
+  return line
+
+
+def test_tictactoe_line():
+  line = line_of(['--workload', 'tictactoe', '--envs', '256', '--steps', '16', '--warmup', '4', '--no-cpu-baseline', '--min-seconds', '0.2'])
+  assert 'TicTacToe on the device' in line['config']['environment'] and line['roofline']['bound'] == 'mfma'
+  assert line['roofline']['moves_per_launch'] == 8          # whole moves inside the two-player launch
+  assert 0.5 * 256 * line['timed_steps'] < line['value'] * line['timed_seconds'] < 1.5 * 256 * line['timed_steps']
+
+
+def test_tree_line():
+  line = line_of(['--workload', 'tree', '--envs', '512', '--steps', '4', '--warmup', '1'])
+  r = line['roofline']
+  assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and set(r['per_kernel']) == {'k_tree_select', 'k_tree_expand_backup'}
+  assert all(v['us_per_launch'] > 1.0 for v in r['per_kernel'].values()) and line['config']['mean_leaf_depth'] > 1.5
+
+
+def test_breakout_line():
+  line = line_of(['--workload', 'breakout', '--envs', '32', '--steps', '2', '--warmup', '1'])
+  assert line['config']['host_syncs_in_simulation_loop'] == 0 and line['record_bytes_per_env_step'] == 4 * (4 * 96 * 96 // 4 + 4 + 10)
+  assert line['network_calls']['recurrent_inference_ms'] > 0
+
+
+def test_pong_split_line():
+  line = line_of(['--workload', 'pong', '--split-f16', '--envs', '256', '--steps', '16', '--warmup', '4', '--no-cpu-baseline',
+                  '--min-seconds', '0.2'])
+  assert line.get('secondary_line') and line['roofline']['kernel'] == 'k_search_h2' and 'f16x2' in line['dtype']
