@@ -464,7 +464,9 @@ __device__ __forceinline__ float mz_support_to_scalar_q(const f32x4 &raw, int sm
 #define MZ_FUSED_MAXPL 64   // search-path slots per tree kept in LDS: num_simulations + 2 <= 64
 #define MZ_FUSED_LDS_BASE (16 * MZ_HS + 4 * 6 * 256 + 16 + 16 + 16 * 32 + 96 + 64 + 64 + 64 + 2 * 16 * MZ_XE + 16 * MZ_FUSED_MAXPL + 2 * MZ_FUSED_MAXPL)
 // + the tree step's own staging [16][96] doubles, except beside large trees (LT = 2), where it shares the partials' space
-__host__ __device__ constexpr int mz_fused_lds_floats(int lt) { return MZ_FUSED_LDS_BASE + 16 * 96 * 2; }
+// + [16][MZ_ENVW] words of per-environment state a whole-moves launch keeps across its moves (mz_root_body, envs)
+#define MZ_ENVW 16
+__host__ __device__ constexpr int mz_fused_lds_floats(int lt) { return MZ_FUSED_LDS_BASE + 16 * 96 * 2 + 16 * MZ_ENVW; }
 
 // PROF: diagnostic build only (mz_search_phase_profile): per-wave cycle totals of each phase of the loop.
 #define MZ_NPHASE 14
@@ -495,7 +497,9 @@ __host__ __device__ inline size_t mz_fused_dyn_lds(int sims, int NN, int lt) {
 template <int TL, int LT, bool GAME = false>
 __device__ __forceinline__ void mz_finalize_record(const TreeView &t, const TreeMem<LT> &tm, const SelfplayState &sp,
                                                    int b, int lane, uint32_t legal, uint64_t seed, double *stage,
-                                                   int O) {
+                                                   int O, int *envs = nullptr) {
+  // envs (LDS, optional): this environment's 8 words of state kept by the whole-moves launch (mz_root_body): read here
+  // instead of five dependent global loads, updated for the next move of the launch
   const int A = t.A;
   const bool ok = lane < A && ((legal >> lane) & 1u);
   const int c = ok ? (int)tm.N[1 + lane] : 0;
@@ -506,27 +510,28 @@ __device__ __forceinline__ void mz_finalize_record(const TreeView &t, const Tree
   int *acts = (int *)(stage + 32);
   const int pos = __popc(legal & ((1u << lane) - 1u));
   if (ok) { d[pos] = (double)c; acts[pos] = lane; }
-  const unsigned long long move = sp.movecnt[b];
+  const unsigned long long move = envs ? *(const unsigned long long *)envs : sp.movecnt[b];
   float *rec = sp.ring + ((size_t)(move % (unsigned long long)sp.ring_moves) * t.B + b) * sp.rec_floats;
-  for (int k = lane; k < O; k += TL) rec[k] = sp.obs[(size_t)b * O + k];
+  if (envs && O <= MZ_ENVW - 8) { if (lane < O) rec[lane] = ((const float *)envs)[8 + lane]; }
+  else for (int k = lane; k < O; k += TL) rec[k] = sp.obs[(size_t)b * O + k];
   if (lane < A) rec[O + lane] = (float)(ok ? (double)c / (double)sumv : 0.0);
   if (lane == 0) {
     const int n = __popc(legal);
     const int N0 = (int)tm.N[0];
     const double rv = N0 == 0 ? 0.0 : tm.W[0] / (double)N0;
-    const double err = rv - (double)t.root_value[b];
+    const double err = rv - (double)(envs ? __builtin_bit_cast(float, envs[6]) : t.root_value[b]);
     const uint32_t env = (uint32_t)(sp.env_offset + b);
     const mz_u4 r = mz_philox(seed, env, (uint32_t)move, (uint32_t)(move >> 32), MZ_RNG_ACTION << 24);
     double u = mz_u01(r.x, r.y);
     if constexpr (GAME) { if (sp.draw_uniform) u = sp.draw_uniform[b]; }
-    const int idx = mz_sample_index(d, n, sp.temp[b], u);
+    const int idx = mz_sample_index(d, n, envs ? *(const double *)(envs + 4) : sp.temp[b], u);
     const int action = acts[idx];
     if constexpr (GAME) {
       mz_ttt_apply(sp, b, action, rv, err, rec, A);
       sp.movecnt[b] = move + 1ull;
       return;
     }
-    const int tt = sp.t[b], ep = sp.episode[b];
+    const int tt = envs ? envs[2] : sp.t[b], ep = envs ? envs[3] : sp.episode[b];
     const int done = (tt + 1 >= sp.episode_len) ? 1 : 0;
     mz_rec_put_double(rec + O + A + 0, rv);
     mz_rec_put_double(rec + O + A + 2, err);
@@ -534,11 +539,15 @@ __device__ __forceinline__ void mz_finalize_record(const TreeView &t, const Tree
     int32_t *ri = (int32_t *)(rec + O + A + 5);
     ri[0] = action; ri[1] = done; ri[2] = tt; ri[3] = (int32_t)env; ri[4] = ep;
     if (done) {      // the next game starts: its temperature is evaluated now (actors.py:128-129)
-      sp.t[b] = 0; sp.episode[b] = ep + 1; sp.temp[b] = *sp.temp_next;
+      const double tn = *sp.temp_next;
+      sp.t[b] = 0; sp.episode[b] = ep + 1; sp.temp[b] = tn;
+      if (envs) { envs[2] = 0; envs[3] = ep + 1; *(double *)(envs + 4) = tn; }
     } else {
       sp.t[b] = tt + 1;
+      if (envs) envs[2] = tt + 1;
     }
     sp.movecnt[b] = move + 1ull;
+    if (envs) *(unsigned long long *)envs = move + 1ull;
   }
 }
 
@@ -547,7 +556,7 @@ template <int JTP, int G, bool SELFPLAY, bool GAME, class STAMPF>
 __device__ __forceinline__ void mz_root_body(const NetView &n, const TreeView &t, const float *obs_in,
                                              const f32x4 *istream, int nst0, const SelfplayState &sp, uint64_t seed,
                                              double alpha, double frac, float *smem, int tid, double *root_stage,
-                                             STAMPF stampf);
+                                             STAMPF stampf, int *envs = nullptr);
 // HEAD instantiations: what the root needs, and how many moves the launch plays
 struct MzRootArgs {
   const f32x4 *istream;      // the root network's weight stream (k_root's)
@@ -605,6 +614,7 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
   // [16][96] staging of the tree step: its own (the tree step of one wave overlaps other waves' epilogue), except
   // beside large trees, where it shares the partials' space and the tree step starts behind a barrier
   double *s_stage = (double *)(s_rcp + MZ_FUSED_MAXPL);
+  int *s_env = (int *)(s_stage + 16 * 96);      // [16][MZ_ENVW], HEAD launches only
 
   const int tid0 = threadIdx.x;
   const int b0 = blockIdx.x * MZ_ROWS;
@@ -631,6 +641,15 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
   }
 
   const int nmoves = HEAD ? ra.nmoves : 1;
+  constexpr bool ENVS = HEAD && !GAME;      // per-environment scalars of the synthetic env kept in LDS across the moves
+  if constexpr (ENVS) {
+    if (tid0 < 16 && b0 + tid0 < t.B) {
+      const int b = b0 + tid0;
+      *(unsigned long long *)(s_env + tid0 * MZ_ENVW) = sp.movecnt[b];
+      s_env[tid0 * MZ_ENVW + 2] = sp.t[b]; s_env[tid0 * MZ_ENVW + 3] = sp.episode[b];
+      *(double *)(s_env + tid0 * MZ_ENVW + 4) = sp.temp[b];
+    }
+  }
   // HEAD launches: cycles per phase of a move (s_memtime), accumulated over the launch when `prof` is given
   // (mz_selfplay_phase_profile): 0 root's tree part, 1 ring + barrier, 2 simulations, 3 end of move, 4 root first
   // stage, 5 representation + LayerNorm, 6 prediction, 7 resident steps + tree set-up
@@ -652,7 +671,7 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
     if (ra.nst0 >= 0)
     mz_root_body<JTP, G, true, GAME>(n, t, nullptr, ra.istream, ra.nst0, sp, seed, ra.alpha, ra.frac,
                                (float *)(dyn_lds + (((t.sims + 2) * PBS * 8 + 15) & ~15)), tid_r, s_stage,
-                               [&](int k) __attribute__((always_inline)) { HSTAMP(4 + k) });
+                               [&](int k) __attribute__((always_inline)) { HSTAMP(4 + k) }, ENVS ? s_env : nullptr);
     __syncthreads();
     HSTAMP(0)
   }
@@ -1083,7 +1102,8 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
       const int mt = tid / TL + i * (256 / TL);
-      if (b0 + mt < t.B) mz_finalize_record<TL, LT, GAME>(t, tm[i], sp, b0 + mt, tl, tr[i].legal, seed, s_stage + mt * 96, n.O);
+      if (b0 + mt < t.B) mz_finalize_record<TL, LT, GAME>(t, tm[i], sp, b0 + mt, tl, tr[i].legal, seed, s_stage + mt * 96, n.O,
+                                                           ENVS ? s_env + mt * MZ_ENVW : nullptr);
     }
   }
   // per-tree scalars back to the pool (what export / a later mz_select continue from)

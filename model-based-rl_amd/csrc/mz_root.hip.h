@@ -43,7 +43,11 @@ template <int JTP, int G, bool SELFPLAY, bool GAME = false, class STAMPF>
 __device__ __forceinline__ void mz_root_body(const NetView &n, const TreeView &t, const float *obs_in,
                                              const f32x4 *istream, int nst0, const SelfplayState &sp, uint64_t seed,
                                              double alpha, double frac, float *smem, int tid, double *root_stage,
-                                             STAMPF stampf) {
+                                             STAMPF stampf, int *envs) {
+  // envs (LDS, optional; the whole-moves launch): per row MZ_ENVW words of environment state the launch keeps across its
+  // moves -- [0,1] move counter, [2] step, [3] episode, [4,5] temperature, [6] root value of this move, [8..] the raw
+  // observation if it has at most MZ_ENVW - 8 elements -- so that
+  // neither the root nor the end of the move waits for dependent global loads of per-environment scalars
   using SC = RootSched<JTP>;
   constexpr int NB = MZ_ROOT_NB, NS = SC::NS, E_R2 = SC::R2, E_P1 = E_R2 + SC::P1, NJ2 = 2 + JTP;
   constexpr int XS = MZ_ROOT_XS;
@@ -119,9 +123,11 @@ __device__ __forceinline__ void mz_root_body(const NetView &n, const TreeView &t
             sp.obs[(size_t)b * O + k] = v;
           } else
           if constexpr (SELFPLAY) {   // Game.get_observation(-1) of the synthetic env (game.py:117-121)
-            const uint32_t env = (uint32_t)(sp.env_offset + b), ep = (uint32_t)sp.episode[b], tt = (uint32_t)sp.t[b];
+            const uint32_t env = (uint32_t)(sp.env_offset + b);
+            const uint32_t ep = (uint32_t)(envs ? envs[m * MZ_ENVW + 3] : sp.episode[b]), tt = (uint32_t)(envs ? envs[m * MZ_ENVW + 2] : sp.t[b]);
             v = sp.obs_u8 ? mz_synth_obs_u8(seed, env, ep, tt, (uint32_t)k) : mz_synth_obs_elem(seed, env, ep, tt, (uint32_t)k);
             sp.obs[(size_t)b * O + k] = v;            // History.observations keeps the raw observation (game.py:93-96)
+            if (envs && O <= MZ_ENVW - 8) ((float *)envs)[m * MZ_ENVW + 8 + k] = v;      // (small observations: a copy for the record)
             if (sp.obs_min) v = (v - sp.obs_min[k]) / sp.obs_rng[k];      // actors.py:134-137, float32 like numpy's
           } else {
             v = obs_in[(size_t)b * O + k];
@@ -245,6 +251,7 @@ __device__ __forceinline__ void mz_root_body(const NetView &n, const TreeView &t
         if (q == 0) {
           s_val[col] = v;
           if (live) t.root_value[b0 + col] = v;
+          if (envs) envs[col * MZ_ENVW + 6] = __builtin_bit_cast(int, v);
         }
         for (int a = q; a < n.A; a += 16) {
           const float lg = fin[(32 + a) * 16 + col];
@@ -268,7 +275,7 @@ __device__ __forceinline__ void mz_root_body(const NetView &n, const TreeView &t
       const int mt = tid / TL + i * (256 / TL);
       const int b = b0 + mt;
       if (b < t.B && tl < G) {
-        const uint64_t move = (uint64_t)sp.movecnt[b];
+        const uint64_t move = envs ? (uint64_t)*(const unsigned long long *)(envs + mt * MZ_ENVW) : (uint64_t)sp.movecnt[b];
         double nz;
         if constexpr (GAME) {
           // legal_actions() = the empty cells (tic_tac_toe.py:27-28), game.to_play = env.turn
@@ -316,5 +323,5 @@ __global__ __launch_bounds__(256, 1) void k_root(NetView n, TreeView t, const fl
                                                   int nst0, SelfplayState sp, uint64_t seed, double alpha,
                                                   double frac) {
   __shared__ __attribute__((aligned(16))) float smem[MZ_ROOT_LDS_FLOATS];
-  mz_root_body<JTP, G, SELFPLAY, false>(n, t, obs_in, istream, nst0, sp, seed, alpha, frac, smem, (int)threadIdx.x, nullptr, MzNoStamp());
+  mz_root_body<JTP, G, SELFPLAY, false>(n, t, obs_in, istream, nst0, sp, seed, alpha, frac, smem, (int)threadIdx.x, nullptr, MzNoStamp(), nullptr);
 }
