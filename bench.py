@@ -229,6 +229,48 @@ class Pipeline(object):
     self.work.put(None)
 
 
+def _under_profiler():
+  pre = os.environ.get('LD_PRELOAD', '')
+  return any(k.startswith(('ROCPROF', 'ROCP_', 'ROCTRACER')) for k in os.environ) or 'rocprof' in pre
+
+
+def live_traffic(workload, split_f16, chunk):
+  """HBM-side bytes per launch of the search kernel, measured in THIS run: two child processes -- `rocprofv3 --pmc FETCH_SIZE`
+  and `--pmc WRITE_SIZE` (separate passes, counters only, the program itself behind `--`) around a short run of this very
+  script -- started BEFORE this process touches the GPU.  bytes = 1024 * (2 * FETCH_SIZE + WRITE_SIZE) per launch (KB units
+  and the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md, as scripts/make_traffic.py does).  None where rocprofv3 is
+  missing, the passes fail, or this process is itself being profiled."""
+  import csv, glob, shutil, subprocess, tempfile
+  if _under_profiler() or os.environ.get('MZ_BENCH_CHILD') or not shutil.which('rocprofv3'):
+    return None
+  kernel = 'k_search_h2' if split_f16 else 'k_search_fused'
+  means = {}
+  for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+    d = tempfile.mkdtemp(prefix='mz_pmc_', dir='/tmp')
+    cmd = ['rocprofv3', '--pmc', counter, '--output-format', 'csv', '-d', d, '--', sys.executable, os.path.abspath(__file__),
+           '--steps', '16', '--warmup', '8', '--no-cpu-baseline', '--min-seconds', '0.05', '--workload', workload, '--chunk',
+           str(chunk)] + (['--split-f16'] if split_f16 else [])
+    try:
+      subprocess.run(cmd, env=dict(os.environ, MZ_BENCH_CHILD='1', TMPDIR='/tmp'), cwd='/tmp', stdout=subprocess.DEVNULL,
+                     stderr=subprocess.DEVNULL, timeout=240)
+      n, tot = 0, 0.0
+      for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+        for row in csv.DictReader(open(f, newline='')):
+          if row.get('Counter_Name') == counter and row.get('Kernel_Name', '').replace('void ', '').startswith(kernel):
+            n += 1
+            tot += float(row['Counter_Value'])
+      if n:
+        means[counter] = (tot / n, n)
+    except Exception:
+      pass
+    finally:
+      shutil.rmtree(d, ignore_errors=True)
+  if len(means) != 2:
+    return None
+  return {'bytes_per_launch': 1024.0 * (2.0 * means['FETCH_SIZE'][0] + means['WRITE_SIZE'][0]),
+          'launches': [means['FETCH_SIZE'][1], means['WRITE_SIZE'][1]]}
+
+
 def replay_config():
   return types.SimpleNamespace(batch_size=256, epsilon=0.01, alpha=1.0, beta=1.0, obs_space=(O,), action_space=A,
                                window_size=1 << 21, window_step=None, num_unroll_steps=5, td_steps=10,
@@ -295,6 +337,8 @@ def main():
   ap.add_argument('--one-replay', action='store_true',
                   help='N > 1: the topology of `train --ranks N` -- every rank ships its record chunks through a shared-memory ring '
                        'to rank 0, whose ONE native replay ingests them all (default: one replay per rank; DESIGN.md s6)')
+  ap.add_argument('--no-live-traffic', action='store_true',
+                  help='do not measure roofline.traffic with two rocprofv3 --pmc child runs (N = 1 only; ~20 s)')
   ap.add_argument('--dump-records', default=None,
                   help='(tests) save this rank\'s experience records of the first moves after reset to <path>.rank<r>.npy')
   args = ap.parse_args()
@@ -308,6 +352,10 @@ def main():
 
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
+  # roofline.traffic, live: the two PMC passes run as child processes before this process initialises the GPU
+  measured_traffic = None
+  if world == 1 and 'RANK' not in os.environ and not args.no_live_traffic and not args.envs:
+    measured_traffic = live_traffic(args.workload, args.split_f16, chunk)
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
   dist = None
   backend = None
@@ -477,7 +525,11 @@ def main():
     achieved = flops_per_launch / (launch_us * 1e-6) / 1e12
     traffic, traffic_source = None, None
     tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
-    if os.path.exists(tfile) and WNAME.startswith('Lunar') and B == 4096:
+    if measured_traffic is not None:
+      traffic = measured_traffic['bytes_per_launch']
+      traffic_source = ('measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE child passes of this command '
+                        '(%d / %d launches), 1024 * (2 * FETCH_SIZE + WRITE_SIZE) per launch' % tuple(measured_traffic['launches']))
+    elif os.path.exists(tfile) and WNAME.startswith('Lunar') and B == 4096:
       tj = json.load(open(tfile))
       tk = tj.get('k_search_fused', {})
       # (the PMC passes count per launch; a launch of the profiled command plays moves_per_launch moves)
@@ -551,7 +603,7 @@ def main():
                                'an XCD\'s L2 delivers: that, not the matrix pipe (0.22 busy), bounds the stages (DESIGN.md s3.4)'},
           'note': 'achieved / peak = EXECUTED float16 MFMA FLOP against the dense f16 peak; the algorithmic float32 FLOP of the '
                   'same work are a third of that minus the K padding'}
-    elif world == 1 and O + 1 <= 64 and A <= 13 and not game:
+    elif world == 1 and O + 1 <= 64 and A <= 13 and not game and not os.environ.get('MZ_BENCH_CHILD'):
       # the opt-in split-f16 search kernel on the same workload, as a SECONDARY figure inside the same line (never `value`)
       try:
         out['split_f16_secondary'] = measure_split_f16(device, flat, chunk)

@@ -10,12 +10,12 @@ cd /tmp && export TMPDIR=/tmp
 cd $R
 python3 bench.py > $O/bench_$TAG.json 2> $O/bench_$TAG.err
 tail -c 1500 $O/bench_$TAG.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$TAG -- python3 bench.py --steps 128 --warmup 16 --no-cpu-baseline > $O/bench_prof_$TAG.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$TAG -- python3 bench.py --steps 32 --warmup 4 --no-cpu-baseline > $O/pmc_fetch_$TAG.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_$TAG -- python3 bench.py --steps 32 --warmup 4 --no-cpu-baseline > $O/pmc_write_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$TAG -- python3 bench.py --steps 128 --warmup 16 --no-cpu-baseline --no-live-traffic > $O/bench_prof_$TAG.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$TAG -- python3 bench.py --steps 32 --warmup 4 --no-cpu-baseline --no-live-traffic > $O/pmc_fetch_$TAG.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_$TAG -- python3 bench.py --steps 32 --warmup 4 --no-cpu-baseline --no-live-traffic > $O/pmc_write_$TAG.log 2>&1
 python3 scripts/make_traffic.py $O/pmc_fetch_$TAG $O/pmc_write_$TAG $O/traffic_$TAG.json > /dev/null
 # matrix-pipe utilisation as a counter (its own pass, counters only)
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $O/pmc_mfma_$TAG -- python3 bench.py --steps 32 --warmup 4 --no-cpu-baseline > $O/pmc_mfma_$TAG.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $O/pmc_mfma_$TAG -- python3 bench.py --steps 32 --warmup 4 --no-cpu-baseline --no-live-traffic > $O/pmc_mfma_$TAG.log 2>&1
 python3 scripts/make_mfma_util.py $O/pmc_mfma_$TAG $O/mfma_util_$TAG.json > /dev/null
 python3 scripts/phase_profile.py 8 4 30 ${TAG}_lunar > $O/phase_${TAG}_lunar.txt 2>&1
 python3 scripts/phase_profile.py 128 6 50 ${TAG}_pong > $O/phase_${TAG}_pong.txt 2>&1
