@@ -252,7 +252,7 @@ def live_traffic(workload, split_f16, chunk):
            str(chunk)] + (['--split-f16'] if split_f16 else [])
     try:
       subprocess.run(cmd, env=dict(os.environ, MZ_BENCH_CHILD='1', TMPDIR='/tmp'), cwd='/tmp', stdout=subprocess.DEVNULL,
-                     stderr=subprocess.DEVNULL, timeout=240)
+                     stderr=subprocess.DEVNULL, timeout=90)
       n, tot = 0, 0.0
       for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
         for row in csv.DictReader(open(f, newline='')):
