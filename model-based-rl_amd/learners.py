@@ -190,7 +190,12 @@ class Learner(Logger):
     reward_loss = 0
     value_loss = scalar_loss(value.squeeze(), t_val[:, 0])
     policy_loss = soft_cross_entropy(policy_logits.squeeze(), t_pol[:, 0])
-    for i, action in enumerate(zip(*actions), 1):
+    # the K action columns go to the device ONCE (the reference hands recurrent_inference a Python tuple per unroll step,
+    # learners.py:196-197: one pageable host-to-device copy per step, each of which waits behind whatever else the GPU
+    # runs -- 3 ms per copy beside a self-play loop on the same GPU)
+    act = torch.as_tensor(np.asarray(actions, np.int64), device=dev)
+    for i in range(1, act.shape[1] + 1):
+      action = act[:, i - 1]
       value, reward, policy_logits, hidden = self.network.recurrent_inference(hidden, action)
       hidden.register_hook(lambda grad: grad * 0.5)
       reward_loss = reward_loss + scalar_loss(reward.squeeze(), t_rew[:, i])
