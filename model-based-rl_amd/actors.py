@@ -101,6 +101,8 @@ class Actor(Logger):
     self._game_stats = None
     if state is not None:
       self.load_state(state)
+    from . import gpu_turns
+    gpu_turns.register(self.device, 'actor')
     Logger.__init__(self)
 
   # actors.py:75-79
@@ -256,10 +258,15 @@ class Actor(Logger):
       self._log_games(records_view(buf[:n].numpy(), eng.O, eng.A))
       _call(self.replay_buffer, 'ingest_records', buf, n, eng.B, self.env_base)
 
+    from . import gpu_turns
     while self.training_step < cfg.training_steps and (max_moves is None or self.move_counter < max_moves):
-      eng.selfplay_steps(chunk)
-      buf, n = eng.selfplay_drain(pinned[k & 1], chunk, copy_stream=copy_stream)
-      events[k & 1].record(copy_stream)
+      turn = gpu_turns.turn(self.device)
+      with turn:         # (a learner on the same GPU: one chunk of moves per turn, the GPU to ourselves for it)
+        eng.selfplay_steps(chunk)
+        buf, n = eng.selfplay_drain(pinned[k & 1], chunk, copy_stream=copy_stream)
+        events[k & 1].record(copy_stream)
+        if turn is not gpu_turns.NO_TURNS:
+          events[k & 1].synchronize()
       if pending is not None:
         hand_over(pending)
       pending = (buf, n, events[k & 1])
@@ -298,12 +305,17 @@ class Actor(Logger):
       self._log_games(records_view(buf.numpy(), sp.O, sp.A, obs_u8=sp.obs_u8))
       _call(self.replay_buffer, 'ingest_records', buf, 1, sp.B, self.env_base)
 
+    from . import gpu_turns
     while self.training_step < cfg.training_steps and (max_moves is None or self.move_counter < max_moves):
-      sp.play_move(dev[k & 1])
-      copy_stream.wait_stream(torch.cuda.current_stream(self.device))
-      with torch.cuda.stream(copy_stream):
-        pinned[k & 1][0].copy_(dev[k & 1], non_blocking=True)
-      events[k & 1].record(copy_stream)
+      turn = gpu_turns.turn(self.device)
+      with turn:
+        sp.play_move(dev[k & 1])
+        copy_stream.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(copy_stream):
+          pinned[k & 1][0].copy_(dev[k & 1], non_blocking=True)
+        events[k & 1].record(copy_stream)
+        if turn is not gpu_turns.NO_TURNS:
+          events[k & 1].synchronize()
       if pending is not None:
         hand_over(pending)
       pending = (pinned[k & 1], events[k & 1])

@@ -245,8 +245,16 @@ class Learner(Logger):
     self.throughput['time']['ups'] = time.time()
     last = cfg.training_steps if max_steps is None else min(cfg.training_steps, self.training_step + max_steps)
     log_every = max(1, getattr(cfg, 'learner_log_frequency', 100))
+    from . import gpu_turns
+    if self.device.type == 'cuda':
+      gpu_turns.register(self.device, 'learner')
     while self.training_step < last:
-      self.update_weights(_call(self.replay_buffer, 'sample_batch'))
+      batch = _call(self.replay_buffer, 'sample_batch')
+      turn = gpu_turns.turn(self.device)
+      with turn:         # (an actor on the same GPU: one update per turn, see gpu_turns.py)
+        self.update_weights(batch)
+        if turn is not gpu_turns.NO_TURNS:
+          torch.cuda.current_stream(self.device).synchronize()
       self.training_step += 1
       if self.training_step % cfg.send_weights_frequency == 0:
         self.send_weights()
