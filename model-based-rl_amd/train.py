@@ -100,7 +100,16 @@ def launch_ranks(config, max_moves, selfplay_only=False, learner_steps=None):
   from .engine import flatten_weights
   rstorage = D.RankStorage(rank, world, device, n_flat, storage=storage, storage_call=_call, backend=backend,
                            flatten=flatten_state if torch_net else flatten_weights)
-  actor = Actor(rank, config, rstorage, actor_replay)
+  dedicated = bool(getattr(config, 'dedicated_learner_rank', False)) and world > 1 and not selfplay_only
+  if dedicated and config.environment == 'TicTacToe' and (getattr(config, 'parity_rng', False) or B == 1):
+    raise SystemExit('--dedicated_learner_rank: host-environment actors pull weights per game, not per move count')
+  if dedicated and rank == 0:
+    # rank 0's GPU belongs to the learner alone (an actor beside it would take turns with it, gpu_turns.py, run at a
+    # fraction of the other ranks' pace and hold every rank back at each collective weight pull): rank 0 only joins the
+    # collectives, at the cadence the actors' loops enter them (Actor.run_selfplay)
+    actor = _CollectiveOnly(rank, config, rstorage, chunk)
+  else:
+    actor = Actor(rank, config, rstorage, actor_replay)
   t0 = time.time()
   actor.launch(max_moves)
   if rank > 0:
@@ -125,7 +134,7 @@ def launch_ranks(config, max_moves, selfplay_only=False, learner_steps=None):
                'rank_games': [int(x[2]) for x in every],
                'replay_size': ray.get(replay.size.remote()), 'backend': backend, 'rccl_mapped': D.rccl_mapped(),
                'weights_on_device': bool(rstorage.flat.is_cuda), 'ingest_threads': ray.get(replay.get_ingest_threads.remote()),
-               'drained': not server.is_alive()}
+               'drained': not server.is_alive(), 'dedicated_learner_rank': bool(dedicated)}
     print('MZ_TRAIN_SUMMARY ' + json.dumps(summary), flush=True)
   dist.barrier()
   stop.set()
@@ -136,6 +145,33 @@ def launch_ranks(config, max_moves, selfplay_only=False, learner_steps=None):
   dist.destroy_process_group()
   ray.shutdown()
   return summary
+
+
+class _CollectiveOnly(object):
+  """What a rank without an actor does in `train --ranks N --dedicated_learner_rank`: the weight pulls of
+  Actor.run_selfplay (initial, one per weight_sync_frequency moves, final) and nothing else, so that the collective
+  RankStorage.get_weights stays in step on every rank.  Each pull blocks until the actor ranks arrive."""
+
+  def __init__(self, rank, config, storage, chunk):
+    self.rank, self.config, self.storage, self.chunk = rank, config, storage, chunk
+    self.training_step, self.games_played, self.move_counter = 0, 0, 0
+
+  def _sync(self):
+    from .actors import _call
+    _, self.training_step = _call(self.storage, 'get_weights', self.games_played, self.rank)
+
+  def launch(self, max_moves=None):
+    cfg, chunk = self.config, self.chunk
+    from .actors import _call
+    while not _call(self.storage, 'is_ready'):
+      time.sleep(0.05)
+    self._sync()
+    sync_every = max(1, cfg.weight_sync_frequency)
+    while self.training_step < cfg.training_steps and (max_moves is None or self.move_counter < max_moves):
+      self.move_counter += chunk
+      if (self.move_counter // sync_every) != ((self.move_counter - chunk) // sync_every):
+        self._sync()
+    self._sync()
 
 
 def _spawn_ranks(n, argv):
@@ -161,6 +197,8 @@ def main(argv=None):
   p.add_argument('--learner_steps', type=int, default=None)
   p.add_argument('--ranks', type=int, default=0,
                  help='one process per GPU over torch.distributed: rank 0 = learner + storage + replay + actor 0')
+  p.add_argument('--dedicated_learner_rank', action='store_true',
+                 help='with --ranks N: rank 0 runs no actor -- its GPU is the learner\'s alone, ranks 1..N-1 play')
   args = vars(p.parse_args(argv))
   max_moves, selfplay_only, learner_steps = args.pop('max_moves'), args.pop('selfplay_only'), args.pop('learner_steps')
   ranks = args.pop('ranks')

@@ -153,3 +153,34 @@ def test_rank_storage_and_experience_rings_world2(tmp_path):
                        capture_output=True, text=True, timeout=300)
   assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
   assert out.stdout.count('ok') == 2
+
+
+def test_collective_only_rank_pulls_at_the_actors_cadence():
+  """train --dedicated_learner_rank: the rank without an actor enters the collective weight pull exactly where an actor's
+  device loop does (actors.py of this package, run_selfplay: once up front, whenever the move count crosses a multiple of
+  weight_sync_frequency, once at the end) and stops on the same broadcast training step."""
+  import types
+  from model_based_rl_amd.train import _CollectiveOnly
+
+  class Storage(object):
+    def __init__(self, step_at):
+      self.pulls, self.step_at = 0, step_at
+    def is_ready(self):
+      return True
+    def get_weights(self, games, key):
+      self.pulls += 1
+      return None, self.step_at(self.pulls)
+
+  cfg = types.SimpleNamespace(weight_sync_frequency=16, training_steps=100)
+  st = Storage(lambda n: 0)
+  c = _CollectiveOnly(0, cfg, st, 8)
+  c.launch(max_moves=64)
+  assert st.pulls == 1 + 4 + 1 and c.move_counter == 64
+  st = Storage(lambda n: 100 if n >= 4 else n)              # the learner finishes: seen at the 4th pull, the loop ends there
+  c = _CollectiveOnly(0, cfg, st, 8)
+  c.launch(max_moves=None)
+  assert st.pulls == 4 + 1 and c.training_step == 100 and c.move_counter == 48
+  st = Storage(lambda n: 0)                                 # one move per iteration (the torch-network actors)
+  c = _CollectiveOnly(0, types.SimpleNamespace(weight_sync_frequency=5, training_steps=9), st, 1)
+  c.launch(max_moves=12)
+  assert st.pulls == 1 + 2 + 1

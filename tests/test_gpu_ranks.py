@@ -146,3 +146,24 @@ def test_bench_two_ranks_into_one_replay():
   assert abs(executed - 2 * B * line['timed_steps']) < 1e-6 * executed
   # frames accepted by the ONE replay = both ranks' (steady state: ~B frames per move and rank)
   assert 0.6 * 2 * B * line['timed_steps'] < line['value'] * line['timed_seconds'] < 1.4 * 2 * B * line['timed_steps']
+
+
+def test_train_with_a_dedicated_learner_rank():
+  """train --ranks 2 --dedicated_learner_rank: rank 0 = learner + storage + the one replay and NO actor (it only joins the
+  collective weight pulls, at the actors' cadence), rank 1 = the only actor.  All experience comes through rank 1's ring,
+  the learner's step and weights reach rank 1, nobody hangs in a collective."""
+  env = dict(os.environ, MZ_DIST_BACKEND='gloo', PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''),
+             HSA_ENABLE_IPC_MODE_LEGACY='0')
+  out = subprocess.run([sys.executable, '-m', 'model_based_rl_amd.train', '--ranks', '2', '--dedicated_learner_rank',
+                        '--environment', 'LunarLander-v2', '--num_envs', '64', '--num_simulations', '8',
+                        '--episode_length', '6', '--max_moves', '-1', '--window_size', '16384', '--stored_before_train',
+                        '1024', '--batch_size', '32', '--training_steps', '6', '--send_weights_frequency', '2',
+                        '--weight_sync_frequency', '8', '--seed', '3', '--use_gpu_for', 'actors', 'learner'],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+  assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+  s = json.loads([l for l in out.stdout.splitlines() if l.startswith('MZ_TRAIN_SUMMARY ')][-1][len('MZ_TRAIN_SUMMARY '):])
+  assert s['ranks'] == 2 and s['training_step'] == 6 and s['rank_training_steps'] == [6, 6]
+  assert s['rank_weight_sums'][0] == s['rank_weight_sums'][1]
+  assert s['rank_games'][0] == 0 and s['rank_games'][1] > 0 and s['games'] == s['rank_games'][1]
+  assert s['frames'] >= 1024 and s['drained'] and s['dedicated_learner_rank']
+  assert 'Actor-0' not in out.stdout and 'Actor-1 is online' in out.stdout
