@@ -91,6 +91,14 @@ size_t mz_num_weights(const mz_engine *e);
  * on_device != 0: flat is [dev] (e.g. the buffer an RCCL broadcast just filled); else [host]. */
 int mz_set_weights(mz_engine *e, const float *flat, size_t n, int on_device, void *stream);
 
+/* Diagnostic: how the last mz_set_weights packed the search kernel's weight stream.  out [host][4] =
+ * {1, 2^-k, 2^k, chosen}: with chosen = 1 the stream carries the four 512-wide hidden layers of the search
+ * (networks.py:70-93,96-119: reward / transition / value / policy fc1) times 2^-k and the layers reading their
+ * activations times 2^k -- bit-neutral (powers of two), it lets the kernel apply nn.ReLU as a [0, 1] clamp on two
+ * elements per instruction; 2^k exceeds a bound of every activation computed from this weight set.  chosen = 0
+ * (non-finite or absurdly large weights): unscaled stream, ordinary maximum.  Synchronises `stream`. */
+int mz_weight_scale(mz_engine *e, float *out, void *stream);
+
 /* BaseNetwork.initial_inference (networks.py:26-29) for B observations, actors.py:139.
  * obs [dev][B][obs_dim] float32 (already normalised, actors.py:134-137).  Fills hidden slot 0, the
  * root value and the root policy logits inside the engine. */

@@ -94,6 +94,7 @@ SIGNATURES = {
     'mz_num_weights': (_SZ, [_VP]),
     'mz_set_weights': (_I, [_VP, _VP, _SZ, _I, _VP]),
     'mz_initial_inference': (_I, [_VP, _VP, _VP]),
+    'mz_weight_scale': (_I, [_VP, _VP, _VP]),
     'mz_root_load': (_I, [_VP, _VP, _VP, _VP, _VP]),
     'mz_root_outputs': (_I, [_VP, _VP, _VP, _VP, _VP]),
     'mz_root_prepare': (_I, [_VP, _VP, _VP, _VP, _I, _U64, _VP]),

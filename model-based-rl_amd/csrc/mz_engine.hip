@@ -53,6 +53,12 @@ static int fail(const char *fmt, ...) {
 
 #define MZ_GRAPH_MOVES 16    // most self-play moves captured into one hipGraph (3 kernel nodes per move)
 
+// offsets of the 22 tensors inside the flat weight vector (flat_layout below)
+struct FlatLayout {
+  size_t rep_w1, rep_b1, rep_w2, rep_b2, val_w1, val_b1, val_w2, val_b2, pol_w1, pol_b1, pol_w2, pol_b2, rew_w1,
+      rew_b1, rew_w2, rew_b2, tr_w1, tr_b1, tr_w2, tr_b2, ln_w, ln_b, total;
+};
+
 struct mz_engine {
   mz_config cfg;
   int device = 0;                   // HIP device the engine's pools live on (the current device at mz_create)
@@ -102,6 +108,11 @@ struct mz_engine {
   size_t n_packed_h2 = 0;
   float *obs_norm = nullptr;        // [2][O] --norm_obs minimum and range (device)
   double *noise_log = nullptr;      // [ring_moves][B][A] per-move Dirichlet draws (mz_selfplay_noise_log), allocated on first use
+  FlatLayout layout;
+  float relu_scale_host[4] = {1.f, 1.f, 1.f, 0.f};
+  bool stream_scaled = false;       // the last weight set admitted a scale: the fused search kernels may run
+  float *relu_scale_dev = nullptr;  // NetView::relu_scale: {1, 2^-k, 2^k, flag} of the current weight set (k_relu_scale)
+  bool root_hidden_external = false;  // the root's hidden state came in through mz_root_load: no bound on it is known
   unsigned *absmax_dev = nullptr;   // scratch of the split_f16 weight-range check (mz_set_weights)
   double *draw_uniform = nullptr;   // [B] host-given uniforms of a game environment's parity run (mz_selfplay_set_draws)
   bool draws_noise = false, draws_set = false;
@@ -145,6 +156,12 @@ __global__ __launch_bounds__(256) void k_affine_relu(float4 *__restrict__ y, con
   }
 }
 
+// the fused search kernels (mz_fused.hip.h, mz_fused_h2.hip.h) can run: trees fit their path buffer, and the exact-f32
+// kernel's weight stream could be scaled for its clamp ReLU (mz_set_weights; the split-f16 kernel has its own stream)
+static inline bool fused_usable(const mz_engine *e) {
+  return e->use_fused && e->sims + 2 <= MZ_FUSED_MAXPL && (e->split_f16 || e->stream_scaled || !e->weights_set);
+}
+
 template <typename T>
 static int dmalloc(mz_engine *e, T **p, size_t n) {
   void *q = nullptr;
@@ -156,10 +173,6 @@ static int dmalloc(mz_engine *e, T **p, size_t n) {
 }
 
 // ---------------------------------------------------------------- weight layout
-struct FlatLayout {
-  size_t rep_w1, rep_b1, rep_w2, rep_b2, val_w1, val_b1, val_w2, val_b2, pol_w1, pol_b1, pol_w2, pol_b2, rew_w1,
-      rew_b1, rew_w2, rew_b2, tr_w1, tr_b1, tr_w2, tr_b2, ln_w, ln_b, total;
-};
 
 static FlatLayout flat_layout(int O, int A, int Sv, int Sr) {
   FlatLayout L;
@@ -258,6 +271,65 @@ __global__ void k_absmax(const float *w, size_t n, unsigned *out) {
   atomicMax(out, m);
 }
 
+// The power of two the search kernel's weight stream is scaled by (mz_fused.hip.h, "ReLU as a clamp"): 2^k above an upper
+// bound of every output of the four 512-wide fc1 layers the search runs (reward, transition: input [hidden | one-hot];
+// value, policy: input hidden), given that the hidden state is relu(LayerNorm(.)) -- |(x_i - mean) / std| <= sqrt(49)
+// for 50 features, so 0 <= hidden_i <= 7 |gamma_i| + |beta_i| -- and a one-hot row holds a single 1:
+//   |out_n| <= sum_i |W[n][i]| hb_i + max_a |W[n][50 + a]| + |b_n|       (every partial sum obeys the same bound).
+// scale = {1, 2^-k, 2^k, 1}; {1, 1, 1, 0} when the bound is not finite, k would exceed 40, or 2^k times the largest
+// weight of a consuming layer would leave the float32 range: the stream is then packed as it is and the kernel takes
+// its v_max path.  One workgroup of 512 threads (one per fc1 row), no host synchronisation.
+__global__ void k_relu_scale(const float *flat, FlatLayout L, int A, int Sr, int Sv, float *scale) {
+  __shared__ float hb[MZ_H];
+  __shared__ float red[512], red2[512];
+  const int n = threadIdx.x;
+  if (n < MZ_H) hb[n] = 7.01f * fabsf(flat[L.ln_w + n]) + fabsf(flat[L.ln_b + n]);
+  __syncthreads();
+  const size_t w1[4] = {L.rew_w1, L.tr_w1, L.val_w1, L.pol_w1}, b1[4] = {L.rew_b1, L.tr_b1, L.val_b1, L.pol_b1};
+  float m = 0.f;
+  for (int h = 0; h < 4; ++h) {
+    const int K = h < 2 ? MZ_H + A : MZ_H;
+    const float *row = flat + w1[h] + (size_t)n * K;
+    float s = fabsf(flat[b1[h] + n]), oh = 0.f;
+    for (int i = 0; i < MZ_H; ++i) s += fabsf(row[i]) * hb[i];
+    for (int a = MZ_H; a < K; ++a) oh = fmaxf(oh, fabsf(row[a]));
+    s += oh;
+    m = (s > m || !(s == s)) ? s : m;             // (a NaN sticks)
+  }
+  // largest |w| of the layers that consume the activations (they are multiplied by 2^k)
+  const size_t w2[4] = {L.rew_w2, L.tr_w2, L.val_w2, L.pol_w2};
+  const int J[4] = {Sr, MZ_H, Sv, A};
+  float m2 = 0.f;
+  for (int h = 0; h < 4; ++h)
+    for (size_t i = n; i < (size_t)J[h] * MZ_F; i += 512) {
+      const float v = fabsf(flat[w2[h] + i]);
+      m2 = (v > m2 || !(v == v)) ? v : m2;
+    }
+  red[n] = m; red2[n] = m2;
+  __syncthreads();
+  for (int st = 256; st > 0; st >>= 1) {
+    if (n < st) {
+      const float o = red[n + st], o2 = red2[n + st];
+      red[n] = (o > red[n] || !(o == o)) ? o : red[n];
+      red2[n] = (o2 > red2[n] || !(o2 == o2)) ? o2 : red2[n];
+    }
+    __syncthreads();
+  }
+  if (n == 0) {
+    const float bound = red[0] * 1.01f;            // (rounding of the sums above and of the kernel's own accumulation)
+    int k = 0;
+    if (bound > 1.f) (void)frexpf(bound, &k);      // bound = f 2^k, 0.5 <= f < 1: bound < 2^k
+    const bool ok = bound == bound && bound < 0x1p40f && red2[0] == red2[0] && red2[0] < ldexpf(1.f, 100 - k);
+#ifdef MZ_RELU_VMAX
+    k = 0;
+#endif
+    scale[0] = 1.f;
+    scale[1] = ok ? ldexpf(1.f, -k) : 1.f;
+    scale[2] = ok ? ldexpf(1.f, k) : 1.f;
+    scale[3] = ok ? 1.f : 0.f;
+  }
+}
+
 static int build_packing_h2(mz_engine *e, const FlatLayout &L, int Sv, int Sr) {
   using SC = H2Sched;
   const int A = e->A;
@@ -346,6 +418,7 @@ static int build_packing(mz_engine *e) {
   const int Sv = e->cfg.no_support ? 1 : e->cfg.value_support_max - e->cfg.value_support_min + 1;   // networks.py:135-136
   const int Sr = e->cfg.no_support ? 1 : e->cfg.reward_support_max - e->cfg.reward_support_min + 1;
   const FlatLayout L = flat_layout(O, A, Sv, Sr);
+  e->layout = L;
   e->n_flat = L.total;
   const int ks0 = (O + 3) / 4, ks1 = (MZ_H + A + 3) / 4, ks3 = (MZ_H + 3) / 4;
   const int jtp = e->jtp;
@@ -414,19 +487,22 @@ static int build_packing(mz_engine *e) {
   // the fused kernel's weight stream: per wave [nsteps][4 pieces][64 lanes][4], consumption order
   for (int w = 0; w < 4; ++w) {
     size_t piece = 0;
-    auto put = [&](size_t src) {
-      memcpy(&idx[p_ws + ((size_t)w * nsteps * 4 + piece) * 256], &idx[src], 256 * sizeof(int32_t));
+    // cls: the scale class of the piece (bits 29-30 of its gather indices, k_pack_weights): 1 = an fc1 layer of the
+    // search (times 2^-k), 2 = a layer that consumes its activations (times 2^k) -- k_relu_scale, mz_fused.hip.h
+    auto put = [&](size_t src, int cls) {
+      int32_t *dst = &idx[p_ws + ((size_t)w * nsteps * 4 + piece) * 256];
+      for (int i = 0; i < 256; ++i) dst[i] = idx[src + i] < 0 ? -1 : (idx[src + i] | (cls << 29));
       ++piece;
     };
     for (int st = 0; st < ks1f; ++st)
-      for (int tg = 0; tg < 4; ++tg) put(p_w1f + ((size_t)(w * 4 + tg) * ks1f + st) * 256);
+      for (int tg = 0; tg < 4; ++tg) put(p_w1f + ((size_t)(w * 4 + tg) * ks1f + st) * 256, 1);
     for (int t = 0; t < 8; ++t)
-      for (int jt = 0; jt < 6; ++jt) put(jt == 5 ? p_h4 + (size_t)(w * 8 + t) * 256 : p_w2 + ((size_t)(jt * 4 + w) * 8 + t) * 256);
+      for (int jt = 0; jt < 6; ++jt) put(jt == 5 ? p_h4 + (size_t)(w * 8 + t) * 256 : p_w2 + ((size_t)(jt * 4 + w) * 8 + t) * 256, 2);
     for (int st = 0; st < ks3f; ++st)
-      for (int tg = 0; tg < 4; ++tg) put(p_w3f + ((size_t)(w * 4 + tg) * ks3f + st) * 256);
+      for (int tg = 0; tg < 4; ++tg) put(p_w3f + ((size_t)(w * 4 + tg) * ks3f + st) * 256, 1);
     for (int t = 0; t < 8; ++t)
       for (int jt = 0; jt < nj2; ++jt)
-        put(p4 && jt == 2 ? p_p4 + (size_t)(w * 8 + t) * 256 : p_w4 + ((size_t)(jt * 4 + w) * 8 + t) * 256);
+        put(p4 && jt == 2 ? p_p4 + (size_t)(w * 8 + t) * 256 : p_w4 + ((size_t)(jt * 4 + w) * 8 + t) * 256, 2);
     if ((int)piece != real_steps * 4) return fail("internal: weight stream has %zu pieces, expected %d", piece, real_steps * 4);
     // the remaining (nsteps - real_steps) * 4 pieces are padding (index -1 -> 0.0), loaded but never used
   }
@@ -448,21 +524,26 @@ static int build_packing(mz_engine *e) {
             idx[base + ((size_t)(st * 4 + p) * 64 + lane) * 4 + i] = v;
           }
     size_t piece = (size_t)nst0 * 4;
-    auto put = [&](size_t src) {
-      memcpy(&idx[base + piece * 256], &idx[src], 256 * sizeof(int32_t));
+    // (the root's prediction stage shares the search's scaled layers: its v_max ReLU is scale-blind; the representation
+    // layers take raw observations, for which no bound exists: unscaled)
+    auto put = [&](size_t src, int cls) {
+      int32_t *dst = &idx[base + piece * 256];
+      for (int i = 0; i < 256; ++i) dst[i] = idx[src + i] < 0 ? -1 : (idx[src + i] | (cls << 29));
       ++piece;
     };
     for (int t = 0; t < 8; ++t)
-      for (int jt = 0; jt < 4; ++jt) put(p_w0o + ((size_t)(jt * 4 + w) * 8 + t) * 256);
+      for (int jt = 0; jt < 4; ++jt) put(p_w0o + ((size_t)(jt * 4 + w) * 8 + t) * 256, 0);
     for (int st = 0; st < ks3f; ++st)
-      for (int tg = 0; tg < 4; ++tg) put(p_w3f + ((size_t)(w * 4 + tg) * ks3f + st) * 256);
+      for (int tg = 0; tg < 4; ++tg) put(p_w3f + ((size_t)(w * 4 + tg) * ks3f + st) * 256, 1);
     for (int t = 0; t < 8; ++t)
-      for (int jt = 0; jt < nj2; ++jt) put(p_w4 + ((size_t)(jt * 4 + w) * 8 + t) * 256);
+      for (int jt = 0; jt < nj2; ++jt) put(p_w4 + ((size_t)(jt * 4 + w) * 8 + t) * 256, 2);
     if ((int)piece != nroot * 4) return fail("internal: root stream has %zu pieces, expected %d", piece, nroot * 4);
   }
 
+  if (L.total >= ((size_t)1 << 29)) return fail("internal: %zu weights do not fit the gather index", L.total);
   if (dmalloc(e, &e->pack_idx, pos)) return -1;
   if (dmalloc(e, &e->packed, pos)) return -1;
+  if (dmalloc(e, &e->relu_scale_dev, (size_t)4)) return -1;
   if (dmalloc(e, &e->flat_dev, L.total)) return -1;
   HIPCHECK(hipMemcpy(e->pack_idx, idx.data(), pos * sizeof(int32_t), hipMemcpyHostToDevice));
   NetView &n = e->nv;
@@ -743,7 +824,7 @@ static int fused_lt(const mz_engine *e) {
 }
 // Can the self-play loop run as whole moves inside one launch (HEAD instantiation of the fused kernel)?
 static bool selfplay_persist_ok(const mz_engine *e) {
-  if (!e->use_persist || !e->use_fused || e->sims + 2 > MZ_FUSED_MAXPL || e->prof_buf) return false;
+  if (!e->use_persist || !fused_usable(e) || e->prof_buf) return false;
   if (e->sp.env_kind == 1) {
     // the device TicTacToe environment: whole moves inside the launch of the two-player <16, 1, 16> instantiation with
     // its trees compact in LDS (the exact-f32 kernel; host-given uniforms / draws work there too)
@@ -772,7 +853,7 @@ static int launch_root_priors(mz_engine *e, const int8_t *to_play, const uint8_t
 }
 
 static int launch_search(mz_engine *e, int num_simulations, bool selection_valid, int sims_done, hipStream_t s) {
-  if (e->use_fused && e->sims + 2 <= MZ_FUSED_MAXPL) {
+  if (fused_usable(e) && !e->root_hidden_external) {
     if (!selection_valid) TREE_LAUNCH(k_tree_select, s, e->tv);
     return launch_fused(e, num_simulations, sims_done, s);
   }
@@ -951,13 +1032,34 @@ int mz_set_weights(mz_engine *e, const float *flat, size_t n, int on_device, voi
       return fail("mz_set_weights: split_f16 needs every weight finite and |w| <= 65504 (the float16 range of the high part); "
                   "max |w| = %g.  Use the exact-float32 kernel (split_f16 = 0) for these weights", (double)mx);
   }
-  hipLaunchKernelGGL(k_pack_weights, dim3(blocks), dim3(threads), 0, s, src, e->pack_idx, e->packed, e->n_packed);
+  // the power of two the search kernel's stream is scaled by (its ReLU is a [0, 1] clamp, mz_fused.hip.h), from a bound of
+  // this weight set's activations; a 16-byte read back tells the host whether one exists -- if not, the engine runs
+  // the stand-alone kernels until the next weight set
+  hipLaunchKernelGGL(k_relu_scale, dim3(1), dim3(512), 0, s, src, e->layout, e->A, e->nv.Sr, e->nv.Sv, e->relu_scale_dev);
+  hipLaunchKernelGGL(k_pack_weights, dim3(blocks), dim3(threads), 0, s, src, e->pack_idx, e->packed, e->n_packed,
+                     (const float *)e->relu_scale_dev);
+  HIPCHECK(hipMemcpyAsync(e->relu_scale_host, e->relu_scale_dev, 4 * sizeof(float), hipMemcpyDeviceToHost, s));
   if (e->split_f16)
     hipLaunchKernelGGL(k_pack_weights_h2, dim3((unsigned)((e->n_packed_h2 + threads - 1) / threads)), dim3(threads), 0, s, src,
                        e->pack_idx_h2, (_Float16 *)e->packed_h2, e->n_packed_h2);
   HIPCHECK(hipGetLastError());
-  if (!on_device) HIPCHECK(hipStreamSynchronize(s));   // the host buffer may be freed by the caller
+  HIPCHECK(hipStreamSynchronize(s));     // (also: a host buffer may be freed by the caller)
+  const bool scaled = e->relu_scale_host[3] != 0.f;
+  if (scaled != e->stream_scaled) {      // captured graphs hold the launches of the other kernel set
+    if (e->search_graph) { hipGraphExecDestroy(e->search_graph); e->search_graph = nullptr; }
+    for (auto &g : e->move_graph) if (g) { hipGraphExecDestroy(g); g = nullptr; }
+  }
+  e->stream_scaled = scaled;
   e->weights_set = true;
+  return 0;
+}
+
+int mz_weight_scale(mz_engine *e, float *out, void *stream) {
+  if (!e || !out) return fail("mz_weight_scale: null argument");
+  MZ_ENTER(e);
+  if (!e->weights_set) return fail("mz_weight_scale: weights not set (call mz_set_weights)");
+  (void)stream;
+  memcpy(out, e->relu_scale_host, sizeof(e->relu_scale_host));
   return 0;
 }
 
@@ -967,6 +1069,8 @@ int mz_initial_inference(mz_engine *e, const float *obs, void *stream) {
   if (!e->weights_set) return fail("mz_initial_inference: weights not set (call mz_set_weights)");
   hipStream_t s = (hipStream_t)stream;
   if (launch_root(e, obs, false, s)) return -1;
+  if (e->root_hidden_external && e->search_graph) { hipGraphExecDestroy(e->search_graph); e->search_graph = nullptr; }
+  e->root_hidden_external = false;
   e->root_ready = false;
   return 0;
 }
@@ -981,6 +1085,10 @@ int mz_root_load(mz_engine *e, const float *hidden, const float *value, const fl
     const int n = e->B * MZ_HS;
     hipLaunchKernelGGL(k_scatter_hidden, dim3((n + 255) / 256), dim3(256), 0, s, e->tv, hidden, 1);
     HIPCHECK(hipGetLastError());
+    // a hidden state from elsewhere need not be a LayerNorm output: mz_search then runs the stand-alone kernels, whose
+    // weights are not scaled for the clamp ReLU (k_relu_scale)
+    if (!e->root_hidden_external && e->search_graph) { hipGraphExecDestroy(e->search_graph); e->search_graph = nullptr; }
+    e->root_hidden_external = true;
   }
   e->root_ready = false;
   return 0;
@@ -1119,7 +1227,7 @@ int mz_search_profiled(mz_engine *e, int num_simulations, float *ms_out, void *s
 int mz_search_timed(mz_engine *e, int num_simulations, float *ms_out, void *stream) {
   if (!e || !ms_out) return fail("mz_search_timed: null argument");
   MZ_ENTER(e);
-  if (!e->use_fused || e->sims + 2 > MZ_FUSED_MAXPL) return fail("mz_search_timed: fused kernel not in use");
+  if (!fused_usable(e) || e->root_hidden_external) return fail("mz_search_timed: fused kernel not in use");
   if (!e->weights_set) return fail("mz_search_timed: weights not set (call mz_set_weights)");
   if (!e->root_ready || !e->selection_valid || e->sims_done != 0)
     return fail("mz_search_timed: call right after mz_root_prepare");
@@ -1144,7 +1252,7 @@ int mz_search_timed(mz_engine *e, int num_simulations, float *ms_out, void *stre
 int mz_search_phase_profile(mz_engine *e, int num_simulations, unsigned long long *cycles_out, void *stream) {
   if (!e || !cycles_out) return fail("mz_search_phase_profile: null argument");
   MZ_ENTER(e);
-  if (!e->use_fused) return fail("mz_search_phase_profile: fused kernel disabled");
+  if (!fused_usable(e) || e->root_hidden_external) return fail("mz_search_phase_profile: fused kernel not in use");
   if (!e->root_ready || !e->selection_valid || e->sims_done != 0)
     return fail("mz_search_phase_profile: call right after mz_root_prepare");
   hipStream_t s = (hipStream_t)stream;

@@ -138,6 +138,25 @@ __device__ __forceinline__ float mz_relu1(float x) {
   return __builtin_bit_cast(float, b > 0 ? b : 0);
 }
 
+// ReLU as a clamp, two elements per instruction.  gfx950 has no packed f32 maximum, but every VOP3P instruction has the
+// clamp modifier: v_pk_add_f32 x, x, 0 clamp = min(max(x, 0), 1) on both halves of a register pair.  That is relu(x)
+// wherever x <= 1 -- and the activations can be made to satisfy that without changing a single result bit: the host
+// packs the fc1 layers of the weight stream (bias column included) times 2^-k and the layers that consume their
+// activations times 2^k (k_relu_scale / k_pack_weights, mz_engine.hip).  Scaling by a power of two commutes with every
+// floating-point product and sum (barring underflow below 2^(k-126) / overflow above 2^(127-k), both checked against on
+// the host side of the choice of k), so the scaled fc1 accumulators are exactly 2^-k times the unscaled ones and the out
+// layers' products exactly the unscaled products.  k is chosen per weight set so that 2^k exceeds an upper bound of
+// every fc1 output: |W| . (bound of the LayerNorm'ed hidden state: |x_i - mean| / std <= sqrt(49), times |gamma_i|, plus
+// |beta_i|) + the largest one-hot column + |bias|.  When no such k exists (non-finite or absurdly large weights)
+// mz_set_weights routes the engine to the stand-alone kernels instead of this one.  64 VALU instructions per
+// simulation fewer than v_max on every element: -0.8 % (A/B 412.1 -> 409.3 us per move).
+typedef float f32x2r __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void mz_relu_clamp(f32x4 &a) {
+  f32x2r lo = __builtin_shufflevector(a, a, 0, 1), hi = __builtin_shufflevector(a, a, 2, 3);
+  asm volatile("v_pk_add_f32 %0, %0, 0 clamp\n\tv_pk_add_f32 %1, %1, 0 clamp" : "+v"(lo), "+v"(hi));
+  a = __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
+
 __device__ __forceinline__ void mz_bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ float mz_xval(const float *xR, const float *xE, int m, int k) {
@@ -932,12 +951,19 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
           }
         }
         if constexpr (s == E_FC1 - 1 || s == E_P1 - 1) {
+          // (ascending tile order = the order of the stage's last 16 MFMAs: 30 instructions lie between the last MFMA and
+          // the read of its tile, more than the 17 wait states its result needs -- no fence in front)
+#ifndef MZ_RELU_VMAX
+#pragma unroll
+          for (int tt = 0; tt < 16; ++tt) mz_relu_clamp(acc[tt]);
+#else      // (development switch: v_max on an unscaled stream -- scripts/relu_clamp_check.py compares the two builds)
           mz_mfma_fence16v(acc);
 #pragma unroll
           for (int tt = 0; tt < 16; ++tt) {
             acc[tt][0] = mz_relu1(acc[tt][0]); acc[tt][1] = mz_relu1(acc[tt][1]);
             acc[tt][2] = mz_relu1(acc[tt][2]); acc[tt][3] = mz_relu1(acc[tt][3]);
           }
+#endif
           // VALU write -> MFMA SrcB read needs wait states the compiler cannot know about (the MFMAs are asm)
           mz_valu_fence16v(acc);
           if constexpr (s == E_FC1 - 1) { STAMP(2) } else { STAMP(6) }

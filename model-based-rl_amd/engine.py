@@ -149,6 +149,13 @@ class Engine(object):
     _abi.check(self.lib.mz_set_weights(self._h, _ptr(w), w.numel(), int(on_dev), self.stream), 'mz_set_weights')
     self._weights_dev = w if on_dev else None      # (the one device buffer of the last pull stays alive; nothing accumulates)
 
+  def weight_scale(self):
+    """(1, 2^-k, 2^k, chosen) of the last set_weights (mz_weight_scale): the power of two the search kernel's weight
+    stream is scaled by so that its ReLU can be a clamp."""
+    out = np.zeros(4, np.float32)
+    _abi.check(self.lib.mz_weight_scale(self._h, out.ctypes.data, self.stream), 'mz_weight_scale')
+    return out
+
   # ---- network
   def initial_inference(self, obs):
     obs = self._dev(obs, torch.float32).reshape(self.B, self.O)
