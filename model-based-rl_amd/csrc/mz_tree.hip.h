@@ -427,8 +427,8 @@ __device__ __forceinline__ void mz_tree_backup_select_f(const TreeView &t, const
 #define MZ_MM_STEP(OFF)                                                         \
   {                                                                             \
     const double a_ = mz_xchg_d<OFF>(mn_c), c_ = mz_xchg_d<OFF>(mx_c);         \
-    mn_c = a_ < mn_c ? a_ : mn_c;                                               \
-    mx_c = c_ > mx_c ? c_ : mx_c;                                               \
+    asm("v_min_f64 %0, %1, %2" : "=v"(mn_c) : "v"(mn_c), "v"(a_));             \
+    asm("v_max_f64 %0, %1, %2" : "=v"(mx_c) : "v"(mx_c), "v"(c_));             \
   }
   MZ_MM_STEP(1) MZ_MM_STEP(2) MZ_MM_STEP(4) MZ_MM_STEP(8)
   if constexpr (TL == 32) MZ_MM_STEP(16)
@@ -505,6 +505,7 @@ __device__ __forceinline__ void mz_tree_backup_select_f(const TreeView &t, const
     // one word per child: action + 1 (0 = absent) above expansion index + 1 above visit count -- between two lanes of a
     // group the actions differ, so comparing the words compares the actions, and the winner's E / N ride along
     int key = Nc | ((Ec + 1) << 8) | (valid ? (cl + 1) << 16 : 0);
+#ifdef MZ_ARGMAX_TUPLE       // (development switch: the pairwise tuple comparison this replaced, 11 instructions per step)
 #define MZ_AM_STEP(OFF)                                                                          \
   {                                                                                              \
     const double os = mz_xchg_d<OFF>(score);                                                     \
@@ -519,6 +520,39 @@ __device__ __forceinline__ void mz_tree_backup_select_f(const TreeView &t, const
     if constexpr (G > 8) MZ_AM_STEP(8)
     if constexpr (G > 16) MZ_AM_STEP(16)
 #undef MZ_AM_STEP
+#else
+    // max of the tuples (score, key) in two plain reductions instead of one reduction of pairs: the group's largest score
+    // first (v_max_f64 on exchanged halves: 3 instructions per step), then the largest key among the lanes that hold it
+    // (the others contribute 0; keys of a group differ in their action bits, so this is the winner's own word).  Equal
+    // scores compare equal here exactly where the tuple comparison's == did (+0 and -0 included); a NaN score -- a
+    // network that produced one -- is ignored by v_max_f64 where the tuple comparison kept whichever came first.
+    {
+      double mxs = score;
+#define MZ_AM_MAX(OFF)                                                              \
+  {                                                                                 \
+    const double os = mz_xchg_d<OFF>(mxs);                                          \
+    asm("v_max_f64 %0, %1, %2" : "=v"(mxs) : "v"(mxs), "v"(os));                    \
+  }
+      if constexpr (G > 1) MZ_AM_MAX(1)
+      if constexpr (G > 2) MZ_AM_MAX(2)
+      if constexpr (G > 4) MZ_AM_MAX(4)
+      if constexpr (G > 8) MZ_AM_MAX(8)
+      if constexpr (G > 16) MZ_AM_MAX(16)
+#undef MZ_AM_MAX
+      key = (score == mxs) ? key : 0;
+#define MZ_AM_KEY(OFF)                            \
+  {                                               \
+    const int ok = mz_xchg_i<OFF>(key);           \
+    key = ok > key ? ok : key;                    \
+  }
+      if constexpr (G > 1) MZ_AM_KEY(1)
+      if constexpr (G > 2) MZ_AM_KEY(2)
+      if constexpr (G > 4) MZ_AM_KEY(4)
+      if constexpr (G > 8) MZ_AM_KEY(8)
+      if constexpr (G > 16) MZ_AM_KEY(16)
+#undef MZ_AM_KEY
+    }
+#endif
     a_sel = (key >> 16) - 1;
     parent_e = e;
     node = 1 + __mul24(e, A) + a_sel;
