@@ -231,6 +231,8 @@ __device__ __forceinline__ double mz_xchg_d(double x) {
 }
 
 
+template <bool V> struct MzBool { static constexpr bool value = V; };
+
 // State a tree's lanes keep in registers between the simulations of one fused launch.
 struct TreeRegs {
   int len;          // len(search_path) of the pending descent
@@ -463,6 +465,13 @@ __device__ __forceinline__ void mz_tree_backup_select_f(const TreeView &t, const
     e0 = __builtin_fma(-span, y0, 1.0);
     yspan = __builtin_fma(y0, e0, y0);
   }
+  // The common case of a descent -- every tree of the wave has max > min in its MinMaxStats (true from the second or
+  // third backup of a move on), the span inside the window of the reciprocal, init_value_score 0 (the reference's
+  // default): a wave-uniform branch inside the level skips the selects among normalize's three cases, the division's
+  // fallback branch and the moves of init_value_score into vector registers.  (One loop, not two specialised ones:
+  // the hidden-state prefetch of the level hook is an asm-issued load into a fixed register tuple, and a second loop
+  // instance made the compiler copy that tuple between two homes while a load was in flight.)
+  const bool common = __builtin_amdgcn_ballot_w64(!(span_pos & fast_ok & (t.init_value_score == 0.0))) == 0;
   int node = 0, e = 0, Np = tr.root_n, tpc = tr.root_tp, len2 = 1, a_sel = -1, parent_e = 0;
   if (lane == 0) s_path[0] = 0;
   // the TL lanes of a tree evaluate the children in TL/G redundant copies (child = lane % G), so the
@@ -490,13 +499,18 @@ __device__ __forceinline__ void mz_tree_backup_select_f(const TreeView &t, const
     const double q0 = xm * yspan;
     const double r0 = __builtin_fma(-span, q0, xm);
     double nrm = __builtin_fma(r0, yspan, q0);
-    if (!fast_ok) {                            // (never in practice)
-      double sp_ = span;
-      asm volatile("" : "+v"(sp_));            // not speculatable: left alone, the compiler turns this branch into a
-      nrm = xm / sp_;                          // select and evaluates the division at every level after all
+    double ucb;
+    if (common) {
+      ucb = prior_score + ((Nc > 0) ? nrm : 0.0);
+    } else {
+      if (!fast_ok) {                            // (never in practice)
+        double sp_ = span;
+        asm volatile("" : "+v"(sp_));            // not speculatable: left alone, the compiler turns this branch into a
+        nrm = xm / sp_;                          // select and evaluates the division at every level after all
+      }
+      const double visited = span_pos ? nrm : (span_zero ? 1.0 : x);
+      ucb = prior_score + ((Nc > 0) ? visited : t.init_value_score);
     }
-    const double visited = span_pos ? nrm : (span_zero ? 1.0 : x);
-    const double ucb = prior_score + ((Nc > 0) ? visited : t.init_value_score);
     // tuple max over (score, action); absent children carry score -inf and action -1 (no finite score loses to them,
     // and among themselves nothing is taken), the winner's expansion index and visit count ride along in one word
     // (a descent of this function always follows a backup: the root and every expanded node on the way down have been
