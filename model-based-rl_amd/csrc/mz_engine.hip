@@ -111,7 +111,8 @@ struct mz_engine {
   FlatLayout layout;
   float relu_scale_host[4] = {1.f, 1.f, 1.f, 0.f};
   bool stream_scaled = false;       // the last weight set admitted a scale: the fused search kernels may run
-  float *relu_scale_dev = nullptr;  // NetView::relu_scale: {1, 2^-k, 2^k, flag} of the current weight set (k_relu_scale)
+  float *relu_scale_dev = nullptr;     // {1, 2^-k, 2^k, flag} of the current weight set (k_relu_scale)
+  unsigned *relu_bound_dev = nullptr;  // k_relu_bound's two maxima
   bool root_hidden_external = false;  // the root's hidden state came in through mz_root_load: no bound on it is known
   unsigned *absmax_dev = nullptr;   // scratch of the split_f16 weight-range check (mz_set_weights)
   double *draw_uniform = nullptr;   // [B] host-given uniforms of a game environment's parity run (mz_selfplay_set_draws)
@@ -276,58 +277,62 @@ __global__ void k_absmax(const float *w, size_t n, unsigned *out) {
 // value, policy: input hidden), given that the hidden state is relu(LayerNorm(.)) -- |(x_i - mean) / std| <= sqrt(49)
 // for 50 features, so 0 <= hidden_i <= 7 |gamma_i| + |beta_i| -- and a one-hot row holds a single 1:
 //   |out_n| <= sum_i |W[n][i]| hb_i + max_a |W[n][50 + a]| + |b_n|       (every partial sum obeys the same bound).
-// scale = {1, 2^-k, 2^k, 1}; {1, 1, 1, 0} when the bound is not finite, k would exceed 40, or 2^k times the largest
-// weight of a consuming layer would leave the float32 range: the stream is then packed as it is and the kernel takes
-// its v_max path.  One workgroup of 512 threads (one per fc1 row), no host synchronisation.
-__global__ void k_relu_scale(const float *flat, FlatLayout L, int A, int Sr, int Sv, float *scale) {
+// k_relu_bound: 64 workgroups, 8 lanes per fc1 row; the largest row bound and the largest |w| of the layers that consume
+// the activations (they are multiplied by 2^k) land in mx[0], mx[1] as bit patterns (non-negative floats order like
+// unsigned integers, and every NaN pattern lies above +inf: a NaN sticks).
+__global__ void k_relu_bound(const float *flat, FlatLayout L, int A, int Sr, int Sv, unsigned *mx) {
   __shared__ float hb[MZ_H];
-  __shared__ float red[512], red2[512];
-  const int n = threadIdx.x;
-  if (n < MZ_H) hb[n] = 7.01f * fabsf(flat[L.ln_w + n]) + fabsf(flat[L.ln_b + n]);
+  const int tid = threadIdx.x;
+  if (tid < MZ_H) hb[tid] = 7.01f * fabsf(flat[L.ln_w + tid]) + fabsf(flat[L.ln_b + tid]);
   __syncthreads();
   const size_t w1[4] = {L.rew_w1, L.tr_w1, L.val_w1, L.pol_w1}, b1[4] = {L.rew_b1, L.tr_b1, L.val_b1, L.pol_b1};
-  float m = 0.f;
-  for (int h = 0; h < 4; ++h) {
-    const int K = h < 2 ? MZ_H + A : MZ_H;
-    const float *row = flat + w1[h] + (size_t)n * K;
-    float s = fabsf(flat[b1[h] + n]), oh = 0.f;
-    for (int i = 0; i < MZ_H; ++i) s += fabsf(row[i]) * hb[i];
-    for (int a = MZ_H; a < K; ++a) oh = fmaxf(oh, fabsf(row[a]));
-    s += oh;
-    m = (s > m || !(s == s)) ? s : m;             // (a NaN sticks)
+  const int row = blockIdx.x * 32 + (tid >> 3), q = tid & 7;       // 2048 rows = 4 heads x 512
+  const int h = row >> 9, n = row & 511;
+  const int K = h < 2 ? MZ_H + A : MZ_H;
+  const float *r = flat + w1[h] + (size_t)n * K;
+  float s = 0.f, oh = 0.f;
+  for (int i = q; i < MZ_H; i += 8) s += fabsf(r[i]) * hb[i];
+  for (int a = MZ_H + q; a < K; a += 8) oh = fmaxf(oh, fabsf(r[a]));
+  unsigned nanbit = (s != s || oh != oh) ? 1u : 0u;
+  for (int o = 1; o < 8; o <<= 1) {
+    s += __shfl_xor(s, o); oh = fmaxf(oh, __shfl_xor(oh, o)); nanbit |= __shfl_xor(nanbit, o);
   }
-  // largest |w| of the layers that consume the activations (they are multiplied by 2^k)
+  s += oh + fabsf(flat[b1[h] + n]);
+  unsigned m = __float_as_uint(s) & 0x7fffffffu;
+  if (nanbit) m = 0x7fc00000u;
+  // largest |w| of the consuming layers, grid-strided
   const size_t w2[4] = {L.rew_w2, L.tr_w2, L.val_w2, L.pol_w2};
   const int J[4] = {Sr, MZ_H, Sv, A};
-  float m2 = 0.f;
-  for (int h = 0; h < 4; ++h)
-    for (size_t i = n; i < (size_t)J[h] * MZ_F; i += 512) {
-      const float v = fabsf(flat[w2[h] + i]);
-      m2 = (v > m2 || !(v == v)) ? v : m2;
+  unsigned m2 = 0;
+  for (int hh = 0; hh < 4; ++hh)
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + tid; i < (size_t)J[hh] * MZ_F; i += (size_t)gridDim.x * blockDim.x) {
+      const unsigned u = __float_as_uint(flat[w2[hh] + i]) & 0x7fffffffu;
+      m2 = u > m2 ? u : m2;
     }
-  red[n] = m; red2[n] = m2;
+  __shared__ unsigned red[2];
+  if (tid < 2) red[tid] = 0;
   __syncthreads();
-  for (int st = 256; st > 0; st >>= 1) {
-    if (n < st) {
-      const float o = red[n + st], o2 = red2[n + st];
-      red[n] = (o > red[n] || !(o == o)) ? o : red[n];
-      red2[n] = (o2 > red2[n] || !(o2 == o2)) ? o2 : red2[n];
-    }
-    __syncthreads();
-  }
-  if (n == 0) {
-    const float bound = red[0] * 1.01f;            // (rounding of the sums above and of the kernel's own accumulation)
-    int k = 0;
-    if (bound > 1.f) (void)frexpf(bound, &k);      // bound = f 2^k, 0.5 <= f < 1: bound < 2^k
-    const bool ok = bound == bound && bound < 0x1p40f && red2[0] == red2[0] && red2[0] < ldexpf(1.f, 100 - k);
+  if (q == 0) atomicMax(&red[0], m);
+  atomicMax(&red[1], m2);
+  __syncthreads();
+  if (tid < 2) atomicMax(&mx[tid], red[tid]);
+}
+
+// scale = {1, 2^-k, 2^k, 1}; {1, 1, 1, 0} when the bound is not finite, k would exceed 40, or 2^k times the largest
+// weight of a consuming layer would leave the float32 range: the host then routes the engine to the stand-alone kernels.
+__global__ void k_relu_scale(const unsigned *mx, float *scale) {
+  const float bound = __uint_as_float(mx[0]) * 1.01f;     // (rounding of the sums above and of the kernel's own accumulation)
+  const float w2max = __uint_as_float(mx[1]);
+  int k = 0;
+  if (bound > 1.f) (void)frexpf(bound, &k);               // bound = f 2^k, 0.5 <= f < 1: bound < 2^k
+  const bool ok = bound == bound && bound < 0x1p40f && w2max == w2max && w2max < ldexpf(1.f, 100 - k);
 #ifdef MZ_RELU_VMAX
-    k = 0;
+  k = 0;
 #endif
-    scale[0] = 1.f;
-    scale[1] = ok ? ldexpf(1.f, -k) : 1.f;
-    scale[2] = ok ? ldexpf(1.f, k) : 1.f;
-    scale[3] = ok ? 1.f : 0.f;
-  }
+  scale[0] = 1.f;
+  scale[1] = ok ? ldexpf(1.f, -k) : 1.f;
+  scale[2] = ok ? ldexpf(1.f, k) : 1.f;
+  scale[3] = ok ? 1.f : 0.f;
 }
 
 static int build_packing_h2(mz_engine *e, const FlatLayout &L, int Sv, int Sr) {
@@ -544,6 +549,7 @@ static int build_packing(mz_engine *e) {
   if (dmalloc(e, &e->pack_idx, pos)) return -1;
   if (dmalloc(e, &e->packed, pos)) return -1;
   if (dmalloc(e, &e->relu_scale_dev, (size_t)4)) return -1;
+  if (dmalloc(e, &e->relu_bound_dev, (size_t)2)) return -1;
   if (dmalloc(e, &e->flat_dev, L.total)) return -1;
   HIPCHECK(hipMemcpy(e->pack_idx, idx.data(), pos * sizeof(int32_t), hipMemcpyHostToDevice));
   NetView &n = e->nv;
@@ -1035,7 +1041,9 @@ int mz_set_weights(mz_engine *e, const float *flat, size_t n, int on_device, voi
   // the power of two the search kernel's stream is scaled by (its ReLU is a [0, 1] clamp, mz_fused.hip.h), from a bound of
   // this weight set's activations; a 16-byte read back tells the host whether one exists -- if not, the engine runs
   // the stand-alone kernels until the next weight set
-  hipLaunchKernelGGL(k_relu_scale, dim3(1), dim3(512), 0, s, src, e->layout, e->A, e->nv.Sr, e->nv.Sv, e->relu_scale_dev);
+  HIPCHECK(hipMemsetAsync(e->relu_bound_dev, 0, 2 * sizeof(unsigned), s));
+  hipLaunchKernelGGL(k_relu_bound, dim3(64), dim3(256), 0, s, src, e->layout, e->A, e->nv.Sr, e->nv.Sv, e->relu_bound_dev);
+  hipLaunchKernelGGL(k_relu_scale, dim3(1), dim3(1), 0, s, (const unsigned *)e->relu_bound_dev, e->relu_scale_dev);
   hipLaunchKernelGGL(k_pack_weights, dim3(blocks), dim3(threads), 0, s, src, e->pack_idx, e->packed, e->n_packed,
                      (const float *)e->relu_scale_dev);
   HIPCHECK(hipMemcpyAsync(e->relu_scale_host, e->relu_scale_dev, 4 * sizeof(float), hipMemcpyDeviceToHost, s));
