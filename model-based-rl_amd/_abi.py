@@ -19,7 +19,7 @@ HIPCC_FLAGS = ['-O3', '--offload-arch=gfx950', '-ffp-contract=off', '-std=c++17'
 # kernels (mz_kernels.inc; the same list as launch_fused / launch_h2 in mz_engine.hip dispatch to)
 FUSED_SHAPES = [(14, 1, 4), (14, 1, 8), (15, 1, 8), (16, 1, 16), (18, 1, 16), (18, 2, 32), (21, 2, 32)]
 H2_SHAPES = [4, 8, 16]
-DEV_FUSED_SHAPES, DEV_H2_SHAPES = [(14, 1, 4), (15, 1, 8)], [4, 8]      # -DMZ_DEV_ONLY: the two bench shapes
+DEV_FUSED_SHAPES, DEV_H2_SHAPES = [(14, 1, 4), (14, 1, 8)], [4, 8]      # -DMZ_DEV_ONLY: the two bench shapes
 
 
 def translation_units(extra=()):

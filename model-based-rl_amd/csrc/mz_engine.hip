@@ -68,6 +68,7 @@ struct mz_engine {
   std::vector<void *> allocs;
   float *flat_dev = nullptr;
   int32_t *pack_idx = nullptr;
+  int32_t *pack_idx2 = nullptr;     // a second source element per packed weight (-1: none), added before scaling
   float *packed = nullptr;
   size_t n_flat = 0, n_packed = 0;
   bool weights_set = false;
@@ -229,6 +230,25 @@ static void fill_fc1_biascol(std::vector<int32_t> &idx, size_t wpos, const size_
             if (k < K) v = (int32_t)(woff[head] + (size_t)nf * K + k);
             else if (k == K) v = (int32_t)(boff[head] + nf);
             idx[wpos + ((((size_t)(w * 4 + tg) * ks + s) * 64 + lane) * 4 + i)] = v;
+          }
+}
+
+// dynamics fc1 pack for the fused kernel: as fill_fc1_biascol, but without a bias column -- the input's one-hot part holds
+// exactly one 1, so the bias rides in the one-hot columns: their packed weight is W[n][50 + a] + b[n] (idx2 = the
+// bias element to add, k_pack_weights).  K = 50 + A columns instead of 51 + A: one k-step of four fewer for
+// A = 6, 10, 14, ... (Pong-ram: 14 steps instead of 15).
+static void fill_fc1_foldbias(std::vector<int32_t> &idx, std::vector<int32_t> &idx2, size_t wpos, const size_t *woff,
+                              const size_t *boff, int K, int ks) {
+  for (int w = 0; w < 4; ++w)
+    for (int tg = 0; tg < 4; ++tg)
+      for (int s = 0; s < ks; ++s)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int i = 0; i < 4; ++i) {
+            const int t = 4 * tg + i, head = t / 8, tt = t % 8;
+            const int nf = 128 * w + 16 * tt + (lane & 15), k = 4 * s + (lane >> 4);
+            const size_t o = wpos + ((((size_t)(w * 4 + tg) * ks + s) * 64 + lane) * 4 + i);
+            idx[o] = k < K ? (int32_t)(woff[head] + (size_t)nf * K + k) : -1;
+            idx2[o] = (k >= MZ_H && k < K) ? (int32_t)(boff[head] + nf) : -1;
           }
 }
 
@@ -434,8 +454,9 @@ static int build_packing(mz_engine *e) {
   const size_t p_w3 = seg((size_t)4 * 4 * ks3 * 256), p_b3 = seg(4 * 16 * 256);
   const size_t p_w4 = seg((size_t)(2 + jtp) * 4 * 8 * 256), p_b4 = seg(32 + 16 * jtp);
   const size_t p_lnw = seg(64), p_lnb = seg(64);
-  // fused kernel: fc1 weights with the bias as one more input column (constant-1 input); the k-step
-  // count is that of the kernel instantiation chosen for this action count (zero-padded above 50+A+1)
+  // fused kernel: fc1 weights with the bias inside the packed matrix -- prediction: one more input column (constant-1
+  // input); dynamics: added to the one-hot columns (fill_fc1_foldbias); the k-step count is that of the kernel
+  // instantiation chosen for this action count (zero-padded above 50+A)
   const int ks1f = e->ks1sel, ks3f = (MZ_H + 1 + 3) / 4;
   const size_t p_w1f = seg((size_t)4 * 4 * ks1f * 256), p_w3f = seg((size_t)4 * 4 * ks3f * 256);
   const int nj2 = 2 + jtp;
@@ -451,6 +472,7 @@ static int build_packing(mz_engine *e) {
   const size_t p_is = seg((size_t)4 * nroot * 4 * 256);
   e->n_packed = pos;
   std::vector<int32_t> idx(pos, -1);
+  std::vector<int32_t> idx2(pos, -1);      // second source element, added to the first (the folded bias of fill_fc1_foldbias)
   {
     fill_fc2(idx, p_w0o, 4, L.rep_w2, MZ_H);
     fill_vec(idx, p_b0o, 64, L.rep_b2, MZ_H);
@@ -475,7 +497,7 @@ static int build_packing(mz_engine *e) {
   fill_vec(idx, p_lnb, 64, L.ln_b, MZ_H);
   {
     size_t wo[2] = {L.rew_w1, L.tr_w1}, bo[2] = {L.rew_b1, L.tr_b1};
-    fill_fc1_biascol(idx, p_w1f, wo, bo, MZ_H + A, ks1f);
+    fill_fc1_foldbias(idx, idx2, p_w1f, wo, bo, MZ_H + A, ks1f);
     size_t wo3[2] = {L.val_w1, L.pol_w1}, bo3[2] = {L.val_b1, L.pol_b1};
     fill_fc1_biascol(idx, p_w3f, wo3, bo3, MZ_H, ks3f);
   }
@@ -495,8 +517,11 @@ static int build_packing(mz_engine *e) {
     // cls: the scale class of the piece (bits 29-30 of its gather indices, k_pack_weights): 1 = an fc1 layer of the
     // search (times 2^-k), 2 = a layer that consumes its activations (times 2^k) -- k_relu_scale, mz_fused.hip.h
     auto put = [&](size_t src, int cls) {
-      int32_t *dst = &idx[p_ws + ((size_t)w * nsteps * 4 + piece) * 256];
-      for (int i = 0; i < 256; ++i) dst[i] = idx[src + i] < 0 ? -1 : (idx[src + i] | (cls << 29));
+      const size_t d0 = p_ws + ((size_t)w * nsteps * 4 + piece) * 256;
+      for (int i = 0; i < 256; ++i) {
+        idx[d0 + i] = idx[src + i] < 0 ? -1 : (idx[src + i] | (cls << 29));
+        idx2[d0 + i] = idx2[src + i];
+      }
       ++piece;
     };
     for (int st = 0; st < ks1f; ++st)
@@ -547,11 +572,13 @@ static int build_packing(mz_engine *e) {
 
   if (L.total >= ((size_t)1 << 29)) return fail("internal: %zu weights do not fit the gather index", L.total);
   if (dmalloc(e, &e->pack_idx, pos)) return -1;
+  if (dmalloc(e, &e->pack_idx2, pos)) return -1;
   if (dmalloc(e, &e->packed, pos)) return -1;
   if (dmalloc(e, &e->relu_scale_dev, (size_t)4)) return -1;
   if (dmalloc(e, &e->relu_bound_dev, (size_t)2)) return -1;
   if (dmalloc(e, &e->flat_dev, L.total)) return -1;
   HIPCHECK(hipMemcpy(e->pack_idx, idx.data(), pos * sizeof(int32_t), hipMemcpyHostToDevice));
+  HIPCHECK(hipMemcpy(e->pack_idx2, idx2.data(), pos * sizeof(int32_t), hipMemcpyHostToDevice));
   NetView &n = e->nv;
   const float *P = e->packed;
   n.w0o = (const f32x4 *)(P + p_w0o); n.b0o = P + p_b0o;
@@ -791,8 +818,8 @@ static int launch_fused_t(mz_engine *e, int num_simulations, int sims_done, hipS
 }
 
 // fused-kernel instantiations: (fc1 k-steps, policy tiles, lanes per tree) by action count
-// (dynamics fc1: K = 50 + A + 1 columns in k-steps of 4)
-static int fused_ks1(int A) { return A <= 5 ? 14 : (A <= 8 ? 15 : (A <= 13 ? 16 : (A <= 21 ? 18 : 21))); }
+// (dynamics fc1: K = 50 + A columns in k-steps of 4 -- the bias rides in the one-hot columns, fill_fc1_foldbias)
+static int fused_ks1(int A) { return A <= 6 ? 14 : (A <= 8 ? 15 : (A <= 13 ? 16 : (A <= 21 ? 18 : 21))); }
 
 static int launch_fused(mz_engine *e, int num_simulations, int sims_done, hipStream_t s) {
   const int A = e->A;
@@ -807,11 +834,11 @@ static int launch_fused(mz_engine *e, int num_simulations, int sims_done, hipStr
   }
 #ifdef MZ_DEV_ONLY      // kernel development: only the two bench shapes are instantiated (a quarter of the build time)
   if (A <= 4) return launch_fused_t<14, 1, 4>(e, num_simulations, sims_done, s);
-  if (A >= 6 && A <= 8) return launch_fused_t<15, 1, 8>(e, num_simulations, sims_done, s);
+  if (A >= 5 && A <= 6) return launch_fused_t<14, 1, 8>(e, num_simulations, sims_done, s);
   return fail("MZ_DEV_ONLY build: action_space %d not instantiated", A);
 #else
   if (A <= 4) return launch_fused_t<14, 1, 4>(e, num_simulations, sims_done, s);
-  if (A <= 5) return launch_fused_t<14, 1, 8>(e, num_simulations, sims_done, s);
+  if (A <= 6) return launch_fused_t<14, 1, 8>(e, num_simulations, sims_done, s);
   if (A <= 8) return launch_fused_t<15, 1, 8>(e, num_simulations, sims_done, s);
   if (A <= 13) return launch_fused_t<16, 1, 16>(e, num_simulations, sims_done, s);
   if (A <= 16) return launch_fused_t<18, 1, 16>(e, num_simulations, sims_done, s);
@@ -1044,8 +1071,8 @@ int mz_set_weights(mz_engine *e, const float *flat, size_t n, int on_device, voi
   HIPCHECK(hipMemsetAsync(e->relu_bound_dev, 0, 2 * sizeof(unsigned), s));
   hipLaunchKernelGGL(k_relu_bound, dim3(64), dim3(256), 0, s, src, e->layout, e->A, e->nv.Sr, e->nv.Sv, e->relu_bound_dev);
   hipLaunchKernelGGL(k_relu_scale, dim3(1), dim3(1), 0, s, (const unsigned *)e->relu_bound_dev, e->relu_scale_dev);
-  hipLaunchKernelGGL(k_pack_weights, dim3(blocks), dim3(threads), 0, s, src, e->pack_idx, e->packed, e->n_packed,
-                     (const float *)e->relu_scale_dev);
+  hipLaunchKernelGGL(k_pack_weights, dim3(blocks), dim3(threads), 0, s, src, e->pack_idx, (const int32_t *)e->pack_idx2,
+                     e->packed, e->n_packed, (const float *)e->relu_scale_dev);
   HIPCHECK(hipMemcpyAsync(e->relu_scale_host, e->relu_scale_dev, 4 * sizeof(float), hipMemcpyDeviceToHost, s));
   if (e->split_f16)
     hipLaunchKernelGGL(k_pack_weights_h2, dim3((unsigned)((e->n_packed_h2 + threads - 1) / threads)), dim3(threads), 0, s, src,

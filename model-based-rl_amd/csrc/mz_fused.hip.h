@@ -48,12 +48,12 @@ __device__ __forceinline__ void mz_static_for(F &&f) {
 #define MZ_RS_MAIN 13
 #endif
 __host__ __device__ constexpr int mz_fused_rs(int ks1, int jtp) { return jtp > 1 ? 9 : (ks1 > 16 ? 11 : (ks1 > 14 ? 12 : MZ_RS_MAIN)); }
-#define MZ_XE 36     // row stride of the x-tile extension [one-hot(action) | 1 | 0 ...] (k >= 50)
+#define MZ_XE 36     // row stride of the x-tile extensions (k >= 50): dynamics [one-hot(action) | 0 ...], prediction [1 | 0 ...]
 
 // per-simulation schedule (in steps of 16 MFMAs per wave)
 template <int KS1, int JTP>
 struct FusedSched {
-  static constexpr int FC1 = KS1;               // dynamics fc1: K = 50 + A + 1 (bias column), 4 per step
+  static constexpr int FC1 = KS1;               // dynamics fc1: K = 50 + A (the bias rides in the one-hot columns), 4 per step
   static constexpr int FC2 = 12;                // reward (2 tiles) + next hidden (4 tiles): 48 pieces
   static constexpr int P1 = (MZ_H + 1 + 3) / 4; // prediction fc1: K = 51 -> 13 steps
   static constexpr int P2 = 2 * (2 + JTP);      // value (2 tiles) + policy (JTP tiles)
@@ -626,7 +626,7 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
   float *s_b4 = s_b2 + 96;
   float *s_lnw = s_b4 + 64;
   float *s_lnb = s_lnw + 64;
-  float *xEd = s_lnb + 64;                // [16][MZ_XE] dynamics extension: one-hot(action), then 1 (bias column)
+  float *xEd = s_lnb + 64;                // [16][MZ_XE] dynamics extension: one-hot(action) (the bias rides in its weights)
   float *xEp = xEd + 16 * MZ_XE;          // [16][MZ_XE] prediction extension: 1 (bias column), then 0
   int *s_path = (int *)(xEp + 16 * MZ_XE); // [16][MZ_FUSED_MAXPL] pending search path of every tree
   double *s_rcp = (double *)(s_path + 16 * MZ_FUSED_MAXPL);      // [MZ_FUSED_MAXPL] 1 / n (mz_tree_backup_select_f)
@@ -858,7 +858,7 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
     asm volatile("" : "+s"(sbase));
     int lane_e = lane;                  // epilogue lane index, laundered: the LDS addresses derived from it are
     asm volatile("" : "+v"(lane_e));    // recomputed every simulation instead of living in registers all along
-    // ---- gather: x tile = [hidden of search_path[-2] | one-hot(action) | 1]  (mcts.py:94-96)
+    // ---- gather: x tile = [hidden of search_path[-2] | one-hot(action)]  (mcts.py:94-96; networks.py:167-174)
     // (the parent's hidden state was requested during the descent that chose it -- hv[], see mz_tree_step_fused)
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
@@ -866,7 +866,11 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
       asm volatile("s_waitcnt vmcnt(0)" : "+v"(hv[i]));
       if (tl < MZ_HS / 4) *(f32x4 *)(xR + mt * MZ_HS + 4 * tl) = hv[i];
       // (only the columns the KS1 k-steps of the dynamics fc1 reach: k < 4 KS1)
-      for (int c = tl; c < 4 * KS1 - MZ_H; c += TL) xEd[mt * MZ_XE + c] = (c == my_act[i] || c == n.A) ? 1.f : 0.f;
+      for (int c = tl; c < 4 * KS1 - MZ_H; c += TL) xEd[mt * MZ_XE + c] = (c == my_act[i] || (G == 4 && c == n.A)) ? 1.f : 0.f;
+      // (column A, where it exists, meets zero weights: the bias rides in the one-hot columns, fill_fc1_foldbias.  The
+      // 4-action instantiations still write it as 1: without the second compare their simulation loop came out 13
+      // instructions longer and 0.8 % slower on the LunarLander shapes, with it the 8-lane instantiation is 1 % slower
+      // on the Pong-ram shapes -- register allocation, not arithmetic)
     }
     STAMP(0)
     mz_bar();

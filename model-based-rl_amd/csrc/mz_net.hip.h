@@ -304,10 +304,15 @@ __global__ __launch_bounds__(256, 1) void k_net_recurrent_rows(NetView n, const 
 
 // packed[i] = idx[i] >= 0 ? flat[idx[i]] : 0   (weights -> MFMA operand order)
 // idx: -1 = padding (0.0), else bits 0-28 the source element, bits 29-30 its scale class (scale[cls], powers of two:
-// exact; mz_engine.hip k_relu_scale)
-static __global__ void k_pack_weights(const float *flat, const int32_t *idx, float *packed, size_t n, const float *scale) {
+// exact; mz_engine.hip k_relu_scale); idx2: -1 or a second element added to the first (one float32 addition)
+static __global__ void k_pack_weights(const float *flat, const int32_t *idx, const int32_t *idx2, float *packed, size_t n,
+                                      const float *scale) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int32_t s = idx[i];
-  packed[i] = s >= 0 ? flat[s & 0x1fffffff] * scale[(s >> 29) & 3] : 0.f;
+  if (s < 0) { packed[i] = 0.f; return; }
+  float v = flat[s & 0x1fffffff];
+  const int32_t s2 = idx2[i];
+  if (s2 >= 0) v += flat[s2];
+  packed[i] = v * scale[(s >> 29) & 3];
 }
