@@ -17,7 +17,7 @@ HIPCC_FLAGS = ['-O3', '--offload-arch=gfx950', '-ffp-contract=off', '-std=c++17'
                '-Wno-unused-result']
 # translation units of libmz_hip.so: the host side + root / stepwise kernels, and one unit per shape of the two search
 # kernels (mz_kernels.inc; the same list as launch_fused / launch_h2 in mz_engine.hip dispatch to)
-FUSED_SHAPES = [(14, 1, 4), (14, 1, 8), (15, 1, 8), (16, 1, 16), (18, 1, 16), (18, 2, 32), (21, 2, 32)]
+FUSED_SHAPES = [(14, 1, 4), (14, 1, 8), (15, 1, 8), (15, 1, 16), (16, 1, 16), (18, 1, 16), (18, 2, 32), (21, 2, 32)]
 H2_SHAPES = [4, 8, 16]
 DEV_FUSED_SHAPES, DEV_H2_SHAPES = [(14, 1, 4), (14, 1, 8)], [4, 8]      # -DMZ_DEV_ONLY: the two bench shapes
 
@@ -27,7 +27,7 @@ def translation_units(extra=()):
   units = [('mz_engine', 'mz_engine.hip', [])]
   for ks1, jtp, g in (DEV_FUSED_SHAPES if dev else FUSED_SHAPES):
     units.append(('mz_inst_f_%d_%d_%d' % (ks1, jtp, g), 'mz_inst.hip', ['-DMZ_INST_F=%d,%d,%d' % (ks1, jtp, g)] +
-                  (['-DMZ_INST_GAME=1'] if (ks1, jtp, g) == (16, 1, 16) else [])))
+                  (['-DMZ_INST_GAME=1'] if (ks1, jtp, g) == (15, 1, 16) else [])))
   for g in (DEV_H2_SHAPES if dev else H2_SHAPES):
     units.append(('mz_inst_h_%d' % g, 'mz_inst.hip', ['-DMZ_INST_H=%d' % g]))
   return units

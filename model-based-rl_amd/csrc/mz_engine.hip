@@ -29,8 +29,8 @@
 MZ_ALL_FUSED(extern)
 MZ_ALL_H2(extern)
 #ifndef MZ_DEV_ONLY
-// whole moves of the device TicTacToe environment (two players, 9 actions: the <16, 1, 16> shape, compact LDS trees)
-extern template __global__ void k_search_fused<16, 1, 16, 2, false, false, true, true> MZ_KARGS;
+// whole moves of the device TicTacToe environment (two players, 9 actions: the <15, 1, 16> shape, compact LDS trees)
+extern template __global__ void k_search_fused<15, 1, 16, 2, false, false, true, true> MZ_KARGS;
 #endif
 
 static thread_local std::string g_err;
@@ -681,22 +681,22 @@ static int launch_fused_sp(mz_engine *e, int num_simulations, int sims_done, hip
     }
   }
 #ifndef MZ_DEV_ONLY
-  if constexpr (KS1 == 16 && JTP == 1 && G == 16 && LT == 2 && !SP) {
+  if constexpr (KS1 == 15 && JTP == 1 && G == 16 && LT == 2 && !SP) {
     if (e->persist_moves > 0 && e->sp.env_kind == 1) {      // whole moves of the device TicTacToe environment in this launch
       const size_t dynh = fused_head_dyn_lds(e->sims, e->NN, LT);
       const MzRootArgs ra = {e->istream, e->nst0, e->persist_moves, e->cfg.root_dirichlet_alpha,
                              e->cfg.root_exploration_fraction};
       if (!e->lds_attr_set_head) {
-        HIPCHECK(hipFuncSetAttribute((const void *)k_search_fused<16, 1, 16, 2, false, false, true, true>,
+        HIPCHECK(hipFuncSetAttribute((const void *)k_search_fused<15, 1, 16, 2, false, false, true, true>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)sizeof(float) * mz_fused_lds_floats(LT)));
         e->lds_attr_set_head = true;
       }
       if (e->ev_start)
-        hipExtLaunchKernelGGL((k_search_fused<16, 1, 16, 2, false, false, true, true>), dim3(e->Bp / MZ_ROWS), dim3(256), dynh, s,
+        hipExtLaunchKernelGGL((k_search_fused<15, 1, 16, 2, false, false, true, true>), dim3(e->Bp / MZ_ROWS), dim3(256), dynh, s,
                               e->ev_start, e->ev_stop, 0, e->nv, e->tv, e->wstream, num_simulations, 0,
                               (unsigned long long *)nullptr, e->sp, 1, (uint64_t)e->cfg.seed, ra);
       else
-        hipLaunchKernelGGL((k_search_fused<16, 1, 16, 2, false, false, true, true>), dim3(e->Bp / MZ_ROWS), dim3(256), dynh, s,
+        hipLaunchKernelGGL((k_search_fused<15, 1, 16, 2, false, false, true, true>), dim3(e->Bp / MZ_ROWS), dim3(256), dynh, s,
                            e->nv, e->tv, e->wstream, num_simulations, 0, (unsigned long long *)nullptr, e->sp, 1,
                            (uint64_t)e->cfg.seed, ra);
       HIPCHECK(hipGetLastError());
@@ -819,7 +819,7 @@ static int launch_fused_t(mz_engine *e, int num_simulations, int sims_done, hipS
 
 // fused-kernel instantiations: (fc1 k-steps, policy tiles, lanes per tree) by action count
 // (dynamics fc1: K = 50 + A columns in k-steps of 4 -- the bias rides in the one-hot columns, fill_fc1_foldbias)
-static int fused_ks1(int A) { return A <= 6 ? 14 : (A <= 8 ? 15 : (A <= 13 ? 16 : (A <= 21 ? 18 : 21))); }
+static int fused_ks1(int A) { return A <= 6 ? 14 : (A <= 10 ? 15 : (A <= 13 ? 16 : (A <= 21 ? 18 : 21))); }
 
 static int launch_fused(mz_engine *e, int num_simulations, int sims_done, hipStream_t s) {
   const int A = e->A;
@@ -840,6 +840,7 @@ static int launch_fused(mz_engine *e, int num_simulations, int sims_done, hipStr
   if (A <= 4) return launch_fused_t<14, 1, 4>(e, num_simulations, sims_done, s);
   if (A <= 6) return launch_fused_t<14, 1, 8>(e, num_simulations, sims_done, s);
   if (A <= 8) return launch_fused_t<15, 1, 8>(e, num_simulations, sims_done, s);
+  if (A <= 10) return launch_fused_t<15, 1, 16>(e, num_simulations, sims_done, s);
   if (A <= 13) return launch_fused_t<16, 1, 16>(e, num_simulations, sims_done, s);
   if (A <= 16) return launch_fused_t<18, 1, 16>(e, num_simulations, sims_done, s);
   if (A <= 21) return launch_fused_t<18, 2, 32>(e, num_simulations, sims_done, s);
@@ -859,12 +860,12 @@ static int fused_lt(const mz_engine *e) {
 static bool selfplay_persist_ok(const mz_engine *e) {
   if (!e->use_persist || !fused_usable(e) || e->prof_buf) return false;
   if (e->sp.env_kind == 1) {
-    // the device TicTacToe environment: whole moves inside the launch of the two-player <16, 1, 16> instantiation with
+    // the device TicTacToe environment: whole moves inside the launch of the two-player <15, 1, 16> instantiation with
     // its trees compact in LDS (the exact-f32 kernel; host-given uniforms / draws work there too)
 #ifdef MZ_DEV_ONLY
     return false;
 #else
-    return !e->split_f16 && e->cfg.two_players && e->A > 8 && e->A <= 13 && fused_lt(e) == 2 &&
+    return !e->split_f16 && e->cfg.two_players && e->A > 8 && e->A <= 10 && fused_lt(e) == 2 &&
            sizeof(float) * mz_fused_lds_floats(2) + fused_head_dyn_lds(e->sims, e->NN, 2) <= 160 * 1024;
 #endif
   }

@@ -16,8 +16,8 @@
 
 #if defined(MZ_INST_F)
 MZ_APPLY(MZ_INST_FUSED, , MZ_INST_F)
-#ifdef MZ_INST_GAME      // (the <16, 1, 16> unit) whole moves of the device TicTacToe environment
-template __global__ void k_search_fused<16, 1, 16, 2, false, false, true, true> MZ_KARGS;
+#ifdef MZ_INST_GAME      // (the <15, 1, 16> unit) whole moves of the device TicTacToe environment
+template __global__ void k_search_fused<15, 1, 16, 2, false, false, true, true> MZ_KARGS;
 #endif
 #elif defined(MZ_INST_H)
 MZ_APPLY(MZ_INST_H2, , MZ_INST_H)
