@@ -109,6 +109,14 @@ def check_against_oracle(out, ex, ref, what):
     ((8, 3), 50, 30, True, (-2.0, 2.0), 0.99, 0.8),                    # A = 3, two players, illegal moves
     ('g1_net_lunar_nosupport', 1024, 30, False, (None, None), 0.997, 1.0),   # --no_support: scalar heads, no transform
     ('g1_net_lunar_nosupport', 64, 60, False, (None, None), 0.997, 1.0),     # the same through the hybrid-placement kernel
+    # the dynamics fc1 takes K = 50 + A columns (the bias rides in the one-hot columns): action counts at the edges of the
+    # instantiations' k-step ranges -- K filling the last k-step exactly (A = 6: 14 steps, A = 10: 15, A = 14: 16 of 18)
+    # and one past it (A = 7, 11)
+    ((8, 6), 160, 24, False, (None, None), 0.997, 1.0),
+    ((8, 7), 96, 20, False, (None, None), 0.997, 0.8),
+    ((8, 10), 128, 20, True, (-1.0, 1.0), 1.0, 0.7),
+    ((8, 11), 64, 16, False, (None, None), 0.997, 1.0),
+    ((8, 14), 64, 12, False, (None, None), 0.997, 0.9),
 ])
 def test_search_vs_oracle(name, B, sims, two, bounds, discount, legal_p):
   out, ex, ref = run_both(name, B, sims, two, bounds, discount, legal_p)
