@@ -579,7 +579,8 @@ def test_device_records_to_sampled_batch():
 
 
 @pytest.mark.parametrize('O,A,sims,u8,split', [(8, 4, 30, False, False), (128, 6, 50, True, False), (5, 2, 6, False, False),
-                                               (8, 4, 30, False, True), (60, 6, 50, True, True)])
+                                               (8, 4, 30, False, True), (60, 6, 50, True, True),
+                                               (9, 10, 12, False, False), (12, 7, 20, False, False)])
 def test_persistent_selfplay_launch_equals_graph_of_kernels(O, A, sims, u8, split, monkeypatch):
   """Single-player self-play runs as whole moves inside ONE launch of the search kernel (its HEAD instantiation: root,
   simulations and end of every move, trees never leaving LDS between root and search); MZ_NO_PERSIST=1 keeps the
