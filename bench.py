@@ -42,7 +42,7 @@ for _i, _a in enumerate(sys.argv):
     WNAME, B, O, A, SIMS, EPISODE_LEN = WORKLOADS[sys.argv[_i + 1]]
   if _a == '--envs' and _i + 1 < len(sys.argv):
     B = int(sys.argv[_i + 1])                # (tests: a small pool; the line then says so in config.envs_per_gpu)
-CHUNK = 8                       # moves per drain/ingest chunk
+CHUNK = 16                      # moves per drain/ingest chunk = whole moves per launch of the search kernel (8 until r03_i: +0.5 %)
 FLOP_PER_SIM = 2 * 512 * (312 + 3 * A)            # 331 776 for A = 4
 FLOP_PER_ROOT = 2 * 512 * (O + 181 + A)           # 197 632 for O = 8, A = 4
 PEAK_F32_MFMA_TFLOPS = 157.3                      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense

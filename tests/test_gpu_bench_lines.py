@@ -32,7 +32,7 @@ def line_of(args):
 def test_tictactoe_line():
   line = line_of(['--workload', 'tictactoe', '--envs', '256', '--steps', '16', '--warmup', '4', '--no-cpu-baseline', '--min-seconds', '0.2'])
   assert 'TicTacToe on the device' in line['config']['environment'] and line['roofline']['bound'] == 'mfma'
-  assert line['roofline']['moves_per_launch'] == 8          # whole moves inside the two-player launch
+  assert line['roofline']['moves_per_launch'] == 16         # whole moves inside the two-player launch
   assert 0.5 * 256 * line['timed_steps'] < line['value'] * line['timed_seconds'] < 1.5 * 256 * line['timed_steps']
 
 
