@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <deque>
 #include <functional>
 #include <string>
 #include <vector>
@@ -98,10 +99,15 @@ struct mz_engine {
   unsigned long long *head_prof = nullptr;   // non-null only inside mz_selfplay_phase_profile
   // record drain on a copy stream (mz_selfplay_drain): event behind the last copy, and how far the compute stream
   // has been ordered behind the copies
-  hipEvent_t drain_ev = nullptr;
+  hipEvent_t drain_ev = nullptr;    // the LATEST drain's copy (chains drains issued on different streams)
   hipStream_t drain_stream = nullptr;
   bool drain_pending = false;
-  unsigned long long drained_ordered = 0;
+  // every drain whose copy may still be reading the ring: (first move not covered = sp.drained after it, its event),
+  // oldest first; events come from / go back to drain_ev_pool (mz_selfplay_steps waits for the OLDEST drain that still
+  // covers the slots it is about to overwrite, not for the latest one)
+  std::deque<std::pair<unsigned long long, hipEvent_t>> drain_q;
+  std::vector<hipEvent_t> drain_ev_pool;
+  unsigned long long drain_q_start = 0;     // first move covered by drain_q.front()
   double prof_spread[3] = {0, 0, 0};   // mean / min / max over workgroups of the last phase profile's total cycles
   bool split_f16 = false;           // FCNetwork GEMMs as float16 high/low splits (mz_fused_h2.hip.h)
   int32_t *pack_idx_h2 = nullptr;   // gather table of the split-f16 weight stream (bit 30: low part)
@@ -1007,7 +1013,8 @@ int mz_destroy(mz_engine *e) {
   if (!e) return 0;
   hipSetDevice(e->device);
   hipDeviceSynchronize();
-  if (e->drain_ev) hipEventDestroy(e->drain_ev);
+  for (auto &q : e->drain_q) hipEventDestroy(q.second);
+  for (hipEvent_t ev : e->drain_ev_pool) hipEventDestroy(ev);
   if (e->search_graph) hipGraphExecDestroy(e->search_graph);
   for (auto &g : e->move_graph) if (g) hipGraphExecDestroy(g);
   if (e->cap_stream) hipStreamDestroy(e->cap_stream);
