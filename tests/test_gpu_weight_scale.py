@@ -53,6 +53,34 @@ def _search(sd, O, A, sims, B, seed=5):
   return scale, fin, tree, (obs, noise)
 
 
+@pytest.mark.parametrize('O,A,sims,gain', [(8, 4, 30, 1.0), (128, 6, 50, 1.0), (8, 4, 30, 37.0)])
+def test_no_activation_reaches_the_chosen_power_of_two(O, A, sims, gain):
+  """The premise of the clamp, checked on what a search actually computes: over every hidden state of every tree (root
+  and all expansions) and every action, the largest pre-activation of the four 512-wide hidden layers stays below the
+  2^k the engine chose from the weights alone -- with room (the bound is an L1 bound: it cannot be tight on real data)."""
+  sd = _state(O, A, 3)
+  if gain != 1.0:
+    for k in sd:
+      if k.endswith('fc1.weight') or k.endswith('fc1.bias') or k.startswith('LN.'):
+        sd[k] = sd[k] * (gain if not k.startswith('LN.') else 3.0)
+  scale, _, tree, _ = _search(sd, O, A, sims, 256)
+  assert scale[3] == 1.0
+  two_k = float(scale[2])
+  h = tree['hidden'].reshape(-1, 50).astype(np.float64)
+  h = h[np.abs(h).sum(1) > 0]                                # (unused pool slots are zero)
+  w = {k: v.numpy().astype(np.float64) for k, v in sd.items()}
+  worst = 0.0
+  for head in ('value_head', 'policy_head'):
+    worst = max(worst, np.abs(h @ w[head + '.fc1.weight'].T + w[head + '.fc1.bias']).max())
+  for head in ('reward_head', 'transition_head'):
+    W = w[head + '.fc1.weight']
+    base = h @ W[:, :50].T + w[head + '.fc1.bias']
+    for a in range(A):
+      worst = max(worst, np.abs(base + W[:, 50 + a]).max())
+  print('largest hidden pre-activation %.3f, chosen 2^k = %g' % (worst, two_k))
+  assert worst < 0.9 * two_k and two_k <= 64 * max(worst, 1.0)
+
+
 @pytest.mark.parametrize('O,A,sims', [(8, 4, 30), (128, 6, 50)])
 def test_results_do_not_depend_on_the_scale(O, A, sims):
   sd = _state(O, A, 3)
