@@ -88,7 +88,9 @@ size_t mz_num_weights(const mz_engine *e);
  * state_dict concatenated in its own key order: representation_head.{fc1,out}.{weight,bias},
  * value_head.{fc1,value}, policy_head.{fc1,policy}, reward_head.{fc1,reward},
  * transition_head.{fc1,out}, LN.{weight,bias}; Linear weights [out][in] row-major.
- * on_device != 0: flat is [dev] (e.g. the buffer an RCCL broadcast just filled); else [host]. */
+ * on_device != 0: flat is [dev] (e.g. the buffer an RCCL broadcast just filled); else [host].
+ * Synchronises `stream` before it returns (a 16-byte read back decides which kernel set this weight set runs on,
+ * mz_weight_scale below; a host buffer may be released as soon as the call returns). */
 int mz_set_weights(mz_engine *e, const float *flat, size_t n, int on_device, void *stream);
 
 /* Diagnostic: how the last mz_set_weights packed the search kernel's weight stream.  out [host][4] =
