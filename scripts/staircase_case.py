@@ -1,0 +1,83 @@
+"""The one tree of the round-3 soak (Pong-ram shapes, move 4894, env 3870) whose device search differs from the CPU
+restatement although its smallest decision gap (3.0e-4) is above the 1e-4 margin: where the two searches part, and what
+the network's scalars are there in float32 (device, restatement) and in float64.  Prints a JSON summary."""
+import json, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import oracle as orc
+from model_based_rl_amd.engine import Engine, records_view
+from tests.test_gpu_bench_parity import SHAPES, philox_action_uniform, G
+sh = SHAPES['pong']
+O, A, sims, B, seed, chunk = sh['O'], sh['A'], sh['sims'], 4096, 99, 16
+MOVE, ENV = 4894, 3870
+w = orc.load_weights(np.load(os.path.join(G, sh['gold'] + '.npz')))
+eng = Engine(B, O, A, sims, seed=seed)
+eng.set_weights(w)
+eng.selfplay_set_obs(uint8_obs=True, obs_min=[0.0], obs_range=[255.0])
+eng.selfplay_noise_log(True)
+eng.selfplay_reset(200, 1.0, stagger=True)
+for c in range(MOVE // chunk + 1):
+  eng.selfplay_steps(chunk)
+  buf, n = eng.selfplay_drain()
+torch.cuda.synchronize()
+rec = buf[:n].numpy().copy()
+k = MOVE % chunk
+obs = (rec[k, ENV:ENV + 1, :O] / np.float32(255.0)).astype(np.float32)
+noise = eng.selfplay_noise(MOVE)[ENV:ENV + 1]
+eng.close()
+
+# device: the same root through mz_search, trees exported
+e2 = Engine(16, O, A, sims, seed=seed)
+e2.set_weights(w)
+e2.initial_inference(np.repeat(obs, 16, 0)); e2.root_prepare(None, None, np.repeat(noise, 16, 0)); e2.search()
+dev = e2.export_tree(hidden=True)
+e2.close()
+# restatement, step by step
+net = orc.FCNet(w, O, A)
+t = orc.Trees(orc.tree_cfg(A, sims), 1)
+h0, v0, lg0 = net.initial(obs)
+t.root_expand(np.ones(1, np.int8), lg0, np.ones((1, A), np.uint8)); t.add_noise(noise, 0.25)
+hp = np.zeros((sims + 1, 50), np.float32); hp[0] = h0[0]
+steps = []
+for s in range(sims):
+  leaf, pslot, act, depth = t.select()
+  h, r, v, lg = net.recurrent(hp[pslot[0]][None], act)
+  hp[s + 1] = h[0]
+  steps.append((int(leaf[0]), int(pslot[0]), int(act[0]), float(r[0]), float(v[0])))
+  t.expand_backup(v, r, lg)
+ref = t.export()
+
+def f64_scalar(logits64):
+  p = np.exp(logits64 - logits64.max()); p /= p.sum()
+  x = float((p * np.arange(-15, 16)).sum())
+  return float(np.sign(x) * (((np.sqrt(1 + 4 * 0.001 * (abs(x) + 1 + 0.001)) - 1) / (2 * 0.001)) ** 2 - 1))
+W = {k_: np.asarray(v_, np.float64) for k_, v_ in w.items()}
+def f64_recurrent(h, a):
+  x = np.concatenate([h.astype(np.float64), np.eye(A)[a]])
+  rew = f64_scalar(np.maximum(W['reward_head.fc1.weight'] @ x + W['reward_head.fc1.bias'], 0) @ W['reward_head.reward.weight'].T + W['reward_head.reward.bias'])
+  z = np.maximum(W['transition_head.fc1.weight'] @ x + W['transition_head.fc1.bias'], 0) @ W['transition_head.out.weight'].T + W['transition_head.out.bias']
+  hn = np.maximum((z - z.mean()) / np.sqrt(z.var() + 1e-5) * W['LN.weight'] + W['LN.bias'], 0)
+  val = f64_scalar(np.maximum(W['value_head.fc1.weight'] @ hn + W['value_head.fc1.bias'], 0) @ W['value_head.value.weight'].T + W['value_head.value.bias'])
+  return rew, val
+
+# first simulation at which the device's tree and the restatement's part: node -> expansion slot differs
+dE, rE = dev['E'][0], ref['E'][0]
+first = None
+for s, (leaf, pslot, act, r, v) in enumerate(steps):
+  if dE[leaf] != s + 1:
+    first = s
+    break
+out = {'move': MOVE, 'env': ENV, 'device_visits': dev['N'][0][1:1 + A].tolist(), 'restatement_visits': ref['N'][0][1:1 + A].tolist(),
+       'first_simulation_that_differs': first, 'simulations_before_it': []}
+for s in range(first if first is not None else sims):
+  leaf, pslot, act, r, v = steps[s]
+  r64, v64 = f64_recurrent(hp[pslot], act)
+  dW = float(dev['R'][0][leaf])
+  out['simulations_before_it'].append({'sim': s, 'reward_restatement_f32': r, 'reward_device_f32': dW, 'reward_f64': r64,
+                                       'value_restatement_f32': v, 'value_f64': v64})
+dr = [abs(x['reward_restatement_f32'] - x['reward_device_f32']) for x in out['simulations_before_it']]
+out['max_reward_difference_device_vs_restatement_before_the_split'] = max(dr) if dr else None
+out['max_value_f32_vs_f64'] = max(abs(x['value_restatement_f32'] - x['value_f64']) for x in out['simulations_before_it']) if dr else None
+out['minmax_device'] = dev['minmax'][0].tolist(); out['minmax_restatement'] = ref['minmax'][0].tolist()
+json.dump(out, sys.stdout, indent=1)

@@ -2,7 +2,7 @@
 
 BENCH_rNN's `value` is produced by the persistent HEAD instantiation of the search kernel (whole moves inside one launch,
 mz_selfplay_steps) on a full grid: 4096 environments = 256 workgroups, 8 moves per launch.  This test runs exactly that --
-three launches of 8 moves, a weight update before the third -- with the per-move Dirichlet log on
+three launches of 16 moves (bench.py's launch size), a weight update before the third -- with the per-move Dirichlet log on
 (mz_selfplay_noise_log), takes the observation of a move from its experience record and the Dirichlet draw from the log,
 and replays single moves (the first, one in the middle of the second launch, one in the middle of the third, the last)
 through oracle/mz_oracle.c on all 4096 trees.
@@ -64,7 +64,7 @@ def test_persistent_launch_on_a_full_grid_vs_oracle(shape, split):
   from model_based_rl_amd.engine import Engine, records_view
   sh = SHAPES[shape]
   O, A, sims = sh['O'], sh['A'], sh['sims']
-  B, T, seed, chunk = 4096, 11, 1234, 8                  # bench.py: 4096 envs, 8 moves per launch
+  B, T, seed, chunk = 4096, 11, 1234, 16                 # bench.py: 4096 envs, 16 moves per launch
   w0 = orc.load_weights(np.load(os.path.join(G, sh['gold'] + '.npz')))
   w1 = perturbed(w0, 5)
   eng = Engine(B, O, A, sims, seed=seed, split_f16=split)
@@ -131,7 +131,7 @@ def test_persistent_launch_on_a_full_grid_vs_oracle(shape, split):
 
 
 def _selfplay_digest(shape, persist, split=False):
-  """records of 3 chunks x 8 moves at 4096 envs (bench.py's launch shape) as one sha256, in a child process (the launch
+  """records of 3 chunks x 16 moves at 4096 envs (bench.py's launch shape) as one sha256, in a child process (the launch
   structure is chosen at mz_create from MZ_NO_PERSIST)"""
   import subprocess, sys
   sh = SHAPES[shape]
@@ -152,7 +152,7 @@ if %r:
 eng.selfplay_reset(11, 1.0, stagger=True)
 h = hashlib.sha256()
 for k in range(3):
-  eng.selfplay_steps(8)
+  eng.selfplay_steps(16)
   buf, n = eng.selfplay_drain()
   torch.cuda.synchronize()
   h.update(buf[:n].numpy().tobytes())
@@ -171,7 +171,7 @@ print('DIGEST', h.hexdigest())
 @pytest.mark.parametrize('shape,split', [('lunar', False), ('pong', False), ('lunar', True), ('ttt', False)])
 def test_persistent_launch_equals_kernel_per_phase_on_a_full_grid(shape, split):
   """The whole-moves launch on 256 workgroups against the hipGraph of root + search kernels per move (MZ_NO_PERSIST=1):
-  24 moves of 4096 environments, every byte of every record identical (same device functions, same keys).  'ttt': the
+  48 moves of 4096 environments, every byte of every record identical (same device functions, same keys).  'ttt': the
   two-player whole-moves launch of the device TicTacToe environment against its launch-per-step form (observe, initial
   inference, Dirichlet over the legal moves, root, search, env step as separate kernels)."""
   assert _selfplay_digest(shape, True, split) == _selfplay_digest(shape, False, split)
