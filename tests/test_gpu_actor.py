@@ -418,12 +418,14 @@ def test_small_ring_drain_on_copy_stream_is_ordered():
     eng.selfplay_reset(T, 1.0, stagger=False)
     ring = eng.ring_moves
     chunk = ring // 2 + 3                      # two chunks do not fit the ring: the second reuses slots of the first
-    cs = torch.cuda.Stream()
+    cs = [torch.cuda.Stream(), torch.cuda.Stream()]
     outs = []
     pinned = [torch.empty(chunk, B, eng.rec_floats, dtype=torch.float32).pin_memory() for _ in range(3)]
     for k in range(3):
       eng.selfplay_steps(chunk)
-      buf, n = eng.selfplay_drain(pinned[k], chunk, copy_stream=cs if overlap else None)
+      # overlap == 2: the drains alternate between two copy streams (every drain has its own event; a drain on another
+      # stream is chained behind the previous one, and a launch waits for the oldest drain that still covers its slots)
+      buf, n = eng.selfplay_drain(pinned[k], chunk, copy_stream=(cs[k % overlap] if overlap else None))
       assert n == chunk
       if not overlap:
         torch.cuda.synchronize()
@@ -433,11 +435,12 @@ def test_small_ring_drain_on_copy_stream_is_ordered():
     eng.close()
     return ring, outs
 
-  ring, a = run(False)
+  ring, a = run(0)
   assert ring == 32
-  _, b = run(True)
-  for x, y in zip(a, b):
-    assert np.array_equal(x, y)
+  for streams in (1, 2):
+    _, b = run(streams)
+    for x, y in zip(a, b):
+      assert np.array_equal(x, y), streams
 
 
 def test_actor_load_state_metrics_and_run_dirs(tmp_path):
