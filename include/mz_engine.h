@@ -264,6 +264,25 @@ int mz_selfplay_export_trees(mz_engine *e, int keep);
  * and the observation its record carries. */
 int mz_selfplay_noise_log(mz_engine *e, int keep);
 int mz_selfplay_read_noise(mz_engine *e, uint64_t move, double *out);
+/* Test instrumentation of the fused search kernels' TREE code (the launch mz_search and mz_selfplay_steps run; the
+ * stand-alone kernels get their network outputs through mz_expand_backup anyway).  The tree step of a simulation --
+ * Node.expand, MCTS.backpropagate, the next select_child descent: mcts.py:47-55,83-92,104-143 -- consumes exactly three
+ * things from the network: the value and reward scalars (networks.py:153-154,161-162) and the A policy logits.
+ * buf [dev][keep_moves][num_envs][num_simulations + 1][2 + A] float32 is the caller's and must outlive the mode.
+ *   mode 1, log:    every simulation s of every tree stores (value, reward, logits[A]) in slot 1 + s of row
+ *                   (move % keep_moves, tree); the root of a self-play move stores (value, 0, logits[A]) in slot 0;
+ *                   mz_search uses row 0.  The parity tests replay the logged outputs through the CPU oracle's tree and
+ *                   demand every tree identical -- no network evaluation on the checker's side, hence no tie margin.
+ *   mode 2, inject: mz_search's simulations READ slot 1 + s (row 0, keep_moves = 1) instead of their own network
+ *                   outputs: the reference's recorded outputs (tests/golden) reach the fused kernels' own tree code.
+ *   mode 0, off:    the production state (a null pointer in the kernels' arguments; buf ignored).
+ * Synchronous; drops captured graphs. */
+int mz_sim_io(mz_engine *e, int mode, float *buf, int keep_moves);
+/* Which kernel mz_search / mz_selfplay_steps launch for this engine right now: out4 [host] = kind (0 the stand-alone
+ * kernels, 1 k_search_fused, 2 k_search_h2), LDS placement of the trees (0 node pool, 1 whole trees in LDS, 2 compact in
+ * LDS; -1 for kind 0), dynamics-fc1 k-steps of the instantiation, lanes per child group.  For tests: they assert the
+ * instantiation they mean to exercise. */
+int mz_search_kernel_info(const mz_engine *e, int *out4);
 int mz_selfplay_steps(mz_engine *e, int moves, void *stream);
 /* mz_selfplay_steps with one pair of HIP events around every search-kernel dispatch (hipExtLaunchKernelGGL start / stop
  * events on `stream`: the timestamps rocprofv3's kernel trace reports).  The k moves are launched eagerly, back to back,

@@ -123,6 +123,8 @@ SIGNATURES = {
     'mz_selfplay_export_trees': (_I, [_VP, _I]),
     'mz_selfplay_noise_log': (_I, [_VP, _I]),
     'mz_selfplay_read_noise': (_I, [_VP, _U64, _VP]),
+    'mz_sim_io': (_I, [_VP, _I, _VP, _I]),
+    'mz_search_kernel_info': (_I, [_VP, _VP]),
     'mz_selfplay_steps': (_I, [_VP, _I, _VP]),
     'mz_selfplay_steps_timed': (_I, [_VP, _I, _VP, _VP]),
     'mz_selfplay_phase_profile': (_I, [_VP, _I, _VP, _VP]),
@@ -154,7 +156,7 @@ def load():
 
 
 # ---------------------------------------------------------------- host replay library (include/mz_replay.h)
-_RSO = os.path.join(_CSRC, 'libmz_replay.so')
+_RSO = os.environ.get('MZ_REPLAY_LIB') or os.path.join(_CSRC, 'libmz_replay.so')      # (MZ_REPLAY_LIB: a sanitizer build, tests/test_sanitizers.py)
 _rlib = None
 _I64 = C.c_int64
 
@@ -190,18 +192,23 @@ REPLAY_SIGNATURES = {
 }
 
 
-def build_replay(force=False, verbose=False):
+REPLAY_FLAGS = ['-mavx2', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared', '-pthread']
+
+
+def build_replay(force=False, verbose=False, out=None, extra=None):
+  """out / extra: another library file and other optimisation / instrumentation flags than -O3 (the sanitizer builds of
+  tests/test_sanitizers.py)"""
   src = os.path.join(_CSRC, 'mz_replay.cpp')
   hdr = os.path.join(_CSRC, '..', '..', 'include', 'mz_replay.h')
-  if force or not os.path.exists(_RSO) or os.path.getmtime(_RSO) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+  target = out or os.path.join(_CSRC, 'libmz_replay.so')
+  if force or out or not os.path.exists(target) or os.path.getmtime(target) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
     # -mavx2: the sum tree's per-level running sums are 4-wide double vectors (every x86-64 host of an MI355X box has
     # AVX2; no FMA is enabled and contraction stays off: the sums are the reference's, term by term)
-    cmd = ['g++', '-O3', '-mavx2', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared', '-pthread', 'mz_replay.cpp', '-o',
-           'libmz_replay.so']
+    cmd = ['g++'] + (list(extra) if extra is not None else ['-O3']) + REPLAY_FLAGS + ['mz_replay.cpp', '-o', target]
     if verbose:
       print(' '.join(cmd))
     subprocess.check_call(cmd, cwd=_CSRC)
-  return _RSO
+  return target
 
 
 def load_replay():

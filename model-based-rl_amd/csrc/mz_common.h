@@ -36,7 +36,26 @@ struct TreeView {
   int B, A, sims, NN, PL;
   int two_players, has_min, has_max;
   double min_bound, max_bound, discount, init_value_score;
+  // Test instrumentation of the fused search kernels (mz_sim_io), NULL in production: per move, tree and expansion slot
+  // the three things a simulation's tree step consumes -- value, reward (float32 scalars) and the A policy logits --
+  // [keep moves][B][sims + 1][2 + A] float32; slot 0 = the root of a self-play move (value, 0, logits), slot 1 + s =
+  // simulation s.  sim_io_keep > 0: the kernels store what they computed (log); < 0: they read these values instead of
+  // their own (inject), |sim_io_keep| = moves the buffer holds.
+  float *sim_io;
+  int sim_io_keep;
 };
+
+// the row of (move, tree b, expansion slot) in the sim_io buffer
+__device__ __forceinline__ float *mz_sim_io_row(const TreeView &t, int b, unsigned long long move, int slot) {
+  const int keep = t.sim_io_keep < 0 ? -t.sim_io_keep : t.sim_io_keep;
+  return t.sim_io + (((size_t)(move % (unsigned long long)keep) * (size_t)t.B + (size_t)b) * (size_t)(t.sims + 1) + (size_t)slot) * (size_t)(2 + t.A);
+}
+
+// inject mode's reads, issued and awaited inside one asm statement: the compiler never sees a pending load, so the
+// production path behind the (never taken) branch gets no s_waitcnt for it, and "+v" overwrites the value where it lives
+__device__ __forceinline__ void mz_sim_io_load(float &dst, const float *src) {
+  asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "+v"(dst) : "v"(src) : "memory");
+}
 
 // Packed FCNetwork weights in MFMA operand order (see mz_net.hip.h).
 struct NetView {

@@ -1214,6 +1214,23 @@ int mz_search(mz_engine *e, int num_simulations, void *stream) {
   return 0;
 }
 
+// which search kernel mz_search / mz_selfplay_steps will launch for this engine right now -- out4 [host]: kind (0 the
+// stand-alone kernels, 1 k_search_fused, 2 k_search_h2), LDS placement of the trees (0 global pool, 1 whole trees, 2
+// compact; -1 for kind 0), fc1 k-steps of the instantiation, lanes per child group.  (Tests assert the instantiation
+// they mean to exercise.)
+int mz_search_kernel_info(const mz_engine *e, int *out4) {
+  if (!e || !out4) return fail("mz_search_kernel_info: null argument");
+  int kind = 0, lt = -1;
+  if (fused_usable(e) && !e->root_hidden_external) {
+    kind = 1; lt = fused_lt(e);
+    if (e->split_f16 && e->use_lds_trees)
+      for (int l = 1; l <= (e->use_lds_hybrid ? 2 : 1); ++l)
+        if (sizeof(float) * mz_h2_lds_floats(l) + mz_fused_dyn_lds(e->sims, e->NN, l) <= 160 * 1024) { kind = 2; lt = l; break; }
+  }
+  out4[0] = kind; out4[1] = lt; out4[2] = e->ks1sel; out4[3] = e->G;
+  return 0;
+}
+
 int mz_root_set_priors(mz_engine *e, const int8_t *to_play, const uint8_t *legal, const double *priors,
                        void *stream) {
   if (!e || !priors) return fail("mz_root_set_priors: null argument");

@@ -1102,12 +1102,49 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
       STAMP(9)
       auto stampf = [&](int k) __attribute__((always_inline)) { STAMP(10 + k) };
       if (full || b0 + mt < t.B) {
-        mz_tree_expand_f<TL, G, LT, SP>(t, tm[0], tl, slot0 + sim + 1, s_rew[mt], pr, s_path + mt * MZ_FUSED_MAXPL,
+        float vv = v, rew = s_rew[mt];
+        // test instrumentation (mz_sim_io, inject mode; a zero in production, and absent from the whole-moves launch):
+        // the caller's value / reward / logits -- the goldens' recorded network outputs -- replace this simulation's, so
+        // that they reach THIS tree code.  Loads issued and awaited inside asm (mz_sim_io_load): the production path
+        // behind the never-taken branch gets no s_waitcnt for them.
+        if constexpr (!HEAD) {
+          if (__builtin_expect(t.sim_io_keep < 0, 0)) {
+            const float *io = mz_sim_io_row(t, b0 + mt, 0ull, slot0 + sim + 1);
+            float lgi = 0.f;
+            mz_sim_io_load(vv, io); mz_sim_io_load(rew, io + 1); mz_sim_io_load(lgi, io + 2 + (tl < n.A ? tl : 0));
+            pr = (tl < n.A) ? exp((double)lgi) : 0.0;
+          }
+        }
+        mz_tree_expand_f<TL, G, LT, SP>(t, tm[0], tl, slot0 + sim + 1, rew, pr, s_path + mt * MZ_FUSED_MAXPL,
                                         s_stage + mt * 96, tr[0]);
         stampf(0);
-        mz_tree_backup_select_f<TL, G, LT, SP>(t, tm[0], tl, v, s_rew[mt], s_path + mt * MZ_FUSED_MAXPL,
+        mz_tree_backup_select_f<TL, G, LT, SP>(t, tm[0], tl, vv, rew, s_path + mt * MZ_FUSED_MAXPL,
                                                s_stage + mt * 96, s_pbc, s_rcp, tr[0], sim + 1 < nsims, my_slot[0],
                                                my_act[0], MzHiddenPrefetch{t.hpool, hoff[0], hv[0]}, stampf);
+        // test instrumentation (mz_sim_io, log mode; a zero in production): what the tree step above consumed -- value,
+        // reward, the A logits -- stored for the parity tests' replay through the CPU checker's tree.  BEHIND the tree step and
+        // recomputed from the LDS the values came from (split-K partials, s_rew, s_lg: untouched until the next
+        // simulation's first barrier) by the very same device functions: nothing of the production path lives longer or
+        // is scheduled differently for this block, which costs it one scalar compare + branch per simulation.
+        if (__builtin_expect(t.sim_io_keep > 0, 0)) {
+          unsigned long long mvx = 0;
+          if constexpr (ENVS) mvx = *(const unsigned long long *)(s_env + mt * MZ_ENVW);
+          else if (record) mvx = sp.movecnt[b0 + mt];
+          float *io = mz_sim_io_row(t, b0 + mt, mvx, slot0 + sim + 1);
+          MzQuad V2;
+          mz_quad_issue<0>(V2, mz_quad_addr(red, 4 * q8, mt), mz_lds_addr(s_b4 + 4 * q8));
+          asm volatile("s_waitcnt lgkmcnt(0)" : MZ_Q(V2));
+          const float v2 = mz_support_to_scalar_q(mz_quad_sum(V2), n.vmin, n.no_transform, q8);
+          float lgx;
+          if constexpr (P4) {
+            const f32x4 lg4 = mz_logits4(red, s_b4 + 32, mt, tl);
+            lgx = (tl & 2) ? ((tl & 1) ? lg4[3] : lg4[2]) : ((tl & 1) ? lg4[1] : lg4[0]);
+          } else {
+            lgx = s_lg[mt * 32 + (tl < n.A ? tl : 0)];
+          }
+          if (tl < n.A) io[2 + tl] = lgx;
+          if (tl == 0) { io[0] = v2; io[1] = s_rew[mt]; }
+        }
       }
     } else {
       mz_bar();
@@ -1119,7 +1156,25 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
         const int b = b0 + mt;
         if (b < t.B) {
           auto stampf = [&](int k) __attribute__((always_inline)) { STAMP(10 + k) };
-          mz_tree_step_fused<TL, G, LT, SP>(t, tm[i], tl, slot0 + sim + 1, s_val[mt], s_rew[mt], s_lg + mt * 32,
+          float vv = s_val[mt], rew = s_rew[mt];
+          // test instrumentation (mz_sim_io), as in the 16-lane path above; lane a owns logit a of s_lg
+          if constexpr (!HEAD) {
+            if (__builtin_expect(t.sim_io_keep < 0, 0)) {
+              const float *io = mz_sim_io_row(t, b, 0ull, slot0 + sim + 1);
+              float lgi = 0.f;
+              mz_sim_io_load(vv, io); mz_sim_io_load(rew, io + 1); mz_sim_io_load(lgi, io + 2 + (tl < n.A ? tl : 0));
+              if (tl < n.A) s_lg[mt * 32 + tl] = lgi;
+            }
+          }
+          if (__builtin_expect(t.sim_io_keep > 0, 0)) {
+            unsigned long long mvx = 0;
+            if constexpr (ENVS) mvx = *(const unsigned long long *)(s_env + mt * MZ_ENVW);
+            else if (record) mvx = sp.movecnt[b];
+            float *io = mz_sim_io_row(t, b, mvx, slot0 + sim + 1);
+            if (tl < n.A) io[2 + tl] = s_lg[mt * 32 + tl];
+            if (tl == 0) { io[0] = vv; io[1] = rew; }
+          }
+          mz_tree_step_fused<TL, G, LT, SP>(t, tm[i], tl, slot0 + sim + 1, vv, rew, s_lg + mt * 32,
                                             s_path + mt * MZ_FUSED_MAXPL, s_stage + mt * 96, s_pbc, s_rcp, tr[i],
                                             sim + 1 < nsims, my_slot[i], my_act[i], t.hpool, hoff[i], hv[i], stampf);
         }

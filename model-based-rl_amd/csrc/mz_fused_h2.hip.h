@@ -525,12 +525,34 @@ __global__ __launch_bounds__(256, 1) void k_search_h2(NetView n, TreeView t, con
       STAMP(9)
       auto stampf = [&](int k) __attribute__((always_inline)) { STAMP(10 + k) };
       if (full || b0 + mt < t.B) {
-        mz_tree_expand_f<TL, G, LT, SP>(t, tm, tl, slot0 + sim + 1, s_rew[mt], pr, s_path + mt * MZ_FUSED_MAXPL,
+        float vv = v, rew = s_rew[mt];
+        // test instrumentation (mz_sim_io), zeros in production -- see k_search_fused: inject in front of the tree step
+        // (not in the whole-moves launch), log behind it, recomputed from LDS
+        if constexpr (!HEAD) {
+          if (__builtin_expect(t.sim_io_keep < 0, 0)) {
+            const float *io = mz_sim_io_row(t, b0 + mt, 0ull, slot0 + sim + 1);
+            float lgi = 0.f;
+            mz_sim_io_load(vv, io); mz_sim_io_load(rew, io + 1); mz_sim_io_load(lgi, io + 2 + (tl < n.A ? tl : 0));
+            pr = (tl < n.A) ? exp((double)lgi) : 0.0;
+          }
+        }
+        mz_tree_expand_f<TL, G, LT, SP>(t, tm, tl, slot0 + sim + 1, rew, pr, s_path + mt * MZ_FUSED_MAXPL,
                                         s_stage + mt * 96, tr);
         stampf(0);
-        mz_tree_backup_select_f<TL, G, LT, SP>(t, tm, tl, v, s_rew[mt], s_path + mt * MZ_FUSED_MAXPL, s_stage + mt * 96,
+        mz_tree_backup_select_f<TL, G, LT, SP>(t, tm, tl, vv, rew, s_path + mt * MZ_FUSED_MAXPL, s_stage + mt * 96,
                                                s_pbc, s_rcp, tr, sim + 1 < nsims, my_slot, my_act,
                                                MzHiddenPrefetch{t.hpool, hoff, hv}, stampf);
+        if (__builtin_expect(t.sim_io_keep > 0, 0)) {
+          unsigned long long mvx = 0;
+          if (record) mvx = sp.movecnt[b0 + mt];
+          float *io = mz_sim_io_row(t, b0 + mt, mvx, slot0 + sim + 1);
+          MzQuad V2;
+          mz_quad_issue<0>(V2, mz_quad_addr(red, 4 * q8, mt), mz_lds_addr(s_b4 + 4 * q8));
+          asm volatile("s_waitcnt lgkmcnt(0)" : MZ_Q(V2));
+          const float v2 = mz_support_to_scalar_q(mz_quad_sum(V2), n.vmin, n.no_transform, q8);
+          if (tl < n.A) io[2 + tl] = s_lg[mt * 32 + tl];
+          if (tl == 0) { io[0] = v2; io[1] = s_rew[mt]; }
+        }
       }
     }
     STAMP(13)

@@ -312,6 +312,13 @@ __device__ __forceinline__ void mz_root_body(const NetView &n, const TreeView &t
         // registers and costs a whole store -> load round trip per move (A/B on one box: 0.3 % of the move)
         if (sp.noise_log && tl < A)
           sp.noise_log[((size_t)((uint32_t)move % (uint32_t)sp.ring_moves) * (uint32_t)t.B + (uint32_t)b) * (uint32_t)A + (uint32_t)tl] = nz;
+        // test instrumentation (mz_sim_io, log mode), off in production: the root's value and logits of THIS move in slot 0
+        // of the move's row (the search kernel that follows fills slots 1..)
+        if (t.sim_io_keep > 0 && tl < A) {
+          float *io = mz_sim_io_row(t, b, move, 0);
+          io[2 + tl] = s_lg[mt * 32 + tl];
+          if (tl == 0) { io[0] = s_val[mt]; io[1] = 0.f; }
+        }
       }
     }
   }

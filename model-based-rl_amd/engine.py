@@ -343,6 +343,33 @@ class Engine(object):
     _abi.check(self.lib.mz_selfplay_read_noise(self._h, int(move), out.ctypes.data_as(C.c_void_p)), 'mz_selfplay_read_noise')
     return out
 
+  SIM_IO = {'off': 0, 'log': 1, 'inject': 2}
+
+  def sim_io(self, mode, keep_moves=1, values=None):
+    """Test instrumentation of the fused search kernels (mz_sim_io): 'log' -> returns the device tensor
+    [keep_moves, B, sims + 1, 2 + A] float32 the kernels fill with (value, reward, logits) per tree and simulation (slot 0 =
+    the root of a self-play move); 'inject' -> `values` ([B, sims + 1, 2 + A] or [1, B, ...]) are what mz_search's simulations
+    consume instead of their own network outputs; 'off' -> production state."""
+    m = self.SIM_IO[mode] if isinstance(mode, str) else int(mode)
+    buf = None
+    if m == 1:
+      buf = torch.zeros(int(keep_moves), self.B, self.sims + 1, 2 + self.A, dtype=torch.float32, device=self.device)
+    elif m == 2:
+      buf = torch.as_tensor(np.ascontiguousarray(values, np.float32)).reshape(1, self.B, self.sims + 1, 2 + self.A)
+      buf = buf.to(self.device).contiguous()
+      keep_moves = 1
+    torch.cuda.synchronize(self.device)
+    _abi.check(self.lib.mz_sim_io(self._h, m, _ptr(buf), int(keep_moves)), 'mz_sim_io')
+    self._sim_io_buf = buf          # (the engine reads / writes it until the mode changes)
+    return buf
+
+  def search_kernel_info(self):
+    """dict(kind='standalone' | 'fused' | 'split_f16', lt=LDS placement of the trees, ks1, G) of the kernel mz_search /
+    mz_selfplay_steps launch right now (mz_search_kernel_info)"""
+    out = (C.c_int * 4)()
+    _abi.check(self.lib.mz_search_kernel_info(self._h, out), 'mz_search_kernel_info')
+    return dict(kind=('standalone', 'fused', 'split_f16')[out[0]], lt=int(out[1]), ks1=int(out[2]), G=int(out[3]))
+
   def selfplay_steps(self, moves):
     _abi.check(self.lib.mz_selfplay_steps(self._h, int(moves), self.stream), 'mz_selfplay_steps')
 

@@ -44,6 +44,8 @@ class FC(C.Structure):
 
 
 def build(force=False):
+  if os.environ.get('MZ_ORACLE_LIB'):      # a sanitizer build of the same source (tests/test_sanitizers.py)
+    return os.environ['MZ_ORACLE_LIB']
   so = os.path.join(_HERE, 'libmz_oracle.so')
   src = os.path.join(_HERE, 'mz_oracle.c')
   if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
