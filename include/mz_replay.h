@@ -56,6 +56,12 @@ int mzr_priorities(const mz_replay *r, const double *errors, int64_t n, double *
 int mzr_tree_add(mz_replay *r, const double *priorities, int64_t n, int64_t *positions_out);
 int mzr_tree_update(mz_replay *r, const int64_t *idxs, const double *priorities, int64_t n);
 int64_t mzr_tree_get_leaf(const mz_replay *r, double value);
+/* The payload SumTree.get_leaf returns beside the index and the priority (replay_buffer.py:58-62: `step, history =
+ * self.buffer[buffer_index]`): mzr_leaf_info -> the leaf's priority, its step inside its history slice (-1: empty leaf),
+ * the slice's length and whether it carries a payload; mzr_leaf_history copies the slice's n_steps record rows
+ * ([n_steps][rec_floats], the layout of mzr_ingest_records; byte observations stay packed) to rows_out [host]. */
+int mzr_leaf_info(const mz_replay *r, int64_t idx, double *priority, int64_t *step, int64_t *n_steps, int *has_payload);
+int mzr_leaf_history(const mz_replay *r, int64_t idx, float *rows_out, int64_t n_steps);
 double mzr_total_priority(const mz_replay *r);
 int64_t mzr_size(const mz_replay *r);                  /* PrioritizedReplay.size: tree.num_memories */
 int mzr_tree_leaves(const mz_replay *r, int64_t n, double *out);

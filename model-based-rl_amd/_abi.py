@@ -177,6 +177,8 @@ REPLAY_SIGNATURES = {
     'mzr_tree_add': (_I, [_VP, _VP, _I64, _VP]),
     'mzr_tree_update': (_I, [_VP, _VP, _VP, _I64]),
     'mzr_tree_get_leaf': (_I64, [_VP, _D]),
+    'mzr_leaf_info': (_I, [_VP, _I64, _VP, _VP, _VP, _VP]),
+    'mzr_leaf_history': (_I, [_VP, _I64, _VP, _I64]),
     'mzr_total_priority': (_D, [_VP]),
     'mzr_size': (_I64, [_VP]),
     'mzr_tree_leaves': (_I, [_VP, _I64, _VP]),

@@ -156,14 +156,16 @@ class Actor(Logger):
     return self.config.visit_softmax_temperature(self.training_step)
 
   # ---------------------------------------------------------------- host environments
-  def play_game(self, games):
-    """actors.py:126-176 for a batch of Game objects (one per environment of this actor), until every
-    game is terminal.  `games` may be a single Game (reference call style)."""
-    games = games if isinstance(games, (list, tuple)) else [games]
-    assert len(games) == self.num_envs
+  def play_game(self, game):
+    """actors.py:126-176.  `game`: one Game, as the reference calls it, or a list of up to `num_envs` Games searched in
+    lock-step (one per environment of this actor); returns when every game is terminal.  Rows of the engine beyond the
+    given games repeat the first game's inputs and are ignored."""
+    games = list(game) if isinstance(game, (list, tuple)) else [game]
+    assert 1 <= len(games) <= self.num_envs, (len(games), self.num_envs)
     cfg, eng, A = self.config, self.engine, self.config.action_space
     temperature = self._temperature()
     live = [True] * len(games)
+    pad = [0] * (self.num_envs - len(games))            # engine rows without a game of their own
     while any(live):
       obs = np.stack([np.float32(g.get_observation(-1)).reshape(-1) for g in games])
       if getattr(cfg, 'norm_obs', False):
@@ -176,6 +178,9 @@ class Actor(Logger):
         if cfg.parity_rng:       # mcts.py:59, one draw per move of length #legal
           noise[i, acts] = np.random.dirichlet([cfg.root_dirichlet_alpha] * len(acts))
       to_play = np.array([g.to_play for g in games], np.int8)
+      if pad:
+        obs, legal, to_play = np.concatenate([obs, obs[pad]]), np.concatenate([legal, legal[pad]]), np.concatenate([to_play, to_play[pad]])
+        noise = None if noise is None else np.concatenate([noise, noise[pad]])
       eng.initial_inference(obs)
       eng.root_prepare(to_play, legal, noise, device_rng=not cfg.parity_rng, move=self.move_counter)
       eng.search()
@@ -183,6 +188,8 @@ class Actor(Logger):
         uniform = np.random.random_sample(len(games))   # the draw np.random.choice(n, p=...) consumes (config.py:77)
       else:
         uniform = None if not cfg.parity_rng else np.zeros(len(games))
+      if pad and uniform is not None:
+        uniform = np.concatenate([uniform, uniform[pad]])
       out = {k: v.cpu().numpy() for k, v in eng.finalize(temperature, uniform, move=self.move_counter).items()}
       self.move_counter += 1
       for i, g in enumerate(games):

@@ -106,6 +106,8 @@ def build_parser():
   a('--lr_decay_rate', type=float, default=0.1)
   a('--lr_decay_steps', type=int, default=100000)
   a('--learner_gpu_device_id', type=int, default=None)
+  a('--no_graph_learner', action='store_true',
+    help='run the learner step as eager PyTorch launches instead of one captured hipGraph per update (learners.py)')
   a('--learner_log_frequency', type=int, default=100)
   a('--frames_before_fps_log', type=int, default=10000)
   a('--runs_dir', type=str, default='runs', help='root of the run directories (the reference writes ./runs)')

@@ -45,6 +45,12 @@ struct TreeView {
   int sim_io_keep;
 };
 
+// (development switch -DMZ_NO_SIM_IO: the kernels without the instrumentation's branches, for A/B runs of its cost)
+#ifdef MZ_NO_SIM_IO
+#define MZ_SIM_IO_ON false
+#else
+#define MZ_SIM_IO_ON true
+#endif
 // the row of (move, tree b, expansion slot) in the sim_io buffer
 __device__ __forceinline__ float *mz_sim_io_row(const TreeView &t, int b, unsigned long long move, int slot) {
   const int keep = t.sim_io_keep < 0 ? -t.sim_io_keep : t.sim_io_keep;

@@ -1108,7 +1108,7 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
         // that they reach THIS tree code.  Loads issued and awaited inside asm (mz_sim_io_load): the production path
         // behind the never-taken branch gets no s_waitcnt for them.
         if constexpr (!HEAD) {
-          if (__builtin_expect(t.sim_io_keep < 0, 0)) {
+          if (MZ_SIM_IO_ON && __builtin_expect(t.sim_io_keep < 0, 0)) {
             const float *io = mz_sim_io_row(t, b0 + mt, 0ull, slot0 + sim + 1);
             float lgi = 0.f;
             mz_sim_io_load(vv, io); mz_sim_io_load(rew, io + 1); mz_sim_io_load(lgi, io + 2 + (tl < n.A ? tl : 0));
@@ -1126,7 +1126,7 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
         // recomputed from the LDS the values came from (split-K partials, s_rew, s_lg: untouched until the next
         // simulation's first barrier) by the very same device functions: nothing of the production path lives longer or
         // is scheduled differently for this block, which costs it one scalar compare + branch per simulation.
-        if (__builtin_expect(t.sim_io_keep > 0, 0)) {
+        if (MZ_SIM_IO_ON && __builtin_expect(t.sim_io_keep > 0, 0)) {
           unsigned long long mvx = 0;
           if constexpr (ENVS) mvx = *(const unsigned long long *)(s_env + mt * MZ_ENVW);
           else if (record) mvx = sp.movecnt[b0 + mt];
@@ -1159,14 +1159,14 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
           float vv = s_val[mt], rew = s_rew[mt];
           // test instrumentation (mz_sim_io), as in the 16-lane path above; lane a owns logit a of s_lg
           if constexpr (!HEAD) {
-            if (__builtin_expect(t.sim_io_keep < 0, 0)) {
+            if (MZ_SIM_IO_ON && __builtin_expect(t.sim_io_keep < 0, 0)) {
               const float *io = mz_sim_io_row(t, b, 0ull, slot0 + sim + 1);
               float lgi = 0.f;
               mz_sim_io_load(vv, io); mz_sim_io_load(rew, io + 1); mz_sim_io_load(lgi, io + 2 + (tl < n.A ? tl : 0));
               if (tl < n.A) s_lg[mt * 32 + tl] = lgi;
             }
           }
-          if (__builtin_expect(t.sim_io_keep > 0, 0)) {
+          if (MZ_SIM_IO_ON && __builtin_expect(t.sim_io_keep > 0, 0)) {
             unsigned long long mvx = 0;
             if constexpr (ENVS) mvx = *(const unsigned long long *)(s_env + mt * MZ_ENVW);
             else if (record) mvx = sp.movecnt[b];

@@ -529,7 +529,7 @@ __global__ __launch_bounds__(256, 1) void k_search_h2(NetView n, TreeView t, con
         // test instrumentation (mz_sim_io), zeros in production -- see k_search_fused: inject in front of the tree step
         // (not in the whole-moves launch), log behind it, recomputed from LDS
         if constexpr (!HEAD) {
-          if (__builtin_expect(t.sim_io_keep < 0, 0)) {
+          if (MZ_SIM_IO_ON && __builtin_expect(t.sim_io_keep < 0, 0)) {
             const float *io = mz_sim_io_row(t, b0 + mt, 0ull, slot0 + sim + 1);
             float lgi = 0.f;
             mz_sim_io_load(vv, io); mz_sim_io_load(rew, io + 1); mz_sim_io_load(lgi, io + 2 + (tl < n.A ? tl : 0));
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(256, 1) void k_search_h2(NetView n, TreeView t, con
         mz_tree_backup_select_f<TL, G, LT, SP>(t, tm, tl, vv, rew, s_path + mt * MZ_FUSED_MAXPL, s_stage + mt * 96,
                                                s_pbc, s_rcp, tr, sim + 1 < nsims, my_slot, my_act,
                                                MzHiddenPrefetch{t.hpool, hoff, hv}, stampf);
-        if (__builtin_expect(t.sim_io_keep > 0, 0)) {
+        if (MZ_SIM_IO_ON && __builtin_expect(t.sim_io_keep > 0, 0)) {
           unsigned long long mvx = 0;
           if (record) mvx = sp.movecnt[b0 + mt];
           float *io = mz_sim_io_row(t, b0 + mt, mvx, slot0 + sim + 1);

@@ -489,6 +489,33 @@ static int64_t get_leaf(const mz_replay *r, double value) {
   }
 }
 
+// SumTree.get_leaf's payload (replay_buffer.py:58-62): the (step, history) the leaf at tree index idx holds
+int mzr_leaf_info(const mz_replay *r, int64_t idx, double *priority, int64_t *step, int64_t *n_steps, int *has_payload) {
+  if (!r) return fail("mzr_leaf_info: null handle");
+  drain(r);
+  const int64_t pos = idx - r->max_capacity + 1;
+  if (pos < 0 || pos >= r->max_capacity) return fail("mzr_leaf_info: %lld is not a leaf index", (long long)idx);
+  const Hist *h = r->leaf_hist[(size_t)pos];
+  if (priority) *priority = r->tree[(size_t)idx];
+  if (step) *step = h ? r->leaf_step[(size_t)pos] : -1;
+  if (n_steps) *n_steps = h ? h->n : 0;
+  if (has_payload) *has_payload = (h && h->payload) ? 1 : 0;
+  return 0;
+}
+
+int mzr_leaf_history(const mz_replay *r, int64_t idx, float *rows_out, int64_t n_steps) {
+  if (!r || !rows_out) return fail("mzr_leaf_history: null argument");
+  drain(r);
+  const int64_t pos = idx - r->max_capacity + 1;
+  if (pos < 0 || pos >= r->max_capacity) return fail("mzr_leaf_history: %lld is not a leaf index", (long long)idx);
+  const Hist *h = r->leaf_hist[(size_t)pos];
+  if (!h) return fail("mzr_leaf_history: leaf %lld is empty", (long long)idx);
+  if (!h->payload) return fail("mzr_leaf_history: the history was ingested without payload");
+  if (n_steps != h->n) return fail("mzr_leaf_history: the history has %lld steps, the buffer %lld", (long long)h->n, (long long)n_steps);
+  memcpy(rows_out, h->rows.data() + (size_t)h->off * r->R, (size_t)h->n * r->R * sizeof(float));
+  return 0;
+}
+
 double mzr_total_priority(const mz_replay *r) { drain(r); return r->tree[0]; }
 int64_t mzr_size(const mz_replay *r) { drain(r); return r->num_memories; }
 int mzr_tree_leaves(const mz_replay *r, int64_t n, double *out) {

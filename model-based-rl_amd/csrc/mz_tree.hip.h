@@ -410,8 +410,14 @@ __device__ __forceinline__ void mz_tree_backup_select_f(const TreeView &t, const
       if constexpr (LT != 0) tm.X[vi] = new_q;       // what the descent normalises (the root's is never read)
     }
     const bool inner = act & (j < len - 1);          // MinMaxStats.update for every node but the root (mcts.py:136-141)
-    mn_c = inner ? new_q : mn_c;
-    mx_c = inner ? new_q : mx_c;
+    // (accumulated, not assigned: a path longer than TL nodes takes a second round of this loop, whose nodes must not
+    // replace the first round's in the lane's running pair -- found by the injected-output test of a 26-node chain,
+    // tests/test_gpu_fused_exact.py: until r04 the first round's values of the lanes busy in the second were lost)
+    double mn_t, mx_t;
+    asm("v_min_f64 %0, %1, %2" : "=v"(mn_t) : "v"(new_q), "v"(mn_c));
+    asm("v_max_f64 %0, %1, %2" : "=v"(mx_t) : "v"(new_q), "v"(mx_c));
+    mn_c = inner ? mn_t : mn_c;
+    mx_c = inner ? mx_t : mx_c;
     if (shortp) s_stage[64 + lane] = inner ? new_q : __builtin_nan("");
   }
   tr.root_n += 1;

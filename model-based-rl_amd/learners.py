@@ -3,7 +3,14 @@ prioritized replay, priority refresh, weight publication, checkpoints.  The trai
 (on ROCm when `--use_gpu_for learner`); only its semantics follow the reference: initial inference + K
 recurrent steps, 0.5 gradient scale on the hidden state per step (learners.py:200), importance-sampling
 weighted cross-entropy losses on the categorical supports, 1/K gradient scale on the total loss (214),
-AdamW with eps 1.5e-4 (utils.py:85-97)."""
+AdamW with eps 1.5e-4 (utils.py:85-97).
+
+On a GPU the whole update -- forward, losses, backward, gradient clipping, optimiser step -- is ONE captured hipGraph
+(stock `torch.cuda.CUDAGraph`: static batch tensors, capturable optimiser), replayed once per batch: eager, the step is
+~600 launches of a few microseconds of work each and runs at the launch rate (122-137 updates/s on an idle MI355X,
+profiles/r03_k_tictactoe_learning.json); the priority refresh of batch i reaches the replay while batch i + 1 is on the GPU
+(the reference's learner prefetches `batches_per_fetch` batches and sends its refresh fire-and-forget, learners.py:124,182).
+`--no_graph_learner` and CPU learners run the same tensor code eagerly."""
 import os
 import time
 from copy import deepcopy
@@ -36,9 +43,16 @@ def soft_cross_entropy(logits, target):
   return (-target * torch.log_softmax(logits, dim=1)).sum(1)
 
 
-def make_optimizer(config, params):
+def make_optimizer(config, params, capturable=False):
+  """utils.get_optimizer (utils.py:73-83).  capturable: the step runs inside a captured graph -- step counters and the
+  learning rate live in device tensors (the schedulers below write the rate in place)."""
   name = getattr(config, 'optimizer', 'AdamW')
   lr, wd = config.lr_init, getattr(config, 'weight_decay', 1e-4)
+  if capturable and name in ('AdamW', 'Adam'):
+    params = list(params)
+    lr = torch.tensor(float(lr), dtype=torch.float32, device=params[0].device)
+    cls = torch.optim.AdamW if name == 'AdamW' else torch.optim.Adam
+    return cls(params, lr=lr, weight_decay=wd, eps=0.00015, capturable=True, foreach=True)
   if name == 'AdamW':
     return torch.optim.AdamW(params, lr=lr, weight_decay=wd, eps=0.00015)
   if name == 'Adam':
@@ -48,6 +62,15 @@ def make_optimizer(config, params):
   if name == 'SGD':
     return torch.optim.SGD(params, lr=lr, momentum=getattr(config, 'momentum', 0.9), weight_decay=wd)
   raise NotImplementedError(name)
+
+
+def _set_lr(optimizer, lr):
+  """a capturable optimiser keeps its rate in a device tensor a captured graph reads: written in place (no host sync)"""
+  for g in optimizer.param_groups:
+    if torch.is_tensor(g['lr']):
+      g['lr'].fill_(lr)
+    else:
+      g['lr'] = lr
 
 
 class MuZeroLR(object):
@@ -60,8 +83,20 @@ class MuZeroLR(object):
   def step(self):
     self.lr_step += 1
     self.lr = self.lr_init * self.rate ** (self.lr_step / self.steps)
-    for g in self.optimizer.param_groups:
-      g['lr'] = self.lr
+    _set_lr(self.optimizer, self.lr)
+
+
+class ExponentialLR(object):
+  """torch.optim.lr_scheduler.ExponentialLR(optimizer, lr_decay_rate) (utils.py:124-125): lr_init * rate ** step, as a closed
+  form on the host (the torch class reads the rate back from the optimiser every step: a device sync when it is a tensor)"""
+
+  def __init__(self, optimizer, config):
+    self.optimizer, self.lr_init, self.rate, self.lr_step, self.lr = optimizer, config.lr_init, config.lr_decay_rate, 0, config.lr_init
+
+  def step(self):
+    self.lr_step += 1
+    self.lr = self.lr_init * self.rate ** self.lr_step
+    _set_lr(self.optimizer, self.lr)
 
 
 class WarmUpLR(object):
@@ -73,8 +108,7 @@ class WarmUpLR(object):
 
   def _set(self, lr):
     self.lr = lr
-    for g in self.optimizer.param_groups:
-      g['lr'] = lr
+    _set_lr(self.optimizer, lr)
 
   def step(self):
     self.lr_step += 1
@@ -88,14 +122,91 @@ def make_lr_scheduler(config, optimizer):
   if name is None:
     return None
   if name == 'ExponentialLR':
-    sched = torch.optim.lr_scheduler.ExponentialLR(optimizer, config.lr_decay_rate)
-    sched.lr = config.lr_init
-    return sched
+    return ExponentialLR(optimizer, config)
   if name == 'MuZeroLR':
     return MuZeroLR(optimizer, config)
   if name == 'WarmUpLR':
     return WarmUpLR(optimizer, config)
   raise NotImplementedError(name)
+
+
+class _GraphedUpdate(object):
+  """Learner._device_step as one captured graph over static tensors (torch.cuda.CUDAGraph = a hipGraph on ROCm).
+  launch(host arrays): one pinned staging buffer -> ONE host-to-device copy -> graph replay -> the new errors back into
+  pinned memory, all on the current stream, nothing waited for; errors(slot) waits for that copy.  Two staging slots, so
+  that batch i + 1 is staged while update i runs."""
+  ORDER = ('obs', 'act', 't_rew', 't_val', 't_pol', 'w')
+
+  def __init__(self, learner, host):
+    dev = learner.device
+    self.learner = learner
+    self.meta = {k: (host[k].shape, host[k].dtype) for k in self.ORDER}
+    # every input in one byte buffer (8-byte aligned pieces): one copy per update instead of six
+    off, self.slices = 0, {}
+    for k in self.ORDER:
+      n = host[k].nbytes
+      self.slices[k] = (off, n)
+      off += (n + 7) & ~7
+    self.stage = [torch.empty(off, dtype=torch.uint8).pin_memory() for _ in range(2)]
+    self.stage_np = [st.numpy() for st in self.stage]
+    self.dev_bytes = torch.empty(off, dtype=torch.uint8, device=dev)
+    self.static = {}
+    for k in self.ORDER:
+      o, n = self.slices[k]
+      self.static[k] = self.dev_bytes[o:o + n].view(torch.from_numpy(np.empty(0, self.meta[k][1])).dtype).view(self.meta[k][0])
+    bs = host['obs'].shape[0]
+    self.err_host = [torch.empty(bs, dtype=torch.float32).pin_memory() for _ in range(2)]
+    self.events = [torch.cuda.Event(), torch.cuda.Event()]
+    self.slot = 0
+    self._fill(0, host)
+    self.dev_bytes.copy_(self.stage[0], non_blocking=True)
+    # capture must not train: remember parameters, optimiser state and loss sums, warm up + capture on a side stream, put
+    # everything back IN PLACE (the graph holds the addresses)
+    net, opt = learner.network, learner.optimizer
+    params = [p for g in opt.param_groups for p in g['params']]
+    saved_p = [p.detach().clone() for p in params]
+    saved_s = [{k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in opt.state.get(p, {}).items()} for p in params]
+    saved_l = learner._loss_dev.clone()
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+      for _ in range(3):
+        learner._device_step(*[self.static[k] for k in self.ORDER])
+    torch.cuda.current_stream(dev).wait_stream(side)
+    self.graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(self.graph):
+      self.new_errors = learner._device_step(*[self.static[k] for k in self.ORDER])
+    with torch.no_grad():
+      for p, sp, ss in zip(params, saved_p, saved_s):
+        p.copy_(sp)
+        for k, v in opt.state[p].items():
+          if torch.is_tensor(v):
+            v.copy_(ss[k]) if k in ss else v.zero_()
+      learner._loss_dev.copy_(saved_l)
+
+  def fits(self, host):
+    return all(host[k].shape == self.meta[k][0] and host[k].dtype == self.meta[k][1] for k in self.ORDER)
+
+  def _fill(self, slot, host):
+    buf = self.stage_np[slot]
+    for k in self.ORDER:
+      o, n = self.slices[k]
+      buf[o:o + n] = host[k].reshape(-1).view(np.uint8)
+
+  def launch(self, host):
+    slot = self.slot
+    self.slot ^= 1
+    self.events[slot].synchronize()          # (the update that used this slot two launches ago has read it)
+    self._fill(slot, host)
+    self.dev_bytes.copy_(self.stage[slot], non_blocking=True)
+    self.graph.replay()
+    self.err_host[slot].copy_(self.new_errors, non_blocking=True)
+    self.events[slot].record()
+    return slot
+
+  def errors(self, slot):
+    self.events[slot].synchronize()
+    return self.err_host[slot].numpy().copy()
 
 
 class Learner(Logger):
@@ -115,12 +226,18 @@ class Learner(Logger):
       self.device = torch.device('cpu')
     self.network = get_network(config, self.device)          # utils.get_network (utils.py:21-37)
     self.network.train()
-    self.optimizer = make_optimizer(config, self.network.parameters())
+    # one captured hipGraph per update on a GPU (module docstring); the optimisers with a capturable step only
+    self.use_graph = (self.device.type == 'cuda' and not getattr(config, 'no_graph_learner', False) and
+                      getattr(config, 'optimizer', 'AdamW') in ('AdamW', 'Adam'))
+    self.optimizer = make_optimizer(config, self.network.parameters(), capturable=self.use_graph)
     self.lr_scheduler = make_lr_scheduler(config, self.optimizer)
     if getattr(config, 'scalar_loss', 'MSE') not in ('MSE', 'Huber'):
       raise NotImplementedError(config.scalar_loss)
     self.training_step = 0
-    self.losses_to_log = {'reward': 0., 'value': 0., 'policy': 0.}
+    self._losses = {'reward': 0., 'value': 0., 'policy': 0.}
+    self._loss_dev = torch.zeros(3, dtype=torch.float64, device=self.device)      # summed on the device, read when logged
+    self._graph = None          # _GraphedUpdate, built from the first batch
+    self._pending = None        # (idxs, slot) of the update whose priority refresh has not reached the replay yet
     self.throughput = {'total_frames': 0, 'total_games': 0, 'training_step': 0, 'time': {'ups': 0, 'fps': 0}}
     self.last_throughput = {}
     if getattr(config, 'norm_obs', False):
@@ -159,23 +276,33 @@ class Learner(Logger):
   def send_weights(self):
     _call(self.storage, 'store_weights', self.network.get_weights(), self.training_step)
 
-  # learners.py:164-230
-  def update_weights(self, batch):
+  @property
+  def losses_to_log(self):
+    """{'reward', 'value', 'policy'}: loss sums since the last log (learners.py:228-230).  The steps add them up on the
+    device; they come to the host when somebody looks."""
+    acc = self._loss_dev.tolist()
+    self._loss_dev.zero_()
+    for i, k in enumerate(('reward', 'value', 'policy')):
+      self._losses[k] += acc[i]
+    return self._losses
+
+  def _host_batch(self, batch):
+    """the batch as the six arrays the step consumes (learners.py:165-180), normalised observations included"""
     (observations, actions, (target_rewards, target_values, target_policies)), idxs, is_weights = batch
-    cfg, dev = self.config, self.device
-    if getattr(cfg, 'norm_obs', False):
+    if getattr(self.config, 'norm_obs', False):
       observations = (observations - self.obs_min) / self.obs_range
-    obs = torch.from_numpy(np.ascontiguousarray(observations)).to(dev)
+    return {'obs': np.ascontiguousarray(observations, np.float32), 'act': np.ascontiguousarray(actions, np.int64),
+            't_rew': np.ascontiguousarray(target_rewards), 't_val': np.ascontiguousarray(target_values),
+            't_pol': np.ascontiguousarray(target_policies), 'w': np.ascontiguousarray(is_weights)}, idxs
+
+  # learners.py:164-230 on device tensors: no host round trip inside, so it can be captured
+  def _device_step(self, obs, act, t_rew, t_val, t_pol, w):
+    cfg = self.config
     value, _, policy_logits, hidden = self.network.initial_inference(obs)
     with torch.no_grad():
-      t_pol = torch.from_numpy(target_policies).to(dev)
-      t_val = torch.from_numpy(target_values).to(dev)
-      t_rew = torch.from_numpy(target_rewards).to(dev)
-      w = torch.from_numpy(np.asarray(is_weights)).to(dev)
       no_support = getattr(cfg, 'no_support', False)
       init_value = value if no_support else support_to_scalar(value, cfg.value_support_min, cfg.no_target_transform)
-      new_errors = (init_value.squeeze() - t_val[:, 0]).cpu().numpy()
-      _call(self.replay_buffer, 'update', idxs, new_errors)
+      new_errors = init_value.squeeze() - t_val[:, 0]
       if not cfg.no_target_transform:
         t_val, t_rew = scalar_transform(t_val), scalar_transform(t_rew)
       if not no_support:
@@ -190,13 +317,10 @@ class Learner(Logger):
     reward_loss = 0
     value_loss = scalar_loss(value.squeeze(), t_val[:, 0])
     policy_loss = soft_cross_entropy(policy_logits.squeeze(), t_pol[:, 0])
-    # the K action columns go to the device ONCE (the reference hands recurrent_inference a Python tuple per unroll step,
-    # learners.py:196-197: one pageable host-to-device copy per step, each of which waits behind whatever else the GPU
-    # runs -- 3 ms per copy beside a self-play loop on the same GPU)
-    act = torch.as_tensor(np.asarray(actions, np.int64), device=dev)
+    # (the K action columns are on the device already: the reference hands recurrent_inference a Python tuple per unroll
+    # step, learners.py:196-197 -- one pageable host-to-device copy per step)
     for i in range(1, act.shape[1] + 1):
-      action = act[:, i - 1]
-      value, reward, policy_logits, hidden = self.network.recurrent_inference(hidden, action)
+      value, reward, policy_logits, hidden = self.network.recurrent_inference(hidden, act[:, i - 1])
       hidden.register_hook(lambda grad: grad * 0.5)
       reward_loss = reward_loss + scalar_loss(reward.squeeze(), t_rew[:, i])
       value_loss = value_loss + scalar_loss(value.squeeze(), t_val[:, i])
@@ -204,16 +328,40 @@ class Learner(Logger):
     reward_loss, value_loss, policy_loss = (w * reward_loss).mean(), (w * value_loss).mean(), (w * policy_loss).mean()
     total = reward_loss + value_loss + policy_loss
     total.register_hook(lambda grad: grad * (1 / cfg.num_unroll_steps))
-    self.optimizer.zero_grad()
+    self.optimizer.zero_grad(set_to_none=True)
     total.backward()
     if getattr(cfg, 'clip_grad', 0):
       torch.nn.utils.clip_grad_norm_(self.network.parameters(), cfg.clip_grad)
     self.optimizer.step()
+    self._loss_dev += torch.stack((reward_loss.detach(), value_loss.detach(), policy_loss.detach())).to(torch.float64)
+    return new_errors
+
+  def flush_priorities(self):
+    """hand the last update's priority refresh to the replay (learners.py:182), waiting for its copy to arrive"""
+    if self._pending is not None:
+      idxs, slot = self._pending
+      self._pending = None
+      _call(self.replay_buffer, 'update', idxs, self._graph.errors(slot))
+
+  def update_weights(self, batch, defer_priorities=False):
+    """One training step (learners.py:164-230).  defer_priorities (learn()'s loop): this batch's new errors go to the replay
+    at the NEXT call, i.e. while the following update is already running on the GPU."""
+    host, idxs = self._host_batch(batch)
+    if self.use_graph:
+      if self._graph is None or not self._graph.fits(host):
+        self.flush_priorities()
+        self._graph = _GraphedUpdate(self, host)
+      slot = self._graph.launch(host)
+      self.flush_priorities()                    # the previous batch's, whose copy has had a whole update to arrive
+      self._pending = (idxs, slot)
+      if not defer_priorities:
+        self.flush_priorities()
+    else:
+      dev = self.device
+      new_errors = self._device_step(*[torch.from_numpy(host[k]).to(dev) for k in _GraphedUpdate.ORDER])
+      _call(self.replay_buffer, 'update', idxs, new_errors.detach().cpu().numpy())
     if self.lr_scheduler is not None:             # learners.py:225-226
       self.lr_scheduler.step()
-    self.losses_to_log['reward'] += reward_loss.item()
-    self.losses_to_log['value'] += value_loss.item()
-    self.losses_to_log['policy'] += policy_loss.item()
 
   # learners.py:88-113: the reference's own throughput scalars -- frames_per_second is its env-steps/sec metric
   def log_throughput(self, force=False):
@@ -252,7 +400,7 @@ class Learner(Logger):
       batch = _call(self.replay_buffer, 'sample_batch')
       turn = gpu_turns.turn(self.device)
       with turn:         # (an actor on the same GPU: one update per turn, see gpu_turns.py)
-        self.update_weights(batch)
+        self.update_weights(batch, defer_priorities=True)
         if turn is not gpu_turns.NO_TURNS:
           torch.cuda.current_stream(self.device).synchronize()
       self.training_step += 1
@@ -267,6 +415,7 @@ class Learner(Logger):
         self.log_throughput()
         if self.lr_scheduler is not None:
           self.log_scalar(tag='loss/learning_rate', value=self.optimizer.param_groups[0]['lr'], i=self.training_step)      # (what the optimizer really uses, every scheduler)
+    self.flush_priorities()
     self.log_throughput(force=True)
     self.send_weights()
 

@@ -32,6 +32,7 @@ class SumTree(object):
       self._h, self._own = h, True
     else:
       self._h, self._own = _owner, False
+    self._rows = (False, int(obs_dim), int(action_space))      # (byte observations, obs_dim, action_space) of the record rows
 
   def __del__(self):
     if getattr(self, '_own', False) and getattr(self, '_h', None):
@@ -51,6 +52,26 @@ class SumTree(object):
 
   def get_leaf_index(self, value):
     return int(self.lib.mzr_tree_get_leaf(self._h, float(value)))
+
+  def get_leaf(self, value):
+    """replay_buffer.py:42-62: (leaf_index, priority, step, history) -- the history comes back as a HistorySlice
+    (game.py:5-16) rebuilt from the record rows the native replay keeps (None for a priorities-only leaf); like the
+    stored slice it has as many observations as steps (the reference's History keeps one more, game.py:93-96)."""
+    idx = self.get_leaf_index(value)
+    pri, step, n, has = C.c_double(0), C.c_int64(0), C.c_int64(0), C.c_int(0)
+    _abi.check_replay(self.lib.mzr_leaf_info(self._h, idx, C.byref(pri), C.byref(step), C.byref(n), C.byref(has)), 'mzr_leaf_info')
+    history = None
+    if has.value:
+      from .engine import REC_EXTRA, records_view
+      from .game import HistorySlice
+      u8, O, A = self._rows
+      rows = np.zeros((n.value, ((O + 3) // 4 if u8 else O) + A + REC_EXTRA), np.float32)
+      _abi.check_replay(self.lib.mzr_leaf_history(self._h, idx, _p(rows), n.value), 'mzr_leaf_history')
+      v = records_view(rows, O, A, obs_u8=u8)
+      history = HistorySlice(list(v['obs']), [list(map(float, c)) for c in v['child_visits']], v['root_value'].tolist(),
+                             v['action'].tolist(), v['reward'].tolist(), v['error'].tolist(),
+                             [bool(d) for d in v['done']], v['step'].tolist(), [], v['to_play'].tolist())
+    return idx, pri.value, int(step.value), history
 
   @property
   def total_priority(self):
@@ -101,7 +122,8 @@ class PrioritizedReplay(object):
     h = C.c_void_p()
     _abi.check_replay(self.lib.mzr_create(C.byref(cfg), C.byref(h)), 'mzr_create')
     self._h = h
-    self.tree = SumTree(capacity, step, _owner=self._h)
+    self.tree = SumTree(capacity, step, _owner=self._h, obs_dim=self.obs_dim, action_space=self.action_space)
+    self.tree._rows = (bool(getattr(config, 'obs_u8', False)), self.obs_dim, self.action_space)
     if config.seed is not None:          # replay_buffer.py:104-106
       np.random.seed(config.seed)
       random.seed(config.seed + 1)

@@ -29,6 +29,24 @@ def test_header_symbols_exported():
   assert lib.mz_version() == 1
 
 
+def test_replay_header_symbols_exported():
+  """include/mz_replay.h (the host replay's C ABI) against libmz_replay.so and the ctypes table"""
+  from model_based_rl_amd import _abi
+  _abi.build_replay()
+  lib = _abi.load_replay()
+  text = re.sub(r'/\*.*?\*/', '', open(os.path.join(ROOT, 'include', 'mz_replay.h')).read(), flags=re.S)
+  syms = sorted(set(re.findall(r'\b(mzr_[a-z_0-9]+)\s*\(', text)))
+  assert len(syms) >= 15
+  for s in syms:
+    assert hasattr(lib, s), 'libmz_replay.so does not export %s' % s
+  assert set(_abi.REPLAY_SIGNATURES) == set(syms), set(_abi.REPLAY_SIGNATURES) ^ set(syms)
+  subprocess.check_call(['gcc', '-std=c99', '-fsyntax-only', '-x', 'c', os.path.join(ROOT, 'include', 'mz_replay.h')])
+  src = '#include "mz_replay.h"\n#include <stdio.h>\nint main(){printf("%zu", sizeof(mzr_config));return 0;}\n'
+  exe = '/tmp/mzr_sizeof_test'
+  subprocess.run(['gcc', '-x', 'c', '-', '-I', os.path.join(ROOT, 'include'), '-o', exe], input=src.encode(), check=True)
+  assert int(subprocess.check_output([exe])) == C.sizeof(_abi.MzrConfig)
+
+
 def test_config_struct_size_matches_c():
   from model_based_rl_amd import _abi
   src = '#include "mz_engine.h"\n#include <stdio.h>\nint main(){printf("%zu", sizeof(mz_config));return 0;}\n'
@@ -65,3 +83,52 @@ def test_product_does_not_touch_oracle():
       if f.endswith(('.py', '.hip', '.h', '.inc')):
         text = open(os.path.join(d, f)).read()
         assert 'oracle' not in text.replace('no oracle', ''), os.path.join(d, f)
+
+
+def cdef_text(header):
+  """include/<header> as cffi.cdef() takes it: comments and preprocessor lines out, integer #defines kept"""
+  text = re.sub(r'/\*.*?\*/', '', open(os.path.join(ROOT, 'include', header)).read(), flags=re.S)
+  keep = []
+  for line in text.splitlines():
+    if line.startswith('#'):
+      if re.match(r'#define\s+\w+\s+\d+\s*$', line):
+        keep.append(line)
+      continue
+    if line.strip() in ('extern "C" {', '}'):
+      continue
+    keep.append(line)
+  return '\n'.join(keep)
+
+
+def test_headers_reduce_to_plain_declarations():
+  """what the cffi binding would be given: after stripping, only typedefs, structs, integer #defines and prototypes remain"""
+  for h, n in (('mz_engine.h', 40), ('mz_replay.h', 15)):
+    t = cdef_text(h)
+    assert '#include' not in t and '__cplusplus' not in t
+    assert len(re.findall(r'\bmzr?_[a-z_0-9]+\s*\(', t)) >= n
+    src = '#include <stdint.h>\n#include <stddef.h>\n' + t + '\nint main(void){return 0;}\n'
+    subprocess.run(['gcc', '-std=c99', '-fsyntax-only', '-x', 'c', '-'], input=src.encode(), check=True)
+
+
+def test_cffi_dlopen_fast_path():
+  """north_star names cffi; it is not installed in this image (ctypes binds the same symbols), so this runs wherever cffi exists"""
+  cffi = pytest.importorskip('cffi')
+  from model_based_rl_amd import _abi
+  _abi.build(); _abi.build_replay()
+  ffi = cffi.FFI()
+  ffi.cdef(cdef_text('mz_replay.h'))
+  lib = ffi.dlopen(os.path.join(ROOT, 'model-based-rl_amd', 'csrc', 'libmz_replay.so'))
+  cfg = ffi.new('mzr_config *', dict(window_size=64, window_step=64, obs_dim=3, action_space=2, num_unroll_steps=5, td_steps=10,
+                                     max_history_length=500, batch_size=4, epsilon=0.01, alpha=1.0, beta=1.0,
+                                     beta_increment_per_sampling=0.001, discount=0.997, seed=0))
+  h = ffi.new('mz_replay **')
+  assert lib.mzr_create(cfg, h) == 0
+  pri = ffi.new('double[]', [1.0, 2.0, 3.0])
+  assert lib.mzr_tree_add(h[0], pri, 3, ffi.NULL) == 0
+  assert lib.mzr_total_priority(h[0]) == 6.0 and lib.mzr_tree_get_leaf(h[0], 2.5) == 64
+  assert lib.mzr_destroy(h[0]) == 0
+  ffi2 = cffi.FFI()
+  ffi2.cdef(cdef_text('mz_engine.h'))
+  import torch  # noqa: F401  (one HIP runtime per process: torch's first, model_based_rl_amd/_abi.py)
+  eng = ffi2.dlopen(os.path.join(ROOT, 'model-based-rl_amd', 'csrc', 'libmz_hip.so'))
+  assert eng.mz_version() == 1

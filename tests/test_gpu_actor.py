@@ -24,8 +24,10 @@ class RecordingReplay(object):
     self.inner.save_history(history, ignore=ignore, terminal=terminal)
 
 
-@pytest.mark.parametrize('gi,temp', [(0, 1.0), (1, 0.1), (2, 0.0), (3, 1.0)])
-def test_actor_reproduces_reference_games(gi, temp):
+@pytest.mark.parametrize('gi,temp,envs', [(0, 1.0, 1), (1, 0.1, 1), (2, 0.0, 1), (3, 1.0, 1), (0, 1.0, 3)])
+def test_actor_reproduces_reference_games(gi, temp, envs):
+  # (envs = 3: Actor.play_game(game) with ONE Game, the reference's call (actors.py:126), on an actor whose engine searches
+  # three environments in lock-step -- the rows without a game of their own are ignored)
   from oracle import oracle as orc
   from model_based_rl_amd.actors import Actor
   from model_based_rl_amd.config import make_config
@@ -33,7 +35,7 @@ def test_actor_reproduces_reference_games(gi, temp):
   from model_based_rl_amd.shared_storage import SharedStorage
   g = np.load(os.path.join(G, 'g3_game_ttt_%d.npz' % gi))
   cfg = make_config(['--environment', 'TicTacToe', '--two_players', '--known_bounds', '-1', '1', '--discount', '1',
-                     '--num_simulations', '30', '--seed', '0', '--num_envs', '1', '--parity_rng', '--window_size', '60000',
+                     '--num_simulations', '30', '--seed', '0', '--num_envs', str(envs), '--parity_rng', '--window_size', '60000',
                      '--max_history_length', str(int(g['max_history_length'])), '--fixed_temperatures', str(temp)])
   storage = SharedStorage(cfg)
   storage.store_weights(orc.load_weights(g), 0)

@@ -180,6 +180,14 @@ def test_fused_tree_code_vs_oracle_on_injected_random_outputs(shape, variant):
   lg[rng.uniform(size=(B, sims)) < 0.1] = 0.5              # exact ties among the priors
   val[rng.uniform(size=(B, sims)) < 0.05] = 0.0
   rew[rng.uniform(size=(B, sims)) < 0.3] = 0.0             # (value 0 / reward 0: exact score ties between siblings)
+  # chains: in the first 128 trees one action carries nearly all the prior at every node, so the search keeps extending ONE
+  # path -- up to num_simulations + 1 nodes, more than the 16 (32) lanes a tree's backup handles per round (the r04 bug:
+  # MinMaxStats lost the first round's nodes of such a path)
+  lg[:128] = (rng.standard_normal((128, sims, A)) * 0.1).astype(np.float32)
+  lg[:128, :, rng.randint(0, A)] += 9.0
+  logits[:128] = lg[:128, 0]
+  legal[:128] = 1
+  noise[:128] = rng.dirichlet([0.25] * A, size=128)
   eng.root_load(v0, logits)
   eng.root_prepare(tp, legal, noise)
   vals = np.zeros((B, sims + 1, 2 + A), np.float32)
@@ -196,6 +204,7 @@ def test_fused_tree_code_vs_oracle_on_injected_random_outputs(shape, variant):
   ex, eo = eng.export_tree(), t.export()
   EX = eo['EX'].astype(bool)
   assert t.margin().min() == 0.0                            # (the ties are there)
+  assert (eo['N'][:128] > 0).sum(1).max() > min(sims, 17)   # (and the long chains: more visited nodes than one backup round)
   assert np.array_equal(ex['EX'].astype(bool), EX)
   for k in ('N', 'E', 'TP', 'W'):
     assert np.array_equal(ex[k][EX], eo[k][EX]), (k, info)

@@ -35,8 +35,16 @@ def test_save_history_matches_reference(path):
     assert rep.size() == int(meta[5])
     assert rep.get_throughput() == {'frames': int(meta[6]), 'games': int(meta[7])}
   assert np.array_equal(rep.tree.leaves(), g['replay_leaves'])
-  for draw, idx in zip(g['sample_draws'], g['sample_idxs']):
+  leaves = rep.tree.leaves()
+  for i, (draw, idx) in enumerate(zip(g['sample_draws'], g['sample_idxs'])):
     assert rep.tree.get_leaf_index(float(draw)) == int(idx)
+    # SumTree.get_leaf (replay_buffer.py:42-62): leaf index, priority, and the (step, history) payload -- checked against the
+    # observation and first action the reference's sample_batch read through that very payload (replay_buffer.py:142-152)
+    li, pri, step, hist = rep.tree.get_leaf(float(draw))
+    assert li == int(idx) and pri == leaves[li - (rep.tree.max_capacity - 1)]
+    assert np.array_equal(np.asarray(hist.observations[step], np.float32).reshape(-1), g['sample_obs'][i].reshape(-1))
+    assert hist.actions[step] == int(g['sample_actions'][i][0])
+    assert len(hist.actions) == len(hist.errors) == len(hist.child_visits) == len(hist.to_play)
 
 
 def test_tree_matches_oracle_with_growing_capacity():
