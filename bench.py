@@ -248,8 +248,8 @@ def live_traffic(workload, split_f16, chunk):
   for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
     d = tempfile.mkdtemp(prefix='mz_pmc_', dir='/tmp')
     cmd = ['rocprofv3', '--pmc', counter, '--output-format', 'csv', '-d', d, '--', sys.executable, os.path.abspath(__file__),
-           '--steps', '16', '--warmup', '8', '--no-cpu-baseline', '--min-seconds', '0.05', '--workload', workload, '--chunk',
-           str(chunk)] + (['--split-f16'] if split_f16 else [])
+           '--steps', str(chunk), '--warmup', str(chunk), '--no-cpu-baseline', '--min-seconds', '0.05', '--workload', workload,
+           '--chunk', str(chunk)] + (['--split-f16'] if split_f16 else [])
     try:
       subprocess.run(cmd, env=dict(os.environ, MZ_BENCH_CHILD='1', TMPDIR='/tmp'), cwd='/tmp', stdout=subprocess.DEVNULL,
                      stderr=subprocess.DEVNULL, timeout=90)
@@ -318,6 +318,47 @@ def measure_split_f16(device, flat, chunk, moves=384):
           'algorithmic_tflops': (SIMS * FLOP_PER_SIM + (FLOP_PER_ROOT if persistent else 0)) * B / (us * 1e-6) / 1e12}
 
 
+def ingest_threads_for(world, one_replay_rank0=False):
+  """Ingest threads of a rank's native replay, sized so that `world` ranks fit the box's usable cores (the GPU boxes run a job
+  under a 16-CPU quota): every rank keeps its launching thread and its ingest worker (~1.2 cores busy); what is
+  left of the rank's share -- at most 4 -- assembles histories.  One thread sustains 42-46 M records/s against the 10 M/s a
+  GPU produces (profiles/r03_*_ingest_bench.json).  one_replay_rank0: the ONE replay of `--one-replay` takes every other
+  rank's records too and gets the cores the other ranks leave."""
+  cores = _usable_cores()
+  if one_replay_rank0:
+    return int(max(1, min(8, cores - 1.25 * world)))
+  return int(max(1, min(4, cores // max(1, world) - 1)))
+
+
+def self_launch(args):
+  """`python bench.py --gpus N` with N > 1 and no launcher: start `python -m torch.distributed.run --nproc-per-node N bench.py
+  ...` as a CHILD process (this process has not touched the GPU -- and never replaces itself: os.exec* from a GPU process takes
+  the box down), relay rank 0's JSON line and exit with the child's code.  (Reference wiring: train.py:62-78 starts N actor
+  processes from one command.)"""
+  import socket
+  import subprocess
+  with socket.socket() as sk:
+    sk.bind(('127.0.0.1', 0))
+    port = sk.getsockname()[1]
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr',
+         '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+  env = dict(os.environ)
+  env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+  env.setdefault('OMP_NUM_THREADS', '1')
+  proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+  line = None
+  for out in proc.stdout:
+    out = out.rstrip('\n')
+    if out.startswith('{') and '"metric"' in out:
+      line = out
+    else:
+      print(out, file=sys.stderr, flush=True)
+  rc = proc.wait()
+  if line is not None:
+    print(line, flush=True)
+  sys.exit(rc if rc else (0 if line is not None else 1))
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
@@ -330,13 +371,18 @@ def main():
   ap.add_argument('--sync-every', type=int, default=128,
                   help='moves between weight pulls (the path\'s one exchange: broadcast + repack)')
   ap.add_argument('--min-seconds', type=float, default=1.2,
-                  help='the --steps block is repeated back to back until the timed region is at least this long')
+                  help='the --steps block is repeated back to back until one timed region is at least this long')
+  ap.add_argument('--runs', type=int, default=5,
+                  help='timed regions (SURVEY.md s8d: mean +- std of 5 runs); `value` covers all of them')
   ap.add_argument('--split-f16', action='store_true',
                   help='secondary line: the FCNetwork GEMMs as float16 high/low splits on the f16 matrix pipe '
                        '(mz_config.split_f16; float32-level accuracy, not bit-identical to the exact-f32 default)')
   ap.add_argument('--one-replay', action='store_true',
-                  help='N > 1: the topology of `train --ranks N` -- every rank ships its record chunks through a shared-memory ring '
-                       'to rank 0, whose ONE native replay ingests them all (default: one replay per rank; DESIGN.md s6)')
+                  help='N > 1: `value` in the topology of `train --ranks N` -- every rank ships its record chunks through a '
+                       'shared-memory ring to rank 0, whose ONE native replay ingests them all (default: one replay per rank, '
+                       'and this layout as `one_replay_secondary` in the same line; DESIGN.md s6)')
+  ap.add_argument('--no-one-replay-secondary', action='store_true')
+  ap.add_argument('--ingest-threads', type=int, default=None, help='ingest threads per replay (default: from usable cores / ranks)')
   ap.add_argument('--no-live-traffic', action='store_true',
                   help='do not measure roofline.traffic with two rocprofv3 --pmc child runs (N = 1 only; ~20 s)')
   ap.add_argument('--dump-records', default=None,
@@ -348,7 +394,10 @@ def main():
   if args.workload == 'tree':
     import bench_tree              # secondary line: the stand-alone tree kernels against the HBM / cache rooflines (SURVEY.md s8d ii)
     return bench_tree.main(args)
+  if args.gpus > 1 and 'RANK' not in os.environ:
+    return self_launch(args)       # one process per GPU, started from here (before anything touches the GPU)
   chunk = max(1, args.chunk)
+  child = bool(os.environ.get('MZ_BENCH_CHILD'))     # a PMC pass of live_traffic(): every launch must play `chunk` moves
 
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
@@ -373,8 +422,6 @@ def main():
       dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     else:
       dist.init_process_group(backend)
-  elif args.gpus > 1:
-    raise SystemExit('--gpus %d needs the torch.distributed.run launcher (one process per GPU)' % args.gpus)
   device = torch.device('cuda', local_rank)
   torch.cuda.set_device(device)
   coll_dev = device if backend != 'gloo' else torch.device('cpu')     # where collective buffers live
@@ -404,62 +451,119 @@ def main():
     n_syncs[0] += 1
 
   sync_weights()
-  replay = PrioritizedReplay(replay_config())
-  n_ingest = replay.ingest_threads
   ram = '-ram' in WNAME
   if ram:        # the -ram- envs: byte observations, --norm_obs --obs_range 0 255 inside the root kernel (actors.py:134-137)
     eng.selfplay_set_obs(uint8_obs=True, obs_min=[0.0], obs_range=[255.0])
   eng.selfplay_reset(EPISODE_LEN, 1.0, stagger=True)
-  one_replay = bool(args.one_replay) and dist is not None and world > 1
-  rings, ring_stop = {}, None
-  if one_replay:
-    # train.launch_ranks' wiring (reference train.py:71-72: ONE replay buffer for all actors): rank r > 0 owns a ring in
-    # shared memory, a thread on rank 0 drains the rings into the one replay with env_base = r * B
-    import threading
-    from model_based_rl_amd import distributed as D
-    run_id = 'mzb_%s' % os.environ.get('MASTER_PORT', '0')
-    if rank == 0:
-      rings = {r: D.ShmRing('%s_%d' % (run_id, r), chunk, B, eng.rec_floats, slots=4, create=True) for r in range(1, world)}
-    dist.barrier()
-    if rank == 0:
-      lock, inner = threading.Lock(), replay
 
-      class Locked(object):              # two callers on rank 0: its own pipeline worker and the ring server
-        def __getattr__(self, name):
-          def call(*a, **k):
-            with lock:
-              return getattr(inner, name)(*a, **k)
-          return call
-      replay = Locked()
-      ring_stop = threading.Event()
-      threading.Thread(target=D.serve_rings, args=(rings, lambda name, *a: getattr(replay, name)(*a), B, ring_stop), daemon=True).start()
-    else:
-      my_ring = D.ShmRing('%s_%d' % (run_id, rank))
-      replay = D.RingReplay(my_ring)
-      replay.get_throughput = lambda: {'frames': 0, 'games': 0}      # (counted where they are accepted: rank 0's replay)
-  pipe = Pipeline(eng, replay, chunk, device, sync_weights, max(chunk, args.sync_every), dump=[] if args.dump_records else None)
-  state, run, pinned, dump = pipe.state, pipe.run, pipe.pinned, pipe.dump
+  def make_replay(threads):
+    cfg = replay_config()
+    cfg.ingest_threads = threads
+    return PrioritizedReplay(cfg)
 
-  def barrier():
-    torch.cuda.synchronize(device)
-    if dist is not None:
+  class Layout(object):
+    """where this rank's records go: its own native replay (bench layout), or -- one_replay -- through a shared-memory
+    ring to the ONE replay on rank 0 (train.launch_ranks' wiring; reference train.py:71-72: one replay buffer for all actors)"""
+
+    def __init__(self, one_replay, tag):
+      self.one_replay = one_replay
+      self.rings, self.ring_stop, self.my_ring = {}, None, None
+      if not one_replay:
+        self.n_ingest = args.ingest_threads or ingest_threads_for(world)
+        self.replay = make_replay(self.n_ingest)
+        return
+      import threading
+      from model_based_rl_amd import distributed as D
+      run_id = 'mzb_%s_%s' % (os.environ.get('MASTER_PORT', '0'), tag)
+      self.n_ingest = args.ingest_threads or ingest_threads_for(world, one_replay_rank0=True)
+      if rank == 0:
+        self.rings = {r: D.ShmRing('%s_%d' % (run_id, r), chunk, B, eng.rec_floats, slots=4, create=True) for r in range(1, world)}
       dist.barrier()
-      if one_replay:        # every producer has put its last chunk: the region ends when the one replay has accepted them all
-        if rank == 0:
-          while any(int(r.hdr[1]) < int(r.hdr[0]) for r in rings.values()):
-            time.sleep(0.0002)
-          replay.size()     # (takes the lock behind an ingest in flight, and waits for the deferred insertions)
-        dist.barrier()
+      if rank == 0:
+        lock, inner = threading.Lock(), make_replay(self.n_ingest)
+
+        class Locked(object):              # two callers on rank 0: its own pipeline worker and the ring server
+          def __getattr__(self, name):
+            def call(*a, **k):
+              with lock:
+                return getattr(inner, name)(*a, **k)
+            return call
+        self.replay = Locked()
+        self.ring_stop = threading.Event()
+        threading.Thread(target=D.serve_rings, args=(self.rings, lambda name, *a: getattr(self.replay, name)(*a), B, self.ring_stop),
+                         daemon=True).start()
+      else:
+        self.my_ring = D.ShmRing('%s_%d' % (run_id, rank))
+        self.replay = D.RingReplay(self.my_ring)
+        self.replay.get_throughput = lambda: {'frames': 0, 'games': 0}      # (counted where they are accepted: rank 0's replay)
+
+    def barrier(self):
       torch.cuda.synchronize(device)
+      if dist is not None:
+        dist.barrier()
+        if self.one_replay:   # every producer has put its last chunk: the region ends when the one replay has accepted them all
+          if rank == 0:
+            while any(int(r.hdr[1]) < int(r.hdr[0]) for r in self.rings.values()):
+              time.sleep(0.0002)
+            self.replay.size()     # (takes the lock behind an ingest in flight, and waits for the deferred insertions)
+          dist.barrier()
+        torch.cuda.synchronize(device)
+
+    def close(self):
+      if self.one_replay:
+        dist.barrier()
+        if self.ring_stop is not None:
+          self.ring_stop.set()
+        for r_ in list(self.rings.values()) + ([self.my_ring] if self.my_ring is not None else []):
+          r_.release()
+
+  def timed_regions(pipe, layout, blocks, n_runs, marks_out=None):
+    """n_runs timed regions, each = `blocks` run back to back in one pipelined stream of chunks, bracketed by barrier +
+    torch.cuda.synchronize on both sides; the region's time is the MAX over ranks, its frames the SUM over ranks of what the
+    replays accepted.  -> list of (frames, seconds, host cores busy on this rank)"""
+    runs = []
+    for _ in range(n_runs):
+      layout.barrier()
+      frames0 = layout.replay.get_throughput()['frames']
+      marks = [] if marks_out is not None else None
+      start_ev = torch.cuda.Event(enable_timing=True)
+      t0 = time.perf_counter()
+      c0 = time.process_time()
+      start_ev.record()
+      pipe.run(blocks, marks)
+      layout.barrier()
+      dt = time.perf_counter() - t0
+      busy = (time.process_time() - c0) / dt      # CPU seconds of this rank (all its threads) per wall second
+      frames = layout.replay.get_throughput()['frames'] - frames0
+      if marks_out is not None:
+        marks_out += [a.elapsed_time(b) / blocks[0] for a, b in zip([start_ev] + marks[:-1], marks)]   # GPU clock, per step
+      if dist is not None:
+        tt = torch.tensor([dt, busy], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt, busy_max = float(tt[0].item()), float(tt[1].item())
+        ff = torch.tensor([frames], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(ff, op=dist.ReduceOp.SUM)
+        frames = float(ff.item())
+      else:
+        busy_max = busy
+      runs.append((frames, dt, busy, busy_max))
+    return runs
+
+  one_replay = bool(args.one_replay) and dist is not None and world > 1
+  layout = Layout(one_replay, 'a')
+  pipe = Pipeline(eng, layout.replay, chunk, device, sync_weights, max(chunk, args.sync_every), dump=[] if args.dump_records else None)
+  state, run, pinned, dump = pipe.state, pipe.run, pipe.pinned, pipe.dump
 
   # priming (untimed, not part of --warmup): every env finishes its first, partial (staggered) episode, so
   # that from here on B/EPISODE_LEN episodes end per move and the replay accepts B frames per move on
   # average -- the steady state the reference's frames_per_second metric is defined on
-  run([EPISODE_LEN])
+  # (a PMC child pass rounds every block to whole chunks: all its launches then play the same number of moves)
+  whole = lambda n: -(-n // chunk) * chunk if child else n
+  run([whole(EPISODE_LEN)])
   if dump is not None:
     np.save('%s.rank%d.npy' % (args.dump_records, rank), np.concatenate(dump, 0))
     dump = pipe.dump = None
-  run([args.steps])             # one untimed block: builds the hipGraphs of every chunk size a block uses
+  run([whole(args.steps)])      # one untimed block: builds the hipGraphs of every chunk size a block uses
   # calibration: how many --steps blocks make a timed region of >= --min-seconds (same count on every rank)
   torch.cuda.synchronize(device)
   t0 = time.perf_counter()
@@ -472,34 +576,23 @@ def main():
     rt = torch.tensor([repeats], dtype=torch.int64, device=coll_dev)
     dist.all_reduce(rt, op=dist.ReduceOp.MAX)
     repeats = int(rt.item())
-  total = repeats * args.steps
-  # the weight pull (broadcast + repack) fires inside the timed region whatever --steps is
-  state['sync_every'] = max(chunk, min(args.sync_every, max(chunk, total // 2)))
+  per_run = repeats * args.steps
+  n_runs = max(1, args.runs) if not child else 1
+  total = n_runs * per_run
+  # the weight pull (broadcast + repack) fires inside every timed region whatever --steps is
+  state['sync_every'] = max(chunk, min(args.sync_every, max(chunk, per_run // 2)))
   state['last_sync_q'] = state['gmove'] // state['sync_every']
-  run([args.warmup] if args.warmup > 0 else [])
-  barrier()
-  frames0 = replay.get_throughput()['frames']
+  run([whole(args.warmup)] if args.warmup > 0 else [])
   syncs0 = n_syncs[0]
-  marks = []
-  start_ev = torch.cuda.Event(enable_timing=True)
-  t0 = time.perf_counter()
-  c0 = time.process_time()
-  start_ev.record()
-  run([args.steps] * repeats, marks)
-  barrier()
-  dt = time.perf_counter() - t0
-  host_cores_busy = (time.process_time() - c0) / dt      # CPU seconds of this rank (all its threads) per wall second
-  frames = replay.get_throughput()['frames'] - frames0
+  block_ms = []
+  runs = timed_regions(pipe, layout, [whole(args.steps)] * repeats, n_runs, block_ms)
+  frames = sum(r[0] for r in runs)
+  dt = sum(r[1] for r in runs)
+  host_cores_busy = float(np.mean([r[2] for r in runs]))
+  host_cores_busy_max = float(np.max([r[3] for r in runs]))
   syncs_in_region = n_syncs[0] - syncs0
-  block_ms = [a.elapsed_time(b) / args.steps for a, b in zip([start_ev] + marks[:-1], marks)]   # GPU clock, per step
-  if dist is not None:
-    tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
-    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt = float(tt.item())
-    ff = torch.tensor([frames], dtype=torch.float64, device=coll_dev)
-    dist.all_reduce(ff, op=dist.ReduceOp.SUM)
-    frames = float(ff.item())
-  env_steps = world * B * total            # env.step() calls in the timed region, all ranks
+  env_steps = world * B * total            # env.step() calls in the timed regions, all ranks
+  run_values = [r[0] / r[1] for r in runs]
 
   # dominant kernel = k_search_fused (one launch = all simulations of all trees of this rank + the end of the move:
   # descent, f32-MFMA dynamics + prediction, expand, backup, action/record).  Its duration is measured live with HIP
@@ -516,6 +609,23 @@ def main():
   persistent = eng.selfplay_moves_per_launch() > 0
   moves_per_launch = min(chunk, eng.selfplay_moves_per_launch()) if persistent else 1
 
+  # N > 1: the topology of `train --ranks N` (ONE replay on rank 0) as a secondary figure of the same line
+  one_replay_secondary = None
+  if dist is not None and world > 1 and not one_replay and not args.no_one_replay_secondary:
+    pipe.close()
+    lay2 = Layout(True, 'b')
+    pipe2 = Pipeline(eng, lay2.replay, chunk, device, sync_weights, state['sync_every'])
+    pipe2.state.update(gmove=state['gmove'], last_sync_q=state['gmove'] // state['sync_every'])
+    pipe2.run([whole(args.warmup)] if args.warmup > 0 else [64])
+    r2 = timed_regions(pipe2, lay2, [args.steps] * repeats, 1)[0]
+    one_replay_secondary = {
+        'what': 'the layout of `train --ranks N` (reference train.py:71-72: ONE replay buffer for all actors): every rank ships its '
+                'record chunks through a shared-memory ring to rank 0, whose one native replay ingests them all',
+        'value': r2[0] / r2[1], 'unit': 'env-steps/s', 'timed_steps': per_run, 'timed_seconds': r2[1],
+        'ingest_threads_rank0': lay2.n_ingest, 'host_cores_busy_rank0': r2[2], 'host_cores_busy_max_rank': r2[3]}
+    pipe2.close()
+    lay2.close()
+
   if rank == 0:
     value = frames / dt
     # algorithmic: SURVEY.md s8(d) per-simulation figure x sims x trees (+ the per-root figure where the root runs
@@ -528,7 +638,8 @@ def main():
     if measured_traffic is not None:
       traffic = measured_traffic['bytes_per_launch']
       traffic_source = ('measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE child passes of this command '
-                        '(%d / %d launches), 1024 * (2 * FETCH_SIZE + WRITE_SIZE) per launch' % tuple(measured_traffic['launches']))
+                        '(%d / %d launches of %d moves each), 1024 * (2 * FETCH_SIZE + WRITE_SIZE) per launch' %
+                        (tuple(measured_traffic['launches']) + (moves_per_launch,)))
     elif os.path.exists(tfile) and WNAME.startswith('Lunar') and B == 4096:
       tj = json.load(open(tfile))
       tk = tj.get('k_search_fused', {})
@@ -539,6 +650,12 @@ def main():
         traffic = tk.get('hbm_bytes_per_launch')
       traffic_source = 'profiles/traffic.json (builder-run rocprofv3 --pmc passes of this command, %s; not re-measured ' \
                        'in this run)' % tj.get('tag', 'see file')
+    if game:
+      env_desc = ('TicTacToe on the device (custom_environments/tic_tac_toe.py rules; two players, known bounds (-1, 1), discount 1); ' +
+                  ('whole moves inside one launch of the two-player <15,1,16> instantiation, %d moves per launch' % moves_per_launch
+                   if persistent else 'one launch per step of a move, 16 moves per hipGraph'))
+    else:
+      env_desc = 'synthetic fixed-length episodes on the device'
     out = {
         'metric': 'env-steps/sec (self-play, whole node) at num_simulations=%d' % SIMS,
         'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -546,29 +663,34 @@ def main():
         'dtype': 'f32' if not args.split_f16 else 'f16x2-split products, f32 accumulate (f32-level accuracy; secondary line)',
         'data': 'synthetic',
         'repeats': repeats, 'timed_steps': total, 'timed_seconds': dt,
+        'runs': {'n': n_runs, 'values': run_values, 'mean': float(np.mean(run_values)), 'std': float(np.std(run_values)),
+                 'min': float(np.min(run_values)), 'max': float(np.max(run_values)), 'steps_per_run': per_run,
+                 'what': 'SURVEY.md s8(d): mean +- std of %d timed regions of %d steps each (every region bracketed by barrier + '
+                         'synchronize, MAX over ranks); `value` = all frames / all seconds of the %d regions' % (n_runs, per_run, n_runs)},
         'ms_per_step_blocks': {'median': float(np.median(block_ms)), 'std': float(np.std(block_ms)),
                                'min': float(np.min(block_ms)), 'max': float(np.max(block_ms)), 'n': len(block_ms),
-                               'clock': 'GPU events at block boundaries inside the one pipelined timed region'},
+                               'clock': 'GPU events at block boundaries inside the pipelined timed regions'},
         'config': {'workload': '%s shapes (obs %d%s, actions %d), FCNetwork, num_simulations=%d, '
                                '%d parallel self-play envs per GPU, synthetic fixed-length episodes T=%d, '
                                'random-init weights (torch.manual_seed(0))'
                                % (WNAME, O, ' uint8 + norm_obs 0 255' if ram else '', A, SIMS, B, EPISODE_LEN),
                    'envs_per_gpu': B, 'num_simulations': SIMS, 'episode_len': EPISODE_LEN,
-                   'environment': 'TicTacToe on the device (custom_environments/tic_tac_toe.py rules; two players, known bounds '
-                                  '(-1, 1), discount 1; one launch per step of a move, 16 moves per hipGraph)' if game else
-                                  'synthetic fixed-length episodes on the device',
+                   'environment': env_desc,
                    'priming': '%d untimed moves before warm-up so episode ends are in steady state' % EPISODE_LEN,
-                   'timed_region': 'the --steps block repeated %d times back to back in one pipelined region of %.2f s '
-                                   '(barrier + synchronize on both sides)' % (repeats, dt),
+                   'timed_region': '%d regions; each = the --steps block repeated %d times back to back in one pipelined region of %.2f s '
+                                   '(barrier + synchronize on both sides)' % (n_runs, repeats, dt / n_runs),
                    'sharding': 'env-id sharded, %d rank(s), weight broadcast over %s' % (world, {'nccl': 'RCCL (torch.distributed nccl backend)', None: 'nothing (one rank, no process group)'}.get(backend, backend)),
                    'replay': ('ONE native replay on rank 0 fed by every rank through shared-memory rings (--one-replay: the layout of '
                               '`train --ranks N`, reference train.py:71-72), %d ingest threads' if one_replay else
-                              'one native replay per rank (bench layout: the metric counts frames accepted; `train --ranks N` and '
-                              '--one-replay merge all ranks into ONE replay on rank 0, DESIGN.md s6), %d ingest threads') % n_ingest,
-                   'weight_sync': 'flat f32 buffer broadcast from rank 0 + repack every %d moves: %d pulls inside the '
-                                  'timed region' % (state['sync_every'], syncs_in_region)},
+                              'one native replay per rank (bench layout: the metric counts frames accepted; `train --ranks N` merges '
+                              'all ranks into ONE replay on rank 0 -- that layout is `one_replay_secondary` when N > 1; DESIGN.md s6), '
+                              '%d ingest threads per rank') % layout.n_ingest,
+                   'weight_sync': 'flat f32 buffer broadcast from rank 0 + repack every %d moves: %d pulls inside the timed regions; '
+                                  'a pull waits for the moves queued before it (mz_set_weights reads back whether the weight set '
+                                  'admits the clamp-ReLU scale): the launch-ahead pipeline drains once per pull' % (state['sync_every'], syncs_in_region)},
         'env_steps_executed_per_s': env_steps / dt,
-        'host_cores_busy_per_rank': host_cores_busy,
+        'host_cores_busy_per_rank': host_cores_busy, 'host_cores_busy_max_rank': host_cores_busy_max,
+        'usable_host_cores': _usable_cores(), 'ingest_threads_per_rank': layout.n_ingest,
         'collectives': {'backend': backend, 'world': world, 'forced_at_world_1': bool(force_dist and world == 1),
                         'rccl_mapped': rccl_mapped(), 'weights_on_device': bool(flat.is_cuda),
                         'what': 'broadcast of the flat f32 weights (%d floats) per pull, MAX / SUM all-reduces of the timing, '
@@ -576,7 +698,8 @@ def main():
         'mcts_sims_per_s_per_gpu': env_steps * SIMS / dt / world,
         'roofline': {'bound': 'mfma', 'kernel': 'k_search_fused', 'achieved': achieved,
                      'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS,
-                     'traffic': traffic, 'traffic_source': traffic_source, 'us_per_launch': launch_us,
+                     'traffic': traffic, 'traffic_source': traffic_source,
+                     'traffic_per_move': None if traffic is None else traffic / moves_per_launch, 'us_per_launch': launch_us,
                      'flop_per_launch': flops_per_launch, 'moves_per_launch': moves_per_launch,
                      'us_per_move': search_us,
                      'launch': ('one launch = %d whole moves of all trees: root (observation, initial inference, Dirichlet '
@@ -585,6 +708,8 @@ def main():
                      'whole_path_frac': (env_steps / dt / world) * (SIMS * FLOP_PER_SIM + FLOP_PER_ROOT) / 1e12 /
                                         PEAK_F32_MFMA_TFLOPS},
     }
+    if one_replay_secondary is not None:
+      out['one_replay_secondary'] = one_replay_secondary
     if args.split_f16:
       out['secondary_line'] = True
       # the split kernel executes 300 v_mfma_f32_16x16x32_f16 per wave and simulation (3 products per block, K padded to
@@ -603,7 +728,7 @@ def main():
                                'an XCD\'s L2 delivers: that, not the matrix pipe (0.22 busy), bounds the stages (DESIGN.md s3.4)'},
           'note': 'achieved / peak = EXECUTED float16 MFMA FLOP against the dense f16 peak; the algorithmic float32 FLOP of the '
                   'same work are a third of that minus the K padding'}
-    elif world == 1 and O + 1 <= 64 and A <= 13 and not game and not os.environ.get('MZ_BENCH_CHILD'):
+    elif world == 1 and O + 1 <= 64 and A <= 13 and not game and not child:
       # the opt-in split-f16 search kernel on the same workload, as a SECONDARY figure inside the same line (never `value`)
       try:
         out['split_f16_secondary'] = measure_split_f16(device, flat, chunk)
@@ -615,11 +740,7 @@ def main():
     print(json.dumps(out), flush=True)
   if dist is not None:
     dist.barrier()
-    if one_replay:
-      if ring_stop is not None:
-        ring_stop.set()
-      for r_ in list(rings.values()) + ([my_ring] if rank > 0 else []):
-        r_.release()
+    layout.close()
     dist.destroy_process_group()
 
 

@@ -1,0 +1,61 @@
+"""Learner updates per second on an idle GPU: one captured hipGraph per update (default) against eager PyTorch launches
+(--no_graph_learner), FCNetwork, batch 256, K = 5 (reference learners.py:164-230).  The loop is
+Learner.learn's: sample_batch from the native replay, update_weights with the priority refresh one update behind.
+usage: learner_graph_speed.py [out.json]"""
+import json, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from model_based_rl_amd.config import make_config
+from model_based_rl_amd.engine import Engine, flatten_weights
+from model_based_rl_amd.learners import Learner
+from model_based_rl_amd.networks import get_network
+from model_based_rl_amd.replay_buffer import PrioritizedReplay
+from model_based_rl_amd.shared_storage import SharedStorage
+
+def setup(extra):
+  cfg = make_config(['--environment', 'LunarLander-v2', '--num_simulations', '30', '--seed', '0', '--num_envs', '1024',
+                     '--window_size', '200000', '--batch_size', '256', '--use_gpu_for', 'actors', 'learner',
+                     '--runs_dir', '/tmp/mz_ls', '--run_tag', 'x'] + extra)
+  storage, replay = SharedStorage(cfg), PrioritizedReplay(cfg)
+  torch.manual_seed(0)
+  eng = Engine.from_config(cfg, 1024)
+  eng.set_weights(flatten_weights(get_network(cfg, torch.device('cpu')).state_dict()))
+  eng.selfplay_reset(32, 1.0, stagger=True)
+  for _ in range(8):
+    eng.selfplay_steps(16); buf, n = eng.selfplay_drain(); torch.cuda.synchronize(); replay.ingest_records(buf[:n], n, 1024)
+  eng.close()
+  return cfg, storage, replay, Learner(cfg, storage, replay)
+
+def loop(learner, replay, n):
+  ts = [0.0, 0.0]
+  t0 = time.perf_counter()
+  for _ in range(n):
+    a = time.perf_counter(); batch = replay.sample_batch(); b = time.perf_counter()
+    learner.update_weights(batch, defer_priorities=True); c = time.perf_counter()
+    ts[0] += b - a; ts[1] += c - b
+  learner.flush_priorities()
+  torch.cuda.synchronize()
+  dt = time.perf_counter() - t0
+  return {'updates_per_second': n / dt, 'sample_batch_ms': 1e3 * ts[0] / n, 'update_call_ms': 1e3 * ts[1] / n}
+
+out = {}
+for name, extra in (('graph', []), ('eager', ['--no_graph_learner'])):
+  cfg, storage, replay, learner = setup(extra)
+  loop(learner, replay, 30)
+  res = [loop(learner, replay, 300) for _ in range(3)]
+  out[name] = max(res, key=lambda r: r['updates_per_second'])
+  out[name]['runs_updates_per_second'] = [r['updates_per_second'] for r in res]
+  if name == 'graph':
+    # GPU time of one replay of the graph, on the event clock
+    g = learner._graph
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(50): g.graph.replay()
+    e1.record(); torch.cuda.synchronize()
+    out[name]['graph_replay_gpu_ms'] = e0.elapsed_time(e1) / 50
+    out[name]['replay_size'] = replay.size()
+out['what'] = 'FCNetwork (LunarLander shapes: obs 8, 4 actions), batch 256, K = 5 unroll, AdamW; idle MI355X; native replay of %d frames' % out['graph']['replay_size']
+out['speedup'] = out['graph']['updates_per_second'] / out['eager']['updates_per_second']
+print(json.dumps(out, indent=1))
+if len(sys.argv) > 1:
+  json.dump(out, open(sys.argv[1], 'w'), indent=1)

@@ -1,45 +1,35 @@
-"""The launch bench.py times, at the size bench.py times it, against the CPU oracle.
+"""The launch bench.py times, at the size bench.py times it, END TO END against the CPU oracle (network included).
 
 BENCH_rNN's `value` is produced by the persistent HEAD instantiation of the search kernel (whole moves inside one launch,
-mz_selfplay_steps) on a full grid: 4096 environments = 256 workgroups, 8 moves per launch.  This test runs exactly that --
-three launches of 16 moves (bench.py's launch size), a weight update before the third -- with the per-move Dirichlet log on
-(mz_selfplay_noise_log), takes the observation of a move from its experience record and the Dirichlet draw from the log,
+mz_selfplay_steps) on a full grid: 4096 environments = 256 workgroups, 16 moves per launch.  This test runs exactly that --
+three launches of 16 moves (bench.py's launch size), a weight update before the third -- with the per-move Dirichlet log
+(mz_selfplay_noise_log) and the simulation log (mz_sim_io) on, takes the observation of a move from its experience record,
 and replays single moves (the first, one in the middle of the second launch, one in the middle of the third, the last)
-through oracle/mz_oracle.c on all 4096 trees.
+through oracle/mz_oracle.c -- the oracle's OWN float32 network evaluation and its tree -- on all 4096 trees.
 
-Rule: the oracle reports, per tree, the smallest gap between the best and the second-best score over
-all select_child decisions of the search (mcts.py:104-113; pinned bit for bit against the reference's own number in
-tests/test_oracle_tree.py).  In EVERY tree whose margin is above MARGIN the device's visit vector, sampled action and --
-where the tree is exported -- every integer field must be the oracle's: 100 %, no percentage threshold.  Trees below the
-margin are counted and printed; a decision that close to a tie may legitimately resolve the other way, because the two
-float32 network evaluations differ in summation order (network outputs agree to 1e-5, tests/test_gpu_net.py).
+What is proven where:
+  * the TREE code of this launch is proven exactly, on every tree, by tests/test_gpu_fused_exact.py (the device's logged
+    network outputs replayed through the oracle's tree: no margin, no excluded trees);
+  * here the two float32 NETWORK evaluations are different summation orders, so a select_child decision (mcts.py:104-113)
+    whose two best scores are closer than that noise may legitimately resolve the other way.  The oracle reports, per tree,
+    the smallest top-2 score gap of the search (pinned against the reference's own number in tests/test_oracle_tree.py).
+    Trees whose margin exceeds MARGIN are EXPECTED to have the oracle's visit vector and action; an exception is accepted
+    only if it is explained: that tree, replayed through the oracle's tree on the device's own logged outputs, gives exactly
+    the device's result (so the tree code is not the cause), and its logged root outputs lie within the network tolerance of
+    the oracle's (value: one step of the reference's float32 inverse-transform staircase, config.py:27-33; logits 1e-5) --
+    at most MAX_EXPLAINED per move (r03's soak met one such tree in 1.69 M).  Trees below the margin are counted and printed.
 """
 import os
 
 import numpy as np
 import pytest
 
+from tests.parity_util import philox_action_uniform, replay_move
+
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(__file__), 'golden')
 MARGIN = 1e-4
-
-
-def philox_action_uniform(seed, env, move):
-  """The uniform the device's select_action consumes for (env, move): Philox4x32-10 keyed by the engine seed, counter
-  (env, move lo, move hi, MZ_RNG_ACTION << 24), 53 bits of (x, y) (csrc/mz_rng.h, csrc/mz_tree.hip.h:mz_finalize_tree) --
-  integer arithmetic, restated here so that the oracle's Config.select_action gets the draw the device used."""
-  env = np.asarray(env, np.uint64)
-  c = [env & np.uint64(0xFFFFFFFF), np.full_like(env, move & 0xFFFFFFFF), np.full_like(env, move >> 32),
-       np.full_like(env, 4 << 24)]
-  k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
-  M = np.uint64(0xFFFFFFFF)
-  for _ in range(10):
-    p0 = np.uint64(0xD2511F53) * c[0]
-    p1 = np.uint64(0xCD9E8D57) * c[2]
-    c = [(p1 >> np.uint64(32)) ^ c[1] ^ np.uint64(k0), p1 & M, (p0 >> np.uint64(32)) ^ c[3] ^ np.uint64(k1), p0 & M]
-    k0, k1 = (k0 + 0x9E3779B9) & 0xFFFFFFFF, (k1 + 0xBB67AE85) & 0xFFFFFFFF
-  v = ((c[0] << np.uint64(32)) | c[1]) >> np.uint64(11)
-  return v.astype(np.float64) * (1.0 / 9007199254740992.0)
+MAX_EXPLAINED = 2
 
 
 SHAPES = {
@@ -75,6 +65,7 @@ def test_persistent_launch_on_a_full_grid_vs_oracle(shape, split):
     eng.selfplay_set_obs(uint8_obs=True, obs_min=[0.0], obs_range=[255.0])
   eng.selfplay_noise_log(True)
   eng.selfplay_reset(T, 1.0, stagger=True)
+  log = eng.sim_io('log', keep_moves=3 * chunk)
   eng.selfplay_steps(chunk)
   eng.selfplay_steps(chunk)
   eng.set_weights(w1)
@@ -112,17 +103,28 @@ def test_persistent_launch_on_a_full_grid_vs_oracle(shape, split):
     report.append(line)
     assert wide.mean() > 0.5                              # (the guard must not empty the test)
     bad = np.flatnonzero(wide & ~same)
-    assert bad.size == 0, (m, bad[:8], ref['margin'][bad[:8]], cv[bad[:8]], ref['child_visits'][bad[:8]])
-    assert np.all(same_act[wide & same]), (m, np.flatnonzero(wide & ~same_act)[:8])
-    assert drv[wide].max() <= 5e-4 and derr[wide].max() <= 5e-4
+    if bad.size:      # expected: none.  An exception must be explained by the network outputs, not by the tree code
+      assert bad.size <= MAX_EXPLAINED, (m, bad[:8], ref['margin'][bad[:8]], cv[bad[:8]], ref['child_visits'][bad[:8]])
+      io = log[m].cpu().numpy()[bad]
+      rep = replay_move(cfg, bad.size, A, sims, io, noise[bad], 0.25, np.ones(bad.size, np.int8), None, 1.0, u[bad])
+      assert np.array_equal(rep['child_visits'].astype(np.float32), cv[bad]) and np.array_equal(rep['action'], rv['action'][m][bad])
+      dv = np.abs(io[:, 0, 0] - ref['v0'][bad])
+      assert np.all(dv <= 1.5e-4 * (1 + np.abs(ref['v0'][bad]))), (m, bad, dv)
+      line += '; %d tree(s) above the margin differ, explained by their network outputs: %s' % (bad.size, bad.tolist())
+      report[-1] = line
+      print(line)
+    ok = wide & same
+    assert np.all(same_act[ok]), (m, np.flatnonzero(ok & ~same_act)[:8])
+    assert drv[ok].max() <= 5e-4 and derr[ok].max() <= 5e-4
     assert np.all(np.take_along_axis(cv, rv['action'][m][:, None], -1) > 0)
     if ref.get('tree') is not None:                       # the last move: every integer field of the exported trees
       for k in ('N', 'E'):
         eq = np.all(tree[k] == ref['tree'][k], axis=1)
-        assert np.all(eq[wide]), (k, np.flatnonzero(wide & ~eq)[:8])
+        assert np.all(eq[wide & same]), (k, np.flatnonzero(wide & same & ~eq)[:8])
       whole = np.all(tree['N'] == ref['tree']['N'], axis=1) & np.all(tree['E'] == ref['tree']['E'], axis=1)
       assert np.abs(tree['W'][whole] - ref['tree']['W'][whole]).max() <= 5e-3
       assert np.array_equal(tree['noise'], noise)
+  eng.sim_io('off')
   eng.close()
   out = os.environ.get('MZ_PARITY_REPORT')
   if out:

@@ -23,55 +23,11 @@ import os
 import numpy as np
 import pytest
 
-from tests.test_gpu_bench_parity import philox_action_uniform
+from tests.parity_util import env_switches, philox_action_uniform, random_weights, replay_move, ulp_diff
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(__file__), 'golden')
 TREE_FILES = sorted(glob.glob(os.path.join(G, 'g2_tree_*.npz')) + glob.glob(os.path.join(G, 'g3_game_*.npz')))
-
-
-def ulp_diff(a, b):
-  a = np.ascontiguousarray(a, np.float64).view(np.int64)
-  b = np.ascontiguousarray(b, np.float64).view(np.int64)
-  return np.abs(a - b)
-
-
-def random_weights(O, A, seed=0, scale=1.0):
-  """FCNetwork-shaped weights (reference key names) with PyTorch-like magnitudes: the injected runs never look at what
-  the network computes, they only need a weight set the fused kernel accepts (mz_set_weights' clamp-ReLU scale)."""
-  from oracle import oracle as orc
-  rng = np.random.RandomState(seed)
-  shapes = {'representation_head.fc1': (512, O), 'representation_head.out': (50, 512), 'value_head.fc1': (512, 50),
-            'value_head.value': (31, 512), 'policy_head.fc1': (512, 50), 'policy_head.policy': (A, 512),
-            'reward_head.fc1': (512, 50 + A), 'reward_head.reward': (31, 512), 'transition_head.fc1': (512, 50 + A),
-            'transition_head.out': (50, 512)}
-  w = {}
-  for k, (n, m) in shapes.items():
-    w[k + '.weight'] = (rng.uniform(-1, 1, (n, m)) * scale / np.sqrt(m)).astype(np.float32)
-    w[k + '.bias'] = (rng.uniform(-1, 1, n) * scale / np.sqrt(m)).astype(np.float32)
-  w['LN.weight'] = np.ones(50, np.float32)
-  w['LN.bias'] = np.zeros(50, np.float32)
-  assert set(w) == set(orc.WEIGHT_ORDER)
-  return w
-
-
-class env_switches(object):
-  """MZ_* switches are read by mz_create: set them around the construction of an engine"""
-
-  def __init__(self, **kv):
-    self.kv = {k: v for k, v in kv.items() if v is not None}
-
-  def __enter__(self):
-    self.old = {k: os.environ.get(k) for k in ('MZ_NO_LDS_TREES', 'MZ_NO_LDS_HYBRID', 'MZ_SPLIT_F16', 'MZ_NO_PERSIST', 'MZ_NO_FUSED')}
-    for k in self.old:
-      os.environ.pop(k, None)
-    os.environ.update(self.kv)
-
-  def __exit__(self, *a):
-    for k, v in self.old.items():
-      os.environ.pop(k, None)
-      if v is not None:
-        os.environ[k] = v
 
 
 VARIANTS = {
@@ -231,20 +187,6 @@ LOG_SHAPES = {
     'ttt': dict(gold='g1_net_ttt', O=9, A=9, sims=30, u8=False, game=True, info=dict(kind='fused', lt=2, ks1=15, G=16)),
     'wide18': dict(gold=None, O=8, A=18, sims=20, u8=False, info=dict(kind='fused', lt=2, ks1=18, G=32)),
 }
-
-
-def replay_move(cfg, B, A, sims, io, noise, frac, to_play, legal, temperature, uniform, want_tree=False):
-  """one move of B trees through the oracle's TREE on logged network outputs io [B, sims + 1, 2 + A]"""
-  from oracle import oracle as orc
-  t = orc.Trees(cfg, B)
-  t.root_expand(to_play, io[:, 0, 2:], legal)
-  t.add_noise(noise, frac)
-  for s in range(sims):
-    t.select()
-    t.expand_backup(io[:, 1 + s, 0], io[:, 1 + s, 1], io[:, 1 + s, 2:])
-  action, cv, rv, vc = t.finalize(temperature, uniform)
-  return dict(action=action, child_visits=cv, root_value=rv, visit_counts=vc, v0=io[:, 0, 0], margin=t.margin(),
-              tree=t.export() if want_tree else None)
 
 
 @pytest.mark.parametrize('shape,mode', [('lunar', 'exact'), ('lunar', 'split_f16'), ('pong', 'exact'), ('pong', 'split_f16'),

@@ -37,7 +37,12 @@ def test_bench_two_ranks_shard_the_environments(tmp_path):
   assert line['n_gpus'] == 2 and line['steps'] == steps and line['config']['envs_per_gpu'] == B
   executed = line['env_steps_executed_per_s'] * line['timed_seconds']
   assert abs(executed - 2 * B * line['timed_steps']) < 1e-6 * executed
-  assert line['timed_steps'] == steps * line['repeats'] and line['timed_seconds'] >= 0.15
+  assert line['timed_steps'] == steps * line['repeats'] * line['runs']['n'] and line['timed_seconds'] >= 0.15
+  assert line['runs']['n'] == 5 and len(line['runs']['values']) == 5 and line['runs']['std'] >= 0      # 5 runs
+  # the layout of `train --ranks N` -- ONE replay on rank 0 -- rides in the same line
+  o = line['one_replay_secondary']
+  assert 0.6 * 2 * B * o['timed_steps'] < o['value'] * o['timed_seconds'] < 1.4 * 2 * B * o['timed_steps']
+  assert line['ingest_threads_per_rank'] >= 1 and line['usable_host_cores'] >= 1
   assert 'pulls inside the timed region' in line['config']['weight_sync'] and not line['config']['weight_sync'].startswith('0 ')
   assert 0.5 * 2 * B * line['timed_steps'] < line['value'] * line['timed_seconds'] < 1.5 * 2 * B * line['timed_steps']
   assert line['collectives']['backend'] == 'gloo' and line['collectives']['world'] == 2
@@ -62,6 +67,29 @@ def test_bench_two_ranks_shard_the_environments(tmp_path):
   assert np.array_equal(one.view(np.int32), rec1.view(np.int32))
   assert np.array_equal(records_view(rec0, 8, 4)['env_id'][0], np.arange(B))
   assert np.array_equal(records_view(rec1, 8, 4)['env_id'][0], np.arange(B, 2 * B))
+
+
+def test_bench_launches_its_own_ranks():
+  """`python3 bench.py --gpus 2` with no launcher (how the driver starts N = 1): bench.py starts
+  torch.distributed.run as a CHILD process before touching the GPU, relays rank 0's line and the exit code."""
+  B, steps = 64, 16
+  env = dict(os.environ, MZ_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+  for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+    env.pop(k, None)
+  out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', str(steps), '--warmup', '4',
+                        '--no-cpu-baseline', '--envs', str(B), '--min-seconds', '0.2', '--runs', '2'],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+  assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+  rows = [l for l in out.stdout.splitlines() if l.startswith('{')]
+  assert len(rows) == 1, out.stdout[-2000:]                   # ONE JSON line on stdout
+  line = json.loads(rows[0])
+  assert line['n_gpus'] == 2 and line['collectives']['world'] == 2 and line['runs']['n'] == 2
+  assert 0.5 * 2 * B * line['timed_steps'] < line['value'] * line['timed_seconds'] < 1.5 * 2 * B * line['timed_steps']
+  assert 'one_replay_secondary' in line and line['host_cores_busy_per_rank'] <= 2.0
+  # a failing child's exit code comes back
+  bad = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--envs', '-5',
+                        '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+  assert bad.returncode != 0 and not [l for l in bad.stdout.splitlines() if l.startswith('{')]
 
 
 def test_train_two_ranks_learner_broadcast_and_one_replay():
