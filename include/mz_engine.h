@@ -278,6 +278,22 @@ int mz_selfplay_read_noise(mz_engine *e, uint64_t move, double *out);
  *   mode 0, off:    the production state (a null pointer in the kernels' arguments; buf ignored).
  * Synchronous; drops captured graphs. */
 int mz_sim_io(mz_engine *e, int mode, float *buf, int keep_moves);
+/* The elementwise ends of the learner step (reference learners.py:164-230) as single launches -- the step is launch-bound,
+ * and PyTorch spells these as ~45 (targets) and ~11 (each categorical loss) tiny kernels.  Engine-free: device pointers,
+ * sizes, a stream; capturable into a graph (no synchronisation, no allocation).
+ * mz_learner_targets (learners.py:176-189; config.py:27-33,51-68): t_val, t_rew [bs][k1] as sample_batch returns them (k1 = K
+ *   + 1 unroll positions), value0 [bs][sv] the value logits of the initial inference ->  sup_val [k1][bs][sv], sup_rew
+ *   [k1][bs][sr]: two-hot supports of h(target) (h skipped with no_target_transform), position-major; new_errors [bs] =
+ *   inverse_transform(value0) - t_val[:, 0], the priority refresh.
+ * mz_soft_ce_forward / _backward (utils.py:53-60, summed over the unroll positions as learners.py:191-203 does): logits
+ *   [positions][bs][bins], target element (p, b, s) at target[p * target_pos_stride + b * target_row_stride + s] -> loss [bs]
+ *   = sum_p sum_s -target log_softmax(logits); backward: grad_logits = grad_loss[b] (softmax(logits) sum_s target - target). */
+int mz_learner_targets(const float *t_val, const float *t_rew, const float *value0, int bs, int k1, int sv, int vmin, int sr,
+                       int rmin, int no_target_transform, float *sup_val, float *sup_rew, float *new_errors, void *stream);
+int mz_soft_ce_forward(const float *logits, const float *target, int positions, int bs, int bins, int64_t target_pos_stride,
+                       int64_t target_row_stride, float *loss, void *stream);
+int mz_soft_ce_backward(const float *logits, const float *target, const float *grad_loss, int positions, int bs, int bins,
+                        int64_t target_pos_stride, int64_t target_row_stride, float *grad_logits, void *stream);
 /* Which kernel mz_search / mz_selfplay_steps launch for this engine right now: out4 [host] = kind (0 the stand-alone
  * kernels, 1 k_search_fused, 2 k_search_h2), LDS placement of the trees (0 node pool, 1 whole trees in LDS, 2 compact in
  * LDS; -1 for kind 0), dynamics-fc1 k-steps of the instantiation, lanes per child group.  For tests: they assert the

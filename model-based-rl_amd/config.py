@@ -106,6 +106,13 @@ def build_parser():
   a('--lr_decay_rate', type=float, default=0.1)
   a('--lr_decay_steps', type=int, default=100000)
   a('--learner_gpu_device_id', type=int, default=None)
+  a('--unbatched_learner', action='store_true',
+    help='FCNetwork learner step position by position as the reference writes it, instead of the three heads batched over '
+         'all K + 1 unroll positions (learners.py)')
+  a('--no_tune_gemms', action='store_true',
+    help='graphed learner: keep the BLAS libraries\' default kernel choice instead of PyTorch TunableOp picking the fastest per shape')
+  a('--no_hip_learner_ops', action='store_true',
+    help='learner targets and categorical losses as PyTorch elementwise kernels instead of the single HIP launches of csrc/mz_learner.hip.h')
   a('--no_graph_learner', action='store_true',
     help='run the learner step as eager PyTorch launches instead of one captured hipGraph per update (learners.py)')
   a('--learner_log_frequency', type=int, default=100)

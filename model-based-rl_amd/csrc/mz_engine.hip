@@ -25,6 +25,7 @@
 #include "mz_fused.hip.h"
 #include "mz_root.hip.h"
 #include "mz_fused_h2.hip.h"
+#include "mz_learner.hip.h"
 // the search kernels are compiled in their own translation units, one per shape (mz_inst.hip); here they are launched
 #include "mz_kernels.inc"
 MZ_ALL_FUSED(extern)
@@ -1038,6 +1039,37 @@ int mz_affine_relu(float *y, const float *scale, const float *shift, const float
   else
     hipLaunchKernelGGL(k_affine_relu<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float4 *)y, scale, shift,
                        (const float4 *)nullptr, n4, channels, hw / 4);
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
+
+// ---- the elementwise ends of the learner step (mz_learner.hip.h); engine-free: device pointers and sizes only
+int mz_learner_targets(const float *t_val, const float *t_rew, const float *value0, int bs, int k1, int sv, int vmin, int sr,
+                       int rmin, int no_target_transform, float *sup_val, float *sup_rew, float *new_errors, void *stream) {
+  if (!t_val || !t_rew || !value0 || !sup_val || !sup_rew || !new_errors) return fail("mz_learner_targets: null argument");
+  if (bs < 1 || k1 < 1 || sv < 1 || sr < 1 || sv > 4096 || sr > 4096) return fail("mz_learner_targets: bad sizes");
+  // (bs * k1 threads for the supports, then -- from the next 32-lane boundary on -- 32 lanes per sample for the priority refresh)
+  hipLaunchKernelGGL(k_learner_targets, dim3((((bs * k1 + 31) & ~31) + 32 * bs + 127) / 128), dim3(128), 0, (hipStream_t)stream, t_val, t_rew, value0, bs,
+                     k1, sv, vmin, sr, rmin, no_target_transform, sup_val, sup_rew, new_errors);
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
+
+int mz_soft_ce_forward(const float *logits, const float *target, int positions, int bs, int bins, int64_t target_pos_stride,
+                       int64_t target_row_stride, float *loss, void *stream) {
+  if (!logits || !target || !loss) return fail("mz_soft_ce_forward: null argument");
+  if (positions < 1 || positions > 8) return fail("mz_soft_ce_forward: 1..8 positions (num_unroll_steps + 1), got %d", positions);
+  hipLaunchKernelGGL(k_soft_ce_fwd, dim3((8 * bs + 127) / 128), dim3(128), 0, (hipStream_t)stream, logits, target, positions, bs, bins,
+                     target_pos_stride, target_row_stride, loss);
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
+
+int mz_soft_ce_backward(const float *logits, const float *target, const float *grad_loss, int positions, int bs, int bins,
+                        int64_t target_pos_stride, int64_t target_row_stride, float *grad_logits, void *stream) {
+  if (!logits || !target || !grad_loss || !grad_logits) return fail("mz_soft_ce_backward: null argument");
+  hipLaunchKernelGGL(k_soft_ce_bwd, dim3((8 * positions * bs + 127) / 128), dim3(128), 0, (hipStream_t)stream, logits, target, grad_loss,
+                     positions, bs, bins, target_pos_stride, target_row_stride, grad_logits);
   HIPCHECK(hipGetLastError());
   return 0;
 }

@@ -52,7 +52,9 @@ def make_optimizer(config, params, capturable=False):
     params = list(params)
     lr = torch.tensor(float(lr), dtype=torch.float32, device=params[0].device)
     cls = torch.optim.AdamW if name == 'AdamW' else torch.optim.Adam
-    return cls(params, lr=lr, weight_decay=wd, eps=0.00015, capturable=True, foreach=True)
+    # fused: ONE multi-tensor kernel for all 22 parameters (the foreach form spends ~150 launches per step on the
+    # per-parameter step counters and bias corrections)
+    return cls(params, lr=lr, weight_decay=wd, eps=0.00015, capturable=True, fused=True)
   if name == 'AdamW':
     return torch.optim.AdamW(params, lr=lr, weight_decay=wd, eps=0.00015)
   if name == 'Adam':
@@ -130,6 +132,42 @@ def make_lr_scheduler(config, optimizer):
   raise NotImplementedError(name)
 
 
+def _stream_ptr(t):
+  import ctypes as C
+  return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+class _SoftCE(torch.autograd.Function):
+  """sum over the unroll positions of (-target * log_softmax(logits)).sum(-1)  (utils.py:53-60, learners.py:191-203) as one
+  HIP launch forward and one backward (mz_soft_ce_forward / _backward) instead of ~11 elementwise PyTorch kernels.
+  logits [P, bs, S] contiguous; target: any float32 tensor whose element (p, b, s) sits at p * tp + b * tb + s."""
+
+  @staticmethod
+  def forward(ctx, logits, target, tp, tb):
+    import ctypes as C
+    from . import _abi
+    P, bs, S = logits.shape
+    loss = torch.empty(bs, dtype=torch.float32, device=logits.device)
+    _abi.check(_abi.load().mz_soft_ce_forward(C.c_void_p(logits.data_ptr()), C.c_void_p(target.data_ptr()), P, bs, S, tp, tb,
+                                              C.c_void_p(loss.data_ptr()), _stream_ptr(logits)), 'mz_soft_ce_forward')
+    ctx.save_for_backward(logits, target)
+    ctx.strides = (tp, tb)
+    return loss
+
+  @staticmethod
+  def backward(ctx, grad_loss):
+    import ctypes as C
+    from . import _abi
+    logits, target = ctx.saved_tensors
+    P, bs, S = logits.shape
+    g = grad_loss.to(torch.float32).contiguous()
+    out = torch.empty_like(logits)
+    _abi.check(_abi.load().mz_soft_ce_backward(C.c_void_p(logits.data_ptr()), C.c_void_p(target.data_ptr()), C.c_void_p(g.data_ptr()),
+                                               P, bs, S, ctx.strides[0], ctx.strides[1], C.c_void_p(out.data_ptr()),
+                                               _stream_ptr(logits)), 'mz_soft_ce_backward')
+    return out, None, None, None
+
+
 class _GraphedUpdate(object):
   """Learner._device_step as one captured graph over static tensors (torch.cuda.CUDAGraph = a hipGraph on ROCm).
   launch(host arrays): one pinned staging buffer -> ONE host-to-device copy -> graph replay -> the new errors back into
@@ -174,7 +212,8 @@ class _GraphedUpdate(object):
         learner._device_step(*[self.static[k] for k in self.ORDER])
     torch.cuda.current_stream(dev).wait_stream(side)
     self.graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(self.graph):
+    # (thread_local: an actor's thread of the same process keeps launching and copying while this thread captures)
+    with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
       self.new_errors = learner._device_step(*[self.static[k] for k in self.ORDER])
     with torch.no_grad():
       for p, sp, ss in zip(params, saved_p, saved_s):
@@ -229,6 +268,17 @@ class Learner(Logger):
     # one captured hipGraph per update on a GPU (module docstring); the optimisers with a capturable step only
     self.use_graph = (self.device.type == 'cuda' and not getattr(config, 'no_graph_learner', False) and
                       getattr(config, 'optimizer', 'AdamW') in ('AdamW', 'Adam'))
+    if self.use_graph and not getattr(config, 'no_tune_gemms', False):
+      # PyTorch's TunableOp: every GEMM shape of the step (2 x 512-wide layers on 256..1536 rows) is timed once against the
+      # rocBLAS / hipBLASLt solutions during the graph's warm-up and the fastest one is what gets captured -- the default
+      # heuristic picks 64 x 256 tiles for the skinny weight-gradient GEMMs ([512 x 54] over K = 256: 35 us each, a
+      # quarter of the update; profiles/r04_learner_kernel_stats_untuned.csv).  Summation order may differ between
+      # solutions: float32-rounding-level, inside every parity bound of tests/test_learner.py.
+      import torch.cuda.tunable as tunable
+      tunable.enable(True)
+      tunable.tuning_enable(True)
+      tunable.set_max_tuning_duration(20)
+      tunable.write_file_on_exit(False)
     self.optimizer = make_optimizer(config, self.network.parameters(), capturable=self.use_graph)
     self.lr_scheduler = make_lr_scheduler(config, self.optimizer)
     if getattr(config, 'scalar_loss', 'MSE') not in ('MSE', 'Huber'):
@@ -236,6 +286,9 @@ class Learner(Logger):
     self.training_step = 0
     self._losses = {'reward': 0., 'value': 0., 'policy': 0.}
     self._loss_dev = torch.zeros(3, dtype=torch.float64, device=self.device)      # summed on the device, read when logged
+    # the elementwise ends of the FCNetwork step as single HIP launches (csrc/mz_learner.hip.h); PyTorch's own elementwise
+    # kernels on a CPU learner and with --no_hip_learner_ops
+    self.hip_ops = self.device.type == 'cuda' and not getattr(config, 'no_hip_learner_ops', False)
     self._graph = None          # _GraphedUpdate, built from the first batch
     self._pending = None        # (idxs, slot) of the update whose priority refresh has not reached the replay yet
     self.throughput = {'total_frames': 0, 'total_games': 0, 'training_step': 0, 'time': {'ups': 0, 'fps': 0}}
@@ -295,19 +348,84 @@ class Learner(Logger):
             't_rew': np.ascontiguousarray(target_rewards), 't_val': np.ascontiguousarray(target_values),
             't_pol': np.ascontiguousarray(target_policies), 'w': np.ascontiguousarray(is_weights)}, idxs
 
+  def _targets(self, value0, t_rew, t_val):
+    """learners.py:176-189: the priority refresh (initial value against the first value target) and the categorical targets"""
+    cfg = self.config
+    no_support = getattr(cfg, 'no_support', False)
+    init_value = value0 if no_support else support_to_scalar(value0, cfg.value_support_min, cfg.no_target_transform)
+    new_errors = init_value.squeeze() - t_val[:, 0]
+    if not cfg.no_target_transform:
+      t_val, t_rew = scalar_transform(t_val), scalar_transform(t_rew)
+    if not no_support:
+      t_val = scalar_to_support(t_val, cfg.value_support_min, cfg.value_support_max)
+      t_rew = scalar_to_support(t_rew, cfg.reward_support_min, cfg.reward_support_max)
+    return new_errors, t_rew, t_val
+
+  # learners.py:164-230 for FCNetwork with the three heads evaluated ONCE over all K + 1 unroll positions: only the
+  # transition chain h_0 -> h_1 -> ... -> h_K is sequential (networks.py:158-165); value and policy of every position
+  # (networks.py:151-156) and the rewards of the K transitions (networks.py:160-162) are batched GEMMs over (K + 1) bs
+  # resp. K bs rows, the losses one expression over [K + 1, bs].  Same arithmetic per row, a third of the launches of the
+  # position-by-position form below -- and this step is launch-bound (a captured update is ~3 ms of ~4 us launches).
+  def _device_step_fc(self, obs, act, t_rew, t_val, t_pol, w):
+    cfg, net = self.config, self.network
+    K, bs, A = act.shape[1], obs.shape[0], net.action_space
+    onehot = torch.nn.functional.one_hot(act, A).to(torch.float32)              # [bs, K, A]  (networks.py:167-174)
+    h = net.representation(obs)
+    hs, xs = [h], []
+    for i in range(K):
+      x = torch.cat((h, onehot[:, i]), dim=1)
+      xs.append(x)
+      h = torch.relu(net.LN(net.transition_head(x)))
+      h.register_hook(lambda grad: grad * 0.5)                                  # learners.py:200
+      hs.append(h)
+    H = torch.cat(hs, dim=0)                                                    # [(K + 1) bs, 50], position-major
+    value = net.value_head(H).view(K + 1, bs, -1)
+    policy = net.policy_head(H).view(K + 1, bs, A)
+    reward = net.reward_head(torch.cat(xs, dim=0)).view(K, bs, -1)
+    no_support = getattr(cfg, 'no_support', False)
+    if self.hip_ops and not no_support and K + 1 <= 8:
+      # the elementwise ends as single HIP launches (csrc/mz_learner.hip.h): targets + priority refresh, and one fused
+      # soft cross-entropy per head over all its positions
+      import ctypes as C
+      from . import _abi
+      Sv, Sr = value.shape[2], reward.shape[2]
+      sup_val = torch.empty(K + 1, bs, Sv, dtype=torch.float32, device=obs.device)
+      sup_rew = torch.empty(K + 1, bs, Sr, dtype=torch.float32, device=obs.device)
+      new_errors = torch.empty(bs, dtype=torch.float32, device=obs.device)
+      v0 = value[0].detach()
+      ptr = lambda t: C.c_void_p(t.data_ptr())
+      _abi.check(_abi.load().mz_learner_targets(ptr(t_val), ptr(t_rew), ptr(v0), bs, K + 1, Sv, int(cfg.value_support_min), Sr,
+                                                int(cfg.reward_support_min), int(bool(cfg.no_target_transform)), ptr(sup_val),
+                                                ptr(sup_rew), ptr(new_errors), _stream_ptr(obs)), 'mz_learner_targets')
+      value_loss = _SoftCE.apply(value, sup_val, bs * Sv, Sv)
+      reward_loss = _SoftCE.apply(reward, sup_rew[1:], bs * Sr, Sr)
+      policy_loss = _SoftCE.apply(policy, t_pol, A, (K + 1) * A)
+      return new_errors, reward_loss, value_loss, policy_loss
+    with torch.no_grad():
+      new_errors, t_rew, t_val = self._targets(value[0], t_rew, t_val)
+    t_pol, t_val, t_rew = t_pol.transpose(0, 1), t_val.transpose(0, 1), t_rew.transpose(0, 1)      # [K + 1, bs, ...]
+    policy_loss = (-t_pol * torch.log_softmax(policy, dim=2)).sum(2).sum(0)
+    if not no_support:
+      value_loss = (-t_val * torch.log_softmax(value, dim=2)).sum(2).sum(0)
+      reward_loss = (-t_rew[1:] * torch.log_softmax(reward, dim=2)).sum(2).sum(0)
+    else:
+      fn = torch.nn.SmoothL1Loss(reduction='none') if getattr(cfg, 'scalar_loss', 'MSE') == 'Huber' else torch.nn.MSELoss(reduction='none')
+      value_loss = fn(value.squeeze(2), t_val).sum(0)
+      reward_loss = fn(reward.squeeze(2), t_rew[1:]).sum(0)
+    return new_errors, reward_loss, value_loss, policy_loss
+
   # learners.py:164-230 on device tensors: no host round trip inside, so it can be captured
   def _device_step(self, obs, act, t_rew, t_val, t_pol, w):
     cfg = self.config
+    from .networks import FCNetwork
+    if isinstance(self.network, FCNetwork) and not getattr(cfg, 'unbatched_learner', False):
+      new_errors, reward_loss, value_loss, policy_loss = self._device_step_fc(obs, act, t_rew, t_val, t_pol, w)
+      return self._finish_step(new_errors, reward_loss, value_loss, policy_loss, w)
+    # any network (MuZeroNetwork / TinyNetwork; --unbatched_learner): position by position, as the reference writes it
     value, _, policy_logits, hidden = self.network.initial_inference(obs)
+    no_support = getattr(cfg, 'no_support', False)
     with torch.no_grad():
-      no_support = getattr(cfg, 'no_support', False)
-      init_value = value if no_support else support_to_scalar(value, cfg.value_support_min, cfg.no_target_transform)
-      new_errors = init_value.squeeze() - t_val[:, 0]
-      if not cfg.no_target_transform:
-        t_val, t_rew = scalar_transform(t_val), scalar_transform(t_rew)
-      if not no_support:
-        t_val = scalar_to_support(t_val, cfg.value_support_min, cfg.value_support_max)
-        t_rew = scalar_to_support(t_rew, cfg.reward_support_min, cfg.reward_support_max)
+      new_errors, t_rew, t_val = self._targets(value, t_rew, t_val)
     if not no_support:
       scalar_loss = soft_cross_entropy
     elif getattr(cfg, 'scalar_loss', 'MSE') == 'Huber':        # utils.py:62-70
@@ -325,6 +443,11 @@ class Learner(Logger):
       reward_loss = reward_loss + scalar_loss(reward.squeeze(), t_rew[:, i])
       value_loss = value_loss + scalar_loss(value.squeeze(), t_val[:, i])
       policy_loss = policy_loss + soft_cross_entropy(policy_logits.squeeze(), t_pol[:, i])
+    return self._finish_step(new_errors, reward_loss, value_loss, policy_loss, w)
+
+  def _finish_step(self, new_errors, reward_loss, value_loss, policy_loss, w):
+    """learners.py:208-230: importance weights, 1 / K gradient scale, backward, clipping, optimiser step, loss sums"""
+    cfg = self.config
     reward_loss, value_loss, policy_loss = (w * reward_loss).mean(), (w * value_loss).mean(), (w * policy_loss).mean()
     total = reward_loss + value_loss + policy_loss
     total.register_hook(lambda grad: grad * (1 / cfg.num_unroll_steps))

@@ -135,6 +135,9 @@ def launch_ranks(config, max_moves, selfplay_only=False, learner_steps=None):
                'replay_size': ray.get(replay.size.remote()), 'backend': backend, 'rccl_mapped': D.rccl_mapped(),
                'weights_on_device': bool(rstorage.flat.is_cuda), 'ingest_threads': ray.get(replay.get_ingest_threads.remote()),
                'drained': not server.is_alive(), 'dedicated_learner_rank': bool(dedicated)}
+    if not selfplay_only:          # the reference's own throughput scalars (learners.py:88-113)
+      lt = ray.get(learner.get_last_throughput.remote())
+      summary.update({k: lt[k] for k in ('updates_per_second', 'replay_ratio', 'sample_ratio', 'frames_per_second') if k in lt})
     print('MZ_TRAIN_SUMMARY ' + json.dumps(summary), flush=True)
   dist.barrier()
   stop.set()
