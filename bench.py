@@ -275,7 +275,7 @@ def replay_config():
   return types.SimpleNamespace(batch_size=256, epsilon=0.01, alpha=1.0, beta=1.0, obs_space=(O,), action_space=A,
                                window_size=1 << 21, window_step=None, num_unroll_steps=5, td_steps=10,
                                max_history_length=500, discount=1.0 if WNAME == 'TicTacToe' else 0.997, seed=0,
-                               two_players=WNAME == 'TicTacToe')
+                               two_players=WNAME == 'TicTacToe', obs_u8='-ram' in WNAME)      # (-ram- observations: bytes in records and replay)
 
 
 def measure_split_f16(device, flat, chunk, moves=384):
@@ -287,7 +287,7 @@ def measure_split_f16(device, flat, chunk, moves=384):
   eng = Engine(B, O, A, SIMS, seed=1234, device=device, split_f16=True)
   eng.set_weights(flat if flat.is_cuda else flat.to(device))
   if '-ram' in WNAME:
-    eng.selfplay_set_obs(uint8_obs=True, obs_min=[0.0], obs_range=[255.0])
+    eng.selfplay_set_obs(uint8_obs=True, obs_min=[0.0], obs_range=[255.0], packed=True)
   eng.selfplay_reset(EPISODE_LEN, 1.0, stagger=True)
   replay = PrioritizedReplay(replay_config())
   pipe = Pipeline(eng, replay, chunk, device)
@@ -452,8 +452,8 @@ def main():
 
   sync_weights()
   ram = '-ram' in WNAME
-  if ram:        # the -ram- envs: byte observations, --norm_obs --obs_range 0 255 inside the root kernel (actors.py:134-137)
-    eng.selfplay_set_obs(uint8_obs=True, obs_min=[0.0], obs_range=[255.0])
+  if ram:        # the -ram- envs: byte observations (bytes in the records too), --norm_obs --obs_range 0 255 inside the root kernel (actors.py:134-137)
+    eng.selfplay_set_obs(uint8_obs=True, obs_min=[0.0], obs_range=[255.0], packed=True)
   eng.selfplay_reset(EPISODE_LEN, 1.0, stagger=True)
 
   def make_replay(threads):
@@ -675,7 +675,7 @@ def main():
                                'random-init weights (torch.manual_seed(0))'
                                % (WNAME, O, ' uint8 + norm_obs 0 255' if ram else '', A, SIMS, B, EPISODE_LEN),
                    'envs_per_gpu': B, 'num_simulations': SIMS, 'episode_len': EPISODE_LEN,
-                   'environment': env_desc,
+                   'environment': env_desc, 'record_bytes_per_env_step': 4 * eng.rec_floats,
                    'priming': '%d untimed moves before warm-up so episode ends are in steady state' % EPISODE_LEN,
                    'timed_region': '%d regions; each = the --steps block repeated %d times back to back in one pipelined region of %.2f s '
                                    '(barrier + synchronize on both sides)' % (n_runs, repeats, dt / n_runs),

@@ -249,8 +249,11 @@ int mz_selfplay_set_temperature(mz_engine *e, double temperature, void *stream);
  * from the caller -- numpy's stream in the reference's order -- instead of the device RNG; NULL, NULL switches back. */
 int mz_selfplay_set_env(mz_engine *e, int kind);
 int mz_selfplay_set_draws(mz_engine *e, const double *noise, const double *uniform, void *stream);
-/* Observation format of the synthetic env (call before mz_selfplay_reset; synchronous).  uint8_obs != 0: observations
- * are bytes 0..255 (the -ram- envs).  obs_min / obs_range [host][obs_dim], both or neither: --norm_obs
+/* Observation format of the synthetic env (call before mz_selfplay_reset, with the ring drained; synchronous).  uint8_obs
+ * 1: observations are bytes 0..255 (the -ram- envs), one per float slot of the record; 2: the same observations, and the
+ * record carries them as BYTES, four per float slot -- rec_floats = ceil(obs_dim / 4) + action_space + MZ_REC_EXTRA
+ * (mz_selfplay_rec_floats), the layout mz_replay.h's obs_u8 replay ingests (game.py:93-96 keeps the raw uint8 observation):
+ * 208 instead of 592 bytes per env-step on the Pong-ram shapes.  obs_min / obs_range [host][obs_dim], both or neither: --norm_obs
  * (actors.py:55-58,134-137): the network input is (obs - obs_min) / obs_range in float32, the record keeps the raw
  * observation (the learner normalises its own batches, learners.py:167-168). */
 int mz_selfplay_set_obs(mz_engine *e, int uint8_obs, const float *obs_min, const float *obs_range);

@@ -245,8 +245,9 @@ class Actor(Logger):
     if getattr(cfg, 'norm_obs', False) or '-ram' in str(cfg.environment):
       # the -ram- environments emit bytes; --norm_obs is applied inside the root kernel (actors.py:134-137)
       norm = getattr(cfg, 'norm_obs', False)
-      eng.selfplay_set_obs(uint8_obs='-ram' in str(cfg.environment), obs_min=self.obs_min if norm else None,
-                           obs_range=self.obs_range if norm else None)
+      ram = '-ram' in str(cfg.environment)
+      eng.selfplay_set_obs(uint8_obs=ram, obs_min=self.obs_min if norm else None, obs_range=self.obs_range if norm else None,
+                           packed=ram and bool(getattr(cfg, 'obs_u8', False)))      # (bytes in the records: a replay with obs_u8)
     temperature = self._temperature()
     if cfg.environment == 'TicTacToe':
       eng.selfplay_set_env('tictactoe')
@@ -262,7 +263,7 @@ class Actor(Logger):
       ev.synchronize()
       # games this actor finished (actors.py:94-99 counts one per play_game return; reported to the storage with the
       # next weight pull, actors.py:82, shared_storage.py:12-14) and their logged statistics
-      self._log_games(records_view(buf[:n].numpy(), eng.O, eng.A))
+      self._log_games(records_view(buf[:n].numpy(), eng.O, eng.A, obs_u8=eng.obs_packed))
       _call(self.replay_buffer, 'ingest_records', buf, n, eng.B, self.env_base)
 
     from . import gpu_turns

@@ -154,6 +154,12 @@ def env_shapes(config):
   return A, tuple(obs)
 
 
+def obs_are_bytes(cfg):
+  """image frames and the 128 bytes of console RAM of the -ram- environments travel as bytes in the experience records and
+  the replay (game.py:93-96 keeps the raw uint8 observation)"""
+  return len(tuple(getattr(cfg, 'obs_space', ()))) == 3 or '-ram' in str(getattr(cfg, 'environment', ''))
+
+
 def make_config(argv=None, **overrides):
   args = vars(build_parser().parse_args(argv))
   args.update(overrides)
@@ -161,5 +167,5 @@ def make_config(argv=None, **overrides):
   if cfg.environment in ENV_SHAPES and not hasattr(cfg, 'action_space'):
     cfg.action_space, cfg.obs_space = env_shapes(cfg)   # train.py:66-68 probes the env for these
   if not hasattr(cfg, 'obs_u8'):
-    cfg.obs_u8 = len(tuple(getattr(cfg, 'obs_space', ()))) == 3      # image frames travel as bytes
+    cfg.obs_u8 = obs_are_bytes(cfg)
   return cfg

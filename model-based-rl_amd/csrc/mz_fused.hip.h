@@ -531,9 +531,10 @@ __device__ __forceinline__ void mz_finalize_record(const TreeView &t, const Tree
   if (ok) { d[pos] = (double)c; acts[pos] = lane; }
   const unsigned long long move = envs ? *(const unsigned long long *)envs : sp.movecnt[b];
   float *rec = sp.ring + ((size_t)(move % (unsigned long long)sp.ring_moves) * t.B + b) * sp.rec_floats;
-  if (envs && O <= MZ_ENVW - 8) { if (lane < O) rec[lane] = ((const float *)envs)[8 + lane]; }
-  else for (int k = lane; k < O; k += TL) rec[k] = sp.obs[(size_t)b * O + k];
-  if (lane < A) rec[O + lane] = (float)(ok ? (double)c / (double)sumv : 0.0);
+  const int OS = sp.obs_slots;       // float slots of the observation in the record (O, or ceil(O / 4) for packed bytes)
+  if (envs && O <= MZ_ENVW - 8 && sp.obs_u8 != 2) { if (lane < O) rec[lane] = ((const float *)envs)[8 + lane]; }
+  else for (int k = lane; k < OS; k += TL) rec[k] = mz_rec_obs_slot(sp, sp.obs + (size_t)b * O, O, k);
+  if (lane < A) rec[OS + lane] = (float)(ok ? (double)c / (double)sumv : 0.0);
   if (lane == 0) {
     const int n = __popc(legal);
     const int N0 = (int)tm.N[0];
@@ -552,10 +553,10 @@ __device__ __forceinline__ void mz_finalize_record(const TreeView &t, const Tree
     }
     const int tt = envs ? envs[2] : sp.t[b], ep = envs ? envs[3] : sp.episode[b];
     const int done = (tt + 1 >= sp.episode_len) ? 1 : 0;
-    mz_rec_put_double(rec + O + A + 0, rv);
-    mz_rec_put_double(rec + O + A + 2, err);
-    rec[O + A + 4] = mz_synth_reward(seed, env, (uint32_t)ep, (uint32_t)tt);
-    int32_t *ri = (int32_t *)(rec + O + A + 5);
+    mz_rec_put_double(rec + OS + A + 0, rv);
+    mz_rec_put_double(rec + OS + A + 2, err);
+    rec[OS + A + 4] = mz_synth_reward(seed, env, (uint32_t)ep, (uint32_t)tt);
+    int32_t *ri = (int32_t *)(rec + OS + A + 5);
     ri[0] = action; ri[1] = done; ri[2] = tt; ri[3] = (int32_t)env; ri[4] = ep;
     if (done) {      // the next game starts: its temperature is evaluated now (actors.py:128-129)
       const double tn = *sp.temp_next;

@@ -15,7 +15,9 @@ struct SelfplayState {
   double *temp;          // [B] visit-softmax temperature of the env's CURRENT game (actors.py:128-129: evaluated once per game)
   double *temp_next;     // [1] temperature the next game of every env starts with (mz_selfplay_set_temperature)
   const float *obs_min, *obs_rng;   // [O] --norm_obs: network input = (obs - min) / range (actors.py:55-58,134-137); null = raw
-  int obs_u8;            // synthetic observations are uint8-valued (the -ram- envs: 128 bytes of console RAM), else ~N(0,1)
+  int obs_u8;            // synthetic observations are uint8-valued (the -ram- envs: 128 bytes of console RAM), else ~N(0,1);
+                         // 2: ... and the experience record carries them as BYTES, four per float slot (obs_slots = ceil(O / 4))
+  int obs_slots;         // float slots the observation takes in a record: O, or ceil(O / 4) when packed
   int export_trees;      // write the searched trees back to the global pool at the end of every move (tests / tree export)
   double *noise_log;     // [ring_moves][B][A] or null: every move's Dirichlet draw, kept per move (mz_selfplay_noise_log: the
                          // parity tests replay the moves of a whole-moves launch on the CPU with the device's own draws)
@@ -104,6 +106,16 @@ __device__ __forceinline__ void mz_rec_put_double(float *dst, double v) {
   ((uint32_t *)dst)[0] = (uint32_t)u; ((uint32_t *)dst)[1] = (uint32_t)(u >> 32);
 }
 
+// float slot k of a record's observation: obs[k], or -- packed byte observations (obs_u8 == 2) -- the bytes obs[4k .. 4k + 3]
+// (History keeps the raw uint8 observation, game.py:93-96; the values are exact small integers in float32)
+__device__ __forceinline__ float mz_rec_obs_slot(const SelfplayState &sp, const float *obs, int O, int k) {
+  if (sp.obs_u8 != 2) return obs[k];
+  uint32_t w = 0;
+  for (int j = 0; j < 4; ++j)
+    if (4 * k + j < O) w |= ((uint32_t)obs[4 * k + j] & 0xFFu) << (8 * j);
+  return __builtin_bit_cast(float, w);
+}
+
 // Game.apply (game.py:79-104) on the synthetic env + the experience record of this move.
 static __global__ void k_env_step_record(TreeView tv, SelfplayState sp, int B, int O, int A, uint64_t seed) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -115,14 +127,15 @@ static __global__ void k_env_step_record(TreeView tv, SelfplayState sp, int B, i
                    sp.error, nullptr);
   float *rec = sp.ring + ((size_t)(move % (unsigned long long)sp.ring_moves) * B + b) * sp.rec_floats;
   const int t = sp.t[b], ep = sp.episode[b];
-  for (int k = 0; k < O; ++k) rec[k] = sp.obs[(size_t)b * O + k];
-  for (int a = 0; a < A; ++a) rec[O + a] = (float)sp.child_visits[(size_t)b * A + a];
+  const int OS = sp.obs_slots;
+  for (int k = 0; k < OS; ++k) rec[k] = mz_rec_obs_slot(sp, sp.obs + (size_t)b * O, O, k);
+  for (int a = 0; a < A; ++a) rec[OS + a] = (float)sp.child_visits[(size_t)b * A + a];
   const float reward = mz_synth_reward(seed, (uint32_t)(sp.env_offset + b), (uint32_t)ep, (uint32_t)t);
   const int done = (t + 1 >= sp.episode_len) ? 1 : 0;
-  mz_rec_put_double(rec + O + A + 0, sp.root_value[b]);
-  mz_rec_put_double(rec + O + A + 2, sp.error[b]);
-  rec[O + A + 4] = reward;
-  int32_t *ri = (int32_t *)(rec + O + A + 5);
+  mz_rec_put_double(rec + OS + A + 0, sp.root_value[b]);
+  mz_rec_put_double(rec + OS + A + 2, sp.error[b]);
+  rec[OS + A + 4] = reward;
+  int32_t *ri = (int32_t *)(rec + OS + A + 5);
   ri[0] = sp.action[b]; ri[1] = done; ri[2] = t; ri[3] = sp.env_offset + b; ri[4] = ep;
   if (done) {      // the next game starts: its temperature is evaluated now (actors.py:128-129)
     sp.t[b] = 0; sp.episode[b] = ep + 1; sp.temp[b] = *sp.temp_next;

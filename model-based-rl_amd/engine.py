@@ -90,6 +90,7 @@ class Engine(object):
     self.NN = self.lib.mz_nodes_per_tree(self._h)
     self.num_weights = self.lib.mz_num_weights(self._h)
     self._keep = []
+    self.obs_packed = False
 
   @classmethod
   def from_config(cls, config, num_envs, device=None, seed=None, env_id_offset=0):
@@ -310,15 +311,20 @@ class Engine(object):
     _abi.check(self.lib.mz_selfplay_set_temperature(self._h, float(temperature), self.stream),
                'mz_selfplay_set_temperature')
 
-  def selfplay_set_obs(self, uint8_obs=False, obs_min=None, obs_range=None):
+  def selfplay_set_obs(self, uint8_obs=False, obs_min=None, obs_range=None, packed=False):
     """Synthetic observations as bytes (the -ram- envs) and / or --norm_obs (actors.py:55-58,134-137): obs_min and
-    obs_range are broadcast to obs_dim like numpy does in the reference's (obs - min) / range."""
+    obs_range are broadcast to obs_dim like numpy does in the reference's (obs - min) / range.  packed: the experience
+    records carry the byte observations four per float slot (records_view(..., obs_u8=True), a replay with obs_u8)."""
     mn = rg = None
     if obs_min is not None:
       mn = np.ascontiguousarray(np.broadcast_to(np.asarray(obs_min, np.float32).reshape(-1), (self.O,)))
       rg = np.ascontiguousarray(np.broadcast_to(np.asarray(obs_range, np.float32).reshape(-1), (self.O,)))
     p = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
-    _abi.check(self.lib.mz_selfplay_set_obs(self._h, int(bool(uint8_obs)), p(mn), p(rg)), 'mz_selfplay_set_obs')
+    if packed and not uint8_obs:
+      raise ValueError('packed records need byte-valued observations (uint8_obs=True)')
+    _abi.check(self.lib.mz_selfplay_set_obs(self._h, 2 if packed else int(bool(uint8_obs)), p(mn), p(rg)), 'mz_selfplay_set_obs')
+    self.obs_packed = bool(packed)
+    self.rec_floats = self.lib.mz_selfplay_rec_floats(self._h)
 
   ENVS = {'synthetic': 0, 'tictactoe': 1}
 

@@ -278,7 +278,8 @@ class Learner(Logger):
       tunable.enable(True)
       tunable.tuning_enable(True)
       tunable.set_max_tuning_duration(20)
-      tunable.write_file_on_exit(False)
+      import tempfile
+      tunable.set_filename(os.path.join(tempfile.gettempdir(), 'mz_tunableop_%d.csv' % os.getpid()))      # (its exit-time dump: not into the cwd)
     self.optimizer = make_optimizer(config, self.network.parameters(), capturable=self.use_graph)
     self.lr_scheduler = make_lr_scheduler(config, self.optimizer)
     if getattr(config, 'scalar_loss', 'MSE') not in ('MSE', 'Huber'):

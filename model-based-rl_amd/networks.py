@@ -118,7 +118,11 @@ def _bn_affine(bn):
 
 
 def _fused_ok(y):
-  return y.is_cuda and y.dtype == torch.float32 and y.dim() == 4 and y.is_contiguous() and (y.shape[2] * y.shape[3]) % 4 == 0
+  """may `y` go through the in-place HIP epilogue (mz_affine_relu)?  Only where autograd is off -- the kernel is invisible to
+  it: eval() with gradients enabled (saliency, reanalyse with gradients) must take the PyTorch path -- and only for float32
+  NCHW-contiguous tensors (a channels_last convolution output would be read with the wrong layout)."""
+  return (not torch.is_grad_enabled() and y.is_cuda and y.dtype == torch.float32 and y.dim() == 4 and y.is_contiguous() and
+          (y.shape[2] * y.shape[3]) % 4 == 0)
 
 
 def _affine_relu_(y, scale, shift, residual=None):
@@ -163,13 +167,13 @@ class _Block(nn.Module):
     self.norm = norm
 
   def forward(self, x):
-    if self.norm and not self.training and _fused_ok(x):
-      x = x if x.is_contiguous() else x.contiguous()
-      y = _affine_relu_(self.conv1(x), *_bn_affine(self.bn1))
-      return _affine_relu_(self.conv2(y), *_bn_affine(self.bn2), residual=x)
+    fused = self.norm and not self.training and _fused_ok(x)
     y = self.conv1(x)
-    y = torch.relu(_bn_infer(self.bn1, y) if self.norm else y)
+    # (every tensor handed to the kernel is checked, the convolutions' outputs too)
+    y = _affine_relu_(y, *_bn_affine(self.bn1)) if fused and _fused_ok(y) else torch.relu(_bn_infer(self.bn1, y) if self.norm else y)
     y = self.conv2(y)
+    if fused and _fused_ok(y):
+      return _affine_relu_(y, *_bn_affine(self.bn2), residual=x)
     y = _bn_infer(self.bn2, y) if self.norm else y
     return torch.relu(y + x)
 

@@ -211,7 +211,8 @@ def main(argv=None):
     max_moves = None              # run until the learner has reached --training_steps (actors.py:93)
   cfg = Config(args)
   cfg.action_space, cfg.obs_space = env_shapes(cfg)
-  cfg.obs_u8 = len(cfg.obs_space) == 3               # image frames travel as bytes (records, replay)
+  from .config import obs_are_bytes
+  cfg.obs_u8 = obs_are_bytes(cfg)                    # image frames and -ram- observations travel as bytes (records, replay)
   if cfg.seed is None:
     cfg.seed = 0
   if cfg.run_tag is None:           # train.py:83-90: a date-stamped run directory (the launcher's start time under --ranks)
