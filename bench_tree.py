@@ -82,9 +82,10 @@ def main(args):
   both = (bytes_sel + bytes_exb) / ((sel_us + exb_us) * 1e-6) / 1e9
   NN = 1 + (SIMS + 1) * A
   traffic = None
-  tfile = os.path.join(ROOT, 'profiles', 'r03_tree_traffic.json')
+  tfile = os.path.join(ROOT, 'profiles', 'r04_tree_traffic.json')      # (FETCH_SIZE / WRITE_SIZE passes of this command, builder-run)
   if os.path.exists(tfile) and B == 4096:
     traffic = json.load(open(tfile))
+
   out = {
       'metric': 'MCTS sims/sec/GPU (tree kernels alone: mz_select + mz_expand_backup, network outputs replayed)',
       'value': B * SIMS * moves / dt, 'unit': 'simulations/s', 'n_gpus': 1, 'steps': moves, 'warmup': warmup,
@@ -93,7 +94,8 @@ def main(args):
       'config': {'workload': 'stand-alone tree kernels, %d trees x %d actions x %d simulations per move, %d nodes per tree, '
                              'replayed network outputs, Dirichlet noise on the device' % (B, A, SIMS, NN),
                  'envs_per_gpu': B, 'num_simulations': SIMS, 'mean_leaf_depth': d_mean,
-                 'working_set_bytes': B * NN * 33 + B * (SIMS + 2) * 4,
+                 'working_set_bytes': B * ((NN + 3 + 3) // 4 * 4) * 32 + B * (SIMS + 2) * 4,
+                 'node_pool': '32-byte node records (W f64, P f64, N i32, E i32, R f32, to_play i8): the A children of a node are 32 A contiguous bytes',
                  'note': 'one step = one move = %d x (k_tree_select, k_tree_expand_backup) + root; wall time includes the '
                          'launch gaps of %d dependent launches per move' % (SIMS, 2 * SIMS + 3)},
       'env_steps_per_s': B * moves / dt,
@@ -104,7 +106,7 @@ def main(args):
                                          'frac_of_hbm_peak': ach_sel / (HBM_TBPS * 1e3)},
                        'k_tree_expand_backup': {'us_per_launch': exb_us, 'algorithmic_bytes_per_launch': bytes_exb,
                                                 'achieved_GBps': ach_exb, 'frac_of_hbm_peak': ach_exb / (HBM_TBPS * 1e3)}},
-                   'against_the_caches': {'working set': 'cache resident (%.0f MB of node arrays)' % (B * NN * 33 / 1e6),
+                   'against_the_caches': {'working set': 'cache resident (%.0f MB of node records)' % (B * NN * 32 / 1e6),
                                           'frac_of_infinity_cache_random_rows_8.6TBps': both / (MALL_TBPS * 1e3),
                                           'frac_of_l2_34.5TBps': both / (L2_TBPS * 1e3),
                                           'frac_of_measured_hbm_6.29TBps': both / (HBM_MEASURED_TBPS * 1e3)},
@@ -112,7 +114,10 @@ def main(args):
                               'each (one 16-lane group per tree), %.0f KB of algorithmic traffic per launch in %.1f us; what '
                               'bounds them is the chain of dependent cache round trips and the %.1f us launch floor, not bytes' %
                               (bytes_sel / 1e3, sel_us, 1.5),
-                   'hbm_side_traffic': 'profiles/r03_tree_traffic.json: FETCH_SIZE / WRITE_SIZE passes of this command' if traffic else None,
+                   'hbm_side_traffic': ({'source': 'profiles/r04_tree_traffic.json: FETCH_SIZE / WRITE_SIZE passes of this command',
+                                         'k_tree_select_fetched_over_algorithmic': traffic['k_tree_select']['hbm_bytes_per_launch'] / bytes_sel,
+                                         'k_tree_expand_backup_fetched_over_algorithmic': traffic['k_tree_expand_backup']['hbm_bytes_per_launch'] / bytes_exb}
+                                        if traffic and 'k_tree_select' in traffic else None),
                    'clock': 'start / stop events on each kernel\'s own dispatch (hipExtLaunchKernelGGL, mz_tree_pair_timed), every '
                             'launch of 4 moves (%d launches of each kernel)' % len(timing)},
   }

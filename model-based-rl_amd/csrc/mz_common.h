@@ -10,15 +10,37 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Struct-of-arrays node pool: one slab of NN nodes per tree, children of one node contiguous.
-// Node numbering: root 0; child a of the node with expansion index e is 1 + e*A + a.
+// Node pool in HBM: one slab of NN nodes per tree, ONE 32-byte record per node (array of structs), children of one node
+// contiguous.  Node numbering: root 0; child a of the node with expansion index e is 1 + e*A + a.  The fields a descent reads
+// of a child -- visit count, expansion index, prior, value sum, reward -- sit in one record, the A children of a node in 32 A
+// contiguous bytes: a level of MCTS.select_child (mcts.py:104-113) over 4 children is ONE 128-byte line (until r04 the pool
+// was six arrays: a level touched five lines and used 16-32 bytes of each -- 4-7 x the algorithmic bytes by the FETCH_SIZE /
+// WRITE_SIZE counters, profiles/r03_tree_traffic.json).  A slab starts MZ_NODE_OFF records into its NS-record stride so that
+// the child blocks of a 4-action tree are line-aligned.  Code addresses fields as t.N[slab + node] etc. (MzField).
+struct MzNode {
+  double W;          // value_sum              (mcts.py:33)
+  double P;          // prior                  (mcts.py:36)
+  int32_t N;         // visit_count            (mcts.py:32)
+  int32_t E;         // expansion index / hidden slot, -1 = leaf (mcts.py:39-40)
+  float R;           // reward (float32 network scalar, exact in double) (mcts.py:34)
+  int8_t TP;         // to_play                (mcts.py:37)
+  int8_t pad_[3];
+};
+#define MZ_NODE_OFF 3
+template <class T, int OFF>
+struct MzField {       // one field of the records, indexable like the array it used to be
+  MzNode *base;
+  __device__ __forceinline__ T &operator[](size_t i) const { return *(T *)((char *)(base + i) + OFF); }
+  __host__ __device__ __forceinline__ MzField operator+(size_t o) const { return MzField{base + o}; }
+};
 struct TreeView {
-  int32_t *N;        // [B][NN] visit_count            (mcts.py:32)
-  double *W;         // [B][NN] value_sum              (mcts.py:33)
-  double *P;         // [B][NN] prior                  (mcts.py:36)
-  float *R;          // [B][NN] reward (float32 network scalar, exact in double) (mcts.py:34)
-  int32_t *E;        // [B][NN] expansion index / hidden slot, -1 = leaf (mcts.py:39-40)
-  int8_t *TP;        // [B][NN] to_play                (mcts.py:37)
+  MzField<int32_t, 16> N;
+  MzField<double, 0> W;
+  MzField<double, 8> P;
+  MzField<float, 24> R;
+  MzField<int32_t, 20> E;
+  MzField<int8_t, 28> TP;
+  int NS;            // records per tree slab (NN + MZ_NODE_OFF rounded up to a multiple of 4)
   uint32_t *legal;   // [B] bit a = root child a exists (actors.py:141-142)
   double *mn, *mx;   // [B] MinMaxStats                (mcts.py:6-25)
   int32_t *nexp;     // [B] expansions so far
@@ -32,6 +54,7 @@ struct TreeView {
   float *root_logits;// [B][A]
   double *noise;     // [B][A] Dirichlet draw mixed into the root
   const double *sqrttab;  // [sims+2] sqrt(n)                      (host libm, mcts.py:117)
+  const double *logtab;   // [sims+2] log((n + base + 1) / base) + init    (host libm, mcts.py:116)
   const double *pbctab;   // [sims+2][sims+2] pb_c(Np, Nc) = logtab[Np] * (sqrttab[Np] / (Nc + 1))  (mcts.py:116-117)
   int B, A, sims, NN, PL;
   int two_players, has_min, has_max;
@@ -44,6 +67,9 @@ struct TreeView {
   float *sim_io;
   int sim_io_keep;
 };
+
+// first record index of tree b's slab (node k of tree b = record mz_slab(t, b) + k)
+__device__ __forceinline__ size_t mz_slab(const TreeView &t, int b) { return (size_t)b * (size_t)t.NS + MZ_NODE_OFF; }
 
 // (development switch -DMZ_NO_SIM_IO: the kernels without the instrumentation's branches, for A/B runs of its cost)
 #ifdef MZ_NO_SIM_IO

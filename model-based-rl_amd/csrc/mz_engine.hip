@@ -65,6 +65,8 @@ struct mz_engine {
   mz_config cfg;
   int device = 0;                   // HIP device the engine's pools live on (the current device at mz_create)
   int B, Bp, A, O, sims, NN, PL, G, jtp;
+  int NS = 0;                       // records per tree slab of the node pool
+  MzNode *nodes = nullptr;          // the node pool [Bp][NS]
   TreeView tv;
   NetView nv;
   std::vector<void *> allocs;
@@ -960,16 +962,22 @@ int mz_create(const mz_config *cfg, mz_engine **out) {
   }
   TreeView &t = e->tv;
   memset(&t, 0, sizeof t);
-  const size_t nb = (size_t)e->Bp, nn = nb * e->NN;
+  const size_t nb = (size_t)e->Bp;
 #define DM(p, n) if (dmalloc(e, &(p), (n))) { mz_destroy(e); return -1; }
-  DM(t.N, nn) DM(t.W, nn) DM(t.P, nn) DM(t.R, nn) DM(t.E, nn) DM(t.TP, nn)
+  // the node pool: 32-byte records, NS per tree (mz_common.h: MzNode)
+  e->NS = (e->NN + MZ_NODE_OFF + 3) & ~3;
+  MzNode *nodes;
+  DM(nodes, nb * e->NS)
+  e->nodes = nodes;
+  t.N.base = t.W.base = t.P.base = t.R.base = t.E.base = t.TP.base = nodes;
+  t.NS = e->NS;
   DM(t.legal, nb) DM(t.mn, nb) DM(t.mx, nb) DM(t.nexp, nb) DM(t.path, nb * e->PL) DM(t.plen, nb) DM(t.leaf_tp, nb)
   DM(t.leaf, nb) DM(t.slot, nb) DM(t.act, nb) DM(t.depth, nb)
   DM(t.hpool, nb * (e->sims + 1) * MZ_HS)
   DM(t.value, nb) DM(t.reward, nb) DM(t.logits, nb * e->A) DM(t.root_value, nb) DM(t.root_logits, nb * e->A)
   DM(t.noise, nb * e->A)
-  double *sqrttab, *pbctab;
-  DM(sqrttab, e->sims + 2) DM(pbctab, (size_t)(e->sims + 2) * (e->sims + 2))
+  double *sqrttab, *pbctab, *logtab;
+  DM(sqrttab, e->sims + 2) DM(pbctab, (size_t)(e->sims + 2) * (e->sims + 2)) DM(logtab, e->sims + 2)
 #undef DM
   {
     // mcts.py:116-117: math.log((N + base + 1) / base) + init and math.sqrt(N), for every N a parent
@@ -990,12 +998,13 @@ int mz_create(const mz_config *cfg, mz_engine **out) {
         pt[(size_t)np * T + nc] = v;
       }
     if (hipMemcpy(pbctab, pt.data(), pt.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(logtab, lt.data(), lt.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(sqrttab, st.data(), st.size() * 8, hipMemcpyHostToDevice) != hipSuccess) {
       mz_destroy(e);
       return fail("mz_create: table upload failed");
     }
   }
-  t.sqrttab = sqrttab; t.pbctab = pbctab;
+  t.sqrttab = sqrttab; t.pbctab = pbctab; t.logtab = logtab;
   t.B = e->B; t.A = e->A; t.sims = e->sims; t.NN = e->NN; t.PL = e->PL;
   t.two_players = cfg->two_players; t.has_min = cfg->has_min_bound; t.has_max = cfg->has_max_bound;
   t.min_bound = cfg->min_bound; t.max_bound = cfg->max_bound; t.discount = cfg->discount;
@@ -1492,14 +1501,22 @@ int mz_export_tree(mz_engine *e, int32_t *N, double *W, double *P, float *R, int
   if (!e) return fail("mz_export_tree: null engine");
   MZ_ENTER(e);
   HIPCHECK(hipDeviceSynchronize());
-  const size_t nn = (size_t)e->B * e->NN;
   const TreeView &t = e->tv;
-  if (N) HIPCHECK(hipMemcpy(N, t.N, nn * 4, hipMemcpyDeviceToHost));
-  if (W) HIPCHECK(hipMemcpy(W, t.W, nn * 8, hipMemcpyDeviceToHost));
-  if (P) HIPCHECK(hipMemcpy(P, t.P, nn * 8, hipMemcpyDeviceToHost));
-  if (R) HIPCHECK(hipMemcpy(R, t.R, nn * 4, hipMemcpyDeviceToHost));
-  if (E) HIPCHECK(hipMemcpy(E, t.E, nn * 4, hipMemcpyDeviceToHost));
-  if (TP) HIPCHECK(hipMemcpy(TP, t.TP, nn, hipMemcpyDeviceToHost));
+  if (N || W || P || R || E || TP) {      // the record pool -> the caller's per-field arrays [B][NN]
+    std::vector<MzNode> pool((size_t)e->B * e->NS);
+    HIPCHECK(hipMemcpy(pool.data(), e->nodes, pool.size() * sizeof(MzNode), hipMemcpyDeviceToHost));
+    for (int b = 0; b < e->B; ++b)
+      for (int k = 0; k < e->NN; ++k) {
+        const MzNode &n = pool[(size_t)b * e->NS + MZ_NODE_OFF + k];
+        const size_t i = (size_t)b * e->NN + k;
+        if (N) N[i] = n.N;
+        if (W) W[i] = n.W;
+        if (P) P[i] = n.P;
+        if (R) R[i] = n.R;
+        if (E) E[i] = n.E;
+        if (TP) TP[i] = n.TP;
+      }
+  }
   if (legal_mask) HIPCHECK(hipMemcpy(legal_mask, t.legal, (size_t)e->B * 4, hipMemcpyDeviceToHost));
   if (minmax) {
     std::vector<double> mn(e->B), mx(e->B);

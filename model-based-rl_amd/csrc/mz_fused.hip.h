@@ -716,7 +716,7 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
       tm[i].N = l_N + o; tm[i].E = l_E + o; tm[i].P = l_P + o; tm[i].TP = l_TP + o;
       tm[i].X = l_Q + ov; tm[i].W = l_W + ov; tm[i].R = l_R + ov;
     } else {
-      const size_t o = (size_t)(b < t.B ? b : 0) * t.NN;
+      const size_t o = mz_slab(t, b < t.B ? b : 0);
       tm[i].N = t.N + o; tm[i].W = t.W + o; tm[i].P = t.P + o; tm[i].R = t.R + o; tm[i].E = t.E + o; tm[i].TP = t.TP + o;
     }
   }
@@ -794,14 +794,14 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
       my_act[i] = t.act[b];
       tr[i].len = t.plen[b];
       tr[i].tp = t.leaf_tp[b];
-      tr[i].root_tp = t.TP[(size_t)b * t.NN];
-      tr[i].root_n = t.N[(size_t)b * t.NN];
+      tr[i].root_tp = t.TP[mz_slab(t, b)];
+      tr[i].root_n = t.N[mz_slab(t, b)];
       tr[i].legal = t.legal[b];
       tr[i].mn = t.mn[b];
       tr[i].mx = t.mx[b];
       for (int k = tl; k < tr[i].len; k += TL) s_path[mt * MZ_FUSED_MAXPL + k] = t.path[(size_t)b * t.PL + k];
       if constexpr (LT == 1) {       // bring the existing part of the tree (root, expanded slabs) into LDS
-        const size_t o = (size_t)b * t.NN;
+        const size_t o = mz_slab(t, b);
         const int have = 1 + (slot0 + 1) * t.A;
         // every node this launch can create starts as a fresh Node (mcts.py:30-37): visit_count 0, value_sum 0, reward 0,
         // no children, to_play 1 -- written once here, so that an expansion only has to set the priors
@@ -816,7 +816,7 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
           tm[i].E[k] = (int16_t)t.E[o + k]; tm[i].TP[k] = t.TP[o + k];
         }
       } else if constexpr (LT == 2) {
-        const size_t o = (size_t)b * t.NN;
+        const size_t o = mz_slab(t, b);
         const int have = 1 + (slot0 + 1) * t.A;
         for (int k = tl; k < have; k += TL) {
           const int nk = t.N[o + k], ek = t.E[o + k];
@@ -1202,7 +1202,7 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
     // and has finalized this one from LDS above (15 MB of dead stores per launch at 4096 x 125 nodes)
     if constexpr (LT != 0) {
       if (b < t.B && (!record || sp.export_trees)) {
-        const size_t o = (size_t)b * t.NN;
+        const size_t o = mz_slab(t, b);
         const int have = 1 + (slot0 + nsims + 1) * t.A;
         for (int k = tl; k < have; k += TL) {
           t.N[o + k] = tm[i].N[k]; t.P[o + k] = tm[i].P[k]; t.E[o + k] = tm[i].E[k];

@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256, 1) void k_search_h2(NetView n, TreeView t, con
       tm.N = l_N + o; tm.E = l_E + o; tm.P = l_P + o; tm.TP = l_TP + o;
       tm.X = l_Q + ov; tm.W = l_W + ov; tm.R = l_R + ov;
     } else {
-      const size_t o = (size_t)(b < t.B ? b : 0) * t.NN;
+      const size_t o = mz_slab(t, b < t.B ? b : 0);
       tm.N = t.N + o; tm.W = t.W + o; tm.P = t.P + o; tm.R = t.R + o; tm.E = t.E + o; tm.TP = t.TP + o;
     }
     tr.len = 1; tr.tp = 1; tr.root_tp = 1; tr.legal = 0; tr.mn = 0.0; tr.mx = 0.0; tr.root_n = 0;
@@ -298,14 +298,14 @@ __global__ __launch_bounds__(256, 1) void k_search_h2(NetView n, TreeView t, con
       my_act = t.act[b];
       tr.len = t.plen[b];
       tr.tp = t.leaf_tp[b];
-      tr.root_tp = t.TP[(size_t)b * t.NN];
-      tr.root_n = t.N[(size_t)b * t.NN];
+      tr.root_tp = t.TP[mz_slab(t, b)];
+      tr.root_n = t.N[mz_slab(t, b)];
       tr.legal = t.legal[b];
       tr.mn = t.mn[b];
       tr.mx = t.mx[b];
       for (int k = tl; k < tr.len; k += TL) s_path[mt * MZ_FUSED_MAXPL + k] = t.path[(size_t)b * t.PL + k];
       if constexpr (LT == 1) {
-        const size_t o = (size_t)b * t.NN;
+        const size_t o = mz_slab(t, b);
         const int have = 1 + (slot0 + 1) * t.A;
         for (int k = have + tl; k < t.NN; k += TL) {
           tm.N[k] = 0; tm.W[k] = 0.0; tm.R[k] = 0.f; tm.E[k] = -1; tm.TP[k] = 1;
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256, 1) void k_search_h2(NetView n, TreeView t, con
           tm.E[k] = (int16_t)t.E[o + k]; tm.TP[k] = t.TP[o + k];
         }
       } else if constexpr (LT == 2) {
-        const size_t o = (size_t)b * t.NN;
+        const size_t o = mz_slab(t, b);
         const int have = 1 + (slot0 + 1) * t.A;
         for (int k = tl; k < have; k += TL) {
           const int nk = t.N[o + k], ek = t.E[o + k];
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(256, 1) void k_search_h2(NetView n, TreeView t, con
     if (b < t.B && tl == 0) { t.mn[b] = tr.mn; t.mx[b] = tr.mx; t.nexp[b] = slot0 + nsims + 1; }
     if constexpr (LT != 0) {
       if (b < t.B && (!record || sp.export_trees)) {
-        const size_t o = (size_t)b * t.NN;
+        const size_t o = mz_slab(t, b);
         const int have = 1 + (slot0 + nsims + 1) * t.A;
         for (int k = tl; k < have; k += TL) {
           t.N[o + k] = tm.N[k]; t.P[o + k] = tm.P[k]; t.E[o + k] = tm.E[k];

@@ -1,4 +1,4 @@
-// mz_tree.hip.h -- MCTS tree kernels over the SoA node pool (gfx950).
+// mz_tree.hip.h -- MCTS tree kernels over the node pool (32-byte records, mz_common.h: MzNode; gfx950).
 //
 // One group of G lanes (G = power of two >= A, <= 32) owns one tree; a 64-wide wavefront carries 64/G
 // trees.  Children of a node are contiguous, so the G lanes of a group read one coalesced segment per
@@ -17,37 +17,64 @@ __device__ __forceinline__ double mz_normalize(double v, double mn, double mx) {
   return v;
 }
 
+// whole-record access to the node pool: two 16-byte loads / stores per node
+typedef int mz_i32x4 __attribute__((ext_vector_type(4)));
+union MzNodeBits { MzNode n; mz_i32x4 q[2]; };
+__device__ __forceinline__ MzNode mz_node_load(const TreeView &t, size_t i) {
+  MzNodeBits u;
+  const mz_i32x4 *src = (const mz_i32x4 *)(t.W.base + i);
+  u.q[0] = src[0]; u.q[1] = src[1];
+  return u.n;
+}
+// a fresh Node(prior) (mcts.py:30-40): visit_count 0, value_sum 0, reward 0, no children
+__device__ __forceinline__ void mz_node_fresh(const TreeView &t, size_t i, double prior, int8_t to_play) {
+  MzNodeBits u;
+  u.q[0] = mz_i32x4{0, 0, 0, 0}; u.q[1] = mz_i32x4{0, 0, 0, 0};
+  u.n.W = 0.0; u.n.P = prior; u.n.N = 0; u.n.E = -1; u.n.R = 0.f; u.n.TP = to_play;
+  mz_i32x4 *dst = (mz_i32x4 *)(t.W.base + i);
+  dst[0] = u.q[0]; dst[1] = u.q[1];
+}
+
 // The descent of MCTS.run (mcts.py:83-94) with MCTS.select_child (104-113) and ucb_score (115-124).
+// One dependent memory round trip per level: every child lane fetches its child's whole 32-byte record -- the A children of
+// a node are 32 A contiguous bytes -- and the winner's expansion index and visit count (the next level's `e` and parent
+// count) ride along in the arg-max instead of being fetched afterwards.
 template <int G>
 __device__ __forceinline__ void mz_tree_select(const TreeView &t, int b, int lane, int &slot_out, int &act_out) {
   const int A = t.A;
-  const size_t o = (size_t)b * t.NN;
+  const size_t o = mz_slab(t, b);
   int32_t *path = t.path + (size_t)b * t.PL;
   const double mn = t.mn[b], mx = t.mx[b];
   const uint32_t legal = t.legal[b];
-  int node = 0, parent = 0, len = 1, a_sel = -1;
-  int tp = t.TP[o];
+  int node = 0, parent_e = 0, len = 1, a_sel = -1;
+  const MzNode root = mz_node_load(t, o);
+  int tp = root.TP;
   if (lane == 0) path[0] = 0;
-  int e = t.E[o];
+  int e = root.E, Np = root.N;
   while (e >= 0) {
-    const int Np = t.N[o + node];
     const int ch = 1 + e * A + lane;
     const bool valid = lane < A && (node != 0 || ((legal >> lane) & 1u));
     double score = 0.0;
-    int best = -1;
+    int best = -1, ce = -1, cn = 0;
+    // log((Np + base + 1) / base) + init and sqrt(Np) of THIS level's parent count (host libm tables): requested beside the
+    // children's records, not behind them -- pb_c is then the reference's own two operations on them (mcts.py:116-117:
+    // pb_c = log(..) + init; pb_c *= sqrt(Np) / (Nc + 1)), IEEE double like the host-built pb_c table of the fused kernels
+    const double lgn = t.logtab[Np], sqn = t.sqrttab[Np];
     if (valid) {
-      const int Nc = t.N[o + ch];
-      const double p = t.P[o + ch];
+      const MzNode c = mz_node_load(t, o + ch);
+      const int Nc = c.N;
+      const double p = c.P;
+      ce = c.E; cn = Nc;
       if (Np == 0) {
         score = p;                                     // fresh root: rank by prior (mcts.py:105-108)
       } else {
-        const double pb_c = t.pbctab[Np * (t.sims + 2) + Nc];   // (log((Np+base+1)/base)+init) * (sqrt(Np)/(Nc+1))
+        const double pb_c = lgn * (sqn / (double)(Nc + 1));
         const double prior_score = pb_c * p;
         double value_score;
         if (Nc > 0) {
-          const double q = t.W[o + ch] / (double)Nc;
+          const double q = c.W / (double)Nc;
           const double v = t.two_players ? -q : q;
-          value_score = mz_normalize((double)t.R[o + ch] + t.discount * v, mn, mx);
+          value_score = mz_normalize((double)c.R + t.discount * v, mn, mx);
         } else {
           value_score = t.init_value_score;
         }
@@ -59,19 +86,20 @@ __device__ __forceinline__ void mz_tree_select(const TreeView &t, int b, int lan
 #pragma unroll
     for (int off = G / 2; off >= 1; off >>= 1) {
       const double os = __shfl_xor(score, off, G);
-      const int ob = __shfl_xor(best, off, G);
+      const int ob = __shfl_xor(best, off, G), oe = __shfl_xor(ce, off, G), on = __shfl_xor(cn, off, G);
       const bool take = ob >= 0 && (best < 0 || os > score || (os == score && ob > best));
-      if (take) { score = os; best = ob; }
+      if (take) { score = os; best = ob; ce = oe; cn = on; }
     }
     a_sel = best;
-    parent = node;
+    parent_e = e;
     node = 1 + e * A + a_sel;
     if (lane == 0) path[len] = node;
     ++len;
     if (t.two_players) tp = -tp;
-    e = t.E[o + node];
+    e = ce;
+    Np = cn;
   }
-  slot_out = t.E[o + parent];
+  slot_out = parent_e;
   act_out = a_sel;
   if (lane == 0) {
     t.plen[b] = len;
@@ -91,11 +119,13 @@ __device__ __forceinline__ void mz_tree_select(const TreeView &t, int b, int lan
 
 // Node.expand for the selected leaf (mcts.py:47-55, all actions: mcts.py:97) followed by
 // MCTS.backpropagate (mcts.py:126-143).  value/reward/logits: this tree's network outputs.
+// The path's nodes are fetched G at a time, one record per lane (one round trip per G nodes instead of one per node);
+// lane 0 then runs the reference's sequential recurrence on the shuffled fields and stores the results.
 template <int G>
 __device__ __forceinline__ void mz_tree_expand_backup(const TreeView &t, int b, int lane, float value,
                                                       float reward, const float *logits) {
   const int A = t.A;
-  const size_t o = (size_t)b * t.NN;
+  const size_t o = mz_slab(t, b);
   const int32_t *path = t.path + (size_t)b * t.PL;
   const int len = t.plen[b];
   const int tp = t.leaf_tp[b];
@@ -105,34 +135,42 @@ __device__ __forceinline__ void mz_tree_expand_backup(const TreeView &t, int b, 
   const double p = (lane < A) ? exp((double)logits[lane]) : 0.0;
   double sum = 0.0;
   for (int a = 0; a < A; ++a) sum = sum + __shfl(p, a, G);
-  if (lane < A) {
-    const int ch = 1 + e * A + lane;
-    t.N[o + ch] = 0; t.W[o + ch] = 0.0; t.R[o + ch] = 0.f; t.E[o + ch] = -1; t.TP[o + ch] = 1;
-    t.P[o + ch] = p / sum;
+  if (lane < A) mz_node_fresh(t, o + 1 + e * A + lane, p / sum, 1);
+  const double g = t.discount;
+  double mn = 0.0, mx = 0.0, v = (double)value;
+  if (lane == 0) { mn = t.mn[b]; mx = t.mx[b]; t.nexp[b] = e + 1; }
+  for (int base = 0; base < len; base += G) {
+    const int j = base + lane;
+    const int mynode = path[len - 1 - (j < len ? j : len - 1)];
+    const MzNode c = mz_node_load(t, o + mynode);
+    const int cnt = (len - base) < G ? (len - base) : G;
+    for (int jj = 0; jj < cnt; ++jj) {
+      const int idx = base + jj;
+      const int node = __shfl(mynode, jj, G);
+      const double Wn = __shfl(c.W, jj, G);
+      const int Nn = __shfl(c.N, jj, G);
+      const float Rn = __shfl(c.R, jj, G);
+      const int TPn = __shfl((int)c.TP, jj, G);
+      if (lane == 0) {
+        const int ntp = (idx == 0) ? tp : TPn;
+        const double r_node = (idx == 0) ? (double)reward : (double)Rn;
+        const double w = Wn + ((ntp == tp) ? v : -v);
+        const int n = Nn + 1;
+        t.W[o + node] = w;
+        t.N[o + node] = n;
+        const double r = (t.two_players && ntp == tp) ? -r_node : r_node;
+        if (idx < len - 1) {
+          const double q = w / (double)n;
+          const double new_q = t.two_players ? r_node - g * q : r_node + g * q;
+          mn = new_q < mn ? new_q : mn;
+          mx = new_q > mx ? new_q : mx;
+        }
+        v = r + g * v;
+      }
+    }
   }
   if (lane == 0) {
     t.E[o + leafnode] = e;
-    t.nexp[b] = e + 1;
-    const double g = t.discount;
-    double mn = t.mn[b], mx = t.mx[b];
-    double v = (double)value;
-    for (int idx = 0; idx < len; ++idx) {
-      const int node = path[len - 1 - idx];
-      const int ntp = (idx == 0) ? tp : (int)t.TP[o + node];
-      const double r_node = (idx == 0) ? (double)reward : (double)t.R[o + node];
-      const double w = t.W[o + node] + ((ntp == tp) ? v : -v);
-      const int n = t.N[o + node] + 1;
-      t.W[o + node] = w;
-      t.N[o + node] = n;
-      const double r = (t.two_players && ntp == tp) ? -r_node : r_node;
-      if (idx < len - 1) {
-        const double q = w / (double)n;
-        const double new_q = t.two_players ? r_node - g * q : r_node + g * q;
-        mn = new_q < mn ? new_q : mn;
-        mx = new_q > mx ? new_q : mx;
-      }
-      v = r + g * v;
-    }
     t.TP[o + leafnode] = (int8_t)tp;
     t.R[o + leafnode] = reward;
     t.mn[b] = mn;
@@ -152,7 +190,7 @@ __device__ __forceinline__ void mz_tree_root(const TreeView &t, int b, int lane,
                                              const float *logits, const double *noise, double frac,
                                              double *stage = nullptr) {
   const int A = t.A;
-  const size_t o = (size_t)b * t.NN;
+  const size_t o = mz_slab(t, b);
   const bool ok = lane < A && ((legal >> lane) & 1u);
   const double p = ok ? exp((double)logits[lane]) : 0.0;
   double sum = 0.0;
@@ -161,8 +199,7 @@ __device__ __forceinline__ void mz_tree_root(const TreeView &t, int b, int lane,
     const int ch = 1 + lane;
     double prior = ok ? p / sum : 0.0;
     if (ok && noise) prior = prior * (1 - frac) + noise[lane] * frac;
-    t.N[o + ch] = 0; t.W[o + ch] = 0.0; t.R[o + ch] = 0.f; t.E[o + ch] = -1; t.TP[o + ch] = ok ? 1 : 0;
-    t.P[o + ch] = prior;
+    mz_node_fresh(t, o + ch, prior, ok ? 1 : 0);
     if (stage) stage[lane] = prior;
   }
   if (lane == 0) {
@@ -256,7 +293,9 @@ struct TreeRegs {
 //      fetches X[E[child]] beside its pb_c lookup (both hang on the first round trip), the backup E[node] first.
 //      Pong-ram shapes (307 nodes per tree): 97 KB instead of the 162 KB of placement (1).
 template <int LT> struct TreeMem;
-template <> struct TreeMem<0> { int32_t *N; double *W; double *P; float *R; int32_t *E; int8_t *TP; };
+template <> struct TreeMem<0> {      // the tree's slab of the global pool: fields of its 32-byte node records (MzField)
+  MzField<int32_t, 16> N; MzField<double, 0> W; MzField<double, 8> P; MzField<float, 24> R; MzField<int32_t, 20> E; MzField<int8_t, 28> TP;
+};
 template <> struct TreeMem<1> { int16_t *N; double *W; double *P; float *R; int16_t *E; int8_t *TP; double *X; };
 template <> struct TreeMem<2> { int16_t *N; double *W; double *P; float *R; int16_t *E; int8_t *TP; double *X; };
 
@@ -648,14 +687,13 @@ __global__ void k_tree_root_priors(TreeView t, const int8_t *to_play, const uint
   const int b = gt / G, lane = gt % G;
   if (b >= t.B) return;
   const int A = t.A;
-  const size_t o = (size_t)b * t.NN;
+  const size_t o = mz_slab(t, b);
   uint32_t mask = 0;
   for (int a = 0; a < A; ++a) mask |= ((legal ? legal[(size_t)b * A + a] : 1) ? 1u : 0u) << a;
   if (lane < A) {
     const bool ok = (mask >> lane) & 1u;
     const int ch = 1 + lane;
-    t.N[o + ch] = 0; t.W[o + ch] = 0.0; t.R[o + ch] = 0.f; t.E[o + ch] = -1; t.TP[o + ch] = ok ? 1 : 0;
-    t.P[o + ch] = ok ? priors[(size_t)b * A + lane] : 0.0;
+    mz_node_fresh(t, o + ch, ok ? priors[(size_t)b * A + lane] : 0.0, ok ? 1 : 0);
   }
   if (lane == 0) {
     t.N[o] = 0; t.W[o] = 0.0; t.R[o] = 0.f; t.E[o] = 0; t.TP[o] = to_play ? to_play[b] : (int8_t)1; t.P[o] = 0.0;
@@ -722,7 +760,7 @@ __device__ __forceinline__ void mz_finalize_tree(const TreeView &t, int b, const
                                                  int32_t *action, double *child_visits, double *root_value,
                                                  double *error, int32_t *visit_counts) {
   const int A = t.A;
-  const size_t o = (size_t)b * t.NN;
+  const size_t o = mz_slab(t, b);
   const uint32_t legal = t.legal[b];
   int acts[MZ_MAX_ACTIONS_K];
   double d[MZ_MAX_ACTIONS_K];
