@@ -14,6 +14,8 @@ names = {
     'mfma_util_%s.json': '%s_mfma_util.json', 'ingest_bench_%s.json': '%s_ingest_bench.json',
     'one_replay_8ranks_4threads_%s.json': '%s_one_replay_8ranks_4threads.json',
     'one_replay_8ranks_8threads_%s.json': '%s_one_replay_8ranks_8threads.json',
+    'tree_traffic_%s.json': '%s_tree_traffic.json', 'learner_speed_%s.json': '%s_learner_speed.json',
+    'bench_selflaunch_2ranks_1gpu_%s.json': '%s_bench_selflaunch_2ranks_1gpu.json',
 }
 for src, dst in names.items():
   s = os.path.join(G, src % tag)

@@ -10,12 +10,12 @@ cd /tmp && export TMPDIR=/tmp
 cd $R
 python3 bench.py > $O/bench_$TAG.json 2> $O/bench_$TAG.err
 tail -c 1500 $O/bench_$TAG.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$TAG -- python3 bench.py --steps 128 --warmup 16 --no-cpu-baseline --no-live-traffic > $O/bench_prof_$TAG.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$TAG -- python3 bench.py --steps 32 --warmup 4 --no-cpu-baseline --no-live-traffic > $O/pmc_fetch_$TAG.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_$TAG -- python3 bench.py --steps 32 --warmup 4 --no-cpu-baseline --no-live-traffic > $O/pmc_write_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$TAG -- python3 bench.py --steps 128 --warmup 16 --runs 1 --no-cpu-baseline --no-live-traffic > $O/bench_prof_$TAG.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$TAG -- python3 bench.py --steps 32 --warmup 16 --runs 1 --no-cpu-baseline --no-live-traffic > $O/pmc_fetch_$TAG.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_$TAG -- python3 bench.py --steps 32 --warmup 16 --runs 1 --no-cpu-baseline --no-live-traffic > $O/pmc_write_$TAG.log 2>&1
 python3 scripts/make_traffic.py $O/pmc_fetch_$TAG $O/pmc_write_$TAG $O/traffic_$TAG.json > /dev/null
 # matrix-pipe utilisation as a counter (its own pass, counters only)
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $O/pmc_mfma_$TAG -- python3 bench.py --steps 32 --warmup 4 --no-cpu-baseline --no-live-traffic > $O/pmc_mfma_$TAG.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $O/pmc_mfma_$TAG -- python3 bench.py --steps 32 --warmup 16 --runs 1 --no-cpu-baseline --no-live-traffic > $O/pmc_mfma_$TAG.log 2>&1
 python3 scripts/make_mfma_util.py $O/pmc_mfma_$TAG $O/mfma_util_$TAG.json > /dev/null
 python3 scripts/phase_profile.py 8 4 30 ${TAG}_lunar > $O/phase_${TAG}_lunar.txt 2>&1
 python3 scripts/phase_profile.py 128 6 50 ${TAG}_pong > $O/phase_${TAG}_pong.txt 2>&1
@@ -31,6 +31,15 @@ python3 bench.py --workload breakout > $O/bench_breakout_$TAG.json 2>> $O/bench_
 # two-player games on the device (TicTacToe, reference rules), and the stand-alone tree kernels against the HBM / cache roofs
 python3 bench.py --workload tictactoe --no-cpu-baseline > $O/bench_tictactoe_$TAG.json 2>> $O/bench_$TAG.err
 python3 bench.py --workload tree > $O/bench_tree_$TAG.json 2>> $O/bench_$TAG.err
+# HBM-side traffic of the stand-alone tree kernels (separate counter passes), then the tree line again with it
+(cd /tmp; rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_tree_fetch_$TAG -- python3 $R/bench.py --workload tree --steps 4 --warmup 1 > /dev/null 2>&1
+ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_tree_write_$TAG -- python3 $R/bench.py --workload tree --steps 4 --warmup 1 > /dev/null 2>&1)
+python3 scripts/make_traffic.py $O/pmc_tree_fetch_$TAG $O/pmc_tree_write_$TAG $O/tree_traffic_$TAG.json > /dev/null
+rm -rf $O/pmc_tree_fetch_$TAG $O/pmc_tree_write_$TAG
+# the learner step: one captured hipGraph per update against eager launches
+python3 scripts/learner_graph_speed.py $O/learner_speed_$TAG.json > /dev/null 2>> $O/bench_$TAG.err
+# bench.py --gpus 2 launching its own ranks (two ranks on this one GPU over gloo: the path of the driver's N > 1 runs)
+MZ_BENCH_BACKEND=gloo python3 bench.py --gpus 2 --envs 2048 --no-cpu-baseline > $O/bench_selflaunch_2ranks_1gpu_$TAG.json 2>> $O/bench_$TAG.err
 # the world-size-1 RCCL branch of the bench (process group over nccl, device-side weight broadcasts)
 MZ_BENCH_FORCE_DIST=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29591 bench.py --gpus 1 --no-cpu-baseline > $O/bench_rccl_world1_$TAG.json 2>> $O/bench_$TAG.err
 # host side: ingest thread scaling, the one-replay path of train --ranks 8 with synthetic producers
