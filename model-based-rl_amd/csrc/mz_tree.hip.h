@@ -449,14 +449,8 @@ __device__ __forceinline__ void mz_tree_backup_select_f(const TreeView &t, const
       if constexpr (LT != 0) tm.X[vi] = new_q;       // what the descent normalises (the root's is never read)
     }
     const bool inner = act & (j < len - 1);          // MinMaxStats.update for every node but the root (mcts.py:136-141)
-    // (accumulated, not assigned: a path longer than TL nodes takes a second round of this loop, whose nodes must not
-    // replace the first round's in the lane's running pair -- found by the injected-output test of a 26-node chain,
-    // tests/test_gpu_fused_exact.py: until r04 the first round's values of the lanes busy in the second were lost)
-    double mn_t, mx_t;
-    asm("v_min_f64 %0, %1, %2" : "=v"(mn_t) : "v"(new_q), "v"(mn_c));
-    asm("v_max_f64 %0, %1, %2" : "=v"(mx_t) : "v"(new_q), "v"(mx_c));
-    mn_c = inner ? mn_t : mn_c;
-    mx_c = inner ? mx_t : mx_c;
+    mn_c = inner ? new_q : mn_c;
+    mx_c = inner ? new_q : mx_c;
     if (shortp) s_stage[64 + lane] = inner ? new_q : __builtin_nan("");
   }
   tr.root_n += 1;
@@ -471,6 +465,35 @@ __device__ __forceinline__ void mz_tree_backup_select_f(const TreeView &t, const
     asm("v_min_f64 %0, %1, %2" : "=v"(mn_c) : "v"(n01), "v"(n23));
     asm("v_max_f64 %0, %1, %2" : "=v"(mx_c) : "v"(x01), "v"(x23));
   } else {
+    // A path longer than TL nodes took more than one round above, and a later round's nodes REPLACED the earlier rounds' in
+    // the lanes' (mn_c, mx_c) -- until r04 those nodes were missing from MinMaxStats.update (found by the injected-output test
+    // of a 26-node chain, tests/test_gpu_fused_exact.py; 31-node chains occur in real runs).  Rare, so it is repaired here,
+    // outside the loop every simulation runs (anything added INSIDE it cost 0.3-0.4 % of a move in A/B runs, whatever its
+    // form): every inner node's value is read back (the X cache holds exactly new_q; pool trees recompute it from what was
+    // stored) and accumulated -- min / max are idempotent, the last round's nodes may be seen twice.
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(len > TL) != 0, 0)) {
+      if constexpr (LT == 0) __threadfence_block();      // (the loop's stores to the pool, read back by other lanes of the wave)
+      for (int base = 0; base < len; base += TL) {
+        const int j = base + lane;
+        const int node = s_path[j < len ? len - 1 - j : 0];
+        double x;
+        if constexpr (LT == 0) {
+          const double wq = tm.W[node], dq = (double)tm.N[node], yq = rcptab[tm.N[node]];
+          const double q0 = wq * yq;
+          const double q = __builtin_fma(__builtin_fma(-dq, q0, wq), yq, q0);
+          const double rq = (j == 0) ? (double)reward : (double)tm.R[node];
+          x = two ? rq - g * q : rq + g * q;
+        } else {
+          int vi = node;
+          if constexpr (LT == 2) vi = tm.E[node];
+          x = tm.X[vi];
+        }
+        if (j < len - 1) {
+          mn_c = x < mn_c ? x : mn_c;
+          mx_c = x > mx_c ? x : mx_c;
+        }
+      }
+    }
 #define MZ_MM_STEP(OFF)                                                         \
   {                                                                             \
     const double a_ = mz_xchg_d<OFF>(mn_c), c_ = mz_xchg_d<OFF>(mx_c);         \

@@ -230,9 +230,20 @@ class _MuZeroDynamics(nn.Module):
     the 128-channel convolution), and a constant plane contributes its value times the layer's response to a plane of
     ones: conv(cat(hidden, plane)) = conv_128(hidden) + plane value * conv_1(ones) + bias.  plane_value: [B, 1, 1, 1]."""
     w = self.conv.weight
-    ones = torch.ones((1, 1) + tuple(hidden_state.shape[2:]), dtype=hidden_state.dtype, device=hidden_state.device)
-    response = nn.functional.conv2d(ones, w[:, 128:129].contiguous(), None, 1, 1)
-    y = nn.functional.conv2d(hidden_state, w[:, :128].contiguous(), self.conv.bias, 1, 1)
+    # the plane of ones' response and the 128-channel slice of the kernel depend on the weights only: cached until the
+    # weights are written (load_state_dict / load_flat copy in place: the version counter moves) -- the one-channel
+    # convolution is a MIOpen naive kernel + transposes, ~6 launches per recurrent inference otherwise
+    key = (w._version, w.device, tuple(hidden_state.shape[2:]), hidden_state.dtype)
+    cache = getattr(self, '_mz_plane', None)
+    if cache is None or cache[0] != key or torch.is_grad_enabled():
+      ones = torch.ones((1, 1) + tuple(hidden_state.shape[2:]), dtype=hidden_state.dtype, device=hidden_state.device)
+      response = nn.functional.conv2d(ones, w[:, 128:129].contiguous(), None, 1, 1)
+      w128 = w[:, :128].contiguous()
+      if not torch.is_grad_enabled():
+        self._mz_plane = (key, response, w128)
+    else:
+      response, w128 = cache[1], cache[2]
+    y = nn.functional.conv2d(hidden_state, w128, self.conv.bias, 1, 1)
     return self._tail(torch.addcmul(y, plane_value, response))
 
   def _tail(self, y):
