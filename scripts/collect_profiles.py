@@ -24,8 +24,8 @@ for src, dst in names.items():
     open(os.path.join(P, dst % tag), 'w').write((text[-1] if s.endswith('.json') and text and text[-1].startswith('{') and len(text) > 1 else '\n'.join(text)) + '\n')
     print('->', dst % tag)
 ks = glob.glob(os.path.join(G, 'prof_%s' % tag, '**', '*kernel_stats.csv'), recursive=True)
-if ks:
-  shutil.copy(ks[0], os.path.join(P, '%s_kernel_stats.csv' % tag)); print('->', '%s_kernel_stats.csv' % tag)
+if ks:      # (a tag run twice leaves two: the latest)
+  shutil.copy(max(ks, key=os.path.getmtime), os.path.join(P, '%s_kernel_stats.csv' % tag)); print('->', '%s_kernel_stats.csv' % tag)
 for f in glob.glob(os.path.join(G, 'phase_cycles_%s_*.json' % tag)):
   shutil.copy(f, P); print('->', os.path.basename(f))
 t = os.path.join(G, 'traffic_%s.json' % tag)
