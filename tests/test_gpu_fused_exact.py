@@ -72,6 +72,9 @@ def test_goldens_injected_into_the_fused_kernels(path, variant):
   if lt is not None:
     assert info['lt'] == lt, info
   eng.search()
+  with pytest.raises(RuntimeError, match='inject mode applies to mz_search only'):      # (the self-play loop refuses it loudly)
+    eng.selfplay_reset(4, 1.0)
+    eng.selfplay_steps(1)
   ex = eng.export_tree()
   EX = g['tree_EX'].astype(bool)
   assert np.array_equal(ex['EX'].astype(bool), EX)
