@@ -82,7 +82,7 @@ def main(args):
   both = (bytes_sel + bytes_exb) / ((sel_us + exb_us) * 1e-6) / 1e9
   NN = 1 + (SIMS + 1) * A
   traffic = None
-  tfile = os.path.join(ROOT, 'profiles', 'r04_tree_traffic.json')      # (FETCH_SIZE / WRITE_SIZE passes of this command, builder-run)
+  tfile = os.path.join(ROOT, 'profiles', 'r04_a_tree_traffic.json')      # (FETCH_SIZE / WRITE_SIZE passes of this command, builder-run)
   if os.path.exists(tfile) and B == 4096:
     traffic = json.load(open(tfile))
 
@@ -114,7 +114,7 @@ def main(args):
                               'each (one 16-lane group per tree), %.0f KB of algorithmic traffic per launch in %.1f us; what '
                               'bounds them is the chain of dependent cache round trips and the %.1f us launch floor, not bytes' %
                               (bytes_sel / 1e3, sel_us, 1.5),
-                   'hbm_side_traffic': ({'source': 'profiles/r04_tree_traffic.json: FETCH_SIZE / WRITE_SIZE passes of this command',
+                   'hbm_side_traffic': ({'source': 'profiles/r04_a_tree_traffic.json: FETCH_SIZE / WRITE_SIZE passes of this command',
                                          'k_tree_select_fetched_over_algorithmic': traffic['k_tree_select']['hbm_bytes_per_launch'] / bytes_sel,
                                          'k_tree_expand_backup_fetched_over_algorithmic': traffic['k_tree_expand_backup']['hbm_bytes_per_launch'] / bytes_exb}
                                         if traffic and 'k_tree_select' in traffic else None),
