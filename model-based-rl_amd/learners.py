@@ -306,7 +306,15 @@ class Learner(Logger):
   def load_state(self, state):
     self.run_tag = os.path.join(str(self.run_tag), 'resumed', '{}'.format(state['training_step']))
     self.network.load_state_dict(state['weights'])
+    # the optimiser's state comes from the checkpoint, HOW it steps (capturable / fused / foreach, the learning rate as a
+    # device tensor the captured graph reads) stays this learner's: a checkpoint of an eager learner resumes under a graphed
+    # one and vice versa
+    keep = [{k: g.get(k) for k in ('capturable', 'fused', 'foreach', 'differentiable', 'maximize')} for g in self.optimizer.param_groups]
     self.optimizer.load_state_dict(state['optimizer'])
+    for g, kept in zip(self.optimizer.param_groups, keep):
+      g.update({k: v for k, v in kept.items() if k in g or v is not None})
+      lr = float(g['lr'])
+      g['lr'] = torch.tensor(lr, dtype=torch.float32, device=self.device) if self.use_graph else lr
     _call(self.replay_buffer, 'add_initial_throughput', state['total_frames'], state['total_games'])
     self.throughput['total_frames'] = state['total_frames']
     self.throughput['training_step'] = state['training_step']
@@ -317,8 +325,12 @@ class Learner(Logger):
     thr = _call(self.replay_buffer, 'get_throughput')        # (the reference refreshes these in log_throughput)
     self.throughput['total_games'] = thr['games']
     self.throughput['total_frames'] = max(self.throughput['total_frames'], thr['frames'])
+    self.flush_priorities()
+    opt = self.optimizer.state_dict()
+    for g in opt['param_groups']:               # (a plain float in the file, whatever this learner keeps it in)
+      g['lr'] = float(g['lr'])
     state = {'dirs': self.dirs, 'config': self.config, 'weights': self.network.get_weights(),
-             'optimizer': self.optimizer.state_dict(), 'training_step': self.training_step,
+             'optimizer': opt, 'training_step': self.training_step,
              'total_games': self.throughput['total_games'], 'total_frames': self.throughput['total_frames'],
              'actor_games': _call(self.storage, 'get_stats', 'actor_games')}
     path = path or os.path.join(self.saves_dir, str(self.training_step))

@@ -29,16 +29,19 @@ def publish_initial_weights(config, storage):
   storage.store_weights.remote(net.get_weights(), 0).result()
 
 
-def launch(config, max_moves, selfplay_only=False, learner_steps=None):
+def launch(config, max_moves, selfplay_only=False, learner_steps=None, state=None):
+  """train.launch (train.py:62-78); state: a checkpoint written by Learner.save_state (--load_state, train.py:130-134): the
+  learner resumes weights, optimiser, training step and throughput totals (learners.py:62-70), every actor its weights,
+  training step and game count (actors.py:75-79)"""
   ray.init()
   storage = ray.remote(SharedStorage).remote(config)
   replay = ray.remote(PrioritizedReplay).remote(config)
-  actors = [ray.remote(Actor).remote(k, config, storage, replay) for k in range(config.num_actors)]
+  actors = [ray.remote(Actor).remote(k, config, storage, replay, state) for k in range(config.num_actors)]
   workers = [a.launch.remote(max_moves) for a in actors]
   if selfplay_only:
     publish_initial_weights(config, storage)
   else:
-    learner = ray.remote(Learner).remote(config, storage, replay)
+    learner = ray.remote(Learner).remote(config, storage, replay, state)
     workers.append(learner.launch.remote(learner_steps))
   t0 = time.time()
   ray.get(workers)
@@ -56,7 +59,7 @@ def launch(config, max_moves, selfplay_only=False, learner_steps=None):
   return thr
 
 
-def launch_ranks(config, max_moves, selfplay_only=False, learner_steps=None):
+def launch_ranks(config, max_moves, selfplay_only=False, learner_steps=None, state=None):
   """One process per GPU (this function runs in every rank; see distributed.py for what is exchanged where):
   rank 0 = learner + storage + the one replay + actor 0, rank r = actor r.  train.py:62-78 on ranks instead of Ray."""
   import json
@@ -91,7 +94,7 @@ def launch_ranks(config, max_moves, selfplay_only=False, learner_steps=None):
     if selfplay_only:
       storage.store_weights.remote(probe.get_weights(), 0).result()
     else:
-      learner = ray.remote(Learner).remote(config, storage, replay)
+      learner = ray.remote(Learner).remote(config, storage, replay, state)
       workers.append(learner.launch.remote(learner_steps))
   else:
     ring = D.ShmRing('%s_%d' % (run_id, rank))
@@ -109,7 +112,7 @@ def launch_ranks(config, max_moves, selfplay_only=False, learner_steps=None):
     # collectives, at the cadence the actors' loops enter them (Actor.run_selfplay)
     actor = _CollectiveOnly(rank, config, rstorage, chunk)
   else:
-    actor = Actor(rank, config, rstorage, actor_replay)
+    actor = Actor(rank, config, rstorage, actor_replay, state)
   t0 = time.time()
   actor.launch(max_moves)
   if rank > 0:
@@ -202,6 +205,9 @@ def main(argv=None):
                  help='one process per GPU over torch.distributed: rank 0 = learner + storage + replay + actor 0')
   p.add_argument('--dedicated_learner_rank', action='store_true',
                  help='with --ranks N: rank 0 runs no actor -- its GPU is the learner\'s alone, ranks 1..N-1 play')
+  p.add_argument('--load_state', type=str, default=None,
+                 help='resume from a checkpoint written by Learner.save_state (train.py:130-134): its config is the run\'s config; '
+                      '--training_steps / --max_moves / --runs_dir given here override it')
   args = vars(p.parse_args(argv))
   max_moves, selfplay_only, learner_steps = args.pop('max_moves'), args.pop('selfplay_only'), args.pop('learner_steps')
   ranks = args.pop('ranks')
@@ -209,7 +215,17 @@ def main(argv=None):
     raise SystemExit(_spawn_ranks(ranks, argv))
   if max_moves is not None and max_moves < 0:
     max_moves = None              # run until the learner has reached --training_steps (actors.py:93)
+  load_state = args.pop('load_state')
+  state = None
   cfg = Config(args)
+  if load_state:                    # train.py:130-134: launch(state['config'], date, state=state)
+    state = torch.load(load_state, map_location='cpu', weights_only=False)
+    given = {a.lstrip('-') for a in argv if a.startswith('--')}
+    saved = state['config']
+    for k in ('training_steps', 'runs_dir', 'num_envs', 'stored_before_train', 'save_state_frequency', 'use_gpu_for'):
+      if k in given:
+        setattr(saved, k, getattr(cfg, k))
+    cfg = saved
   cfg.action_space, cfg.obs_space = env_shapes(cfg)
   from .config import obs_are_bytes
   cfg.obs_u8 = obs_are_bytes(cfg)                    # image frames and -ram- observations travel as bytes (records, replay)
@@ -218,8 +234,8 @@ def main(argv=None):
   if cfg.run_tag is None:           # train.py:83-90: a date-stamped run directory (the launcher's start time under --ranks)
     cfg.run_tag = os.environ.get('MZ_RUN_TAG') or time.strftime('%Y-%m-%d_%H-%M-%S')
   if 'RANK' in os.environ and int(os.environ.get('WORLD_SIZE', '1')) >= 1 and ranks:
-    return launch_ranks(cfg, max_moves, selfplay_only, learner_steps)
-  return launch(cfg, max_moves, selfplay_only, learner_steps)
+    return launch_ranks(cfg, max_moves, selfplay_only, learner_steps, state)
+  return launch(cfg, max_moves, selfplay_only, learner_steps, state)
 
 
 if __name__ == '__main__':

@@ -508,6 +508,29 @@ def test_train_driver_with_learner():
   assert abs(lt['replay_ratio'] - lt['updates_per_second'] / lt['frames_per_second']) < 1e-9
 
 
+def test_train_resumes_from_a_checkpoint(tmp_path):
+  """`train --load_state <checkpoint>` (train.py:130-134): the run continues from the learner's checkpoint -- its config, weights,
+  optimiser, training step and frame / game totals (learners.py:62-83), the actors' weights, step and game counts
+  (actors.py:75-79) -- in a run directory `<run>/resumed/<step>` (learners.py:63)."""
+  import glob
+  from model_based_rl_amd import train
+  common = ['--environment', 'LunarLander-v2', '--num_envs', '64', '--num_simulations', '8', '--seed', '3', '--episode_length', '6',
+            '--window_size', '8192', '--stored_before_train', '512', '--batch_size', '32', '--send_weights_frequency', '2',
+            '--save_state_frequency', '4', '--use_gpu_for', 'actors', 'learner', '--runs_dir', str(tmp_path), '--run_tag', 'r']
+  thr = train.main(common + ['--max_moves', '-1', '--training_steps', '4'])
+  ck = glob.glob(os.path.join(str(tmp_path), '**', 'saves', '4'), recursive=True)
+  assert len(ck) == 1 and thr['frames'] >= 512
+  thr2 = train.main(['--load_state', ck[0], '--max_moves', '-1', '--training_steps', '8'])
+  ck2 = glob.glob(os.path.join(str(tmp_path), '**', 'resumed', '4', 'saves', '8'), recursive=True)
+  assert len(ck2) == 1, glob.glob(os.path.join(str(tmp_path), '**', 'saves', '*'), recursive=True)
+  import torch
+  state4 = torch.load(ck[0], map_location='cpu', weights_only=False)
+  state = torch.load(ck2[0], map_location='cpu', weights_only=False)
+  assert state4['training_step'] == 4 and state['training_step'] == 8
+  assert state['total_frames'] > state4['total_frames'] > 0 and state['total_games'] > state4['total_games']      # totals carried over (add_initial_throughput)
+  assert 0 in state['actor_games'] and thr2['learner']['updates_per_second'] > 0 and thr2['games'] > thr['games'] // 2
+
+
 def test_device_records_to_sampled_batch():
   """Device loop -> drain -> native ingest -> PrioritizedReplay.sample_batch: every sampled position is traced back to the
   experience record it came from (observations are unique) and its targets are recomputed from the raw records with
