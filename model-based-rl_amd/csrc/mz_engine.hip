@@ -706,7 +706,7 @@ static int launch_fused_sp(mz_engine *e, int num_simulations, int sims_done, hip
                               (unsigned long long *)nullptr, e->sp, 1, (uint64_t)e->cfg.seed, ra);
       else
         hipLaunchKernelGGL((k_search_fused<15, 1, 16, 2, false, false, true, true>), dim3(e->Bp / MZ_ROWS), dim3(256), dynh, s,
-                           e->nv, e->tv, e->wstream, num_simulations, 0, (unsigned long long *)nullptr, e->sp, 1,
+                           e->nv, e->tv, e->wstream, num_simulations, 0, e->head_prof, e->sp, 1,
                            (uint64_t)e->cfg.seed, ra);
       HIPCHECK(hipGetLastError());
       return 0;
