@@ -282,3 +282,16 @@ def test_benchmarked_launch_replayed_exactly_on_its_logged_outputs(shape, mode):
       f.write('%s %s: %d moves x %d trees identical on logged outputs; %d trees below the 1e-4 margin among them\n' % (shape, mode, nm, B, below))
   eng.sim_io('off')
   eng.close()
+
+
+def test_random_sweep_of_the_dispatch_table():
+  """scripts/fuzz_inject.py: 80 random configurations -- 1..32 actions, 1..62 simulations (search paths of up to 63 nodes: four
+  rounds of the fused backup), tree counts that are not multiples of 16, one / two players, known bounds, init_value_score,
+  illegal root actions, ties, chains; LDS whole / compact / pool placements and k_search_h2 -- every tree identical to the
+  oracle's on the injected outputs."""
+  import subprocess, sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  out = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'fuzz_inject.py'), '80', '3'], capture_output=True, text=True,
+                       timeout=1200, cwd=root)
+  assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-2500:])
+  assert 'configurations identical' in out.stdout.splitlines()[-1] and out.stdout.count('\nok ') + out.stdout.startswith('ok ') >= 70
