@@ -295,3 +295,15 @@ def test_random_sweep_of_the_dispatch_table():
                        timeout=1200, cwd=root)
   assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-2500:])
   assert 'configurations identical' in out.stdout.splitlines()[-1] and out.stdout.count('\nok ') + out.stdout.startswith('ok ') >= 70
+
+
+def test_random_sweep_of_the_selfplay_loop():
+  """scripts/fuzz_selfplay_log.py: 60 random shapes of the device self-play loop (1..32 actions, observations of 1..200 floats /
+  bytes / packed bytes, 2..61 simulations, ragged tree counts, whole-moves launches and kernel-per-phase graphs, LDS and pool
+  trees, exact and split-f16, temperature 1 and 0) -- every move of every tree equals the oracle's tree on its logged outputs."""
+  import subprocess, sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  out = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'fuzz_selfplay_log.py'), '60', '5'], capture_output=True,
+                       text=True, timeout=1200, cwd=root)
+  assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-2500:])
+  assert 'configurations identical' in out.stdout.splitlines()[-1]
