@@ -297,6 +297,39 @@ int mz_soft_ce_forward(const float *logits, const float *target, int positions, 
                        int64_t target_row_stride, float *loss, void *stream);
 int mz_soft_ce_backward(const float *logits, const float *target, const float *grad_loss, int positions, int bs, int bins,
                         int64_t target_pos_stride, int64_t target_row_stride, float *grad_logits, void *stream);
+/* ---- The FCNetwork learner step as six launches (csrc/mz_fcl.hip.h): reference learners.py:164-230 (update_weights: K-step
+ * unroll, categorical targets, soft cross-entropy, gradient hooks 0.5 and 1 / K, importance weights, clip_grad_norm_,
+ * optimizer.step) with networks.py:135-180 (FCNetwork), config.py:27-33,51-68, utils.py:53-60,73-83 (Adam / AdamW,
+ * eps 1.5e-4).  No GEMM library, no autograd tape: forward chain, heads + losses + their backward, backward chain, weight
+ * gradients (deterministic: no atomics), gradient norm, optimiser.  Every pointer below is a DEVICE pointer unless it says
+ * host; nothing synchronises or allocates after mz_fcl_create, so a step can be captured into a graph.
+ * mz_fcl_create: batch (a multiple of 16), unroll steps K (1..7), FCNetwork sizes (actions <= 14, supports <= 64 bins).
+ * mz_fcl_bind: the flat float32 parameter vector (engine.WEIGHT_ORDER = mz_set_weights' order, mz_fcl_num_params
+ *   floats), Adam's exp_avg / exp_avg_sq of the same shape, `nsteps` float32 step counters (torch keeps one per parameter:
+ *   all are incremented, the first is read) and the learning rate as a device float; builds the packed weight copies.
+ * mz_fcl_repack: after anything else wrote the parameter vector (load_state_dict).
+ * mz_fcl_step: obs [batch][obs_dim] (normalised), actions int64 [batch][K], target_rewards / target_values [batch][K + 1],
+ *   target_policies [batch][K + 1][actions], is_weights [batch] (float64 or float32) as replay_buffer.sample_batch returns
+ *   them -> the parameters, optimiser state and step counters updated in place (unless no_update: gradients only),
+ *   new_errors [batch] = inverse_transform(value_0) - target_values[:, 0] (the priority refresh, learners.py:181-182),
+ *   loss_sums float64 [3] += the weighted means of the reward, value and policy losses (learners.py:228-230).
+ * mz_fcl_read_grad: the last step's gradient (after the sum over positions, before clipping) into a HOST buffer; waits. */
+typedef struct mz_fcl mz_fcl;
+int mz_fcl_create(int batch, int unroll_steps, int obs_dim, int action_space, int value_support_min, int value_support_max,
+                  int reward_support_min, int reward_support_max, int no_target_transform, mz_fcl **out);
+int mz_fcl_destroy(mz_fcl *c);
+size_t mz_fcl_num_params(mz_fcl *c);
+int mz_fcl_bind(mz_fcl *c, float *params, float *exp_avg, float *exp_avg_sq, float *steps, int nsteps, const float *lr,
+                void *stream);
+int mz_fcl_repack(mz_fcl *c, void *stream);
+int mz_fcl_step(mz_fcl *c, const float *obs, const int64_t *actions, const float *target_rewards, const float *target_values,
+                const float *target_policies, const void *is_weights, int weights_are_f64, double beta1, double beta2, double eps,
+                double weight_decay, double clip_grad, int adamw, int no_update, float *new_errors, double *loss_sums, void *stream);
+int mz_fcl_read_grad(mz_fcl *c, float *host_out, size_t n);
+/* test hook: tape `which` of the last step into a HOST buffer (0 chain inputs, 1 chain fc1 activations, 2 LayerNorm x-hat, 3 rstd,
+ * 4 hidden states, 5 / 6 chain deltas, 7 head fc1 activations, 8 / 9 head deltas, 10 d loss / d hidden state per head, 11 per-sample
+ * losses; [position][feature][row] each, heads [head][position][feature][row]); host_out null: returns the float count. */
+long long mz_fcl_read_tape(mz_fcl *c, int which, float *host_out, size_t n);
 /* Which kernel mz_search / mz_selfplay_steps launch for this engine right now: out4 [host] = kind (0 the stand-alone
  * kernels, 1 k_search_fused, 2 k_search_h2), LDS placement of the trees (0 node pool, 1 whole trees in LDS, 2 compact in
  * LDS; -1 for kind 0), dynamics-fc1 k-steps of the instantiation, lanes per child group.  For tests: they assert the

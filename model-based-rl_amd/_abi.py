@@ -9,7 +9,7 @@ import subprocess
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 _SO = os.environ.get('MZ_HIP_LIB') or os.path.join(_CSRC, 'libmz_hip.so')      # (MZ_HIP_LIB: A/B runs of two builds on one box)
-_SOURCES = ['mz_engine.hip', 'mz_learner.hip.h', 'mz_inst.hip', 'mz_kernels.inc', 'mz_common.h', 'mz_net.hip.h', 'mz_tree.hip.h', 'mz_rng.h',
+_SOURCES = ['mz_engine.hip', 'mz_learner.hip.h', 'mz_fcl.hip.h', 'mz_fcl_abi.inc', 'mz_inst.hip', 'mz_kernels.inc', 'mz_common.h', 'mz_net.hip.h', 'mz_tree.hip.h', 'mz_rng.h',
             'mz_selfplay.hip.h', 'mz_selfplay_abi.inc', 'mz_fused.hip.h', 'mz_root.hip.h', 'mz_fused_h2.hip.h']
 _lib = None
 
@@ -128,6 +128,14 @@ SIGNATURES = {
     'mz_learner_targets': (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP, _VP]),
     'mz_soft_ce_forward': (_I, [_VP, _VP, _I, _I, _I, C.c_int64, C.c_int64, _VP, _VP]),
     'mz_soft_ce_backward': (_I, [_VP, _VP, _VP, _I, _I, _I, C.c_int64, C.c_int64, _VP, _VP]),
+    'mz_fcl_create': (_I, [_I] * 9 + [C.POINTER(_VP)]),
+    'mz_fcl_destroy': (_I, [_VP]),
+    'mz_fcl_num_params': (_SZ, [_VP]),
+    'mz_fcl_bind': (_I, [_VP, _VP, _VP, _VP, _VP, _I, _VP, _VP]),
+    'mz_fcl_repack': (_I, [_VP, _VP]),
+    'mz_fcl_step': (_I, [_VP] * 7 + [_I, _D, _D, _D, _D, _D, _I, _I, _VP, _VP, _VP]),
+    'mz_fcl_read_grad': (_I, [_VP, _VP, _SZ]),
+    'mz_fcl_read_tape': (C.c_longlong, [_VP, _I, _VP, _SZ]),
     'mz_selfplay_steps': (_I, [_VP, _I, _VP]),
     'mz_selfplay_steps_timed': (_I, [_VP, _I, _VP, _VP]),
     'mz_selfplay_phase_profile': (_I, [_VP, _I, _VP, _VP]),

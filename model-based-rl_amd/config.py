@@ -113,6 +113,9 @@ def build_parser():
     help='graphed learner: keep the BLAS libraries\' default kernel choice instead of PyTorch TunableOp picking the fastest per shape')
   a('--no_hip_learner_ops', action='store_true',
     help='learner targets and categorical losses as PyTorch elementwise kernels instead of the single HIP launches of csrc/mz_learner.hip.h')
+  a('--no_native_learner', action='store_true',
+    help='FCNetwork learner step through PyTorch operators (GEMM library + autograd) instead of the six HIP launches of '
+         'csrc/mz_fcl.hip.h (mz_fcl_step)')
   a('--no_graph_learner', action='store_true',
     help='run the learner step as eager PyTorch launches instead of one captured hipGraph per update (learners.py)')
   a('--learner_log_frequency', type=int, default=100)

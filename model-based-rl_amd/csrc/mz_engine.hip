@@ -26,6 +26,7 @@
 #include "mz_root.hip.h"
 #include "mz_fused_h2.hip.h"
 #include "mz_learner.hip.h"
+#include "mz_fcl.hip.h"
 // the search kernels are compiled in their own translation units, one per shape (mz_inst.hip); here they are launched
 #include "mz_kernels.inc"
 MZ_ALL_FUSED(extern)
@@ -1535,5 +1536,6 @@ int mz_export_tree(mz_engine *e, int32_t *N, double *W, double *P, float *R, int
 }
 
 #include "mz_selfplay_abi.inc"
+#include "mz_fcl_abi.inc"
 
 }  // extern "C"

@@ -1,0 +1,580 @@
+// mz_fcl.hip.h -- the FCNetwork learner step (reference learners.py:164-230, networks.py:135-180, config.py:27-33,51-68,
+// utils.py:53-60) as SIX launches: the whole update -- K-step unroll forward, the three heads' losses, backward, clipping,
+// AdamW -- without a GEMM library or an autograd tape.  The step is ~1.5 GFLOP (batch 256, K = 5): as PyTorch operators it
+// is ~220 kernels of ~4 us of launch floor each; here its shape follows the data dependences instead:
+//
+//   k_fcl_chain_fwd   one workgroup per 16 samples: h_0 = representation(obs), h_p = dynamics(h_{p-1}, a_{p-1}) -- the only
+//                     sequential part -- with the 16 samples as the 16 columns of v_mfma_f32_16x16x4_f32, the weights as
+//                     the A operand (pre-packed in fragment order, streamed from L2), activations in LDS
+//   k_fcl_heads       one workgroup per (16 samples, unroll position, head): value / policy / reward head forward,
+//                     two-hot targets, soft cross-entropy, and the head's backward down to d loss / d hidden state
+//   k_fcl_chain_bwd   one workgroup per 16 samples: the chain backwards (gradient hooks 0.5, LayerNorm, ReLU)
+//   k_fcl_dw          every weight gradient dW = sum_rows delta (x) input as 16 x 64 MFMA strips over the activation /
+//                     delta tapes the three kernels above left in HBM (one strip per wave, one unroll position per strip:
+//                     deterministic, no atomics)
+//   k_fcl_grad        adds the per-position strips up, squares for the global norm
+//   k_fcl_adam        clip_grad_norm_, Adam / AdamW (torch's fused-kernel arithmetic), the new weights into the flat vector
+//                     AND into the packed fragment-order copies the next step's MFMAs read; loss sums
+//
+// Layouts.  "k-step layout" of an LDS activation array: element (feature f, sample n) at ((f >> 2) * 16 + n) * 4 + (f & 3)
+// -- the B operand of k-step s is one conflict-free ds_read_b32 (s * 64 + 4 n + k) and a D fragment is one ds_write_b128.
+// Tapes in HBM: [feature][row] (row = sample, stride R = batch size), so that k_fcl_dw reads 16 rows of a feature as one
+// 16-byte load.  Packed weights P(W; M, K): [ceil(M / 64)][k-steps][64 lanes] f32x4, component i of lane (m16, g4) of
+// k-step s of group tg = W[64 tg + 16 i + m16][4 s + g4]: one 16-byte load feeds four MFMAs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define FCL_NW 8                    // waves per workgroup of the three per-sample-slice kernels
+#define FCL_THREADS (FCL_NW * 64)
+#define FCL_MAXP 8                  // unroll positions K + 1
+#define FCL_LN_EPS 1e-5f
+
+struct FclPack {          // float offsets into the packed buffer; k-steps (even, zero-padded)
+  size_t F1, F2, B2, B1;
+  int ks1, ks2;           // fc1 forward (input features / 4), fc2 backward (output features / 4)
+  int mout, nt;           // fc2 output features, 16-row tiles of them
+};
+
+struct FclView {
+  int bs, K, O, A, KD, Sv, Sr, vmin, rmin, ntt, R, XR, xks;
+  const float *P;           // flat parameters (engine.WEIGHT_ORDER)
+  const float *pk;          // packed copies
+  size_t rep_b1, rep_b2, tr_b1, tr_b2, ln_w, ln_b, hb1[3], hb2[3];      // bias offsets in P (heads: value, policy, reward)
+  FclPack rep, tr, head[3];
+  const float *obs; const int64_t *act; const float *t_rew, *t_val, *t_pol; const void *w; int w_f64;
+  float *xin, *a1c, *xhat, *rstd, *h, *d2c, *d1c;      // chain tapes, [K + 1][...][R]
+  float *a1h, *d2h, *d1h, *dH, *lossb;                 // head tapes, [3][K + 1][...][R]
+  float *lnpart;                                        // [bs / 16][128] LayerNorm weight / bias gradient partials
+  float *new_errors;
+};
+
+__device__ __forceinline__ int fcl_at(int f, int n) { return ((f >> 2) * 16 + n) * 4 + (f & 3); }
+
+__device__ __forceinline__ f32x4 fcl_mfma(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// out[512 x 16] = W[512 x 4 ks] . X[4 ks x 16]: wave w owns the 64 output features [64 w, 64 w + 64) (tiles i = 0..3: rows
+// 64 w + 16 i + 4 g4 + r, column m16).  pk: P(W; 512, 4 ks) with ks + 2 k-steps allocated per group (the prefetch runs one
+// pair ahead).  X in k-step layout.
+__device__ __forceinline__ void fcl_wide(const f32x4 *__restrict__ pk, int ks, const float *X, int w, int lane, f32x4 acc[4]) {
+  const f32x4 *p = pk + (size_t)w * (ks + 2) * 64 + lane;
+  const float *x = X + 4 * (lane & 15) + (lane >> 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 c0 = p[0], c1 = p[64];
+  for (int s = 0; s < ks; s += 2) {
+    const f32x4 n0 = p[(s + 2) * 64], n1 = p[(s + 3) * 64];
+    const float x0 = x[s * 64], x1 = x[(s + 1) * 64];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = fcl_mfma(c0[i], x0, acc[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = fcl_mfma(c1[i], x1, acc[i]);
+    c0 = n0; c1 = n1;
+  }
+}
+
+// partial of out[16 NT x 16] = W[16 NT x 512] . A1[512 x 16] over this wave's 16 k-steps (split-K over the 8 waves);
+// pk: P(W; <= 64, 512), 128 k-steps.  The partials go to red[w][4][64] (f32x4); fcl_reduce adds them up.
+template <int NT>
+__device__ __forceinline__ void fcl_narrow(const f32x4 *__restrict__ pk, const float *A1, f32x4 *red, int w, int lane) {
+  const f32x4 *p = pk + (size_t)(16 * w) * 64 + lane;
+  const float *x = A1 + (16 * w) * 64 + 4 * (lane & 15) + (lane >> 4);
+  f32x4 acc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 c[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) c[s] = p[s * 64];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    const float xs = x[s * 64];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[i] = fcl_mfma(c[s][i], xs, acc[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < NT; ++i) red[(w * 4 + i) * 64 + lane] = acc[i];
+}
+
+__device__ __forceinline__ void fcl_narrow_nt(int nt, const f32x4 *pk, const float *A1, f32x4 *red, int w, int lane) {
+  if (nt == 1) fcl_narrow<1>(pk, A1, red, w, lane);
+  else if (nt == 2) fcl_narrow<2>(pk, A1, red, w, lane);
+  else fcl_narrow<4>(pk, A1, red, w, lane);
+}
+
+// Y (k-step layout, 64 features) = sum of the 8 partials + bias (rows >= mreal: 0).  Call between two barriers.
+__device__ __forceinline__ void fcl_reduce(const f32x4 *red, int nt, const float *bias, int mreal, float *Y, int tid) {
+  if (tid < 256) {
+    const int i = tid >> 6, l = tid & 63;
+    f32x4 y = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (i < nt) {
+#pragma unroll
+      for (int w = 0; w < FCL_NW; ++w) y += red[(w * 4 + i) * 64 + l];
+      const int f0 = 16 * i + 4 * (l >> 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) y[r] = (f0 + r < mreal) ? y[r] + (bias ? bias[f0 + r] : 0.f) : 0.f;
+    }
+    *(f32x4 *)(Y + ((4 * i + (l >> 4)) * 16 + (l & 15)) * 4) = y;
+  }
+}
+
+// LDS of the three slice kernels (floats): X [xks * 64] | A1 [8192] | red [8192] | Y [1024] | S [3 * 1024] | misc [64]
+#define FCL_LDS_FLOATS(xks) ((xks) * 64 + 8192 + 8192 + 1024 + 3 * 1024 + 64)
+
+// Config.scalar_transform + scalar_to_support (config.py:51-68): bin s of the two-hot target of scalar x
+struct FclTwoHot { int lo_i, hi_i; float p_hi; };
+__device__ __forceinline__ FclTwoHot fcl_two_hot(float x, int lo, int S, int ntt) {
+  if (!ntt) x = mzl_scalar_transform(x);
+  x = fminf(fmaxf(x, (float)lo), (float)(lo + S - 1));
+  const float low = floorf(x), high = ceilf(x);
+  FclTwoHot t;
+  t.p_hi = x - low; t.lo_i = (int)low - lo; t.hi_i = (int)high - lo;
+  return t;
+}
+__device__ __forceinline__ float fcl_two_hot_at(const FclTwoHot &t, int s) {
+  float v = (s == t.hi_i) ? t.p_hi : 0.f;
+  if (s == t.lo_i) v = 1.f - t.p_hi;          // (the reference scatters high first, then low: an integral x ends as 1)
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------ chain, forward
+__global__ __launch_bounds__(FCL_THREADS) void k_fcl_chain_fwd(FclView v) {
+  extern __shared__ __attribute__((aligned(16))) float fcl_smem[];
+  float *X = fcl_smem, *A1 = X + v.xks * 64, *redf = A1 + 8192, *Y = redf + 8192, *S = Y + 1024, *misc = S + 3 * 1024;
+  f32x4 *red = (f32x4 *)redf;
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, g4 = lane >> 4, m16 = lane & 15;
+  const int row0 = blockIdx.x * 16, R = v.R;
+  const size_t T64 = (size_t)64 * R, T512 = (size_t)512 * R, TX = (size_t)v.XR * R;
+  // p = 0: the observations (learners.py:171-173)
+  for (int idx = tid; idx < v.xks * 64; idx += FCL_THREADS) {
+    const int f = idx >> 4, n = idx & 15;
+    const float val = f < v.O ? v.obs[(size_t)(row0 + n) * v.O + f] : 0.f;
+    X[fcl_at(f, n)] = val;
+    if (f < v.XR) v.xin[(size_t)f * R + row0 + n] = val;
+  }
+  __syncthreads();
+  for (int p = 0; p <= v.K; ++p) {
+    const FclPack &pk = p == 0 ? v.rep : v.tr;
+    const float *b1 = v.P + (p == 0 ? v.rep_b1 : v.tr_b1), *b2 = v.P + (p == 0 ? v.rep_b2 : v.tr_b2);
+    f32x4 acc[4];
+    fcl_wide((const f32x4 *)(v.pk + pk.F1), pk.ks1, X, w, lane, acc);
+    float *a1t = v.a1c + (size_t)p * T512;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int f0 = 64 * w + 16 * i + 4 * g4;
+      f32x4 a;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        a[r] = fmaxf(acc[i][r] + b1[f0 + r], 0.f);
+        a1t[(size_t)(f0 + r) * R + row0 + m16] = a[r];
+      }
+      *(f32x4 *)(A1 + ((f0 >> 2) * 16 + m16) * 4) = a;
+    }
+    __syncthreads();
+    fcl_narrow<4>((const f32x4 *)(v.pk + pk.F2), A1, red, w, lane);
+    __syncthreads();
+    fcl_reduce(red, 4, b2, MZ_H, Y, tid);
+    __syncthreads();
+    // LayerNorm over the 50 features + ReLU (networks.py:147,165): 32 lanes per sample, features q and q + 32
+    {
+      const int n = tid >> 5, q = tid & 31;
+      const bool two = q + 32 < MZ_H;
+      const float y0 = Y[fcl_at(q, n)], y1 = two ? Y[fcl_at(q + 32, n)] : 0.f;
+      float s = y0 + y1;
+      for (int o = 16; o >= 1; o >>= 1) s += __shfl_xor(s, o, 32);
+      const float mean = s / (float)MZ_H;
+      const float d0 = y0 - mean, d1 = two ? y1 - mean : 0.f;
+      float var = d0 * d0 + d1 * d1;
+      for (int o = 16; o >= 1; o >>= 1) var += __shfl_xor(var, o, 32);
+      const float rstd = 1.0f / sqrtf(var / (float)MZ_H + FCL_LN_EPS);
+      const float xh0 = d0 * rstd, xh1 = d1 * rstd;
+      const float h0 = fmaxf(xh0 * v.P[v.ln_w + q] + v.P[v.ln_b + q], 0.f);
+      const float h1 = two ? fmaxf(xh1 * v.P[v.ln_w + q + 32] + v.P[v.ln_b + q + 32], 0.f) : 0.f;
+      S[q * 16 + n] = xh0; S[(q + 32) * 16 + n] = xh1;
+      if (q == 0) misc[n] = rstd;
+      // the next input: [h | one-hot(action) | 0]  (networks.py:167-174)
+      const int a = p < v.K ? (int)v.act[(size_t)(row0 + n) * v.K + p] : -1;
+      X[fcl_at(q, n)] = h0;
+      X[fcl_at(q + 32, n)] = two ? h1 : ((q + 32 - MZ_H) == a ? 1.f : 0.f);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 64 * 16; idx += FCL_THREADS) {
+      const int f = idx >> 4, n = idx & 15;
+      const float xv = X[fcl_at(f, n)];
+      v.xhat[(size_t)p * T64 + (size_t)f * R + row0 + n] = S[f * 16 + n];
+      v.h[(size_t)p * T64 + (size_t)f * R + row0 + n] = f < MZ_H ? xv : 0.f;
+      if (p < v.K) v.xin[(size_t)(p + 1) * TX + (size_t)f * R + row0 + n] = xv;
+    }
+    if (tid < 16) v.rstd[(size_t)p * R + row0 + tid] = misc[tid];
+    // (X beyond feature 64 still holds observation columns when O > 64: the dynamics' packed k-steps end at 64)
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ heads
+// grid (bs / 16, K + 1, 3): head 0 value (input h_p), 1 policy (h_p), 2 reward (x_p = [h_{p-1} | one-hot], p >= 1)
+__global__ __launch_bounds__(FCL_THREADS) void k_fcl_heads(FclView v) {
+  extern __shared__ __attribute__((aligned(16))) float fcl_smem[];
+  float *X = fcl_smem, *A1 = X + v.xks * 64, *redf = A1 + 8192, *Y = redf + 8192, *S = Y + 1024;
+  f32x4 *red = (f32x4 *)redf;
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, g4 = lane >> 4, m16 = lane & 15;
+  const int row0 = blockIdx.x * 16, p = blockIdx.y, hd = blockIdx.z, R = v.R, K1 = v.K + 1;
+  if (hd == 2 && p == 0) return;
+  const size_t T64 = (size_t)64 * R, T512 = (size_t)512 * R, TX = (size_t)v.XR * R;
+  const FclPack &pk = v.head[hd];
+  const size_t hp = (size_t)hd * K1 + p;
+  const float *src = hd == 2 ? v.xin + (size_t)p * TX : v.h + (size_t)p * T64;
+  for (int idx = tid; idx < 64 * 16; idx += FCL_THREADS) {
+    const int f = idx >> 4, n = idx & 15;
+    X[fcl_at(f, n)] = src[(size_t)f * R + row0 + n];
+  }
+  __syncthreads();
+  const float *b1 = v.P + v.hb1[hd], *b2 = v.P + v.hb2[hd];
+  f32x4 acc[4];
+  fcl_wide((const f32x4 *)(v.pk + pk.F1), pk.ks1, X, w, lane, acc);
+  {
+    float *a1t = v.a1h + hp * T512;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int f0 = 64 * w + 16 * i + 4 * g4;
+      f32x4 a;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        a[r] = fmaxf(acc[i][r] + b1[f0 + r], 0.f);
+        a1t[(size_t)(f0 + r) * R + row0 + m16] = a[r];
+      }
+      *(f32x4 *)(A1 + ((f0 >> 2) * 16 + m16) * 4) = a;
+    }
+  }
+  __syncthreads();
+  fcl_narrow_nt(pk.nt, (const f32x4 *)(v.pk + pk.F2), A1, red, w, lane);
+  __syncthreads();
+  fcl_reduce(red, pk.nt, b2, pk.mout, Y, tid);
+  __syncthreads();
+  // soft cross-entropy against the categorical target (utils.py:53-60; learners.py:186-203) and its gradient, 32 lanes per
+  // sample, bins q and q + 32; the gradient of the weighted mean and the 1 / K hook (learners.py:205-212) ride in g
+  {
+    const int n = tid >> 5, q = tid & 31, M = pk.mout, row = row0 + n;
+    const bool in0 = q < M, in1 = q + 32 < M;
+    const float x0 = in0 ? Y[fcl_at(q, n)] : -__builtin_inff(), x1 = in1 ? Y[fcl_at(q + 32, n)] : -__builtin_inff();
+    float t0 = 0.f, t1 = 0.f;
+    if (hd == 1) {
+      const float *tp = v.t_pol + ((size_t)row * K1 + p) * v.A;
+      t0 = in0 ? tp[q] : 0.f; t1 = in1 ? tp[q + 32] : 0.f;
+    } else {
+      const float ts = (hd == 0 ? v.t_val : v.t_rew)[(size_t)row * K1 + p];
+      const FclTwoHot th = fcl_two_hot(ts, hd == 0 ? v.vmin : v.rmin, M, v.ntt);
+      t0 = in0 ? fcl_two_hot_at(th, q) : 0.f; t1 = in1 ? fcl_two_hot_at(th, q + 32) : 0.f;
+    }
+    float mx = fmaxf(x0, x1);
+    for (int o = 16; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 32));
+    const float e0 = in0 ? expf(x0 - mx) : 0.f, e1 = in1 ? expf(x1 - mx) : 0.f;
+    float sum = e0 + e1, tsum = t0 + t1;
+    float ex = e0 * (float)(v.vmin + q) + e1 * (float)(v.vmin + q + 32);
+    for (int o = 16; o >= 1; o >>= 1) { sum += __shfl_xor(sum, o, 32); tsum += __shfl_xor(tsum, o, 32); ex += __shfl_xor(ex, o, 32); }
+    const float lse = mx + logf(sum);
+    float l = (in0 ? -t0 * (x0 - lse) : 0.f) + (in1 ? -t1 * (x1 - lse) : 0.f);
+    for (int o = 16; o >= 1; o >>= 1) l += __shfl_xor(l, o, 32);
+    const double wb = v.w_f64 ? ((const double *)v.w)[row] : (double)((const float *)v.w)[row];
+    const float g = (float)(((1.0 / (double)v.K) / (double)v.bs) * wb);
+    S[fcl_at(q, n)] = in0 ? g * ((e0 / sum) * tsum - t0) : 0.f;
+    S[fcl_at(q + 32, n)] = in1 ? g * ((e1 / sum) * tsum - t1) : 0.f;
+    if (q == 0) {
+      v.lossb[hp * R + row] = l;
+      if (hd == 0 && p == 0) {          // the priority refresh (learners.py:181-182; Config.inverse_transform, config.py:27-33)
+        float xs = ex / sum;
+        if (!v.ntt) {
+          const float sg = (xs > 0.f) ? 1.f : ((xs < 0.f) ? -1.f : 0.f);
+          const float tt = (sqrtf(1.f + 4.f * 0.001f * (fabsf(xs) + 1.f + 0.001f)) - 1.f) / (2.f * 0.001f);
+          xs = sg * (tt * tt - 1.f);
+        }
+        v.new_errors[row] = xs - v.t_val[(size_t)row * K1];
+      }
+    }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < 64 * 16; idx += FCL_THREADS) {
+    const int f = idx >> 4, n = idx & 15;
+    v.d2h[hp * T64 + (size_t)f * R + row0 + n] = S[fcl_at(f, n)];
+  }
+  // backward: d a1 = W2^T d logits, through the ReLU; then d x = W1^T d a1 (its first 50 features: d hidden state)
+  fcl_wide((const f32x4 *)(v.pk + pk.B2), pk.ks2, S, w, lane, acc);
+  {
+    float *d1t = v.d1h + hp * T512;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int f0 = 64 * w + 16 * i + 4 * g4;
+      f32x4 *slot = (f32x4 *)(A1 + ((f0 >> 2) * 16 + m16) * 4);
+      const f32x4 a = *slot;
+      f32x4 d;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        d[r] = a[r] > 0.f ? acc[i][r] : 0.f;
+        d1t[(size_t)(f0 + r) * R + row0 + m16] = d[r];
+      }
+      *slot = d;
+    }
+  }
+  __syncthreads();
+  fcl_narrow<4>((const f32x4 *)(v.pk + pk.B1), A1, red, w, lane);
+  __syncthreads();
+  fcl_reduce(red, 4, nullptr, MZ_H, Y, tid);
+  __syncthreads();
+  for (int idx = tid; idx < 64 * 16; idx += FCL_THREADS) {
+    const int f = idx >> 4, n = idx & 15;
+    v.dH[hp * T64 + (size_t)f * R + row0 + n] = Y[fcl_at(f, n)];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ chain, backward
+__global__ __launch_bounds__(FCL_THREADS) void k_fcl_chain_bwd(FclView v) {
+  extern __shared__ __attribute__((aligned(16))) float fcl_smem[];
+  float *X = fcl_smem, *A1 = X + v.xks * 64, *redf = A1 + 8192, *Y = redf + 8192, *S = Y + 1024;
+  float *GH = S, *HM = S + 1024, *XH = S + 2048;      // [feature][16]
+  float *D2 = X;                                       // d (pre-LayerNorm output), k-step layout (X holds >= 16 k-steps)
+  f32x4 *red = (f32x4 *)redf;
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, g4 = lane >> 4, m16 = lane & 15;
+  const int row0 = blockIdx.x * 16, R = v.R, K1 = v.K + 1;
+  const size_t T64 = (size_t)64 * R, T512 = (size_t)512 * R;
+  float dgam[2] = {0.f, 0.f}, dbet[2] = {0.f, 0.f};
+  for (int idx = tid; idx < 1024; idx += FCL_THREADS) Y[idx] = 0.f;      // d chain of position K + 1: none
+  __syncthreads();
+  for (int p = v.K; p >= 0; --p) {
+    // gradient arriving at h_p: value and policy heads of position p, reward head and transition of position p + 1
+    for (int idx = tid; idx < 64 * 16; idx += FCL_THREADS) {
+      const int f = idx >> 4, n = idx & 15;
+      const size_t o = (size_t)f * R + row0 + n;
+      float g = v.dH[((size_t)0 * K1 + p) * T64 + o] + v.dH[((size_t)1 * K1 + p) * T64 + o];
+      if (p < v.K) g = g + v.dH[((size_t)2 * K1 + p + 1) * T64 + o] + Y[fcl_at(f, n)];
+      if (p >= 1) g *= 0.5f;                                     // hidden_state.register_hook (learners.py:200)
+      GH[idx] = g;
+      HM[idx] = v.h[(size_t)p * T64 + o];
+      XH[idx] = v.xhat[(size_t)p * T64 + o];
+    }
+    __syncthreads();
+    {   // ReLU and LayerNorm backwards, 32 lanes per sample
+      const int n = tid >> 5, q = tid & 31;
+      const bool two = q + 32 < MZ_H;
+      const float rstd = v.rstd[(size_t)p * R + row0 + n];
+      const float gy0 = HM[q * 16 + n] > 0.f ? GH[q * 16 + n] : 0.f;
+      const float gy1 = (two && HM[(q + 32) * 16 + n] > 0.f) ? GH[(q + 32) * 16 + n] : 0.f;
+      const float xh0 = XH[q * 16 + n], xh1 = two ? XH[(q + 32) * 16 + n] : 0.f;
+      dgam[0] += gy0 * xh0; dbet[0] += gy0; dgam[1] += gy1 * xh1; dbet[1] += gy1;
+      const float dx0 = gy0 * v.P[v.ln_w + q], dx1 = two ? gy1 * v.P[v.ln_w + q + 32] : 0.f;
+      float s1 = dx0 + dx1, s2 = dx0 * xh0 + dx1 * xh1;
+      for (int o = 16; o >= 1; o >>= 1) { s1 += __shfl_xor(s1, o, 32); s2 += __shfl_xor(s2, o, 32); }
+      const float inv = 1.f / (float)MZ_H;
+      D2[fcl_at(q, n)] = rstd * (dx0 - s1 * inv - xh0 * (s2 * inv));
+      D2[fcl_at(q + 32, n)] = two ? rstd * (dx1 - s1 * inv - xh1 * (s2 * inv)) : 0.f;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 64 * 16; idx += FCL_THREADS) {
+      const int f = idx >> 4, n = idx & 15;
+      v.d2c[(size_t)p * T64 + (size_t)f * R + row0 + n] = D2[fcl_at(f, n)];
+    }
+    const FclPack &pk = p == 0 ? v.rep : v.tr;
+    const float *a1t = v.a1c + (size_t)p * T512;
+    f32x4 msk[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int f0 = 64 * w + 16 * i + 4 * g4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) msk[i][r] = a1t[(size_t)(f0 + r) * R + row0 + m16];
+    }
+    f32x4 acc[4];
+    fcl_wide((const f32x4 *)(v.pk + pk.B2), pk.ks2, D2, w, lane, acc);
+    {
+      float *d1t = v.d1c + (size_t)p * T512;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int f0 = 64 * w + 16 * i + 4 * g4;
+        f32x4 d;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          d[r] = msk[i][r] > 0.f ? acc[i][r] : 0.f;
+          d1t[(size_t)(f0 + r) * R + row0 + m16] = d[r];
+        }
+        *(f32x4 *)(A1 + ((f0 >> 2) * 16 + m16) * 4) = d;
+      }
+    }
+    __syncthreads();
+    if (p >= 1) {
+      fcl_narrow<4>((const f32x4 *)(v.pk + pk.B1), A1, red, w, lane);
+      __syncthreads();
+      fcl_reduce(red, 4, nullptr, MZ_H, Y, tid);
+      __syncthreads();
+    }
+  }
+  // LayerNorm weight / bias gradients of this workgroup's 16 samples over all positions
+  {
+    const int n = tid >> 5, q = tid & 31;
+    GH[q * 16 + n] = dgam[0]; GH[(q + 32) * 16 + n] = dgam[1];
+    HM[q * 16 + n] = dbet[0]; HM[(q + 32) * 16 + n] = dbet[1];
+  }
+  __syncthreads();
+  if (tid < 128) {
+    const float *src = tid < 64 ? GH + tid * 16 : HM + (tid - 64) * 16;
+    float s = 0.f;
+    for (int n = 0; n < 16; ++n) s += src[n];
+    v.lnpart[(size_t)blockIdx.x * 128 + tid] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradients
+// One wave per job: G[16 x 64] strip of dW = D . X^T over the R rows of one unroll position's tapes
+// (D [M][R] deltas, X [N][R] layer inputs), out rows 16 tm .., out columns 64 ng ..; the bias gradient = row sums of D.
+struct FclJob {
+  size_t d_off, x_off;      // float offsets of the two tapes (feature 0, row 0)
+  size_t w_off, b_off;      // flat offsets of W [M][N] and of its bias (b_off used by the ng == 0 strip)
+  int M, N, tm, ng, slab;
+};
+
+__global__ __launch_bounds__(256) void k_fcl_dw(const FclJob *jobs, int njobs, const float *tapes, float *part, size_t nflat, int R) {
+  const int wj = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wj >= njobs) return;
+  const FclJob j = jobs[wj];
+  const int lane = threadIdx.x & 63, g4 = lane >> 4, m16 = lane & 15;
+  const float *Dp = tapes + j.d_off + (size_t)(16 * j.tm + m16) * R + 4 * g4;
+  const float *Xp = tapes + j.x_off + (size_t)(64 * j.ng + m16) * R + 4 * g4;
+  f32x4 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+  // (k index g4 of k-step jj of chunk c = row 16 c + 4 g4 + jj, in both operands: the sum over rows is order-free)
+  for (int c = 0; c < R; c += 16) {
+    const f32x4 a = *(const f32x4 *)(Dp + c);
+    f32x4 b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b[i] = *(const f32x4 *)(Xp + (size_t)(16 * i) * R + c);
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = fcl_mfma(a[jj], b[i][jj], acc[i]);
+    }
+    bsum += (a[0] + a[1]) + (a[2] + a[3]);
+  }
+  float *out = part + (size_t)j.slab * nflat;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = 64 * j.ng + 16 * i + m16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = 16 * j.tm + 4 * g4 + r;
+      if (m < j.M && n < j.N) out[j.w_off + (size_t)m * j.N + n] = acc[i][r];
+    }
+  }
+  bsum += __shfl_xor(bsum, 16, 64);
+  bsum += __shfl_xor(bsum, 32, 64);
+  if (j.ng == 0 && g4 == 0 && 16 * j.tm + m16 < j.M) out[j.b_off + 16 * j.tm + m16] = bsum;
+}
+
+// ------------------------------------------------------------------------------------------------ gradient, optimiser
+struct FclOpt {
+  double beta1, beta2, eps, wd;
+  float clip;
+  int adamw, no_update;
+};
+
+// grad[i] = sum over the unroll positions' strips (LayerNorm parameters: over the workgroups' partials); per-block sum
+// of squares for clip_grad_norm_
+__global__ __launch_bounds__(256) void k_fcl_grad(const float *part, int nslab, const float *lnpart, int nwg, size_t ln_w,
+                                                  size_t nflat, float *grad, float *bsq) {
+  __shared__ float sh[256];
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  float g = 0.f;
+  if (i < nflat) {
+    if (i >= ln_w && i < ln_w + 2 * MZ_H) {
+      const int k = (int)(i - ln_w), col = k < MZ_H ? k : 64 + (k - MZ_H);
+      for (int wg = 0; wg < nwg; ++wg) g += lnpart[(size_t)wg * 128 + col];
+    } else {
+      for (int q = 0; q < nslab; ++q) g += part[(size_t)q * nflat + i];
+    }
+    grad[i] = g;
+  }
+  sh[threadIdx.x] = g * g;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) bsq[blockIdx.x] = sh[0];
+}
+
+// clip_grad_norm_ (learners.py:217-218), Adam / AdamW with torch's fused-kernel arithmetic (utils.py:73-83: eps 1.5e-4),
+// new weights -> flat vector + the packed copies; block 0 also adds the three weighted loss means up (learners.py:205-207,228-230)
+__global__ __launch_bounds__(256) void k_fcl_adam(float *P, float *pk, const int32_t *posA, const int32_t *posB, const float *grad,
+                                                  const float *bsq, int nblk, float *m, float *vv, float *steps, int nsteps,
+                                                  const float *lr_p, FclOpt o, size_t nflat, const float *lossb, const void *w,
+                                                  int w_f64, int bs, int K1, double *loss_acc) {
+  __shared__ float sh[256];
+  __shared__ double shd[256];
+  float s = 0.f;
+  for (int b = threadIdx.x; b < nblk; b += 256) s += bsq[b];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k >= 1; k >>= 1) {
+    if ((int)threadIdx.x < k) sh[threadIdx.x] += sh[threadIdx.x + k];
+    __syncthreads();
+  }
+  const float norm = sqrtf(sh[0]);
+  float coef = 1.f;
+  if (o.clip > 0.f) coef = fminf(o.clip / (norm + 1e-6f), 1.f);
+  const float step = steps[0] + 1.f;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < nflat && !o.no_update) {
+    // (the hyper-parameters are doubles in torch's fused kernel and the moments' updates are evaluated in double there:
+    // 1 - 0.999 as a float is 4.7e-5 off)
+    const double lr = (double)*lr_p;
+    float g = grad[i] * coef, p = P[i];
+    if (o.wd != 0.0) {
+      if (o.adamw) p = (float)((double)p - lr * o.wd * (double)p);
+      else g = (float)((double)g + (double)p * o.wd);
+    }
+    float ea = m[i], es = vv[i];
+    ea = (float)((double)ea + (1.0 - o.beta1) * ((double)g - (double)ea));            // torch lerp, weight < 0.5
+    es = (float)(o.beta2 * (double)es + (1.0 - o.beta2) * (double)g * (double)g);
+    const float bc1 = (float)(1.0 - pow(o.beta1, (double)step)), bc2 = (float)(1.0 - pow(o.beta2, (double)step));
+    const float step_size = (float)(lr / (double)bc1), bc2s = sqrtf(bc2);
+    const float denom = (float)((double)(sqrtf(es) / bc2s) + o.eps);
+    p -= step_size * ea / denom;
+    m[i] = ea; vv[i] = es; P[i] = p;
+    if (posA[i] >= 0) pk[posA[i]] = p;
+    if (posB[i] >= 0) pk[posB[i]] = p;
+  }
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    for (int hd = 0; hd < 3; ++hd) {
+      double acc = 0.0;
+      for (int b = threadIdx.x; b < bs; b += 256) {
+        float l = 0.f;
+        for (int p = (hd == 2 ? 1 : 0); p < K1; ++p) l += lossb[((size_t)hd * K1 + p) * bs + b];
+        const double wb = w_f64 ? ((const double *)w)[b] : (double)((const float *)w)[b];
+        acc += wb * (double)l;
+      }
+      shd[threadIdx.x] = acc;
+      __syncthreads();
+      for (int k = 128; k >= 1; k >>= 1) {
+        if ((int)threadIdx.x < k) shd[threadIdx.x] += shd[threadIdx.x + k];
+        __syncthreads();
+      }
+      // _loss_dev order: reward, value, policy
+      if (threadIdx.x == 0) loss_acc[hd == 2 ? 0 : (hd == 0 ? 1 : 2)] += shd[0] / (double)bs;
+      __syncthreads();
+    }
+  }
+}
+
+// step counters (torch keeps one per parameter): written by a separate tiny launch AFTER k_fcl_adam has read steps[0]
+__global__ void k_fcl_steps(float *steps, int n) {
+  if ((int)threadIdx.x < n) steps[threadIdx.x] += 1.f;
+}
+
+// packed copies from the flat vector (after a load_state_dict / any write that did not go through k_fcl_adam)
+__global__ __launch_bounds__(256) void k_fcl_repack(const float *P, float *pk, const int32_t *posA, const int32_t *posB, size_t nflat) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nflat) return;
+  const float p = P[i];
+  if (posA[i] >= 0) pk[posA[i]] = p;
+  if (posB[i] >= 0) pk[posB[i]] = p;
+}

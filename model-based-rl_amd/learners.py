@@ -168,6 +168,125 @@ class _SoftCE(torch.autograd.Function):
     return out, None, None, None
 
 
+class _NativeFC(object):
+  """The FCNetwork update as the six HIP launches of csrc/mz_fcl.hip.h (mz_fcl_step, include/mz_engine.h): forward chain,
+  heads + losses + their backward, backward chain, weight gradients, gradient norm, Adam / AdamW -- no GEMM library, no
+  autograd tape, nothing PyTorch launches.  The network's parameters and the optimiser's exp_avg / exp_avg_sq / step
+  tensors become VIEWS of three flat device vectors (engine.WEIGHT_ORDER) the kernels update in place, so state_dicts,
+  checkpoints, get_weights and the PyTorch step itself keep working on the same storage.  The kernels read the weights
+  from packed fragment-order copies they rewrite at every step; a write from PyTorch's side (load_state_dict, the
+  graph capture's restore) is noticed through the parameters' version counters and repacked (sync)."""
+
+  @staticmethod
+  def eligible(learner, host):
+    from .networks import FCNetwork
+    cfg, net = learner.config, learner.network
+    if learner.device.type != 'cuda' or not isinstance(net, FCNetwork) or getattr(cfg, 'no_native_learner', False):
+      return False
+    if getattr(cfg, 'no_support', False) or getattr(cfg, 'optimizer', 'AdamW') not in ('AdamW', 'Adam') or not learner.use_graph:
+      return False
+    g = learner.optimizer.param_groups[0]
+    if len(learner.optimizer.param_groups) != 1 or g.get('amsgrad') or g.get('maximize') or not torch.is_tensor(g['lr']):
+      return False
+    bs, K, A = host['obs'].shape[0], host['act'].shape[1], net.action_space
+    Sv = cfg.value_support_max - cfg.value_support_min + 1
+    Sr = cfg.reward_support_max - cfg.reward_support_min + 1
+    return (bs % 16 == 0 and 1 <= K <= 7 and A <= 14 and Sv <= 64 and Sr <= 64 and host['obs'].ndim == 2 and
+            host['act'].dtype == np.int64 and host['w'].dtype in (np.float64, np.float32) and
+            all(host[k].dtype == np.float32 for k in ('obs', 't_rew', 't_val', 't_pol')))
+
+  def __init__(self, learner, host):
+    import ctypes as C
+    from . import _abi
+    from .engine import WEIGHT_ORDER
+    cfg, net, dev, opt = learner.config, learner.network, learner.device, learner.optimizer
+    self.lib, self.learner, self.dev = _abi.load(), learner, dev
+    self.bs, self.K = host['obs'].shape[0], host['act'].shape[1]
+    self.shape = {k: host[k].shape for k in _GraphedUpdate.ORDER}
+    self.h = C.c_void_p()
+    with torch.cuda.device(dev):
+      _abi.check(self.lib.mz_fcl_create(self.bs, self.K, host['obs'].shape[1], net.action_space, int(cfg.value_support_min),
+                                        int(cfg.value_support_max), int(cfg.reward_support_min), int(cfg.reward_support_max),
+                                        int(bool(cfg.no_target_transform)), C.byref(self.h)), 'mz_fcl_create')
+    named = dict(net.named_parameters())
+    self.params = [named[k] for k in WEIGHT_ORDER]
+    n = sum(p.numel() for p in self.params)
+    assert n == self.lib.mz_fcl_num_params(self.h) and len(self.params) == len(list(net.parameters())), 'FCNetwork parameter layout'
+    self.flat = torch.empty(n, dtype=torch.float32, device=dev)
+    self.m, self.v = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
+    self.steps = torch.zeros(len(self.params), dtype=torch.float32, device=dev)
+    off = 0
+    with torch.no_grad():
+      for i, p in enumerate(self.params):
+        k = p.numel()
+        st = opt.state[p]
+        self.flat[off:off + k].copy_(p.reshape(-1))
+        if 'exp_avg' in st:
+          self.m[off:off + k].copy_(st['exp_avg'].reshape(-1))
+          self.v[off:off + k].copy_(st['exp_avg_sq'].reshape(-1))
+          self.steps[i] = float(st['step'])
+        p.data = self.flat[off:off + k].view(p.shape)
+        st['step'] = self.steps[i]
+        st['exp_avg'] = self.m[off:off + k].view(p.shape)
+        st['exp_avg_sq'] = self.v[off:off + k].view(p.shape)
+        off += k
+    g = opt.param_groups[0]
+    self.lr = g['lr']
+    self.versions = None
+    self.sync(force=True)
+
+  def fits(self, host):
+    return all(host[k].shape == self.shape[k] for k in _GraphedUpdate.ORDER)
+
+  def sync(self, force=False):
+    """the packed weight copies follow the parameters: (re)bind after a write that did not come from mz_fcl_step"""
+    import ctypes as C
+    from . import _abi
+    ver = tuple(p._version for p in self.params)
+    if force or ver != self.versions:
+      ptr = lambda t: C.c_void_p(t.data_ptr())
+      _abi.check(self.lib.mz_fcl_bind(self.h, ptr(self.flat), ptr(self.m), ptr(self.v), ptr(self.steps), len(self.params),
+                                      ptr(self.lr), _stream_ptr(self.flat)), 'mz_fcl_bind')
+      self.versions = ver
+
+  def step(self, obs, act, t_rew, t_val, t_pol, w, no_update=False):
+    import ctypes as C
+    from . import _abi
+    cfg, g = self.learner.config, self.learner.optimizer.param_groups[0]
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    new_errors = torch.empty(self.bs, dtype=torch.float32, device=self.dev)
+    b1, b2 = g['betas']
+    _abi.check(self.lib.mz_fcl_step(self.h, ptr(obs), ptr(act), ptr(t_rew), ptr(t_val), ptr(t_pol), ptr(w), int(w.dtype == torch.float64),
+                                    float(b1), float(b2), float(g['eps']), float(g['weight_decay']), float(getattr(cfg, 'clip_grad', 0) or 0),
+                                    int(isinstance(self.learner.optimizer, torch.optim.AdamW)), int(bool(no_update)), ptr(new_errors),
+                                    ptr(self.learner._loss_dev), _stream_ptr(obs)), 'mz_fcl_step')
+    return new_errors
+
+  def grad(self):
+    """the last step's gradient as {parameter name: tensor} (tests)"""
+    import ctypes as C
+    from . import _abi
+    from .engine import WEIGHT_ORDER
+    out = np.empty(self.flat.numel(), np.float32)
+    _abi.check(self.lib.mz_fcl_read_grad(self.h, out.ctypes.data_as(C.c_void_p), out.size), 'mz_fcl_read_grad')
+    res, off = {}, 0
+    for k, p in zip(WEIGHT_ORDER, self.params):
+      res[k] = torch.from_numpy(out[off:off + p.numel()].reshape(tuple(p.shape)).copy())
+      off += p.numel()
+    return res
+
+  def close(self):
+    if self.h:
+      self.lib.mz_fcl_destroy(self.h)
+      self.h = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:
+      pass
+
+
 class _GraphedUpdate(object):
   """Learner._device_step as one captured graph over static tensors (torch.cuda.CUDAGraph = a hipGraph on ROCm).
   launch(host arrays): one pinned staging buffer -> ONE host-to-device copy -> graph replay -> the new errors back into
@@ -291,6 +410,7 @@ class Learner(Logger):
     # kernels on a CPU learner and with --no_hip_learner_ops
     self.hip_ops = self.device.type == 'cuda' and not getattr(config, 'no_hip_learner_ops', False)
     self._graph = None          # _GraphedUpdate, built from the first batch
+    self._native = None         # _NativeFC (FCNetwork, Adam / AdamW, categorical losses), built from the first batch
     self._pending = None        # (idxs, slot) of the update whose priority refresh has not reached the replay yet
     self.throughput = {'total_frames': 0, 'total_games': 0, 'training_step': 0, 'time': {'ups': 0, 'fps': 0}}
     self.last_throughput = {}
@@ -305,6 +425,9 @@ class Learner(Logger):
   # learners.py:62-70
   def load_state(self, state):
     self.run_tag = os.path.join(str(self.run_tag), 'resumed', '{}'.format(state['training_step']))
+    if getattr(self, '_native', None) is not None:      # (the optimiser's loaded state replaces the flat views: rebuilt at the next update)
+      self._native.close()
+      self._native, self._graph = None, None
     self.network.load_state_dict(state['weights'])
     # the optimiser's state comes from the checkpoint, HOW it steps (capturable / fused / foreach, the learning rate as a
     # device tensor the captured graph reads) stays this learner's: a checkpoint of an eager learner resumes under a graphed
@@ -329,6 +452,8 @@ class Learner(Logger):
     opt = self.optimizer.state_dict()
     for g in opt['param_groups']:               # (a plain float in the file, whatever this learner keeps it in)
       g['lr'] = float(g['lr'])
+    # (views of the native step's flat vectors would each be saved with the whole vector's storage)
+    opt['state'] = {i: {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in st.items()} for i, st in opt['state'].items()}
     state = {'dirs': self.dirs, 'config': self.config, 'weights': self.network.get_weights(),
              'optimizer': opt, 'training_step': self.training_step,
              'total_games': self.throughput['total_games'], 'total_frames': self.throughput['total_frames'],
@@ -431,6 +556,8 @@ class Learner(Logger):
   def _device_step(self, obs, act, t_rew, t_val, t_pol, w):
     cfg = self.config
     from .networks import FCNetwork
+    if self._native is not None:          # the whole update as six HIP launches (csrc/mz_fcl.hip.h)
+      return self._native.step(obs, act, t_rew, t_val, t_pol, w)
     if isinstance(self.network, FCNetwork) and not getattr(cfg, 'unbatched_learner', False):
       new_errors, reward_loss, value_loss, policy_loss = self._device_step_fc(obs, act, t_rew, t_val, t_pol, w)
       return self._finish_step(new_errors, reward_loss, value_loss, policy_loss, w)
@@ -486,7 +613,14 @@ class Learner(Logger):
     if self.use_graph:
       if self._graph is None or not self._graph.fits(host):
         self.flush_priorities()
+        if self._native is not None and not self._native.fits(host):
+          self._native.close()
+          self._native = None
+        if self._native is None and _NativeFC.eligible(self, host):
+          self._native = _NativeFC(self, host)
         self._graph = _GraphedUpdate(self, host)
+      if self._native is not None:
+        self._native.sync()
       slot = self._graph.launch(host)
       self.flush_priorities()                    # the previous batch's, whose copy has had a whole update to arrive
       self._pending = (idxs, slot)
