@@ -328,7 +328,7 @@ int mz_fcl_step(mz_fcl *c, const float *obs, const int64_t *actions, const float
 int mz_fcl_read_grad(mz_fcl *c, float *host_out, size_t n);
 /* test hook: tape `which` of the last step into a HOST buffer (0 chain inputs, 1 chain fc1 activations, 2 LayerNorm x-hat, 3 rstd,
  * 4 hidden states, 5 / 6 chain deltas, 7 head fc1 activations, 8 / 9 head deltas, 10 d loss / d hidden state per head, 11 per-sample
- * losses; [position][feature][row] each, heads [head][position][feature][row]); host_out null: returns the float count. */
+ * losses; [position][row / 16][feature][16 rows] each, heads [head][position]...); host_out null: returns the float count. */
 long long mz_fcl_read_tape(mz_fcl *c, int which, float *host_out, size_t n);
 /* Which kernel mz_search / mz_selfplay_steps launch for this engine right now: out4 [host] = kind (0 the stand-alone
  * kernels, 1 k_search_fused, 2 k_search_h2), LDS placement of the trees (0 node pool, 1 whole trees in LDS, 2 compact in

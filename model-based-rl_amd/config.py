@@ -113,6 +113,9 @@ def build_parser():
     help='graphed learner: keep the BLAS libraries\' default kernel choice instead of PyTorch TunableOp picking the fastest per shape')
   a('--no_hip_learner_ops', action='store_true',
     help='learner targets and categorical losses as PyTorch elementwise kernels instead of the single HIP launches of csrc/mz_learner.hip.h')
+  a('--batches_per_fetch', type=int, default=15,
+    help='reference config.py:173: batches sampled ahead of the updates that consume them; here a background thread keeps '
+         'min(this, 4) batches sampled ahead (1: sample in the learner\'s own thread, just before each update)')
   a('--no_native_learner', action='store_true',
     help='FCNetwork learner step through PyTorch operators (GEMM library + autograd) instead of the six HIP launches of '
          'csrc/mz_fcl.hip.h (mz_fcl_step)')

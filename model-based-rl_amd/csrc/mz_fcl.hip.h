@@ -12,14 +12,14 @@
 //   k_fcl_dw          every weight gradient dW = sum_rows delta (x) input as 16 x 64 MFMA strips over the activation /
 //                     delta tapes the three kernels above left in HBM (one strip per wave, one unroll position per strip:
 //                     deterministic, no atomics)
-//   k_fcl_grad        adds the per-position strips up, squares for the global norm
+//   k_fcl_grad        adds the per-position strips up, squares for the global norm, advances the step counters
 //   k_fcl_adam        clip_grad_norm_, Adam / AdamW (torch's fused-kernel arithmetic), the new weights into the flat vector
 //                     AND into the packed fragment-order copies the next step's MFMAs read; loss sums
 //
 // Layouts.  "k-step layout" of an LDS activation array: element (feature f, sample n) at ((f >> 2) * 16 + n) * 4 + (f & 3)
 // -- the B operand of k-step s is one conflict-free ds_read_b32 (s * 64 + 4 n + k) and a D fragment is one ds_write_b128.
-// Tapes in HBM: [feature][row] (row = sample, stride R = batch size), so that k_fcl_dw reads 16 rows of a feature as one
-// 16-byte load.  Packed weights P(W; M, K): [ceil(M / 64)][k-steps][64 lanes] f32x4, component i of lane (m16, g4) of
+// Tapes in HBM: [position][row chunk of 16][feature][16 rows]: a slice kernel's workgroup owns one contiguous block per
+// position, and k_fcl_dw reads 16 features x 16 rows as ONE contiguous KiB per wave and load.  Packed weights P(W; M, K): [ceil(M / 64)][k-steps][64 lanes] f32x4, component i of lane (m16, g4) of
 // k-step s of group tg = W[64 tg + 16 i + m16][4 s + g4]: one 16-byte load feeds four MFMAs.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -49,52 +49,106 @@ struct FclView {
   float *new_errors;
 };
 
+// workgroup barrier that waits for this wave's LDS traffic only: the tapes are write-only inside a kernel, so a barrier need
+// not wait for the global stores in flight (__syncthreads() would: a microsecond per barrier behind every tape write)
+__device__ __forceinline__ void fcl_bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// tape element (feature f of F, sample n of the 16 of workgroup / row chunk c): [chunk][feature][16]
+__device__ __forceinline__ size_t fcl_tp(int F, int c, int f, int n) { return ((size_t)c * F + f) * 16 + n; }
+
 __device__ __forceinline__ int fcl_at(int f, int n) { return ((f >> 2) * 16 + n) * 4 + (f & 3); }
 
 __device__ __forceinline__ f32x4 fcl_mfma(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// k-steps allocated per 64-row group of a wide pack: whole groups of 8 (fcl_wide requests 8 k-steps at a time)
+#define FCL_KSA(ks) (((ks) + 7) & ~7)
+
 // out[512 x 16] = W[512 x 4 ks] . X[4 ks x 16]: wave w owns the 64 output features [64 w, 64 w + 64) (tiles i = 0..3: rows
-// 64 w + 16 i + 4 g4 + r, column m16).  pk: P(W; 512, 4 ks) with ks + 2 k-steps allocated per group (the prefetch runs one
-// pair ahead).  X in k-step layout.
+// 64 w + 16 i + 4 g4 + r, column m16).  pk: P(W; 512, 4 ks), FCL_KSA(ks) k-steps per group.  X in k-step layout.  The
+// weights stream from L2 GS k-steps per request (GS divides 8), one request ahead of the MFMAs.
+template <int GS>
 __device__ __forceinline__ void fcl_wide(const f32x4 *__restrict__ pk, int ks, const float *X, int w, int lane, f32x4 acc[4]) {
-  const f32x4 *p = pk + (size_t)w * (ks + 2) * 64 + lane;
+  const int ng = (ks + GS - 1) / GS;
+  const f32x4 *p = pk + (size_t)w * FCL_KSA(ks) * 64 + lane;
   const float *x = X + 4 * (lane & 15) + (lane >> 4);
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  f32x4 c0 = p[0], c1 = p[64];
-  for (int s = 0; s < ks; s += 2) {
-    const f32x4 n0 = p[(s + 2) * 64], n1 = p[(s + 3) * 64];
-    const float x0 = x[s * 64], x1 = x[(s + 1) * 64];
+  f32x4 c[GS];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = fcl_mfma(c0[i], x0, acc[i]);
+  for (int j = 0; j < GS; ++j) c[j] = p[j * 64];
+  for (int g = 0; g < ng; ++g) {
+    f32x4 n[GS];
+    if (g + 1 < ng) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = fcl_mfma(c1[i], x1, acc[i]);
-    c0 = n0; c1 = n1;
+      for (int j = 0; j < GS; ++j) n[j] = p[((g + 1) * GS + j) * 64];
+    }
+#pragma unroll
+    for (int j = 0; j < GS; ++j) {
+      if (GS * g + j < ks) {
+        const float xs = x[(GS * g + j) * 64];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = fcl_mfma(c[j][i], xs, acc[i]);
+      }
+    }
+    if (g + 1 < ng) {
+#pragma unroll
+      for (int j = 0; j < GS; ++j) c[j] = n[j];
+    }
   }
+}
+
+// the same product with the wave's KS k-steps of weights resident in registers (the transition's, used at every position)
+template <int KS>
+__device__ __forceinline__ void fcl_wide_res(const f32x4 (&W)[KS], const float *X, int lane, f32x4 acc[4]) {
+  const float *x = X + 4 * (lane & 15) + (lane >> 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const float xs = x[s * 64];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = fcl_mfma(W[s][i], xs, acc[i]);
+  }
+}
+
+template <int KS>
+__device__ __forceinline__ void fcl_load_wide(f32x4 (&W)[KS], const f32x4 *__restrict__ pk, int w, int lane) {
+  const f32x4 *p = pk + (size_t)w * FCL_KSA(KS) * 64 + lane;
+#pragma unroll
+  for (int s = 0; s < KS; ++s) W[s] = p[s * 64];
 }
 
 // partial of out[16 NT x 16] = W[16 NT x 512] . A1[512 x 16] over this wave's 16 k-steps (split-K over the 8 waves);
 // pk: P(W; <= 64, 512), 128 k-steps.  The partials go to red[w][4][64] (f32x4); fcl_reduce adds them up.
-template <int NT>
-__device__ __forceinline__ void fcl_narrow(const f32x4 *__restrict__ pk, const float *A1, f32x4 *red, int w, int lane) {
+__device__ __forceinline__ void fcl_load_narrow(f32x4 (&W)[16], const f32x4 *__restrict__ pk, int w, int lane) {
   const f32x4 *p = pk + (size_t)(16 * w) * 64 + lane;
+#pragma unroll
+  for (int s = 0; s < 16; ++s) W[s] = p[s * 64];
+}
+
+template <int NT>
+__device__ __forceinline__ void fcl_narrow_res(const f32x4 (&W)[16], const float *A1, f32x4 *red, int w, int lane) {
   const float *x = A1 + (16 * w) * 64 + 4 * (lane & 15) + (lane >> 4);
   f32x4 acc[NT];
 #pragma unroll
   for (int i = 0; i < NT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  f32x4 c[16];
-#pragma unroll
-  for (int s = 0; s < 16; ++s) c[s] = p[s * 64];
 #pragma unroll
   for (int s = 0; s < 16; ++s) {
     const float xs = x[s * 64];
 #pragma unroll
-    for (int i = 0; i < NT; ++i) acc[i] = fcl_mfma(c[s][i], xs, acc[i]);
+    for (int i = 0; i < NT; ++i) acc[i] = fcl_mfma(W[s][i], xs, acc[i]);
   }
 #pragma unroll
   for (int i = 0; i < NT; ++i) red[(w * 4 + i) * 64 + lane] = acc[i];
+}
+
+template <int NT>
+__device__ __forceinline__ void fcl_narrow(const f32x4 *__restrict__ pk, const float *A1, f32x4 *red, int w, int lane) {
+  f32x4 c[16];
+  fcl_load_narrow(c, pk, w, lane);
+  fcl_narrow_res<NT>(c, A1, red, w, lane);
 }
 
 __device__ __forceinline__ void fcl_narrow_nt(int nt, const f32x4 *pk, const float *A1, f32x4 *red, int w, int lane) {
@@ -119,8 +173,11 @@ __device__ __forceinline__ void fcl_reduce(const f32x4 *red, int nt, const float
   }
 }
 
-// LDS of the three slice kernels (floats): X [xks * 64] | A1 [8192] | red [8192] | Y [1024] | S [3 * 1024] | misc [64]
-#define FCL_LDS_FLOATS(xks) ((xks) * 64 + 8192 + 8192 + 1024 + 3 * 1024 + 64)
+// LDS of the chain kernels (floats): X [xks * 64] | A1 [8192] | red [8192] | Y [1024] | S [3 * 1024] | misc [64] | PV [1408]
+// (PV: the small parameter vectors -- biases, LayerNorm -- read once per launch);
+// of the heads kernel: X [1024] | A1 [8192] | red [8192] | Y [1024] | S [1024] | PV [576]: two workgroups per CU
+#define FCL_LDS_FLOATS(xks) ((xks) * 64 + 8192 + 8192 + 1024 + 3 * 1024 + 64 + 1408)
+#define FCL_LDS_HEADS (1024 + 8192 + 8192 + 1024 + 1024 + 576)
 
 // Config.scalar_transform + scalar_to_support (config.py:51-68): bin s of the two-hot target of scalar x
 struct FclTwoHot { int lo_i, hi_i; float p_hi; };
@@ -138,48 +195,95 @@ __device__ __forceinline__ float fcl_two_hot_at(const FclTwoHot &t, int s) {
   return v;
 }
 
+// Tape addressing of a D fragment (rows 64 w + 16 i + 4 g4 + r, column = sample m16): a wave-uniform row base (scalar
+// registers) + ONE per-lane offset, so that no per-(i, r) 64-bit address lives in vector registers across the positions
+__device__ __forceinline__ int fcl_lane_off(int lane) { return 64 * (lane >> 4) + (lane & 15); }
+
+// fc1 epilogue: bias (LDS), ReLU, the activations to LDS (k-step layout) and to the tape
+__device__ __forceinline__ void fcl_fc1_out(const f32x4 acc[4], const float *b1, float *A1, float *a1t, int loff, int w, int lane) {
+  const int g4 = lane >> 4, m16 = lane & 15;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int f0 = 64 * w + 16 * i + 4 * g4;
+    const f32x4 b = *(const f32x4 *)(b1 + f0);
+    f32x4 a;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      a[r] = fmaxf(acc[i][r] + b[r], 0.f);
+      (a1t + (64 * w + 16 * i + r) * 16)[loff] = a[r];
+    }
+    *(f32x4 *)(A1 + ((f0 >> 2) * 16 + m16) * 4) = a;
+  }
+}
+
+// d a1 through the ReLU (mask: the activation a > 0), to LDS and to the delta tape
+__device__ __forceinline__ void fcl_mask_out(const f32x4 acc[4], const f32x4 msk[4], float *A1, float *d1t, int loff, int w, int lane) {
+  const int g4 = lane >> 4, m16 = lane & 15;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int f0 = 64 * w + 16 * i + 4 * g4;
+    f32x4 d;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      d[r] = msk[i][r] > 0.f ? acc[i][r] : 0.f;
+      (d1t + (64 * w + 16 * i + r) * 16)[loff] = d[r];
+    }
+    *(f32x4 *)(A1 + ((f0 >> 2) * 16 + m16) * 4) = d;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ chain, forward
+// the compiler's wait-count bookkeeping treats a register whose load was requested before a loop as pending inside the
+// loop and waits at its first use in EVERY iteration -- and a wait for a load also waits for every older store.  Touching
+// the registers once in front of the loop settles them there.
+template <int N>
+__device__ __forceinline__ void fcl_settle(f32x4 (&W)[N]) {
+#pragma unroll
+  for (int s = 0; s < N; ++s) asm volatile("" : "+v"(W[s]));
+}
+
+// KS1: k-steps of the transition's fc1 (50 + actions input features: 14 up to 6 actions, 16 up to 14)
+template <int KS1>
 __global__ __launch_bounds__(FCL_THREADS) void k_fcl_chain_fwd(FclView v) {
   extern __shared__ __attribute__((aligned(16))) float fcl_smem[];
-  float *X = fcl_smem, *A1 = X + v.xks * 64, *redf = A1 + 8192, *Y = redf + 8192, *S = Y + 1024, *misc = S + 3 * 1024;
+  float *X = fcl_smem, *A1 = X + v.xks * 64, *redf = A1 + 8192, *Y = redf + 8192, *S = Y + 1024, *misc = S + 3 * 1024, *PV = misc + 64;
+  float *b1r = PV, *b1t = PV + 512, *b2r = PV + 1024, *b2t = PV + 1088, *lnw = PV + 1152, *lnb = PV + 1216;
+  int *acts = (int *)(PV + 1280);          // [16 samples][8]: the actions of the K transitions
   f32x4 *red = (f32x4 *)redf;
-  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, g4 = lane >> 4, m16 = lane & 15;
-  const int row0 = blockIdx.x * 16, R = v.R;
+  const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int row0 = blockIdx.x * 16, R = v.R, loff = fcl_lane_off(lane), cb = blockIdx.x;
   const size_t T64 = (size_t)64 * R, T512 = (size_t)512 * R, TX = (size_t)v.XR * R;
+  // the transition's weights stay in registers for positions 1..K (requested now, they arrive under position 0)
+  f32x4 WT1[KS1], WT2[16];
+  fcl_load_wide<KS1>(WT1, (const f32x4 *)(v.pk + v.tr.F1), w, lane);
+  fcl_load_narrow(WT2, (const f32x4 *)(v.pk + v.tr.F2), w, lane);
+  b1r[tid] = v.P[v.rep_b1 + tid]; b1t[tid] = v.P[v.tr_b1 + tid];
+  if (tid < 64) {
+    b2r[tid] = tid < MZ_H ? v.P[v.rep_b2 + tid] : 0.f; b2t[tid] = tid < MZ_H ? v.P[v.tr_b2 + tid] : 0.f;
+    lnw[tid] = tid < MZ_H ? v.P[v.ln_w + tid] : 0.f; lnb[tid] = tid < MZ_H ? v.P[v.ln_b + tid] : 0.f;
+  }
+  if (tid < 128) acts[tid] = (tid & 7) < v.K ? (int)v.act[(size_t)(row0 + (tid >> 3)) * v.K + (tid & 7)] : -1;
   // p = 0: the observations (learners.py:171-173)
   for (int idx = tid; idx < v.xks * 64; idx += FCL_THREADS) {
     const int f = idx >> 4, n = idx & 15;
     const float val = f < v.O ? v.obs[(size_t)(row0 + n) * v.O + f] : 0.f;
     X[fcl_at(f, n)] = val;
-    if (f < v.XR) v.xin[(size_t)f * R + row0 + n] = val;
+    if (f < v.XR) v.xin[fcl_tp(v.XR, cb, f, n)] = val;
   }
-  __syncthreads();
-  for (int p = 0; p <= v.K; ++p) {
-    const FclPack &pk = p == 0 ? v.rep : v.tr;
-    const float *b1 = v.P + (p == 0 ? v.rep_b1 : v.tr_b1), *b2 = v.P + (p == 0 ? v.rep_b2 : v.tr_b2);
-    f32x4 acc[4];
-    fcl_wide((const f32x4 *)(v.pk + pk.F1), pk.ks1, X, w, lane, acc);
-    float *a1t = v.a1c + (size_t)p * T512;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int f0 = 64 * w + 16 * i + 4 * g4;
-      f32x4 a;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        a[r] = fmaxf(acc[i][r] + b1[f0 + r], 0.f);
-        a1t[(size_t)(f0 + r) * R + row0 + m16] = a[r];
-      }
-      *(f32x4 *)(A1 + ((f0 >> 2) * 16 + m16) * 4) = a;
-    }
-    __syncthreads();
-    fcl_narrow<4>((const f32x4 *)(v.pk + pk.F2), A1, red, w, lane);
-    __syncthreads();
+  fcl_bar();
+  // one position: fc1 (done by the caller into acc) -> ReLU -> fc2 -> LayerNorm -> ReLU -> tapes, next input
+  auto rest = [&](int p, const f32x4 (&acc)[4], const f32x4 (&W2)[16], const float *b1, const float *b2) __attribute__((always_inline)) {
+    fcl_fc1_out(acc, b1, A1, v.a1c + (size_t)p * T512 + fcl_tp(512, cb, 0, 0), loff, w, lane);
+    fcl_bar();
+    fcl_narrow_res<4>(W2, A1, red, w, lane);
+    fcl_bar();
     fcl_reduce(red, 4, b2, MZ_H, Y, tid);
-    __syncthreads();
+    fcl_bar();
     // LayerNorm over the 50 features + ReLU (networks.py:147,165): 32 lanes per sample, features q and q + 32
     {
       const int n = tid >> 5, q = tid & 31;
       const bool two = q + 32 < MZ_H;
+      const int act_p = acts[n * 8 + (p < 7 ? p : 7)];
       const float y0 = Y[fcl_at(q, n)], y1 = two ? Y[fcl_at(q + 32, n)] : 0.f;
       float s = y0 + y1;
       for (int o = 16; o >= 1; o >>= 1) s += __shfl_xor(s, o, 32);
@@ -189,37 +293,49 @@ __global__ __launch_bounds__(FCL_THREADS) void k_fcl_chain_fwd(FclView v) {
       for (int o = 16; o >= 1; o >>= 1) var += __shfl_xor(var, o, 32);
       const float rstd = 1.0f / sqrtf(var / (float)MZ_H + FCL_LN_EPS);
       const float xh0 = d0 * rstd, xh1 = d1 * rstd;
-      const float h0 = fmaxf(xh0 * v.P[v.ln_w + q] + v.P[v.ln_b + q], 0.f);
-      const float h1 = two ? fmaxf(xh1 * v.P[v.ln_w + q + 32] + v.P[v.ln_b + q + 32], 0.f) : 0.f;
+      const float h0 = fmaxf(xh0 * lnw[q] + lnb[q], 0.f);
+      const float h1 = two ? fmaxf(xh1 * lnw[q + 32] + lnb[q + 32], 0.f) : 0.f;
       S[q * 16 + n] = xh0; S[(q + 32) * 16 + n] = xh1;
       if (q == 0) misc[n] = rstd;
-      // the next input: [h | one-hot(action) | 0]  (networks.py:167-174)
-      const int a = p < v.K ? (int)v.act[(size_t)(row0 + n) * v.K + p] : -1;
+      // the next input: [h | one-hot(action) | 0]  (networks.py:167-174); past the last transition: no action
       X[fcl_at(q, n)] = h0;
-      X[fcl_at(q + 32, n)] = two ? h1 : ((q + 32 - MZ_H) == a ? 1.f : 0.f);
+      X[fcl_at(q + 32, n)] = two ? h1 : ((p < v.K && (q + 32 - MZ_H) == act_p) ? 1.f : 0.f);
     }
-    __syncthreads();
+    fcl_bar();
     for (int idx = tid; idx < 64 * 16; idx += FCL_THREADS) {
       const int f = idx >> 4, n = idx & 15;
       const float xv = X[fcl_at(f, n)];
-      v.xhat[(size_t)p * T64 + (size_t)f * R + row0 + n] = S[f * 16 + n];
-      v.h[(size_t)p * T64 + (size_t)f * R + row0 + n] = f < MZ_H ? xv : 0.f;
-      if (p < v.K) v.xin[(size_t)(p + 1) * TX + (size_t)f * R + row0 + n] = xv;
+      v.xhat[(size_t)p * T64 + fcl_tp(64, cb, f, n)] = S[f * 16 + n];
+      v.h[(size_t)p * T64 + fcl_tp(64, cb, f, n)] = f < MZ_H ? xv : 0.f;
+      if (p < v.K) v.xin[(size_t)(p + 1) * TX + fcl_tp(v.XR, cb, f, n)] = xv;
     }
     if (tid < 16) v.rstd[(size_t)p * R + row0 + tid] = misc[tid];
-    // (X beyond feature 64 still holds observation columns when O > 64: the dynamics' packed k-steps end at 64)
-    __syncthreads();
+    // (no barrier here: X, S and misc are next written by the NEXT position's LayerNorm phase, three barriers away.
+    //  X beyond feature 64 still holds observation columns when O > 64: the transition's k-steps end at 64)
+  };
+  {   // position 0: the representation, its weights streamed
+    f32x4 acc[4], WR2[16];
+    fcl_load_narrow(WR2, (const f32x4 *)(v.pk + v.rep.F2), w, lane);
+    fcl_wide<2>((const f32x4 *)(v.pk + v.rep.F1), v.rep.ks1, X, w, lane, acc);
+    rest(0, acc, WR2, b1r, b2r);
+  }
+  fcl_settle(WT1);
+  fcl_settle(WT2);
+  for (int p = 1; p <= v.K; ++p) {      // (no global load in here: no wait behind the tape stores)
+    f32x4 acc[4];
+    fcl_wide_res<KS1>(WT1, X, lane, acc);
+    rest(p, acc, WT2, b1t, b2t);
   }
 }
 
 // ------------------------------------------------------------------------------------------------ heads
 // grid (bs / 16, K + 1, 3): head 0 value (input h_p), 1 policy (h_p), 2 reward (x_p = [h_{p-1} | one-hot], p >= 1)
-__global__ __launch_bounds__(FCL_THREADS) void k_fcl_heads(FclView v) {
+__global__ __launch_bounds__(FCL_THREADS, 4) void k_fcl_heads(FclView v) {
   extern __shared__ __attribute__((aligned(16))) float fcl_smem[];
-  float *X = fcl_smem, *A1 = X + v.xks * 64, *redf = A1 + 8192, *Y = redf + 8192, *S = Y + 1024;
+  float *X = fcl_smem, *A1 = X + 1024, *redf = A1 + 8192, *Y = redf + 8192, *S = Y + 1024, *PV = S + 1024;
   f32x4 *red = (f32x4 *)redf;
-  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, g4 = lane >> 4, m16 = lane & 15;
-  const int row0 = blockIdx.x * 16, p = blockIdx.y, hd = blockIdx.z, R = v.R, K1 = v.K + 1;
+  const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, g4 = lane >> 4, m16 = lane & 15;
+  const int row0 = blockIdx.x * 16, p = blockIdx.y, hd = blockIdx.z, R = v.R, K1 = v.K + 1, loff = fcl_lane_off(lane), cb = blockIdx.x;
   if (hd == 2 && p == 0) return;
   const size_t T64 = (size_t)64 * R, T512 = (size_t)512 * R, TX = (size_t)v.XR * R;
   const FclPack &pk = v.head[hd];
@@ -227,43 +343,37 @@ __global__ __launch_bounds__(FCL_THREADS) void k_fcl_heads(FclView v) {
   const float *src = hd == 2 ? v.xin + (size_t)p * TX : v.h + (size_t)p * T64;
   for (int idx = tid; idx < 64 * 16; idx += FCL_THREADS) {
     const int f = idx >> 4, n = idx & 15;
-    X[fcl_at(f, n)] = src[(size_t)f * R + row0 + n];
+    X[fcl_at(f, n)] = src[fcl_tp(hd == 2 ? v.XR : 64, cb, f, n)];
   }
-  __syncthreads();
-  const float *b1 = v.P + v.hb1[hd], *b2 = v.P + v.hb2[hd];
+  PV[tid] = v.P[v.hb1[hd] + tid];
+  if (tid < 64) PV[512 + tid] = tid < pk.mout ? v.P[v.hb2[hd] + tid] : 0.f;
+  // this sample's targets and weight: needed after the two forward layers, requested now
+  const int n_s = tid >> 5, q_s = tid & 31, row_s = row0 + n_s, M = pk.mout;
+  const bool in0 = q_s < M, in1 = q_s + 32 < M;
+  float t0 = 0.f, t1 = 0.f, ts = 0.f;
+  if (hd == 1) {
+    const float *tp = v.t_pol + ((size_t)row_s * K1 + p) * v.A;
+    t0 = in0 ? tp[q_s] : 0.f; t1 = in1 ? tp[q_s + 32] : 0.f;
+  } else {
+    ts = (hd == 0 ? v.t_val : v.t_rew)[(size_t)row_s * K1 + p];
+  }
+  const double wb = v.w_f64 ? ((const double *)v.w)[row_s] : (double)((const float *)v.w)[row_s];
+  const float tv0 = v.t_val[(size_t)row_s * K1];
+  fcl_bar();
   f32x4 acc[4];
-  fcl_wide((const f32x4 *)(v.pk + pk.F1), pk.ks1, X, w, lane, acc);
-  {
-    float *a1t = v.a1h + hp * T512;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int f0 = 64 * w + 16 * i + 4 * g4;
-      f32x4 a;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        a[r] = fmaxf(acc[i][r] + b1[f0 + r], 0.f);
-        a1t[(size_t)(f0 + r) * R + row0 + m16] = a[r];
-      }
-      *(f32x4 *)(A1 + ((f0 >> 2) * 16 + m16) * 4) = a;
-    }
-  }
-  __syncthreads();
+  fcl_wide<4>((const f32x4 *)(v.pk + pk.F1), pk.ks1, X, w, lane, acc);
+  fcl_fc1_out(acc, PV, A1, v.a1h + hp * T512 + fcl_tp(512, cb, 0, 0), loff, w, lane);
+  fcl_bar();
   fcl_narrow_nt(pk.nt, (const f32x4 *)(v.pk + pk.F2), A1, red, w, lane);
-  __syncthreads();
-  fcl_reduce(red, pk.nt, b2, pk.mout, Y, tid);
-  __syncthreads();
+  fcl_bar();
+  fcl_reduce(red, pk.nt, PV + 512, pk.mout, Y, tid);
+  fcl_bar();
   // soft cross-entropy against the categorical target (utils.py:53-60; learners.py:186-203) and its gradient, 32 lanes per
   // sample, bins q and q + 32; the gradient of the weighted mean and the 1 / K hook (learners.py:205-212) ride in g
   {
-    const int n = tid >> 5, q = tid & 31, M = pk.mout, row = row0 + n;
-    const bool in0 = q < M, in1 = q + 32 < M;
+    const int n = n_s, q = q_s, row = row_s;
     const float x0 = in0 ? Y[fcl_at(q, n)] : -__builtin_inff(), x1 = in1 ? Y[fcl_at(q + 32, n)] : -__builtin_inff();
-    float t0 = 0.f, t1 = 0.f;
-    if (hd == 1) {
-      const float *tp = v.t_pol + ((size_t)row * K1 + p) * v.A;
-      t0 = in0 ? tp[q] : 0.f; t1 = in1 ? tp[q + 32] : 0.f;
-    } else {
-      const float ts = (hd == 0 ? v.t_val : v.t_rew)[(size_t)row * K1 + p];
+    if (hd != 1) {
       const FclTwoHot th = fcl_two_hot(ts, hd == 0 ? v.vmin : v.rmin, M, v.ntt);
       t0 = in0 ? fcl_two_hot_at(th, q) : 0.f; t1 = in1 ? fcl_two_hot_at(th, q + 32) : 0.f;
     }
@@ -276,7 +386,6 @@ __global__ __launch_bounds__(FCL_THREADS) void k_fcl_heads(FclView v) {
     const float lse = mx + logf(sum);
     float l = (in0 ? -t0 * (x0 - lse) : 0.f) + (in1 ? -t1 * (x1 - lse) : 0.f);
     for (int o = 16; o >= 1; o >>= 1) l += __shfl_xor(l, o, 32);
-    const double wb = v.w_f64 ? ((const double *)v.w)[row] : (double)((const float *)v.w)[row];
     const float g = (float)(((1.0 / (double)v.K) / (double)v.bs) * wb);
     S[fcl_at(q, n)] = in0 ? g * ((e0 / sum) * tsum - t0) : 0.f;
     S[fcl_at(q + 32, n)] = in1 ? g * ((e1 / sum) * tsum - t1) : 0.f;
@@ -289,121 +398,120 @@ __global__ __launch_bounds__(FCL_THREADS) void k_fcl_heads(FclView v) {
           const float tt = (sqrtf(1.f + 4.f * 0.001f * (fabsf(xs) + 1.f + 0.001f)) - 1.f) / (2.f * 0.001f);
           xs = sg * (tt * tt - 1.f);
         }
-        v.new_errors[row] = xs - v.t_val[(size_t)row * K1];
+        v.new_errors[row] = xs - tv0;
       }
     }
   }
-  __syncthreads();
+  fcl_bar();
   for (int idx = tid; idx < 64 * 16; idx += FCL_THREADS) {
     const int f = idx >> 4, n = idx & 15;
-    v.d2h[hp * T64 + (size_t)f * R + row0 + n] = S[fcl_at(f, n)];
+    v.d2h[hp * T64 + fcl_tp(64, cb, f, n)] = S[fcl_at(f, n)];
   }
   // backward: d a1 = W2^T d logits, through the ReLU; then d x = W1^T d a1 (its first 50 features: d hidden state)
-  fcl_wide((const f32x4 *)(v.pk + pk.B2), pk.ks2, S, w, lane, acc);
+  fcl_wide<4>((const f32x4 *)(v.pk + pk.B2), pk.ks2, S, w, lane, acc);
   {
-    float *d1t = v.d1h + hp * T512;
+    f32x4 msk[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int f0 = 64 * w + 16 * i + 4 * g4;
-      f32x4 *slot = (f32x4 *)(A1 + ((f0 >> 2) * 16 + m16) * 4);
-      const f32x4 a = *slot;
-      f32x4 d;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        d[r] = a[r] > 0.f ? acc[i][r] : 0.f;
-        d1t[(size_t)(f0 + r) * R + row0 + m16] = d[r];
-      }
-      *slot = d;
-    }
+    for (int i = 0; i < 4; ++i) msk[i] = *(const f32x4 *)(A1 + (((64 * w + 16 * i + 4 * g4) >> 2) * 16 + m16) * 4);
+    fcl_mask_out(acc, msk, A1, v.d1h + hp * T512 + fcl_tp(512, cb, 0, 0), loff, w, lane);
   }
-  __syncthreads();
+  fcl_bar();
   fcl_narrow<4>((const f32x4 *)(v.pk + pk.B1), A1, red, w, lane);
-  __syncthreads();
+  fcl_bar();
   fcl_reduce(red, 4, nullptr, MZ_H, Y, tid);
-  __syncthreads();
+  fcl_bar();
   for (int idx = tid; idx < 64 * 16; idx += FCL_THREADS) {
     const int f = idx >> 4, n = idx & 15;
-    v.dH[hp * T64 + (size_t)f * R + row0 + n] = Y[fcl_at(f, n)];
+    v.dH[hp * T64 + fcl_tp(64, cb, f, n)] = Y[fcl_at(f, n)];
   }
 }
 
 // ------------------------------------------------------------------------------------------------ chain, backward
 __global__ __launch_bounds__(FCL_THREADS) void k_fcl_chain_bwd(FclView v) {
   extern __shared__ __attribute__((aligned(16))) float fcl_smem[];
-  float *X = fcl_smem, *A1 = X + v.xks * 64, *redf = A1 + 8192, *Y = redf + 8192, *S = Y + 1024;
+  float *X = fcl_smem, *A1 = X + v.xks * 64, *redf = A1 + 8192, *Y = redf + 8192, *S = Y + 1024, *PV = S + 3 * 1024 + 64;
   float *GH = S, *HM = S + 1024, *XH = S + 2048;      // [feature][16]
   float *D2 = X;                                       // d (pre-LayerNorm output), k-step layout (X holds >= 16 k-steps)
+  float *lnw = PV;
   f32x4 *red = (f32x4 *)redf;
-  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, g4 = lane >> 4, m16 = lane & 15;
-  const int row0 = blockIdx.x * 16, R = v.R, K1 = v.K + 1;
+  const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int row0 = blockIdx.x * 16, R = v.R, K1 = v.K + 1, loff = fcl_lane_off(lane), cb = blockIdx.x;
   const size_t T64 = (size_t)64 * R, T512 = (size_t)512 * R;
+  // the transition's transposed weights stay in registers (fc2: 50 output features = 14 k-steps; fc1: its 50 hidden inputs)
+  f32x4 WB2[14], WB1[16];
+  fcl_load_wide<14>(WB2, (const f32x4 *)(v.pk + v.tr.B2), w, lane);
+  fcl_load_narrow(WB1, (const f32x4 *)(v.pk + v.tr.B1), w, lane);
+  if (tid < 64) lnw[tid] = tid < MZ_H ? v.P[v.ln_w + tid] : 0.f;
   float dgam[2] = {0.f, 0.f}, dbet[2] = {0.f, 0.f};
   for (int idx = tid; idx < 1024; idx += FCL_THREADS) Y[idx] = 0.f;      // d chain of position K + 1: none
-  __syncthreads();
+  // the tape values of a position are requested one position ahead: (d value head, d policy head, d reward head of p + 1,
+  // h, x-hat) for this thread's two (feature, sample) entries, and rstd
+  float tv[2][5], trs;
+  auto request = [&](int p) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int idx = tid + k * FCL_THREADS, f = idx >> 4, n = idx & 15;
+      const size_t o = fcl_tp(64, cb, f, n);
+      tv[k][0] = v.dH[((size_t)0 * K1 + p) * T64 + o];
+      tv[k][1] = v.dH[((size_t)1 * K1 + p) * T64 + o];
+      tv[k][2] = p < v.K ? v.dH[((size_t)2 * K1 + p + 1) * T64 + o] : 0.f;
+      tv[k][3] = v.h[(size_t)p * T64 + o];
+      tv[k][4] = v.xhat[(size_t)p * T64 + o];
+    }
+    trs = v.rstd[(size_t)p * R + row0 + (tid >> 5)];
+  };
+  request(v.K);
+  fcl_bar();
   for (int p = v.K; p >= 0; --p) {
     // gradient arriving at h_p: value and policy heads of position p, reward head and transition of position p + 1
-    for (int idx = tid; idx < 64 * 16; idx += FCL_THREADS) {
-      const int f = idx >> 4, n = idx & 15;
-      const size_t o = (size_t)f * R + row0 + n;
-      float g = v.dH[((size_t)0 * K1 + p) * T64 + o] + v.dH[((size_t)1 * K1 + p) * T64 + o];
-      if (p < v.K) g = g + v.dH[((size_t)2 * K1 + p + 1) * T64 + o] + Y[fcl_at(f, n)];
+    const float rstd = trs;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int idx = tid + k * FCL_THREADS, f = idx >> 4, n = idx & 15;
+      float g = tv[k][0] + tv[k][1];
+      if (p < v.K) g = g + tv[k][2] + Y[fcl_at(f, n)];
       if (p >= 1) g *= 0.5f;                                     // hidden_state.register_hook (learners.py:200)
-      GH[idx] = g;
-      HM[idx] = v.h[(size_t)p * T64 + o];
-      XH[idx] = v.xhat[(size_t)p * T64 + o];
+      GH[idx] = g; HM[idx] = tv[k][3]; XH[idx] = tv[k][4];
     }
-    __syncthreads();
+    if (p > 0) request(p - 1);
+    // the ReLU mask of this position's fc1 (its activations on the tape), needed after the fc2-transposed product
+    const float *a1t = v.a1c + (size_t)p * T512 + fcl_tp(512, cb, 0, 0);
+    f32x4 msk[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) msk[i][r] = (a1t + (64 * w + 16 * i + r) * 16)[loff];
+    }
+    fcl_bar();
     {   // ReLU and LayerNorm backwards, 32 lanes per sample
       const int n = tid >> 5, q = tid & 31;
       const bool two = q + 32 < MZ_H;
-      const float rstd = v.rstd[(size_t)p * R + row0 + n];
       const float gy0 = HM[q * 16 + n] > 0.f ? GH[q * 16 + n] : 0.f;
       const float gy1 = (two && HM[(q + 32) * 16 + n] > 0.f) ? GH[(q + 32) * 16 + n] : 0.f;
       const float xh0 = XH[q * 16 + n], xh1 = two ? XH[(q + 32) * 16 + n] : 0.f;
       dgam[0] += gy0 * xh0; dbet[0] += gy0; dgam[1] += gy1 * xh1; dbet[1] += gy1;
-      const float dx0 = gy0 * v.P[v.ln_w + q], dx1 = two ? gy1 * v.P[v.ln_w + q + 32] : 0.f;
+      const float dx0 = gy0 * lnw[q], dx1 = two ? gy1 * lnw[q + 32] : 0.f;
       float s1 = dx0 + dx1, s2 = dx0 * xh0 + dx1 * xh1;
       for (int o = 16; o >= 1; o >>= 1) { s1 += __shfl_xor(s1, o, 32); s2 += __shfl_xor(s2, o, 32); }
       const float inv = 1.f / (float)MZ_H;
       D2[fcl_at(q, n)] = rstd * (dx0 - s1 * inv - xh0 * (s2 * inv));
       D2[fcl_at(q + 32, n)] = two ? rstd * (dx1 - s1 * inv - xh1 * (s2 * inv)) : 0.f;
     }
-    __syncthreads();
+    fcl_bar();
     for (int idx = tid; idx < 64 * 16; idx += FCL_THREADS) {
       const int f = idx >> 4, n = idx & 15;
-      v.d2c[(size_t)p * T64 + (size_t)f * R + row0 + n] = D2[fcl_at(f, n)];
-    }
-    const FclPack &pk = p == 0 ? v.rep : v.tr;
-    const float *a1t = v.a1c + (size_t)p * T512;
-    f32x4 msk[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int f0 = 64 * w + 16 * i + 4 * g4;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) msk[i][r] = a1t[(size_t)(f0 + r) * R + row0 + m16];
+      v.d2c[(size_t)p * T64 + fcl_tp(64, cb, f, n)] = D2[fcl_at(f, n)];
     }
     f32x4 acc[4];
-    fcl_wide((const f32x4 *)(v.pk + pk.B2), pk.ks2, D2, w, lane, acc);
-    {
-      float *d1t = v.d1c + (size_t)p * T512;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int f0 = 64 * w + 16 * i + 4 * g4;
-        f32x4 d;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          d[r] = msk[i][r] > 0.f ? acc[i][r] : 0.f;
-          d1t[(size_t)(f0 + r) * R + row0 + m16] = d[r];
-        }
-        *(f32x4 *)(A1 + ((f0 >> 2) * 16 + m16) * 4) = d;
-      }
-    }
-    __syncthreads();
+    fcl_wide_res<14>(WB2, D2, lane, acc);
+    if (p == 1) fcl_load_wide<14>(WB2, (const f32x4 *)(v.pk + v.rep.B2), w, lane);      // position 0 is the representation's
+    fcl_mask_out(acc, msk, A1, v.d1c + (size_t)p * T512 + fcl_tp(512, cb, 0, 0), loff, w, lane);
+    fcl_bar();
     if (p >= 1) {
-      fcl_narrow<4>((const f32x4 *)(v.pk + pk.B1), A1, red, w, lane);
-      __syncthreads();
+      fcl_narrow_res<4>(WB1, A1, red, w, lane);
+      fcl_bar();
       fcl_reduce(red, 4, nullptr, MZ_H, Y, tid);
-      __syncthreads();
+      fcl_bar();
     }
   }
   // LayerNorm weight / bias gradients of this workgroup's 16 samples over all positions
@@ -412,7 +520,7 @@ __global__ __launch_bounds__(FCL_THREADS) void k_fcl_chain_bwd(FclView v) {
     GH[q * 16 + n] = dgam[0]; GH[(q + 32) * 16 + n] = dgam[1];
     HM[q * 16 + n] = dbet[0]; HM[(q + 32) * 16 + n] = dbet[1];
   }
-  __syncthreads();
+  fcl_bar();
   if (tid < 128) {
     const float *src = tid < 64 ? GH + tid * 16 : HM + (tid - 64) * 16;
     float s = 0.f;
@@ -423,11 +531,12 @@ __global__ __launch_bounds__(FCL_THREADS) void k_fcl_chain_bwd(FclView v) {
 
 // ------------------------------------------------------------------------------------------------ weight gradients
 // One wave per job: G[16 x 64] strip of dW = D . X^T over the R rows of one unroll position's tapes
-// (D [M][R] deltas, X [N][R] layer inputs), out rows 16 tm .., out columns 64 ng ..; the bias gradient = row sums of D.
+// (D: deltas, Mp features per row chunk; X: layer inputs, Np features), out rows 16 tm .., out columns 64 ng ..; the bias
+// gradient = row sums of D.
 struct FclJob {
   size_t d_off, x_off;      // float offsets of the two tapes (feature 0, row 0)
   size_t w_off, b_off;      // flat offsets of W [M][N] and of its bias (b_off used by the ng == 0 strip)
-  int M, N, tm, ng, slab;
+  int M, N, Mp, Np, tm, ng, slab;      // Mp, Np: feature counts of the two tapes (their row-chunk strides / 16)
 };
 
 __global__ __launch_bounds__(256) void k_fcl_dw(const FclJob *jobs, int njobs, const float *tapes, float *part, size_t nflat, int R) {
@@ -435,24 +544,40 @@ __global__ __launch_bounds__(256) void k_fcl_dw(const FclJob *jobs, int njobs, c
   if (wj >= njobs) return;
   const FclJob j = jobs[wj];
   const int lane = threadIdx.x & 63, g4 = lane >> 4, m16 = lane & 15;
-  const float *Dp = tapes + j.d_off + (size_t)(16 * j.tm + m16) * R + 4 * g4;
-  const float *Xp = tapes + j.x_off + (size_t)(64 * j.ng + m16) * R + 4 * g4;
+  // tapes: [row chunk][feature][16 rows] -- 16 features x 16 rows of chunk c are one contiguous KiB
+  const float *Dp = tapes + j.d_off + (size_t)(16 * j.tm + m16) * 16 + 4 * g4;
+  const float *Xp = tapes + j.x_off + (size_t)(64 * j.ng + m16) * 16 + 4 * g4;
+  const size_t dstr = (size_t)j.Mp * 16, xstr = (size_t)j.Np * 16;      // floats per row chunk
   f32x4 acc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
-  // (k index g4 of k-step jj of chunk c = row 16 c + 4 g4 + jj, in both operands: the sum over rows is order-free)
-  for (int c = 0; c < R; c += 16) {
-    const f32x4 a = *(const f32x4 *)(Dp + c);
-    f32x4 b[4];
+  // (k index g4 of k-step jj of chunk c = row 16 c + 4 g4 + jj, in both operands: the sum over rows is order-free.)
+  // There is about one of these waves per SIMD: latency is hidden inside the wave -- the loads of 8 chunks (40 x 16 bytes
+  // per lane) are requested before the first MFMA of the group
+  const int nch = R >> 4;
+  for (int c0 = 0; c0 < nch; c0 += 8) {
+    f32x4 a[8], b[8][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) b[i] = *(const f32x4 *)(Xp + (size_t)(16 * i) * R + c);
+    for (int cc = 0; cc < 8; ++cc) {
+      const int c = c0 + cc;
+      if (c < nch) {
+        a[cc] = *(const f32x4 *)(Dp + c * dstr);
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i] = fcl_mfma(a[jj], b[i][jj], acc[i]);
+        for (int i = 0; i < 4; ++i) b[cc][i] = *(const f32x4 *)(Xp + c * xstr + 256 * i);
+      }
     }
-    bsum += (a[0] + a[1]) + (a[2] + a[3]);
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) {
+      if (c0 + cc < nch) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[i] = fcl_mfma(a[cc][jj], b[cc][i][jj], acc[i]);
+        }
+        bsum += (a[cc][0] + a[cc][1]) + (a[cc][2] + a[cc][3]);
+      }
+    }
   }
   float *out = part + (size_t)j.slab * nflat;
 #pragma unroll
@@ -477,9 +602,9 @@ struct FclOpt {
 };
 
 // grad[i] = sum over the unroll positions' strips (LayerNorm parameters: over the workgroups' partials); per-block sum
-// of squares for clip_grad_norm_
+// of squares for clip_grad_norm_; block 0 also advances the step counters (torch keeps one per parameter)
 __global__ __launch_bounds__(256) void k_fcl_grad(const float *part, int nslab, const float *lnpart, int nwg, size_t ln_w,
-                                                  size_t nflat, float *grad, float *bsq) {
+                                                  size_t nflat, float *grad, float *bsq, float *steps, int nsteps) {
   __shared__ float sh[256];
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   float g = 0.f;
@@ -492,6 +617,7 @@ __global__ __launch_bounds__(256) void k_fcl_grad(const float *part, int nslab, 
     }
     grad[i] = g;
   }
+  if (blockIdx.x == 0 && (int)threadIdx.x < nsteps) steps[threadIdx.x] += 1.f;
   sh[threadIdx.x] = g * g;
   __syncthreads();
   for (int o = 128; o >= 1; o >>= 1) {
@@ -502,48 +628,16 @@ __global__ __launch_bounds__(256) void k_fcl_grad(const float *part, int nslab, 
 }
 
 // clip_grad_norm_ (learners.py:217-218), Adam / AdamW with torch's fused-kernel arithmetic (utils.py:73-83: eps 1.5e-4),
-// new weights -> flat vector + the packed copies; block 0 also adds the three weighted loss means up (learners.py:205-207,228-230)
+// new weights -> flat vector + the packed copies; one more block (the last) adds the three weighted loss means up
+// (learners.py:205-207,228-230).  steps[0] has been advanced by k_fcl_grad.
 __global__ __launch_bounds__(256) void k_fcl_adam(float *P, float *pk, const int32_t *posA, const int32_t *posB, const float *grad,
-                                                  const float *bsq, int nblk, float *m, float *vv, float *steps, int nsteps,
+                                                  const float *bsq, int nblk, float *m, float *vv, const float *steps,
                                                   const float *lr_p, FclOpt o, size_t nflat, const float *lossb, const void *w,
                                                   int w_f64, int bs, int K1, double *loss_acc) {
   __shared__ float sh[256];
   __shared__ double shd[256];
-  float s = 0.f;
-  for (int b = threadIdx.x; b < nblk; b += 256) s += bsq[b];
-  sh[threadIdx.x] = s;
-  __syncthreads();
-  for (int k = 128; k >= 1; k >>= 1) {
-    if ((int)threadIdx.x < k) sh[threadIdx.x] += sh[threadIdx.x + k];
-    __syncthreads();
-  }
-  const float norm = sqrtf(sh[0]);
-  float coef = 1.f;
-  if (o.clip > 0.f) coef = fminf(o.clip / (norm + 1e-6f), 1.f);
-  const float step = steps[0] + 1.f;
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < nflat && !o.no_update) {
-    // (the hyper-parameters are doubles in torch's fused kernel and the moments' updates are evaluated in double there:
-    // 1 - 0.999 as a float is 4.7e-5 off)
-    const double lr = (double)*lr_p;
-    float g = grad[i] * coef, p = P[i];
-    if (o.wd != 0.0) {
-      if (o.adamw) p = (float)((double)p - lr * o.wd * (double)p);
-      else g = (float)((double)g + (double)p * o.wd);
-    }
-    float ea = m[i], es = vv[i];
-    ea = (float)((double)ea + (1.0 - o.beta1) * ((double)g - (double)ea));            // torch lerp, weight < 0.5
-    es = (float)(o.beta2 * (double)es + (1.0 - o.beta2) * (double)g * (double)g);
-    const float bc1 = (float)(1.0 - pow(o.beta1, (double)step)), bc2 = (float)(1.0 - pow(o.beta2, (double)step));
-    const float step_size = (float)(lr / (double)bc1), bc2s = sqrtf(bc2);
-    const float denom = (float)((double)(sqrtf(es) / bc2s) + o.eps);
-    p -= step_size * ea / denom;
-    m[i] = ea; vv[i] = es; P[i] = p;
-    if (posA[i] >= 0) pk[posA[i]] = p;
-    if (posB[i] >= 0) pk[posB[i]] = p;
-  }
-  __syncthreads();
-  if (blockIdx.x == 0) {
+  __shared__ float shc[4];
+  if ((int)blockIdx.x == nblk) {
     for (int hd = 0; hd < 3; ++hd) {
       double acc = 0.0;
       for (int b = threadIdx.x; b < bs; b += 256) {
@@ -562,12 +656,46 @@ __global__ __launch_bounds__(256) void k_fcl_adam(float *P, float *pk, const int
       if (threadIdx.x == 0) loss_acc[hd == 2 ? 0 : (hd == 0 ? 1 : 2)] += shd[0] / (double)bs;
       __syncthreads();
     }
+    return;
   }
-}
-
-// step counters (torch keeps one per parameter): written by a separate tiny launch AFTER k_fcl_adam has read steps[0]
-__global__ void k_fcl_steps(float *steps, int n) {
-  if ((int)threadIdx.x < n) steps[threadIdx.x] += 1.f;
+  if (o.no_update) return;
+  float s = 0.f;
+  for (int b = threadIdx.x; b < nblk; b += 256) s += bsq[b];
+  sh[threadIdx.x] = s;
+  if (threadIdx.x == 0) {
+    const double step = (double)steps[0];
+    shc[0] = (float)(1.0 - pow(o.beta1, step));
+    shc[1] = (float)(1.0 - pow(o.beta2, step));
+  }
+  __syncthreads();
+  for (int k = 128; k >= 1; k >>= 1) {
+    if ((int)threadIdx.x < k) sh[threadIdx.x] += sh[threadIdx.x + k];
+    __syncthreads();
+  }
+  const float norm = sqrtf(sh[0]);
+  float coef = 1.f;
+  if (o.clip > 0.f) coef = fminf(o.clip / (norm + 1e-6f), 1.f);
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < nflat) {
+    // (the hyper-parameters are doubles in torch's fused kernel and the moments' updates are evaluated in double there:
+    // 1 - 0.999 as a float is 4.7e-5 off)
+    const double lr = (double)*lr_p;
+    float g = grad[i] * coef, p = P[i];
+    if (o.wd != 0.0) {
+      if (o.adamw) p = (float)((double)p - lr * o.wd * (double)p);
+      else g = (float)((double)g + (double)p * o.wd);
+    }
+    float ea = m[i], es = vv[i];
+    ea = (float)((double)ea + (1.0 - o.beta1) * ((double)g - (double)ea));            // torch lerp, weight < 0.5
+    es = (float)(o.beta2 * (double)es + (1.0 - o.beta2) * (double)g * (double)g);
+    const float bc1 = shc[0], bc2 = shc[1];
+    const float step_size = (float)(lr / (double)bc1), bc2s = sqrtf(bc2);
+    const float denom = (float)((double)(sqrtf(es) / bc2s) + o.eps);
+    p -= step_size * ea / denom;
+    m[i] = ea; vv[i] = es; P[i] = p;
+    if (posA[i] >= 0) pk[posA[i]] = p;
+    if (posB[i] >= 0) pk[posB[i]] = p;
+  }
 }
 
 // packed copies from the flat vector (after a load_state_dict / any write that did not go through k_fcl_adam)

@@ -464,9 +464,38 @@ int mzr_tree_update(mz_replay *r, const int64_t *idxs, const double *priorities,
   if (!r || !idxs || !priorities) return fail("mzr_tree_update: null argument");
   drain(r);
   const int64_t len = 2 * r->max_capacity - 1;
-  for (int64_t i = 0; i < n; ++i) {
+  for (int64_t i = 0; i < n; ++i)
     if (idxs[i] < 0 || idxs[i] >= len) return fail("mzr_tree_update: index %lld out of range", (long long)idxs[i]);
-    tree_update(r, idxs[i], priorities[i]);
+  if (n < 8) {
+    for (int64_t i = 0; i < n; ++i) tree_update(r, idxs[i], priorities[i]);
+    return 0;
+  }
+  // A batch (the learner's priority refresh, replay_buffer.py:200-203 -> 34-40): every node must receive its `change`
+  // terms in arrival order for the float64 sums to equal the reference's leaf-by-leaf walks -- the order between different
+  // nodes is free.  So: the leaves first, in order (a repeated leaf sees its predecessor's write), then level by level,
+  // every level in arrival order: independent read-modify-writes whose cache misses overlap, instead of n dependent
+  // walks to the root.
+  double *t = r->tree.data();
+  std::vector<double> &chg = r->chg;
+  std::vector<int64_t> node((size_t)n);
+  chg.resize((size_t)n);
+  for (int64_t i = 0; i < n; ++i) __builtin_prefetch(&t[idxs[i]], 1);
+  for (int64_t i = 0; i < n; ++i) {
+    chg[(size_t)i] = priorities[i] - t[idxs[i]];
+    t[idxs[i]] = priorities[i];
+    node[(size_t)i] = idxs[i];
+  }
+  for (bool any = true; any;) {
+    any = false;
+    for (int64_t i = 0; i < n; ++i)
+      if (node[(size_t)i] != 0) __builtin_prefetch(&t[(node[(size_t)i] - 1) / 2], 1);
+    for (int64_t i = 0; i < n; ++i) {
+      int64_t &k = node[(size_t)i];
+      if (k == 0) continue;
+      k = (k - 1) / 2;
+      t[k] += chg[(size_t)i];
+      any = true;
+    }
   }
   return 0;
 }
@@ -675,13 +704,58 @@ int mzr_sample_batch(const mz_replay *r, const double *draws, int bs, float *obs
   if (K + td > 256) return fail("mzr_sample_batch: num_unroll_steps + td_steps too large");
   for (int n = 0; n < K + td; ++n) disc[n] = (float)pow(r->c.discount, (double)n);
   const double disc_td = pow(r->c.discount, (double)td);
-  for (int i = 0; i < bs; ++i) {
-    const int64_t idx = get_leaf(r, draws[i]);                       // replay_buffer.py:142
+  for (int b0 = 0; b0 < bs; b0 += 128) {          // (blocks of 128 samples: what the passes prefetch stays in cache until it is used)
+  const int b1 = b0 + 128 < bs ? b0 + 128 : bs;
+  // The batch is bound by cache misses, not arithmetic (a window of 2e5 frames: a 32 MB tree and rows spread over the
+  // heap): the work is laid out in passes of independent iterations, so that the misses of many samples are in flight at
+  // once.  Pass 1: the bs tree descents (replay_buffer.py:142, SumTree.get_leaf 42-62), eight interleaved level by level
+  // -- the same comparisons and subtractions per draw as get_leaf.
+  {
+    const int64_t len = 2 * r->max_capacity - 1;
+    const double *t = r->tree.data();
+    for (int i0 = b0; i0 < b1; i0 += 8) {
+      const int g = b1 - i0 < 8 ? b1 - i0 : 8;
+      int64_t par[8];
+      double val[8];
+      for (int k = 0; k < g; ++k) { par[k] = 0; val[k] = draws[i0 + k]; }
+      for (bool any = true; any;) {
+        any = false;
+        for (int k = 0; k < g; ++k) {
+          const int64_t left = 2 * par[k] + 1;
+          if (left >= len) continue;
+          const double tl = t[left];
+          const bool go_left = val[k] <= tl;
+          val[k] = go_left ? val[k] : val[k] - tl;
+          par[k] = go_left ? left : left + 1;
+          any = true;
+        }
+      }
+      for (int k = 0; k < g; ++k) idxs[i0 + k] = par[k];
+    }
+  }
+  // pass 2: the leaves' payload pointers; pass 3: the histories' headers; pass 4: the rows the targets will read
+  for (int i = b0; i < b1; ++i) __builtin_prefetch(&r->leaf_hist[(size_t)(idxs[i] - r->max_capacity + 1)]);
+  for (int i = b0; i < b1; ++i) {
+    const Hist *h = r->leaf_hist[(size_t)(idxs[i] - r->max_capacity + 1)];
+    if (h) __builtin_prefetch(h);
+    __builtin_prefetch(&r->leaf_step[(size_t)(idxs[i] - r->max_capacity + 1)]);
+    __builtin_prefetch(&r->tree[(size_t)idxs[i]]);
+  }
+  for (int i = b0; i < b1; ++i) {
+    const int64_t pos = idxs[i] - r->max_capacity + 1;
+    const Hist *h = r->leaf_hist[(size_t)pos];
+    if (!h || !h->payload) continue;
+    const float *p0 = h->rows.data() + ((size_t)h->off + (size_t)r->leaf_step[(size_t)pos]) * R;
+    const int64_t left = h->n - r->leaf_step[(size_t)pos];
+    const int64_t span = (left < K + td + 1 ? left : K + td + 1) * R;      // floats the targets may touch from this step on
+    for (int64_t o = -(int64_t)R; o < span; o += 16) __builtin_prefetch(p0 + (o < 0 ? (r->leaf_step[(size_t)pos] > 0 ? o : 0) : o));
+  }
+  for (int i = b0; i < b1; ++i) {
+    const int64_t idx = idxs[i];
     const int64_t pos = idx - r->max_capacity + 1;
     const Hist *h = r->leaf_hist[(size_t)pos];
     if (!h) return fail("mzr_sample_batch: draw %d hit an empty leaf (buffer smaller than the draw range?)", i);
     const int64_t step = r->leaf_step[(size_t)pos];
-    idxs[i] = idx;
     priorities[i] = r->tree[(size_t)idx];
     if (!h->payload) return fail("mzr_sample_batch: history was ingested without payload");
     const float *rows = h->rows.data() + (size_t)h->off * R;
@@ -725,6 +799,7 @@ int mzr_sample_batch(const mz_replay *r, const double *draws, int bs, float *obs
         target_values[(size_t)i * TL + j] = 0.f;
       }
     }
+  }
   }
   return 0;
 }

@@ -367,6 +367,54 @@ class _GraphedUpdate(object):
     return self.err_host[slot].numpy().copy()
 
 
+class _BatchSource(object):
+  """The learner's side of the replay during learn(): batches sampled `depth` ahead of the updates that consume them and
+  priority refreshes sent without waiting -- the reference's own pattern (learners.py:124-127: `batches_per_fetch`
+  sample_batch.remote() calls in flight; learners.py:182: replay_buffer.update.remote fire-and-forget).  A rayshim / ray
+  handle is used as it is (its worker thread runs the calls in submission order: sampling, refreshes and the actors' ingest
+  never overlap); a plain in-process replay gets a private rayshim handle for the time of the loop, so that its calls run
+  on one thread, outside the learner's.  Batches come as arrays (replay_buffer.sample_batch_arrays) where the replay offers
+  them.  depth <= batches_per_fetch: a batch's priorities are at least as fresh as in the reference."""
+
+  def __init__(self, replay, depth):
+    from collections import deque
+    from . import rayshim
+    self.private = None
+    if not hasattr(getattr(replay, 'sample_batch'), 'remote'):
+      self.private = rayshim._Handle(replay)
+      replay = self.private
+    self.replay, self.depth, self.inflight, self.sent = replay, max(1, int(depth)), deque(), deque()
+    arrays = getattr(getattr(replay, '_obj', None), 'sample_batch_arrays', None) is not None
+    self.method = getattr(replay, 'sample_batch_arrays' if arrays else 'sample_batch')
+
+  def _result(self, fut):
+    return fut.result() if hasattr(fut, 'result') else __import__('ray').get(fut)
+
+  def get(self):
+    while len(self.inflight) < self.depth:
+      self.inflight.append(self.method.remote())
+    batch = self._result(self.inflight.popleft())
+    self.inflight.append(self.method.remote())
+    return batch
+
+  def update(self, idxs, errors):
+    """fire-and-forget, but a refresh that failed is reported at the next one"""
+    while self.sent and (not hasattr(self.sent[0], 'done') or self.sent[0].done()):
+      self._result(self.sent.popleft())
+    self.sent.append(self.replay.update.remote(idxs, errors))
+
+  def close(self):
+    for fut in list(self.inflight) + list(self.sent):      # (the handle's thread finishes what was submitted)
+      try:
+        self._result(fut)
+      except Exception:
+        pass
+    self.inflight.clear(); self.sent.clear()
+    if self.private is not None:
+      self.private._q.put((None, (), {}, None))
+      self.private._t.join(timeout=5)
+
+
 class Learner(Logger):
 
   def __init__(self, config, storage, replay_buffer, state=None):
@@ -411,6 +459,7 @@ class Learner(Logger):
     self.hip_ops = self.device.type == 'cuda' and not getattr(config, 'no_hip_learner_ops', False)
     self._graph = None          # _GraphedUpdate, built from the first batch
     self._native = None         # _NativeFC (FCNetwork, Adam / AdamW, categorical losses), built from the first batch
+    self._source = None         # _BatchSource while learn() runs
     self._pending = None        # (idxs, slot) of the update whose priority refresh has not reached the replay yet
     self.throughput = {'total_frames': 0, 'total_games': 0, 'training_step': 0, 'time': {'ups': 0, 'fps': 0}}
     self.last_throughput = {}
@@ -478,7 +527,13 @@ class Learner(Logger):
     return self._losses
 
   def _host_batch(self, batch):
-    """the batch as the six arrays the step consumes (learners.py:165-180), normalised observations included"""
+    """the batch as the six arrays the step consumes (learners.py:165-180), normalised observations included.  Either the
+    reference's tuple (sample_batch) or the array form (replay_buffer.sample_batch_arrays: no lists to convert)."""
+    if isinstance(batch[0], dict):
+      host, idxs = batch
+      if getattr(self.config, 'norm_obs', False):
+        host = dict(host, obs=np.ascontiguousarray((host['obs'] - self.obs_min) / self.obs_range, np.float32))
+      return host, idxs
     (observations, actions, (target_rewards, target_values, target_policies)), idxs, is_weights = batch
     if getattr(self.config, 'norm_obs', False):
       observations = (observations - self.obs_min) / self.obs_range
@@ -604,7 +659,10 @@ class Learner(Logger):
     if self._pending is not None:
       idxs, slot = self._pending
       self._pending = None
-      _call(self.replay_buffer, 'update', idxs, self._graph.errors(slot))
+      if getattr(self, '_source', None) is not None:
+        self._source.update(idxs, self._graph.errors(slot))
+      else:
+        _call(self.replay_buffer, 'update', idxs, self._graph.errors(slot))
 
   def update_weights(self, batch, defer_priorities=False):
     """One training step (learners.py:164-230).  defer_priorities (learn()'s loop): this batch's new errors go to the replay
@@ -629,7 +687,10 @@ class Learner(Logger):
     else:
       dev = self.device
       new_errors = self._device_step(*[torch.from_numpy(host[k]).to(dev) for k in _GraphedUpdate.ORDER])
-      _call(self.replay_buffer, 'update', idxs, new_errors.detach().cpu().numpy())
+      if self._source is not None:
+        self._source.update(idxs, new_errors.detach().cpu().numpy())
+      else:
+        _call(self.replay_buffer, 'update', idxs, new_errors.detach().cpu().numpy())
     if self.lr_scheduler is not None:             # learners.py:225-226
       self.lr_scheduler.step()
 
@@ -666,8 +727,22 @@ class Learner(Logger):
     from . import gpu_turns
     if self.device.type == 'cuda':
       gpu_turns.register(self.device, 'learner')
+    # batches sampled a few updates ahead, priority refreshes fire-and-forget (_BatchSource; the reference's learners.py:124,182)
+    depth = min(4, int(getattr(cfg, 'batches_per_fetch', 15)))
+    self._source = _BatchSource(self.replay_buffer, depth) if depth > 1 else None
+    try:
+      self._learn_loop(cfg, last, log_every, self._source, gpu_turns)
+      self.flush_priorities()
+    finally:
+      if self._source is not None:
+        self._source.close()
+        self._source = None
+    self.log_throughput(force=True)
+    self.send_weights()
+
+  def _learn_loop(self, cfg, last, log_every, prefetch, gpu_turns):
     while self.training_step < last:
-      batch = _call(self.replay_buffer, 'sample_batch')
+      batch = prefetch.get() if prefetch is not None else _call(self.replay_buffer, 'sample_batch')
       turn = gpu_turns.turn(self.device)
       with turn:         # (an actor on the same GPU: one update per turn, see gpu_turns.py)
         self.update_weights(batch, defer_priorities=True)
@@ -685,9 +760,6 @@ class Learner(Logger):
         self.log_throughput()
         if self.lr_scheduler is not None:
           self.log_scalar(tag='loss/learning_rate', value=self.optimizer.param_groups[0]['lr'], i=self.training_step)      # (what the optimizer really uses, every scheduler)
-    self.flush_priorities()
-    self.log_throughput(force=True)
-    self.send_weights()
 
   def get_last_throughput(self):
     return dict(self.last_throughput)

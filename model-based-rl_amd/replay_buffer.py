@@ -15,7 +15,8 @@ from . import _abi
 
 
 def _p(a):
-  return None if a is None else a.ctypes.data_as(C.c_void_p)
+  """the array's address for a void * parameter (cheaper than ndarray.ctypes.data_as: these calls sit in the sampling loop)"""
+  return None if a is None else C.c_void_p(a.__array_interface__['data'][0])
 
 
 class SumTree(object):
@@ -173,13 +174,24 @@ class PrioritizedReplay(object):
                       'mzr_ingest_records')
 
   # replay_buffer.py:124-163 (+ insert_target 165-198 inside the native call)
-  def sample_batch(self):
+  def sample_batch_arrays(self):
+    """sample_batch as the arrays the learner step consumes, no Python lists in between: (dict obs float32 [bs, ...], act
+    int64 [bs, K], t_rew / t_val float32 [bs, K + 1], t_pol float32 [bs, K + 1, A], w float64 [bs]), idxs int64 [bs].  The
+    same draws as sample_batch (which wraps this): stratified random.uniform segments in the reference's order."""
     bs, K, A, O = self.batch_size, int(self.config.num_unroll_steps), self.action_space, self.obs_dim
     if self.beta < 1:
       self.beta = np.min([1., self.beta + getattr(self.config, 'beta_increment_per_sampling', 0.001)])
     total = self.tree.total_priority
     seg = total / bs
-    draws = np.array([random.uniform(seg * i, seg * (i + 1)) for i in range(bs)], np.float64)
+    # random.uniform(a, b) is a + (b - a) * random.random() (CPython's random.py), and random.random() is two consecutive
+    # 32-bit Mersenne Twister outputs a, b -> ((a >> 5) * 2**26 + (b >> 6)) / 2**53 (_randommodule.c): the bs draws of the
+    # reference's loop (replay_buffer.py:138-140), bit for bit and from the same generator state, out of ONE
+    # getrandbits call (its words come out least significant first) with the arithmetic vectorised
+    words = np.frombuffer(random.getrandbits(64 * bs).to_bytes(8 * bs, 'little'), np.uint32)
+    u = ((words[0::2] >> 5).astype(np.float64) * 67108864.0 + (words[1::2] >> 6).astype(np.float64)) * (1.0 / 9007199254740992.0)
+    i = np.arange(bs, dtype=np.float64)
+    lo, hi = seg * i, seg * (i + 1.0)
+    draws = lo + (hi - lo) * u
     obs = np.zeros((bs,) + tuple(self.config.obs_space), np.float32)
     actions = np.zeros((bs, K), np.int32)
     t_rew = np.zeros((bs, K + 1), np.float32); t_val = np.zeros((bs, K + 1), np.float32)
@@ -187,12 +199,17 @@ class PrioritizedReplay(object):
     idxs = np.zeros(bs, np.int64); pri = np.zeros(bs, np.float64)
     _abi.check_replay(self.lib.mzr_sample_batch(self._h, _p(draws), bs, _p(obs), _p(actions), _p(t_rew), _p(t_val),
                                                 _p(t_pol), _p(idxs), _p(pri)), 'mzr_sample_batch')
-    for i, k in zip(*np.nonzero(actions < 0)):      # replay_buffer.py:150-151, in the reference's draw order
-      actions[i, k] = np.random.randint(A)
+    if (actions < 0).any():
+      for i_, k in zip(*np.nonzero(actions < 0)):      # replay_buffer.py:150-151, in the reference's draw order
+        actions[i_, k] = np.random.randint(A)
     probs = pri / total
     is_weights = np.power(self.tree.num_memories * probs, -self.beta)
     is_weights /= is_weights.max()
-    return (obs, actions.tolist(), (t_rew, t_val, t_pol)), idxs.tolist(), is_weights
+    return {'obs': obs, 'act': actions.astype(np.int64), 't_rew': t_rew, 't_val': t_val, 't_pol': t_pol, 'w': is_weights}, idxs
+
+  def sample_batch(self):
+    b, idxs = self.sample_batch_arrays()
+    return (b['obs'], b['act'].tolist(), (b['t_rew'], b['t_val'], b['t_pol'])), idxs.tolist(), b['w']
 
   # replay_buffer.py:200-203
   def update(self, idxs, errors):

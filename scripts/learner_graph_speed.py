@@ -1,5 +1,6 @@
-"""Learner updates per second on an idle GPU: one captured hipGraph per update (default) against eager PyTorch launches
-(--no_graph_learner), FCNetwork, batch 256, K = 5 (reference learners.py:164-230).  The loop is
+"""Learner updates per second on an idle GPU: the native step (mz_fcl_step: six HIP launches per update, captured in one
+hipGraph; the default) against the PyTorch step captured in one hipGraph (--no_native_learner) and against eager PyTorch
+launches (--no_graph_learner), FCNetwork, batch 256, K = 5 (reference learners.py:164-230).  The loop is
 Learner.learn's: sample_batch from the native replay, update_weights with the priority refresh one update behind.
 usage: learner_graph_speed.py [out.json]"""
 import json, os, sys, time
@@ -27,35 +28,58 @@ def setup(extra):
   return cfg, storage, replay, Learner(cfg, storage, replay)
 
 def loop(learner, replay, n):
+  """Learner._learn_loop's body: batches sampled ahead on the replay's own thread (_BatchSource), priority refreshes
+  fire-and-forget, one update behind"""
+  from model_based_rl_amd.learners import _BatchSource
+  src = _BatchSource(replay, 4) if not os.environ.get('MZ_LS_NO_PREFETCH') else None
+  learner._source = src
   ts = [0.0, 0.0]
   t0 = time.perf_counter()
   for _ in range(n):
-    a = time.perf_counter(); batch = replay.sample_batch(); b = time.perf_counter()
+    a = time.perf_counter(); batch = src.get() if src else replay.sample_batch_arrays(); b = time.perf_counter()
     learner.update_weights(batch, defer_priorities=True); c = time.perf_counter()
     ts[0] += b - a; ts[1] += c - b
   learner.flush_priorities()
   torch.cuda.synchronize()
+  if src: src.close()
+  learner._source = None
   dt = time.perf_counter() - t0
-  return {'updates_per_second': n / dt, 'sample_batch_ms': 1e3 * ts[0] / n, 'update_call_ms': 1e3 * ts[1] / n}
+  return {'updates_per_second': n / dt, 'batch_wait_ms': 1e3 * ts[0] / n, 'update_call_ms': 1e3 * ts[1] / n}
 
-out = {}
-for name, extra in (('graph', []), ('eager', ['--no_graph_learner'])):
-  cfg, storage, replay, learner = setup(extra)
-  loop(learner, replay, 30)
-  res = [loop(learner, replay, 300) for _ in range(3)]
-  out[name] = max(res, key=lambda r: r['updates_per_second'])
-  out[name]['runs_updates_per_second'] = [r['updates_per_second'] for r in res]
-  if name == 'graph':
-    # GPU time of one replay of the graph, on the event clock
-    g = learner._graph
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize(); e0.record()
-    for _ in range(50): g.graph.replay()
-    e1.record(); torch.cuda.synchronize()
-    out[name]['graph_replay_gpu_ms'] = e0.elapsed_time(e1) / 50
-    out[name]['replay_size'] = replay.size()
-out['what'] = 'FCNetwork (LunarLander shapes: obs 8, 4 actions), batch 256, K = 5 unroll, AdamW; idle MI355X; native replay of %d frames' % out['graph']['replay_size']
-out['speedup'] = out['graph']['updates_per_second'] / out['eager']['updates_per_second']
-print(json.dumps(out, indent=1))
-if len(sys.argv) > 1:
-  json.dump(out, open(sys.argv[1], 'w'), indent=1)
+def main():
+  out = {}
+  variants = (('native', []), ('graph', ['--no_native_learner']), ('eager', ['--no_graph_learner']))
+  if os.environ.get('MZ_LS_ONLY'):
+    variants = tuple(v for v in variants if v[0] in os.environ['MZ_LS_ONLY'].split(','))
+  for name, extra in variants:
+    cfg, storage, replay, learner = setup(extra)
+    loop(learner, replay, 30)
+    res = [loop(learner, replay, 1000 if name != 'eager' else 300) for _ in range(3)]
+    t0 = time.perf_counter()
+    for _ in range(200): replay.sample_batch_arrays()
+    sample_ms = (time.perf_counter() - t0) / 200 * 1e3
+    out[name] = max(res, key=lambda r: r['updates_per_second'])
+    out[name]['runs_updates_per_second'] = [r['updates_per_second'] for r in res]
+    out[name]['sample_batch_arrays_ms'] = sample_ms
+    if name in ('graph', 'native'):
+      assert (learner._native is not None) == (name == 'native')
+      # GPU time of one replay of the graph, on the event clock
+      g = learner._graph
+      e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+      torch.cuda.synchronize(); e0.record()
+      for _ in range(50): g.graph.replay()
+      e1.record(); torch.cuda.synchronize()
+      out[name]['graph_replay_gpu_ms'] = e0.elapsed_time(e1) / 50
+      out[name]['replay_size'] = replay.size()
+  first = out[variants[0][0]]
+  out['what'] = 'FCNetwork (LunarLander shapes: obs 8, 4 actions), batch 256, K = 5 unroll, AdamW; idle MI355X; native replay of %d frames' % first.get('replay_size', 0)
+  if 'eager' in out and 'graph' in out:
+    out['speedup_graph_over_eager'] = out['graph']['updates_per_second'] / out['eager']['updates_per_second']
+  if 'native' in out and 'graph' in out:
+    out['speedup_native_over_graph'] = out['native']['updates_per_second'] / out['graph']['updates_per_second']
+  print(json.dumps(out, indent=1))
+  if len(sys.argv) > 1:
+    json.dump(out, open(sys.argv[1], 'w'), indent=1)
+
+if __name__ == '__main__':
+  main()

@@ -59,9 +59,32 @@ def test_tree_matches_oracle_with_growing_capacity():
     p2 = rng.uniform(0.01, 3, size=10)
     a.update(idx, p2); b.update(idx, p2)
     assert a.total_priority == b.total
+  # the learner's refresh: one call with a whole batch of leaves (level-by-level in the native tree), repeated leaves included
+  for n in (8, 64, 256):
+    idx = rng.randint(999, 999 + a.num_memories, size=n)
+    idx[n // 2] = idx[0]; idx[-1] = idx[1]
+    p2 = rng.uniform(0.01, 3, size=n)
+    a.update(idx, p2); b.update(idx, p2)
+    assert a.total_priority == b.total
   assert np.array_equal(a.leaves(1000), b.leaves(1000))
   for v in rng.uniform(0, a.total_priority, 100):
     assert a.get_leaf_index(v) == b.get_leaf(v)
+
+
+def test_vectorised_draws_are_random_uniform():
+  """sample_batch_arrays draws its stratified segments (replay_buffer.py:138-140: random.uniform per segment) out of one
+  getrandbits call: the same doubles, and the generator ends in the same state"""
+  import random
+  for bs, seg in ((1, 0.5), (16, 1.25), (256, 0.37), (2048, 3.0e-3)):
+    random.seed(bs)
+    want = np.array([random.uniform(seg * i, seg * (i + 1)) for i in range(bs)])
+    nxt = random.random()
+    random.seed(bs)
+    words = np.frombuffer(random.getrandbits(64 * bs).to_bytes(8 * bs, 'little'), np.uint32)
+    u = ((words[0::2] >> 5).astype(np.float64) * 67108864.0 + (words[1::2] >> 6).astype(np.float64)) * (1.0 / 9007199254740992.0)
+    i = np.arange(bs, dtype=np.float64)
+    lo, hi = seg * i, seg * (i + 1.0)
+    assert np.array_equal(lo + (hi - lo) * u, want) and random.random() == nxt
 
 
 def python_flush_rules(dones, errors, max_history_length, overlap):
