@@ -303,12 +303,13 @@ int mz_soft_ce_backward(const float *logits, const float *target, const float *g
  * eps 1.5e-4).  No GEMM library, no autograd tape: forward chain, heads + losses + their backward, backward chain, weight
  * gradients (deterministic: no atomics), gradient norm, optimiser.  Every pointer below is a DEVICE pointer unless it says
  * host; nothing synchronises or allocates after mz_fcl_create, so a step can be captured into a graph.
- * mz_fcl_create: batch (a multiple of 16), unroll steps K (1..7), FCNetwork sizes (actions <= 14, supports <= 64 bins).
+ * mz_fcl_create: batch (a multiple of 16), unroll steps K (1..7), FCNetwork sizes (observations <= 1024
+ *   features, actions <= 14, supports <= 64 bins).
  * mz_fcl_bind: the flat float32 parameter vector (engine.WEIGHT_ORDER = mz_set_weights' order, mz_fcl_num_params
  *   floats), Adam's exp_avg / exp_avg_sq of the same shape, `nsteps` float32 step counters (torch keeps one per parameter:
  *   all are incremented, the first is read) and the learning rate as a device float; builds the packed weight copies.
  * mz_fcl_repack: after anything else wrote the parameter vector (load_state_dict).
- * mz_fcl_step: obs [batch][obs_dim] (normalised), actions int64 [batch][K], target_rewards / target_values [batch][K + 1],
+ * mz_fcl_step: obs [batch][obs_dim] (normalised), actions int64 or int32 [batch][K], target_rewards / target_values [batch][K + 1],
  *   target_policies [batch][K + 1][actions], is_weights [batch] (float64 or float32) as replay_buffer.sample_batch returns
  *   them -> the parameters, optimiser state and step counters updated in place (unless no_update: gradients only),
  *   new_errors [batch] = inverse_transform(value_0) - target_values[:, 0] (the priority refresh, learners.py:181-182),
@@ -322,7 +323,7 @@ size_t mz_fcl_num_params(mz_fcl *c);
 int mz_fcl_bind(mz_fcl *c, float *params, float *exp_avg, float *exp_avg_sq, float *steps, int nsteps, const float *lr,
                 void *stream);
 int mz_fcl_repack(mz_fcl *c, void *stream);
-int mz_fcl_step(mz_fcl *c, const float *obs, const int64_t *actions, const float *target_rewards, const float *target_values,
+int mz_fcl_step(mz_fcl *c, const float *obs, const void *actions, int actions_are_i32, const float *target_rewards, const float *target_values,
                 const float *target_policies, const void *is_weights, int weights_are_f64, double beta1, double beta2, double eps,
                 double weight_decay, double clip_grad, int adamw, int no_update, float *new_errors, double *loss_sums, void *stream);
 int mz_fcl_read_grad(mz_fcl *c, float *host_out, size_t n);

@@ -133,7 +133,7 @@ SIGNATURES = {
     'mz_fcl_num_params': (_SZ, [_VP]),
     'mz_fcl_bind': (_I, [_VP, _VP, _VP, _VP, _VP, _I, _VP, _VP]),
     'mz_fcl_repack': (_I, [_VP, _VP]),
-    'mz_fcl_step': (_I, [_VP] * 7 + [_I, _D, _D, _D, _D, _D, _I, _I, _VP, _VP, _VP]),
+    'mz_fcl_step': (_I, [_VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _I, _D, _D, _D, _D, _D, _I, _I, _VP, _VP, _VP]),
     'mz_fcl_read_grad': (_I, [_VP, _VP, _SZ]),
     'mz_fcl_read_tape': (C.c_longlong, [_VP, _I, _VP, _SZ]),
     'mz_selfplay_steps': (_I, [_VP, _I, _VP]),

@@ -42,7 +42,7 @@ struct FclView {
   const float *pk;          // packed copies
   size_t rep_b1, rep_b2, tr_b1, tr_b2, ln_w, ln_b, hb1[3], hb2[3];      // bias offsets in P (heads: value, policy, reward)
   FclPack rep, tr, head[3];
-  const float *obs; const int64_t *act; const float *t_rew, *t_val, *t_pol; const void *w; int w_f64;
+  const float *obs; const void *act; int act_i32; const float *t_rew, *t_val, *t_pol; const void *w; int w_f64;
   float *xin, *a1c, *xhat, *rstd, *h, *d2c, *d1c;      // chain tapes, [K + 1][...][R]
   float *a1h, *d2h, *d1h, *dH, *lossb;                 // head tapes, [3][K + 1][...][R]
   float *lnpart;                                        // [bs / 16][128] LayerNorm weight / bias gradient partials
@@ -262,7 +262,10 @@ __global__ __launch_bounds__(FCL_THREADS) void k_fcl_chain_fwd(FclView v) {
     b2r[tid] = tid < MZ_H ? v.P[v.rep_b2 + tid] : 0.f; b2t[tid] = tid < MZ_H ? v.P[v.tr_b2 + tid] : 0.f;
     lnw[tid] = tid < MZ_H ? v.P[v.ln_w + tid] : 0.f; lnb[tid] = tid < MZ_H ? v.P[v.ln_b + tid] : 0.f;
   }
-  if (tid < 128) acts[tid] = (tid & 7) < v.K ? (int)v.act[(size_t)(row0 + (tid >> 3)) * v.K + (tid & 7)] : -1;
+  if (tid < 128) {
+    const size_t ai = (size_t)(row0 + (tid >> 3)) * v.K + (tid & 7);
+    acts[tid] = (tid & 7) < v.K ? (v.act_i32 ? ((const int32_t *)v.act)[ai] : (int)((const int64_t *)v.act)[ai]) : -1;
+  }
   // p = 0: the observations (learners.py:171-173)
   for (int idx = tid; idx < v.xks * 64; idx += FCL_THREADS) {
     const int f = idx >> 4, n = idx & 15;

@@ -191,8 +191,8 @@ class _NativeFC(object):
     bs, K, A = host['obs'].shape[0], host['act'].shape[1], net.action_space
     Sv = cfg.value_support_max - cfg.value_support_min + 1
     Sr = cfg.reward_support_max - cfg.reward_support_min + 1
-    return (bs % 16 == 0 and 1 <= K <= 7 and A <= 14 and Sv <= 64 and Sr <= 64 and host['obs'].ndim == 2 and
-            host['act'].dtype == np.int64 and host['w'].dtype in (np.float64, np.float32) and
+    return (bs % 16 == 0 and 1 <= K <= 7 and A <= 14 and Sv <= 64 and Sr <= 64 and host['obs'].ndim == 2 and host['obs'].shape[1] <= 1024 and
+            host['act'].dtype in (np.int64, np.int32) and host['w'].dtype in (np.float64, np.float32) and
             all(host[k].dtype == np.float32 for k in ('obs', 't_rew', 't_val', 't_pol')))
 
   def __init__(self, learner, host):
@@ -256,7 +256,7 @@ class _NativeFC(object):
     ptr = lambda t: C.c_void_p(t.data_ptr())
     new_errors = torch.empty(self.bs, dtype=torch.float32, device=self.dev)
     b1, b2 = g['betas']
-    _abi.check(self.lib.mz_fcl_step(self.h, ptr(obs), ptr(act), ptr(t_rew), ptr(t_val), ptr(t_pol), ptr(w), int(w.dtype == torch.float64),
+    _abi.check(self.lib.mz_fcl_step(self.h, ptr(obs), ptr(act), int(act.dtype == torch.int32), ptr(t_rew), ptr(t_val), ptr(t_pol), ptr(w), int(w.dtype == torch.float64),
                                     float(b1), float(b2), float(g['eps']), float(g['weight_decay']), float(getattr(cfg, 'clip_grad', 0) or 0),
                                     int(isinstance(self.learner.optimizer, torch.optim.AdamW)), int(bool(no_update)), ptr(new_errors),
                                     ptr(self.learner._loss_dev), _stream_ptr(obs)), 'mz_fcl_step')
@@ -306,6 +306,9 @@ class _GraphedUpdate(object):
       off += (n + 7) & ~7
     self.stage = [torch.empty(off, dtype=torch.uint8).pin_memory() for _ in range(2)]
     self.stage_np = [st.numpy() for st in self.stage]
+    # typed views of every input's piece of a staging slot: filling a slot is one np.copyto per input
+    self.stage_views = [{k: buf[self.slices[k][0]:self.slices[k][0] + self.slices[k][1]].view(self.meta[k][1]).reshape(self.meta[k][0])
+                         for k in self.ORDER} for buf in self.stage_np]
     self.dev_bytes = torch.empty(off, dtype=torch.uint8, device=dev)
     self.static = {}
     for k in self.ORDER:
@@ -346,10 +349,9 @@ class _GraphedUpdate(object):
     return all(host[k].shape == self.meta[k][0] and host[k].dtype == self.meta[k][1] for k in self.ORDER)
 
   def _fill(self, slot, host):
-    buf = self.stage_np[slot]
+    views = self.stage_views[slot]
     for k in self.ORDER:
-      o, n = self.slices[k]
-      buf[o:o + n] = host[k].reshape(-1).view(np.uint8)
+      np.copyto(views[k], host[k])
 
   def launch(self, host):
     slot = self.slot
@@ -613,6 +615,7 @@ class Learner(Logger):
     from .networks import FCNetwork
     if self._native is not None:          # the whole update as six HIP launches (csrc/mz_fcl.hip.h)
       return self._native.step(obs, act, t_rew, t_val, t_pol, w)
+    act = act.to(torch.int64)             # (sample_batch_arrays hands int32 actions over)
     if isinstance(self.network, FCNetwork) and not getattr(cfg, 'unbatched_learner', False):
       new_errors, reward_loss, value_loss, policy_loss = self._device_step_fc(obs, act, t_rew, t_val, t_pol, w)
       return self._finish_step(new_errors, reward_loss, value_loss, policy_loss, w)

@@ -176,7 +176,7 @@ class PrioritizedReplay(object):
   # replay_buffer.py:124-163 (+ insert_target 165-198 inside the native call)
   def sample_batch_arrays(self):
     """sample_batch as the arrays the learner step consumes, no Python lists in between: (dict obs float32 [bs, ...], act
-    int64 [bs, K], t_rew / t_val float32 [bs, K + 1], t_pol float32 [bs, K + 1, A], w float64 [bs]), idxs int64 [bs].  The
+    int32 [bs, K], t_rew / t_val float32 [bs, K + 1], t_pol float32 [bs, K + 1, A], w float64 [bs]), idxs int64 [bs].  The
     same draws as sample_batch (which wraps this): stratified random.uniform segments in the reference's order."""
     bs, K, A, O = self.batch_size, int(self.config.num_unroll_steps), self.action_space, self.obs_dim
     if self.beta < 1:
@@ -192,11 +192,11 @@ class PrioritizedReplay(object):
     i = np.arange(bs, dtype=np.float64)
     lo, hi = seg * i, seg * (i + 1.0)
     draws = lo + (hi - lo) * u
-    obs = np.zeros((bs,) + tuple(self.config.obs_space), np.float32)
-    actions = np.zeros((bs, K), np.int32)
-    t_rew = np.zeros((bs, K + 1), np.float32); t_val = np.zeros((bs, K + 1), np.float32)
-    t_pol = np.zeros((bs, K + 1, A), np.float32)
-    idxs = np.zeros(bs, np.int64); pri = np.zeros(bs, np.float64)
+    obs = np.empty((bs,) + tuple(self.config.obs_space), np.float32)      # (the native call writes every element)
+    actions = np.empty((bs, K), np.int32)
+    t_rew = np.empty((bs, K + 1), np.float32); t_val = np.empty((bs, K + 1), np.float32)
+    t_pol = np.empty((bs, K + 1, A), np.float32)
+    idxs = np.empty(bs, np.int64); pri = np.empty(bs, np.float64)
     _abi.check_replay(self.lib.mzr_sample_batch(self._h, _p(draws), bs, _p(obs), _p(actions), _p(t_rew), _p(t_val),
                                                 _p(t_pol), _p(idxs), _p(pri)), 'mzr_sample_batch')
     if (actions < 0).any():
@@ -205,7 +205,7 @@ class PrioritizedReplay(object):
     probs = pri / total
     is_weights = np.power(self.tree.num_memories * probs, -self.beta)
     is_weights /= is_weights.max()
-    return {'obs': obs, 'act': actions.astype(np.int64), 't_rew': t_rew, 't_val': t_val, 't_pol': t_pol, 'w': is_weights}, idxs
+    return {'obs': obs, 'act': actions, 't_rew': t_rew, 't_val': t_val, 't_pol': t_pol, 'w': is_weights}, idxs
 
   def sample_batch(self):
     b, idxs = self.sample_batch_arrays()
