@@ -14,7 +14,8 @@ torch.manual_seed(0)
 O, A, SIMS = (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (8, 4, 30)
 tag = sys.argv[4] if len(sys.argv) > 4 else None
 net = FCNetwork(O, A, torch.device('cpu'), types.SimpleNamespace()).eval()
-eng = Engine(4096, O, A, SIMS, seed=1)
+two = bool(os.environ.get('MZ_PP_TWO'))          # two players, known bounds (-1, 1), discount 1: the TicTacToe recipe's tree
+eng = Engine(4096, O, A, SIMS, seed=1, **(dict(two_players=True, known_bounds=(-1.0, 1.0), discount=1.0) if two else {}))
 eng.set_weights(net.state_dict())
 obs = torch.randn(4096, O, device='cuda')
 names = ['gather', 'bar', 'dyn_fc1', 'dyn_fc2', 'comb1', 'ln/rew', 'pred_fc1', 'pred_fc2', 'comb2', 'val/lg', 't_expand',

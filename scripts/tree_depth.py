@@ -3,11 +3,11 @@ import sys, types, numpy as np, torch
 sys.path.insert(0, '.')
 from model_based_rl_amd.engine import Engine
 from model_based_rl_amd.networks import FCNetwork
-for O, A, SIMS in ((8, 4, 30), (128, 6, 50)):
+for O, A, SIMS, two in ((8, 4, 30, False), (128, 6, 50, False), (9, 9, 30, False), (9, 9, 30, True)):
   torch.manual_seed(0)
   net = FCNetwork(O, A, torch.device('cpu'), types.SimpleNamespace()).eval()
   B = 1024
-  eng = Engine(B, O, A, SIMS, seed=1)
+  eng = Engine(B, O, A, SIMS, seed=1, **(dict(two_players=True, known_bounds=(-1.0, 1.0), discount=1.0) if two else {}))
   eng.set_weights(net.state_dict())
   eng.initial_inference(torch.randn(B, O, device='cuda'))
   eng.root_prepare(None, None, None, device_rng=True, move=0)
