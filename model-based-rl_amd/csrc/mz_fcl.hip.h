@@ -3,12 +3,13 @@
 // AdamW -- without a GEMM library or an autograd tape.  The step is ~1.5 GFLOP (batch 256, K = 5): as PyTorch operators it
 // is ~220 kernels of ~4 us of launch floor each; here its shape follows the data dependences instead:
 //
-//   k_fcl_chain_fwd   one workgroup per 16 samples: h_0 = representation(obs), h_p = dynamics(h_{p-1}, a_{p-1}) -- the only
-//                     sequential part -- with the 16 samples as the 16 columns of v_mfma_f32_16x16x4_f32, the weights as
-//                     the A operand (pre-packed in fragment order, streamed from L2), activations in LDS
-//   k_fcl_heads       one workgroup per (16 samples, unroll position, head): value / policy / reward head forward,
+//   k_fcl_chain_fwd4  one workgroup per 4 samples: h_0 = representation(obs), h_p = dynamics(h_{p-1}, a_{p-1}) -- the only
+//                     sequential part -- on v_mfma_f32_4x4x1_16b_f32 (64 output rows x 4 samples per instruction), the
+//                     transition's weights resident in registers across positions, activations in LDS
+//   k_fcl_heads       one workgroup per (16 samples = the 16 columns of v_mfma_f32_16x16x4_f32, unroll position, head):
+//                     value / policy / reward head forward,
 //                     two-hot targets, soft cross-entropy, and the head's backward down to d loss / d hidden state
-//   k_fcl_chain_bwd   one workgroup per 16 samples: the chain backwards (gradient hooks 0.5, LayerNorm, ReLU)
+//   k_fcl_chain_bwd4  one workgroup per 4 samples: the chain backwards (gradient hooks 0.5, LayerNorm, ReLU)
 //   k_fcl_dw          every weight gradient dW = sum_rows delta (x) input as 16 x 64 MFMA strips over the activation /
 //                     delta tapes the three kernels above left in HBM (one strip per wave, one unroll position per strip:
 //                     deterministic, no atomics)
@@ -37,7 +38,7 @@ struct FclPack {          // float offsets into the packed buffer; k-steps (even
 };
 
 struct FclView {
-  int bs, K, O, A, KD, Sv, Sr, vmin, rmin, ntt, R, XR, xks;
+  int bs, K, O, A, KD, Sv, Sr, vmin, rmin, ntt, R, XR, xks, xq;
   const float *P;           // flat parameters (engine.WEIGHT_ORDER)
   const float *pk;          // packed copies
   size_t rep_b1, rep_b2, tr_b1, tr_b2, ln_w, ln_b, hb1[3], hb2[3];      // bias offsets in P (heads: value, policy, reward)
@@ -99,27 +100,6 @@ __device__ __forceinline__ void fcl_wide(const f32x4 *__restrict__ pk, int ks, c
   }
 }
 
-// the same product with the wave's KS k-steps of weights resident in registers (the transition's, used at every position)
-template <int KS>
-__device__ __forceinline__ void fcl_wide_res(const f32x4 (&W)[KS], const float *X, int lane, f32x4 acc[4]) {
-  const float *x = X + 4 * (lane & 15) + (lane >> 4);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int s = 0; s < KS; ++s) {
-    const float xs = x[s * 64];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = fcl_mfma(W[s][i], xs, acc[i]);
-  }
-}
-
-template <int KS>
-__device__ __forceinline__ void fcl_load_wide(f32x4 (&W)[KS], const f32x4 *__restrict__ pk, int w, int lane) {
-  const f32x4 *p = pk + (size_t)w * FCL_KSA(KS) * 64 + lane;
-#pragma unroll
-  for (int s = 0; s < KS; ++s) W[s] = p[s * 64];
-}
-
 // partial of out[16 NT x 16] = W[16 NT x 512] . A1[512 x 16] over this wave's 16 k-steps (split-K over the 8 waves);
 // pk: P(W; <= 64, 512), 128 k-steps.  The partials go to red[w][4][64] (f32x4); fcl_reduce adds them up.
 __device__ __forceinline__ void fcl_load_narrow(f32x4 (&W)[16], const f32x4 *__restrict__ pk, int w, int lane) {
@@ -173,10 +153,8 @@ __device__ __forceinline__ void fcl_reduce(const f32x4 *red, int nt, const float
   }
 }
 
-// LDS of the chain kernels (floats): X [xks * 64] | A1 [8192] | red [8192] | Y [1024] | S [3 * 1024] | misc [64] | PV [1408]
-// (PV: the small parameter vectors -- biases, LayerNorm -- read once per launch);
-// of the heads kernel: X [1024] | A1 [8192] | red [8192] | Y [1024] | S [1024] | PV [576]: two workgroups per CU
-#define FCL_LDS_FLOATS(xks) ((xks) * 64 + 8192 + 8192 + 1024 + 3 * 1024 + 64 + 1408)
+// LDS of the heads kernel (floats): X [1024] | A1 [8192] | red [8192] | Y [1024] | S [1024] | PV [576] (PV: the small
+// parameter vectors, read once per launch): two workgroups per CU
 #define FCL_LDS_HEADS (1024 + 8192 + 8192 + 1024 + 1024 + 576)
 
 // Config.scalar_transform + scalar_to_support (config.py:51-68): bin s of the two-hot target of scalar x
@@ -233,104 +211,6 @@ __device__ __forceinline__ void fcl_mask_out(const f32x4 acc[4], const f32x4 msk
 }
 
 // ------------------------------------------------------------------------------------------------ chain, forward
-// the compiler's wait-count bookkeeping treats a register whose load was requested before a loop as pending inside the
-// loop and waits at its first use in EVERY iteration -- and a wait for a load also waits for every older store.  Touching
-// the registers once in front of the loop settles them there.
-template <int N>
-__device__ __forceinline__ void fcl_settle(f32x4 (&W)[N]) {
-#pragma unroll
-  for (int s = 0; s < N; ++s) asm volatile("" : "+v"(W[s]));
-}
-
-// KS1: k-steps of the transition's fc1 (50 + actions input features: 14 up to 6 actions, 16 up to 14)
-template <int KS1>
-__global__ __launch_bounds__(FCL_THREADS) void k_fcl_chain_fwd(FclView v) {
-  extern __shared__ __attribute__((aligned(16))) float fcl_smem[];
-  float *X = fcl_smem, *A1 = X + v.xks * 64, *redf = A1 + 8192, *Y = redf + 8192, *S = Y + 1024, *misc = S + 3 * 1024, *PV = misc + 64;
-  float *b1r = PV, *b1t = PV + 512, *b2r = PV + 1024, *b2t = PV + 1088, *lnw = PV + 1152, *lnb = PV + 1216;
-  int *acts = (int *)(PV + 1280);          // [16 samples][8]: the actions of the K transitions
-  f32x4 *red = (f32x4 *)redf;
-  const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int row0 = blockIdx.x * 16, R = v.R, loff = fcl_lane_off(lane), cb = blockIdx.x;
-  const size_t T64 = (size_t)64 * R, T512 = (size_t)512 * R, TX = (size_t)v.XR * R;
-  // the transition's weights stay in registers for positions 1..K (requested now, they arrive under position 0)
-  f32x4 WT1[KS1], WT2[16];
-  fcl_load_wide<KS1>(WT1, (const f32x4 *)(v.pk + v.tr.F1), w, lane);
-  fcl_load_narrow(WT2, (const f32x4 *)(v.pk + v.tr.F2), w, lane);
-  b1r[tid] = v.P[v.rep_b1 + tid]; b1t[tid] = v.P[v.tr_b1 + tid];
-  if (tid < 64) {
-    b2r[tid] = tid < MZ_H ? v.P[v.rep_b2 + tid] : 0.f; b2t[tid] = tid < MZ_H ? v.P[v.tr_b2 + tid] : 0.f;
-    lnw[tid] = tid < MZ_H ? v.P[v.ln_w + tid] : 0.f; lnb[tid] = tid < MZ_H ? v.P[v.ln_b + tid] : 0.f;
-  }
-  if (tid < 128) {
-    const size_t ai = (size_t)(row0 + (tid >> 3)) * v.K + (tid & 7);
-    acts[tid] = (tid & 7) < v.K ? (v.act_i32 ? ((const int32_t *)v.act)[ai] : (int)((const int64_t *)v.act)[ai]) : -1;
-  }
-  // p = 0: the observations (learners.py:171-173)
-  for (int idx = tid; idx < v.xks * 64; idx += FCL_THREADS) {
-    const int f = idx >> 4, n = idx & 15;
-    const float val = f < v.O ? v.obs[(size_t)(row0 + n) * v.O + f] : 0.f;
-    X[fcl_at(f, n)] = val;
-    if (f < v.XR) v.xin[fcl_tp(v.XR, cb, f, n)] = val;
-  }
-  fcl_bar();
-  // one position: fc1 (done by the caller into acc) -> ReLU -> fc2 -> LayerNorm -> ReLU -> tapes, next input
-  auto rest = [&](int p, const f32x4 (&acc)[4], const f32x4 (&W2)[16], const float *b1, const float *b2) __attribute__((always_inline)) {
-    fcl_fc1_out(acc, b1, A1, v.a1c + (size_t)p * T512 + fcl_tp(512, cb, 0, 0), loff, w, lane);
-    fcl_bar();
-    fcl_narrow_res<4>(W2, A1, red, w, lane);
-    fcl_bar();
-    fcl_reduce(red, 4, b2, MZ_H, Y, tid);
-    fcl_bar();
-    // LayerNorm over the 50 features + ReLU (networks.py:147,165): 32 lanes per sample, features q and q + 32
-    {
-      const int n = tid >> 5, q = tid & 31;
-      const bool two = q + 32 < MZ_H;
-      const int act_p = acts[n * 8 + (p < 7 ? p : 7)];
-      const float y0 = Y[fcl_at(q, n)], y1 = two ? Y[fcl_at(q + 32, n)] : 0.f;
-      float s = y0 + y1;
-      for (int o = 16; o >= 1; o >>= 1) s += __shfl_xor(s, o, 32);
-      const float mean = s / (float)MZ_H;
-      const float d0 = y0 - mean, d1 = two ? y1 - mean : 0.f;
-      float var = d0 * d0 + d1 * d1;
-      for (int o = 16; o >= 1; o >>= 1) var += __shfl_xor(var, o, 32);
-      const float rstd = 1.0f / sqrtf(var / (float)MZ_H + FCL_LN_EPS);
-      const float xh0 = d0 * rstd, xh1 = d1 * rstd;
-      const float h0 = fmaxf(xh0 * lnw[q] + lnb[q], 0.f);
-      const float h1 = two ? fmaxf(xh1 * lnw[q + 32] + lnb[q + 32], 0.f) : 0.f;
-      S[q * 16 + n] = xh0; S[(q + 32) * 16 + n] = xh1;
-      if (q == 0) misc[n] = rstd;
-      // the next input: [h | one-hot(action) | 0]  (networks.py:167-174); past the last transition: no action
-      X[fcl_at(q, n)] = h0;
-      X[fcl_at(q + 32, n)] = two ? h1 : ((p < v.K && (q + 32 - MZ_H) == act_p) ? 1.f : 0.f);
-    }
-    fcl_bar();
-    for (int idx = tid; idx < 64 * 16; idx += FCL_THREADS) {
-      const int f = idx >> 4, n = idx & 15;
-      const float xv = X[fcl_at(f, n)];
-      v.xhat[(size_t)p * T64 + fcl_tp(64, cb, f, n)] = S[f * 16 + n];
-      v.h[(size_t)p * T64 + fcl_tp(64, cb, f, n)] = f < MZ_H ? xv : 0.f;
-      if (p < v.K) v.xin[(size_t)(p + 1) * TX + fcl_tp(v.XR, cb, f, n)] = xv;
-    }
-    if (tid < 16) v.rstd[(size_t)p * R + row0 + tid] = misc[tid];
-    // (no barrier here: X, S and misc are next written by the NEXT position's LayerNorm phase, three barriers away.
-    //  X beyond feature 64 still holds observation columns when O > 64: the transition's k-steps end at 64)
-  };
-  {   // position 0: the representation, its weights streamed
-    f32x4 acc[4], WR2[16];
-    fcl_load_narrow(WR2, (const f32x4 *)(v.pk + v.rep.F2), w, lane);
-    fcl_wide<2>((const f32x4 *)(v.pk + v.rep.F1), v.rep.ks1, X, w, lane, acc);
-    rest(0, acc, WR2, b1r, b2r);
-  }
-  fcl_settle(WT1);
-  fcl_settle(WT2);
-  for (int p = 1; p <= v.K; ++p) {      // (no global load in here: no wait behind the tape stores)
-    f32x4 acc[4];
-    fcl_wide_res<KS1>(WT1, X, lane, acc);
-    rest(p, acc, WT2, b1t, b2t);
-  }
-}
-
 // ------------------------------------------------------------------------------------------------ heads
 // grid (bs / 16, K + 1, 3): head 0 value (input h_p), 1 policy (h_p), 2 reward (x_p = [h_{p-1} | one-hot], p >= 1)
 __global__ __launch_bounds__(FCL_THREADS, 4) void k_fcl_heads(FclView v) {
@@ -429,111 +309,288 @@ __global__ __launch_bounds__(FCL_THREADS, 4) void k_fcl_heads(FclView v) {
   }
 }
 
-// ------------------------------------------------------------------------------------------------ chain, backward
-__global__ __launch_bounds__(FCL_THREADS) void k_fcl_chain_bwd(FclView v) {
-  extern __shared__ __attribute__((aligned(16))) float fcl_smem[];
-  float *X = fcl_smem, *A1 = X + v.xks * 64, *redf = A1 + 8192, *Y = redf + 8192, *S = Y + 1024, *PV = S + 3 * 1024 + 64;
-  float *GH = S, *HM = S + 1024, *XH = S + 2048;      // [feature][16]
-  float *D2 = X;                                       // d (pre-LayerNorm output), k-step layout (X holds >= 16 k-steps)
-  float *lnw = PV;
-  f32x4 *red = (f32x4 *)redf;
-  const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int row0 = blockIdx.x * 16, R = v.R, K1 = v.K + 1, loff = fcl_lane_off(lane), cb = blockIdx.x;
-  const size_t T64 = (size_t)64 * R, T512 = (size_t)512 * R;
-  // the transition's transposed weights stay in registers (fc2: 50 output features = 14 k-steps; fc1: its 50 hidden inputs)
-  f32x4 WB2[14], WB1[16];
-  fcl_load_wide<14>(WB2, (const f32x4 *)(v.pk + v.tr.B2), w, lane);
-  fcl_load_narrow(WB1, (const f32x4 *)(v.pk + v.tr.B1), w, lane);
-  if (tid < 64) lnw[tid] = tid < MZ_H ? v.P[v.ln_w + tid] : 0.f;
-  float dgam[2] = {0.f, 0.f}, dbet[2] = {0.f, 0.f};
-  for (int idx = tid; idx < 1024; idx += FCL_THREADS) Y[idx] = 0.f;      // d chain of position K + 1: none
-  // the tape values of a position are requested one position ahead: (d value head, d policy head, d reward head of p + 1,
-  // h, x-hat) for this thread's two (feature, sample) entries, and rstd
-  float tv[2][5], trs;
-  auto request = [&](int p) __attribute__((always_inline)) {
+// ------------------------------------------------------------------------------------------------ chain (4 samples per workgroup)
+// The chain is the step's only sequential part.  With 16 samples per workgroup (the 16 x 16 x 4 MFMA's columns, as the
+// heads kernel does) it had batch / 16 workgroups: 16 of 256 CUs at batch 256, 42 + 37 us.  v_mfma_f32_4x4x1_16b_f32 (sixteen 4 x 4 outer products per instruction: 64 output rows x 4 columns x 1 k) has the
+// same arithmetic rate per instruction byte as the 16 x 16 x 4 shape but needs only FOUR samples to fill its columns:
+// batch / 4 workgroups, a quarter of the matrix time each.  Operands: A = lane l's weight of output row l (of the wave's
+// 64) for ONE k -- packed "quad" copies Q(W; M, K): [M / 64][K][64 lanes] floats, resident in registers across positions
+// like the 16-column version's; B = X[k][sample lane & 3] (LDS, [feature][4]); D register i of lane (b, j) = row 4 b + i,
+// sample j.  Tapes as before: a workgroup owns 4 of the 16 rows of its row chunk.
+__device__ __forceinline__ f32x4 fcl_mfma4(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
+}
+
+// out[64 rows of wave w][4] = sum_k W[k] x X[sample][k]: xrow = this lane's sample row (LDS, sample-major, 16-byte aligned,
+// at least K rounded up to 4 floats): the whole row is requested in 16-byte reads before the first MFMA (left to
+// itself the compiler read one k at a time and waited out an LDS round trip in front of every pair of MFMAs); four
+// accumulators in rotation (a 2-pass MFMA's result is not forwarded to an immediately following dependent one)
+template <int K>
+__device__ __forceinline__ f32x4 fcl_quad_res(const float (&W)[K], const float *xrow) {
+  constexpr int NV = (K + 3) / 4;
+  f32x4 xv[NV];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int idx = tid + k * FCL_THREADS, f = idx >> 4, n = idx & 15;
-      const size_t o = fcl_tp(64, cb, f, n);
-      tv[k][0] = v.dH[((size_t)0 * K1 + p) * T64 + o];
-      tv[k][1] = v.dH[((size_t)1 * K1 + p) * T64 + o];
-      tv[k][2] = p < v.K ? v.dH[((size_t)2 * K1 + p + 1) * T64 + o] : 0.f;
-      tv[k][3] = v.h[(size_t)p * T64 + o];
-      tv[k][4] = v.xhat[(size_t)p * T64 + o];
+  for (int q = 0; q < NV; ++q) xv[q] = *(const f32x4 *)(xrow + 4 * q);
+  f32x4 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < K; ++k) acc[k & 3] = fcl_mfma4(W[k], xv[k >> 2][k & 3], acc[k & 3]);
+  return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+
+template <int K>
+__device__ __forceinline__ void fcl_quad_load(float (&W)[K], const float *__restrict__ pk, int lane) {
+#pragma unroll
+  for (int k = 0; k < K; ++k) W[k] = pk[k * 64 + lane];
+}
+
+// the compiler's wait-count bookkeeping treats a register whose load was requested before a loop as pending inside the
+// loop and waits at its first use in EVERY iteration -- and a wait for a load also waits for every older store.  Touching
+// the registers once in front of the loop settles them there.
+template <int K>
+__device__ __forceinline__ void fcl_quad_settle(float (&W)[K]) {
+#pragma unroll
+  for (int k = 0; k < K; ++k) asm volatile("" : "+v"(W[k]));
+}
+
+// the same product with the weights streamed (the representation's fc1: K = observation features, used once)
+__device__ __forceinline__ f32x4 fcl_quad_stream(const float *__restrict__ pk, int K, const float *xrow, int lane) {
+  f32x4 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int k = 0;
+  for (; k + 8 <= K; k += 8) {
+    float wv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wv[j] = pk[(k + j) * 64 + lane];
+    const f32x4 x0 = *(const f32x4 *)(xrow + k), x1 = *(const f32x4 *)(xrow + k + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = fcl_mfma4(wv[j], x0[j], acc[j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = fcl_mfma4(wv[4 + j], x1[j], acc[j]);
+  }
+  for (; k < K; ++k) acc[k & 3] = fcl_mfma4(pk[k * 64 + lane], xrow[k], acc[k & 3]);
+  return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+
+// LDS of the 4-sample chain kernels (floats), activations SAMPLE-major: X [4][xq + 4] | A1 [4][516] | red [2048] | misc [16] | PV [1408]
+#define FCL_LDS4_FLOATS(xq) (4 * ((xq) + 4) + 4 * 516 + 2048 + 16 + 1408)
+#define FCL_LDA 516
+
+// D fragment (rows 64 w + 4 b + i, sample j) -> tape [chunk][feature][16]: wave-uniform base + one lane offset + i * 16
+__device__ __forceinline__ int fcl_lane_off4(int lane, int n0) { return (lane >> 2) * 64 + n0 + (lane & 3); }
+
+// KP: the transition's fc1 input features (50 + actions), padded: 56 (up to 6 actions) or 64
+template <int KP>
+__global__ __launch_bounds__(FCL_THREADS) void k_fcl_chain_fwd4(FclView v) {
+  extern __shared__ __attribute__((aligned(16))) float fcl_smem[];
+  const int LDX = v.xq + 4;
+  float *X = fcl_smem, *A1 = X + 4 * LDX, *red = A1 + 4 * FCL_LDA, *misc = red + 2048, *PV = misc + 16;
+  float *b1r = PV, *b1t = PV + 512, *b2r = PV + 1024, *b2t = PV + 1088, *lnw = PV + 1152, *lnb = PV + 1216;
+  int *acts = (int *)(PV + 1280);          // [4 samples][8]
+  const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int cb = blockIdx.x >> 2, n0 = 4 * (blockIdx.x & 3), row0 = blockIdx.x * 4, R = v.R, loff = fcl_lane_off4(lane, n0);
+  const size_t T64 = (size_t)64 * R, T512 = (size_t)512 * R, TX = (size_t)v.XR * R;
+  float WT1[KP], WT2[64];
+  fcl_quad_load<KP>(WT1, v.pk + v.tr.F1 + (size_t)w * KP * 64, lane);
+  fcl_quad_load<64>(WT2, v.pk + v.tr.F2 + (size_t)w * 64 * 64, lane);
+  b1r[tid] = v.P[v.rep_b1 + tid]; b1t[tid] = v.P[v.tr_b1 + tid];
+  if (tid < 64) {
+    b2r[tid] = tid < MZ_H ? v.P[v.rep_b2 + tid] : 0.f; b2t[tid] = tid < MZ_H ? v.P[v.tr_b2 + tid] : 0.f;
+    lnw[tid] = tid < MZ_H ? v.P[v.ln_w + tid] : 0.f; lnb[tid] = tid < MZ_H ? v.P[v.ln_b + tid] : 0.f;
+  }
+  if (tid < 32) {
+    const size_t ai = (size_t)(row0 + (tid >> 3)) * v.K + (tid & 7);
+    acts[tid] = (tid & 7) < v.K ? (v.act_i32 ? ((const int32_t *)v.act)[ai] : (int)((const int64_t *)v.act)[ai]) : -1;
+  }
+  for (int idx = tid; idx < v.xq * 4; idx += FCL_THREADS) {
+    const int f = idx >> 2, n = idx & 3;
+    const float val = f < v.O ? v.obs[(size_t)(row0 + n) * v.O + f] : 0.f;
+    X[n * LDX + f] = val;
+    if (f < v.XR) v.xin[fcl_tp(v.XR, cb, f, n0 + n)] = val;
+  }
+  fcl_bar();
+  auto rest = [&](int p, f32x4 acc, const float (&W2)[64], const float *b1, const float *b2) __attribute__((always_inline)) {
+    {   // fc1 epilogue: bias, ReLU, to LDS (one 16-byte write: the lane's four features of its sample) and to the tape
+      const int f0 = 64 * w + 4 * (lane >> 2);
+      const f32x4 b = *(const f32x4 *)(b1 + f0);
+      float *a1t = v.a1c + (size_t)p * T512 + fcl_tp(512, cb, 64 * w, 0);
+      f32x4 a;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a[i] = fmaxf(acc[i] + b[i], 0.f);
+        (a1t + i * 16)[loff] = a[i];
+      }
+      *(f32x4 *)(A1 + (lane & 3) * FCL_LDA + f0) = a;
     }
-    trs = v.rstd[(size_t)p * R + row0 + (tid >> 5)];
+    fcl_bar();
+    *(f32x4 *)(red + (w * 64 + lane) * 4) = fcl_quad_res<64>(W2, A1 + (lane & 3) * FCL_LDA + 64 * w);
+    fcl_bar();
+    if (w == 0) {
+      // wave 0 alone: lane (b, j) adds up rows 4 b + i of the 8 partials, then LayerNorm + ReLU (networks.py:147,165) of
+      // sample j across the 16 lanes that share it (shuffles over the lane bits 2..5), the tapes and the next input
+      // straight from registers
+      const int j = lane & 3, f0 = 4 * (lane >> 2);
+      f32x4 y = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ww = 0; ww < FCL_NW; ++ww) y += *(const f32x4 *)(red + (ww * 64 + lane) * 4);
+      float yv[4], s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { yv[i] = (f0 + i < MZ_H) ? y[i] + b2[f0 + i] : 0.f; s += yv[i]; }
+      for (int o = 4; o <= 32; o <<= 1) s += __shfl_xor(s, o, 64);
+      const float mean = s / (float)MZ_H;
+      float d[4], var = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { d[i] = (f0 + i < MZ_H) ? yv[i] - mean : 0.f; var += d[i] * d[i]; }
+      for (int o = 4; o <= 32; o <<= 1) var += __shfl_xor(var, o, 64);
+      const float rstd = 1.0f / sqrtf(var / (float)MZ_H + FCL_LN_EPS);
+      const int act_p = acts[j * 8 + (p < 7 ? p : 7)];
+      const size_t tp = fcl_tp(64, cb, f0, n0 + j);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int f = f0 + i;
+        const float xh = d[i] * rstd;
+        const float hv = f < MZ_H ? fmaxf(xh * lnw[f] + lnb[f], 0.f) : 0.f;
+        // the next input: [h | one-hot(action) | 0]  (networks.py:167-174); past the last transition: no action
+        const float xv = f < MZ_H ? hv : ((p < v.K && f - MZ_H == act_p) ? 1.f : 0.f);
+        X[j * LDX + f] = xv;
+        v.xhat[(size_t)p * T64 + tp + i * 16] = xh;
+        v.h[(size_t)p * T64 + tp + i * 16] = hv;
+        if (p < v.K) v.xin[(size_t)(p + 1) * TX + fcl_tp(v.XR, cb, f, n0 + j)] = xv;
+      }
+      if (lane < 4) v.rstd[(size_t)p * R + row0 + lane] = rstd;
+    }
+    fcl_bar();
   };
+  {   // position 0: the representation, its weights streamed
+    float WR2[64];
+    fcl_quad_load<64>(WR2, v.pk + v.rep.F2 + (size_t)w * 64 * 64, lane);
+    const f32x4 acc = fcl_quad_stream(v.pk + v.rep.F1 + (size_t)w * v.O * 64, v.O, X + (lane & 3) * LDX, lane);
+    rest(0, acc, WR2, b1r, b2r);
+  }
+  fcl_quad_settle(WT1);
+  fcl_quad_settle(WT2);
+  for (int p = 1; p <= v.K; ++p) rest(p, fcl_quad_res<KP>(WT1, X + (lane & 3) * LDX), WT2, b1t, b2t);
+}
+
+__global__ __launch_bounds__(FCL_THREADS) void k_fcl_chain_bwd4(FclView v) {
+  extern __shared__ __attribute__((aligned(16))) float fcl_smem[];
+  const int LDX = v.xq + 4;
+  float *X = fcl_smem, *A1 = X + 4 * LDX, *red = A1 + 4 * FCL_LDA, *PV = red + 2048 + 16;
+  float *D2 = X;                                     // d (pre-LayerNorm output), sample-major like X (rows of >= 64 floats)
+  float *lnw = PV;
+  const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int cb = blockIdx.x >> 2, n0 = 4 * (blockIdx.x & 3), row0 = blockIdx.x * 4, R = v.R, K1 = v.K + 1, loff = fcl_lane_off4(lane, n0);
+  const size_t T64 = (size_t)64 * R, T512 = (size_t)512 * R;
+  float WB2[MZ_H], WB1[64];
+  fcl_quad_load<MZ_H>(WB2, v.pk + v.tr.B2 + (size_t)w * MZ_H * 64, lane);
+  fcl_quad_load<64>(WB1, v.pk + v.tr.B1 + (size_t)w * 64 * 64, lane);
+  float WR2[MZ_H];      // the representation's, for position 0 (requested now)
+  fcl_quad_load<MZ_H>(WR2, v.pk + v.rep.B2 + (size_t)w * MZ_H * 64, lane);
+  if (tid < 64) lnw[tid] = tid < MZ_H ? v.P[v.ln_w + tid] : 0.f;
+  // wave 0 carries the per-sample work in registers: lane (b, j) = features 4 b + i of sample j
+  const int j = lane & 3, f0 = 4 * (lane >> 2);
+  float dgam[4] = {0.f, 0.f, 0.f, 0.f}, dbet[4] = {0.f, 0.f, 0.f, 0.f};
+  f32x4 dch = (f32x4){0.f, 0.f, 0.f, 0.f};         // d chain: gradient from the transition of position p + 1 into h_p
+  float tv[4][5], trs = 0.f;
+  auto request = [&](int p) __attribute__((always_inline)) {
+    if (w == 0) {
+      const size_t o = fcl_tp(64, cb, f0, n0 + j);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        tv[i][0] = v.dH[((size_t)0 * K1 + p) * T64 + o + i * 16];
+        tv[i][1] = v.dH[((size_t)1 * K1 + p) * T64 + o + i * 16];
+        tv[i][2] = p < v.K ? v.dH[((size_t)2 * K1 + p + 1) * T64 + o + i * 16] : 0.f;
+        tv[i][3] = v.h[(size_t)p * T64 + o + i * 16];
+        tv[i][4] = v.xhat[(size_t)p * T64 + o + i * 16];
+      }
+      trs = v.rstd[(size_t)p * R + row0 + j];
+    }
+  };
+  for (int idx = tid; idx < 4 * LDX; idx += FCL_THREADS) X[idx] = 0.f;
   request(v.K);
   fcl_bar();
-  for (int p = v.K; p >= 0; --p) {
-    // gradient arriving at h_p: value and policy heads of position p, reward head and transition of position p + 1
-    const float rstd = trs;
+  auto body = [&](int p, const float (&W2)[MZ_H]) __attribute__((always_inline)) {
+    if (w == 0) {
+      // gradient arriving at h_p (value and policy heads of position p, reward head and transition of position p + 1;
+      // hook 0.5, learners.py:200), then ReLU and LayerNorm backwards over the sample's 16 lanes
+      const float rstd = trs;
+      float gy[4], xh[4], dx[4], s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int idx = tid + k * FCL_THREADS, f = idx >> 4, n = idx & 15;
-      float g = tv[k][0] + tv[k][1];
-      if (p < v.K) g = g + tv[k][2] + Y[fcl_at(f, n)];
-      if (p >= 1) g *= 0.5f;                                     // hidden_state.register_hook (learners.py:200)
-      GH[idx] = g; HM[idx] = tv[k][3]; XH[idx] = tv[k][4];
+      for (int i = 0; i < 4; ++i) {
+        float g = tv[i][0] + tv[i][1];
+        if (p < v.K) g = g + tv[i][2] + dch[i];
+        if (p >= 1) g *= 0.5f;
+        const bool real = f0 + i < MZ_H;
+        gy[i] = (real && tv[i][3] > 0.f) ? g : 0.f;
+        xh[i] = real ? tv[i][4] : 0.f;
+        dgam[i] += gy[i] * xh[i]; dbet[i] += gy[i];
+        dx[i] = real ? gy[i] * lnw[f0 + i] : 0.f;
+        s1 += dx[i]; s2 += dx[i] * xh[i];
+      }
+      for (int o = 4; o <= 32; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+      const float inv = 1.f / (float)MZ_H;
+      const size_t tp = fcl_tp(64, cb, f0, n0 + j);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float dy = (f0 + i < MZ_H) ? rstd * (dx[i] - s1 * inv - xh[i] * (s2 * inv)) : 0.f;
+        D2[j * LDX + f0 + i] = dy;
+        v.d2c[(size_t)p * T64 + tp + i * 16] = dy;
+      }
     }
     if (p > 0) request(p - 1);
-    // the ReLU mask of this position's fc1 (its activations on the tape), needed after the fc2-transposed product
-    const float *a1t = v.a1c + (size_t)p * T512 + fcl_tp(512, cb, 0, 0);
-    f32x4 msk[4];
+    const float *a1t = v.a1c + (size_t)p * T512 + fcl_tp(512, cb, 64 * w, 0);
+    f32x4 msk;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 4; ++i) msk[i] = (a1t + i * 16)[loff];
+    fcl_bar();
+    const f32x4 acc = fcl_quad_res<MZ_H>(W2, D2 + (lane & 3) * LDX);
+    {
+      const int g0 = 64 * w + 4 * (lane >> 2);
+      float *d1t = v.d1c + (size_t)p * T512 + fcl_tp(512, cb, 64 * w, 0);
+      f32x4 d;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) msk[i][r] = (a1t + (64 * w + 16 * i + r) * 16)[loff];
+      for (int i = 0; i < 4; ++i) {
+        d[i] = msk[i] > 0.f ? acc[i] : 0.f;
+        (d1t + i * 16)[loff] = d[i];
+      }
+      *(f32x4 *)(A1 + (lane & 3) * FCL_LDA + g0) = d;
     }
-    fcl_bar();
-    {   // ReLU and LayerNorm backwards, 32 lanes per sample
-      const int n = tid >> 5, q = tid & 31;
-      const bool two = q + 32 < MZ_H;
-      const float gy0 = HM[q * 16 + n] > 0.f ? GH[q * 16 + n] : 0.f;
-      const float gy1 = (two && HM[(q + 32) * 16 + n] > 0.f) ? GH[(q + 32) * 16 + n] : 0.f;
-      const float xh0 = XH[q * 16 + n], xh1 = two ? XH[(q + 32) * 16 + n] : 0.f;
-      dgam[0] += gy0 * xh0; dbet[0] += gy0; dgam[1] += gy1 * xh1; dbet[1] += gy1;
-      const float dx0 = gy0 * lnw[q], dx1 = two ? gy1 * lnw[q + 32] : 0.f;
-      float s1 = dx0 + dx1, s2 = dx0 * xh0 + dx1 * xh1;
-      for (int o = 16; o >= 1; o >>= 1) { s1 += __shfl_xor(s1, o, 32); s2 += __shfl_xor(s2, o, 32); }
-      const float inv = 1.f / (float)MZ_H;
-      D2[fcl_at(q, n)] = rstd * (dx0 - s1 * inv - xh0 * (s2 * inv));
-      D2[fcl_at(q + 32, n)] = two ? rstd * (dx1 - s1 * inv - xh1 * (s2 * inv)) : 0.f;
-    }
-    fcl_bar();
-    for (int idx = tid; idx < 64 * 16; idx += FCL_THREADS) {
-      const int f = idx >> 4, n = idx & 15;
-      v.d2c[(size_t)p * T64 + fcl_tp(64, cb, f, n)] = D2[fcl_at(f, n)];
-    }
-    f32x4 acc[4];
-    fcl_wide_res<14>(WB2, D2, lane, acc);
-    if (p == 1) fcl_load_wide<14>(WB2, (const f32x4 *)(v.pk + v.rep.B2), w, lane);      // position 0 is the representation's
-    fcl_mask_out(acc, msk, A1, v.d1c + (size_t)p * T512 + fcl_tp(512, cb, 0, 0), loff, w, lane);
     fcl_bar();
     if (p >= 1) {
-      fcl_narrow_res<4>(WB1, A1, red, w, lane);
+      *(f32x4 *)(red + (w * 64 + lane) * 4) = fcl_quad_res<64>(WB1, A1 + (lane & 3) * FCL_LDA + 64 * w);
       fcl_bar();
-      fcl_reduce(red, 4, nullptr, MZ_H, Y, tid);
-      fcl_bar();
+      if (w == 0) {
+        f32x4 y = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ww = 0; ww < FCL_NW; ++ww) y += *(const f32x4 *)(red + (ww * 64 + lane) * 4);
+        dch = y;            // (rows >= 50 come out of zero weights)
+      }
+      // (red is next written after two more barriers)
     }
-  }
-  // LayerNorm weight / bias gradients of this workgroup's 16 samples over all positions
-  {
-    const int n = tid >> 5, q = tid & 31;
-    GH[q * 16 + n] = dgam[0]; GH[(q + 32) * 16 + n] = dgam[1];
-    HM[q * 16 + n] = dbet[0]; HM[(q + 32) * 16 + n] = dbet[1];
-  }
-  fcl_bar();
-  if (tid < 128) {
-    const float *src = tid < 64 ? GH + tid * 16 : HM + (tid - 64) * 16;
-    float s = 0.f;
-    for (int n = 0; n < 16; ++n) s += src[n];
-    v.lnpart[(size_t)blockIdx.x * 128 + tid] = s;
+  };
+  fcl_quad_settle(WB2);
+  fcl_quad_settle(WB1);
+  for (int p = v.K; p >= 1; --p) body(p, WB2);
+  body(0, WR2);      // position 0: the representation's fc2
+  // LayerNorm weight / bias gradients of this workgroup's 4 samples over all positions
+  if (w == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float a = dgam[i], b = dbet[i];
+      a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64);
+      b += __shfl_xor(b, 1, 64); b += __shfl_xor(b, 2, 64);
+      if (j == 0 && f0 + i < 64) {
+        v.lnpart[(size_t)blockIdx.x * 128 + f0 + i] = a;
+        v.lnpart[(size_t)blockIdx.x * 128 + 64 + f0 + i] = b;
+      }
+    }
   }
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradients
-// One wave per job: G[16 x 64] strip of dW = D . X^T over the R rows of one unroll position's tapes
+// Two waves per job: G[16 x 64] strip of dW = D . X^T over the R rows of one unroll position's tapes
 // (D: deltas, Mp features per row chunk; X: layer inputs, Np features), out rows 16 tm .., out columns 64 ng ..; the bias
 // gradient = row sums of D.
 struct FclJob {
@@ -543,9 +600,13 @@ struct FclJob {
 };
 
 __global__ __launch_bounds__(256) void k_fcl_dw(const FclJob *jobs, int njobs, const float *tapes, float *part, size_t nflat, int R) {
-  const int wj = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (wj >= njobs) return;
-  const FclJob j = jobs[wj];
+  // two waves per strip, each over half of the rows (twice the waves in flight: the kernel is bound by load latency, its
+  // MFMAs are ~3 us); the second half's partial goes through LDS and is added last -- a fixed order
+  __shared__ __attribute__((aligned(16))) float sh[2][17][64];
+  const int wv = threadIdx.x >> 6, half = wv & 1, pair = wv >> 1;
+  const int wj = blockIdx.x * 2 + pair;
+  const bool live = wj < njobs;
+  const FclJob j = jobs[live ? wj : 0];
   const int lane = threadIdx.x & 63, g4 = lane >> 4, m16 = lane & 15;
   // tapes: [row chunk][feature][16 rows] -- 16 features x 16 rows of chunk c are one contiguous KiB
   const float *Dp = tapes + j.d_off + (size_t)(16 * j.tm + m16) * 16 + 4 * g4;
@@ -556,15 +617,14 @@ __global__ __launch_bounds__(256) void k_fcl_dw(const FclJob *jobs, int njobs, c
   for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
   // (k index g4 of k-step jj of chunk c = row 16 c + 4 g4 + jj, in both operands: the sum over rows is order-free.)
-  // There is about one of these waves per SIMD: latency is hidden inside the wave -- the loads of 8 chunks (40 x 16 bytes
-  // per lane) are requested before the first MFMA of the group
-  const int nch = R >> 4;
-  for (int c0 = 0; c0 < nch; c0 += 8) {
+  // The loads of 8 chunks (40 x 16 bytes per lane) are requested before the first MFMA of the group
+  const int nch = R >> 4, ch0 = half ? (nch + 1) / 2 : 0, ch1 = half ? nch : (nch + 1) / 2;
+  for (int c0 = ch0; live && c0 < ch1; c0 += 8) {
     f32x4 a[8], b[8][4];
 #pragma unroll
     for (int cc = 0; cc < 8; ++cc) {
       const int c = c0 + cc;
-      if (c < nch) {
+      if (c < ch1) {
         a[cc] = *(const f32x4 *)(Dp + c * dstr);
 #pragma unroll
         for (int i = 0; i < 4; ++i) b[cc][i] = *(const f32x4 *)(Xp + c * xstr + 256 * i);
@@ -572,7 +632,7 @@ __global__ __launch_bounds__(256) void k_fcl_dw(const FclJob *jobs, int njobs, c
     }
 #pragma unroll
     for (int cc = 0; cc < 8; ++cc) {
-      if (c0 + cc < nch) {
+      if (c0 + cc < ch1) {
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
 #pragma unroll
@@ -582,6 +642,20 @@ __global__ __launch_bounds__(256) void k_fcl_dw(const FclJob *jobs, int njobs, c
       }
     }
   }
+  if (half) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sh[pair][4 * i + r][lane] = acc[i][r];
+    sh[pair][16][lane] = bsum;
+  }
+  __syncthreads();
+  if (half || !live) return;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[i][r] += sh[pair][4 * i + r][lane];
+  bsum += sh[pair][16][lane];
   float *out = part + (size_t)j.slab * nflat;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -614,7 +688,15 @@ __global__ __launch_bounds__(256) void k_fcl_grad(const float *part, int nslab, 
   if (i < nflat) {
     if (i >= ln_w && i < ln_w + 2 * MZ_H) {
       const int k = (int)(i - ln_w), col = k < MZ_H ? k : 64 + (k - MZ_H);
-      for (int wg = 0; wg < nwg; ++wg) g += lnpart[(size_t)wg * 128 + col];
+      // (eight independent chains: the loads of a round are in flight together; the order of the sum is fixed)
+      float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      int wg = 0;
+      for (; wg + 8 <= nwg; wg += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += lnpart[(size_t)(wg + j) * 128 + col];
+      }
+      for (; wg < nwg; ++wg) a[wg & 7] += lnpart[(size_t)wg * 128 + col];
+      g = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     } else {
       for (int q = 0; q < nslab; ++q) g += part[(size_t)q * nflat + i];
     }
