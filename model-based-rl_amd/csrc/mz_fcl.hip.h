@@ -1,5 +1,5 @@
 // mz_fcl.hip.h -- the FCNetwork learner step (reference learners.py:164-230, networks.py:135-180, config.py:27-33,51-68,
-// utils.py:53-60) as SIX launches: the whole update -- K-step unroll forward, the three heads' losses, backward, clipping,
+// utils.py:53-60) as FIVE launches (six with gradient clipping): the whole update -- K-step unroll forward, the three heads' losses, backward, clipping,
 // AdamW -- without a GEMM library or an autograd tape.  The step is ~1.5 GFLOP (batch 256, K = 5): as PyTorch operators it
 // is ~220 kernels of ~4 us of launch floor each; here its shape follows the data dependences instead:
 //
@@ -13,7 +13,7 @@
 //   k_fcl_dw          every weight gradient dW = sum_rows delta (x) input as 16 x 64 MFMA strips over the activation /
 //                     delta tapes the three kernels above left in HBM (one strip per wave, one unroll position per strip:
 //                     deterministic, no atomics)
-//   k_fcl_grad        adds the per-position strips up, squares for the global norm, advances the step counters
+//   k_fcl_grad        (only with clip_grad) adds the per-position strips up, squares for the global norm
 //   k_fcl_adam        clip_grad_norm_, Adam / AdamW (torch's fused-kernel arithmetic), the new weights into the flat vector
 //                     AND into the packed fragment-order copies the next step's MFMAs read; loss sums
 //
@@ -599,7 +599,10 @@ struct FclJob {
   int M, N, Mp, Np, tm, ng, slab;      // Mp, Np: feature counts of the two tapes (their row-chunk strides / 16)
 };
 
-__global__ __launch_bounds__(256) void k_fcl_dw(const FclJob *jobs, int njobs, const float *tapes, float *part, size_t nflat, int R) {
+__global__ __launch_bounds__(256) void k_fcl_dw(const FclJob *jobs, int njobs, const float *tapes, float *part, size_t nflat, int R,
+                                                float *steps, int nsteps) {
+  // (the step counters -- torch keeps one per parameter -- advance here, a launch ahead of the optimiser kernel that reads them)
+  if (blockIdx.x == 0 && (int)threadIdx.x < nsteps) steps[threadIdx.x] += 1.f;
   // two waves per strip, each over half of the rows (twice the waves in flight: the kernel is bound by load latency, its
   // MFMAs are ~3 us); the second half's partial goes through LDS and is added last -- a fixed order
   __shared__ __attribute__((aligned(16))) float sh[2][17][64];
@@ -679,30 +682,36 @@ struct FclOpt {
 };
 
 // grad[i] = sum over the unroll positions' strips (LayerNorm parameters: over the workgroups' partials); per-block sum
-// of squares for clip_grad_norm_; block 0 also advances the step counters (torch keeps one per parameter)
+// of squares for clip_grad_norm_ (launched only when clipping is on: without it k_fcl_adam adds the strips up itself)
+// one parameter's gradient: the unroll positions' strips in order (LayerNorm parameters: the chain workgroups' partials,
+// eight independent chains so that the loads of a round are in flight together; the order of the sum is fixed)
+__device__ __forceinline__ float fcl_grad_of(size_t i, const float *part, int nslab, const float *lnpart, int nwg, size_t ln_w, size_t nflat) {
+  float g = 0.f;
+  if (i >= ln_w && i < ln_w + 2 * MZ_H) {
+    const int k = (int)(i - ln_w), col = k < MZ_H ? k : 64 + (k - MZ_H);
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int wg = 0;
+    for (; wg + 8 <= nwg; wg += 8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] += lnpart[(size_t)(wg + j) * 128 + col];
+    }
+    for (; wg < nwg; ++wg) a[wg & 7] += lnpart[(size_t)wg * 128 + col];
+    g = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  } else {
+    for (int q = 0; q < nslab; ++q) g += part[(size_t)q * nflat + i];
+  }
+  return g;
+}
+
 __global__ __launch_bounds__(256) void k_fcl_grad(const float *part, int nslab, const float *lnpart, int nwg, size_t ln_w,
-                                                  size_t nflat, float *grad, float *bsq, float *steps, int nsteps) {
+                                                  size_t nflat, float *grad, float *bsq) {
   __shared__ float sh[256];
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   float g = 0.f;
   if (i < nflat) {
-    if (i >= ln_w && i < ln_w + 2 * MZ_H) {
-      const int k = (int)(i - ln_w), col = k < MZ_H ? k : 64 + (k - MZ_H);
-      // (eight independent chains: the loads of a round are in flight together; the order of the sum is fixed)
-      float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      int wg = 0;
-      for (; wg + 8 <= nwg; wg += 8) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) a[j] += lnpart[(size_t)(wg + j) * 128 + col];
-      }
-      for (; wg < nwg; ++wg) a[wg & 7] += lnpart[(size_t)wg * 128 + col];
-      g = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-    } else {
-      for (int q = 0; q < nslab; ++q) g += part[(size_t)q * nflat + i];
-    }
+    g = fcl_grad_of(i, part, nslab, lnpart, nwg, ln_w, nflat);
     grad[i] = g;
   }
-  if (blockIdx.x == 0 && (int)threadIdx.x < nsteps) steps[threadIdx.x] += 1.f;
   sh[threadIdx.x] = g * g;
   __syncthreads();
   for (int o = 128; o >= 1; o >>= 1) {
@@ -714,8 +723,9 @@ __global__ __launch_bounds__(256) void k_fcl_grad(const float *part, int nslab, 
 
 // clip_grad_norm_ (learners.py:217-218), Adam / AdamW with torch's fused-kernel arithmetic (utils.py:73-83: eps 1.5e-4),
 // new weights -> flat vector + the packed copies; one more block (the last) adds the three weighted loss means up
-// (learners.py:205-207,228-230).  steps[0] has been advanced by k_fcl_grad.
-__global__ __launch_bounds__(256) void k_fcl_adam(float *P, float *pk, const int32_t *posA, const int32_t *posB, const float *grad,
+// (learners.py:205-207,228-230).  steps[0] has been advanced by k_fcl_dw.
+__global__ __launch_bounds__(256) void k_fcl_adam(float *P, float *pk, const int32_t *posA, const int32_t *posB, float *grad,
+                                                  const float *part, int nslab, const float *lnpart, int nwg, size_t ln_w,
                                                   const float *bsq, int nblk, float *m, float *vv, const float *steps,
                                                   const float *lr_p, FclOpt o, size_t nflat, const float *lossb, const void *w,
                                                   int w_f64, int bs, int K1, double *loss_acc) {
@@ -743,9 +753,12 @@ __global__ __launch_bounds__(256) void k_fcl_adam(float *P, float *pk, const int
     }
     return;
   }
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (part && i < nflat) grad[i] = fcl_grad_of(i, part, nslab, lnpart, nwg, ln_w, nflat);      // (no clipping: no k_fcl_grad launch)
   if (o.no_update) return;
   float s = 0.f;
-  for (int b = threadIdx.x; b < nblk; b += 256) s += bsq[b];
+  if (o.clip > 0.f)
+    for (int b = threadIdx.x; b < nblk; b += 256) s += bsq[b];
   sh[threadIdx.x] = s;
   if (threadIdx.x == 0) {
     const double step = (double)steps[0];
@@ -760,7 +773,6 @@ __global__ __launch_bounds__(256) void k_fcl_adam(float *P, float *pk, const int
   const float norm = sqrtf(sh[0]);
   float coef = 1.f;
   if (o.clip > 0.f) coef = fminf(o.clip / (norm + 1e-6f), 1.f);
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i < nflat) {
     // (the hyper-parameters are doubles in torch's fused kernel and the moments' updates are evaluated in double there:
     // 1 - 0.999 as a float is 4.7e-5 off)
