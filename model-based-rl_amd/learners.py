@@ -262,6 +262,29 @@ class _NativeFC(object):
                                     ptr(self.learner._loss_dev), _stream_ptr(obs)), 'mz_fcl_step')
     return new_errors
 
+  def launch(self, host):
+    """one update from the host batch (mz_fcl_update: pinned staging, one copy in, the step, the new errors on their way
+    back); returns the slot errors() hands them over from"""
+    import ctypes as C
+    from . import _abi
+    cfg, g = self.learner.config, self.learner.optimizer.param_groups[0]
+    ptr = lambda a: C.c_void_p(a.__array_interface__['data'][0])
+    b1, b2 = g['betas']
+    slot = C.c_int(0)
+    _abi.check(self.lib.mz_fcl_update(self.h, ptr(host['obs']), ptr(host['act']), int(host['act'].dtype == np.int32), ptr(host['t_rew']),
+                                      ptr(host['t_val']), ptr(host['t_pol']), ptr(host['w']), int(host['w'].dtype == np.float64),
+                                      float(b1), float(b2), float(g['eps']), float(g['weight_decay']), float(getattr(cfg, 'clip_grad', 0) or 0),
+                                      int(isinstance(self.learner.optimizer, torch.optim.AdamW)), C.c_void_p(self.learner._loss_dev.data_ptr()),
+                                      _stream_ptr(self.flat), C.byref(slot)), 'mz_fcl_update')
+    return slot.value
+
+  def errors(self, slot):
+    import ctypes as C
+    from . import _abi
+    out = np.empty(self.bs, np.float32)
+    _abi.check(self.lib.mz_fcl_errors(self.h, int(slot), C.c_void_p(out.__array_interface__['data'][0])), 'mz_fcl_errors')
+    return out
+
   def grad(self):
     """the last step's gradient as {parameter name: tensor} (tests)"""
     import ctypes as C
@@ -660,31 +683,38 @@ class Learner(Logger):
   def flush_priorities(self):
     """hand the last update's priority refresh to the replay (learners.py:182), waiting for its copy to arrive"""
     if self._pending is not None:
-      idxs, slot = self._pending
+      idxs, slot, getter = self._pending
       self._pending = None
       if getattr(self, '_source', None) is not None:
-        self._source.update(idxs, self._graph.errors(slot))
+        self._source.update(idxs, getter(slot))
       else:
-        _call(self.replay_buffer, 'update', idxs, self._graph.errors(slot))
+        _call(self.replay_buffer, 'update', idxs, getter(slot))
 
   def update_weights(self, batch, defer_priorities=False):
     """One training step (learners.py:164-230).  defer_priorities (learn()'s loop): this batch's new errors go to the replay
     at the NEXT call, i.e. while the following update is already running on the GPU."""
     host, idxs = self._host_batch(batch)
     if self.use_graph:
-      if self._graph is None or not self._graph.fits(host):
+      if self._native is not None and not self._native.fits(host):
         self.flush_priorities()
-        if self._native is not None and not self._native.fits(host):
-          self._native.close()
-          self._native = None
-        if self._native is None and _NativeFC.eligible(self, host):
-          self._native = _NativeFC(self, host)
-        self._graph = _GraphedUpdate(self, host)
+        self._native.close()
+        self._native = None
+      if self._native is None and (self._graph is None or not self._graph.fits(host)) and _NativeFC.eligible(self, host):
+        self.flush_priorities()
+        self._native = _NativeFC(self, host)
       if self._native is not None:
+        # FCNetwork: five HIP launches from the host batch (mz_fcl_update), no PyTorch operator, no graph to capture
         self._native.sync()
-      slot = self._graph.launch(host)
+        slot = self._native.launch(host)
+        getter = self._native.errors
+      else:
+        if self._graph is None or not self._graph.fits(host):
+          self.flush_priorities()
+          self._graph = _GraphedUpdate(self, host)
+        slot = self._graph.launch(host)
+        getter = self._graph.errors
       self.flush_priorities()                    # the previous batch's, whose copy has had a whole update to arrive
-      self._pending = (idxs, slot)
+      self._pending = (idxs, slot, getter)
       if not defer_priorities:
         self.flush_priorities()
     else:

@@ -180,7 +180,7 @@ class PrioritizedReplay(object):
     same draws as sample_batch (which wraps this): stratified random.uniform segments in the reference's order."""
     bs, K, A, O = self.batch_size, int(self.config.num_unroll_steps), self.action_space, self.obs_dim
     if self.beta < 1:
-      self.beta = np.min([1., self.beta + getattr(self.config, 'beta_increment_per_sampling', 0.001)])
+      self.beta = np.float64(min(1., self.beta + getattr(self.config, 'beta_increment_per_sampling', 0.001)))
     total = self.tree.total_priority
     seg = total / bs
     # random.uniform(a, b) is a + (b - a) * random.random() (CPython's random.py), and random.random() is two consecutive
@@ -189,8 +189,10 @@ class PrioritizedReplay(object):
     # getrandbits call (its words come out least significant first) with the arithmetic vectorised
     words = np.frombuffer(random.getrandbits(64 * bs).to_bytes(8 * bs, 'little'), np.uint32)
     u = ((words[0::2] >> 5).astype(np.float64) * 67108864.0 + (words[1::2] >> 6).astype(np.float64)) * (1.0 / 9007199254740992.0)
-    i = np.arange(bs, dtype=np.float64)
-    lo, hi = seg * i, seg * (i + 1.0)
+    if getattr(self, '_seg_i', None) is None or self._seg_i[0].size != bs:
+      i = np.arange(bs, dtype=np.float64)
+      self._seg_i = (i, i + 1.0)
+    lo, hi = seg * self._seg_i[0], seg * self._seg_i[1]
     draws = lo + (hi - lo) * u
     obs = np.empty((bs,) + tuple(self.config.obs_space), np.float32)      # (the native call writes every element)
     actions = np.empty((bs, K), np.int32)
@@ -199,7 +201,7 @@ class PrioritizedReplay(object):
     idxs = np.empty(bs, np.int64); pri = np.empty(bs, np.float64)
     _abi.check_replay(self.lib.mzr_sample_batch(self._h, _p(draws), bs, _p(obs), _p(actions), _p(t_rew), _p(t_val),
                                                 _p(t_pol), _p(idxs), _p(pri)), 'mzr_sample_batch')
-    if (actions < 0).any():
+    if actions.min() < 0:
       for i_, k in zip(*np.nonzero(actions < 0)):      # replay_buffer.py:150-151, in the reference's draw order
         actions[i_, k] = np.random.randint(A)
     probs = pri / total

@@ -63,11 +63,15 @@ def main():
     out[name]['sample_batch_arrays_ms'] = sample_ms
     if name in ('graph', 'native'):
       assert (learner._native is not None) == (name == 'native')
-      # GPU time of one replay of the graph, on the event clock
-      g = learner._graph
+      # GPU time of one update (graph replay, or the native step's launches with their two copies), on the event clock
       e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+      if name == 'native':
+        host = learner._host_batch(replay.sample_batch_arrays())[0]
+        run = lambda: learner._native.launch(host)
+      else:
+        run = learner._graph.graph.replay
       torch.cuda.synchronize(); e0.record()
-      for _ in range(50): g.graph.replay()
+      for _ in range(50): run()
       e1.record(); torch.cuda.synchronize()
       out[name]['graph_replay_gpu_ms'] = e0.elapsed_time(e1) / 50
       out[name]['replay_size'] = replay.size()
