@@ -31,7 +31,8 @@ if ROOT not in sys.path:
 # envs per GPU.  Secondary lines for profiles/, never the headline: --workload pong = configs[3]'s shapes on one GPU
 # (Pong-ram: 128 uint8 observations with --norm_obs 0 255, 6 actions, 50 simulations); --workload breakout =
 # configs[4] (MuZeroNetwork through PyTorch-ROCm behind the external-inference entry points, bench_torch.py);
-# --workload tree = the stand-alone tree kernels of that path against the HBM / cache rooflines (bench_tree.py).
+# --workload tree = the stand-alone tree kernels of that path against the HBM / cache rooflines (bench_tree.py);
+# --workload learner = the learner step (row f2) in Learner.learn's loop (bench_learner.py).
 WORKLOADS = {'lunar': ('LunarLander-v2', 4096, 8, 4, 30, 256), 'pong': ('Pong-ramNoFrameskip-v4', 4096, 128, 6, 50, 1024),
              # configs[0]'s game at throughput size (SURVEY.md s8d Config 1): TicTacToe with the reference's rules ON THE DEVICE,
              # two players, known bounds (-1, 1), discount 1; games last 5-9 moves
@@ -365,7 +366,7 @@ def main():
   ap.add_argument('--steps', type=int, default=512)
   ap.add_argument('--warmup', type=int, default=64)
   ap.add_argument('--no-cpu-baseline', action='store_true')
-  ap.add_argument('--workload', choices=sorted(WORKLOADS) + ['breakout', 'tree'], default='lunar')
+  ap.add_argument('--workload', choices=sorted(WORKLOADS) + ['breakout', 'tree', 'learner'], default='lunar')
   ap.add_argument('--envs', type=int, default=None, help='override the number of environments per GPU (tests)')
   ap.add_argument('--chunk', type=int, default=CHUNK, help='moves per drain / ingest chunk')
   ap.add_argument('--sync-every', type=int, default=128,
@@ -394,6 +395,9 @@ def main():
   if args.workload == 'tree':
     import bench_tree              # secondary line: the stand-alone tree kernels against the HBM / cache rooflines (SURVEY.md s8d ii)
     return bench_tree.main(args)
+  if args.workload == 'learner':
+    import bench_learner           # secondary line: the learner step in Learner.learn's loop
+    return bench_learner.main(args)
   if args.gpus > 1 and 'RANK' not in os.environ:
     return self_launch(args)       # one process per GPU, started from here (before anything touches the GPU)
   chunk = max(1, args.chunk)

@@ -53,3 +53,11 @@ def test_pong_split_line():
   line = line_of(['--workload', 'pong', '--split-f16', '--envs', '256', '--steps', '16', '--warmup', '4', '--no-cpu-baseline',
                   '--min-seconds', '0.2'])
   assert line.get('secondary_line') and line['roofline']['kernel'] == 'k_search_h2' and 'f16x2' in line['dtype']
+
+
+def test_learner_line():
+  line = line_of(['--workload', 'learner', '--steps', '60', '--runs', '1'])
+  assert line['metric'] == 'learner_updates_per_second' and line['roofline']['bound'] == 'mfma' and line.get('secondary')
+  assert line['roofline']['flop_per_update'] == 1425801216        # batch 256, K = 5, LunarLander shapes: 3 x forward
+  assert 20 < line['roofline']['us_per_update'] < 400              # the native step (the PyTorch graph: ~900)
+  assert line['torch_graph']['gpu_ms_per_update'] > 2e-3 * line['roofline']['us_per_update']
