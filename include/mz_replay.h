@@ -112,6 +112,12 @@ int mzr_ingest_records_from(mz_replay *r, const float *records, int n_moves, int
 int mzr_sample_batch(const mz_replay *r, const double *draws, int bs, float *obs, int32_t *actions,
                      float *target_rewards, float *target_values, float *target_policies, int64_t *idxs,
                      double *priorities);
+/* mzr_sample_batch with the draws made inside from the caller's generator words (2 bs consecutive 32-bit Mersenne
+ * Twister outputs = random.getrandbits(64 bs), least significant first): bit for bit the reference's
+ * random.uniform(seg i, seg (i + 1)) loop (replay_buffer.py:136-140).  Also: probs [bs] = priority / total_priority
+ * (replay_buffer.py:157), info[0] = number of -1 (to be padded) actions, info[1] = num_memories. */
+int mzr_sample_batch_words(const mz_replay *r, const uint32_t *words, int bs, float *obs, int32_t *actions, float *target_rewards,
+                           float *target_values, float *target_policies, int64_t *idxs, double *probs, int64_t *info);
 
 /* number of ingest threads of the handle (mzr_config.ingest_threads at creation; the setter re-creates the pool) */
 int mzr_set_ingest_threads(mz_replay *r, int threads);

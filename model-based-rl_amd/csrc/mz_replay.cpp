@@ -804,6 +804,35 @@ int mzr_sample_batch(const mz_replay *r, const double *draws, int bs, float *obs
   return 0;
 }
 
+// mzr_sample_batch with the stratified draws made here from the caller's generator words: `words` are 2 bs consecutive
+// 32-bit Mersenne Twister outputs (random.getrandbits(64 bs), least significant word first); draw i is what
+// random.uniform(seg i, seg (i + 1)) returns on them -- random.random() = ((a >> 5) 2^26 + (b >> 6)) / 2^53
+// (_randommodule.c), uniform(lo, hi) = lo + (hi - lo) random() (random.py), seg = total_priority / bs
+// (replay_buffer.py:136-140) -- in IEEE double, no contraction: the same doubles as the Python expressions.  Also out:
+// probs [bs] = priority / total (replay_buffer.py:157), info[0] = the number of padded (-1) actions, info[1] = num_memories.
+int mzr_sample_batch_words(const mz_replay *r, const uint32_t *words, int bs, float *obs, int32_t *actions, float *target_rewards,
+                           float *target_values, float *target_policies, int64_t *idxs, double *probs, int64_t *info) {
+  if (!r || !words || !probs || !info || bs < 1) return fail("mzr_sample_batch_words: bad argument");
+  drain(r);
+  const double total = r->tree[0];
+  const double seg = total / (double)bs;
+  std::vector<double> draws((size_t)bs);
+  for (int i = 0; i < bs; ++i) {
+    const double a = (double)(words[2 * i] >> 5), b = (double)(words[2 * i + 1] >> 6);
+    const double u = (a * 67108864.0 + b) * (1.0 / 9007199254740992.0);
+    const double lo = seg * (double)i, hi = seg * ((double)i + 1.0);
+    draws[(size_t)i] = lo + (hi - lo) * u;
+  }
+  if (mzr_sample_batch(r, draws.data(), bs, obs, actions, target_rewards, target_values, target_policies, idxs, probs)) return -1;
+  for (int i = 0; i < bs; ++i) probs[i] = probs[i] / total;
+  int64_t pad = 0;
+  const int K = r->c.num_unroll_steps;
+  for (int i = 0; i < bs * K; ++i) pad += actions[i] < 0;
+  info[0] = pad;
+  info[1] = r->num_memories;
+  return 0;
+}
+
 int64_t mzr_frames(const mz_replay *r) { drain(r); return r->frames; }
 int64_t mzr_games(const mz_replay *r) { drain(r); return r->games; }
 int mzr_add_initial_throughput(mz_replay *r, int64_t frames, int64_t games) {

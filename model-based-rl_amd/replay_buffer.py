@@ -181,31 +181,22 @@ class PrioritizedReplay(object):
     bs, K, A, O = self.batch_size, int(self.config.num_unroll_steps), self.action_space, self.obs_dim
     if self.beta < 1:
       self.beta = np.float64(min(1., self.beta + getattr(self.config, 'beta_increment_per_sampling', 0.001)))
-    total = self.tree.total_priority
-    seg = total / bs
     # random.uniform(a, b) is a + (b - a) * random.random() (CPython's random.py), and random.random() is two consecutive
     # 32-bit Mersenne Twister outputs a, b -> ((a >> 5) * 2**26 + (b >> 6)) / 2**53 (_randommodule.c): the bs draws of the
-    # reference's loop (replay_buffer.py:138-140), bit for bit and from the same generator state, out of ONE
-    # getrandbits call (its words come out least significant first) with the arithmetic vectorised
+    # reference's loop (replay_buffer.py:138-140) come, bit for bit and from the same generator state, out of ONE
+    # getrandbits call (its words come out least significant first); the arithmetic runs inside the native call
     words = np.frombuffer(random.getrandbits(64 * bs).to_bytes(8 * bs, 'little'), np.uint32)
-    u = ((words[0::2] >> 5).astype(np.float64) * 67108864.0 + (words[1::2] >> 6).astype(np.float64)) * (1.0 / 9007199254740992.0)
-    if getattr(self, '_seg_i', None) is None or self._seg_i[0].size != bs:
-      i = np.arange(bs, dtype=np.float64)
-      self._seg_i = (i, i + 1.0)
-    lo, hi = seg * self._seg_i[0], seg * self._seg_i[1]
-    draws = lo + (hi - lo) * u
     obs = np.empty((bs,) + tuple(self.config.obs_space), np.float32)      # (the native call writes every element)
     actions = np.empty((bs, K), np.int32)
     t_rew = np.empty((bs, K + 1), np.float32); t_val = np.empty((bs, K + 1), np.float32)
     t_pol = np.empty((bs, K + 1, A), np.float32)
-    idxs = np.empty(bs, np.int64); pri = np.empty(bs, np.float64)
-    _abi.check_replay(self.lib.mzr_sample_batch(self._h, _p(draws), bs, _p(obs), _p(actions), _p(t_rew), _p(t_val),
-                                                _p(t_pol), _p(idxs), _p(pri)), 'mzr_sample_batch')
-    if actions.min() < 0:
+    idxs = np.empty(bs, np.int64); probs = np.empty(bs, np.float64); info = np.empty(2, np.int64)
+    _abi.check_replay(self.lib.mzr_sample_batch_words(self._h, _p(words), bs, _p(obs), _p(actions), _p(t_rew), _p(t_val),
+                                                      _p(t_pol), _p(idxs), _p(probs), _p(info)), 'mzr_sample_batch_words')
+    if info[0]:
       for i_, k in zip(*np.nonzero(actions < 0)):      # replay_buffer.py:150-151, in the reference's draw order
         actions[i_, k] = np.random.randint(A)
-    probs = pri / total
-    is_weights = np.power(self.tree.num_memories * probs, -self.beta)
+    is_weights = np.power(int(info[1]) * probs, -self.beta)
     is_weights /= is_weights.max()
     return {'obs': obs, 'act': actions, 't_rew': t_rew, 't_val': t_val, 't_pol': t_pol, 'w': is_weights}, idxs
 
