@@ -1,39 +1,42 @@
 // mz_fcl.hip.h -- the FCNetwork learner step (reference learners.py:164-230, networks.py:135-180, config.py:27-33,51-68,
-// utils.py:53-60) as FIVE launches (six with gradient clipping): the whole update -- K-step unroll forward, the three heads' losses, backward, clipping,
-// AdamW -- without a GEMM library or an autograd tape.  The step is ~1.5 GFLOP (batch 256, K = 5): as PyTorch operators it
-// is ~220 kernels of ~4 us of launch floor each; here its shape follows the data dependences instead:
+// utils.py:53-60) as FIVE launches (six with gradient clipping): the whole update -- K-step unroll forward, the three heads'
+// losses, backward, clipping, AdamW -- without a GEMM library or an autograd tape.  The step is ~1.4 GFLOP (batch 256,
+// K = 5): as PyTorch operators it is ~220 kernels of ~4 us of launch floor each; here its shape follows the data
+// dependences instead:
 //
 //   k_fcl_chain_fwd4  one workgroup per 4 samples: h_0 = representation(obs), h_p = dynamics(h_{p-1}, a_{p-1}) -- the only
 //                     sequential part -- on v_mfma_f32_4x4x1_16b_f32 (64 output rows x 4 samples per instruction), the
 //                     transition's weights resident in registers across positions, activations in LDS
 //   k_fcl_heads       one workgroup per (16 samples = the 16 columns of v_mfma_f32_16x16x4_f32, unroll position, head):
-//                     value / policy / reward head forward,
-//                     two-hot targets, soft cross-entropy, and the head's backward down to d loss / d hidden state
+//                     value / policy / reward head forward, two-hot targets, soft cross-entropy, and the head's backward
+//                     down to d loss / d hidden state
 //   k_fcl_chain_bwd4  one workgroup per 4 samples: the chain backwards (gradient hooks 0.5, LayerNorm, ReLU)
 //   k_fcl_dw          every weight gradient dW = sum_rows delta (x) input as 16 x 64 MFMA strips over the activation /
-//                     delta tapes the three kernels above left in HBM (one strip per wave, one unroll position per strip:
-//                     deterministic, no atomics)
+//                     delta tapes the three kernels above left in HBM (two waves per strip and unroll position, summed
+//                     in a fixed order: deterministic, no atomics)
 //   k_fcl_grad        (only with clip_grad) adds the per-position strips up, squares for the global norm
-//   k_fcl_adam        clip_grad_norm_, Adam / AdamW (torch's fused-kernel arithmetic), the new weights into the flat vector
-//                     AND into the packed fragment-order copies the next step's MFMAs read; loss sums
+//   k_fcl_adam        (adds the strips up,) clip_grad_norm_, Adam / AdamW (torch's fused-kernel arithmetic), the new weights
+//                     into the flat vector AND into the packed copies the next step's MFMAs read; loss sums
 //
-// Layouts.  "k-step layout" of an LDS activation array: element (feature f, sample n) at ((f >> 2) * 16 + n) * 4 + (f & 3)
-// -- the B operand of k-step s is one conflict-free ds_read_b32 (s * 64 + 4 n + k) and a D fragment is one ds_write_b128.
-// Tapes in HBM: [position][row chunk of 16][feature][16 rows]: a slice kernel's workgroup owns one contiguous block per
-// position, and k_fcl_dw reads 16 features x 16 rows as ONE contiguous KiB per wave and load.  Packed weights P(W; M, K): [ceil(M / 64)][k-steps][64 lanes] f32x4, component i of lane (m16, g4) of
-// k-step s of group tg = W[64 tg + 16 i + m16][4 s + g4]: one 16-byte load feeds four MFMAs.
+// Layouts.  Tapes in HBM: [position][row chunk of 16][feature][16 rows]: a slice kernel's workgroup owns one contiguous
+// block (a quarter of it: the chain kernels) per position, and k_fcl_dw reads 16 features x 16 rows as ONE contiguous KiB
+// per wave and load.  Heads kernel: LDS activations in "k-step layout" -- element (feature f, sample n) at
+// ((f >> 2) * 16 + n) * 4 + (f & 3): the B operand of k-step s is one conflict-free ds_read_b32 (s * 64 + 4 n + k), a D
+// fragment one ds_write_b128; packed weights P(W; M, K): [ceil(M / 64)][k-steps][64 lanes] f32x4, component i of lane
+// (m16, g4) of k-step s of group tg = W[64 tg + 16 i + m16][4 s + g4]: one 16-byte load feeds four MFMAs.  Chain kernels:
+// LDS activations sample-major, packed "quad" copies Q(W; M, K): [M / 64][K][64 lanes] floats (see there).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define FCL_NW 8                    // waves per workgroup of the three per-sample-slice kernels
+#define FCL_NW 8                    // waves per workgroup of the chain and heads kernels
 #define FCL_THREADS (FCL_NW * 64)
 #define FCL_MAXP 8                  // unroll positions K + 1
 #define FCL_LN_EPS 1e-5f
 
-struct FclPack {          // float offsets into the packed buffer; k-steps (even, zero-padded)
+struct FclPack {          // float offsets into the packed buffer
   size_t F1, F2, B2, B1;
-  int ks1, ks2;           // fc1 forward (input features / 4), fc2 backward (output features / 4)
+  int ks1, ks2;           // heads: k-steps (even, zero-padded) of fc1 forward / fc2 backward; chain (quad copies): K of fc1 / fc2^T
   int mout, nt;           // fc2 output features, 16-row tiles of them
 };
 
@@ -46,7 +49,7 @@ struct FclView {
   const float *obs; const void *act; int act_i32; const float *t_rew, *t_val, *t_pol; const void *w; int w_f64;
   float *xin, *a1c, *xhat, *rstd, *h, *d2c, *d1c;      // chain tapes, [K + 1][...][R]
   float *a1h, *d2h, *d1h, *dH, *lossb;                 // head tapes, [3][K + 1][...][R]
-  float *lnpart;                                        // [bs / 16][128] LayerNorm weight / bias gradient partials
+  float *lnpart;                                        // [bs / 4][128] LayerNorm weight / bias gradient partials (per chain workgroup)
   float *new_errors;
 };
 
@@ -63,7 +66,7 @@ __device__ __forceinline__ f32x4 fcl_mfma(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// k-steps allocated per 64-row group of a wide pack: whole groups of 8 (fcl_wide requests 8 k-steps at a time)
+// k-steps allocated per 64-row group of a wide pack: whole groups of 8 (fcl_wide requests GS k-steps at a time, GS | 8)
 #define FCL_KSA(ks) (((ks) + 7) & ~7)
 
 // out[512 x 16] = W[512 x 4 ks] . X[4 ks x 16]: wave w owns the 64 output features [64 w, 64 w + 64) (tiles i = 0..3: rows
