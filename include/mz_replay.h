@@ -118,6 +118,11 @@ int mzr_sample_batch(const mz_replay *r, const double *draws, int bs, float *obs
  * (replay_buffer.py:157), info[0] = number of -1 (to be padded) actions, info[1] = num_memories. */
 int mzr_sample_batch_words(const mz_replay *r, const uint32_t *words, int bs, float *obs, int32_t *actions, float *target_rewards,
                            float *target_values, float *target_policies, int64_t *idxs, double *probs, int64_t *info);
+/* n consecutive mzr_sample_batch_words calls in one: batch j consumes words [2 bs j, 2 bs (j + 1)) and fills row block j of
+ * every output (obs [n][bs][O], ...); info [n][2]. */
+int mzr_sample_batches_words(const mz_replay *r, const uint32_t *words, int n, int bs, float *obs, int32_t *actions,
+                             float *target_rewards, float *target_values, float *target_policies, int64_t *idxs, double *probs,
+                             int64_t *info);
 
 /* number of ingest threads of the handle (mzr_config.ingest_threads at creation; the setter re-creates the pool) */
 int mzr_set_ingest_threads(mz_replay *r, int threads);

@@ -200,6 +200,7 @@ REPLAY_SIGNATURES = {
     'mzr_ingest_records_from': (_I, [_VP, _VP, _I, _I, _I, _I]),
     'mzr_sample_batch': (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     'mzr_sample_batch_words': (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    'mzr_sample_batches_words': (_I, [_VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     'mzr_set_ingest_threads': (_I, [_VP, _I]),
     'mzr_ingest_threads': (_I, [_VP]),
     'mzr_frames': (_I64, [_VP]),

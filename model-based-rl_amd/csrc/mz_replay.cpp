@@ -833,6 +833,23 @@ int mzr_sample_batch_words(const mz_replay *r, const uint32_t *words, int bs, fl
   return 0;
 }
 
+// n consecutive mzr_sample_batch_words calls in one (the learner samples a few batches ahead anyway, learners.py:124): batch j
+// uses words [2 bs j, 2 bs (j + 1)) -- the generator words n consecutive sample_batch calls would consume -- and writes row
+// block j of every output; info [n][2].
+int mzr_sample_batches_words(const mz_replay *r, const uint32_t *words, int n, int bs, float *obs, int32_t *actions,
+                             float *target_rewards, float *target_values, float *target_policies, int64_t *idxs, double *probs,
+                             int64_t *info) {
+  if (!r || n < 1) return fail("mzr_sample_batches_words: bad argument");
+  const size_t O = (size_t)r->c.obs_dim, A = (size_t)r->c.action_space, K = (size_t)r->c.num_unroll_steps, B = (size_t)bs;
+  for (int j = 0; j < n; ++j) {
+    const size_t o = (size_t)j * B;
+    if (mzr_sample_batch_words(r, words + 2 * o, bs, obs + o * O, actions + o * K, target_rewards + o * (K + 1), target_values + o * (K + 1),
+                               target_policies + o * (K + 1) * A, idxs + o, probs + o, info + 2 * j))
+      return -1;
+  }
+  return 0;
+}
+
 int64_t mzr_frames(const mz_replay *r) { drain(r); return r->frames; }
 int64_t mzr_games(const mz_replay *r) { drain(r); return r->games; }
 int mzr_add_initial_throughput(mz_replay *r, int64_t frames, int64_t games) {

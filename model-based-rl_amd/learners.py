@@ -408,19 +408,27 @@ class _BatchSource(object):
     if not hasattr(getattr(replay, 'sample_batch'), 'remote'):
       self.private = rayshim._Handle(replay)
       replay = self.private
-    self.replay, self.depth, self.inflight, self.sent = replay, max(1, int(depth)), deque(), deque()
-    arrays = getattr(getattr(replay, '_obj', None), 'sample_batch_arrays', None) is not None
-    self.method = getattr(replay, 'sample_batch_arrays' if arrays else 'sample_batch')
+    self.replay, self.depth, self.inflight, self.sent, self.ready = replay, max(1, int(depth)), deque(), deque(), deque()
+    obj = getattr(replay, '_obj', None)
+    # the native replay samples two batches per call (sample_batches_arrays: half the per-call host overhead per batch)
+    self.multi = 2 if callable(getattr(obj, 'sample_batches_arrays', None)) and self.depth >= 2 else 1
+    arrays = getattr(obj, 'sample_batch_arrays', None) is not None
+    self.method = getattr(replay, 'sample_batches_arrays' if self.multi > 1 else ('sample_batch_arrays' if arrays else 'sample_batch'))
 
   def _result(self, fut):
     return fut.result() if hasattr(fut, 'result') else __import__('ray').get(fut)
 
+  def _submit(self):
+    self.inflight.append(self.method.remote(self.multi) if self.multi > 1 else self.method.remote())
+
   def get(self):
-    while len(self.inflight) < self.depth:
-      self.inflight.append(self.method.remote())
-    batch = self._result(self.inflight.popleft())
-    self.inflight.append(self.method.remote())
-    return batch
+    if not self.ready:
+      while len(self.inflight) * self.multi < self.depth:
+        self._submit()
+      got = self._result(self.inflight.popleft())
+      self.ready.extend(got if self.multi > 1 else [got])
+      self._submit()
+    return self.ready.popleft()
 
   def update(self, idxs, errors):
     """fire-and-forget, but a refresh that failed is reported at the next one"""

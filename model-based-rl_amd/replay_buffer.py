@@ -178,27 +178,38 @@ class PrioritizedReplay(object):
     """sample_batch as the arrays the learner step consumes, no Python lists in between: (dict obs float32 [bs, ...], act
     int32 [bs, K], t_rew / t_val float32 [bs, K + 1], t_pol float32 [bs, K + 1, A], w float64 [bs]), idxs int64 [bs].  The
     same draws as sample_batch (which wraps this): stratified random.uniform segments in the reference's order."""
+    return self.sample_batches_arrays(1)[0]
+
+  def sample_batches_arrays(self, n):
+    """n consecutive sample_batch_arrays calls in one native call (the learner samples a few batches ahead of its updates
+    anyway, learners.py:124): the same generator words, beta steps and weights as n calls in a row would give with no
+    priority refresh in between."""
     bs, K, A, O = self.batch_size, int(self.config.num_unroll_steps), self.action_space, self.obs_dim
-    if self.beta < 1:
-      self.beta = np.float64(min(1., self.beta + getattr(self.config, 'beta_increment_per_sampling', 0.001)))
+    betas = np.empty(n, np.float64)
+    for j in range(n):
+      if self.beta < 1:
+        self.beta = np.float64(min(1., self.beta + getattr(self.config, 'beta_increment_per_sampling', 0.001)))
+      betas[j] = self.beta
     # random.uniform(a, b) is a + (b - a) * random.random() (CPython's random.py), and random.random() is two consecutive
     # 32-bit Mersenne Twister outputs a, b -> ((a >> 5) * 2**26 + (b >> 6)) / 2**53 (_randommodule.c): the bs draws of the
     # reference's loop (replay_buffer.py:138-140) come, bit for bit and from the same generator state, out of ONE
     # getrandbits call (its words come out least significant first); the arithmetic runs inside the native call
-    words = np.frombuffer(random.getrandbits(64 * bs).to_bytes(8 * bs, 'little'), np.uint32)
-    obs = np.empty((bs,) + tuple(self.config.obs_space), np.float32)      # (the native call writes every element)
-    actions = np.empty((bs, K), np.int32)
-    t_rew = np.empty((bs, K + 1), np.float32); t_val = np.empty((bs, K + 1), np.float32)
-    t_pol = np.empty((bs, K + 1, A), np.float32)
-    idxs = np.empty(bs, np.int64); probs = np.empty(bs, np.float64); info = np.empty(2, np.int64)
-    _abi.check_replay(self.lib.mzr_sample_batch_words(self._h, _p(words), bs, _p(obs), _p(actions), _p(t_rew), _p(t_val),
-                                                      _p(t_pol), _p(idxs), _p(probs), _p(info)), 'mzr_sample_batch_words')
-    if info[0]:
-      for i_, k in zip(*np.nonzero(actions < 0)):      # replay_buffer.py:150-151, in the reference's draw order
-        actions[i_, k] = np.random.randint(A)
-    is_weights = np.power(int(info[1]) * probs, -self.beta)
-    is_weights /= is_weights.max()
-    return {'obs': obs, 'act': actions, 't_rew': t_rew, 't_val': t_val, 't_pol': t_pol, 'w': is_weights}, idxs
+    words = np.frombuffer(random.getrandbits(64 * bs * n).to_bytes(8 * bs * n, 'little'), np.uint32)
+    obs = np.empty((n, bs) + tuple(self.config.obs_space), np.float32)      # (the native call writes every element)
+    actions = np.empty((n, bs, K), np.int32)
+    t_rew = np.empty((n, bs, K + 1), np.float32); t_val = np.empty((n, bs, K + 1), np.float32)
+    t_pol = np.empty((n, bs, K + 1, A), np.float32)
+    idxs = np.empty((n, bs), np.int64); probs = np.empty((n, bs), np.float64); info = np.empty((n, 2), np.int64)
+    _abi.check_replay(self.lib.mzr_sample_batches_words(self._h, _p(words), n, bs, _p(obs), _p(actions), _p(t_rew), _p(t_val),
+                                                        _p(t_pol), _p(idxs), _p(probs), _p(info)), 'mzr_sample_batches_words')
+    if info[:, 0].any():
+      for j in range(n):
+        for i_, k in zip(*np.nonzero(actions[j] < 0)):      # replay_buffer.py:150-151, in the reference's draw order
+          actions[j, i_, k] = np.random.randint(A)
+    is_weights = np.power(info[:, 1:2] * probs, -betas[:, None])
+    is_weights /= is_weights.max(axis=1, keepdims=True)
+    return [({'obs': obs[j], 'act': actions[j], 't_rew': t_rew[j], 't_val': t_val[j], 't_pol': t_pol[j], 'w': is_weights[j]}, idxs[j])
+            for j in range(n)]
 
   def sample_batch(self):
     b, idxs = self.sample_batch_arrays()

@@ -326,3 +326,36 @@ def test_deferred_insertion_is_invisible():
     assert a[0] == b[0]
     for x, y in zip(a[1:], b[1:]):
       assert np.array_equal(np.asarray(x), np.asarray(y)) if not isinstance(x, dict) else x == y, a[0]
+
+
+def test_sample_batches_arrays_equals_consecutive_calls():
+  """PrioritizedReplay.sample_batches_arrays(n) (one native call for the batches the learner samples ahead) against n
+  sample_batch_arrays() calls on a twin replay from the same generator state: same draws, beta steps, weights, targets"""
+  import random
+  from model_based_rl_amd.replay_buffer import PrioritizedReplay
+  rng = np.random.RandomState(3)
+  O, A, B, n = 5, 3, 8, 40
+  reps = [PrioritizedReplay(make_cfg(obs_space=(O,), action_space=A, window_size=4096, batch_size=32, discount=0.99)) for _ in range(2)]
+  rec = np.zeros((n, B, O + A + 10), np.float32)
+  rec[..., :O] = rng.standard_normal((n, B, O))
+  rec[..., O:O + A] = rng.dirichlet([1.0] * A, size=(n, B))
+  rec[..., O + A:O + A + 2] = np.ascontiguousarray(rng.standard_normal((n, B))).view(np.float32).reshape(n, B, 2)
+  rec[..., O + A + 2:O + A + 4] = np.ascontiguousarray(np.abs(rng.standard_normal((n, B))) + 0.05).view(np.float32).reshape(n, B, 2)
+  rec[..., O + A + 4] = rng.uniform(-1, 1, (n, B))
+  ints = rec[..., O + A + 5:].view(np.int32)
+  ints[..., 0] = rng.randint(0, A, (n, B)); ints[n // 2, :, 1] = 1; ints[-1, :, 1] = 1
+  ints[..., 2] = np.concatenate([np.arange(n // 2 + 1), np.arange(n - n // 2 - 1)])[:, None]; ints[..., 3] = np.arange(B)[None, :]
+  ints[n // 2 + 1:, :, 4] = 1
+  for r in reps:
+    r.ingest_records(rec, n, B)
+  assert reps[0].size() == reps[1].size() > 100
+  random.seed(5); np.random.seed(5)
+  one = [reps[0].sample_batch_arrays() for _ in range(3)]
+  state = random.getstate()
+  random.seed(5); np.random.seed(5)
+  many = reps[1].sample_batches_arrays(3)
+  assert random.getstate() == state and reps[0].beta == reps[1].beta
+  for (ha, ia), (hb, ib) in zip(one, many):
+    assert np.array_equal(ia, ib)
+    for k in ha:
+      assert ha[k].dtype == hb[k].dtype and np.array_equal(ha[k], hb[k]), k
