@@ -468,18 +468,6 @@ class Learner(Logger):
     # one captured hipGraph per update on a GPU (module docstring); the optimisers with a capturable step only
     self.use_graph = (self.device.type == 'cuda' and not getattr(config, 'no_graph_learner', False) and
                       getattr(config, 'optimizer', 'AdamW') in ('AdamW', 'Adam'))
-    if self.use_graph and not getattr(config, 'no_tune_gemms', False):
-      # PyTorch's TunableOp: every GEMM shape of the step (2 x 512-wide layers on 256..1536 rows) is timed once against the
-      # rocBLAS / hipBLASLt solutions during the graph's warm-up and the fastest one is what gets captured -- the default
-      # heuristic picks 64 x 256 tiles for the skinny weight-gradient GEMMs ([512 x 54] over K = 256: 35 us each, a
-      # quarter of the update; profiles/r04_learner_kernel_stats_untuned.csv).  Summation order may differ between
-      # solutions: float32-rounding-level, inside every parity bound of tests/test_learner.py.
-      import torch.cuda.tunable as tunable
-      tunable.enable(True)
-      tunable.tuning_enable(True)
-      tunable.set_max_tuning_duration(20)
-      import tempfile
-      tunable.set_filename(os.path.join(tempfile.gettempdir(), 'mz_tunableop_%d.csv' % os.getpid()))      # (its exit-time dump: not into the cwd)
     self.optimizer = make_optimizer(config, self.network.parameters(), capturable=self.use_graph)
     self.lr_scheduler = make_lr_scheduler(config, self.optimizer)
     if getattr(config, 'scalar_loss', 'MSE') not in ('MSE', 'Huber'):
@@ -503,6 +491,24 @@ class Learner(Logger):
       self.load_state(state)
     Logger.__init__(self)
     self.saves_dir = self.dirs['saves']
+
+  def _tune_gemms(self):
+    """PyTorch's TunableOp for the captured PyTorch step (the native step has no use for it: switched on when the first
+    PyTorch graph is built)"""
+    if getattr(self, '_tuned', False) or getattr(self.config, 'no_tune_gemms', False):
+      return
+    self._tuned = True
+    # PyTorch's TunableOp: every GEMM shape of the step (2 x 512-wide layers on 256..1536 rows) is timed once against the
+    # rocBLAS / hipBLASLt solutions during the graph's warm-up and the fastest one is what gets captured -- the default
+    # heuristic picks 64 x 256 tiles for the skinny weight-gradient GEMMs ([512 x 54] over K = 256: 35 us each, a
+    # quarter of the update; profiles/r04_learner_kernel_stats_untuned.csv).  Summation order may differ between
+    # solutions: float32-rounding-level, inside every parity bound of tests/test_learner.py.
+    import torch.cuda.tunable as tunable
+    tunable.enable(True)
+    tunable.tuning_enable(True)
+    tunable.set_max_tuning_duration(20)
+    import tempfile
+    tunable.set_filename(os.path.join(tempfile.gettempdir(), 'mz_tunableop_%d.csv' % os.getpid()))      # (its exit-time dump: not into the cwd)
 
   # learners.py:62-70
   def load_state(self, state):
@@ -718,6 +724,7 @@ class Learner(Logger):
       else:
         if self._graph is None or not self._graph.fits(host):
           self.flush_priorities()
+          self._tune_gemms()
           self._graph = _GraphedUpdate(self, host)
         slot = self._graph.launch(host)
         getter = self._graph.errors
