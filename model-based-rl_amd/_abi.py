@@ -138,6 +138,7 @@ SIGNATURES = {
     'mz_fcl_errors': (_I, [_VP, _I, _VP]),
     'mz_fcl_read_grad': (_I, [_VP, _VP, _SZ]),
     'mz_fcl_read_tape': (C.c_longlong, [_VP, _I, _VP, _SZ]),
+    'mz_fcl_heads_profile': (_I, [_VP, _I, _VP]),
     'mz_selfplay_steps': (_I, [_VP, _I, _VP]),
     'mz_selfplay_steps_timed': (_I, [_VP, _I, _VP, _VP]),
     'mz_selfplay_phase_profile': (_I, [_VP, _I, _VP, _VP]),

@@ -51,6 +51,7 @@ struct FclView {
   float *a1h, *d2h, *d1h, *dH, *lossb;                 // head tapes, [3][K + 1][...][R]
   float *lnpart;                                        // [bs / 4][128] LayerNorm weight / bias gradient partials (per chain workgroup)
   float *new_errors;
+  unsigned long long *prof;      // development: s_memtime stamps of k_fcl_heads' phases (workgroup 0 of every head at position 1), else null
 };
 
 // workgroup barrier that waits for this wave's LDS traffic only: the tapes are write-only inside a kernel, so a barrier need
@@ -214,6 +215,41 @@ __device__ __forceinline__ void fcl_mask_out(const f32x4 acc[4], const f32x4 msk
 }
 
 // ------------------------------------------------------------------------------------------------ chain, forward
+// Weights of one layer in registers, requested a phase ahead of their use (scripts/fcl_heads_phases.py: streamed inside the
+// phase, the four layers' first requests were four exposed L2 round trips of ~1.5 k cycles in a 17 us workgroup).  Up to 16
+// k-steps; the guards are wave-uniform.
+__device__ __forceinline__ void fcl_req_wide(f32x4 (&W)[16], const f32x4 *__restrict__ pk, int ks, int w, int lane) {
+  const f32x4 *p = pk + (size_t)w * FCL_KSA(ks) * 64 + lane;
+#pragma unroll
+  for (int s = 0; s < 16; ++s)
+    if (s < ks) W[s] = p[s * 64];
+}
+__device__ __forceinline__ void fcl_wide_regs(const f32x4 (&W)[16], int ks, const float *X, int lane, f32x4 acc[4]) {
+  const float *x = X + 4 * (lane & 15) + (lane >> 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    if (s < ks) {
+      const float xs = x[s * 64];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = fcl_mfma(W[s][i], xs, acc[i]);
+    }
+  }
+}
+
+// sum / max over the 32 lanes of a sample: four DPP exchanges inside the 16-lane rows and one cross-row shuffle (a
+// ds_bpermute per step, as __shfl_xor compiles to, is a dependent LDS round trip each)
+template <int OFF> __device__ __forceinline__ float fcl_xchg(float x) { return __int_as_float(mz_xchg_i<OFF>(__float_as_int(x))); }
+__device__ __forceinline__ float fcl_sum32(float x) {
+  x += fcl_xchg<1>(x); x += fcl_xchg<2>(x); x += fcl_xchg<4>(x); x += fcl_xchg<8>(x);
+  return x + __shfl_xor(x, 16, 32);
+}
+__device__ __forceinline__ float fcl_max32(float x) {
+  x = fmaxf(x, fcl_xchg<1>(x)); x = fmaxf(x, fcl_xchg<2>(x)); x = fmaxf(x, fcl_xchg<4>(x)); x = fmaxf(x, fcl_xchg<8>(x));
+  return fmaxf(x, __shfl_xor(x, 16, 32));
+}
+
 // ------------------------------------------------------------------------------------------------ heads
 // grid (bs / 16, K + 1, 3): head 0 value (input h_p), 1 policy (h_p), 2 reward (x_p = [h_{p-1} | one-hot], p >= 1)
 __global__ __launch_bounds__(FCL_THREADS, 4) void k_fcl_heads(FclView v) {
@@ -223,9 +259,17 @@ __global__ __launch_bounds__(FCL_THREADS, 4) void k_fcl_heads(FclView v) {
   const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, g4 = lane >> 4, m16 = lane & 15;
   const int row0 = blockIdx.x * 16, p = blockIdx.y, hd = blockIdx.z, R = v.R, K1 = v.K + 1, loff = fcl_lane_off(lane), cb = blockIdx.x;
   if (hd == 2 && p == 0) return;
+  int stamp_i = 0;
+#define FCL_STAMP() if (v.prof && blockIdx.x == 0 && p == 1 && tid == 0) v.prof[hd * 16 + stamp_i++] = __builtin_amdgcn_s_memtime();
+  FCL_STAMP()
   const size_t T64 = (size_t)64 * R, T512 = (size_t)512 * R, TX = (size_t)v.XR * R;
   const FclPack &pk = v.head[hd];
   const size_t hp = (size_t)hd * K1 + p;
+  // the layers' weights pass through ONE set of 16 registers per lane, each layer's requested as soon as the previous
+  // layer's products have been issued (the compiler barriers keep the requests from being hoisted above those products,
+  // which would need a second register set: 128 registers is what two workgroups per CU leave); fc1's now
+  f32x4 WA[16];
+  fcl_req_wide(WA, (const f32x4 *)(v.pk + pk.F1), pk.ks1, w, lane);
   const float *src = hd == 2 ? v.xin + (size_t)p * TX : v.h + (size_t)p * T64;
   for (int idx = tid; idx < 64 * 16; idx += FCL_THREADS) {
     const int f = idx >> 4, n = idx & 15;
@@ -246,14 +290,25 @@ __global__ __launch_bounds__(FCL_THREADS, 4) void k_fcl_heads(FclView v) {
   const double wb = v.w_f64 ? ((const double *)v.w)[row_s] : (double)((const float *)v.w)[row_s];
   const float tv0 = v.t_val[(size_t)row_s * K1];
   fcl_bar();
+  FCL_STAMP()      // 1: inputs in LDS
   f32x4 acc[4];
-  fcl_wide<4>((const f32x4 *)(v.pk + pk.F1), pk.ks1, X, w, lane, acc);
+  fcl_wide_regs(WA, pk.ks1, X, lane, acc);
+  asm volatile("" ::: "memory");
+  fcl_load_narrow(WA, (const f32x4 *)(v.pk + pk.F2), w, lane);          // fc2's, under the epilogue
+  FCL_STAMP()      // 2: fc1 products
   fcl_fc1_out(acc, PV, A1, v.a1h + hp * T512 + fcl_tp(512, cb, 0, 0), loff, w, lane);
   fcl_bar();
-  fcl_narrow_nt(pk.nt, (const f32x4 *)(v.pk + pk.F2), A1, red, w, lane);
+  FCL_STAMP()      // 3: fc1 epilogue + barrier
+  if (pk.nt == 1) fcl_narrow_res<1>(WA, A1, red, w, lane);
+  else if (pk.nt == 2) fcl_narrow_res<2>(WA, A1, red, w, lane);
+  else fcl_narrow_res<4>(WA, A1, red, w, lane);
+  asm volatile("" ::: "memory");
+  fcl_req_wide(WA, (const f32x4 *)(v.pk + pk.B2), pk.ks2, w, lane);     // fc2-transposed's, under the reduce and the loss
   fcl_bar();
+  FCL_STAMP()      // 4: fc2 partials + barrier
   fcl_reduce(red, pk.nt, PV + 512, pk.mout, Y, tid);
   fcl_bar();
+  FCL_STAMP()      // 5: reduce + barrier
   // soft cross-entropy against the categorical target (utils.py:53-60; learners.py:186-203) and its gradient, 32 lanes per
   // sample, bins q and q + 32; the gradient of the weighted mean and the 1 / K hook (learners.py:205-212) ride in g
   {
@@ -263,15 +318,12 @@ __global__ __launch_bounds__(FCL_THREADS, 4) void k_fcl_heads(FclView v) {
       const FclTwoHot th = fcl_two_hot(ts, hd == 0 ? v.vmin : v.rmin, M, v.ntt);
       t0 = in0 ? fcl_two_hot_at(th, q) : 0.f; t1 = in1 ? fcl_two_hot_at(th, q + 32) : 0.f;
     }
-    float mx = fmaxf(x0, x1);
-    for (int o = 16; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 32));
+    const float mx = fcl_max32(fmaxf(x0, x1));
     const float e0 = in0 ? expf(x0 - mx) : 0.f, e1 = in1 ? expf(x1 - mx) : 0.f;
-    float sum = e0 + e1, tsum = t0 + t1;
-    float ex = e0 * (float)(v.vmin + q) + e1 * (float)(v.vmin + q + 32);
-    for (int o = 16; o >= 1; o >>= 1) { sum += __shfl_xor(sum, o, 32); tsum += __shfl_xor(tsum, o, 32); ex += __shfl_xor(ex, o, 32); }
+    const float sum = fcl_sum32(e0 + e1), tsum = fcl_sum32(t0 + t1);
+    const float ex = fcl_sum32(e0 * (float)(v.vmin + q) + e1 * (float)(v.vmin + q + 32));
     const float lse = mx + logf(sum);
-    float l = (in0 ? -t0 * (x0 - lse) : 0.f) + (in1 ? -t1 * (x1 - lse) : 0.f);
-    for (int o = 16; o >= 1; o >>= 1) l += __shfl_xor(l, o, 32);
+    const float l = fcl_sum32((in0 ? -t0 * (x0 - lse) : 0.f) + (in1 ? -t1 * (x1 - lse) : 0.f));
     const float g = (float)(((1.0 / (double)v.K) / (double)v.bs) * wb);
     S[fcl_at(q, n)] = in0 ? g * ((e0 / sum) * tsum - t0) : 0.f;
     S[fcl_at(q + 32, n)] = in1 ? g * ((e1 / sum) * tsum - t1) : 0.f;
@@ -289,12 +341,16 @@ __global__ __launch_bounds__(FCL_THREADS, 4) void k_fcl_heads(FclView v) {
     }
   }
   fcl_bar();
+  FCL_STAMP()      // 6: loss + barrier
   for (int idx = tid; idx < 64 * 16; idx += FCL_THREADS) {
     const int f = idx >> 4, n = idx & 15;
     v.d2h[hp * T64 + fcl_tp(64, cb, f, n)] = S[fcl_at(f, n)];
   }
   // backward: d a1 = W2^T d logits, through the ReLU; then d x = W1^T d a1 (its first 50 features: d hidden state)
-  fcl_wide<4>((const f32x4 *)(v.pk + pk.B2), pk.ks2, S, w, lane, acc);
+  fcl_wide_regs(WA, pk.ks2, S, lane, acc);
+  asm volatile("" ::: "memory");
+  fcl_load_narrow(WA, (const f32x4 *)(v.pk + pk.B1), w, lane);          // fc1-transposed's, under the mask
+  FCL_STAMP()      // 7: d2 tape + fc2-transposed products
   {
     f32x4 msk[4];
 #pragma unroll
@@ -302,14 +358,19 @@ __global__ __launch_bounds__(FCL_THREADS, 4) void k_fcl_heads(FclView v) {
     fcl_mask_out(acc, msk, A1, v.d1h + hp * T512 + fcl_tp(512, cb, 0, 0), loff, w, lane);
   }
   fcl_bar();
-  fcl_narrow<4>((const f32x4 *)(v.pk + pk.B1), A1, red, w, lane);
+  FCL_STAMP()      // 8: mask + barrier
+  fcl_narrow_res<4>(WA, A1, red, w, lane);
   fcl_bar();
+  FCL_STAMP()      // 9: fc1-transposed partials + barrier
   fcl_reduce(red, 4, nullptr, MZ_H, Y, tid);
   fcl_bar();
+  FCL_STAMP()      // 10: reduce + barrier
   for (int idx = tid; idx < 64 * 16; idx += FCL_THREADS) {
     const int f = idx >> 4, n = idx & 15;
     v.dH[hp * T64 + fcl_tp(64, cb, f, n)] = Y[fcl_at(f, n)];
   }
+  FCL_STAMP()        // 11: d hidden stored
+#undef FCL_STAMP
 }
 
 // ------------------------------------------------------------------------------------------------ chain (4 samples per workgroup)
