@@ -245,6 +245,14 @@ __device__ __forceinline__ float fcl_sum32(float x) {
   x += fcl_xchg<1>(x); x += fcl_xchg<2>(x); x += fcl_xchg<4>(x); x += fcl_xchg<8>(x);
   return x + __shfl_xor(x, 16, 32);
 }
+// sum over the 16 lanes of a wave that share lane & 3 (the chain kernels' sample j): lane bits 2..5 -- two row rotations
+// (DPP row_ror:4, row_ror:8: the four lanes of a 16-lane row with the same lane & 3), then the rows by shuffle
+__device__ __forceinline__ float fcl_sum_bits2to5(float x) {
+  x += __int_as_float(mz_dpp_i<0x124>(__float_as_int(x)));
+  x += __int_as_float(mz_dpp_i<0x128>(__float_as_int(x)));
+  x += __shfl_xor(x, 16, 64);
+  return x + __shfl_xor(x, 32, 64);
+}
 __device__ __forceinline__ float fcl_max32(float x) {
   x = fmaxf(x, fcl_xchg<1>(x)); x = fmaxf(x, fcl_xchg<2>(x)); x = fmaxf(x, fcl_xchg<4>(x)); x = fmaxf(x, fcl_xchg<8>(x));
   return fmaxf(x, __shfl_xor(x, 16, 32));
@@ -502,12 +510,12 @@ __global__ __launch_bounds__(FCL_THREADS) void k_fcl_chain_fwd4(FclView v) {
       float yv[4], s = 0.f;
 #pragma unroll
       for (int i = 0; i < 4; ++i) { yv[i] = (f0 + i < MZ_H) ? y[i] + b2[f0 + i] : 0.f; s += yv[i]; }
-      for (int o = 4; o <= 32; o <<= 1) s += __shfl_xor(s, o, 64);
+      s = fcl_sum_bits2to5(s);
       const float mean = s / (float)MZ_H;
       float d[4], var = 0.f;
 #pragma unroll
       for (int i = 0; i < 4; ++i) { d[i] = (f0 + i < MZ_H) ? yv[i] - mean : 0.f; var += d[i] * d[i]; }
-      for (int o = 4; o <= 32; o <<= 1) var += __shfl_xor(var, o, 64);
+      var = fcl_sum_bits2to5(var);
       const float rstd = 1.0f / sqrtf(var / (float)MZ_H + FCL_LN_EPS);
       const int act_p = acts[j * 8 + (p < 7 ? p : 7)];
       const size_t tp = fcl_tp(64, cb, f0, n0 + j);
@@ -593,7 +601,7 @@ __global__ __launch_bounds__(FCL_THREADS) void k_fcl_chain_bwd4(FclView v) {
         dx[i] = real ? gy[i] * lnw[f0 + i] : 0.f;
         s1 += dx[i]; s2 += dx[i] * xh[i];
       }
-      for (int o = 4; o <= 32; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+      s1 = fcl_sum_bits2to5(s1); s2 = fcl_sum_bits2to5(s2);
       const float inv = 1.f / (float)MZ_H;
       const size_t tp = fcl_tp(64, cb, f0, n0 + j);
 #pragma unroll
