@@ -340,8 +340,9 @@ int mz_fcl_read_grad(mz_fcl *c, float *host_out, size_t n);
  * 4 hidden states, 5 / 6 chain deltas, 7 head fc1 activations, 8 / 9 head deltas, 10 d loss / d hidden state per head, 11 per-sample
  * losses; [position][row / 16][feature][16 rows] each, heads [head][position]...); host_out null: returns the float count. */
 long long mz_fcl_read_tape(mz_fcl *c, int which, float *host_out, size_t n);
-/* development hook: s_memtime stamps (100 MHz) at the phase boundaries of k_fcl_heads, workgroup 0 of every head at unroll
- * position 1: enable = 1 arms it for the following steps, enable = 0 reads the 3 x 16 stamps of the last step into host_out [48]. */
+/* development hook: s_memtime stamps (shader clock) at the phase boundaries of k_fcl_heads, workgroup 0 of every head at unroll
+ * position 1 (3 x 16 slots), and of k_fcl_chain_fwd4's position 2 (slots 48..53): enable = 1 arms it for the following steps,
+ * enable = 0 reads the stamps of the last step into host_out [64]. */
 int mz_fcl_heads_profile(mz_fcl *c, int enable, unsigned long long *host_out);
 /* Which kernel mz_search / mz_selfplay_steps launch for this engine right now: out4 [host] = kind (0 the stand-alone
  * kernels, 1 k_search_fused, 2 k_search_h2), LDS placement of the trees (0 node pool, 1 whole trees in LDS, 2 compact in

@@ -483,7 +483,10 @@ __global__ __launch_bounds__(FCL_THREADS) void k_fcl_chain_fwd4(FclView v) {
     if (f < v.XR) v.xin[fcl_tp(v.XR, cb, f, n0 + n)] = val;
   }
   fcl_bar();
+  // (development: stamps of position 2's phases in workgroup 0, mz_fcl_heads_profile, slots 48..)
+#define FCL_CSTAMP(k) if (v.prof && blockIdx.x == 0 && p == 2 && tid == 0) v.prof[48 + (k)] = __builtin_amdgcn_s_memtime();
   auto rest = [&](int p, f32x4 acc, const float (&W2)[64], const float *b1, const float *b2) __attribute__((always_inline)) {
+    FCL_CSTAMP(1)      // fc1 products done
     {   // fc1 epilogue: bias, ReLU, to LDS (one 16-byte write: the lane's four features of its sample) and to the tape
       const int f0 = 64 * w + 4 * (lane >> 2);
       const f32x4 b = *(const f32x4 *)(b1 + f0);
@@ -497,8 +500,10 @@ __global__ __launch_bounds__(FCL_THREADS) void k_fcl_chain_fwd4(FclView v) {
       *(f32x4 *)(A1 + (lane & 3) * FCL_LDA + f0) = a;
     }
     fcl_bar();
+    FCL_CSTAMP(2)      // epilogue + barrier
     *(f32x4 *)(red + (w * 64 + lane) * 4) = fcl_quad_res<64>(W2, A1 + (lane & 3) * FCL_LDA + 64 * w);
     fcl_bar();
+    FCL_CSTAMP(3)      // fc2 partials + barrier
     if (w == 0) {
       // wave 0 alone: lane (b, j) adds up rows 4 b + i of the 8 partials, then LayerNorm + ReLU (networks.py:147,165) of
       // sample j across the 16 lanes that share it (shuffles over the lane bits 2..5), the tapes and the next input
@@ -533,7 +538,9 @@ __global__ __launch_bounds__(FCL_THREADS) void k_fcl_chain_fwd4(FclView v) {
       }
       if (lane < 4) v.rstd[(size_t)p * R + row0 + lane] = rstd;
     }
+    FCL_CSTAMP(4)      // wave 0: reduce + LayerNorm + tapes
     fcl_bar();
+    FCL_CSTAMP(5)      // barrier
   };
   {   // position 0: the representation, its weights streamed
     float WR2[64];
@@ -543,7 +550,11 @@ __global__ __launch_bounds__(FCL_THREADS) void k_fcl_chain_fwd4(FclView v) {
   }
   fcl_quad_settle(WT1);
   fcl_quad_settle(WT2);
-  for (int p = 1; p <= v.K; ++p) rest(p, fcl_quad_res<KP>(WT1, X + (lane & 3) * LDX), WT2, b1t, b2t);
+  for (int p = 1; p <= v.K; ++p) {
+    FCL_CSTAMP(0)
+    rest(p, fcl_quad_res<KP>(WT1, X + (lane & 3) * LDX), WT2, b1t, b2t);
+  }
+#undef FCL_CSTAMP
 }
 
 __global__ __launch_bounds__(FCL_THREADS) void k_fcl_chain_bwd4(FclView v) {

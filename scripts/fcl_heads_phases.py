@@ -1,5 +1,6 @@
 """development aid: where a k_fcl_heads workgroup spends its time (mz_fcl_heads_profile: s_memtime stamps at the phase
-boundaries, workgroup 0 of every head at unroll position 1; LunarLander shapes, batch 256, K = 5).  100 MHz ticks -> us."""
+boundaries, workgroup 0 of every head at unroll position 1, and of k_fcl_chain_fwd4's position 2; LunarLander shapes, batch
+256, K = 5).  Shader-clock cycles / 100."""
 import ctypes as C, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,18 +13,21 @@ lib, h = _abi.load(), learner._native.h
 _abi.check(lib.mz_fcl_heads_profile(h, 1, None), 'arm')
 names = ['inputs -> LDS', 'fc1 products', 'fc1 epilogue + barrier', 'fc2 partials + barrier', 'reduce + barrier', 'loss + barrier',
          'd2 tape + fc2^T products', 'mask + barrier', 'fc1^T partials + barrier', 'reduce + barrier', 'd hidden stored']
-acc = np.zeros((3, 11))
+acc = np.zeros((3, 11)); cacc = np.zeros(5)
 N = 20
 for _ in range(N):
   ls.loop(learner, replay, 3)
-  out = np.zeros(48, np.uint64)
-  _abi.check(lib.mz_fcl_heads_profile(h, 0 if False else 0, out.ctypes.data_as(C.c_void_p)), 'read') if False else None
   torch.cuda.synchronize()
-  buf = np.zeros(48, np.uint64)
+  buf = np.zeros(64, np.uint64)
   _abi.check(lib.mz_fcl_heads_profile(h, 0, buf.ctypes.data_as(C.c_void_p)), 'read')
-  st = buf.reshape(3, 16).astype(np.float64)
+  st = buf[:48].reshape(3, 16).astype(np.float64)
   acc += np.diff(st[:, :12], axis=1) / 100.0
+  cacc += np.diff(buf[48:54].astype(np.float64)) / 100.0
 acc /= N
 for i, nme in enumerate(names):
-  print('%-28s value %6.2f  policy %6.2f  reward %6.2f us' % (nme, acc[0, i], acc[1, i], acc[2, i]))
-print('%-28s value %6.2f  policy %6.2f  reward %6.2f us' % ('total', acc[0].sum(), acc[1].sum(), acc[2].sum()))
+  print('%-28s value %6.2f  policy %6.2f  reward %6.2f' % (nme, acc[0, i], acc[1, i], acc[2, i]))
+print('%-28s value %6.2f  policy %6.2f  reward %6.2f (x 100 cycles)' % ('total', acc[0].sum(), acc[1].sum(), acc[2].sum()))
+cacc /= N
+for nme, x in zip(['fc1 products', 'epilogue + barrier', 'fc2 partials + barrier', 'wave 0: reduce + LayerNorm + tapes', 'barrier'], cacc):
+  print('chain fwd position 2: %-36s %6.2f' % (nme, x))
+print('chain fwd position 2: total %6.2f (x 100 cycles)' % cacc.sum())
