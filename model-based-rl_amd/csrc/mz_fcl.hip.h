@@ -446,8 +446,8 @@ __device__ __forceinline__ f32x4 fcl_quad_stream(const float *__restrict__ pk, i
   return (acc[0] + acc[1]) + (acc[2] + acc[3]);
 }
 
-// LDS of the 4-sample chain kernels (floats), activations SAMPLE-major: X [4][xq + 4] | A1 [4][516] | red [2048] | misc [16] | PV [1408]
-#define FCL_LDS4_FLOATS(xq) (4 * ((xq) + 4) + 4 * 516 + 2048 + 16 + 1408)
+// LDS of the 4-sample chain kernels (floats), activations SAMPLE-major: X [4][xq + 4] | A1 [4][516] | red [2048] | misc [16] | PV [1408] | S [256]
+#define FCL_LDS4_FLOATS(xq) (4 * ((xq) + 4) + 4 * 516 + 2048 + 16 + 1408 + 256)
 #define FCL_LDA 516
 
 // D fragment (rows 64 w + 4 b + i, sample j) -> tape [chunk][feature][16]: wave-uniform base + one lane offset + i * 16
@@ -461,9 +461,12 @@ __global__ __launch_bounds__(FCL_THREADS) void k_fcl_chain_fwd4(FclView v) {
   float *X = fcl_smem, *A1 = X + 4 * LDX, *red = A1 + 4 * FCL_LDA, *misc = red + 2048, *PV = misc + 16;
   float *b1r = PV, *b1t = PV + 512, *b2r = PV + 1024, *b2t = PV + 1088, *lnw = PV + 1152, *lnb = PV + 1216;
   int *acts = (int *)(PV + 1280);          // [4 samples][8]
+  float *S = PV + 1408;                    // [4 samples][64] x-hat of the position just finished (for the tapes)
   const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int cb = blockIdx.x >> 2, n0 = 4 * (blockIdx.x & 3), row0 = blockIdx.x * 4, R = v.R, loff = fcl_lane_off4(lane, n0);
   const size_t T64 = (size_t)64 * R, T512 = (size_t)512 * R, TX = (size_t)v.XR * R;
+#define FCL_KSTAMP(k) if (v.prof && blockIdx.x == 0 && tid == 0) v.prof[54 + (k)] = __builtin_amdgcn_s_memtime();
+  FCL_KSTAMP(0)      // kernel start
   float WT1[KP], WT2[64];
   fcl_quad_load<KP>(WT1, v.pk + v.tr.F1 + (size_t)w * KP * 64, lane);
   fcl_quad_load<64>(WT2, v.pk + v.tr.F2 + (size_t)w * 64 * 64, lane);
@@ -483,6 +486,7 @@ __global__ __launch_bounds__(FCL_THREADS) void k_fcl_chain_fwd4(FclView v) {
     if (f < v.XR) v.xin[fcl_tp(v.XR, cb, f, n0 + n)] = val;
   }
   fcl_bar();
+  FCL_KSTAMP(1)      // requests out, observations in LDS
   // (development: stamps of position 2's phases in workgroup 0, mz_fcl_heads_profile, slots 48..)
 #define FCL_CSTAMP(k) if (v.prof && blockIdx.x == 0 && p == 2 && tid == 0) v.prof[48 + (k)] = __builtin_amdgcn_s_memtime();
   auto rest = [&](int p, f32x4 acc, const float (&W2)[64], const float *b1, const float *b2) __attribute__((always_inline)) {
@@ -523,24 +527,33 @@ __global__ __launch_bounds__(FCL_THREADS) void k_fcl_chain_fwd4(FclView v) {
       var = fcl_sum_bits2to5(var);
       const float rstd = 1.0f / sqrtf(var / (float)MZ_H + FCL_LN_EPS);
       const int act_p = acts[j * 8 + (p < 7 ? p : 7)];
-      const size_t tp = fcl_tp(64, cb, f0, n0 + j);
+      f32x4 xv4, xh4;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int f = f0 + i;
-        const float xh = d[i] * rstd;
-        const float hv = f < MZ_H ? fmaxf(xh * lnw[f] + lnb[f], 0.f) : 0.f;
+        xh4[i] = d[i] * rstd;
+        const float hv = f < MZ_H ? fmaxf(xh4[i] * lnw[f] + lnb[f], 0.f) : 0.f;
         // the next input: [h | one-hot(action) | 0]  (networks.py:167-174); past the last transition: no action
-        const float xv = f < MZ_H ? hv : ((p < v.K && f - MZ_H == act_p) ? 1.f : 0.f);
-        X[j * LDX + f] = xv;
-        v.xhat[(size_t)p * T64 + tp + i * 16] = xh;
-        v.h[(size_t)p * T64 + tp + i * 16] = hv;
-        if (p < v.K) v.xin[(size_t)(p + 1) * TX + fcl_tp(v.XR, cb, f, n0 + j)] = xv;
+        xv4[i] = f < MZ_H ? hv : ((p < v.K && f - MZ_H == act_p) ? 1.f : 0.f);
       }
-      if (lane < 4) v.rstd[(size_t)p * R + row0 + lane] = rstd;
+      *(f32x4 *)(X + j * LDX + f0) = xv4;
+      *(f32x4 *)(S + j * 64 + f0) = xh4;
+      if (lane < 4) misc[lane] = rstd;
     }
-    FCL_CSTAMP(4)      // wave 0: reduce + LayerNorm + tapes
+    FCL_CSTAMP(4)      // wave 0: reduce + LayerNorm
     fcl_bar();
     FCL_CSTAMP(5)      // barrier
+    // the tapes of this position, by the upper half of the workgroup (wave 0 above is the serial part: seven waves wait for
+    // it); X, S and misc are next written three barriers from here
+    if (tid >= 256) {
+      const int t = tid - 256, f = t >> 2, n = t & 3;
+      const float xv = X[n * LDX + f];
+      const size_t tp = fcl_tp(64, cb, f, n0 + n);
+      v.xhat[(size_t)p * T64 + tp] = S[n * 64 + f];
+      v.h[(size_t)p * T64 + tp] = f < MZ_H ? xv : 0.f;
+      if (p < v.K) v.xin[(size_t)(p + 1) * TX + fcl_tp(v.XR, cb, f, n0 + n)] = xv;
+      if (t < 4) v.rstd[(size_t)p * R + row0 + t] = misc[t];
+    }
   };
   {   // position 0: the representation, its weights streamed
     float WR2[64];
@@ -548,13 +561,17 @@ __global__ __launch_bounds__(FCL_THREADS) void k_fcl_chain_fwd4(FclView v) {
     const f32x4 acc = fcl_quad_stream(v.pk + v.rep.F1 + (size_t)w * v.O * 64, v.O, X + (lane & 3) * LDX, lane);
     rest(0, acc, WR2, b1r, b2r);
   }
+  FCL_KSTAMP(2)      // position 0 done
   fcl_quad_settle(WT1);
   fcl_quad_settle(WT2);
+  FCL_KSTAMP(3)      // the transition's weights have arrived
   for (int p = 1; p <= v.K; ++p) {
     FCL_CSTAMP(0)
     rest(p, fcl_quad_res<KP>(WT1, X + (lane & 3) * LDX), WT2, b1t, b2t);
   }
 #undef FCL_CSTAMP
+  FCL_KSTAMP(4)        // positions 1..K done
+#undef FCL_KSTAMP
 }
 
 __global__ __launch_bounds__(FCL_THREADS) void k_fcl_chain_bwd4(FclView v) {
@@ -614,13 +631,10 @@ __global__ __launch_bounds__(FCL_THREADS) void k_fcl_chain_bwd4(FclView v) {
       }
       s1 = fcl_sum_bits2to5(s1); s2 = fcl_sum_bits2to5(s2);
       const float inv = 1.f / (float)MZ_H;
-      const size_t tp = fcl_tp(64, cb, f0, n0 + j);
+      f32x4 dy;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float dy = (f0 + i < MZ_H) ? rstd * (dx[i] - s1 * inv - xh[i] * (s2 * inv)) : 0.f;
-        D2[j * LDX + f0 + i] = dy;
-        v.d2c[(size_t)p * T64 + tp + i * 16] = dy;
-      }
+      for (int i = 0; i < 4; ++i) dy[i] = (f0 + i < MZ_H) ? rstd * (dx[i] - s1 * inv - xh[i] * (s2 * inv)) : 0.f;
+      *(f32x4 *)(D2 + j * LDX + f0) = dy;
     }
     if (p > 0) request(p - 1);
     const float *a1t = v.a1c + (size_t)p * T512 + fcl_tp(512, cb, 64 * w, 0);
@@ -628,6 +642,10 @@ __global__ __launch_bounds__(FCL_THREADS) void k_fcl_chain_bwd4(FclView v) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) msk[i] = (a1t + i * 16)[loff];
     fcl_bar();
+    if (tid >= 256) {      // the delta tape of this position, by the upper half of the workgroup (D2 is next written three barriers on)
+      const int t = tid - 256;
+      v.d2c[(size_t)p * T64 + fcl_tp(64, cb, t >> 2, n0 + (t & 3))] = D2[(t & 3) * LDX + (t >> 2)];
+    }
     const f32x4 acc = fcl_quad_res<MZ_H>(W2, D2 + (lane & 3) * LDX);
     {
       const int g0 = 64 * w + 4 * (lane >> 2);

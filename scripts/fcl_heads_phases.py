@@ -13,7 +13,7 @@ lib, h = _abi.load(), learner._native.h
 _abi.check(lib.mz_fcl_heads_profile(h, 1, None), 'arm')
 names = ['inputs -> LDS', 'fc1 products', 'fc1 epilogue + barrier', 'fc2 partials + barrier', 'reduce + barrier', 'loss + barrier',
          'd2 tape + fc2^T products', 'mask + barrier', 'fc1^T partials + barrier', 'reduce + barrier', 'd hidden stored']
-acc = np.zeros((3, 11)); cacc = np.zeros(5)
+acc = np.zeros((3, 11)); cacc = np.zeros(5); kacc = np.zeros(4)
 N = 20
 for _ in range(N):
   ls.loop(learner, replay, 3)
@@ -23,6 +23,7 @@ for _ in range(N):
   st = buf[:48].reshape(3, 16).astype(np.float64)
   acc += np.diff(st[:, :12], axis=1) / 100.0
   cacc += np.diff(buf[48:54].astype(np.float64)) / 100.0
+  kacc += np.diff(buf[54:59].astype(np.float64)) / 100.0
 acc /= N
 for i, nme in enumerate(names):
   print('%-28s value %6.2f  policy %6.2f  reward %6.2f' % (nme, acc[0, i], acc[1, i], acc[2, i]))
@@ -31,3 +32,6 @@ cacc /= N
 for nme, x in zip(['fc1 products', 'epilogue + barrier', 'fc2 partials + barrier', 'wave 0: reduce + LayerNorm + tapes', 'barrier'], cacc):
   print('chain fwd position 2: %-36s %6.2f' % (nme, x))
 print('chain fwd position 2: total %6.2f (x 100 cycles)' % cacc.sum())
+kacc /= N
+for nme, x in zip(['start -> requests out, observations in LDS', 'position 0', 'wait for the resident weights', 'positions 1..K'], kacc):
+  print('chain fwd kernel: %-44s %7.2f' % (nme, x))
