@@ -28,10 +28,12 @@ def setup(extra):
   return cfg, storage, replay, Learner(cfg, storage, replay)
 
 def loop(learner, replay, n):
-  """Learner._learn_loop's body: batches sampled ahead on the replay's own thread (_BatchSource), priority refreshes
-  fire-and-forget, one update behind"""
+  """Learner._learn_loop's body: batches through _BatchSource (a plain replay: sampled in this thread, two per native call;
+  MZ_LS_HANDLE=1: through a rayshim handle, i.e. on the replay's own thread as under train.py), priority refreshes one update behind"""
   from model_based_rl_amd.learners import _BatchSource
-  src = _BatchSource(replay, 4) if not os.environ.get('MZ_LS_NO_PREFETCH') else None
+  from model_based_rl_amd import rayshim
+  target = rayshim._Handle(replay) if os.environ.get('MZ_LS_HANDLE') else replay
+  src = _BatchSource(target, int(os.environ.get('MZ_LS_DEPTH', '4'))) if not os.environ.get('MZ_LS_NO_PREFETCH') else None
   learner._source = src
   ts = [0.0, 0.0]
   t0 = time.perf_counter()
@@ -42,11 +44,15 @@ def loop(learner, replay, n):
   learner.flush_priorities()
   torch.cuda.synchronize()
   if src: src.close()
+  if target is not replay:
+    target._q.put((None, (), {}, None)); target._t.join(timeout=5)
   learner._source = None
   dt = time.perf_counter() - t0
   return {'updates_per_second': n / dt, 'batch_wait_ms': 1e3 * ts[0] / n, 'update_call_ms': 1e3 * ts[1] / n}
 
 def main():
+  if os.environ.get('MZ_SWITCH_INTERVAL'):          # experiment: the interpreter's thread switch interval (default 5 ms)
+    sys.setswitchinterval(float(os.environ['MZ_SWITCH_INTERVAL']))
   out = {}
   variants = (('native', []), ('graph', ['--no_native_learner']), ('eager', ['--no_graph_learner']))
   if os.environ.get('MZ_LS_ONLY'):
