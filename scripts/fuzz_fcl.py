@@ -1,7 +1,8 @@
 """Randomised sweep of the native learner step (mz_fcl_step, csrc/mz_fcl.hip.h) over its shape space: batch 16..160 (multiples
 of 16), K 1..7, 1..14 actions, 1..300 observation features, supports of 3..64 bins, with / without the target transform,
 float32 / float64 importance weights, int32 / int64 actions -- every parameter's gradient, the priority refresh and the loss
-sums against PyTorch autograd on the same parameters and batch (the criteria of tests/test_learner.py).
+sums against PyTorch autograd on the same parameters and batch with the native run's ReLU patterns (tests/test_learner.py:
+masked_reference -- every entry within 2e-5 of its tensor's scale).
 usage: fuzz_fcl.py [configurations] [seed]"""
 import os, sys, tempfile, time
 import numpy as np, torch
@@ -10,7 +11,7 @@ sys.path.insert(0, ROOT)
 import model_based_rl_amd
 from model_based_rl_amd.config import make_config
 from model_based_rl_amd.learners import Learner, _NativeFC, _GraphedUpdate
-from tests.test_learner import _random_batch, Sink
+from tests.test_learner import _random_batch, Sink, grads_close, masked_reference
 
 n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -38,28 +39,19 @@ for it in range(n_cfg):
   if rng.integers(0, 2): host['act'] = host['act'].astype(np.int32)
   assert _NativeFC.eligible(learner, host), (bs, K, A, O)
   dev = [torch.from_numpy(host[k]).to(learner.device) for k in _GraphedUpdate.ORDER]
-  tdev = list(dev); tdev[1] = dev[1].to(torch.int64)
-  new_errors, rl, vl, pl = learner._device_step_fc(*tdev)
-  w = dev[-1]
-  losses = [(w * rl).mean(), (w * vl).mean(), (w * pl).mean()]
-  total = losses[0] + losses[1] + losses[2]
-  total.register_hook(lambda grad: grad * (1 / K))
-  total.backward()
-  want = {k: p.grad.detach().cpu().clone() for k, p in net.named_parameters()}
   nat = _NativeFC(learner, host)
   learner._loss_dev.zero_()
   got_errors = nat.step(*dev, no_update=True)
   got = nat.grad()
-  worst = 0.0
-  for k in want:
-    scale = float(want[k].abs().max()) + 1e-12
-    d = (got[k] - want[k]).abs().reshape(-1).numpy() / scale
-    worst = max(worst, float(np.quantile(d, 0.999)))
-    assert np.quantile(d, 0.999) <= 5e-4 + 1e-9 / scale, (it, k, bs, K, A, O, float(np.quantile(d, 0.999)))
-    assert float((got[k] - want[k]).norm()) <= 1e-2 * float(want[k].norm()) + 1e-9, (it, k, bs, K, A, O)
+  got_l = learner._loss_dev.tolist()
+  try:
+    want, new_errors, losses = masked_reference(learner, nat, dev)
+    worst = grads_close(got, want)
+  except AssertionError as e:
+    raise AssertionError((it, bs, K, A, O) + tuple(e.args))
   assert (got_errors - new_errors).abs().max().item() <= 2e-4 * (1 + new_errors.abs().max().item()), (it, bs, K, A, O)
-  for a_, b_ in zip(learner._loss_dev.tolist(), [float(x.detach()) for x in losses]):
+  for a_, b_ in zip(got_l, losses):
     assert abs(a_ - b_) <= 1e-5 * max(1.0, abs(b_)), (it, bs, K, A, O)
   worst_all = max(worst_all, worst)
   nat.close()
-print('%d configurations agree with autograd (worst 99.9th-percentile relative gradient difference %.2g), %.0f s' % (n_cfg, worst_all, time.time() - t0))
+print('%d configurations agree with autograd (worst relative gradient difference of any entry %.2g), %.0f s' % (n_cfg, worst_all, time.time() - t0))
