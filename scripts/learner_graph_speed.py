@@ -2,7 +2,10 @@
 hipGraph; the default) against the PyTorch step captured in one hipGraph (--no_native_learner) and against eager PyTorch
 launches (--no_graph_learner), FCNetwork, batch 256, K = 5 (reference learners.py:164-230).  The loop is
 Learner.learn's: sample_batch from the native replay, update_weights with the priority refresh one update behind.
-usage: learner_graph_speed.py [out.json]"""
+usage: learner_graph_speed.py [out.json]
+environment: MZ_LS_ONLY=native,graph,eager (variants to run); MZ_LS_HANDLE=1 (the replay behind a rayshim handle, as under
+train.py: sampled on its own thread); MZ_LS_NO_PREFETCH=1 (no batch source: one sample_batch_arrays call per update);
+MZ_LS_DEPTH (batches in flight on a handle, default 4); MZ_SWITCH_INTERVAL (the interpreter's thread switch interval)."""
 import json, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
