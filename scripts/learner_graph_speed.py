@@ -1,5 +1,5 @@
-"""Learner updates per second on an idle GPU: the native step (mz_fcl_step: six HIP launches per update, captured in one
-hipGraph; the default) against the PyTorch step captured in one hipGraph (--no_native_learner) and against eager PyTorch
+"""Learner updates per second on an idle GPU: the native step (mz_fcl_update: five HIP launches per update, no graph;
+the default) against the PyTorch step captured in one hipGraph (--no_native_learner) and against eager PyTorch
 launches (--no_graph_learner), FCNetwork, batch 256, K = 5 (reference learners.py:164-230).  The loop is
 Learner.learn's: sample_batch from the native replay, update_weights with the priority refresh one update behind.
 usage: learner_graph_speed.py [out.json]
