@@ -48,11 +48,12 @@ def main(args):
   def move(m, timing=None):
     eng.root_load(val[SIMS], lg[SIMS])
     eng.root_prepare(None, None, None, device_rng=True, move=m)
+    sel = eng.select()
     for s in range(SIMS):
-      leaf, slot, action, depth = eng.select()
-      eng.expand_backup(val[s], rew[s], lg[s])
       if timing is not None:
-        depth_sum.add_(depth.long())
+        depth_sum.add_(sel[3].long())
+      # expand + backup of this simulation and the descent of the next in one launch (mz_expand_backup_select)
+      sel = eng.expand_backup_select(val[s], rew[s], lg[s], last=(s + 1 == SIMS))
 
   for m in range(warmup):
     move(m)
@@ -82,12 +83,12 @@ def main(args):
   both = (bytes_sel + bytes_exb) / ((sel_us + exb_us) * 1e-6) / 1e9
   NN = 1 + (SIMS + 1) * A
   traffic = None
-  tfile = os.path.join(ROOT, 'profiles', 'r04_a_tree_traffic.json')      # (FETCH_SIZE / WRITE_SIZE passes of this command, builder-run)
+  tfile = os.path.join(ROOT, 'profiles', 'r04_b_tree_traffic.json')      # (FETCH_SIZE / WRITE_SIZE passes of this command, builder-run)
   if os.path.exists(tfile) and B == 4096:
     traffic = json.load(open(tfile))
 
   out = {
-      'metric': 'MCTS sims/sec/GPU (tree kernels alone: mz_select + mz_expand_backup, network outputs replayed)',
+      'metric': 'MCTS sims/sec/GPU (tree kernels alone: mz_expand_backup_select, network outputs replayed)',
       'value': B * SIMS * moves / dt, 'unit': 'simulations/s', 'n_gpus': 1, 'steps': moves, 'warmup': warmup,
       'ms_per_step': 1e3 * dt / moves, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
       'dtype': 'f64 tree arithmetic (i32 / f64 / f32 node fields)', 'data': 'synthetic', 'secondary_line': True,
@@ -96,8 +97,10 @@ def main(args):
                  'envs_per_gpu': B, 'num_simulations': SIMS, 'mean_leaf_depth': d_mean,
                  'working_set_bytes': B * ((NN + 3 + 3) // 4 * 4) * 32 + B * (SIMS + 2) * 4,
                  'node_pool': '32-byte node records (W f64, P f64, N i32, E i32, R f32, to_play i8): the A children of a node are 32 A contiguous bytes',
-                 'note': 'one step = one move = %d x (k_tree_select, k_tree_expand_backup) + root; wall time includes the '
-                         'launch gaps of %d dependent launches per move' % (SIMS, 2 * SIMS + 3)},
+                 'note': 'one step = one move = root + %d x k_tree_step_ext (expand + backup + the next descent in one launch, '
+                         'mz_expand_backup_select); wall time includes the launch gaps of %d dependent launches per move; the per-kernel '
+                         'figures below clock the two stand-alone kernels (mz_select, mz_expand_backup) on their own dispatches' % (SIMS, SIMS + 3),
+                 'us_per_simulation_wall': 1e6 * dt / moves / SIMS},
       'env_steps_per_s': B * moves / dt,
       'roofline': {'bound': 'hbm', 'kernel': 'k_tree_select + k_tree_expand_backup (pair)', 'achieved': both, 'peak': HBM_TBPS * 1e3,
                    'unit': 'GB/s', 'frac': both / (HBM_TBPS * 1e3), 'traffic': traffic,
@@ -114,7 +117,9 @@ def main(args):
                               'each (one 16-lane group per tree), %.0f KB of algorithmic traffic per launch in %.1f us; what '
                               'bounds them is the chain of dependent cache round trips and the %.1f us launch floor, not bytes' %
                               (bytes_sel / 1e3, sel_us, 1.5),
-                   'hbm_side_traffic': ({'source': 'profiles/r04_a_tree_traffic.json: FETCH_SIZE / WRITE_SIZE passes of this command',
+                   'hbm_side_traffic': ({'source': 'profiles/r04_b_tree_traffic.json: FETCH_SIZE / WRITE_SIZE passes of this command',
+                                         'k_tree_step_ext_fetched_over_algorithmic_of_the_pair': (traffic['k_tree_step_ext']['hbm_bytes_per_launch'] / (bytes_sel + bytes_exb)
+                                                                                                     if 'k_tree_step_ext' in traffic else None),
                                          'k_tree_select_fetched_over_algorithmic': traffic['k_tree_select']['hbm_bytes_per_launch'] / bytes_sel,
                                          'k_tree_expand_backup_fetched_over_algorithmic': traffic['k_tree_expand_backup']['hbm_bytes_per_launch'] / bytes_exb}
                                         if traffic and 'k_tree_select' in traffic else None),

@@ -176,6 +176,12 @@ int mz_tree_pair_timed(mz_engine *e, const float *value, const float *reward, co
                        void *stream);
 int mz_expand_backup(mz_engine *e, const float *value, const float *reward, const float *logits,
                      const float *hidden, void *stream);
+/* mz_expand_backup followed by the next simulation's mz_select (mcts.py:97-99 then 83-94 of the next iteration) in ONE launch:
+ * the descent reads the lines the backup has just written from cache, and a simulation of an external network costs one tree
+ * launch instead of three.  Same arguments as mz_expand_backup, then mz_select's outputs (any may be null).  At a move's
+ * last simulation there is no next descent: it is mz_expand_backup alone and the outputs are left untouched. */
+int mz_expand_backup_select(mz_engine *e, const float *value, const float *reward, const float *logits, const float *hidden,
+                            int32_t *leaf_node, int32_t *parent_slot, int32_t *action, int32_t *depth, void *stream);
 
 /* BaseNetwork.recurrent_inference (networks.py:31-34) on arbitrary rows, outside any tree:
  * hidden_in [dev][n][50], action [dev][n] int32 -> hidden_out [dev][n][50], reward/value [dev][n],

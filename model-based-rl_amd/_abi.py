@@ -109,6 +109,7 @@ SIGNATURES = {
     'mz_gather_hidden': (_I, [_VP, _VP, _VP]),
     'mz_tree_pair_timed': (_I, [_VP, _VP, _VP, _VP, _VP, _VP]),
     'mz_expand_backup': (_I, [_VP, _VP, _VP, _VP, _VP, _VP]),
+    'mz_expand_backup_select': (_I, [_VP] * 10),
     'mz_recurrent_inference': (_I, [_VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP]),
     'mz_finalize': (_I, [_VP, _VP, _VP, _U64, _VP, _VP, _VP, _VP, _VP, _VP]),
     'mz_export_tree': (_I, [_VP] * 11),

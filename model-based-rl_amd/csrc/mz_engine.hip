@@ -1470,6 +1470,25 @@ int mz_expand_backup(mz_engine *e, const float *value, const float *reward, cons
   return 0;
 }
 
+int mz_expand_backup_select(mz_engine *e, const float *value, const float *reward, const float *logits, const float *hidden,
+                            int32_t *leaf_node, int32_t *parent_slot, int32_t *action, int32_t *depth, void *stream) {
+  if (!e || !value || !reward || !logits) return fail("mz_expand_backup_select: null argument");
+  MZ_ENTER(e);
+  if (!e->selection_valid) return fail("mz_expand_backup_select: call mz_select first");
+  if (e->sims_done + 1 >= e->sims)        // the move's last simulation: nothing to descend for
+    return mz_expand_backup(e, value, reward, logits, hidden, stream);
+  hipStream_t s = (hipStream_t)stream;
+  if (hidden) {
+    const int n = e->B * MZ_HS;
+    hipLaunchKernelGGL(k_scatter_hidden, dim3((n + 255) / 256), dim3(256), 0, s, e->tv, hidden, 0);
+  }
+  TREE_LAUNCH(k_tree_step_ext, s, e->tv, value, reward, logits, leaf_node, parent_slot, action, depth);
+  HIPCHECK(hipGetLastError());
+  e->sims_done += 1;
+  e->selection_valid = true;
+  return 0;
+}
+
 int mz_recurrent_inference(mz_engine *e, const float *hidden_in, const int32_t *action, int n, float *hidden_out,
                            float *reward, float *value, float *logits, void *stream) {
   if (!e || !hidden_in || !action || !hidden_out || !reward || !value || !logits)

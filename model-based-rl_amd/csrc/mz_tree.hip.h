@@ -682,6 +682,26 @@ __global__ void k_tree_step(TreeView t, int do_select) {
   }
 }
 
+// the same step for an external network (mz_expand_backup_select): expand + backup on the caller's outputs, the next descent,
+// and what mz_select hands back -- one launch per simulation instead of three, and the descent finds the lines the backup has
+// just written in cache
+template <int G>
+__global__ void k_tree_step_ext(TreeView t, const float *value, const float *reward, const float *logits, int32_t *leaf,
+                                int32_t *slot, int32_t *act, int32_t *depth) {
+  const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = gt / G, lane = gt % G;
+  if (b >= t.B) return;
+  mz_tree_expand_backup<G>(t, b, lane, value[b], reward[b], logits + (size_t)b * t.A);
+  __threadfence_block();          // lane 0's node updates -> visible to the group's other lanes
+  mz_tree_select<G>(t, b, lane);
+  if (lane == 0) {                // (lane 0 wrote them)
+    if (leaf) leaf[b] = t.leaf[b];
+    if (slot) slot[b] = t.slot[b];
+    if (act) act[b] = t.act[b];
+    if (depth) depth[b] = t.depth[b];
+  }
+}
+
 template <int G>
 __global__ void k_tree_root(TreeView t, const int8_t *to_play, const uint8_t *legal, const double *noise,
                             double frac, int then_select) {

@@ -260,6 +260,17 @@ class Engine(object):
     _abi.check(self.lib.mz_expand_backup(self._h, _ptr(value), _ptr(reward), _ptr(logits), _ptr(hidden), self.stream),
                'mz_expand_backup')
 
+  def expand_backup_select(self, value, reward, logits, hidden=None, last=False):
+    """expand_backup of this simulation and select of the next in one launch (mz_expand_backup_select); returns what
+    select() returns, or None after the move's last simulation (`last`: the caller's count of simulations)"""
+    value = self._dev(value, torch.float32); reward = self._dev(reward, torch.float32)
+    logits = self._dev(logits, torch.float32); hidden = self._dev(hidden, torch.float32)
+    out = None if last else [torch.empty(self.B, dtype=torch.int32, device=self.device) for _ in range(4)]
+    ptrs = [None] * 4 if last else [_ptr(o) for o in out]
+    _abi.check(self.lib.mz_expand_backup_select(self._h, _ptr(value), _ptr(reward), _ptr(logits), _ptr(hidden), *ptrs, self.stream),
+               'mz_expand_backup_select')
+    return out
+
   def finalize(self, temperature, uniform=None, move=0):
     if torch.is_tensor(temperature):
       t = temperature.to(self.device, torch.float64).expand(self.B)

@@ -7,6 +7,7 @@ Per simulation, with no host synchronisation anywhere in the loop:
     index_select         parent hidden states out of a device-resident pool [B, sims+1, ...] keyed by parent_slot
     recurrent_inference  ONE batched call of the torch network (PyTorch-ROCm / MIOpen)   mcts.py:96
     mz_expand_backup     expand + backpropagate of every tree (HIP tree kernel)  mcts.py:97-99
+    (mz_expand_backup_select: that and the next simulation's mz_select in one launch)
 The tree arithmetic is the engine's (IEEE double, bit-exact against the CPU restatement of the reference given the same network outputs); the
 network arithmetic is PyTorch's.  The engine's own FCNetwork kernels are not involved (its weight buffer stays unset).
 
@@ -60,13 +61,15 @@ class BatchedSearch(object):
     pool[:, 0].copy_(init.hidden_state)
     eng.root_load(init.value.reshape(B).float(), init.policy_logits.reshape(B, self.A).float())
     eng.root_prepare(to_play, legal, noise, device_rng=device_rng, move=move)
+    sel = eng.select()                                                           # [B] int32 each, on the device
     for s in range(self.sims):
-      leaf, slot, action, depth = eng.select()                                   # [B] int32, on the device
+      leaf, slot, action, depth = sel
       parent = self._flat.index_select(0, self._row0 + slot.long()).view((B,) + self._hshape)
       out = net.recurrent_inference(parent, action)
       pool[:, s + 1].copy_(out.hidden_state)
-      eng.expand_backup(out.value.reshape(B).float(), out.reward.reshape(B).float(),
-                        out.policy_logits.reshape(B, self.A).float())
+      # expand + backup of this simulation and the descent of the next: one tree launch per simulation
+      sel = eng.expand_backup_select(out.value.reshape(B).float(), out.reward.reshape(B).float(),
+                                     out.policy_logits.reshape(B, self.A).float(), last=(s + 1 == self.sims))
       if self.on_simulation is not None:
         self.on_simulation(s, leaf, slot, action, depth, out)
     return init
