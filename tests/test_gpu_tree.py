@@ -120,3 +120,50 @@ def test_tree_vs_oracle_random_large():
     assert np.array_equal(out['root_value'], rv)
     assert np.array_equal(out['visit_counts'], vc)
     eng.close()
+
+
+def test_fused_step_vs_oracle_random_large():
+  """mz_expand_backup_select (k_tree_step_ext: a simulation's expand + backup and the next descent in one launch) against
+  the CPU oracle stepped the reference's way (mcts.py:83-99): every selection it hands back and the final trees, same bar."""
+  from oracle import oracle as orc
+  from model_based_rl_amd.engine import Engine
+  rng = np.random.RandomState(11)
+  for (A, sims, two, bounds) in [(4, 30, False, (None, None)), (9, 25, True, (-1.0, 1.0)), (6, 50, False, (None, None)),
+                                 (18, 12, False, (None, None))]:
+    B = 2048 if A <= 6 else 512
+    eng = Engine(B, 8, A, sims, two_players=two, known_bounds=bounds, discount=0.997)
+    t = orc.Trees(orc.tree_cfg(A, sims, two, bounds, 0.997), B)
+    logits = (rng.standard_normal((B, A)) * 2).astype(np.float32)
+    legal = (rng.uniform(size=(B, A)) < 0.8).astype(np.uint8)
+    legal[np.arange(B), rng.randint(0, A, B)] = 1
+    noise = rng.dirichlet([0.25] * A, size=B) * legal
+    noise /= noise.sum(1, keepdims=True)
+    tp = rng.choice([-1, 1], size=B).astype(np.int8) if two else np.ones(B, np.int8)
+    eng.root_load(rng.standard_normal(B).astype(np.float32), logits)
+    eng.root_prepare(tp, legal, noise)
+    t.root_expand(tp, logits, legal)
+    t.add_noise(noise, 0.25)
+    sel = eng.select()
+    for s in range(sims):
+      want = t.select()
+      for gg, ww, nm in zip(sel, want, ('leaf', 'slot', 'action', 'depth')):
+        assert np.array_equal(gg.cpu().numpy(), ww), (nm, s)
+      val = (rng.standard_normal(B) * 3).astype(np.float32)
+      rew = (rng.standard_normal(B)).astype(np.float32)
+      lg = (rng.standard_normal((B, A)) * 2).astype(np.float32)
+      lg[rng.uniform(size=B) < 0.1] = 0.5          # exact ties
+      sel = eng.expand_backup_select(val, rew, lg, last=(s + 1 == sims))
+      t.expand_backup(val, rew, lg)
+    assert sel is None
+    ex, eo = eng.export_tree(), t.export()
+    EX = eo['EX'].astype(bool)
+    assert np.array_equal(ex['EX'].astype(bool), EX)
+    for k in ('N', 'E', 'TP', 'W'):
+      assert np.array_equal(ex[k][EX], eo[k][EX]), k
+    assert np.array_equal(ex['minmax'], eo['minmax'])
+    temp = rng.choice([1.0, 0.5, 0.0], size=B)
+    u = rng.uniform(size=B)
+    out = {k: v.cpu().numpy() for k, v in eng.finalize(temp, u).items()}
+    action, cv, rv, vc = t.finalize(temp, u)
+    assert np.array_equal(out['action'], action) and np.array_equal(out['child_visits'], cv) and np.array_equal(out['visit_counts'], vc)
+    eng.close()
