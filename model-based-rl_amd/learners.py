@@ -1,16 +1,17 @@
 """Learner with the reference's surface (learners.py:14-235): K-step unrolled training step on batches from the
-prioritized replay, priority refresh, weight publication, checkpoints.  The training step is stock PyTorch
-(on ROCm when `--use_gpu_for learner`); only its semantics follow the reference: initial inference + K
-recurrent steps, 0.5 gradient scale on the hidden state per step (learners.py:200), importance-sampling
-weighted cross-entropy losses on the categorical supports, 1/K gradient scale on the total loss (214),
-AdamW with eps 1.5e-4 (utils.py:85-97).
+prioritized replay, priority refresh, weight publication, checkpoints.  Semantics of the step: initial inference + K
+recurrent steps, 0.5 gradient scale on the hidden state per step (learners.py:200), importance-sampling weighted
+cross-entropy losses on the categorical supports, 1/K gradient scale on the total loss (214), AdamW with eps 1.5e-4
+(utils.py:85-97).
 
-On a GPU the whole update -- forward, losses, backward, gradient clipping, optimiser step -- is ONE captured hipGraph
-(stock `torch.cuda.CUDAGraph`: static batch tensors, capturable optimiser), replayed once per batch: eager, the step is
-~600 launches of a few microseconds of work each and runs at the launch rate (122-137 updates/s on an idle MI355X,
-profiles/r03_k_tictactoe_learning.json); the priority refresh of batch i reaches the replay while batch i + 1 is on the GPU
-(the reference's learner prefetches `batches_per_fetch` batches and sends its refresh fire-and-forget, learners.py:124,182).
-`--no_graph_learner` and CPU learners run the same tensor code eagerly."""
+On a GPU, for FCNetwork with Adam / AdamW and categorical losses, the whole update is `mz_fcl_update` (_NativeFC): five
+hand-written HIP launches (csrc/mz_fcl.hip.h) straight from the host batch -- no PyTorch operator, no autograd tape, no graph
+to capture; the parameters and the optimiser's state are views of the flat vectors those kernels update.  Every other case
+(MuZeroNetwork / TinyNetwork, scalar losses, other optimisers, `--no_native_learner`) runs the same step as PyTorch
+operators, captured in ONE hipGraph per update (stock `torch.cuda.CUDAGraph`: static batch tensors, capturable optimiser);
+`--no_graph_learner` and CPU learners run that tensor code eagerly.  The loop (`learn`) takes its batches through
+_BatchSource: sampled a few updates ahead, priority refreshes one update behind and not waited for (the reference's learner
+prefetches `batches_per_fetch` batches and sends its refresh fire-and-forget, learners.py:124,182)."""
 import os
 import time
 from copy import deepcopy
