@@ -831,27 +831,33 @@ __global__ __launch_bounds__(256) void k_fcl_adam(float *P, float *pk, const int
                                                   const float *lr_p, FclOpt o, size_t nflat, const float *lossb, const void *w,
                                                   int w_f64, int bs, int K1, double *loss_acc) {
   __shared__ float sh[256];
-  __shared__ double shd[256];
   __shared__ float shc[4];
   if ((int)blockIdx.x == nblk) {
-    for (int hd = 0; hd < 3; ++hd) {
-      double acc = 0.0;
-      for (int b = threadIdx.x; b < bs; b += 256) {
-        float l = 0.f;
-        for (int p = (hd == 2 ? 1 : 0); p < K1; ++p) l += lossb[((size_t)hd * K1 + p) * bs + b];
-        const double wb = w_f64 ? ((const double *)w)[b] : (double)((const float *)w)[b];
-        acc += wb * (double)l;
+    // the three heads together: every thread's loads are independent (one round trip), one reduction of three doubles
+    // (head by head this block was the kernel's critical path: three dependent rounds of loads + tree reductions)
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int b = threadIdx.x; b < bs; b += 256) {
+      float l[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int hd = 0; hd < 3; ++hd)
+        for (int p = (hd == 2 ? 1 : 0); p < K1; ++p) l[hd] += lossb[((size_t)hd * K1 + p) * bs + b];
+      const double wb = w_f64 ? ((const double *)w)[b] : (double)((const float *)w)[b];
+#pragma unroll
+      for (int hd = 0; hd < 3; ++hd) acc[hd] += wb * (double)l[hd];
+    }
+    __shared__ double shd3[3][256];
+#pragma unroll
+    for (int hd = 0; hd < 3; ++hd) shd3[hd][threadIdx.x] = acc[hd];
+    __syncthreads();
+    for (int k = 128; k >= 1; k >>= 1) {
+      if ((int)threadIdx.x < k) {
+#pragma unroll
+        for (int hd = 0; hd < 3; ++hd) shd3[hd][threadIdx.x] += shd3[hd][threadIdx.x + k];
       }
-      shd[threadIdx.x] = acc;
-      __syncthreads();
-      for (int k = 128; k >= 1; k >>= 1) {
-        if ((int)threadIdx.x < k) shd[threadIdx.x] += shd[threadIdx.x + k];
-        __syncthreads();
-      }
-      // _loss_dev order: reward, value, policy
-      if (threadIdx.x == 0) loss_acc[hd == 2 ? 0 : (hd == 0 ? 1 : 2)] += shd[0] / (double)bs;
       __syncthreads();
     }
+    // _loss_dev order: reward, value, policy
+    if (threadIdx.x < 3) loss_acc[threadIdx.x == 2 ? 0 : (threadIdx.x == 0 ? 1 : 2)] += shd3[threadIdx.x][0] / (double)bs;
     return;
   }
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
