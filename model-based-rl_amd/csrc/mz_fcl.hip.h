@@ -12,7 +12,7 @@
 //                     down to d loss / d hidden state
 //   k_fcl_chain_bwd4  one workgroup per 4 samples: the chain backwards (gradient hooks 0.5, LayerNorm, ReLU)
 //   k_fcl_dw          every weight gradient dW = sum_rows delta (x) input as 16 x 64 MFMA strips over the activation /
-//                     delta tapes the three kernels above left in HBM (two waves per strip and unroll position, summed
+//                     delta tapes the three kernels above left in HBM (four waves per strip and unroll position, summed
 //                     in a fixed order: deterministic, no atomics)
 //   k_fcl_grad        (only with clip_grad) adds the per-position strips up, squares for the global norm
 //   k_fcl_adam        (adds the strips up,) clip_grad_norm_, Adam / AdamW (torch's fused-kernel arithmetic), the new weights
@@ -691,7 +691,7 @@ __global__ __launch_bounds__(FCL_THREADS) void k_fcl_chain_bwd4(FclView v) {
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradients
-// Two waves per job: G[16 x 64] strip of dW = D . X^T over the R rows of one unroll position's tapes
+// One workgroup (four waves) per job: G[16 x 64] strip of dW = D . X^T over the R rows of one unroll position's tapes
 // (D: deltas, Mp features per row chunk; X: layer inputs, Np features), out rows 16 tm .., out columns 64 ng ..; the bias
 // gradient = row sums of D.
 struct FclJob {
@@ -704,11 +704,11 @@ __global__ __launch_bounds__(256) void k_fcl_dw(const FclJob *jobs, int njobs, c
                                                 float *steps, int nsteps) {
   // (the step counters -- torch keeps one per parameter -- advance here, a launch ahead of the optimiser kernel that reads them)
   if (blockIdx.x == 0 && (int)threadIdx.x < nsteps) steps[threadIdx.x] += 1.f;
-  // two waves per strip, each over half of the rows (twice the waves in flight: the kernel is bound by load latency, its
-  // MFMAs are ~3 us); the second half's partial goes through LDS and is added last -- a fixed order
-  __shared__ __attribute__((aligned(16))) float sh[2][17][64];
-  const int wv = threadIdx.x >> 6, half = wv & 1, pair = wv >> 1;
-  const int wj = blockIdx.x * 2 + pair;
+  // four waves per strip, each over a quarter of the rows (the kernel is bound by how many load streams are in flight, its
+  // MFMAs are ~3 us: 17.1 us with two waves per strip, 20.4 with one); the partials meet in LDS and are added in a fixed order
+  __shared__ __attribute__((aligned(16))) float sh[3][17][64];
+  const int qt = threadIdx.x >> 6;          // this wave's quarter of the rows
+  const int wj = blockIdx.x;
   const bool live = wj < njobs;
   const FclJob j = jobs[live ? wj : 0];
   const int lane = threadIdx.x & 63, g4 = lane >> 4, m16 = lane & 15;
@@ -721,8 +721,8 @@ __global__ __launch_bounds__(256) void k_fcl_dw(const FclJob *jobs, int njobs, c
   for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
   // (k index g4 of k-step jj of chunk c = row 16 c + 4 g4 + jj, in both operands: the sum over rows is order-free.)
-  // The loads of 8 chunks (40 x 16 bytes per lane) are requested before the first MFMA of the group
-  const int nch = R >> 4, ch0 = half ? (nch + 1) / 2 : 0, ch1 = half ? nch : (nch + 1) / 2;
+  // The loads of a wave's chunks (up to 8: 40 x 16 bytes per lane) are requested before the first MFMA of the group
+  const int nch = R >> 4, per = (nch + 3) >> 2, ch0 = qt * per, ch1 = ch0 + per < nch ? ch0 + per : nch;
   for (int c0 = ch0; live && c0 < ch1; c0 += 8) {
     f32x4 a[8], b[8][4];
 #pragma unroll
@@ -746,20 +746,23 @@ __global__ __launch_bounds__(256) void k_fcl_dw(const FclJob *jobs, int njobs, c
       }
     }
   }
-  if (half) {
+  if (qt > 0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sh[pair][4 * i + r][lane] = acc[i][r];
-    sh[pair][16][lane] = bsum;
+      for (int r = 0; r < 4; ++r) sh[qt - 1][4 * i + r][lane] = acc[i][r];
+    sh[qt - 1][16][lane] = bsum;
   }
   __syncthreads();
-  if (half || !live) return;
+  if (qt > 0 || !live) return;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int qq = 0; qq < 3; ++qq) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[i][r] += sh[pair][4 * i + r][lane];
-  bsum += sh[pair][16][lane];
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][r] += sh[qq][4 * i + r][lane];
+    bsum += sh[qq][16][lane];
+  }
   float *out = part + (size_t)j.slab * nflat;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
