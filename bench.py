@@ -148,86 +148,51 @@ def cpu_baseline_reference_shaped():
           'fidelity': 'profiles/r02_ref_shaped_ratio.json (timed beside the imported reference in the build container)'}
 
 
-class Pipeline(object):
-  """Host side of the self-play loop, the same for the headline and for every secondary figure: the main thread only
-  launches (moves, D2H copy on a copy stream); a worker thread waits for each chunk's copy and feeds the native replay
-  (PrioritizedReplay.ingest_records: the GIL is released, the environments of a chunk are split over the replay's ingest
-  threads) -- up to NBUF - 1 chunks behind the GPU, so one slow ingest does not idle the GPU.  run() returns when every
-  chunk has been ingested: `frames accepted by the replay` is what every rate below counts."""
-  NBUF = 4
+def bench_config(workload_name, envs, sims, episode_len, world, sync_every, ingest_threads, split_f16=False, run_tag='bench'):
+  """The run's Config, from the flags `python -m model_based_rl_amd.train` takes (reference config.py:87-231 names): what
+  Actor / PrioritizedReplay / SharedStorage are constructed from below, exactly as train.launch constructs them."""
+  import tempfile
+  from model_based_rl_amd.config import make_config
+  argv = ['--environment', workload_name, '--num_envs', str(envs), '--num_simulations', str(sims), '--episode_length', str(episode_len),
+          '--seed', '1234', '--num_actors', str(world), '--window_size', str(1 << 21), '--batch_size', '256', '--num_unroll_steps', '5',
+          '--td_steps', '10', '--max_history_length', '500', '--weight_sync_frequency', str(sync_every), '--ingest_threads', str(ingest_threads),
+          '--runs_dir', os.path.join(tempfile.gettempdir(), 'mz_bench_runs'), '--run_tag', run_tag, '--actor_log_frequency', '1',
+          '--fixed_temperatures'] + ['1.0'] * world      # (T = 1 whatever training step the weight publisher has reached)
+  if workload_name == 'TicTacToe':
+    argv += ['--two_players', '--known_bounds', '-1', '1', '--discount', '1']
+  if '-ram' in workload_name:          # the -ram- envs: byte observations, --norm_obs --obs_range 0 255 (actors.py:55-58,134-137)
+    argv += ['--norm_obs', '--obs_range', '0', '255']
+  if split_f16:
+    argv += ['--split_f16']
+  return make_config(argv)
 
-  def __init__(self, eng, replay, chunk, device, sync_weights=None, sync_every=1 << 30, dump=None):
-    import queue
+
+class WeightPublisher(object):
+  """Stand-in for the learner where none runs ("weight broadcast ... timer-driven if no learner"): a thread on
+  the storage rank that does what Learner.send_weights does (learners.py:85-86,132-133) -- storage.store_weights(weights,
+  training_step) with a growing step -- every `period` seconds, so that the actors' pulls (Actor.sync_weights, actors.py:81-85)
+  find a new training step and really reload + repack inside the timed regions."""
+
+  def __init__(self, storage, weights, period=0.1):
     import threading
-    self.eng, self.replay, self.chunk, self.device, self.sync_weights, self.dump = eng, replay, chunk, device, sync_weights, dump
-    self.pinned = [torch.empty(chunk, eng.B, eng.rec_floats, dtype=torch.float32).pin_memory() for _ in range(self.NBUF)]
-    self.events = [torch.cuda.Event() for _ in range(self.NBUF)]
-    self.copy_stream = torch.cuda.Stream(device)
-    self.state = {'gmove': 0, 'sync_every': sync_every, 'last_sync_q': 0}
-    self.free, self.work, self.failed = queue.Queue(), queue.Queue(), []
-    for i in range(self.NBUF):
-      self.free.put(i)
-    threading.Thread(target=self._ingest_worker, daemon=True).start()
+    from model_based_rl_amd.actors import _call
+    self.storage, self.weights, self.period, self.step, self._call = storage, weights, period, 0, _call
+    self.stop = threading.Event()
+    self.publish()
+    self.thread = threading.Thread(target=self._run, daemon=True)
+    self.thread.start()
 
-  @staticmethod
-  def _wait(ev):
-    # the chunk's copy is a few milliseconds out: sleep-poll instead of spinning a core on hipEventSynchronize (one
-    # process per GPU shares the host's cores with seven others)
-    while not ev.query():
-      time.sleep(0.0002)
+  def publish(self):
+    self.step += 1
+    self._call(self.storage, 'store_weights', self.weights, self.step)
 
-  def _ingest_worker(self):
-    torch.cuda.set_device(self.device)
-    while True:
-      item = self.work.get()
-      if item is None:
-        return
-      try:
-        i, n = item
-        self._wait(self.events[i])
-        if self.dump is not None and len(self.dump) < 4:
-          self.dump.append(self.pinned[i][:n].numpy().copy())
-        self.replay.ingest_records(self.pinned[i], n, self.eng.B)
-      except Exception as exc:      # surfaced by run()
-        self.failed.append(exc)
-      finally:
-        self.free.put(item[0])
-        self.work.task_done()
-
-  def run(self, blocks, marks=None):
-    """blocks: list of step counts, run back to back in ONE pipelined stream of chunks (D2H + host ingest of the
-    previous chunks overlap the GPU work of chunk i, across block boundaries too).  marks: list that receives one GPU
-    event per block boundary (recorded on the compute stream behind the block's last move).  Returns when every chunk
-    has been ingested."""
-    eng, state, chunk = self.eng, self.state, self.chunk
-    for steps in blocks:
-      done = 0
-      # the block in equal chunks of at most `chunk` moves (20 -> 10 + 10, not 16 + 4: every launch of the persistent
-      # self-play kernel pays its start-up once)
-      even = -(-steps // -(-steps // chunk))
-      while done < steps:
-        m = min(even, steps - done)
-        g0 = state['gmove']
-        if self.sync_weights is not None and g0 // state['sync_every'] != state['last_sync_q']:   # a multiple of sync_every was crossed
-          state['last_sync_q'] = g0 // state['sync_every']
-          self.sync_weights()     # Actor.sync_weights (actors.py:81-85): fresh weights from the storage rank, in stream order
-        i = self.free.get()       # (blocks while the worker is NBUF chunks behind)
-        eng.selfplay_steps(m)
-        _, n = eng.selfplay_drain(self.pinned[i], m, copy_stream=self.copy_stream)   # overlaps the next chunk's moves
-        self.events[i].record(self.copy_stream)
-        self.work.put((i, n))
-        done += m
-        state['gmove'] += m
-      if marks is not None:
-        ev = torch.cuda.Event(enable_timing=True)
-        ev.record()
-        marks.append(ev)
-    self.work.join()
-    if self.failed:
-      raise self.failed[0]
+  def _run(self):
+    while not self.stop.wait(self.period):
+      self.publish()
 
   def close(self):
-    self.work.put(None)
+    self.stop.set()
+    self.thread.join(timeout=5)
 
 
 def _under_profiler():
@@ -272,36 +237,30 @@ def live_traffic(workload, split_f16, chunk):
           'launches': [means['FETCH_SIZE'][1], means['WRITE_SIZE'][1]]}
 
 
-def replay_config():
-  return types.SimpleNamespace(batch_size=256, epsilon=0.01, alpha=1.0, beta=1.0, obs_space=(O,), action_space=A,
-                               window_size=1 << 21, window_step=None, num_unroll_steps=5, td_steps=10,
-                               max_history_length=500, discount=1.0 if WNAME == 'TicTacToe' else 0.997, seed=0,
-                               two_players=WNAME == 'TicTacToe', obs_u8='-ram' in WNAME)      # (-ram- observations: bytes in records and replay)
-
-
-def measure_split_f16(device, flat, chunk, moves=384):
-  """Short measurement of the opt-in split-f16 search kernel (mz_config.split_f16) on the headline workload, through the
-  SAME host pipeline as `value` (records drained to pinned memory and ingested by a native replay of its own): frames
-  accepted by the replay per second over `moves` moves of the device loop, and the search kernel's launch duration."""
-  from model_based_rl_amd.engine import Engine
+def measure_split_f16(device, weights, chunk, moves=384):
+  """Short measurement of the opt-in split-f16 search kernel (mz_config.split_f16, `--split_f16`) on the headline workload,
+  through the SAME product loop as `value` -- an Actor of its own (storage, native replay) driven by Actor.launch: frames
+  accepted by the replay per second over `moves` moves, and the search kernel's launch duration."""
+  from model_based_rl_amd import rayshim as ray
+  from model_based_rl_amd.actors import Actor
   from model_based_rl_amd.replay_buffer import PrioritizedReplay
-  eng = Engine(B, O, A, SIMS, seed=1234, device=device, split_f16=True)
-  eng.set_weights(flat if flat.is_cuda else flat.to(device))
-  if '-ram' in WNAME:
-    eng.selfplay_set_obs(uint8_obs=True, obs_min=[0.0], obs_range=[255.0], packed=True)
-  eng.selfplay_reset(EPISODE_LEN, 1.0, stagger=True)
-  replay = PrioritizedReplay(replay_config())
-  pipe = Pipeline(eng, replay, chunk, device)
+  from model_based_rl_amd.shared_storage import SharedStorage
+  cfg = bench_config(WNAME, B, SIMS, EPISODE_LEN, 1, 1 << 20, ingest_threads_for(1), split_f16=True, run_tag='bench_split_f16')
+  cfg.selfplay_chunk = chunk
+  storage, replay = ray.remote(SharedStorage).remote(cfg), ray.remote(PrioritizedReplay).remote(cfg)
+  storage.store_weights.remote(weights, 1).result()
+  actor = Actor(0, cfg, storage, replay)
+  eng = actor.engine
   moves = (moves // chunk) * chunk
-  pipe.run([EPISODE_LEN, 64])            # priming (every env past its first, partial episode) + warm-up
+  actor.launch(EPISODE_LEN + 64)         # priming (every env past its first, partial episode) + warm-up
   torch.cuda.synchronize(device)
-  f0 = replay.get_throughput()['frames']
+  f0 = replay.get_throughput.remote().result()['frames']
   t0 = time.perf_counter()
-  pipe.run([moves])
+  actor.launch(moves)
   torch.cuda.synchronize(device)
   dt = time.perf_counter() - t0
-  frames = replay.get_throughput()['frames'] - f0
-  pinned = pipe.pinned[0]
+  frames = replay.get_throughput.remote().result()['frames'] - f0
+  pinned = actor._pipe.pinned[0]
   durs = []
   for _ in range(3):
     durs += eng.selfplay_steps_timed(chunk)
@@ -309,11 +268,11 @@ def measure_split_f16(device, flat, chunk, moves=384):
     torch.cuda.synchronize(device)
   us = 1e3 * float(np.mean(durs[chunk:]))
   persistent = eng.selfplay_moves_per_launch() > 0      # whole moves inside the launch: `us` then includes the (f32) root
-  pipe.close()
+  actor.close()
   eng.close()
   return {'what': 'mz_config.split_f16 = 1: FCNetwork GEMMs as float16 high/low splits on v_mfma_f32_16x16x32_f16, f32 '
                   'accumulation; float32-level accuracy (every parity test passes), not bit-identical to the exact-f32 path',
-          'env_steps_per_s': frames / dt, 'counted': 'frames accepted by the replay (same drain + ingest pipeline as `value`)',
+          'env_steps_per_s': frames / dt, 'counted': 'frames accepted by the replay (Actor.launch, the same loop as `value`)',
           'env_steps_executed_per_s': B * moves / dt, 'ms_per_step': 1e3 * dt / moves,
           'kernel_us_per_move': us, 'root_inside_the_launch': persistent, 'moves': moves,
           'algorithmic_tflops': (SIMS * FLOP_PER_SIM + (FLOP_PER_ROOT if persistent else 0)) * B / (us * 1e-6) / 1e12}
@@ -371,6 +330,8 @@ def main():
   ap.add_argument('--chunk', type=int, default=CHUNK, help='moves per drain / ingest chunk')
   ap.add_argument('--sync-every', type=int, default=128,
                   help='moves between weight pulls (the path\'s one exchange: broadcast + repack)')
+  ap.add_argument('--publish-period', type=float, default=0.02,
+                  help='seconds between the weight publisher\'s store_weights calls on rank 0 (stand-in for Learner.send_weights)')
   ap.add_argument('--min-seconds', type=float, default=1.2,
                   help='the --steps block is repeated back to back until one timed region is at least this long')
   ap.add_argument('--runs', type=int, default=5,
@@ -430,40 +391,47 @@ def main():
   torch.cuda.set_device(device)
   coll_dev = device if backend != 'gloo' else torch.device('cpu')     # where collective buffers live
 
-  from model_based_rl_amd.engine import Engine, flatten_weights
+  import contextlib
+  from model_based_rl_amd import rayshim as ray
+  from model_based_rl_amd import distributed as D
+  from model_based_rl_amd.actors import Actor, _call
+  from model_based_rl_amd.engine import flatten_weights
   from model_based_rl_amd.networks import FCNetwork
   from model_based_rl_amd.replay_buffer import PrioritizedReplay
-  from model_based_rl_amd.shared_storage import broadcast_flat
+  from model_based_rl_amd.shared_storage import SharedStorage
   from model_based_rl_amd.distributed import rccl_mapped
 
-  # random-init FCNetwork, torch.manual_seed(0) default init; rank 0 owns the weights
+  # ---- the product's own objects, wired as train.launch / train.launch_ranks wire them (reference train.py:62-78): a
+  # SharedStorage and a PrioritizedReplay behind actor handles, one Actor per rank (one GPU each); everything below only calls
+  # Actor.launch(moves) -- the launch-ahead record pipeline, the game statistics, the ingest and the weight pulls
+  # (Actor.sync_weights every --sync-every moves) are the Actor's (model-based-rl_amd/actors.py)
+  game = WNAME == 'TicTacToe'
+  ram = '-ram' in WNAME
+  sync_every = max(chunk, args.sync_every)
+  cfg = bench_config(WNAME, B, SIMS, EPISODE_LEN, world, sync_every, args.ingest_threads or ingest_threads_for(world), split_f16=args.split_f16,
+                     run_tag='bench_%s_%d_rank%d' % (os.environ.get('MASTER_PORT', 'single'), os.getpid() if world == 1 else 0, rank))
+  cfg.selfplay_chunk = chunk
+  # random-init FCNetwork, torch.manual_seed(0) default init; rank 0 owns the weights: they reach the actors
+  # through the storage (N > 1: + one broadcast of the flat float32 buffer per pull, distributed.RankStorage)
   torch.manual_seed(0)
   net = FCNetwork(O, A, torch.device('cpu'), types.SimpleNamespace()).eval()
-  flat = flatten_weights(net.state_dict()).to(coll_dev)
-  if rank != 0:
-    flat.zero_()
-  game = WNAME == 'TicTacToe'
-  eng = Engine(B, O, A, SIMS, seed=1234, env_id_offset=rank * B, device=device, split_f16=args.split_f16,
-               **(dict(two_players=True, known_bounds=(-1.0, 1.0), discount=1.0) if game else {}))
-  if game:
-    eng.selfplay_set_env('tictactoe')
-  n_syncs = [0]
-
-  def sync_weights():
-    broadcast_flat(flat, src=0)            # RCCL over xGMI: one flattened f32 buffer (0.79 MB); no-op on one rank
-    eng.set_weights(flat if flat.is_cuda else flat.to(device))
-    n_syncs[0] += 1
-
-  sync_weights()
-  ram = '-ram' in WNAME
-  if ram:        # the -ram- envs: byte observations (bytes in the records too), --norm_obs --obs_range 0 255 inside the root kernel (actors.py:134-137)
-    eng.selfplay_set_obs(uint8_obs=True, obs_min=[0.0], obs_range=[255.0], packed=True)
-  eng.selfplay_reset(EPISODE_LEN, 1.0, stagger=True)
+  weights = net.get_weights()
+  n_flat = int(flatten_weights(weights).numel())
+  storage = publisher = None
+  if rank == 0:
+    storage = ray.remote(SharedStorage).remote(cfg)
+    # no learner in this run: its send_weights (learners.py:85-86,132-133) on a timer, often enough that every pull of the
+    # actors finds a new training step and reloads + repacks
+    publisher = WeightPublisher(storage, weights, period=args.publish_period)
+  if dist is not None:
+    rstorage = D.RankStorage(rank, world, device, n_flat, storage=storage, storage_call=_call, backend=backend, flatten=flatten_weights)
+  else:
+    rstorage = storage
 
   def make_replay(threads):
-    cfg = replay_config()
-    cfg.ingest_threads = threads
-    return PrioritizedReplay(cfg)
+    c = types.SimpleNamespace(**cfg.__dict__)
+    c.ingest_threads = threads
+    return ray.remote(PrioritizedReplay).remote(c)
 
   class Layout(object):
     """where this rank's records go: its own native replay (bench layout), or -- one_replay -- through a shared-memory
@@ -477,29 +445,23 @@ def main():
         self.replay = make_replay(self.n_ingest)
         return
       import threading
-      from model_based_rl_amd import distributed as D
       run_id = 'mzb_%s_%s' % (os.environ.get('MASTER_PORT', '0'), tag)
       self.n_ingest = args.ingest_threads or ingest_threads_for(world, one_replay_rank0=True)
       if rank == 0:
-        self.rings = {r: D.ShmRing('%s_%d' % (run_id, r), chunk, B, eng.rec_floats, slots=4, create=True) for r in range(1, world)}
+        self.rings = {r: D.ShmRing('%s_%d' % (run_id, r), chunk, B, rec_floats, slots=4, create=True) for r in range(1, world)}
       dist.barrier()
       if rank == 0:
-        lock, inner = threading.Lock(), make_replay(self.n_ingest)
-
-        class Locked(object):              # two callers on rank 0: its own pipeline worker and the ring server
-          def __getattr__(self, name):
-            def call(*a, **k):
-              with lock:
-                return getattr(inner, name)(*a, **k)
-            return call
-        self.replay = Locked()
+        self.replay = make_replay(self.n_ingest)          # (its handle serialises the two callers on rank 0: the actor and the ring server)
         self.ring_stop = threading.Event()
-        threading.Thread(target=D.serve_rings, args=(self.rings, lambda name, *a: getattr(self.replay, name)(*a), B, self.ring_stop),
+        threading.Thread(target=D.serve_rings, args=(self.rings, lambda name, *a: _call(self.replay, name, *a), B, self.ring_stop),
                          daemon=True).start()
       else:
         self.my_ring = D.ShmRing('%s_%d' % (run_id, rank))
         self.replay = D.RingReplay(self.my_ring)
         self.replay.get_throughput = lambda: {'frames': 0, 'games': 0}      # (counted where they are accepted: rank 0's replay)
+
+    def frames(self):
+      return _call(self.replay, 'get_throughput')['frames']
 
     def barrier(self):
       torch.cuda.synchronize(device)
@@ -509,7 +471,7 @@ def main():
           if rank == 0:
             while any(int(r.hdr[1]) < int(r.hdr[0]) for r in self.rings.values()):
               time.sleep(0.0002)
-            self.replay.size()     # (takes the lock behind an ingest in flight, and waits for the deferred insertions)
+            _call(self.replay, 'size')     # (queues behind an ingest in flight, and waits for the deferred insertions)
           dist.barrier()
         torch.cuda.synchronize(device)
 
@@ -521,26 +483,22 @@ def main():
         for r_ in list(self.rings.values()) + ([self.my_ring] if self.my_ring is not None else []):
           r_.release()
 
-  def timed_regions(pipe, layout, blocks, n_runs, marks_out=None):
-    """n_runs timed regions, each = `blocks` run back to back in one pipelined stream of chunks, bracketed by barrier +
-    torch.cuda.synchronize on both sides; the region's time is the MAX over ranks, its frames the SUM over ranks of what the
-    replays accepted.  -> list of (frames, seconds, host cores busy on this rank)"""
+  def timed_regions(actor, layout, moves, n_runs):
+    """n_runs timed regions, each = ONE call of Actor.launch(moves) (this rank's environments play `moves` moves; the call
+    returns when the replay has taken every record), bracketed by barrier + torch.cuda.synchronize on both sides; the
+    region's time is the MAX over ranks, its frames the SUM over ranks of what the replays accepted.
+    -> list of (frames, seconds, host cores busy on this rank, ... max over ranks)"""
     runs = []
     for _ in range(n_runs):
       layout.barrier()
-      frames0 = layout.replay.get_throughput()['frames']
-      marks = [] if marks_out is not None else None
-      start_ev = torch.cuda.Event(enable_timing=True)
+      frames0 = layout.frames()
       t0 = time.perf_counter()
       c0 = time.process_time()
-      start_ev.record()
-      pipe.run(blocks, marks)
+      actor.launch(moves)
       layout.barrier()
       dt = time.perf_counter() - t0
       busy = (time.process_time() - c0) / dt      # CPU seconds of this rank (all its threads) per wall second
-      frames = layout.replay.get_throughput()['frames'] - frames0
-      if marks_out is not None:
-        marks_out += [a.elapsed_time(b) / blocks[0] for a, b in zip([start_ev] + marks[:-1], marks)]   # GPU clock, per step
+      frames = layout.frames() - frames0
       if dist is not None:
         tt = torch.tensor([dt, busy], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -553,25 +511,34 @@ def main():
       runs.append((frames, dt, busy, busy_max))
     return runs
 
+  OS = (O + 3) // 4 if ram else O
+  rec_floats = OS + A + 10                 # include/mz_engine.h: observation (packed bytes for -ram-), visit distribution, MZ_REC_EXTRA
   one_replay = bool(args.one_replay) and dist is not None and world > 1
   layout = Layout(one_replay, 'a')
-  pipe = Pipeline(eng, layout.replay, chunk, device, sync_weights, max(chunk, args.sync_every), dump=[] if args.dump_records else None)
-  state, run, pinned, dump = pipe.state, pipe.run, pipe.pinned, pipe.dump
+  stdout = sys.stdout
+  sys.stdout = sys.stderr                  # (the product prints "Actor-k is online ..."; stdout carries the ONE JSON line)
+  actor = Actor(rank, cfg, rstorage, layout.replay)
+  eng = actor.engine
+  dump = [] if args.dump_records else None
+  if dump is not None:
+    actor.record_tap = lambda v: dump.append(v.copy()) if len(dump) < 4 else None
 
-  # priming (untimed, not part of --warmup): every env finishes its first, partial (staggered) episode, so
-  # that from here on B/EPISODE_LEN episodes end per move and the replay accepts B frames per move on
-  # average -- the steady state the reference's frames_per_second metric is defined on
+  # priming (untimed, not part of --warmup): every env finishes its first, partial (staggered) episode, so that from here on
+  # B / EPISODE_LEN episodes end per move and the replay accepts B frames per move on average -- the steady state the
+  # reference's frames_per_second metric is defined on -- and the replay's window has been filled once (its storage is
+  # touched: until r04 the first timed region ran 2 % below the others)
   # (a PMC child pass rounds every block to whole chunks: all its launches then play the same number of moves)
   whole = lambda n: -(-n // chunk) * chunk if child else n
-  run([whole(EPISODE_LEN)])
+  prime = max(EPISODE_LEN, min(int(cfg.window_size) // B + chunk, 1024)) if not child else EPISODE_LEN
+  actor.launch(whole(prime))
   if dump is not None:
     np.save('%s.rank%d.npy' % (args.dump_records, rank), np.concatenate(dump, 0))
-    dump = pipe.dump = None
-  run([whole(args.steps)])      # one untimed block: builds the hipGraphs of every chunk size a block uses
+    actor.record_tap = dump = None
+  assert eng.rec_floats == rec_floats, (eng.rec_floats, rec_floats)
   # calibration: how many --steps blocks make a timed region of >= --min-seconds (same count on every rank)
   torch.cuda.synchronize(device)
   t0 = time.perf_counter()
-  run([64])
+  actor.launch(whole(64))
   torch.cuda.synchronize(device)
   est = (time.perf_counter() - t0) / 64
   repeats = max(1, int(np.ceil(args.min_seconds / max(1e-6, est * args.steps))))
@@ -580,28 +547,28 @@ def main():
     rt = torch.tensor([repeats], dtype=torch.int64, device=coll_dev)
     dist.all_reduce(rt, op=dist.ReduceOp.MAX)
     repeats = int(rt.item())
-  per_run = repeats * args.steps
+  per_run = repeats * whole(args.steps)
   n_runs = max(1, args.runs) if not child else 1
   total = n_runs * per_run
-  # the weight pull (broadcast + repack) fires inside every timed region whatever --steps is
-  state['sync_every'] = max(chunk, min(args.sync_every, max(chunk, per_run // 2)))
-  state['last_sync_q'] = state['gmove'] // state['sync_every']
-  run([whole(args.warmup)] if args.warmup > 0 else [])
-  syncs0 = n_syncs[0]
-  block_ms = []
-  runs = timed_regions(pipe, layout, [whole(args.steps)] * repeats, n_runs, block_ms)
+  # the weight pull (storage -> [broadcast ->] repack) fires inside every timed region whatever --steps is
+  sync_every = actor.config.weight_sync_frequency = max(chunk, min(sync_every, max(chunk, per_run // 2)))
+  actor.launch(whole(max(args.warmup, 64 if not child and not args.envs else 0)))      # --warmup, at least 64 moves: the regions start in steady state
+  pulls0 = actor.weight_pulls
+  runs = timed_regions(actor, layout, per_run, n_runs)
   frames = sum(r[0] for r in runs)
   dt = sum(r[1] for r in runs)
   host_cores_busy = float(np.mean([r[2] for r in runs]))
   host_cores_busy_max = float(np.max([r[3] for r in runs]))
-  syncs_in_region = n_syncs[0] - syncs0
+  syncs_in_region = actor.weight_pulls - pulls0 - n_runs       # (minus the forced pull that ends every Actor.launch)
   env_steps = world * B * total            # env.step() calls in the timed regions, all ranks
   run_values = [r[0] / r[1] for r in runs]
+  flat = rstorage.flat if dist is not None else None
 
   # dominant kernel = k_search_fused (one launch = all simulations of all trees of this rank + the end of the move:
   # descent, f32-MFMA dynamics + prediction, expand, backup, action/record).  Its duration is measured live with HIP
   # events on the stream it is launched on: start / stop events of every dispatch (mz_selfplay_steps_timed, the
   # timestamps rocprofv3's kernel trace reports) over a stretch of the same self-play loop, launched back to back.
+  pinned = actor._pipe.pinned
   durs = []
   for _ in range(4):
     durs += eng.selfplay_steps_timed(chunk)
@@ -616,19 +583,19 @@ def main():
   # N > 1: the topology of `train --ranks N` (ONE replay on rank 0) as a secondary figure of the same line
   one_replay_secondary = None
   if dist is not None and world > 1 and not one_replay and not args.no_one_replay_secondary:
-    pipe.close()
     lay2 = Layout(True, 'b')
-    pipe2 = Pipeline(eng, lay2.replay, chunk, device, sync_weights, state['sync_every'])
-    pipe2.state.update(gmove=state['gmove'], last_sync_q=state['gmove'] // state['sync_every'])
-    pipe2.run([whole(args.warmup)] if args.warmup > 0 else [64])
-    r2 = timed_regions(pipe2, lay2, [args.steps] * repeats, 1)[0]
+    actor.replay_buffer = lay2.replay
+    actor.launch(whole(max(args.warmup, 64)))
+    r2 = timed_regions(actor, lay2, per_run, 1)[0]
     one_replay_secondary = {
         'what': 'the layout of `train --ranks N` (reference train.py:71-72: ONE replay buffer for all actors): every rank ships its '
                 'record chunks through a shared-memory ring to rank 0, whose one native replay ingests them all',
         'value': r2[0] / r2[1], 'unit': 'env-steps/s', 'timed_steps': per_run, 'timed_seconds': r2[1],
         'ingest_threads_rank0': lay2.n_ingest, 'host_cores_busy_rank0': r2[2], 'host_cores_busy_max_rank': r2[3]}
-    pipe2.close()
     lay2.close()
+  if publisher is not None:
+    publisher.close()
+  sys.stdout = stdout
 
   if rank == 0:
     value = frames / dt
@@ -671,9 +638,6 @@ def main():
                  'min': float(np.min(run_values)), 'max': float(np.max(run_values)), 'steps_per_run': per_run,
                  'what': 'SURVEY.md s8(d): mean +- std of %d timed regions of %d steps each (every region bracketed by barrier + '
                          'synchronize, MAX over ranks); `value` = all frames / all seconds of the %d regions' % (n_runs, per_run, n_runs)},
-        'ms_per_step_blocks': {'median': float(np.median(block_ms)), 'std': float(np.std(block_ms)),
-                               'min': float(np.min(block_ms)), 'max': float(np.max(block_ms)), 'n': len(block_ms),
-                               'clock': 'GPU events at block boundaries inside the pipelined timed regions'},
         'config': {'workload': '%s shapes (obs %d%s, actions %d), FCNetwork, num_simulations=%d, '
                                '%d parallel self-play envs per GPU, synthetic fixed-length episodes T=%d, '
                                'random-init weights (torch.manual_seed(0))'
@@ -689,9 +653,14 @@ def main():
                               'one native replay per rank (bench layout: the metric counts frames accepted; `train --ranks N` merges '
                               'all ranks into ONE replay on rank 0 -- that layout is `one_replay_secondary` when N > 1; DESIGN.md s6), '
                               '%d ingest threads per rank') % layout.n_ingest,
-                   'weight_sync': 'flat f32 buffer broadcast from rank 0 + repack every %d moves: %d pulls inside the timed regions; '
-                                  'a pull waits for the moves queued before it (mz_set_weights reads back whether the weight set '
-                                  'admits the clamp-ReLU scale): the launch-ahead pipeline drains once per pull' % (state['sync_every'], syncs_in_region)},
+                   'weight_sync': 'Actor.sync_weights every %d moves (storage%s -> engine repack): %d pulls inside the timed regions '
+                                  '(+ the forced pull that ends each Actor.launch); a weight publisher on rank 0 stands in for '
+                                  'Learner.send_weights every %.3f s; a pull waits for the moves queued before it (mz_set_weights reads back whether '
+                                  'the weight set admits the clamp-ReLU scale): the launch-ahead pipeline drains once per pull'
+                                  % (sync_every, ' -> broadcast of the flat f32 buffer' if dist is not None else '', syncs_in_region, args.publish_period),
+                   'timed_call': 'Actor.launch(%d) per region (model-based-rl_amd/actors.py: _RecordPipe, %d-move chunks, %d pinned buffers; '
+                                 'records logged + ingested on its worker thread); storage / replay behind rayshim handles as in train.launch'
+                                 % (per_run, chunk, actor._pipe.NBUF)},
         'env_steps_executed_per_s': env_steps / dt,
         'host_cores_busy_per_rank': host_cores_busy, 'host_cores_busy_max_rank': host_cores_busy_max,
         'usable_host_cores': _usable_cores(), 'ingest_threads_per_rank': layout.n_ingest,
@@ -735,7 +704,8 @@ def main():
     elif world == 1 and O + 1 <= 64 and A <= 13 and not game and not child:
       # the opt-in split-f16 search kernel on the same workload, as a SECONDARY figure inside the same line (never `value`)
       try:
-        out['split_f16_secondary'] = measure_split_f16(device, flat, chunk)
+        with contextlib.redirect_stdout(sys.stderr):
+          out['split_f16_secondary'] = measure_split_f16(device, weights, chunk)
       except Exception as exc:          # the headline must not depend on it
         out['split_f16_secondary'] = {'error': str(exc)[:200]}
     if world == 1 and not args.no_cpu_baseline:

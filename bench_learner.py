@@ -25,30 +25,66 @@ def step_flop(bs, K, O, A, Sv, Sr, H=50, F=512):
   return 3 * bs * fwd
 
 
+def setup(extra, updates_hint=1000):
+  """storage, replay and learner behind actor handles, wired as train.launch wires them (reference train.py:62-78); the replay is
+  filled by the product's own Actor (1024 environments, 128 moves of the device loop) before the learner starts"""
+  import tempfile
+  from model_based_rl_amd import rayshim as ray
+  from model_based_rl_amd import train
+  from model_based_rl_amd.actors import Actor
+  from model_based_rl_amd.config import make_config
+  from model_based_rl_amd.learners import Learner
+  from model_based_rl_amd.replay_buffer import PrioritizedReplay
+  from model_based_rl_amd.shared_storage import SharedStorage
+  cfg = make_config(['--environment', 'LunarLander-v2', '--num_simulations', '30', '--seed', '0', '--num_envs', '1024', '--episode_length', '32',
+                     '--window_size', '200000', '--batch_size', '256', '--stored_before_train', '50000', '--use_gpu_for', 'actors', 'learner',
+                     '--runs_dir', os.path.join(tempfile.gettempdir(), 'mz_bench_runs'), '--run_tag', 'learner_%d' % os.getpid()] + extra)
+  storage = ray.remote(SharedStorage).remote(cfg)
+  replay = ray.remote(PrioritizedReplay).remote(cfg)
+  train.publish_initial_weights(cfg, storage)
+  actor = Actor(0, cfg, storage, replay)
+  actor.launch(128)
+  actor.close()
+  actor.engine.close()
+  learner = ray.remote(Learner).remote(cfg, storage, replay)
+  return cfg, storage, replay, learner
+
+
 def main(args):
   if int(os.environ.get('WORLD_SIZE', '1')) > 1:
     raise SystemExit('--workload learner is a one-GPU secondary line')
+  import contextlib
   sys.path.insert(0, ROOT)
-  sys.path.insert(0, os.path.join(ROOT, 'scripts'))
-  import learner_graph_speed as ls
+  from model_based_rl_amd import rayshim as ray
   updates = args.steps if args.steps != 512 else 1000
+  warm = max(30, args.warmup if args.warmup != 64 else 30)
   out = {}
-  for name, extra in (('native', []), ('torch_graph', ['--no_native_learner'])):
-    cfg, storage, replay, learner = ls.setup(extra)
-    ls.loop(learner, replay, max(30, args.warmup if args.warmup != 64 else 30))
-    runs = [ls.loop(learner, replay, updates) for _ in range(max(1, args.runs))]
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    if learner._native is not None:
-      host = learner._host_batch(replay.sample_batch_arrays())[0]
-      run = lambda: learner._native.launch(host)
-    else:
-      run = learner._graph.graph.replay
-    torch.cuda.synchronize(); e0.record()
-    for _ in range(50): run()
-    e1.record(); torch.cuda.synchronize()
-    v = np.array([r['updates_per_second'] for r in runs])
-    out[name] = {'updates_per_second': float(v.mean()), 'std': float(v.std()), 'runs': v.tolist(), 'gpu_ms_per_update': e0.elapsed_time(e1) / 50,
-                 'native_step': learner._native is not None, 'replay_frames': replay.size(), 'cfg': cfg}
+  with contextlib.redirect_stdout(sys.stderr):
+    for name, extra in (('native', []), ('torch_graph', ['--no_native_learner'])):
+      cfg, storage, replay, learner = setup(extra)
+      ray.get(learner.launch.remote(warm))          # Learner.launch -> Learner.learn(max_steps) (learners.py:115-153)
+      runs = []
+      for _ in range(max(1, args.runs)):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ray.get(learner.launch.remote(updates))     # the timed region: ONE call of the product's entry point
+        torch.cuda.synchronize()
+        runs.append(updates / (time.perf_counter() - t0))
+      lrn = learner._obj                            # (the object behind the handle: GPU time of one update, for the roofline)
+      e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+      if lrn._native is not None:
+        host = lrn._host_batch(ray.get(replay.sample_batch_arrays.remote()))[0]
+        run = lambda: lrn._native.launch(host)
+      else:
+        run = lrn._graph.graph.replay
+      torch.cuda.synchronize(); e0.record()
+      for _ in range(50): run()
+      e1.record(); torch.cuda.synchronize()
+      v = np.array(runs)
+      out[name] = {'updates_per_second': float(v.mean()), 'std': float(v.std()), 'runs': v.tolist(), 'gpu_ms_per_update': e0.elapsed_time(e1) / 50,
+                   'native_step': lrn._native is not None, 'native_loop': bool(getattr(lrn, 'native_loop_updates', 0)),
+                   'replay_frames': ray.get(replay.size.remote()), 'training_step': lrn.training_step,
+                   'last_throughput': lrn.get_last_throughput(), 'cfg': cfg}
   cfg = out['native'].pop('cfg'); out['torch_graph'].pop('cfg')
   bs, K, A = cfg.batch_size, cfg.num_unroll_steps, cfg.action_space
   O = int(np.prod(cfg.obs_space))
@@ -60,7 +96,10 @@ def main(args):
           'ms_per_step': 1e3 / n['updates_per_second'], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
           'data': 'synthetic self-play records in the native replay (%d frames), random-init weights' % n['replay_frames'],
           'config': {'workload': 'learner step, FCNetwork LunarLander shapes (obs %d, actions %d), batch %d, K = %d unroll, AdamW; '
-                                 'Learner.learn\'s loop: sample ahead, mz_fcl_update, refresh one update behind' % (O, A, bs, K),
+                                 'timed call: Learner.launch(%d) = Learner.learn on the replay / storage handles train.launch builds '
+                                 '(send_weights every %d, save_state every %d, loss + throughput scalars every %d updates)'
+                                 % (O, A, bs, K, updates, cfg.send_weights_frequency, cfg.save_state_frequency, cfg.learner_log_frequency),
+                     'native_loop': n['native_loop'],
                      'runs': '%d x %d updates: mean +- std' % (len(n['runs']), updates)},
           'runs': {'mean': n['updates_per_second'], 'std': n['std'], 'values': n['runs']},
           'roofline': {'bound': 'mfma', 'kernel': 'mz_fcl_update (k_fcl_chain_fwd4, k_fcl_heads, k_fcl_chain_bwd4, k_fcl_dw, k_fcl_adam + 2 copies)',

@@ -45,6 +45,99 @@ def _call(obj, name, *args, **kwargs):
   return fn(*args, **kwargs)
 
 
+def selfplay_chunk(config):
+  """Moves per launch / drain / ingest chunk of the device loop: what one launch of the persistent search kernel plays
+  (mz_selfplay_moves_per_launch: 16 whole moves; 8 until r03_i).  A torch network plays one move per iteration.  Every
+  rank -- and the rank without an actor, train._CollectiveOnly -- derives its weight-pull cadence from this number."""
+  if getattr(config, 'architecture', 'FCNetwork') != 'FCNetwork':
+    return 1
+  return max(1, int(getattr(config, 'selfplay_chunk', None) or 16))
+
+
+def chunk_schedule(total, chunk):
+  """`total` moves in equal chunks of at most `chunk` (20 -> 10 + 10, not 16 + 4: every launch of the persistent
+  self-play kernel pays its start-up once); total None: `chunk` for ever."""
+  if total is None:
+    while True:
+      yield chunk
+  left = int(total)
+  if left <= 0:
+    return
+  even = -(-left // -(-left // chunk))
+  while left > 0:
+    m = min(even, left)
+    yield m
+    left -= m
+
+
+class _RecordPipe(object):
+  """Host side of the device self-play loop (actors.py:126-173 for `num_envs` environments at a time): the actor's thread
+  only launches -- a chunk of moves, then the chunk's records D2H into pinned memory on a copy stream; a worker thread waits
+  for each chunk's copy and hands it over (game statistics of actors.py:99-117, then replay_buffer.ingest_records: the
+  native replay releases the GIL and splits the environments of a chunk over its ingest threads) -- up to NBUF - 1 chunks
+  behind the GPU, so that one slow ingest does not idle it.  join() returns when every chunk has been handed over."""
+  NBUF = 4
+
+  def __init__(self, actor, chunk):
+    import queue
+    import threading
+    eng = actor.engine
+    self.actor, self.chunk, self.rec_floats = actor, chunk, eng.rec_floats
+    self.pinned = [torch.empty(chunk, eng.B, eng.rec_floats, dtype=torch.float32).pin_memory() for _ in range(self.NBUF)]
+    self.events = [torch.cuda.Event() for _ in range(self.NBUF)]
+    self.copy_stream = torch.cuda.Stream(actor.device)        # D2H of chunk i overlaps the moves of chunk i + 1
+    self.free, self.work, self.failed = queue.Queue(), queue.Queue(), []
+    for i in range(self.NBUF):
+      self.free.put(i)
+    self.thread = threading.Thread(target=self._worker, daemon=True)
+    self.thread.start()
+
+  @staticmethod
+  def _wait(ev):
+    # the chunk's copy is a few milliseconds out: sleep-poll instead of spinning a core on hipEventSynchronize (one
+    # process per GPU shares the host's cores with seven others)
+    while not ev.query():
+      time.sleep(0.0002)
+
+  def _worker(self):
+    torch.cuda.set_device(self.actor.device)
+    while True:
+      item = self.work.get()
+      if item is None:
+        return
+      try:
+        i, n = item
+        self._wait(self.events[i])
+        if not self.failed:
+          self.actor._hand_over(self.pinned[i], n)
+      except BaseException as exc:      # surfaced by submit() / join()
+        self.failed.append(exc)
+      finally:
+        self.free.put(item[0])
+        self.work.task_done()
+
+  def submit(self, moves, wait=False):
+    """launch `moves` moves and the copy of their records; wait: until the copy has arrived (a GPU shared in turns)"""
+    eng = self.actor.engine
+    if self.failed:
+      raise self.failed[0]
+    i = self.free.get()               # (blocks while the worker is NBUF chunks behind)
+    eng.selfplay_steps(moves)
+    _, n = eng.selfplay_drain(self.pinned[i], moves, copy_stream=self.copy_stream)      # overlaps the next chunk's moves
+    self.events[i].record(self.copy_stream)
+    if wait:
+      self.events[i].synchronize()
+    self.work.put((i, n))
+
+  def join(self):
+    self.work.join()
+    if self.failed:
+      raise self.failed[0]
+
+  def close(self):
+    self.work.put(None)
+
+
 class Actor(Logger):
 
   def __init__(self, actor_key, config, storage, replay_buffer, state=None):
@@ -74,12 +167,14 @@ class Actor(Logger):
         lo = torch.tensor(config.obs_range[::2], dtype=torch.float32, device=self.device)
         hi = torch.tensor(config.obs_range[1::2], dtype=torch.float32, device=self.device)
         norm = (lo, hi - lo)
-      self.selfplay = TorchSelfplay(config, self.network, self.num_envs, self.device, seed=(config.seed or 0) + actor_key,
+      self.selfplay = TorchSelfplay(config, self.network, self.num_envs, self.device, seed=config.seed or 0,
                                     env_id_offset=actor_key * self.num_envs, norm=norm)
       self.engine = self.selfplay.search.engine
     else:
+      # (the device RNG is keyed by (seed, GLOBAL environment id, episode, move): one seed for every actor, so that what an
+      # environment plays does not depend on how many actors share the environments -- SURVEY.md s8e)
       self.engine = Engine.from_config(config, self.num_envs, device=self.device,
-                                       seed=(config.seed or 0) + actor_key, env_id_offset=actor_key * self.num_envs)
+                                       seed=config.seed or 0, env_id_offset=actor_key * self.num_envs)
     if self.host_env:
       self.environments = [get_environment(config) for _ in range(self.num_envs)]
       for env in self.environments:
@@ -98,11 +193,21 @@ class Actor(Logger):
     self.training_step = 0
     self.games_played = 0
     self.move_counter = 0
+    self.weight_pulls = 0        # weight sets adopted (actors.py:83-85)
     self._game_stats = None
     if state is not None:
       self.load_state(state)
-    from . import gpu_turns
-    gpu_turns.register(self.device, 'actor')
+    self._pipe = None           # _RecordPipe of the device loop, kept across launch() calls
+    self._stream = None
+    self._selfplay_started = False
+    self._launched = False
+    self.record_tap = None      # (tests: callable(records [n, B, rec] numpy view) on every chunk before it is ingested)
+    self.last_run = {}
+    self._turns = None
+    if getattr(config, 'gpu_turns', False):      # --gpu_turns: an actor and a learner of this process share ONE GPU (gpu_turns.py)
+      from . import gpu_turns
+      gpu_turns.register(self.device, 'actor')
+      self._turns = gpu_turns
     Logger.__init__(self)
 
   # actors.py:75-79
@@ -128,27 +233,50 @@ class Actor(Logger):
     if training_step != self.training_step or force:
       self._set_weights(weights)
       self.training_step = training_step
+      self.weight_pulls += 1
 
   def _log_games(self, rv):
-    """games/{return,length,avg_value,max_value} (actors.py:99-117) from a chunk of experience records: one running
-    game per environment; the games that ended in a move are logged as one averaged point at i = games_played."""
-    B = rv['done'].shape[1]
+    """games/{return,length,avg_value,max_value} (actors.py:99-117) from a chunk of experience records [moves, B]: one
+    running game per environment; the games that ended in a move are logged as one averaged point at i = games_played.
+    Vectorised over the chunk: per environment the chunk is cut into games at its `done` records (segment sums / maxima by
+    np.*.reduceat over an environment-major layout with one sentinel column, so that the game still running at the end of
+    the chunk is a non-empty segment), the game running at the start continues with the carried-over statistics."""
+    done = rv['done'] != 0
+    M, B = done.shape
     if self._game_stats is None:
       self._game_stats = {'ret': np.zeros(B), 'len': np.zeros(B), 'sumv': np.zeros(B), 'maxv': np.full(B, -np.inf)}
     st = self._game_stats
-    for m in range(rv['done'].shape[0]):
-      st['ret'] += rv['reward'][m]; st['len'] += 1; st['sumv'] += rv['root_value'][m]
-      st['maxv'] = np.maximum(st['maxv'], rv['root_value'][m])
-      d = rv['done'][m] != 0
-      k = int(d.sum())
-      if k:
-        self.games_played += k
-        if self.games_played // max(1, self.config.actor_log_frequency) != (self.games_played - k) // max(1, self.config.actor_log_frequency):
-          self.log_scalar(tag='games/return', value=st['ret'][d].mean(), i=self.games_played)
-          self.log_scalar(tag='games/length', value=st['len'][d].mean(), i=self.games_played)
-          self.log_scalar(tag='games/avg_value', value=(st['sumv'][d] / st['len'][d]).mean(), i=self.games_played)
-          self.log_scalar(tag='games/max_value', value=st['maxv'][d].mean(), i=self.games_played)
-        st['ret'][d] = 0; st['len'][d] = 0; st['sumv'][d] = 0; st['maxv'][d] = -np.inf
+    if not done.any():
+      st['ret'] += rv['reward'].sum(0, dtype=np.float64); st['len'] += M; st['sumv'] += rv['root_value'].sum(0)
+      st['maxv'] = np.maximum(st['maxv'], rv['root_value'].max(0))
+      return
+    rew = np.zeros((B, M + 1)); val = np.zeros((B, M + 1)); vmx = np.full((B, M + 1), -np.inf)
+    rew[:, :M] = rv['reward'].T; val[:, :M] = rv['root_value'].T; vmx[:, :M] = val[:, :M]
+    eb, em = np.nonzero(done.T)                       # (environment, move) of every game end, environment-major
+    env0 = np.arange(B) * (M + 1)
+    starts = np.concatenate((env0, eb * (M + 1) + em + 1))
+    starts.sort()
+    flat = lambda a: a.reshape(-1)
+    ret, sumv, maxv = np.add.reduceat(flat(rew), starts), np.add.reduceat(flat(val), starts), np.maximum.reduceat(flat(vmx), starts)
+    length = np.diff(np.append(starts, B * (M + 1))).astype(np.float64)
+    first = np.searchsorted(starts, env0)             # every environment's first segment: the game carried in
+    last = np.append(first[1:], starts.size) - 1      # ... and its last: the game still running (the sentinel counts as a step)
+    ret[first] += st['ret']; sumv[first] += st['sumv']; length[first] += st['len']; maxv[first] = np.maximum(maxv[first], st['maxv'])
+    length[last] -= 1
+    st['ret'], st['len'], st['sumv'], st['maxv'] = ret[last], length[last], sumv[last], maxv[last]
+    closed = np.ones(starts.size, bool)
+    closed[last] = False                              # the closed segments come in (environment, move) order, like (eb, em)
+    ret, length, sumv, maxv = ret[closed], length[closed], sumv[closed], maxv[closed]
+    per_move = np.bincount(em, minlength=M)
+    played = self.games_played + np.cumsum(per_move)
+    f = max(1, self.config.actor_log_frequency)
+    logged = np.flatnonzero((per_move > 0) & (played // f != (played - per_move) // f))
+    if logged.size:                                   # one averaged point per move in which games ended
+      mean = lambda x: np.bincount(em, weights=x, minlength=M) / np.maximum(per_move, 1)
+      stats = (('games/return', mean(ret)), ('games/length', mean(length)), ('games/avg_value', mean(sumv / length)),
+               ('games/max_value', mean(maxv)))
+      self.log_points([(tag, int(played[m]), v[m]) for m in logged for tag, v in stats])
+    self.games_played = int(played[-1])
 
   def _temperature(self):
     if self.config.fixed_temperatures:
@@ -221,13 +349,17 @@ class Actor(Logger):
           live[i] = False
 
   # ---------------------------------------------------------------- run loop
-  def run_selfplay(self, max_moves=None, chunk=8):
+  def run_selfplay(self, max_moves=None, chunk=None):
+    """actors.py:87-124.  max_moves: play this many MORE moves per environment (None: until the learner has reached
+    training_steps); the device loop continues where the previous call stopped (episodes, record ring, pipeline)."""
     while not _call(self.storage, 'is_ready'):
       time.sleep(0.05)
-    self.sync_weights(force=True)
+    self.sync_weights(force=not self._launched)      # (a later call continues: its predecessor ended with a forced pull)
+    self._launched = True
     cfg = self.config
     if self.host_env:
-      while self.training_step < cfg.training_steps and (max_moves is None or self.move_counter < max_moves):
+      stop_at = None if max_moves is None else self.move_counter + max_moves
+      while self.training_step < cfg.training_steps and (stop_at is None or self.move_counter < stop_at):
         games = [cfg.new_game(env) for env in self.environments]
         self.play_game(games)
         for g in games:                                  # actors.py:99-117
@@ -240,57 +372,65 @@ class Actor(Logger):
       return
     if self.torch_net:
       return self._run_selfplay_torch(max_moves)
-    # synthetic on-device environments
+    # synthetic on-device environments: the launch-ahead pipeline of _RecordPipe
     eng = self.engine
-    if getattr(cfg, 'norm_obs', False) or '-ram' in str(cfg.environment):
-      # the -ram- environments emit bytes; --norm_obs is applied inside the root kernel (actors.py:134-137)
-      norm = getattr(cfg, 'norm_obs', False)
-      ram = '-ram' in str(cfg.environment)
-      eng.selfplay_set_obs(uint8_obs=ram, obs_min=self.obs_min if norm else None, obs_range=self.obs_range if norm else None,
-                           packed=ram and bool(getattr(cfg, 'obs_u8', False)))      # (bytes in the records: a replay with obs_u8)
+    chunk = selfplay_chunk(cfg) if chunk is None else int(chunk)
     temperature = self._temperature()
-    if cfg.environment == 'TicTacToe':
-      eng.selfplay_set_env('tictactoe')
-    eng.selfplay_reset(cfg.episode_length, temperature, stagger=True)
-    pinned = [torch.empty(chunk, eng.B, eng.rec_floats, dtype=torch.float32).pin_memory() for _ in range(2)]
-    events = [torch.cuda.Event(), torch.cuda.Event()]
-    copy_stream = torch.cuda.Stream(self.device)        # D2H of chunk i overlaps the moves of chunk i+1
-    pending, k = None, 0
+    if not self._selfplay_started:
+      if getattr(cfg, 'norm_obs', False) or '-ram' in str(cfg.environment):
+        # the -ram- environments emit bytes; --norm_obs is applied inside the root kernel (actors.py:134-137)
+        norm = getattr(cfg, 'norm_obs', False)
+        ram = '-ram' in str(cfg.environment)
+        eng.selfplay_set_obs(uint8_obs=ram, obs_min=self.obs_min if norm else None, obs_range=self.obs_range if norm else None,
+                             packed=ram and bool(getattr(cfg, 'obs_u8', False)))      # (bytes in the records: a replay with obs_u8)
+      if cfg.environment == 'TicTacToe':
+        eng.selfplay_set_env('tictactoe')
+      eng.selfplay_reset(cfg.episode_length, temperature, stagger=True)
+      self._selfplay_temperature = temperature
+      self._selfplay_started = True
+    elif temperature != self._selfplay_temperature:
+      eng.selfplay_set_temperature(temperature)
+      self._selfplay_temperature = temperature
+    if self._pipe is None or self._pipe.chunk < chunk or self._pipe.rec_floats != eng.rec_floats:
+      if self._pipe is not None:
+        self._pipe.close()
+      self._pipe = _RecordPipe(self, chunk)
+    pipe = self._pipe
     sync_every = max(1, cfg.weight_sync_frequency)      # experiences per environment between weight pulls
-
-    def hand_over(p):
-      buf, n, ev = p
-      ev.synchronize()
-      # games this actor finished (actors.py:94-99 counts one per play_game return; reported to the storage with the
-      # next weight pull, actors.py:82, shared_storage.py:12-14) and their logged statistics
-      self._log_games(records_view(buf[:n].numpy(), eng.O, eng.A, obs_u8=eng.obs_packed))
-      _call(self.replay_buffer, 'ingest_records', buf, n, eng.B, self.env_base)
-
-    from . import gpu_turns
-    while self.training_step < cfg.training_steps and (max_moves is None or self.move_counter < max_moves):
-      turn = gpu_turns.turn(self.device)
-      with turn:         # (a learner on the same GPU: one chunk of moves per turn, the GPU to ourselves for it)
-        eng.selfplay_steps(chunk)
-        buf, n = eng.selfplay_drain(pinned[k & 1], chunk, copy_stream=copy_stream)
-        events[k & 1].record(copy_stream)
-        if turn is not gpu_turns.NO_TURNS:
-          events[k & 1].synchronize()
-      if pending is not None:
-        hand_over(pending)
-      pending = (buf, n, events[k & 1])
-      k += 1
-      self.move_counter += chunk
-      self.experiences_collected += chunk * eng.B
-      if (self.move_counter // sync_every) != ((self.move_counter - chunk) // sync_every):
+    t0, moves0, pulls0 = time.perf_counter(), self.move_counter, self.weight_pulls
+    for m in chunk_schedule(max_moves, chunk):
+      if self.training_step >= cfg.training_steps:
+        break
+      if self._turns is not None:
+        turn = self._turns.turn(self.device)
+        with turn:      # (a learner on the same GPU: one chunk of moves per turn, the GPU to ourselves for it)
+          pipe.submit(m, wait=turn is not self._turns.NO_TURNS)
+      else:
+        pipe.submit(m)
+      self.move_counter += m
+      self.experiences_collected += m * eng.B
+      if (self.move_counter // sync_every) != ((self.move_counter - m) // sync_every):
         self.sync_weights()
         # actors.py:128-129: the temperature of the schedule is evaluated at the start of every game; on the device the
         # new value reaches each environment at its next episode start (games in progress keep theirs)
-        if self._temperature() != temperature:
-          temperature = self._temperature()
-          eng.selfplay_set_temperature(temperature)
-    if pending is not None:
-      hand_over(pending)
+        if self._temperature() != self._selfplay_temperature:
+          self._selfplay_temperature = self._temperature()
+          eng.selfplay_set_temperature(self._selfplay_temperature)
+    pipe.join()                   # every chunk has been logged and ingested: games_played is final
+    self.last_run = {'moves': self.move_counter - moves0, 'seconds': time.perf_counter() - t0, 'chunk': chunk,
+                     'weight_pulls': self.weight_pulls - pulls0}
     self.sync_weights(force=True)
+
+  def _hand_over(self, buf, n):
+    """one chunk of records, on the pipeline's worker thread: the games this actor finished (actors.py:94-99 counts one per
+    play_game return; reported to the storage with the next weight pull, actors.py:82, shared_storage.py:12-14) and their
+    logged statistics, then the replay (actors.py:169)"""
+    eng = self.engine
+    view = buf[:n].numpy()
+    if self.record_tap is not None:
+      self.record_tap(view)
+    self._log_games(records_view(view, eng.O, eng.A, obs_u8=eng.obs_packed))
+    _call(self.replay_buffer, 'ingest_records', buf, n, eng.B, self.env_base)
 
   def _run_selfplay_torch(self, max_moves=None):
     """The same loop for a torch network (MuZeroNetwork / TinyNetwork, config 5): one move of all environments per
@@ -313,16 +453,17 @@ class Actor(Logger):
       self._log_games(records_view(buf.numpy(), sp.O, sp.A, obs_u8=sp.obs_u8))
       _call(self.replay_buffer, 'ingest_records', buf, 1, sp.B, self.env_base)
 
-    from . import gpu_turns
-    while self.training_step < cfg.training_steps and (max_moves is None or self.move_counter < max_moves):
-      turn = gpu_turns.turn(self.device)
+    import contextlib
+    stop_at = None if max_moves is None else self.move_counter + max_moves
+    while self.training_step < cfg.training_steps and (stop_at is None or self.move_counter < stop_at):
+      turn = self._turns.turn(self.device) if self._turns is not None else contextlib.nullcontext()
       with turn:
         sp.play_move(dev[k & 1])
         copy_stream.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(copy_stream):
           pinned[k & 1][0].copy_(dev[k & 1], non_blocking=True)
         events[k & 1].record(copy_stream)
-        if turn is not gpu_turns.NO_TURNS:
+        if self._turns is not None and turn is not self._turns.NO_TURNS:
           events[k & 1].synchronize()
       if pending is not None:
         hand_over(pending)
@@ -344,8 +485,16 @@ class Actor(Logger):
     # the device loop gets a HIP stream of its own: on the default stream every kernel of a learner sharing the GPU
     # (train.py, --use_gpu_for actors learner) would queue behind whole-moves launches of several milliseconds each
     # (measured: 124 updates/s alone, 3.7 beside an actor on the same stream; scripts/learner_speed.py)
-    stream = torch.cuda.Stream(self.device)
+    # (one stream per actor, kept across launch() calls: the record ring orders its slots behind the drains of this stream)
+    if self._stream is None:
+      self._stream = torch.cuda.Stream(self.device)
+    stream = self._stream
     stream.wait_stream(torch.cuda.current_stream(self.device))
     with torch.inference_mode(), torch.cuda.stream(stream):
       self.run_selfplay(max_moves=max_moves)
     torch.cuda.current_stream(self.device).wait_stream(stream)
+
+  def close(self):
+    if self._pipe is not None:
+      self._pipe.close()
+      self._pipe = None

@@ -130,6 +130,10 @@ def build_parser():
   a('--group_tag', type=str, default=None)
   a('--run_tag', type=str, default=None)
   a('--actor_log_frequency', type=int, default=1)
+  a('--selfplay_chunk', type=int, default=None,
+    help='moves per launch / drain / ingest chunk of the device self-play loop (default 16: one launch of the persistent search kernel)')
+  a('--gpu_turns', action='store_true',
+    help='an actor and a learner of this process share ONE GPU: they take turns, one chunk of moves / one update at a time (gpu_turns.py)')
   a('--split_f16', action='store_true',
     help='FCNetwork GEMMs of the search as float16 high/low splits on the f16 matrix pipe (float32-level accuracy, not '
          'bit-identical to the exact-float32 default; include/mz_engine.h mz_config.split_f16)')

@@ -775,8 +775,9 @@ class Learner(Logger):
     self.throughput['time']['ups'] = time.time()
     last = cfg.training_steps if max_steps is None else min(cfg.training_steps, self.training_step + max_steps)
     log_every = max(1, getattr(cfg, 'learner_log_frequency', 100))
-    from . import gpu_turns
-    if self.device.type == 'cuda':
+    gpu_turns = None
+    if self.device.type == 'cuda' and getattr(cfg, 'gpu_turns', False):      # --gpu_turns: this GPU is shared with an actor of this process
+      from . import gpu_turns
       gpu_turns.register(self.device, 'learner')
     # batches sampled a few updates ahead, priority refreshes fire-and-forget (_BatchSource; the reference's learners.py:124,182)
     depth = min(4, int(getattr(cfg, 'batches_per_fetch', 15)))
@@ -794,11 +795,14 @@ class Learner(Logger):
   def _learn_loop(self, cfg, last, log_every, prefetch, gpu_turns):
     while self.training_step < last:
       batch = prefetch.get() if prefetch is not None else _call(self.replay_buffer, 'sample_batch')
-      turn = gpu_turns.turn(self.device)
-      with turn:         # (an actor on the same GPU: one update per turn, see gpu_turns.py)
+      if gpu_turns is not None:
+        turn = gpu_turns.turn(self.device)
+        with turn:       # (an actor on the same GPU: one update per turn, see gpu_turns.py)
+          self.update_weights(batch, defer_priorities=True)
+          if turn is not gpu_turns.NO_TURNS:
+            torch.cuda.current_stream(self.device).synchronize()
+      else:
         self.update_weights(batch, defer_priorities=True)
-        if turn is not gpu_turns.NO_TURNS:
-          torch.cuda.current_stream(self.device).synchronize()
       self.training_step += 1
       if self.training_step % cfg.send_weights_frequency == 0:
         self.send_weights()

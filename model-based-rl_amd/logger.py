@@ -42,6 +42,12 @@ class Logger(object):
     self._metrics.write('%s,%d,%.9g,%.3f\n' % (tag, int(i), float(value), time.time()))
     self._metrics.flush()
 
+  def log_points(self, points):
+    """[(tag, step, value), ...] with one flush"""
+    now = time.time()
+    self._metrics.write(''.join('%s,%d,%.9g,%.3f\n' % (tag, int(i), float(v), now) for tag, i, v in points))
+    self._metrics.flush()
+
   def log_scalars(self, value_dict, group_tag, i):
     for k, v in value_dict.items():
       self.log_scalar(v, '%s/%s' % (group_tag, k), i)

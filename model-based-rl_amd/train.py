@@ -37,18 +37,28 @@ def launch(config, max_moves, selfplay_only=False, learner_steps=None, state=Non
   storage = ray.remote(SharedStorage).remote(config)
   replay = ray.remote(PrioritizedReplay).remote(config)
   actors = [ray.remote(Actor).remote(k, config, storage, replay, state) for k in range(config.num_actors)]
-  workers = [a.launch.remote(max_moves) for a in actors]
+  prime = int(getattr(config, 'prime_moves', 0) or 0)
   if selfplay_only:
     publish_initial_weights(config, storage)
   else:
     learner = ray.remote(Learner).remote(config, storage, replay, state)
-    workers.append(learner.launch.remote(learner_steps))
+  if prime > 0 and max_moves is not None and max_moves > prime:
+    # --prime_moves: the first (staggered, partial) episodes of every environment and the one-time costs (kernel load, pinned
+    # buffers) are played before the clock starts, so that the printed rate is the steady state of the loop -- B / episode_length
+    # games end per move -- the state the reference's frames_per_second is quoted in (learners.py:94-109)
+    ray.get([a.launch.remote(prime) for a in actors])
+    max_moves -= prime
+  frames0 = ray.get(replay.get_throughput.remote())['frames']
   t0 = time.time()
+  workers = [a.launch.remote(max_moves) for a in actors]
+  if not selfplay_only:
+    workers.append(learner.launch.remote(learner_steps))
   ray.get(workers)
   dt = time.time() - t0
   thr = ray.get(replay.get_throughput.remote())
-  print('frames accepted by replay: %d, games: %d, %.1f s -> %.0f env-steps/s' % (thr['frames'], thr['games'], dt,
-                                                                                 thr['frames'] / dt))
+  thr['env_steps_per_s'] = (thr['frames'] - frames0) / dt
+  print('frames accepted by replay: %d (%d after %d priming moves), games: %d, %.2f s -> %.0f env-steps/s' %
+        (thr['frames'], thr['frames'] - frames0, prime, thr['games'], dt, thr['env_steps_per_s']))
   if not selfplay_only:            # the reference's own throughput scalars (learners.py:88-113)
     lt = ray.get(learner.get_last_throughput.remote())
     if lt:
@@ -73,7 +83,8 @@ def launch_ranks(config, max_moves, selfplay_only=False, learner_steps=None, sta
   B = int(config.num_envs)
   torch_net = config.architecture != 'FCNetwork'
   O, A = int(np.prod(config.obs_space)), int(config.action_space)
-  rec, chunk = ((O + 3) // 4 if getattr(config, 'obs_u8', False) else O) + A + 10, (1 if torch_net else 8)
+  from .actors import selfplay_chunk
+  rec, chunk = ((O + 3) // 4 if getattr(config, 'obs_u8', False) else O) + A + 10, selfplay_chunk(config)
   torch.manual_seed(config.seed or 0)
   probe = get_network(config, torch.device('cpu'))
   n_flat = flat_size(probe) if torch_net else sum(v.numel() for v in probe.state_dict().values())
@@ -167,15 +178,17 @@ class _CollectiveOnly(object):
     _, self.training_step = _call(self.storage, 'get_weights', self.games_played, self.rank)
 
   def launch(self, max_moves=None):
-    cfg, chunk = self.config, self.chunk
-    from .actors import _call
+    cfg = self.config
+    from .actors import _call, chunk_schedule
     while not _call(self.storage, 'is_ready'):
       time.sleep(0.05)
     self._sync()
     sync_every = max(1, cfg.weight_sync_frequency)
-    while self.training_step < cfg.training_steps and (max_moves is None or self.move_counter < max_moves):
-      self.move_counter += chunk
-      if (self.move_counter // sync_every) != ((self.move_counter - chunk) // sync_every):
+    for m in chunk_schedule(max_moves, self.chunk):      # the chunks of Actor.run_selfplay's device loop
+      if self.training_step >= cfg.training_steps:
+        break
+      self.move_counter += m
+      if (self.move_counter // sync_every) != ((self.move_counter - m) // sync_every):
         self._sync()
     self._sync()
 
@@ -205,6 +218,8 @@ def main(argv=None):
                  help='one process per GPU over torch.distributed: rank 0 = learner + storage + replay + actor 0')
   p.add_argument('--dedicated_learner_rank', action='store_true',
                  help='with --ranks N: rank 0 runs no actor -- its GPU is the learner\'s alone, ranks 1..N-1 play')
+  p.add_argument('--prime_moves', type=int, default=0,
+                 help='moves played before the clock of the printed env-steps/s starts (the staggered first episodes); part of --max_moves')
   p.add_argument('--load_state', type=str, default=None,
                  help='resume from a checkpoint written by Learner.save_state (train.py:130-134): its config is the run\'s config; '
                       '--training_steps / --max_moves / --runs_dir given here override it')

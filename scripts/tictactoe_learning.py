@@ -68,7 +68,7 @@ def main():
   t0 = time.time()
   thr = train.main(base + ['--max_moves', '-1', '--training_steps', str(a.training_steps), '--stored_before_train', '20000',
                            '--batch_size', '256', '--window_size', '200000', '--send_weights_frequency', '100',
-                           '--weight_sync_frequency', '16', '--use_gpu_for', 'actors', 'learner', '--runs_dir', saves,
+                           '--weight_sync_frequency', '16', '--use_gpu_for', 'actors', 'learner', '--gpu_turns', '--runs_dir', saves,
                            '--run_tag', 'learn', '--save_state_frequency', str(a.training_steps), '--learner_log_frequency', '500'])
   seconds = time.time() - t0
   import glob

@@ -501,7 +501,7 @@ def test_train_driver_with_learner():
   thr = train.main(['--environment', 'LunarLander-v2', '--num_envs', '64', '--num_simulations', '8', '--seed', '3',
                     '--episode_length', '6', '--max_moves', '48', '--window_size', '8192', '--stored_before_train', '512',
                     '--batch_size', '32', '--learner_steps', '5', '--send_weights_frequency', '2', '--use_gpu_for',
-                    'actors', 'learner'])
+                    'actors', 'learner', '--gpu_turns'])      # (one GPU for both: they take turns, gpu_turns.py)
   assert thr['frames'] >= 64 * 36
   lt = thr['learner']                 # the reference's own throughput scalars (learners.py:88-113)
   assert lt['frames_per_second'] > 0 and lt['updates_per_second'] > 0

@@ -132,3 +132,24 @@ def test_store_search_statistics_takes_a_node_like_the_reference():
   g2.store_search_statistics(want, 0.25)
   assert g2.history.child_visits == g1.history.child_visits and g2.history.root_values == g1.history.root_values
   assert g1.sum_values == 0.25 and g1.max_value == 0.25
+
+
+def test_bench_times_the_products_entry_points():
+  """bench.py's timed regions contain no loop of their own: between the two clock reads of `timed_regions` there is ONE call
+  of Actor.launch (the product's self-play loop, reference actors.py:87-124) and the barriers; the learner line times ONE
+  call of Learner.launch (learners.py:115-153) per run.  No engine / replay primitive is called from a timed region."""
+  import ast
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  tree = ast.parse(open(os.path.join(root, 'bench.py')).read())
+  fn = [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef) and n.name == 'timed_regions']
+  assert len(fn) == 1
+  loops = [n for n in ast.walk(fn[0]) if isinstance(n, (ast.For, ast.While))]
+  assert len(loops) == 1 and isinstance(loops[0], ast.For)                 # `for _ in range(n_runs)`: one region per pass
+  calls = [n.func.attr for n in ast.walk(fn[0]) if isinstance(n, ast.Call) and isinstance(n.func, ast.Attribute)]
+  assert calls.count('launch') == 1
+  assert set(calls) <= {'launch', 'barrier', 'frames', 'perf_counter', 'process_time', 'tensor', 'all_reduce', 'item', 'append'}, set(calls)
+  src = open(os.path.join(root, 'bench.py')).read()
+  assert 'class Pipeline' not in src and 'ingest_records(' not in src and 'selfplay_steps(' not in src
+  # the learner line: the timed statement is learner.launch.remote(updates) through the handle
+  lsrc = open(os.path.join(root, 'bench_learner.py')).read()
+  assert 'learner.launch.remote(updates)' in lsrc and 'update_weights' not in lsrc and 'learner_graph_speed' not in lsrc
