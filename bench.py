@@ -469,7 +469,7 @@ def main():
         dist.barrier()
         if self.one_replay:   # every producer has put its last chunk: the region ends when the one replay has accepted them all
           if rank == 0:
-            while any(int(r.hdr[1]) < int(r.hdr[0]) for r in self.rings.values()):
+            while any(r.pending() > 0 for r in self.rings.values()):
               time.sleep(0.0002)
             _call(self.replay, 'size')     # (queues behind an ingest in flight, and waits for the deferred insertions)
           dist.barrier()
@@ -503,12 +503,12 @@ def main():
         tt = torch.tensor([dt, busy], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt, busy_max = float(tt[0].item()), float(tt[1].item())
-        ff = torch.tensor([frames], dtype=torch.float64, device=coll_dev)
+        ff = torch.tensor([frames, busy], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(ff, op=dist.ReduceOp.SUM)
-        frames = float(ff.item())
+        frames, busy_sum = float(ff[0].item()), float(ff[1].item())
       else:
-        busy_max = busy
-      runs.append((frames, dt, busy, busy_max))
+        busy_max = busy_sum = busy
+      runs.append((frames, dt, busy, busy_max, busy_sum))
     return runs
 
   OS = (O + 3) // 4 if ram else O
@@ -520,8 +520,16 @@ def main():
   actor = Actor(rank, cfg, rstorage, layout.replay)
   eng = actor.engine
   dump = [] if args.dump_records else None
-  if dump is not None:
-    actor.record_tap = lambda v: dump.append(v.copy()) if len(dump) < 4 else None
+  shard = []                               # env ids of this rank's first chunk of records: [first, last]
+
+  def tap(v):
+    if not shard:
+      from model_based_rl_amd.engine import records_view
+      ids = records_view(v[:1], O, A, obs_u8=ram)['env_id']
+      shard.extend([int(ids.min()), int(ids.max())])
+    if dump is not None and len(dump) < 4:
+      dump.append(v.copy())
+  actor.record_tap = tap
 
   # priming (untimed, not part of --warmup): every env finishes its first, partial (staggered) episode, so that from here on
   # B / EPISODE_LEN episodes end per move and the replay accepts B frames per move on average -- the steady state the
@@ -533,7 +541,13 @@ def main():
   actor.launch(whole(prime))
   if dump is not None:
     np.save('%s.rank%d.npy' % (args.dump_records, rank), np.concatenate(dump, 0))
-    actor.record_tap = dump = None
+  actor.record_tap = dump = None
+  shards = [shard]
+  if dist is not None:
+    st = torch.tensor(shard, dtype=torch.int64, device=coll_dev)
+    every = [torch.zeros_like(st) for _ in range(world)]
+    dist.all_gather(every, st)
+    shards = [[int(x[0]), int(x[1])] for x in every]
   assert eng.rec_floats == rec_floats, (eng.rec_floats, rec_floats)
   # calibration: how many --steps blocks make a timed region of >= --min-seconds (same count on every rank)
   torch.cuda.synchronize(device)
@@ -559,6 +573,7 @@ def main():
   dt = sum(r[1] for r in runs)
   host_cores_busy = float(np.mean([r[2] for r in runs]))
   host_cores_busy_max = float(np.max([r[3] for r in runs]))
+  host_cores_busy_sum = float(np.mean([r[4] for r in runs]))
   syncs_in_region = actor.weight_pulls - pulls0 - n_runs       # (minus the forced pull that ends every Actor.launch)
   env_steps = world * B * total            # env.step() calls in the timed regions, all ranks
   run_values = [r[0] / r[1] for r in runs]
@@ -591,7 +606,8 @@ def main():
         'what': 'the layout of `train --ranks N` (reference train.py:71-72: ONE replay buffer for all actors): every rank ships its '
                 'record chunks through a shared-memory ring to rank 0, whose one native replay ingests them all',
         'value': r2[0] / r2[1], 'unit': 'env-steps/s', 'timed_steps': per_run, 'timed_seconds': r2[1],
-        'ingest_threads_rank0': lay2.n_ingest, 'host_cores_busy_rank0': r2[2], 'host_cores_busy_max_rank': r2[3]}
+        'ingest_threads_rank0': lay2.n_ingest, 'host_cores_busy_rank0': r2[2], 'host_cores_busy_max_rank': r2[3],
+        'host_cores_busy_all_ranks': r2[4], 'rings': len(lay2.rings), 'rings_drained': sum(1 for r_ in lay2.rings.values() if r_.pending() == 0)}
     lay2.close()
   if publisher is not None:
     publisher.close()
@@ -663,6 +679,7 @@ def main():
                                  % (per_run, chunk, actor._pipe.NBUF)},
         'env_steps_executed_per_s': env_steps / dt,
         'host_cores_busy_per_rank': host_cores_busy, 'host_cores_busy_max_rank': host_cores_busy_max,
+        'host_cores_busy_all_ranks': host_cores_busy_sum, 'shards_env_ids': shards,
         'usable_host_cores': _usable_cores(), 'ingest_threads_per_rank': layout.n_ingest,
         'collectives': {'backend': backend, 'world': world, 'forced_at_world_1': bool(force_dist and world == 1),
                         'rccl_mapped': rccl_mapped(), 'weights_on_device': bool(flat.is_cuda),

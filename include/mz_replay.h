@@ -132,6 +132,13 @@ int64_t mzr_frames(const mz_replay *r);   /* throughput['frames'] (replay_buffer
 int64_t mzr_games(const mz_replay *r);    /* throughput['games'] */
 int mzr_add_initial_throughput(mz_replay *r, int64_t frames, int64_t games);   /* replay_buffer.py:106-108 */
 
+/* One int64 in memory shared between processes, written with release and read with acquire ordering: the head / tail
+ * counters of the single-producer / single-consumer record rings between actor ranks and the replay rank
+ * (distributed.ShmRing; the reference moves HistorySlices through Ray's object store, actors.py:169).  The producer copies a
+ * chunk, then store-releases the head; the consumer load-acquires the head before it reads the chunk. */
+void mzr_store_release_i64(int64_t *p, int64_t v);
+int64_t mzr_load_acquire_i64(const int64_t *p);
+
 #ifdef __cplusplus
 }
 #endif

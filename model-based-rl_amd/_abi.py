@@ -208,6 +208,8 @@ REPLAY_SIGNATURES = {
     'mzr_frames': (_I64, [_VP]),
     'mzr_games': (_I64, [_VP]),
     'mzr_add_initial_throughput': (_I, [_VP, _I64, _I64]),
+    'mzr_store_release_i64': (None, [_VP, _I64]),
+    'mzr_load_acquire_i64': (_I64, [_VP]),
 }
 
 

@@ -485,6 +485,20 @@ int mzr_tree_update(mz_replay *r, const int64_t *idxs, const double *priorities,
     t[idxs[i]] = priorities[i];
     node[(size_t)i] = idxs[i];
   }
+  // a capacity that is not a power of two puts the leaves at TWO depths: the deeper entries take one step up on their own
+  // first (in arrival order), so that from then on every entry sits at the same depth and ALL the contributions to a node
+  // arrive within one pass, in arrival order (r04 advice: the level-by-level passes alone let a shallower leaf's change
+  // reach a common ancestor one pass before a deeper leaf's that came earlier in the batch)
+  auto depth = [](int64_t k) { return 63 - __builtin_clzll((unsigned long long)k + 1ull); };
+  const int deep = depth(len - 1);
+  if (depth(r->max_capacity - 1) != deep)
+    for (int64_t i = 0; i < n; ++i) {
+      int64_t &k = node[(size_t)i];
+      if (k != 0 && depth(k) == deep) {
+        k = (k - 1) / 2;
+        t[k] += chg[(size_t)i];
+      }
+    }
   for (bool any = true; any;) {
     any = false;
     for (int64_t i = 0; i < n; ++i)
@@ -858,5 +872,9 @@ int mzr_add_initial_throughput(mz_replay *r, int64_t frames, int64_t games) {
   r->frames += frames; r->games += games;
   return 0;
 }
+
+// release store / acquire load of one int64 in shared memory: the head / tail counters of distributed.ShmRing
+void mzr_store_release_i64(int64_t *p, int64_t v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
+int64_t mzr_load_acquire_i64(const int64_t *p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
 
 }  // extern "C"

@@ -58,6 +58,14 @@ class ShmRing(object):
     self.chunk, self.B, self.rec, self.slots = [int(x) for x in self.hdr[3:7]]
     self.slot_bytes = 8 + self.chunk * self.B * self.rec * 4
     self.owner = create
+    # head / tail / closed are read with acquire and written with release ordering (mzr_load_acquire_i64 /
+    # mzr_store_release_i64, include/mz_replay.h): a chunk's payload is visible to the consumer before the head that
+    # announces it, on any host -- not a property borrowed from x86-64's store order
+    from . import _abi
+    lib = _abi.load_replay()
+    base = self.hdr.ctypes.data
+    self._load = lambda i: int(lib.mzr_load_acquire_i64(base + 8 * i))
+    self._store = lambda i, v: lib.mzr_store_release_i64(base + 8 * i, int(v))
 
   def _slot(self, i):
     off = self.HDR * 8 + (i % self.slots) * self.slot_bytes
@@ -68,36 +76,39 @@ class ShmRing(object):
   # producer side
   def put(self, records, n_moves):
     """records: host float32 [>= n_moves][B][rec] (numpy or pinned torch tensor)."""
-    while self.hdr[0] - self.hdr[1] >= self.slots:
+    head = self._load(0)                    # (only this side writes it)
+    while head - self._load(1) >= self.slots:
       time.sleep(0.0002)
-    n, data = self._slot(int(self.hdr[0]))
+    n, data = self._slot(head)
     src = records.numpy() if torch.is_tensor(records) else np.asarray(records)
-    data[:n_moves] = src[:n_moves]
+    data[:n_moves] = src[:n_moves]          # (a synchronous copy: complete when the statement returns)
     n[0] = n_moves
-    # Published after the payload.  This relies on x86-64's store ordering (stores become visible in program order; the
-    # consumer's loads are not reordered with older loads) and on numpy having completed the copy before this statement
-    # runs: the ring is for ONE node of x86-64 hosts (the MI355X boxes are EPYC), not a portable lock-free queue.
-    self.hdr[0] += 1
+    self._store(0, head + 1)                # release: published after the payload
 
   def close_producer(self):
-    self.hdr[2] = 1
+    self._store(2, 1)
 
   # consumer side
   def poll(self):
     """-> (view [n][B][rec], n) of the oldest unconsumed chunk, or None; call done() when it has been ingested."""
-    if self.hdr[1] >= self.hdr[0]:
+    tail = self._load(1)
+    if tail >= self._load(0):               # acquire: the chunk behind a head we have seen is complete
       return None
-    n, data = self._slot(int(self.hdr[1]))
+    n, data = self._slot(tail)
     return data, int(n[0])
 
   def done(self):
-    self.hdr[1] += 1
+    self._store(1, self._load(1) + 1)       # release: the slot is free once the ingest has read it
+
+  def pending(self):
+    """chunks put and not yet done"""
+    return self._load(0) - self._load(1)
 
   def finished(self):
-    return bool(self.hdr[2]) and self.hdr[1] >= self.hdr[0]
+    return bool(self._load(2)) and self._load(1) >= self._load(0)
 
   def release(self):
-    self.hdr = None
+    self.hdr = self._load = self._store = None
     try:
       self.shm.close()
       if self.owner:

@@ -71,6 +71,62 @@ def test_tree_matches_oracle_with_growing_capacity():
     assert a.get_leaf_index(v) == b.get_leaf(v)
 
 
+@pytest.mark.parametrize('capacity', [1000, 777, 1024, 5000])
+def test_batched_refresh_is_exact_at_any_capacity(capacity):
+  """mzr_tree_update with a whole batch (the learner's refresh) against leaf-by-leaf walks (replay_buffer.py:34-40) on a FULL tree
+  whose capacity is not a power of two: the leaves then sit at two depths, and every inner node -- not only the root -- must
+  hold bit for bit the sum the reference's walks leave (r04 advice: tree[0] differed by 4.5e-13 at capacity 1000)."""
+  from model_based_rl_amd.replay_buffer import SumTree
+  rng = np.random.RandomState(capacity)
+  a, b = SumTree(capacity, capacity), orc.SumTree(capacity, capacity)
+  pri = rng.uniform(0.01, 3, size=capacity)
+  a.add(pri); b.add(pri)
+  for _ in range(200):
+    idx = rng.randint(capacity - 1, 2 * capacity - 1, size=256)
+    idx[100] = idx[3]
+    p2 = rng.uniform(0.01, 3, size=256) * 10.0 ** rng.randint(-3, 3, size=256)
+    a.update(idx, p2); b.update(idx, p2)
+    assert a.total_priority == b.total
+  for v in rng.uniform(0, a.total_priority, 500):          # the descent reads every level's sums
+    assert a.get_leaf_index(v) == b.get_leaf(v)
+
+
+def test_shm_ring_orders_payload_before_head(tmp_path):
+  """distributed.ShmRing: chunks come out in order and complete; head / tail travel through the release / acquire helpers of
+  libmz_replay.so (a producer thread against a consumer thread of this process)"""
+  import threading
+  from model_based_rl_amd import distributed as D
+  name = 'mzt_ring_%d' % os.getpid()
+  prod = D.ShmRing(name, chunk=4, B=32, rec=22, slots=3, create=True)
+  cons = D.ShmRing(name)
+  seen = []
+
+  def consume():
+    while not cons.finished():
+      got = cons.poll()
+      if got is None:
+        continue
+      data, n = got
+      seen.append((n, data[:n].copy()))
+      cons.done()
+
+  th = threading.Thread(target=consume)
+  th.start()
+  rng = np.random.RandomState(0)
+  sent = []
+  for i in range(40):
+    n = 1 + i % 4
+    rec = rng.standard_normal((4, 32, 22)).astype(np.float32)
+    sent.append((n, rec[:n].copy()))
+    prod.put(rec, n)
+  prod.close_producer()
+  th.join(timeout=30)
+  assert not th.is_alive() and len(seen) == 40 and cons.pending() == 0
+  for (n0, r0), (n1, r1) in zip(sent, seen):
+    assert n0 == n1 and np.array_equal(r0, r1)
+  cons.release(); prod.release()
+
+
 def test_vectorised_draws_are_random_uniform():
   """sample_batch_arrays draws its stratified segments (replay_buffer.py:138-140: random.uniform per segment) out of one
   getrandbits call: the same doubles, and the generator ends in the same state"""
