@@ -424,7 +424,9 @@ def main():
     # actors finds a new training step and reloads + repacks
     publisher = WeightPublisher(storage, weights, period=args.publish_period)
   if dist is not None:
-    rstorage = D.RankStorage(rank, world, device, n_flat, storage=storage, storage_call=_call, backend=backend, flatten=flatten_weights)
+    from model_based_rl_amd.engine import config_scale_check
+    rstorage = D.RankStorage(rank, world, device, n_flat, storage=storage, storage_call=_call, backend=backend, flatten=flatten_weights,
+                             scale_check=config_scale_check(cfg))
   else:
     rstorage = storage
 
@@ -671,8 +673,8 @@ def main():
                               '%d ingest threads per rank') % layout.n_ingest,
                    'weight_sync': 'Actor.sync_weights every %d moves (storage%s -> engine repack): %d pulls inside the timed regions '
                                   '(+ the forced pull that ends each Actor.launch); a weight publisher on rank 0 stands in for '
-                                  'Learner.send_weights every %.3f s; a pull waits for the moves queued before it (mz_set_weights reads back whether '
-                                  'the weight set admits the clamp-ReLU scale): the launch-ahead pipeline drains once per pull'
+                                  'Learner.send_weights every %.3f s; a pull waits for NOTHING queued on the GPU (mz_set_weights_async: the repack runs '
+                                  'in stream order, the clamp-ReLU scale decision is made on the host copy): 0 pipeline drains'
                                   % (sync_every, ' -> broadcast of the flat f32 buffer' if dist is not None else '', syncs_in_region, args.publish_period),
                    'timed_call': 'Actor.launch(%d) per region (model-based-rl_amd/actors.py: _RecordPipe, %d-move chunks, %d pinned buffers; '
                                  'records logged + ingested on its worker thread); storage / replay behind rayshim handles as in train.launch'
@@ -683,6 +685,8 @@ def main():
         'usable_host_cores': _usable_cores(), 'ingest_threads_per_rank': layout.n_ingest,
         'collectives': {'backend': backend, 'world': world, 'forced_at_world_1': bool(force_dist and world == 1),
                         'rccl_mapped': rccl_mapped(), 'weights_on_device': bool(flat.is_cuda),
+                        'broadcast': 'mz_broadcast_weights: ncclBroadcast from libmz_hip.so on a side stream, step / games / scale_ok over a gloo group'
+                                     if getattr(rstorage, 'native', False) else 'torch.distributed.broadcast + all_gather',
                         'what': 'broadcast of the flat f32 weights (%d floats) per pull, MAX / SUM all-reduces of the timing, '
                                 'barriers' % flat.numel()} if dist is not None else None,
         'mcts_sims_per_s_per_gpu': env_steps * SIMS / dt / world,

@@ -93,12 +93,42 @@ size_t mz_num_weights(const mz_engine *e);
  * mz_weight_scale below; a host buffer may be released as soon as the call returns). */
 int mz_set_weights(mz_engine *e, const float *flat, size_t n, int on_device, void *stream);
 
+/* Actor.sync_weights (actors.py:81-85) without draining the launch-ahead pipeline: mz_set_weights whose host side waits for
+ * NOTHING queued on `stream`.  The repack runs in stream order -- moves queued before the call keep the old weights, everything
+ * queued after it sees the new ones; a [host] source is copied into the engine's pinned staging before the call returns
+ * (the caller's buffer is free again), a [dev] source must stay valid until the stream has passed the call (e.g. the buffer
+ * mz_broadcast_weights filled on the same stream).  No read back: which kernel set the weights run on is the caller's
+ * `scale_ok` = mz_weights_scale_ok(...) evaluated on a HOST copy of the SAME weights (the learner rank has one; it travels
+ * with the training step).  Nothing in it synchronises or allocates after the first call with a [host] source: with a
+ * [dev] source the call can be captured into a graph.  split_f16 engines fall back to mz_set_weights (range check).
+ * mz_weights_scale_ok: 1 if this weight set admits the power-of-two scale of the search kernel's stream (mz_weight_scale),
+ * 0 if not, < 0 on error; host arithmetic only, no GPU.  value_outputs / reward_outputs: the support sizes (1 with
+ * --no_support). */
+int mz_set_weights_async(mz_engine *e, const float *flat, size_t n, int on_device, int scale_ok, void *stream);
+int mz_weights_scale_ok(const float *flat_host, size_t n, int obs_dim, int action_space, int value_outputs, int reward_outputs);
+
+/* The path's ONE collective (reference: every actor pulls the pickled state_dict from the storage actor,
+ * actors.py:81-85, shared_storage.py:12-18, learners.py:85-86): the flat float32 weights from the learner rank to every
+ * actor rank as an RCCL broadcast issued on the caller's HIP stream -- ordered by the stream with the repack that follows
+ * (mz_set_weights_async(on_device = 1) on the same stream), no host wait in between.  librccl is bound at run time:
+ * mz_comm_load(path) (NULL / "": the copy the process already holds, else the loader's search path); mz_comm_unique_id
+ * (rank 0) -> 128 bytes, handed to every rank by the caller (torch.distributed / any channel); mz_comm_create on every rank
+ * (collective: ncclCommInitRank on the calling thread's current device); mz_broadcast_weights: flat [dev][n] in place,
+ * from rank `root`. */
+typedef struct mz_comm mz_comm;
+int mz_comm_load(const char *librccl_path);
+int mz_comm_unique_id(void *out128);
+int mz_comm_create(int rank, int world, const void *unique_id128, mz_comm **out);
+int mz_comm_destroy(mz_comm *c);
+int mz_broadcast_weights(mz_comm *c, float *flat, size_t n, int root, void *stream);
+
 /* Diagnostic: how the last mz_set_weights packed the search kernel's weight stream.  out [host][4] =
  * {1, 2^-k, 2^k, chosen}: with chosen = 1 the stream carries the four 512-wide hidden layers of the search
  * (networks.py:70-93,96-119: reward / transition / value / policy fc1) times 2^-k and the layers reading their
  * activations times 2^k -- bit-neutral (powers of two), it lets the kernel apply nn.ReLU as a [0, 1] clamp on two
  * elements per instruction; 2^k exceeds a bound of every activation computed from this weight set.  chosen = 0
- * (non-finite or absurdly large weights): unscaled stream, ordinary maximum.  Synchronises `stream`. */
+ * (non-finite or absurdly large weights): unscaled stream, ordinary maximum.  Synchronises `stream` after an
+ * mz_set_weights_async (the four floats are read back on demand). */
 int mz_weight_scale(mz_engine *e, float *out, void *stream);
 
 /* BaseNetwork.initial_inference (networks.py:26-29) for B observations, actors.py:139.

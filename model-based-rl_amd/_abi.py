@@ -9,7 +9,7 @@ import subprocess
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 _SO = os.environ.get('MZ_HIP_LIB') or os.path.join(_CSRC, 'libmz_hip.so')      # (MZ_HIP_LIB: A/B runs of two builds on one box)
-_SOURCES = ['mz_engine.hip', 'mz_learner.hip.h', 'mz_fcl.hip.h', 'mz_fcl_abi.inc', 'mz_inst.hip', 'mz_kernels.inc', 'mz_common.h', 'mz_net.hip.h', 'mz_tree.hip.h', 'mz_rng.h',
+_SOURCES = ['mz_engine.hip', 'mz_comm.inc', 'mz_learner.hip.h', 'mz_fcl.hip.h', 'mz_fcl_abi.inc', 'mz_inst.hip', 'mz_kernels.inc', 'mz_common.h', 'mz_net.hip.h', 'mz_tree.hip.h', 'mz_rng.h',
             'mz_selfplay.hip.h', 'mz_selfplay_abi.inc', 'mz_fused.hip.h', 'mz_root.hip.h', 'mz_fused_h2.hip.h']
 _lib = None
 
@@ -93,6 +93,13 @@ SIGNATURES = {
     'mz_destroy': (_I, [_VP]),
     'mz_num_weights': (_SZ, [_VP]),
     'mz_set_weights': (_I, [_VP, _VP, _SZ, _I, _VP]),
+    'mz_set_weights_async': (_I, [_VP, _VP, _SZ, _I, _I, _VP]),
+    'mz_weights_scale_ok': (_I, [_VP, _SZ, _I, _I, _I, _I]),
+    'mz_comm_load': (_I, [C.c_char_p]),
+    'mz_comm_unique_id': (_I, [_VP]),
+    'mz_comm_create': (_I, [_I, _I, _VP, C.POINTER(_VP)]),
+    'mz_comm_destroy': (_I, [_VP]),
+    'mz_broadcast_weights': (_I, [_VP, _VP, _SZ, _I, _VP]),
     'mz_initial_inference': (_I, [_VP, _VP, _VP]),
     'mz_weight_scale': (_I, [_VP, _VP, _VP]),
     'mz_root_load': (_I, [_VP, _VP, _VP, _VP, _VP]),

@@ -212,6 +212,16 @@ class Actor(Logger):
 
   # actors.py:75-79
   def _set_weights(self, weights):
+    from .distributed import FlatWeights
+    if isinstance(weights, FlatWeights):            # the device buffer an RCCL broadcast fills on the storage's side stream
+      torch.cuda.current_stream(self.device).wait_event(weights.event)      # (the stream waits, not the host)
+      if self.torch_net:
+        from .networks import load_flat
+        load_flat(self.network, weights.tensor)
+      else:
+        self.engine.set_weights(weights.tensor, scale_ok=weights.scale_ok)
+      weights.consumed()
+      return
     if self.torch_net:
       if torch.is_tensor(weights):                  # the flat buffer of the weight broadcast (distributed.RankStorage)
         from .networks import load_flat

@@ -121,6 +121,10 @@ struct mz_engine {
   double *noise_log = nullptr;      // [ring_moves][B][A] per-move Dirichlet draws (mz_selfplay_noise_log), allocated on first use
   FlatLayout layout;
   float relu_scale_host[4] = {1.f, 1.f, 1.f, 0.f};
+  bool scale_host_valid = true;     // relu_scale_host mirrors relu_scale_dev (not after mz_set_weights_async: read back on demand)
+  float *wstage[2] = {nullptr, nullptr};      // pinned staging of mz_set_weights_async's host source, used alternately
+  hipEvent_t wstage_ev[2] = {nullptr, nullptr};
+  int wstage_next = 0;
   bool stream_scaled = false;       // the last weight set admitted a scale: the fused search kernels may run
   float *relu_scale_dev = nullptr;     // {1, 2^-k, 2^k, flag} of the current weight set (k_relu_scale)
   unsigned *relu_bound_dev = nullptr;  // k_relu_bound's two maxima
@@ -350,12 +354,21 @@ __global__ void k_relu_bound(const float *flat, FlatLayout L, int A, int Sr, int
 
 // scale = {1, 2^-k, 2^k, 1}; {1, 1, 1, 0} when the bound is not finite, k would exceed 40, or 2^k times the largest
 // weight of a consuming layer would leave the float32 range: the host then routes the engine to the stand-alone kernels.
-__global__ void k_relu_scale(const unsigned *mx, float *scale) {
+// force < 0: decided here; force = 0 / 1: the HOST's decision (mz_weights_scale_ok on a host copy of the same weights,
+// mz_set_weights_async) -- its limits are tighter than the ones below, so a 1 it hands over is one this kernel agrees with;
+// should it ever not, scale[3] = NaN poisons the packed stream (k_pack_weights multiplies by it): every value the search
+// computes is NaN, loudly, instead of a clamp applied to an unscaled stream.
+__global__ void k_relu_scale(const unsigned *mx, float *scale, int force) {
   const float bound = __uint_as_float(mx[0]) * 1.01f;     // (rounding of the sums above and of the kernel's own accumulation)
   const float w2max = __uint_as_float(mx[1]);
   int k = 0;
   if (bound > 1.f) (void)frexpf(bound, &k);               // bound = f 2^k, 0.5 <= f < 1: bound < 2^k
-  const bool ok = bound == bound && bound < 0x1p40f && w2max == w2max && w2max < ldexpf(1.f, 100 - k);
+  const bool own = bound == bound && bound < 0x1p40f && w2max == w2max && w2max < ldexpf(1.f, 100 - k);
+  const bool ok = own && force != 0;
+  if (force > 0 && !own) {
+    scale[0] = scale[1] = scale[2] = scale[3] = __uint_as_float(0x7fc00000u);
+    return;
+  }
 #ifdef MZ_RELU_VMAX
   k = 0;
 #endif
@@ -1030,6 +1043,10 @@ int mz_destroy(mz_engine *e) {
   for (auto &g : e->move_graph) if (g) hipGraphExecDestroy(g);
   if (e->cap_stream) hipStreamDestroy(e->cap_stream);
   for (void *p : e->allocs) hipFree(p);
+  for (int w = 0; w < 2; ++w) {
+    if (e->wstage[w]) hipHostFree(e->wstage[w]);
+    if (e->wstage_ev[w]) hipEventDestroy(e->wstage_ev[w]);
+  }
   if (e->sp.host_ring) hipHostFree(e->sp.host_ring);
   delete e;
   return 0;
@@ -1120,7 +1137,7 @@ int mz_set_weights(mz_engine *e, const float *flat, size_t n, int on_device, voi
   // the stand-alone kernels until the next weight set
   HIPCHECK(hipMemsetAsync(e->relu_bound_dev, 0, 2 * sizeof(unsigned), s));
   hipLaunchKernelGGL(k_relu_bound, dim3(64), dim3(256), 0, s, src, e->layout, e->A, e->nv.Sr, e->nv.Sv, e->relu_bound_dev);
-  hipLaunchKernelGGL(k_relu_scale, dim3(1), dim3(1), 0, s, (const unsigned *)e->relu_bound_dev, e->relu_scale_dev);
+  hipLaunchKernelGGL(k_relu_scale, dim3(1), dim3(1), 0, s, (const unsigned *)e->relu_bound_dev, e->relu_scale_dev, -1);
   hipLaunchKernelGGL(k_pack_weights, dim3(blocks), dim3(threads), 0, s, src, e->pack_idx, (const int32_t *)e->pack_idx2,
                      e->packed, e->n_packed, (const float *)e->relu_scale_dev);
   HIPCHECK(hipMemcpyAsync(e->relu_scale_host, e->relu_scale_dev, 4 * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -1135,6 +1152,92 @@ int mz_set_weights(mz_engine *e, const float *flat, size_t n, int on_device, voi
     for (auto &g : e->move_graph) if (g) { hipGraphExecDestroy(g); g = nullptr; }
   }
   e->stream_scaled = scaled;
+  e->scale_host_valid = true;
+  e->weights_set = true;
+  return 0;
+}
+
+// The host's side of k_relu_bound / k_relu_scale: the same bound in double from a HOST copy of the weights, with tighter
+// limits (a factor 2 on the activation bound, 4 on the consuming layers' largest weight), so that "1" here implies the
+// device's own test passes whatever the float32 rounding of its sums.
+int mz_weights_scale_ok(const float *flat, size_t n, int obs_dim, int action_space, int value_outputs, int reward_outputs) {
+  if (!flat) return fail("mz_weights_scale_ok: null argument");
+  if (obs_dim < 1 || action_space < 1 || value_outputs < 1 || reward_outputs < 1) return fail("mz_weights_scale_ok: bad shape");
+  const FlatLayout L = flat_layout(obs_dim, action_space, value_outputs, reward_outputs);
+  if (n != L.total) return fail("mz_weights_scale_ok: expected %zu floats, got %zu", L.total, n);
+  const int A = action_space;
+  double hb[MZ_H];
+  for (int i = 0; i < MZ_H; ++i) hb[i] = 7.01 * fabs((double)flat[L.ln_w + i]) + fabs((double)flat[L.ln_b + i]);
+  const size_t w1[4] = {L.rew_w1, L.tr_w1, L.val_w1, L.pol_w1}, b1[4] = {L.rew_b1, L.tr_b1, L.val_b1, L.pol_b1};
+  double bound = 0.0;
+  bool nan = false;
+  for (int h = 0; h < 4; ++h) {
+    const int K = h < 2 ? MZ_H + A : MZ_H;
+    for (int r = 0; r < MZ_F; ++r) {
+      const float *row = flat + w1[h] + (size_t)r * K;
+      double s = 0.0, oh = 0.0;
+      for (int i = 0; i < MZ_H; ++i) s += fabs((double)row[i]) * hb[i];
+      for (int a = MZ_H; a < K; ++a) { const double v = fabs((double)row[a]); if (v != v) nan = true; if (v > oh) oh = v; }
+      s += oh + fabs((double)flat[b1[h] + r]);
+      if (s != s) nan = true;
+      if (s > bound) bound = s;
+    }
+  }
+  const size_t w2[4] = {L.rew_w2, L.tr_w2, L.val_w2, L.pol_w2};
+  const int J[4] = {reward_outputs, MZ_H, value_outputs, A};
+  double w2max = 0.0;
+  for (int h = 0; h < 4; ++h)
+    for (size_t i = 0; i < (size_t)J[h] * MZ_F; ++i) {
+      const double v = fabs((double)flat[w2[h] + i]);
+      if (v != v) nan = true;
+      if (v > w2max) w2max = v;
+    }
+  bound *= 1.02;
+  int k = 0;
+  if (bound > 1.0) (void)frexp(bound, &k);
+  return (!nan && bound < 0x1p39 && w2max < ldexp(1.0, 97 - k)) ? 1 : 0;
+}
+
+// mz_set_weights without the host waiting for anything queued on `stream`: the repack runs in stream order (the moves
+// queued before it keep the old weights, everything queued after it sees the new ones), which kernel set the new weights
+// run on is the caller's `scale_ok` (mz_weights_scale_ok on a host copy of the SAME weights).
+int mz_set_weights_async(mz_engine *e, const float *flat, size_t n, int on_device, int scale_ok, void *stream) {
+  if (!e || !flat) return fail("mz_set_weights_async: null argument");
+  MZ_ENTER(e);
+  if (n != e->n_flat) return fail("mz_set_weights_async: expected %zu floats, got %zu", e->n_flat, n);
+  if (e->split_f16) return mz_set_weights(e, flat, n, on_device, stream);      // (its float16 range check reads back: synchronous)
+  hipStream_t s = (hipStream_t)stream;
+  const float *src = flat;
+  if (!on_device) {
+    const int w = e->wstage_next;
+    e->wstage_next ^= 1;
+    if (!e->wstage[w]) {
+      HIPCHECK(hipHostMalloc((void **)&e->wstage[w], n * sizeof(float), hipHostMallocDefault));
+      HIPCHECK(hipEventCreateWithFlags(&e->wstage_ev[w], hipEventDisableTiming));
+    } else {
+      HIPCHECK(hipEventSynchronize(e->wstage_ev[w]));      // the copy out of this slot, two pulls ago (long complete)
+    }
+    memcpy(e->wstage[w], flat, n * sizeof(float));
+    HIPCHECK(hipMemcpyAsync(e->flat_dev, e->wstage[w], n * sizeof(float), hipMemcpyHostToDevice, s));
+    HIPCHECK(hipEventRecord(e->wstage_ev[w], s));
+    src = e->flat_dev;
+  }
+  const int threads = 256;
+  const unsigned blocks = (unsigned)((e->n_packed + threads - 1) / threads);
+  HIPCHECK(hipMemsetAsync(e->relu_bound_dev, 0, 2 * sizeof(unsigned), s));
+  hipLaunchKernelGGL(k_relu_bound, dim3(64), dim3(256), 0, s, src, e->layout, e->A, e->nv.Sr, e->nv.Sv, e->relu_bound_dev);
+  hipLaunchKernelGGL(k_relu_scale, dim3(1), dim3(1), 0, s, (const unsigned *)e->relu_bound_dev, e->relu_scale_dev, scale_ok ? 1 : 0);
+  hipLaunchKernelGGL(k_pack_weights, dim3(blocks), dim3(threads), 0, s, src, e->pack_idx, (const int32_t *)e->pack_idx2,
+                     e->packed, e->n_packed, (const float *)e->relu_scale_dev);
+  HIPCHECK(hipGetLastError());
+  const bool scaled = scale_ok != 0;
+  if (scaled != e->stream_scaled) {      // (rare: captured graphs hold the launches of the other kernel set)
+    HIPCHECK(hipStreamSynchronize(s));
+    if (e->search_graph) { hipGraphExecDestroy(e->search_graph); e->search_graph = nullptr; }
+    for (auto &g : e->move_graph) if (g) { hipGraphExecDestroy(g); g = nullptr; }
+  }
+  e->stream_scaled = scaled;
+  e->scale_host_valid = false;
   e->weights_set = true;
   return 0;
 }
@@ -1143,10 +1246,16 @@ int mz_weight_scale(mz_engine *e, float *out, void *stream) {
   if (!e || !out) return fail("mz_weight_scale: null argument");
   MZ_ENTER(e);
   if (!e->weights_set) return fail("mz_weight_scale: weights not set (call mz_set_weights)");
-  (void)stream;
+  if (!e->scale_host_valid) {
+    HIPCHECK(hipMemcpyAsync(e->relu_scale_host, e->relu_scale_dev, 4 * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
+    e->scale_host_valid = true;
+  }
   memcpy(out, e->relu_scale_host, sizeof(e->relu_scale_host));
   return 0;
 }
+
+#include "mz_comm.inc"
 
 int mz_initial_inference(mz_engine *e, const float *obs, void *stream) {
   if (!e || !obs) return fail("mz_initial_inference: null argument");

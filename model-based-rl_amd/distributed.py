@@ -154,42 +154,136 @@ def serve_rings(rings, replay_call, B, stop):
 
 
 # ------------------------------------------------------------------------------------------------ weights
+class FlatWeights(object):
+  """What RankStorage.get_weights hands an actor over RCCL: the device buffer the broadcast fills (`tensor`), the event
+  that says it has (`event`, on the storage's side stream -- the consumer's stream waits for it, not the host), and the
+  learner rank's mz_weights_scale_ok for this weight set (`scale_ok`, rode along with the training step).  consumed():
+  called by the consumer once its stream has the repack queued -- the storage's next write into this buffer waits for it."""
+
+  def __init__(self, storage, slot, tensor, scale_ok, event):
+    self.storage, self.slot, self.tensor, self.scale_ok, self.event = storage, slot, tensor, scale_ok, event
+
+  def consumed(self):
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(self.tensor.device))
+    self.storage._consumed[self.slot] = ev
+
+
 class RankStorage(object):
   """SharedStorage surface (shared_storage.py:4-25) as every actor rank sees it.  get_weights is COLLECTIVE: all ranks
   call it at the same point of their loop; rank 0 reads its real SharedStorage, everybody receives the flat weights by
-  one broadcast and the training step / game counts by one small all-gather."""
+  one broadcast and the training step / game counts by one small all-gather.
+
+  backend "nccl" (the GPUs of a node, RCCL over xGMI): the broadcast is `mz_broadcast_weights` -- ncclBroadcast called from
+  libmz_hip.so on a communicator of its own (mz_comm_create; torch.distributed only carries rank 0's unique id) -- issued on
+  a SIDE stream into one of two device buffers, so that it neither waits for the moves queued on an actor's stream nor
+  makes that stream wait longer than the broadcast itself takes; the training step, the game counts and rank 0's
+  mz_weights_scale_ok travel over a host-side (gloo) group: nothing on the host waits for the GPU, a weight pull never
+  drains the launch-ahead pipeline.  MZ_TORCH_COLLECTIVES=1 or backend "gloo" (CPU tensors; the one-GPU self-tests):
+  torch.distributed's own broadcast / all_gather."""
 
   def __init__(self, rank, world, device, num_weights, storage=None, storage_call=None, backend='nccl',
-               flatten=flatten_weights):
+               flatten=flatten_weights, scale_check=None):
     self.rank, self.world, self.device = rank, world, torch.device(device)
-    self.storage, self.call, self.flatten = storage, storage_call, flatten
+    self.storage, self.call, self.flatten, self.scale_check = storage, storage_call, flatten, scale_check
     self.cdev = self.device if backend != 'gloo' else torch.device('cpu')
-    self.flat = torch.zeros(int(num_weights), dtype=torch.float32, device=self.cdev)
     self.training_step = 0
     self.broadcasts = 0
+    self.native = backend == 'nccl' and os.environ.get('MZ_TORCH_COLLECTIVES', '0')[:1] != '1'
+    n = int(num_weights)
+    if not self.native:
+      self._flats = [torch.zeros(n, dtype=torch.float32, device=self.cdev)]
+      self._last = 0
+      return
+    import ctypes as C
+    from . import _abi
+    dist = _dist()
+    self.lib = _abi.load()
+    rccl = os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')      # PyTorch-ROCm's own copy: ONE HIP runtime per process
+    _abi.check(self.lib.mz_comm_load(rccl.encode() if os.path.exists(rccl) else None), 'mz_comm_load')
+    uid = (C.c_char * 128)()
+    if rank == 0:
+      _abi.check(self.lib.mz_comm_unique_id(uid), 'mz_comm_unique_id')
+    box = [bytes(uid.raw)]
+    dist.broadcast_object_list(box, src=0)                   # bootstrap only
+    uid = (C.c_char * 128).from_buffer_copy(box[0])
+    self.comm = C.c_void_p()
+    with torch.cuda.device(self.device):
+      _abi.check(self.lib.mz_comm_create(rank, world, uid, C.byref(self.comm)), 'mz_comm_create')
+    self.meta_group = dist.new_group(backend='gloo')         # training step, game counts, scale_ok: host to host
+    self.side = torch.cuda.Stream(self.device)
+    self._flats = [torch.zeros(n, dtype=torch.float32, device=self.device) for _ in range(2)]
+    self._pinned = [torch.zeros(n, dtype=torch.float32).pin_memory() for _ in range(2)] if rank == 0 else None
+    self._staged = [None, None]                              # event behind the host-to-device copy out of _pinned[k]
+    self._consumed = [None, None]                            # event behind the last repack that read _flats[k]
+    self._last = 0
+
+  @property
+  def flat(self):
+    """the buffer the last broadcast filled"""
+    return self._flats[self._last]
 
   def is_ready(self):
     if self.rank == 0:
       return self.call(self.storage, 'is_ready')
     return True                     # the first collective get_weights delivers them
 
-  def get_weights(self, games, actor_key):
+  def _gather_meta(self, meta, group=None):
     dist = _dist()
-    step = 0
-    if self.rank == 0:
-      weights, step = self.call(self.storage, 'get_weights', games, actor_key)
-      flat = weights if torch.is_tensor(weights) else self.flatten(weights)
-      self.flat.copy_(flat.to(self.cdev))
-    dist.broadcast(self.flat, src=0)                                   # the path's one exchange: RCCL over xGMI
-    meta = torch.tensor([step, games], dtype=torch.int64, device=self.cdev)
     gathered = [torch.zeros_like(meta) for _ in range(self.world)]
-    dist.all_gather(gathered, meta)
+    dist.all_gather(gathered, meta, group=group)
     self.training_step = int(gathered[0][0])
     if self.rank == 0:
       for r in range(1, self.world):                                   # shared_storage.py:13: per-actor game counts
         self.call(self.storage, 'get_weights', int(gathered[r][1]), r)
+    return gathered
+
+  def get_weights(self, games, actor_key):
+    dist = _dist()
+    step, host = 0, None
+    if self.rank == 0:
+      weights, step = self.call(self.storage, 'get_weights', games, actor_key)
+      host = weights if torch.is_tensor(weights) else self.flatten(weights)
+    if not self.native:
+      if self.rank == 0:
+        self._flats[0].copy_(host.to(self.cdev))
+      dist.broadcast(self._flats[0], src=0)
+      self._gather_meta(torch.tensor([step, games], dtype=torch.int64, device=self.cdev))
+      self.broadcasts += 1
+      flat = self._flats[0]
+      return (flat if flat.device == self.device else flat.to(self.device)), self.training_step
+    k = self.broadcasts & 1
+    flat, ok = self._flats[k], 1
+    if self.rank == 0:
+      host = host.detach().to('cpu', torch.float32).reshape(-1)
+      ok = int(self.scale_check(host)) if self.scale_check is not None else 1
+      if self._staged[k] is not None:
+        self._staged[k].synchronize()                # the copy out of this staging slot, two pulls ago
+      self._pinned[k].copy_(host)
+    import ctypes as C
+    from . import _abi
+    with torch.cuda.stream(self.side):
+      if self._consumed[k] is not None:
+        self.side.wait_event(self._consumed[k])      # the repack that read this buffer two pulls ago (stream order, no host wait)
+      if self.rank == 0:
+        flat.copy_(self._pinned[k], non_blocking=True)
+        self._staged[k] = torch.cuda.Event()
+        self._staged[k].record(self.side)
+      # the path's one exchange: RCCL over xGMI, on this side stream
+      _abi.check(self.lib.mz_broadcast_weights(self.comm, C.c_void_p(flat.data_ptr()), flat.numel(), 0, C.c_void_p(self.side.cuda_stream)),
+                 'mz_broadcast_weights')
+      done = torch.cuda.Event()
+      done.record(self.side)
+    gathered = self._gather_meta(torch.tensor([step, games, ok], dtype=torch.int64), group=self.meta_group)
     self.broadcasts += 1
-    return (self.flat if self.flat.device == self.device else self.flat.to(self.device)), self.training_step
+    self._last = k
+    return FlatWeights(self, k, flat, int(gathered[0][2]), done), self.training_step
+
+  def close(self):
+    if getattr(self, 'native', False) and getattr(self, 'comm', None):
+      torch.cuda.synchronize(self.device)
+      self.lib.mz_comm_destroy(self.comm)
+      self.comm = None
 
 
 def rccl_mapped():

@@ -35,6 +35,31 @@ def flatten_weights(weights):
   return torch.cat(parts).contiguous()
 
 
+def weights_scale_ok(flat_host, obs_dim, action_space, value_outputs, reward_outputs):
+  """mz_weights_scale_ok (include/mz_engine.h): does this weight set admit the search kernel's clamp-ReLU scale?  Host
+  arithmetic on a host copy of the flat weights (engine.WEIGHT_ORDER); no GPU."""
+  w = flat_host if torch.is_tensor(flat_host) else torch.from_numpy(np.ascontiguousarray(flat_host, np.float32))
+  w = w.detach().to('cpu', torch.float32).contiguous().reshape(-1)
+  rc = _abi.load().mz_weights_scale_ok(C.c_void_p(w.data_ptr()), w.numel(), int(obs_dim), int(action_space), int(value_outputs),
+                                       int(reward_outputs))
+  if rc < 0:
+    _abi.check(rc, 'mz_weights_scale_ok')
+  return int(rc)
+
+
+def config_scale_check(config):
+  """flat host weights -> mz_weights_scale_ok for a Config's FCNetwork shapes (None for the torch networks)"""
+  if getattr(config, 'architecture', 'FCNetwork') != 'FCNetwork':
+    return None
+  O, A = int(np.prod(config.obs_space)), int(config.action_space)
+  if getattr(config, 'no_support', False):
+    sv = sr = 1
+  else:
+    sv = int(config.value_support[1]) - int(config.value_support[0]) + 1
+    sr = int(config.reward_support[1]) - int(config.reward_support[0]) + 1
+  return lambda flat: weights_scale_ok(flat, O, A, sv, sr)
+
+
 REC_EXTRA = 10      # include/mz_engine.h MZ_REC_EXTRA
 
 
@@ -76,6 +101,9 @@ class Engine(object):
     torch.cuda.set_device(self.device)
     lo, hi = known_bounds
     self.B, self.O, self.A, self.sims = int(num_envs), int(obs_dim), int(action_space), int(num_simulations)
+    # outputs of the value / reward heads: the support sizes, one scalar each with --no_support (networks.py:135-136)
+    self._outputs = (1, 1) if no_support else (int(value_support[1]) - int(value_support[0]) + 1,
+                                                int(reward_support[1]) - int(reward_support[0]) + 1)
     self.cfg = _abi.MzConfig(
         self.B, self.O, self.A, self.sims, int(bool(two_players)), int(lo is not None), int(hi is not None),
         int(value_support[0]), int(value_support[1]), int(reward_support[0]), int(reward_support[1]),
@@ -137,7 +165,13 @@ class Engine(object):
     return x
 
   # ---- weights (networks.py:36-37, actors.py:81-85)
-  def set_weights(self, weights):
+  def set_weights(self, weights, scale_ok=None, sync=False):
+    """Weights on the HOST (a state_dict, a numpy array, a CPU tensor): mz_set_weights_async -- the repack is queued in
+    stream order and the call returns without waiting for the moves queued before it (which kernel set the weights run on
+    is decided on the host copy, mz_weights_scale_ok).  Weights on the DEVICE (the buffer a broadcast filled): the same
+    when the caller passes `scale_ok` (the learner rank's mz_weights_scale_ok on its host copy; the tensor must stay valid
+    until the stream has passed the call), else mz_set_weights, which reads the decision back and so waits for the stream.
+    sync: force mz_set_weights."""
     if isinstance(weights, dict):
       weights = flatten_weights(weights)
     if not torch.is_tensor(weights):
@@ -147,8 +181,18 @@ class Engine(object):
       raise ValueError('expected %d weights, got %d' % (self.num_weights, weights.numel()))
     on_dev = weights.is_cuda
     w = weights.to(torch.float32).contiguous()
-    _abi.check(self.lib.mz_set_weights(self._h, _ptr(w), w.numel(), int(on_dev), self.stream), 'mz_set_weights')
+    if not on_dev and scale_ok is None and not sync:
+      scale_ok = self.weights_scale_ok(w)
+    if scale_ok is None or sync:
+      _abi.check(self.lib.mz_set_weights(self._h, _ptr(w), w.numel(), int(on_dev), self.stream), 'mz_set_weights')
+    else:
+      _abi.check(self.lib.mz_set_weights_async(self._h, _ptr(w), w.numel(), int(on_dev), int(bool(scale_ok)), self.stream),
+                 'mz_set_weights_async')
     self._weights_dev = w if on_dev else None      # (the one device buffer of the last pull stays alive; nothing accumulates)
+
+  def weights_scale_ok(self, flat_host):
+    """mz_weights_scale_ok for this engine's shapes on a host copy of the flat weights"""
+    return weights_scale_ok(flat_host, self.O, self.A, self._outputs[0], self._outputs[1])
 
   def weight_scale(self):
     """(1, 2^-k, 2^k, chosen) of the last set_weights (mz_weight_scale): the power of two the search kernel's weight

@@ -111,9 +111,9 @@ def launch_ranks(config, max_moves, selfplay_only=False, learner_steps=None, sta
     ring = D.ShmRing('%s_%d' % (run_id, rank))
     actor_replay = D.RingReplay(ring)
   del probe
-  from .engine import flatten_weights
+  from .engine import config_scale_check, flatten_weights
   rstorage = D.RankStorage(rank, world, device, n_flat, storage=storage, storage_call=_call, backend=backend,
-                           flatten=flatten_state if torch_net else flatten_weights)
+                           flatten=flatten_state if torch_net else flatten_weights, scale_check=config_scale_check(config))
   dedicated = bool(getattr(config, 'dedicated_learner_rank', False)) and world > 1 and not selfplay_only
   if dedicated and config.environment == 'TicTacToe' and (getattr(config, 'parity_rng', False) or B == 1):
     raise SystemExit('--dedicated_learner_rank: host-environment actors pull weights per game, not per move count')
@@ -159,6 +159,7 @@ def launch_ranks(config, max_moves, selfplay_only=False, learner_steps=None, sta
     ring_.release()
   if hasattr(actor, 'selfplay'):
     actor.selfplay.close()
+  rstorage.close()
   dist.destroy_process_group()
   ray.shutdown()
   return summary

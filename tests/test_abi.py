@@ -132,3 +132,43 @@ def test_cffi_dlopen_fast_path():
   import torch  # noqa: F401  (one HIP runtime per process: torch's first, model_based_rl_amd/_abi.py)
   eng = ffi2.dlopen(os.path.join(ROOT, 'model-based-rl_amd', 'csrc', 'libmz_hip.so'))
   assert eng.mz_version() == 1
+
+
+def test_weights_scale_ok_is_host_arithmetic():
+  """mz_weights_scale_ok (the host's side of the clamp-ReLU scale decision, mz_set_weights_async): no GPU involved; 1 for
+  PyTorch-initialised weights, 0 for a weight set with an absurd or non-finite entry in the layers the bound covers, an
+  error for a vector of the wrong length; and equal to a numpy restatement of the bound (k_relu_bound / k_relu_scale)."""
+  import types
+  import numpy as np
+  import torch
+  from model_based_rl_amd.engine import flatten_weights, weights_scale_ok
+  from model_based_rl_amd.networks import FCNetwork
+  torch.manual_seed(0)
+  O, A, S = 8, 4, 31
+  net = FCNetwork(O, A, torch.device('cpu'), types.SimpleNamespace())
+  sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+  flat = flatten_weights(sd)
+  assert weights_scale_ok(flat, O, A, S, S) == 1
+  with pytest.raises(RuntimeError):
+    weights_scale_ok(flat[:-1], O, A, S, S)
+  for key, val in (('reward_head.fc1.weight', 1e30), ('transition_head.fc1.bias', float('nan')), ('LN.weight', float('inf')),
+                   ('policy_head.policy.weight', 3e38), ('value_head.fc1.weight', float('nan'))):
+    bad = {k: v.clone() for k, v in sd.items()}
+    bad[key].view(-1)[3] = val
+    assert weights_scale_ok(flatten_weights(bad), O, A, S, S) == 0, key
+  # weights outside the bound's layers do not matter (the representation runs in the root kernel, unscaled)
+  free = {k: v.clone() for k, v in sd.items()}
+  free['representation_head.fc1.weight'].view(-1)[0] = 1e30
+  assert weights_scale_ok(flatten_weights(free), O, A, S, S) == 1
+  # a large-but-finite gain: the decision follows the bound
+  for gain, want in ((1e3, 1), (1e9, 1), (1e13, 0)):
+    g = {k: v.clone() for k, v in sd.items()}
+    g['value_head.fc1.weight'] *= gain
+    hb = 7.01 * g['LN.weight'].abs().double() + g['LN.bias'].abs().double()
+    bound = 0.0
+    for head, onehot in (('reward_head', A), ('transition_head', A), ('value_head', 0), ('policy_head', 0)):
+      w, b = g[head + '.fc1.weight'].abs().double(), g[head + '.fc1.bias'].abs().double()
+      s = (w[:, :50] * hb).sum(1) + (w[:, 50:].max(1).values if onehot else 0.0) + b
+      bound = max(bound, float(s.max()))
+    assert (bound * 1.02 < 2.0 ** 39) == bool(want), (gain, bound)
+    assert weights_scale_ok(flatten_weights(g), O, A, S, S) == want, gain

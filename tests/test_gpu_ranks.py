@@ -132,6 +132,8 @@ def test_bench_over_rccl_at_world_size_1():
   line = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
   c = line['collectives']
   assert c['backend'] == 'nccl' and c['world'] == 1 and c['forced_at_world_1'] and c['rccl_mapped'] and c['weights_on_device']
+  assert c['broadcast'].startswith('mz_broadcast_weights')            # ncclBroadcast from libmz_hip.so, on a side stream
+  assert '0 pipeline drains' in line['config']['weight_sync']
   assert line['n_gpus'] == 1 and line['metric'].startswith('env-steps/sec') and line['value'] > 0
   pulls = int(line['config']['weight_sync'].split(':')[1].split()[0])
   assert pulls >= 2, line['config']['weight_sync']                     # broadcasts of device buffers inside the timed region
@@ -208,7 +210,7 @@ def test_bench_eight_ranks_on_one_gpu():
   for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
     env.pop(k, None)
   out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(N), '--steps', str(steps), '--warmup', '16',
-                        '--no-cpu-baseline', '--envs', str(B), '--min-seconds', '0.5', '--runs', '2'],
+                        '--no-cpu-baseline', '--envs', str(B), '--min-seconds', '2', '--runs', '2'],      # (regions of ~2 s: the one-replay layout starts on a fresh replay)
                        env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
   assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
   rows = [l for l in out.stdout.splitlines() if l.startswith('{')]

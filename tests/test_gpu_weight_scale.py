@@ -217,3 +217,81 @@ def test_root_hidden_from_outside_runs_the_stand_alone_kernels():
   wide = margin > MARGIN
   same = np.all(tree['N'] == ref['N'], axis=1)
   assert wide.sum() > 0.7 * B and np.all(same[wide]), (wide.sum(), (wide & ~same).sum())
+
+
+def test_async_weight_pull_equals_the_synchronous_one_and_does_not_wait():
+  """mz_set_weights_async (what Engine.set_weights does with host weights; reference actors.py:81-85): the same packed stream
+  and scale as mz_set_weights, bit for bit -- and its host side does not wait for the moves queued before it: with ~20 ms of
+  self-play launches in the queue the call returns in a fraction of that, the moves queued AFTER it play with the new weights."""
+  import time
+  from model_based_rl_amd.engine import Engine, flatten_weights
+  O, A, sims, B = 8, 4, 30, 4096
+  sd0, sd1 = _state(O, A, 0), _state(O, A, 1)
+  obs = np.random.RandomState(0).standard_normal((B, O)).astype(np.float32)
+
+  def outputs(eng):
+    eng.initial_inference(obs)
+    return [x.cpu().numpy() for x in eng.root_outputs()]
+
+  a, b = Engine(B, O, A, sims, seed=3), Engine(B, O, A, sims, seed=3)
+  a.set_weights(flatten_weights(sd1), sync=True)
+  b.set_weights(sd0)
+  b.selfplay_reset(64, 1.0, stagger=True)
+  pinned = torch.empty(48, B, b.rec_floats, dtype=torch.float32).pin_memory()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(3):
+    b.selfplay_steps(16)                # ~6.5 ms of GPU work each
+  t1 = time.perf_counter()
+  b.set_weights(sd1)                    # host weights: flatten, mz_weights_scale_ok, mz_set_weights_async
+  t2 = time.perf_counter()
+  torch.cuda.synchronize()
+  t3 = time.perf_counter()
+  queued_ms, call_ms, gpu_ms = 1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (t3 - t0)
+  assert gpu_ms > 12.0, gpu_ms                           # the launches really were in flight ...
+  assert call_ms < 0.35 * gpu_ms, (call_ms, gpu_ms)      # ... and the pull did not wait for them
+  b.selfplay_drain(pinned, 48)
+  torch.cuda.synchronize()
+  for x, y in zip(outputs(a), outputs(b)):
+    assert np.array_equal(x, y)
+  assert np.array_equal(a.weight_scale(), b.weight_scale()) and b.weight_scale()[3] == 1.0
+  # a device source with the host's decision riding along (the RCCL path, distributed.RankStorage): same result
+  flat0 = flatten_weights(sd0)
+  dev = flat0.cuda()
+  b.set_weights(dev, scale_ok=b.weights_scale_ok(flat0))
+  a.set_weights(flat0, sync=True)
+  for x, y in zip(outputs(a), outputs(b)):
+    assert np.array_equal(x, y)
+  # ... and the call with a device source is capturable: replaying the graph after the buffer changed repacks the new weights
+  side = torch.cuda.Stream()
+  side.wait_stream(torch.cuda.current_stream())
+  with torch.cuda.stream(side):
+    b.set_weights(dev, scale_ok=1)      # (warm-up on the capture stream)
+  torch.cuda.current_stream().wait_stream(side)
+  g = torch.cuda.CUDAGraph()
+  with torch.cuda.graph(g):
+    b.set_weights(dev, scale_ok=1)
+  dev.copy_(flatten_weights(sd1))
+  g.replay()
+  a.set_weights(flatten_weights(sd1), sync=True)
+  for x, y in zip(outputs(a), outputs(b)):
+    assert np.array_equal(x, y)
+  a.close(); b.close()
+
+
+def test_async_pull_of_weights_that_admit_no_scale():
+  """the host's decision (mz_weights_scale_ok = 0) routes the engine to the stand-alone kernels exactly like the synchronous
+  pull's read back does"""
+  from model_based_rl_amd.engine import Engine, flatten_weights
+  O, A, sims, B = 8, 4, 12, 64
+  sd = _state(O, A, 2)
+  bad = {k: v.clone() for k, v in sd.items()}
+  bad['reward_head.fc1.weight'][5, 2] = 1e30
+  eng = Engine(B, O, A, sims)
+  eng.set_weights(sd)
+  assert eng.search_kernel_info()['kind'] == 'fused' and eng.weight_scale()[3] == 1.0
+  eng.set_weights(bad)
+  assert eng.search_kernel_info()['kind'] == 'standalone' and eng.weight_scale()[3] == 0.0
+  eng.set_weights(sd)
+  assert eng.search_kernel_info()['kind'] == 'fused' and eng.weight_scale()[3] == 1.0
+  eng.close()
