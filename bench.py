@@ -602,7 +602,8 @@ def main():
   if dist is not None and world > 1 and not one_replay and not args.no_one_replay_secondary:
     lay2 = Layout(True, 'b')
     actor.replay_buffer = lay2.replay
-    actor.launch(whole(max(args.warmup, 64)))
+    # (the ONE replay starts empty: warm up until its window has been filled once, like the priming above)
+    actor.launch(whole(max(args.warmup, 64, min(int(cfg.window_size) // (B * world) + chunk, 1024))))
     r2 = timed_regions(actor, lay2, per_run, 1)[0]
     one_replay_secondary = {
         'what': 'the layout of `train --ranks N` (reference train.py:71-72: ONE replay buffer for all actors): every rank ships its '

@@ -371,6 +371,30 @@ int mz_fcl_update(mz_fcl *c, const float *obs, const void *actions, int actions_
                   double beta2, double eps, double weight_decay, double clip_grad, int adamw, double *loss_sums, void *stream,
                   int *slot_out);
 int mz_fcl_errors(mz_fcl *c, int slot, float *host_out);
+/* Learner.learn's loop body in native code (learners.py:115-131: sample_batch -> update_weights -> replay_buffer.update),
+ * n_updates training steps per call: Python only at the boundaries where the reference's loop does something else
+ * (send_weights, save_state, logging; learners.py:132-153).  The replay is reached through the caller's function table
+ * (include/mz_replay.h: sample = mzr_sample_batches_full, refresh = mzr_update_errors_f32, last_error = mzr_last_error;
+ * libmz_hip.so does not link libmz_replay.so).  words [n_updates][2 batch]: the generator words of the stratified draws
+ * (random.getrandbits(64 batch n_updates), least significant word first); np_key [624] / *np_pos: numpy's legacy generator
+ * state for the padded actions, advanced in place; *beta_inout: the replay's beta (schedule applied per batch); obs_min /
+ * obs_range [host][obs_dim] or NULL: --norm_obs; lrs [host][n_updates] or NULL: the learning rate of every update (a
+ * scheduler's values; NULL: the device float bound by mz_fcl_bind); loss_sums [dev][3] as mz_fcl_step; *pads_out (may be
+ * NULL): padded actions drawn.  Batch i is sampled while update i - 1 runs on the GPU; the refresh of update i reaches the
+ * replay before batch i + 2 is drawn (the reference's own lag is up to batches_per_fetch = 15 batches, learners.py:124).
+ * Synchronous at its end: returns when the last update's refresh has been handed over. */
+typedef struct mz_fcl_source {
+  void *replay;
+  int (*sample)(void *replay, const uint32_t *words, int n, int bs, float *obs, int32_t *actions, float *target_rewards,
+                float *target_values, float *target_policies, int64_t *idxs, double *is_weights, uint32_t *np_key, int32_t *np_pos,
+                double *beta_inout, int64_t *pads_out);
+  int (*refresh)(void *replay, const int64_t *idxs, const float *errors, int64_t n);
+  const char *(*last_error)(void);
+} mz_fcl_source;
+int mz_fcl_run(mz_fcl *c, const mz_fcl_source *src, int n_updates, const uint32_t *words, uint32_t *np_key, int32_t *np_pos,
+               double *beta_inout, const float *obs_min, const float *obs_range, double beta1, double beta2, double eps,
+               double weight_decay, double clip_grad, int adamw, const float *lrs, double *loss_sums, void *stream,
+               int64_t *pads_out);
 int mz_fcl_read_grad(mz_fcl *c, float *host_out, size_t n);
 /* test hook: tape `which` of the last step into a HOST buffer (0 chain inputs, 1 chain fc1 activations, 2 LayerNorm x-hat, 3 rstd,
  * 4 hidden states, 5 / 6 chain deltas, 7 head fc1 activations, 8 / 9 head deltas, 10 d loss / d hidden state per head, 11 per-sample

@@ -8,9 +8,10 @@
  * propagates `change` leaf-to-root one leaf at a time in arrival order, so tree sums are bit-identical to the
  * reference's for the same sequence of histories.
  *
- * Returns 0 on success, <0 on error (message: mzr_last_error()).  Not thread-safe per handle: one caller at a time
- * (the reference's replay is a Ray actor, replay_buffer.py:69: calls are serialised); mzr_ingest_records* fans the
- * environments of ONE call out over the handle's own ingest threads and joins them before it returns.
+ * Returns 0 on success, <0 on error (message: mzr_last_error(), per calling thread).  One caller at a time per handle (the
+ * reference's replay is a Ray actor, replay_buffer.py:69: calls are serialised): calls from different threads take turns on a
+ * lock inside the handle; mzr_ingest_records* fans the environments of ONE call out over the handle's own ingest threads and
+ * joins them before it returns.
  */
 #ifndef MZ_REPLAY_H
 #define MZ_REPLAY_H
@@ -123,6 +124,23 @@ int mzr_sample_batch_words(const mz_replay *r, const uint32_t *words, int bs, fl
 int mzr_sample_batches_words(const mz_replay *r, const uint32_t *words, int n, int bs, float *obs, int32_t *actions,
                              float *target_rewards, float *target_values, float *target_policies, int64_t *idxs, double *probs,
                              int64_t *info);
+
+/* The learner's side, complete (learners.py:115-153 calls sample_batch and update once per training step; mz_fcl_run in
+ * include/mz_engine.h drives these from native code).
+ * mzr_priorities_f32 / mzr_update_errors_f32: get_priorities / update (replay_buffer.py:110-111,200-203) for the FLOAT32 errors
+ *   the learner sends (learners.py:181-182): numpy evaluates (|e| + epsilon) ** alpha in float32 for a float32 array, the
+ *   refreshed leaves are float32 values (mzr_priorities is the float64 form of save_history's Python-float lists).
+ * mzr_sample_batches_full: n consecutive sample_batch calls with everything the reference does inside them: the stratified
+ *   draws from the caller's generator words (mzr_sample_batches_words), the padded actions from numpy's legacy global
+ *   generator (replay_buffer.py:150-151; its state np_key [624] / *np_pos = np.random.get_state()[1:3], handed back
+ *   advanced), the beta schedule (*beta_inout) and is_weights [n][bs] = (N p)^-beta / max (replay_buffer.py:131-132,157-159;
+ *   the C library's pow: within one unit in the last place of numpy's, whose own power differs between hosts).
+ * All mzr_* entry points of one handle may be called from different threads: they take turns on a lock inside the handle. */
+int mzr_priorities_f32(const mz_replay *r, const float *errors, int64_t n, float *out);
+int mzr_update_errors_f32(mz_replay *r, const int64_t *idxs, const float *errors, int64_t n);
+int mzr_sample_batches_full(mz_replay *r, const uint32_t *words, int n, int bs, float *obs, int32_t *actions, float *target_rewards,
+                            float *target_values, float *target_policies, int64_t *idxs, double *is_weights, uint32_t *np_key,
+                            int32_t *np_pos, double *beta_inout, int64_t *pads_out);
 
 /* number of ingest threads of the handle (mzr_config.ingest_threads at creation; the setter re-creates the pool) */
 int mzr_set_ingest_threads(mz_replay *r, int threads);

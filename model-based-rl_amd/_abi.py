@@ -45,6 +45,11 @@ class MzConfig(C.Structure):
               ('no_support', C.c_int32), ('split_f16', C.c_int32)]
 
 
+class MzFclSource(C.Structure):
+  """mz_fcl_source (include/mz_engine.h): the replay handle and the three entry points of libmz_replay.so mz_fcl_run calls"""
+  _fields_ = [('replay', C.c_void_p), ('sample', C.c_void_p), ('refresh', C.c_void_p), ('last_error', C.c_void_p)]
+
+
 def stale():
   if not os.path.exists(_SO):
     return True
@@ -144,6 +149,7 @@ SIGNATURES = {
     'mz_fcl_step': (_I, [_VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _I, _D, _D, _D, _D, _D, _I, _I, _VP, _VP, _VP]),
     'mz_fcl_update': (_I, [_VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _I, _D, _D, _D, _D, _D, _I, _VP, _VP, C.POINTER(_I)]),
     'mz_fcl_errors': (_I, [_VP, _I, _VP]),
+    'mz_fcl_run': (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _D, _D, _D, _D, _D, _I, _VP, _VP, _VP, _VP]),
     'mz_fcl_read_grad': (_I, [_VP, _VP, _SZ]),
     'mz_fcl_read_tape': (C.c_longlong, [_VP, _I, _VP, _SZ]),
     'mz_fcl_heads_profile': (_I, [_VP, _I, _VP]),
@@ -215,6 +221,9 @@ REPLAY_SIGNATURES = {
     'mzr_frames': (_I64, [_VP]),
     'mzr_games': (_I64, [_VP]),
     'mzr_add_initial_throughput': (_I, [_VP, _I64, _I64]),
+    'mzr_priorities_f32': (_I, [_VP, _VP, _I64, _VP]),
+    'mzr_update_errors_f32': (_I, [_VP, _VP, _VP, _I64]),
+    'mzr_sample_batches_full': (_I, [_VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     'mzr_store_release_i64': (None, [_VP, _I64]),
     'mzr_load_acquire_i64': (_I64, [_VP]),
 }

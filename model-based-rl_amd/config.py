@@ -119,6 +119,9 @@ def build_parser():
   a('--no_native_learner', action='store_true',
     help='FCNetwork learner step through PyTorch operators (GEMM library + autograd) instead of the six HIP launches of '
          'csrc/mz_fcl.hip.h (mz_fcl_step)')
+  a('--no_native_loop', action='store_true',
+    help='drive the native learner step from Python, one update per call (learners.py), instead of mz_fcl_run taking the loop body '
+         '-- sampling, update, priority refresh -- for a whole stretch of updates')
   a('--no_graph_learner', action='store_true',
     help='run the learner step as eager PyTorch launches instead of one captured hipGraph per update (learners.py)')
   a('--learner_log_frequency', type=int, default=100)

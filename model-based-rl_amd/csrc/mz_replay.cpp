@@ -161,7 +161,11 @@ struct mz_replay {
   std::deque<Job> queue;
   std::vector<std::vector<double>> spare;      // recycled priority buffers
   bool inserting = false, qquit = false;
+  // one caller at a time per handle, whoever it is: the actors' ingest on the handle's own Python thread and the native learner
+  // loop's sampling / refresh calls (mz_fcl_run, libmz_hip.so) take turns here
+  std::recursive_mutex api_mu;
 };
+#define MZR_LOCK(r) std::lock_guard<std::recursive_mutex> api_lock_(const_cast<mz_replay *>(r)->api_mu)
 
 static void tree_add(mz_replay *r, const double *priorities, int64_t n, Hist *h, int64_t *positions_out);
 
@@ -441,6 +445,7 @@ int mzr_destroy(mz_replay *r) {
 
 int mzr_set_ingest_threads(mz_replay *r, int threads) {
   if (!r) return fail("mzr_set_ingest_threads: null");
+  MZR_LOCK(r);
   if (threads < 1 || threads > 64) return fail("mzr_set_ingest_threads: threads must be in [1, 64]");
   start_threads(r, threads);
   return 0;
@@ -449,12 +454,14 @@ int mzr_ingest_threads(const mz_replay *r) { return r ? r->pool.T : -1; }
 
 int mzr_priorities(const mz_replay *r, const double *errors, int64_t n, double *out) {
   if (!r || !errors || !out) return fail("mzr_priorities: null argument");
+  MZR_LOCK(r);
   for (int64_t i = 0; i < n; ++i) out[i] = pow(fabs(errors[i]) + r->c.epsilon, r->c.alpha);
   return 0;
 }
 
 int mzr_tree_add(mz_replay *r, const double *priorities, int64_t n, int64_t *positions_out) {
   if (!r || !priorities) return fail("mzr_tree_add: null argument");
+  MZR_LOCK(r);
   drain(r);
   tree_add(r, priorities, n, nullptr, positions_out);
   return 0;
@@ -462,6 +469,7 @@ int mzr_tree_add(mz_replay *r, const double *priorities, int64_t n, int64_t *pos
 
 int mzr_tree_update(mz_replay *r, const int64_t *idxs, const double *priorities, int64_t n) {
   if (!r || !idxs || !priorities) return fail("mzr_tree_update: null argument");
+  MZR_LOCK(r);
   drain(r);
   const int64_t len = 2 * r->max_capacity - 1;
   for (int64_t i = 0; i < n; ++i)
@@ -517,6 +525,7 @@ int mzr_tree_update(mz_replay *r, const int64_t *idxs, const double *priorities,
 // SumTree.get_leaf, replay_buffer.py:42-62 (returns the tree index of the leaf)
 static int64_t get_leaf(const mz_replay *r, double value);
 int64_t mzr_tree_get_leaf(const mz_replay *r, double value) {
+  MZR_LOCK(r);
   drain(r);
   return get_leaf(r, value);
 }
@@ -535,6 +544,7 @@ static int64_t get_leaf(const mz_replay *r, double value) {
 // SumTree.get_leaf's payload (replay_buffer.py:58-62): the (step, history) the leaf at tree index idx holds
 int mzr_leaf_info(const mz_replay *r, int64_t idx, double *priority, int64_t *step, int64_t *n_steps, int *has_payload) {
   if (!r) return fail("mzr_leaf_info: null handle");
+  MZR_LOCK(r);
   drain(r);
   const int64_t pos = idx - r->max_capacity + 1;
   if (pos < 0 || pos >= r->max_capacity) return fail("mzr_leaf_info: %lld is not a leaf index", (long long)idx);
@@ -548,6 +558,7 @@ int mzr_leaf_info(const mz_replay *r, int64_t idx, double *priority, int64_t *st
 
 int mzr_leaf_history(const mz_replay *r, int64_t idx, float *rows_out, int64_t n_steps) {
   if (!r || !rows_out) return fail("mzr_leaf_history: null argument");
+  MZR_LOCK(r);
   drain(r);
   const int64_t pos = idx - r->max_capacity + 1;
   if (pos < 0 || pos >= r->max_capacity) return fail("mzr_leaf_history: %lld is not a leaf index", (long long)idx);
@@ -559,10 +570,11 @@ int mzr_leaf_history(const mz_replay *r, int64_t idx, float *rows_out, int64_t n
   return 0;
 }
 
-double mzr_total_priority(const mz_replay *r) { drain(r); return r->tree[0]; }
-int64_t mzr_size(const mz_replay *r) { drain(r); return r->num_memories; }
+double mzr_total_priority(const mz_replay *r) { MZR_LOCK(r); drain(r); return r->tree[0]; }
+int64_t mzr_size(const mz_replay *r) { MZR_LOCK(r); drain(r); return r->num_memories; }
 int mzr_tree_leaves(const mz_replay *r, int64_t n, double *out) {
   if (!r || !out || n > r->max_capacity) return fail("mzr_tree_leaves: bad argument");
+  MZR_LOCK(r);
   drain(r);
   memcpy(out, r->tree.data() + r->max_capacity - 1, (size_t)n * sizeof(double));
   return 0;
@@ -572,6 +584,7 @@ int mzr_save_history(mz_replay *r, int64_t n, const double *errors, int64_t igno
                      const float *child_visits, const double *root_values, const float *rewards,
                      const int32_t *actions, const uint8_t *dones, const int8_t *to_play) {
   if (!r || (n > 0 && !errors)) return fail("mzr_save_history: null argument");
+  MZR_LOCK(r);
   drain(r);
   return save_history(r, n, errors, ignore, terminal, obs, child_visits, root_values, rewards, actions, dones, to_play);
 }
@@ -656,6 +669,7 @@ static void ingest_range(mz_replay *r, Scratch &sc, const float *records, int n_
 
 int mzr_ingest_records_from(mz_replay *r, const float *records, int n_moves, int B, int rec_floats, int env_base) {
   if (!r || !records) return fail("mzr_ingest_records: null argument");
+  MZR_LOCK(r);
   if (n_moves < 0 || B < 1 || env_base < 0) return fail("mzr_ingest_records: bad shape (n_moves %d, B %d, env_base %d)", n_moves, B, env_base);
   if (rec_floats != r->R)
     return fail("mzr_ingest_records: rec_floats %d != obs slots (%d) + action_space + %d = %d", rec_floats, r->OS, MZR_REC_EXTRA, r->R);
@@ -710,6 +724,7 @@ int mzr_sample_batch(const mz_replay *r, const double *draws, int bs, float *obs
                      double *priorities) {
   if (!r || !draws || !obs || !actions || !target_rewards || !target_values || !target_policies || !idxs || !priorities)
     return fail("mzr_sample_batch: null argument");
+  MZR_LOCK(r);
   drain(r);
   const int O = r->c.obs_dim, OS = r->OS, A = r->c.action_space, K = r->c.num_unroll_steps, td = r->c.td_steps, R = r->R;
   const int TL = K + 1;
@@ -827,6 +842,7 @@ int mzr_sample_batch(const mz_replay *r, const double *draws, int bs, float *obs
 int mzr_sample_batch_words(const mz_replay *r, const uint32_t *words, int bs, float *obs, int32_t *actions, float *target_rewards,
                            float *target_values, float *target_policies, int64_t *idxs, double *probs, int64_t *info) {
   if (!r || !words || !probs || !info || bs < 1) return fail("mzr_sample_batch_words: bad argument");
+  MZR_LOCK(r);
   drain(r);
   const double total = r->tree[0];
   const double seg = total / (double)bs;
@@ -854,6 +870,7 @@ int mzr_sample_batches_words(const mz_replay *r, const uint32_t *words, int n, i
                              float *target_rewards, float *target_values, float *target_policies, int64_t *idxs, double *probs,
                              int64_t *info) {
   if (!r || n < 1) return fail("mzr_sample_batches_words: bad argument");
+  MZR_LOCK(r);
   const size_t O = (size_t)r->c.obs_dim, A = (size_t)r->c.action_space, K = (size_t)r->c.num_unroll_steps, B = (size_t)bs;
   for (int j = 0; j < n; ++j) {
     const size_t o = (size_t)j * B;
@@ -864,10 +881,108 @@ int mzr_sample_batches_words(const mz_replay *r, const uint32_t *words, int n, i
   return 0;
 }
 
-int64_t mzr_frames(const mz_replay *r) { drain(r); return r->frames; }
-int64_t mzr_games(const mz_replay *r) { drain(r); return r->games; }
+// ---- the learner's side of the replay, natively (learners.py:115-153 calls sample_batch / update once per training step)
+
+// PrioritizedReplay.get_priorities on the float32 errors the learner sends (learners.py:181-182: new_errors is a float32
+// numpy array): numpy evaluates np.power(np.abs(errors) + epsilon, alpha) in FLOAT32 for a float32 array and Python-float
+// epsilon / alpha (replay_buffer.py:110-111), so the refreshed leaves are float32 values -- not the doubles mzr_priorities
+// computes for the lists of Python floats save_history passes.
+int mzr_priorities_f32(const mz_replay *r, const float *errors, int64_t n, float *out) {
+  if (!r || !errors || !out) return fail("mzr_priorities_f32: null argument");
+  const float eps = (float)r->c.epsilon, alpha = (float)r->c.alpha;
+  for (int64_t i = 0; i < n; ++i) {
+    const float x = fabsf(errors[i]) + eps;
+    out[i] = alpha == 1.f ? x : powf(x, alpha);
+  }
+  return 0;
+}
+
+// PrioritizedReplay.update (replay_buffer.py:200-203) for float32 errors: float32 priorities, leaf by leaf in arrival order
+int mzr_update_errors_f32(mz_replay *r, const int64_t *idxs, const float *errors, int64_t n) {
+  if (!r || !idxs || !errors || n < 0) return fail("mzr_update_errors_f32: bad argument");
+  MZR_LOCK(r);
+  std::vector<float> p32((size_t)n);
+  std::vector<double> p64((size_t)n);
+  if (mzr_priorities_f32(r, errors, n, p32.data())) return -1;
+  for (int64_t i = 0; i < n; ++i) p64[(size_t)i] = (double)p32[(size_t)i];
+  return mzr_tree_update(r, idxs, p64.data(), n);
+}
+
+// numpy's legacy global generator, np.random.get_state() = ('MT19937', key [624], pos, ...): 32-bit outputs
+static inline uint32_t np_mt_next(uint32_t *key, int32_t *pos) {
+  if (*pos >= 624) {
+    int i;
+    for (i = 0; i < 624 - 397; ++i) {
+      const uint32_t y = (key[i] & 0x80000000u) | (key[i + 1] & 0x7fffffffu);
+      key[i] = key[i + 397] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    for (; i < 623; ++i) {
+      const uint32_t y = (key[i] & 0x80000000u) | (key[i + 1] & 0x7fffffffu);
+      key[i] = key[i + (397 - 624)] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    const uint32_t y = (key[623] & 0x80000000u) | (key[0] & 0x7fffffffu);
+    key[623] = key[396] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    *pos = 0;
+  }
+  uint32_t y = key[(*pos)++];
+  y ^= y >> 11;
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= y >> 18;
+  return y;
+}
+
+// sample_batch COMPLETE for n consecutive batches (replay_buffer.py:124-163): mzr_sample_batches_words, then
+//  * the padded actions (replay_buffer.py:150-151: np.random.randint(action_space) where the history ends before the
+//    unroll does) drawn in element order from numpy's legacy generator, whose state the caller hands over
+//    (np.random.get_state(): np_key [624], *np_pos) and takes back -- RandomState.randint(A) is a masked rejection on
+//    32-bit outputs (numpy/random/_bounded_integers: buffered_bounded_masked_uint32), no draw for A = 1;
+//  * beta += beta_increment up to 1 per batch (replay_buffer.py:131-132), is_weights = (N p)^-beta / max
+//    (replay_buffer.py:157-159) in double.  pow() is the C library's: numpy's vectorised power may differ from it in the
+//    last bit of a double (both are within an ulp; which one numpy uses depends on the host's SIMD level), the one output
+//    of this call that is not bit for bit the reference's.
+// is_weights [n][bs]; pads_out (may be null): total number of padded actions.
+int mzr_sample_batches_full(mz_replay *r, const uint32_t *words, int n, int bs, float *obs, int32_t *actions, float *target_rewards,
+                            float *target_values, float *target_policies, int64_t *idxs, double *is_weights, uint32_t *np_key,
+                            int32_t *np_pos, double *beta_inout, int64_t *pads_out) {
+  if (!r || !words || !is_weights || !np_key || !np_pos || !beta_inout || n < 1 || bs < 1) return fail("mzr_sample_batches_full: bad argument");
+  MZR_LOCK(r);
+  const size_t O = (size_t)r->c.obs_dim, A = (size_t)r->c.action_space, K = (size_t)r->c.num_unroll_steps, B = (size_t)bs;
+  uint32_t mask = (uint32_t)(A - 1);
+  mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+  int64_t pads = 0;
+  for (int j = 0; j < n; ++j) {
+    const size_t o = (size_t)j * B;
+    int64_t info[2];
+    double *w = is_weights + o;
+    if (mzr_sample_batch_words(r, words + 2 * o, bs, obs + o * O, actions + o * K, target_rewards + o * (K + 1), target_values + o * (K + 1),
+                               target_policies + o * (K + 1) * A, idxs + o, w, info))
+      return -1;
+    if (info[0]) {
+      int32_t *act = actions + o * K;
+      for (size_t i = 0; i < B * K; ++i)
+        if (act[i] < 0) {
+          uint32_t v = 0;
+          if (A > 1) do { v = np_mt_next(np_key, np_pos) & mask; } while (v > (uint32_t)(A - 1));
+          act[i] = (int32_t)v;
+        }
+      pads += info[0];
+    }
+    if (*beta_inout < 1.0) { const double b = *beta_inout + r->c.beta_increment_per_sampling; *beta_inout = b < 1.0 ? b : 1.0; }
+    const double beta = *beta_inout, N = (double)info[1];
+    double mx = 0.0;
+    for (size_t i = 0; i < B; ++i) { w[i] = pow(N * w[i], -beta); if (w[i] > mx) mx = w[i]; }
+    for (size_t i = 0; i < B; ++i) w[i] /= mx;
+  }
+  if (pads_out) *pads_out = pads;
+  return 0;
+}
+
+int64_t mzr_frames(const mz_replay *r) { MZR_LOCK(r); drain(r); return r->frames; }
+int64_t mzr_games(const mz_replay *r) { MZR_LOCK(r); drain(r); return r->games; }
 int mzr_add_initial_throughput(mz_replay *r, int64_t frames, int64_t games) {
   if (!r) return fail("mzr_add_initial_throughput: null");
+  MZR_LOCK(r);
   drain(r);
   r->frames += frames; r->games += games;
   return 0;

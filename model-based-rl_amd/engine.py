@@ -181,6 +181,7 @@ class Engine(object):
       raise ValueError('expected %d weights, got %d' % (self.num_weights, weights.numel()))
     on_dev = weights.is_cuda
     w = weights.to(torch.float32).contiguous()
+    sync = sync or os.environ.get('MZ_SYNC_WEIGHTS', '0')[:1] == '1'      # (A/B runs against the synchronous pull)
     if not on_dev and scale_ok is None and not sync:
       scale_ok = self.weights_scale_ok(w)
     if scale_ok is None or sync:

