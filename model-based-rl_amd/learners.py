@@ -388,6 +388,10 @@ class _GraphedUpdate(object):
     params = [p for g in opt.param_groups for p in g['params']]
     saved_p = [p.detach().clone() for p in params]
     saved_s = [{k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in opt.state.get(p, {}).items()} for p in params]
+    # (module buffers too: BatchNorm's running_mean / running_var / num_batches_tracked take a momentum update in every
+    # training-mode forward -- four of them here -- and travel to the actors with get_weights)
+    buffers = list(net.buffers())
+    saved_b = [b.detach().clone() for b in buffers]
     saved_l = learner._loss_dev.clone()
     side = torch.cuda.Stream(dev)
     side.wait_stream(torch.cuda.current_stream(dev))
@@ -405,6 +409,8 @@ class _GraphedUpdate(object):
         for k, v in opt.state[p].items():
           if torch.is_tensor(v):
             v.copy_(ss[k]) if k in ss else v.zero_()
+      for b, sb in zip(buffers, saved_b):
+        b.copy_(sb)
       learner._loss_dev.copy_(saved_l)
 
   def fits(self, host):
@@ -565,7 +571,8 @@ class Learner(Logger):
     self.run_tag = os.path.join(str(self.run_tag), 'resumed', '{}'.format(state['training_step']))
     if getattr(self, '_native', None) is not None:      # (the optimiser's loaded state replaces the flat views: rebuilt at the next update)
       self._native.close()
-      self._native, self._graph = None, None
+    # a captured graph holds the OLD exp_avg / exp_avg_sq / step / lr tensors: load_state_dict below replaces them
+    self._native, self._graph = None, None
     self.network.load_state_dict(state['weights'])
     # the optimiser's state comes from the checkpoint, HOW it steps (capturable / fused / foreach, the learning rate as a
     # device tensor the captured graph reads) stays this learner's: a checkpoint of an eager learner resumes under a graphed
@@ -576,6 +583,12 @@ class Learner(Logger):
       g.update({k: v for k, v in kept.items() if k in g or v is not None})
       lr = float(g['lr'])
       g['lr'] = torch.tensor(lr, dtype=torch.float32, device=self.device) if self.use_graph else lr
+    if self.use_graph:
+      # a checkpoint of an EAGER learner leaves `step` a CPU tensor (Optimizer.load_state_dict casts it by the SAVED group's
+      # capturable / fused flags); the capturable fused step of this learner wants it beside the parameter
+      for p_, st in self.optimizer.state.items():
+        if torch.is_tensor(st.get('step')):
+          st['step'] = st['step'].to(device=p_.device, dtype=torch.float32)
     _call(self.replay_buffer, 'add_initial_throughput', state['total_frames'], state['total_games'])
     self.throughput['total_frames'] = state['total_frames']
     self.throughput['training_step'] = state['training_step']

@@ -236,11 +236,18 @@ def main(argv=None):
   cfg = Config(args)
   if load_state:                    # train.py:130-134: launch(state['config'], date, state=state)
     state = torch.load(load_state, map_location='cpu', weights_only=False)
-    given = {a.lstrip('-') for a in argv if a.startswith('--')}
+    given = {a.lstrip('-').split('=', 1)[0] for a in argv if a.startswith('--')}      # (both `--flag value` and `--flag=value`)
     saved = state['config']
-    for k in ('training_steps', 'runs_dir', 'num_envs', 'stored_before_train', 'save_state_frequency', 'use_gpu_for'):
+    overridable = ('training_steps', 'runs_dir', 'num_envs', 'stored_before_train', 'save_state_frequency', 'use_gpu_for')
+    for k in overridable:
       if k in given:
         setattr(saved, k, getattr(cfg, k))
+    ignored = sorted(k for k in given if k not in overridable and k not in ('load_state', 'max_moves', 'selfplay_only', 'learner_steps', 'ranks',
+                                                                           'dedicated_learner_rank', 'prime_moves')
+                     and getattr(saved, k, None) != getattr(cfg, k, None))
+    if ignored:
+      print('train --load_state: the checkpoint\'s config is the run\'s config (train.py:130-134); ignored on the command line: %s'
+            % ', '.join('--' + k for k in ignored), file=sys.stderr)
     cfg = saved
   cfg.action_space, cfg.obs_space = env_shapes(cfg)
   from .config import obs_are_bytes

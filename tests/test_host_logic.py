@@ -153,3 +153,25 @@ def test_bench_times_the_products_entry_points():
   # the learner line: the timed statement is learner.launch.remote(updates) through the handle
   lsrc = open(os.path.join(root, 'bench_learner.py')).read()
   assert 'learner.launch.remote(updates)' in lsrc and 'update_weights' not in lsrc and 'learner_graph_speed' not in lsrc
+
+
+def test_load_state_overrides_accept_both_flag_forms(tmp_path, capsys):
+  """train --load_state: `--training_steps=8` overrides the checkpoint's config like `--training_steps 8` does, and a flag
+  that cannot override it (the checkpoint's config is the run's config, reference train.py:130-134) is reported, not
+  silently dropped (r04 advice).  The parsing only: no GPU."""
+  import types
+  import torch
+  from model_based_rl_amd import train
+  from model_based_rl_amd.config import make_config
+  saved = make_config(['--environment', 'TicTacToe', '--seed', '1', '--training_steps', '100', '--batch_size', '32'])
+  path = str(tmp_path / 'ckpt')
+  torch.save({'config': saved, 'training_step': 0}, path)
+  seen = {}
+  orig = train.launch
+  train.launch = lambda cfg, *a, **k: seen.setdefault('cfg', cfg)
+  try:
+    train.main(['--environment', 'TicTacToe', '--load_state', path, '--training_steps=8', '--batch_size', '64'])
+  finally:
+    train.launch = orig
+  assert seen['cfg'].training_steps == 8 and seen['cfg'].batch_size == 32
+  assert '--batch_size' in capsys.readouterr().err
