@@ -60,7 +60,10 @@ def main(args):
   warm = max(30, args.warmup if args.warmup != 64 else 30)
   out = {}
   with contextlib.redirect_stdout(sys.stderr):
-    for name, extra in (('native', []), ('torch_graph', ['--no_native_learner'])):
+    variants = (('native', []), ('torch_graph', ['--no_native_learner']))
+    if os.environ.get('MZ_LEARNER_ONLY'):          # (profiling: one variant)
+      variants = tuple(v for v in variants if v[0] in os.environ['MZ_LEARNER_ONLY'].split(','))
+    for name, extra in variants:
       cfg, storage, replay, learner = setup(extra)
       ray.get(learner.launch.remote(warm))          # Learner.launch -> Learner.learn(max_steps) (learners.py:115-153)
       runs = []
@@ -84,8 +87,10 @@ def main(args):
       out[name] = {'updates_per_second': float(v.mean()), 'std': float(v.std()), 'runs': v.tolist(), 'gpu_ms_per_update': e0.elapsed_time(e1) / 50,
                    'native_step': lrn._native is not None, 'native_loop': bool(getattr(lrn, 'native_loop_updates', 0)),
                    'replay_frames': ray.get(replay.size.remote()), 'training_step': lrn.training_step,
-                   'last_throughput': lrn.get_last_throughput(), 'cfg': cfg}
-  cfg = out['native'].pop('cfg'); out['torch_graph'].pop('cfg')
+                   'last_throughput': lrn.get_last_throughput(), 'cfg': cfg,
+                   'native_loop_host_us_per_update': lrn._native.run_stats() if lrn._native is not None else None}
+  cfg = out['native'].pop('cfg')
+  out.setdefault('torch_graph', {'updates_per_second': None, 'std': None, 'gpu_ms_per_update': None, 'cfg': None}).pop('cfg')
   bs, K, A = cfg.batch_size, cfg.num_unroll_steps, cfg.action_space
   O = int(np.prod(cfg.obs_space))
   Sv, Sr = cfg.value_support_max - cfg.value_support_min + 1, cfg.reward_support_max - cfg.reward_support_min + 1
@@ -99,7 +104,7 @@ def main(args):
                                  'timed call: Learner.launch(%d) = Learner.learn on the replay / storage handles train.launch builds '
                                  '(send_weights every %d, save_state every %d, loss + throughput scalars every %d updates)'
                                  % (O, A, bs, K, updates, cfg.send_weights_frequency, cfg.save_state_frequency, cfg.learner_log_frequency),
-                     'native_loop': n['native_loop'],
+                     'native_loop': n['native_loop'], 'native_loop_host_us_per_update': n['native_loop_host_us_per_update'],
                      'runs': '%d x %d updates: mean +- std' % (len(n['runs']), updates)},
           'runs': {'mean': n['updates_per_second'], 'std': n['std'], 'values': n['runs']},
           'roofline': {'bound': 'mfma', 'kernel': 'mz_fcl_update (k_fcl_chain_fwd4, k_fcl_heads, k_fcl_chain_bwd4, k_fcl_dw, k_fcl_adam + 2 copies)',

@@ -364,7 +364,7 @@ int mz_fcl_step(mz_fcl *c, const float *obs, const void *actions, int actions_ar
                 double weight_decay, double clip_grad, int adamw, int no_update, float *new_errors, double *loss_sums, void *stream);
 /* mz_fcl_update: mz_fcl_step from HOST arrays (what replay_buffer.sample_batch returns, learners.py:165-180): staged through
  * pinned memory (two slots), one host-to-device copy, the step, the new errors copied back -- nothing is waited for except
- * the slot's own use two updates ago.  mz_fcl_errors(slot): the new errors of that update into host_out [batch], waiting for
+ * the slot's own use three updates ago.  mz_fcl_errors(slot): the new errors of that update into host_out [batch], waiting for
  * their copy (the priority refresh goes to the replay one update behind, as the reference's fire-and-forget refresh does). */
 int mz_fcl_update(mz_fcl *c, const float *obs, const void *actions, int actions_are_i32, const float *target_rewards,
                   const float *target_values, const float *target_policies, const void *is_weights, int weights_are_f64, double beta1,
@@ -395,6 +395,9 @@ int mz_fcl_run(mz_fcl *c, const mz_fcl_source *src, int n_updates, const uint32_
                double *beta_inout, const float *obs_min, const float *obs_range, double beta1, double beta2, double eps,
                double weight_decay, double clip_grad, int adamw, const float *lrs, double *loss_sums, void *stream,
                int64_t *pads_out);
+/* development hook: mz_fcl_run's host time since the handle was created (or the last reset): out [host][6] = seconds waiting for
+ * a staging slot's previous update, in priority refreshes, in sampling, in launching, in the calls as a whole; number of updates */
+int mz_fcl_run_stats(mz_fcl *c, double *out6, int reset);
 int mz_fcl_read_grad(mz_fcl *c, float *host_out, size_t n);
 /* test hook: tape `which` of the last step into a HOST buffer (0 chain inputs, 1 chain fc1 activations, 2 LayerNorm x-hat, 3 rstd,
  * 4 hidden states, 5 / 6 chain deltas, 7 head fc1 activations, 8 / 9 head deltas, 10 d loss / d hidden state per head, 11 per-sample

@@ -9,9 +9,11 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <deque>
 #include <functional>
 #include <string>
+#include <chrono>
 #include <vector>
 
 #include "../../include/mz_engine.h"

@@ -317,6 +317,15 @@ class _NativeFC(object):
     replay.beta = np.float64(beta.value) if float(replay.beta) < 1 else replay.beta
     return int(pads.value)
 
+  def run_stats(self, reset=False):
+    """where mz_fcl_run's host time went (development hook): microseconds per update"""
+    import ctypes as C
+    out = (C.c_double * 6)()
+    self.lib.mz_fcl_run_stats(self.h, out, int(bool(reset)))
+    n = max(1.0, out[5])
+    return {'updates': int(out[5]), 'wait_us': 1e6 * out[0] / n, 'refresh_us': 1e6 * out[1] / n, 'sample_us': 1e6 * out[2] / n,
+            'launch_us': 1e6 * out[3] / n, 'call_us': 1e6 * out[4] / n}
+
   def errors(self, slot):
     import ctypes as C
     from . import _abi
