@@ -382,7 +382,9 @@ int mz_fcl_errors(mz_fcl *c, int slot, float *host_out);
  * scheduler's values; NULL: the device float bound by mz_fcl_bind); loss_sums [dev][3] as mz_fcl_step; *pads_out (may be
  * NULL): padded actions drawn.  Batch i is sampled while update i - 1 runs on the GPU; the refresh of update i reaches the
  * replay before batch i + 2 is drawn (the reference's own lag is up to batches_per_fetch = 15 batches, learners.py:124).
- * Synchronous at its end: returns when the last update's refresh has been handed over. */
+ * Returns with the last (up to three) updates still in flight: the next call hands their refreshes over as their staging slots come
+ * up; n_updates = 0 flushes -- waits for them and hands the refreshes over (before anything else touches the replay's
+ * priorities or this handle's staging: mz_fcl_update, a checkpoint, the end of Learner.learn). */
 typedef struct mz_fcl_source {
   void *replay;
   int (*sample)(void *replay, const uint32_t *words, int n, int bs, float *obs, int32_t *actions, float *target_rewards,

@@ -494,7 +494,7 @@ class Actor(Logger):
     print('Actor-{} is online on {}.'.format(self.actor_key, self.device))
     # the device loop gets a HIP stream of its own: on the default stream every kernel of a learner sharing the GPU
     # (train.py, --use_gpu_for actors learner) would queue behind whole-moves launches of several milliseconds each
-    # (measured: 124 updates/s alone, 3.7 beside an actor on the same stream; scripts/learner_speed.py)
+    # (measured: 124 updates/s alone, 3.7 beside an actor on the same stream; scripts/experiments/learner_speed.py)
     # (one stream per actor, kept across launch() calls: the record ring orders its slots behind the drains of this stream)
     if self._stream is None:
       self._stream = torch.cuda.Stream(self.device)

@@ -77,7 +77,7 @@ __device__ __forceinline__ void mz_mfma_a0(f32x4 &c, float a, float b) {
 }
 // v_mfma_f32_4x4x1_16b_f32: sixteen independent 4x4 outer products per instruction (block = lane / 4: row r of the
 // result comes from the A operand of lane 4 * block + r, column lane % 4 from the B operand of the lane itself;
-// scripts/mfma4x4_check.hip).  With the B operand = a hidden tile as it stands (lane: tree = lane & 15, feature
+// scripts/experiments/mfma4x4_check.hip).  With the B operand = a hidden tile as it stands (lane: tree = lane & 15, feature
 // 16 t + 4 (lane >> 4) + r) one instruction multiplies FOUR output rows by the 16 trees over the four features the
 // wave's four lane rows hold, at 11.5 cycles instead of 32: output layers with 4 (or 2) useful rows -- the policy head
 // of a 4-action game, rows 48..49 of the 50-wide hidden state -- stop paying for a 16-row tile.  The result of lane
@@ -961,7 +961,7 @@ __global__ __launch_bounds__(256, 1) void k_search_fused(NetView n, TreeView t, 
 #ifndef MZ_RELU_VMAX
 #pragma unroll
           for (int tt = 0; tt < 16; ++tt) mz_relu_clamp(acc[tt]);
-#else      // (development switch: v_max on an unscaled stream -- scripts/relu_clamp_check.py compares the two builds)
+#else      // (development switch: v_max on an unscaled stream -- scripts/experiments/relu_clamp_check.py compares the two builds)
           mz_mfma_fence16v(acc);
 #pragma unroll
           for (int tt = 0; tt < 16; ++tt) {

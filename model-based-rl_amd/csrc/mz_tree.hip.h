@@ -382,7 +382,7 @@ __device__ __forceinline__ void mz_tree_step_fused(const TreeView &t, const Tree
 // rcptab[n] = 1.0 / n (IEEE double, n = 1 .. num_simulations + 1): node.value() = value_sum / visit_count
 // (mcts.py:42-45) is taken as q0 = w * y, r = fma(-n, q0, w), q = fma(r, y, q0) with y = RN(1 / n) -- the correction
 // step of a correctly rounded division (Markstein): bit-identical to w / n for every finite w
-// (scripts/divcheck.c: 0 differences in 5e8 quotients), three dependent operations instead of the eleven of the
+// (scripts/experiments/divcheck.c: 0 differences in 5e8 quotients), three dependent operations instead of the eleven of the
 // division's expansion.
 template <int TL, int G, int LT, bool SP, class LEVELF, class STAMPF>
 __device__ __forceinline__ void mz_tree_backup_select_f(const TreeView &t, const TreeMem<LT> &tm, int lane,
@@ -521,7 +521,7 @@ __device__ __forceinline__ void mz_tree_backup_select_f(const TreeView &t, const
   // MinMaxStats.normalize divides by the same span at every level of this descent: the reciprocal (the rcp + two
   // Newton steps of the compiler's own f64 division) is taken once, a level then costs mul + fma + fma -- the tail
   // of that same expansion, bit-identical to (x - mn) / span as long as v_div_scale would not rescale the operands
-  // (scripts/fastdiv_check.hip: 0 differences in 8e7 quotients).  Outside a generous exponent window the level
+  // (scripts/experiments/fastdiv_check.hip: 0 differences in 8e7 quotients).  Outside a generous exponent window the level
   // falls back to the division itself.
   double yspan = 0.0;
   bool fast_ok = true;

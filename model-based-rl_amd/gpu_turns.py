@@ -1,7 +1,7 @@
 """Turn-taking for an actor and a learner that share ONE GPU in one process (train.py with --use_gpu_for actors learner).
 
 On MI355X two queues with work do not share the GPU gracefully when one of them runs the whole-moves self-play launch:
-measured (scripts/learner_speed.py, scripts/cu_mask_probe.py) both sides lose ~8 x -- the learner 122 -> 15-19 updates/s,
+measured (scripts/experiments/learner_speed.py, scripts/experiments/cu_mask_probe.py) both sides lose ~8 x -- the learner 122 -> 15-19 updates/s,
 the actor 8.7 -> 0.9 M env-steps/s -- with the loop in another thread, another process, on its own stream or behind CU masks
 alike.  Mutual exclusion at chunk granularity costs nothing like that: the actor holds the GPU for one chunk of moves
 (submit + wait), the learner for one update (until its stream is idle), strictly alternating when both want it (FIFO).

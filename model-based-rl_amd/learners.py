@@ -235,6 +235,7 @@ class _NativeFC(object):
     self.lr = g['lr']
     self.versions = None
     self._source = None           # (replay object, its mz_fcl_source table) of run()
+    self.in_flight = False        # run() returned with updates in flight whose refreshes are owed
     self.sync(force=True)
 
   def fits(self, host):
@@ -269,6 +270,7 @@ class _NativeFC(object):
     back); returns the slot errors() hands them over from"""
     import ctypes as C
     from . import _abi
+    self.flush()
     cfg, g = self.learner.config, self.learner.optimizer.param_groups[0]
     ptr = lambda a: C.c_void_p(a.__array_interface__['data'][0])
     b1, b2 = g['betas']
@@ -298,7 +300,7 @@ class _NativeFC(object):
       self._source = (replay, src)
     src = self._source[1]
     bs = self.bs
-    words = np.frombuffer(random.getrandbits(64 * bs * n).to_bytes(8 * bs * n, 'little'), np.uint32)
+    words = np.frombuffer(random.getrandbits(64 * bs * n).to_bytes(8 * bs * n, 'little'), np.uint32) if n else np.zeros(2, np.uint32)
     st = np.random.get_state()
     key, pos = np.array(st[1], np.uint32), C.c_int32(int(st[2]))
     beta, pads = C.c_double(float(replay.beta)), C.c_int64(0)
@@ -315,7 +317,14 @@ class _NativeFC(object):
                               C.c_void_p(self.learner._loss_dev.data_ptr()), _stream_ptr(self.flat), C.byref(pads)), 'mz_fcl_run')
     np.random.set_state((st[0], key, int(pos.value), st[3], st[4]))
     replay.beta = np.float64(beta.value) if float(replay.beta) < 1 else replay.beta
+    self.in_flight = n > 0 or (self.in_flight and n != 0)
     return int(pads.value)
+
+  def flush(self):
+    """the updates mz_fcl_run left in flight: wait for them, hand their priority refreshes to the replay (mz_fcl_run with 0 updates)"""
+    if self.in_flight and self._source is not None:
+      self.run(self._source[0], 0)
+      self.in_flight = False
 
   def run_stats(self, reset=False):
     """where mz_fcl_run's host time went (development hook): microseconds per update"""
@@ -768,6 +777,8 @@ class Learner(Logger):
 
   def flush_priorities(self):
     """hand the last update's priority refresh to the replay (learners.py:182), waiting for its copy to arrive"""
+    if self._native is not None:
+      self._native.flush()          # (the updates the native loop left in flight)
     if self._pending is not None:
       idxs, slot, getter = self._pending
       self._pending = None
@@ -856,6 +867,7 @@ class Learner(Logger):
     try:
       self._learn_loop(cfg, last, log_every, self._source, gpu_turns)
       self.flush_priorities()
+      self._log_losses_behind(log_every, final=True)
     finally:
       if self._source is not None:
         self._source.close()
@@ -903,8 +915,10 @@ class Learner(Logger):
     while self.training_step < last:
       n, replay = self._native_segment(cfg, last, log_every)
       if n > 0:
-        # the loop body in native code (mz_fcl_run): n updates per call, Python only at the boundaries of _after_update
-        self.flush_priorities()
+        # the loop body in native code (mz_fcl_run): n updates per call, Python only at the boundaries of _after_update; the
+        # call returns with its last updates in flight -- what _after_update does overlaps them
+        if self._pending is not None:
+          self.flush_priorities()
         self._native.sync()
         self._native.run(replay, n, self._scheduled_lrs(n))
         self.native_loop_updates += n
@@ -927,6 +941,31 @@ class Learner(Logger):
       self.training_step += 1
       self._after_update(cfg, log_every)
 
+  def _log_losses_behind(self, log_every, final=False):
+    """loss/{reward,value,policy} (learners.py:138-141) without waiting for the GPU: the sums of this interval are copied to
+    pinned memory in stream order (behind the updates in flight) and zeroed; what is WRITTEN now is the previous interval's
+    line, with its own step.  final: write what is pending (the end of learn())."""
+    prev = getattr(self, '_loss_behind', None)
+    if prev is not None:
+      step, buf, ev, n = prev
+      ev.synchronize()                           # (recorded a whole interval ago)
+      vals = buf.tolist()
+      self.log_points([('loss/' + k, step, vals[i] / n) for i, k in enumerate(('reward', 'value', 'policy'))])
+      self._loss_behind = None
+    if final:
+      return
+    bufs = getattr(self, '_loss_bufs', None)
+    if bufs is None:
+      bufs = self._loss_bufs = [torch.empty(3, dtype=torch.float64).pin_memory() for _ in range(2)]
+      self._loss_flip = 0
+    buf = bufs[self._loss_flip]
+    self._loss_flip ^= 1
+    buf.copy_(self._loss_dev, non_blocking=True)
+    self._loss_dev.zero_()
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(self.device))
+    self._loss_behind = (self.training_step, buf, ev, log_every)
+
   def _after_update(self, cfg, log_every):
     """learners.py:132-153: what the loop does besides training, at the steps where it does it"""
     if self.training_step % cfg.send_weights_frequency == 0:
@@ -934,9 +973,12 @@ class Learner(Logger):
     if self.training_step % getattr(cfg, 'save_state_frequency', 1000) == 0:
       self.save_state()
     if self.training_step % log_every == 0:
-      for k in ('reward', 'value', 'policy'):
-        self.log_scalar(tag='loss/' + k, value=self.losses_to_log[k] / log_every, i=self.training_step)
-        self.losses_to_log[k] = 0
+      if self.device.type == 'cuda' and self._native is not None:
+        self._log_losses_behind(log_every)
+      else:
+        for k in ('reward', 'value', 'policy'):
+          self.log_scalar(tag='loss/' + k, value=self.losses_to_log[k] / log_every, i=self.training_step)
+          self.losses_to_log[k] = 0
       self.log_throughput()
       if self.lr_scheduler is not None:
         self.log_scalar(tag='loss/learning_rate', value=self.optimizer.param_groups[0]['lr'], i=self.training_step)      # (what the optimizer really uses, every scheduler)

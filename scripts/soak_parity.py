@@ -61,7 +61,7 @@ for c in range(nchunks):
     # kernel, another launch structure, the same float32 arithmetic.  If that reproduces the launch's visit vector bit
     # for bit, the difference to the CPU restatement is a float32 one: the reference's inverse transform
     # (config.py:27-33) computes sqrt(1 + eps) - 1 in float32, a staircase of ~1.5e-4 per step at |x| ~ 1-3, and early
-    # in a search MinMaxStats' span is small enough for one step to exceed a 1e-4 gap (scripts/staircase_case.py).
+    # in a search MinMaxStats' span is small enough for one step to exceed a 1e-4 gap (scripts/experiments/staircase_case.py).
     e2 = Engine(16, O, A, sims, seed=seed, split_f16=a.split)
     e2.set_weights(w)
     e2.initial_inference(np.repeat(obs[b:b + 1], 16, 0)); e2.root_prepare(None, None, np.repeat(eng.selfplay_noise(m)[b:b + 1], 16, 0))
