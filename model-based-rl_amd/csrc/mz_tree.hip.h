@@ -608,6 +608,35 @@ __device__ __forceinline__ void mz_tree_backup_select_f(const TreeView &t, const
     // (the others contribute 0; keys of a group differ in their action bits, so this is the winner's own word).  Equal
     // scores compare equal here exactly where the tuple comparison's == did (+0 and -0 included); a NaN score -- a
     // network that produced one -- is ignored by v_max_f64 where the tuple comparison kept whichever came first.
+#ifdef MZ_ARGMAX_F32
+    // (r05 experiment) a float32 screen in front of the float64 reductions: rounding to float32 is monotone, so a lane whose
+    // ROUNDED score is strictly the group's largest holds the largest float64 score too -- one DPP-fused v_max_f32 per step
+    // instead of two moves and a v_max_f64; where two lanes of any group of the wave share the largest rounded score (exact
+    // ties included) the wave takes the float64 reductions below.  Exact by construction.
+    bool screened = false;
+    {
+      const float s32 = (float)score;
+      float m32 = s32;
+#define MZ_AM_MAX32(OFF) m32 = fmaxf(m32, __int_as_float(mz_xchg_i<OFF>(__float_as_int(m32))));
+      if constexpr (G > 1) MZ_AM_MAX32(1)
+      if constexpr (G > 2) MZ_AM_MAX32(2)
+      if constexpr (G > 4) MZ_AM_MAX32(4)
+      if constexpr (G > 8) MZ_AM_MAX32(8)
+      if constexpr (G > 16) MZ_AM_MAX32(16)
+#undef MZ_AM_MAX32
+      const bool top = s32 == m32;
+      int k2 = top ? key : 0;
+#define MZ_AM_KEY32(OFF) { const int ok = mz_xchg_i<OFF>(k2); k2 = ok > k2 ? ok : k2; }
+      if constexpr (G > 1) MZ_AM_KEY32(1)
+      if constexpr (G > 2) MZ_AM_KEY32(2)
+      if constexpr (G > 4) MZ_AM_KEY32(4)
+      if constexpr (G > 8) MZ_AM_KEY32(8)
+      if constexpr (G > 16) MZ_AM_KEY32(16)
+#undef MZ_AM_KEY32
+      if (__builtin_amdgcn_ballot_w64(top & (key != k2)) == 0) { key = k2; screened = true; }
+    }
+    if (!screened)
+#endif
     {
       double mxs = score;
 #define MZ_AM_MAX(OFF)                                                              \
