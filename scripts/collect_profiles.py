@@ -16,7 +16,24 @@ names = {
     'one_replay_8ranks_8threads_%s.json': '%s_one_replay_8ranks_8threads.json',
     'tree_traffic_%s.json': '%s_tree_traffic.json', 'learner_speed_%s.json': '%s_learner_speed.json',
     'bench_selflaunch_2ranks_1gpu_%s.json': '%s_bench_selflaunch_2ranks_1gpu.json',
+    'bench_selflaunch_8ranks_1gpu_%s.json': '%s_bench_selflaunch_8ranks_1gpu.json',
+    'bench_learner_%s.json': '%s_bench_learner_secondary.json', 'learner_kernels_%s.csv': '%s_learner_kernels.csv',
+    'bench_steps20_%s.json': '%s_bench_steps20.json', 'weight_sync_ab_%s.txt': '%s_weight_sync_ab.txt',
+    'parity_full_grid_%s.txt': '%s_parity_full_grid.txt',
 }
+# the product's own entry point (train --selfplay_only): its summary line as JSON
+ts = os.path.join(G, 'train_selfplay_%s.txt' % tag)
+if os.path.exists(ts):
+  import re
+  lines = open(ts).read().strip().splitlines()
+  m = re.search(r'frames accepted by replay: (\d+) \((\d+) after (\d+) priming moves\), games: (\d+), ([0-9.]+) s -> (\d+) env-steps/s', lines[-1] if lines else '')
+  if m:
+    json.dump({'what': 'python -m model_based_rl_amd.train --selfplay_only --num_envs 4096 --num_simulations 30 --max_moves 4864 --prime_moves 768 '
+                       '(LunarLander shapes): frames accepted by the replay after the priming moves / wall seconds of Actor.launch',
+               'frames': int(m.group(1)), 'frames_timed': int(m.group(2)), 'prime_moves': int(m.group(3)), 'games': int(m.group(4)),
+               'seconds': float(m.group(5)), 'env_steps_per_s': int(m.group(6)), 'line': lines[-1]},
+              open(os.path.join(P, '%s_train_selfplay.json' % tag), 'w'), indent=1)
+    print('->', '%s_train_selfplay.json' % tag)
 for src, dst in names.items():
   s = os.path.join(G, src % tag)
   if os.path.exists(s):

@@ -36,10 +36,22 @@ python3 bench.py --workload tree > $O/bench_tree_$TAG.json 2>> $O/bench_$TAG.err
  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_tree_write_$TAG -- python3 $R/bench.py --workload tree --steps 4 --warmup 1 > /dev/null 2>&1)
 python3 scripts/make_traffic.py $O/pmc_tree_fetch_$TAG $O/pmc_tree_write_$TAG $O/tree_traffic_$TAG.json > /dev/null
 rm -rf $O/pmc_tree_fetch_$TAG $O/pmc_tree_write_$TAG
-# the learner step: one captured hipGraph per update against eager launches
-python3 scripts/learner_graph_speed.py $O/learner_speed_$TAG.json > /dev/null 2>> $O/bench_$TAG.err
+# the learner line: Learner.launch on the handles train.launch builds (mz_fcl_run takes the loop body), PyTorch graph beside it;
+# per-kernel times of the native loop (rocprofv3 kernel trace of the same command, native variant only)
+python3 bench.py --workload learner > $O/bench_learner_$TAG.json 2>> $O/bench_$TAG.err
+(cd /tmp; MZ_LEARNER_ONLY=native rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_learner_$TAG -- python3 $R/bench.py --workload learner --steps 400 --runs 1 > /dev/null 2>&1)
+f=$(find $O/prof_learner_$TAG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/learner_kernels_$TAG.csv; rm -rf $O/prof_learner_$TAG
+# the product's own entry point: train --selfplay_only at the bench's size (frames accepted by the replay after priming / wall seconds)
+python3 -m model_based_rl_amd.train --environment LunarLander-v2 --num_envs 4096 --num_simulations 30 --seed 0 --selfplay_only --max_moves 4864 --prime_moves 768 --window_size 2097152 --weight_sync_frequency 128 --runs_dir /tmp/mz_runs > $O/train_selfplay_$TAG.txt 2>&1
+# the driver's form of the headline, and the weight pull with / without its host wait (A/B on this box)
+python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_steps20_$TAG.json 2>> $O/bench_$TAG.err
+for i in 1 2 3; do for S in 0 1; do MZ_SYNC_WEIGHTS=$S python3 bench.py --no-cpu-baseline --no-live-traffic --steps 1024 --runs 3 --sync-every 32 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('MZ_SYNC_WEIGHTS=$S', round(d['value']), d['config']['weight_sync'][:60])"; done; done > $O/weight_sync_ab_$TAG.txt 2>&1
+# full-grid parity report (value error distribution included)
+MZ_PARITY_REPORT=$O/parity_full_grid_$TAG.txt python3 -m pytest tests/test_gpu_bench_parity.py -q -k full_grid_vs_oracle > /dev/null 2>&1
 # bench.py --gpus 2 launching its own ranks (two ranks on this one GPU over gloo: the path of the driver's N > 1 runs)
 MZ_BENCH_BACKEND=gloo python3 bench.py --gpus 2 --envs 2048 --no-cpu-baseline > $O/bench_selflaunch_2ranks_1gpu_$TAG.json 2>> $O/bench_$TAG.err
+# ... and eight ranks on this one GPU (512 environments each): shards, host cores of all ranks, seven rings into one replay
+MZ_BENCH_BACKEND=gloo python3 bench.py --gpus 8 --envs 512 --min-seconds 2 --runs 3 --no-cpu-baseline > $O/bench_selflaunch_8ranks_1gpu_$TAG.json 2>> $O/bench_$TAG.err
 # the world-size-1 RCCL branch of the bench (process group over nccl, device-side weight broadcasts)
 MZ_BENCH_FORCE_DIST=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29591 bench.py --gpus 1 --no-cpu-baseline > $O/bench_rccl_world1_$TAG.json 2>> $O/bench_$TAG.err
 # host side: ingest thread scaling, the one-replay path of train --ranks 8 with synthetic producers
