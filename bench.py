@@ -430,6 +430,14 @@ def main():
   else:
     rstorage = storage
 
+  # control-plane collectives (barriers, timing reductions): over the storage's host-side group where the weights travel on the
+  # library's own RCCL communicator -- the process group's communicator is then never created (one proxy thread per rank)
+  ctrl = getattr(rstorage, 'ctrl_group', None) if dist is not None else None
+  ctrl_dev = torch.device('cpu') if ctrl is not None else coll_dev
+
+  def barrier():
+    dist.barrier(group=ctrl) if ctrl is not None else dist.barrier()
+
   def make_replay(threads):
     c = types.SimpleNamespace(**cfg.__dict__)
     c.ingest_threads = threads
@@ -451,7 +459,7 @@ def main():
       self.n_ingest = args.ingest_threads or ingest_threads_for(world, one_replay_rank0=True)
       if rank == 0:
         self.rings = {r: D.ShmRing('%s_%d' % (run_id, r), chunk, B, rec_floats, slots=4, create=True) for r in range(1, world)}
-      dist.barrier()
+      barrier()
       if rank == 0:
         self.replay = make_replay(self.n_ingest)          # (its handle serialises the two callers on rank 0: the actor and the ring server)
         self.ring_stop = threading.Event()
@@ -468,18 +476,18 @@ def main():
     def barrier(self):
       torch.cuda.synchronize(device)
       if dist is not None:
-        dist.barrier()
+        barrier()
         if self.one_replay:   # every producer has put its last chunk: the region ends when the one replay has accepted them all
           if rank == 0:
             while any(r.pending() > 0 for r in self.rings.values()):
               time.sleep(0.0002)
             _call(self.replay, 'size')     # (queues behind an ingest in flight, and waits for the deferred insertions)
-          dist.barrier()
+          barrier()
         torch.cuda.synchronize(device)
 
     def close(self):
       if self.one_replay:
-        dist.barrier()
+        barrier()
         if self.ring_stop is not None:
           self.ring_stop.set()
         for r_ in list(self.rings.values()) + ([self.my_ring] if self.my_ring is not None else []):
@@ -502,11 +510,11 @@ def main():
       busy = (time.process_time() - c0) / dt      # CPU seconds of this rank (all its threads) per wall second
       frames = layout.frames() - frames0
       if dist is not None:
-        tt = torch.tensor([dt, busy], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        tt = torch.tensor([dt, busy], dtype=torch.float64, device=ctrl_dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=ctrl)
         dt, busy_max = float(tt[0].item()), float(tt[1].item())
-        ff = torch.tensor([frames, busy], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(ff, op=dist.ReduceOp.SUM)
+        ff = torch.tensor([frames, busy], dtype=torch.float64, device=ctrl_dev)
+        dist.all_reduce(ff, op=dist.ReduceOp.SUM, group=ctrl)
         frames, busy_sum = float(ff[0].item()), float(ff[1].item())
       else:
         busy_max = busy_sum = busy
@@ -546,9 +554,9 @@ def main():
   actor.record_tap = dump = None
   shards = [shard]
   if dist is not None:
-    st = torch.tensor(shard, dtype=torch.int64, device=coll_dev)
+    st = torch.tensor(shard, dtype=torch.int64, device=ctrl_dev)
     every = [torch.zeros_like(st) for _ in range(world)]
-    dist.all_gather(every, st)
+    dist.all_gather(every, st, group=ctrl)
     shards = [[int(x[0]), int(x[1])] for x in every]
   assert eng.rec_floats == rec_floats, (eng.rec_floats, rec_floats)
   # calibration: how many --steps blocks make a timed region of >= --min-seconds (same count on every rank)
@@ -560,8 +568,8 @@ def main():
   repeats = max(1, int(np.ceil(args.min_seconds / max(1e-6, est * args.steps))))
   repeats = min(repeats, max(1, 200000 // max(1, args.steps)))
   if dist is not None:
-    rt = torch.tensor([repeats], dtype=torch.int64, device=coll_dev)
-    dist.all_reduce(rt, op=dist.ReduceOp.MAX)
+    rt = torch.tensor([repeats], dtype=torch.int64, device=ctrl_dev)
+    dist.all_reduce(rt, op=dist.ReduceOp.MAX, group=ctrl)
     repeats = int(rt.item())
   per_run = repeats * whole(args.steps)
   n_runs = max(1, args.runs) if not child else 1
@@ -735,8 +743,9 @@ def main():
       out['cpu_baseline']['reference_shaped'] = cpu_baseline_reference_shaped()
     print(json.dumps(out), flush=True)
   if dist is not None:
-    dist.barrier()
+    barrier()
     layout.close()
+    rstorage.close()
     dist.destroy_process_group()
 
 

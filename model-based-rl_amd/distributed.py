@@ -191,6 +191,7 @@ class RankStorage(object):
     self.broadcasts = 0
     self.native = backend == 'nccl' and os.environ.get('MZ_TORCH_COLLECTIVES', '0')[:1] != '1'
     n = int(num_weights)
+    self.ctrl_group = None          # (None: the default group)
     if not self.native:
       self._flats = [torch.zeros(n, dtype=torch.float32, device=self.cdev)]
       self._last = 0
@@ -201,19 +202,24 @@ class RankStorage(object):
     self.lib = _abi.load()
     rccl = os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')      # PyTorch-ROCm's own copy: ONE HIP runtime per process
     _abi.check(self.lib.mz_comm_load(rccl.encode() if os.path.exists(rccl) else None), 'mz_comm_load')
+    # host-side control group (gloo): the unique id's bootstrap, then per pull the training step, game counts and scale_ok.
+    # Everything a caller needs besides the weights (barriers, timing reductions) can go through it too (`ctrl_group`): the
+    # process group's own RCCL communicator is then never instantiated -- one communicator (and one proxy thread: ~0.6 of a
+    # host core each, scripts/experiments/rank_storage_cpu_probe.py) per rank instead of two
+    self.meta_group = self.ctrl_group = dist.new_group(backend='gloo')
     uid = (C.c_char * 128)()
     if rank == 0:
       _abi.check(self.lib.mz_comm_unique_id(uid), 'mz_comm_unique_id')
     box = [bytes(uid.raw)]
-    dist.broadcast_object_list(box, src=0)                   # bootstrap only
+    dist.broadcast_object_list(box, src=0, group=self.meta_group)      # bootstrap only
     uid = (C.c_char * 128).from_buffer_copy(box[0])
     self.comm = C.c_void_p()
     with torch.cuda.device(self.device):
       _abi.check(self.lib.mz_comm_create(rank, world, uid, C.byref(self.comm)), 'mz_comm_create')
-    self.meta_group = dist.new_group(backend='gloo')         # training step, game counts, scale_ok: host to host
     self.side = torch.cuda.Stream(self.device)
     self._flats = [torch.zeros(n, dtype=torch.float32, device=self.device) for _ in range(2)]
     self._pinned = [torch.zeros(n, dtype=torch.float32).pin_memory() for _ in range(2)] if rank == 0 else None
+    self._pinned_np = [t.numpy() for t in self._pinned] if rank == 0 else None
     self._staged = [None, None]                              # event behind the host-to-device copy out of _pinned[k]
     self._consumed = [None, None]                            # event behind the last repack that read _flats[k]
     self._last = 0
@@ -259,7 +265,9 @@ class RankStorage(object):
       ok = int(self.scale_check(host)) if self.scale_check is not None else 1
       if self._staged[k] is not None:
         self._staged[k].synchronize()                # the copy out of this staging slot, two pulls ago
-      self._pinned[k].copy_(host)
+      # (numpy's single-threaded copy: torch's CPU copy_ of 200 k floats wakes its whole intra-op thread pool -- 16 cores busy and
+      # 4 ms per pull on a 256-CPU box under a 16-CPU quota, scripts/experiments/rank_storage_cpu_probe.py)
+      np.copyto(self._pinned_np[k], host.numpy())
     import ctypes as C
     from . import _abi
     with torch.cuda.stream(self.side):

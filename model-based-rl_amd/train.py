@@ -95,8 +95,12 @@ def launch_ranks(config, max_moves, selfplay_only=False, learner_steps=None, sta
     storage = ray.remote(SharedStorage).remote(config)
     replay = ray.remote(PrioritizedReplay).remote(config)
     rings = {r: D.ShmRing('%s_%d' % (run_id, r), chunk, B, rec, slots=4, create=True) for r in range(1, world)}
-  dist.barrier()
   from .actors import _call
+  from .engine import config_scale_check, flatten_weights
+  rstorage = D.RankStorage(rank, world, device, n_flat, storage=storage, storage_call=_call, backend=backend,
+                           flatten=flatten_state if torch_net else flatten_weights, scale_check=config_scale_check(config))
+  ctrl = rstorage.ctrl_group          # (the storage's host-side group where the weights travel on the library's own communicator)
+  dist.barrier(group=ctrl) if ctrl is not None else dist.barrier()      # the rings exist
   if rank == 0:
     actor_replay = replay
     server = threading.Thread(target=D.serve_rings, args=(rings, lambda name, *a: _call(replay, name, *a), B, stop), daemon=True)
@@ -111,9 +115,6 @@ def launch_ranks(config, max_moves, selfplay_only=False, learner_steps=None, sta
     ring = D.ShmRing('%s_%d' % (run_id, rank))
     actor_replay = D.RingReplay(ring)
   del probe
-  from .engine import config_scale_check, flatten_weights
-  rstorage = D.RankStorage(rank, world, device, n_flat, storage=storage, storage_call=_call, backend=backend,
-                           flatten=flatten_state if torch_net else flatten_weights, scale_check=config_scale_check(config))
   dedicated = bool(getattr(config, 'dedicated_learner_rank', False)) and world > 1 and not selfplay_only
   if dedicated and config.environment == 'TicTacToe' and (getattr(config, 'parity_rng', False) or B == 1):
     raise SystemExit('--dedicated_learner_rank: host-environment actors pull weights per game, not per move count')
@@ -130,9 +131,9 @@ def launch_ranks(config, max_moves, selfplay_only=False, learner_steps=None, sta
     ring.close_producer()
   # what every rank's actor ended up with: the same broadcast buffer, the same training step
   mine = torch.tensor([float(rstorage.flat.double().sum()), float(actor.training_step), float(actor.games_played)],
-                      dtype=torch.float64, device=rstorage.cdev)
+                      dtype=torch.float64, device=torch.device('cpu') if ctrl is not None else rstorage.cdev)
   every = [torch.zeros_like(mine) for _ in range(world)]
-  dist.all_gather(every, mine)
+  dist.all_gather(every, mine, group=ctrl)
   summary = None
   if rank == 0:
     server.join(timeout=120)        # (`drained` in the summary says whether the rings were emptied in time)
@@ -153,7 +154,7 @@ def launch_ranks(config, max_moves, selfplay_only=False, learner_steps=None, sta
       lt = ray.get(learner.get_last_throughput.remote())
       summary.update({k: lt[k] for k in ('updates_per_second', 'replay_ratio', 'sample_ratio', 'frames_per_second') if k in lt})
     print('MZ_TRAIN_SUMMARY ' + json.dumps(summary), flush=True)
-  dist.barrier()
+  dist.barrier(group=ctrl) if ctrl is not None else dist.barrier()
   stop.set()
   for ring_ in list(rings.values()) + ([ring] if rank > 0 else []):
     ring_.release()
