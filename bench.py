@@ -377,6 +377,11 @@ def main():
   # process it runs the whole collective path -- process group over RCCL, broadcast of the weights into device memory,
   # the MAX / SUM all-reduces, barriers -- on a single GPU)
   force_dist = os.environ.get('MZ_BENCH_FORCE_DIST', '0')[:1] == '1' and 'RANK' in os.environ
+  # stdout carries the ONE JSON line: everything else this process prints there -- the product's "Actor-k is online ...", RCCL's
+  # version banner, gloo's connection notes (C-level writes to descriptor 1) -- goes to stderr until the line is due
+  sys.stdout.flush()
+  saved_stdout = os.dup(1)
+  os.dup2(2, 1)
   if world > 1 or force_dist:
     import torch.distributed as dist
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -384,7 +389,9 @@ def main():
     torch.cuda.set_device(local_rank)
     backend = os.environ.get('MZ_BENCH_BACKEND', 'nccl')             # 'nccl' = RCCL over xGMI; 'gloo' for the 1-GPU self-test
     if backend == 'nccl':
-      dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+      # (no device_id: the group's own RCCL communicator is created lazily, i.e. never -- the weights travel on the library's
+      # communicator, distributed.RankStorage, everything else over its host-side group; MZ_TORCH_COLLECTIVES=1 uses this one)
+      dist.init_process_group('nccl')
     else:
       dist.init_process_group(backend)
   device = torch.device('cuda', local_rank)
@@ -525,8 +532,6 @@ def main():
   rec_floats = OS + A + 10                 # include/mz_engine.h: observation (packed bytes for -ram-), visit distribution, MZ_REC_EXTRA
   one_replay = bool(args.one_replay) and dist is not None and world > 1
   layout = Layout(one_replay, 'a')
-  stdout = sys.stdout
-  sys.stdout = sys.stderr                  # (the product prints "Actor-k is online ..."; stdout carries the ONE JSON line)
   actor = Actor(rank, cfg, rstorage, layout.replay)
   eng = actor.engine
   dump = [] if args.dump_records else None
@@ -622,7 +627,8 @@ def main():
     lay2.close()
   if publisher is not None:
     publisher.close()
-  sys.stdout = stdout
+  sys.stdout.flush()
+  os.dup2(saved_stdout, 1)                 # stdout again: the ONE JSON line
 
   if rank == 0:
     value = frames / dt

@@ -315,7 +315,9 @@ def init_process_group():
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
   if backend == 'nccl':
-    dist.init_process_group('nccl', device_id=device)
+    # (no device_id: the group's own RCCL communicator is created lazily -- never, when RankStorage's own communicator carries the
+    # weights and its host-side group everything else)
+    dist.init_process_group('nccl')
   else:
     dist.init_process_group(backend)
   return rank, world, device, backend
