@@ -199,23 +199,44 @@ class RankStorage(object):
     import ctypes as C
     from . import _abi
     dist = _dist()
-    self.lib = _abi.load()
-    rccl = os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')      # PyTorch-ROCm's own copy: ONE HIP runtime per process
-    _abi.check(self.lib.mz_comm_load(rccl.encode() if os.path.exists(rccl) else None), 'mz_comm_load')
     # host-side control group (gloo): the unique id's bootstrap, then per pull the training step, game counts and scale_ok.
     # Everything a caller needs besides the weights (barriers, timing reductions) can go through it too (`ctrl_group`): the
     # process group's own RCCL communicator is then never instantiated -- one communicator (and one proxy thread: ~0.6 of a
     # host core each, scripts/experiments/rank_storage_cpu_probe.py) per rank instead of two
     self.meta_group = self.ctrl_group = dist.new_group(backend='gloo')
-    uid = (C.c_char * 128)()
-    if rank == 0:
-      _abi.check(self.lib.mz_comm_unique_id(uid), 'mz_comm_unique_id')
+    self.comm, err = C.c_void_p(), None
+    try:
+      self.lib = _abi.load()
+      rccl = os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')      # PyTorch-ROCm's own copy: ONE HIP runtime per process
+      _abi.check(self.lib.mz_comm_load(rccl.encode() if os.path.exists(rccl) else None), 'mz_comm_load')
+      uid = (C.c_char * 128)()
+      if rank == 0:
+        _abi.check(self.lib.mz_comm_unique_id(uid), 'mz_comm_unique_id')
+    except Exception as exc:            # (no librccl / no symbol: every rank must still enter the collectives below)
+      err, uid = exc, (C.c_char * 128)()
     box = [bytes(uid.raw)]
     dist.broadcast_object_list(box, src=0, group=self.meta_group)      # bootstrap only
-    uid = (C.c_char * 128).from_buffer_copy(box[0])
-    self.comm = C.c_void_p()
-    with torch.cuda.device(self.device):
-      _abi.check(self.lib.mz_comm_create(rank, world, uid, C.byref(self.comm)), 'mz_comm_create')
+    if err is None:
+      try:
+        uid = (C.c_char * 128).from_buffer_copy(box[0])
+        with torch.cuda.device(self.device):
+          _abi.check(self.lib.mz_comm_create(rank, world, uid, C.byref(self.comm)), 'mz_comm_create')
+      except Exception as exc:
+        err = exc
+    # all ranks or none: a rank that could not build its communicator sends every rank back to torch.distributed's collectives
+    ok = torch.tensor([0 if err is not None else 1], dtype=torch.int64)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.meta_group)
+    if int(ok[0]) == 0:
+      import sys
+      print('RankStorage: the library\'s RCCL communicator is not available on every rank (%s): falling back to '
+            'torch.distributed\'s broadcast' % (err if err is not None else 'another rank failed'), file=sys.stderr, flush=True)
+      if self.comm:
+        self.lib.mz_comm_destroy(self.comm)
+        self.comm = None
+      self.native, self.ctrl_group = False, None
+      self._flats = [torch.zeros(n, dtype=torch.float32, device=self.cdev)]
+      self._last = 0
+      return
     self.side = torch.cuda.Stream(self.device)
     self._flats = [torch.zeros(n, dtype=torch.float32, device=self.device) for _ in range(2)]
     self._pinned = [torch.zeros(n, dtype=torch.float32).pin_memory() for _ in range(2)] if rank == 0 else None
