@@ -2,6 +2,8 @@
 broadcast from the learner/storage rank (shared_storage.broadcast_flat; RCCL on the GPU box) -- and the
 rank-wise reductions bench.py reports (max time, summed frames); plus the shard map env_id_offset."""
 import os
+
+import numpy as np
 import subprocess
 import sys
 
@@ -184,3 +186,41 @@ def test_collective_only_rank_pulls_at_the_actors_cadence():
   c = _CollectiveOnly(0, types.SimpleNamespace(weight_sync_frequency=5, training_steps=9), st, 1)
   c.launch(max_moves=12)
   assert st.pulls == 1 + 2 + 1
+
+
+def test_shm_ring_orders_payload_before_head(tmp_path):
+  """distributed.ShmRing: chunks come out in order and complete; head / tail travel through the release / acquire helpers of
+  libmz_replay.so (a producer thread against a consumer thread of this process)"""
+  import threading
+  import time
+  from model_based_rl_amd import distributed as D
+  name = 'mzt_ring_%d' % os.getpid()
+  prod = D.ShmRing(name, chunk=4, B=32, rec=22, slots=3, create=True)
+  cons = D.ShmRing(name)
+  seen = []
+
+  def consume():
+    while not cons.finished():
+      got = cons.poll()
+      if got is None:
+        time.sleep(0.0002)          # (as distributed.serve_rings does: a spinning consumer would hold the interpreter lock)
+        continue
+      data, n = got
+      seen.append((n, data[:n].copy()))
+      cons.done()
+
+  th = threading.Thread(target=consume)
+  th.start()
+  rng = np.random.RandomState(0)
+  sent = []
+  for i in range(40):
+    n = 1 + i % 4
+    rec = rng.standard_normal((4, 32, 22)).astype(np.float32)
+    sent.append((n, rec[:n].copy()))
+    prod.put(rec, n)
+  prod.close_producer()
+  th.join(timeout=30)
+  assert not th.is_alive() and len(seen) == 40 and cons.pending() == 0
+  for (n0, r0), (n1, r1) in zip(sent, seen):
+    assert n0 == n1 and np.array_equal(r0, r1)
+  cons.release(); prod.release()

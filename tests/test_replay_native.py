@@ -91,42 +91,6 @@ def test_batched_refresh_is_exact_at_any_capacity(capacity):
     assert a.get_leaf_index(v) == b.get_leaf(v)
 
 
-def test_shm_ring_orders_payload_before_head(tmp_path):
-  """distributed.ShmRing: chunks come out in order and complete; head / tail travel through the release / acquire helpers of
-  libmz_replay.so (a producer thread against a consumer thread of this process)"""
-  import threading
-  from model_based_rl_amd import distributed as D
-  name = 'mzt_ring_%d' % os.getpid()
-  prod = D.ShmRing(name, chunk=4, B=32, rec=22, slots=3, create=True)
-  cons = D.ShmRing(name)
-  seen = []
-
-  def consume():
-    while not cons.finished():
-      got = cons.poll()
-      if got is None:
-        continue
-      data, n = got
-      seen.append((n, data[:n].copy()))
-      cons.done()
-
-  th = threading.Thread(target=consume)
-  th.start()
-  rng = np.random.RandomState(0)
-  sent = []
-  for i in range(40):
-    n = 1 + i % 4
-    rec = rng.standard_normal((4, 32, 22)).astype(np.float32)
-    sent.append((n, rec[:n].copy()))
-    prod.put(rec, n)
-  prod.close_producer()
-  th.join(timeout=30)
-  assert not th.is_alive() and len(seen) == 40 and cons.pending() == 0
-  for (n0, r0), (n1, r1) in zip(sent, seen):
-    assert n0 == n1 and np.array_equal(r0, r1)
-  cons.release(); prod.release()
-
-
 def test_vectorised_draws_are_random_uniform():
   """sample_batch_arrays draws its stratified segments (replay_buffer.py:138-140: random.uniform per segment) out of one
   getrandbits call: the same doubles, and the generator ends in the same state"""
