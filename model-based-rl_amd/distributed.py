@@ -207,6 +207,8 @@ class RankStorage(object):
     self.comm, err = C.c_void_p(), None
     try:
       self.lib = _abi.load()
+      if os.environ.get('MZ_COMM_FAIL', '0')[:1] == '1':      # (tests: the fallback below)
+        raise RuntimeError('MZ_COMM_FAIL=1')
       rccl = os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')      # PyTorch-ROCm's own copy: ONE HIP runtime per process
       _abi.check(self.lib.mz_comm_load(rccl.encode() if os.path.exists(rccl) else None), 'mz_comm_load')
       uid = (C.c_char * 128)()

@@ -129,6 +129,7 @@ def test_bench_over_rccl_at_world_size_1():
                        '4', '--no-cpu-baseline', '--envs', str(B), '--min-seconds', '0.3', '--sync-every', '16'],
                        env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
   assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+  assert len(out.stdout.strip().splitlines()) == 1, out.stdout[-2000:]      # RCCL's banner and gloo's notes went to stderr: ONE line on stdout
   line = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
   c = line['collectives']
   assert c['backend'] == 'nccl' and c['world'] == 1 and c['forced_at_world_1'] and c['rccl_mapped'] and c['weights_on_device']
@@ -140,6 +141,25 @@ def test_bench_over_rccl_at_world_size_1():
   for key in ('roofline', 'ms_per_step', 'steps', 'warmup', 'scaling', 'dtype', 'config'):
     assert key in line
   assert 0.5 * B * line['timed_steps'] < line['value'] * line['timed_seconds'] < 1.5 * B * line['timed_steps']
+
+
+def test_bench_falls_back_to_torch_collectives_when_the_communicator_fails():
+  """The library's own RCCL communicator cannot be built (here: MZ_COMM_FAIL=1 on every rank): all ranks agree on it over the
+  host-side group and the weights travel through torch.distributed's broadcast instead -- the run completes, the line says so."""
+  B, steps = 256, 16
+  env = dict(os.environ, MZ_BENCH_FORCE_DIST='1', MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0', MZ_COMM_FAIL='1')
+  env.pop('MZ_BENCH_BACKEND', None)
+  out = subprocess.run(launcher(1, 29563) + [os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', str(steps), '--warmup',
+                       '4', '--no-cpu-baseline', '--envs', str(B), '--min-seconds', '0.3', '--sync-every', '16', '--runs', '2'],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+  assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+  rows = [l for l in out.stdout.splitlines() if l.startswith('{')]
+  assert len(rows) == 1 and len(out.stdout.strip().splitlines()) == 1, out.stdout[-2000:]      # nothing but the JSON line on stdout
+  line = json.loads(rows[0])
+  c = line['collectives']
+  assert c['backend'] == 'nccl' and c['broadcast'].startswith('torch.distributed') and c['weights_on_device']
+  assert 'falling back' in out.stderr and line['value'] > 0
+  assert int(line['config']['weight_sync'].split(':')[1].split()[0]) >= 2
 
 
 def test_train_over_rccl_at_world_size_1():
