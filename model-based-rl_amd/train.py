@@ -34,6 +34,11 @@ def launch(config, max_moves, selfplay_only=False, learner_steps=None, state=Non
   learner resumes weights, optimiser, training step and throughput totals (learners.py:62-70), every actor its weights,
   training step and game count (actors.py:75-79)"""
   ray.init()
+  if (not selfplay_only and {'actors', 'learner'} <= set(getattr(config, 'use_gpu_for', [])) and not getattr(config, 'gpu_turns', False)
+      and torch.cuda.is_available() and torch.cuda.device_count() == 1):
+    print('train: an actor and a learner share the one GPU of this process; two busy queues do not share an MI355X gracefully '
+          '(both lose ~8 x): add --gpu_turns to let them take turns, or give each its own GPU (--ranks N --dedicated_learner_rank)',
+          file=sys.stderr)
   storage = ray.remote(SharedStorage).remote(config)
   replay = ray.remote(PrioritizedReplay).remote(config)
   actors = [ray.remote(Actor).remote(k, config, storage, replay, state) for k in range(config.num_actors)]
