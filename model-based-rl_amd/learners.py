@@ -612,8 +612,24 @@ class Learner(Logger):
     self.throughput['training_step'] = state['training_step']
     self.training_step = state['training_step']
 
+  def _host_weights(self):
+    """network.get_weights() (networks.py:39-40: the state_dict on the host).  With the native step the parameters are views of
+    ONE flat device vector: one copy to the host and views of it, instead of one synchronising copy per tensor"""
+    nat = self._native
+    if nat is None or len(list(self.network.buffers())):
+      return self.network.get_weights()
+    from .engine import WEIGHT_ORDER
+    host = nat.flat.detach().cpu()
+    out, off = {}, 0
+    for k, p in zip(WEIGHT_ORDER, nat.params):
+      out[k] = host[off:off + p.numel()].view(p.shape)
+      off += p.numel()
+    return {k: out[k] for k in self.network.state_dict().keys()}
+
   # learners.py:72-83 (same dictionary keys)
-  def save_state(self, path=None):
+  def save_state(self, path=None, wait=True):
+    """wait=False (the loop's own periodic checkpoints): the state is copied to the host here, the FILE is written by a
+    background thread -- the previous one is joined first, learn() joins the last"""
     thr = _call(self.replay_buffer, 'get_throughput')        # (the reference refreshes these in log_throughput)
     self.throughput['total_games'] = thr['games']
     self.throughput['total_frames'] = max(self.throughput['total_frames'], thr['frames'])
@@ -621,20 +637,33 @@ class Learner(Logger):
     opt = self.optimizer.state_dict()
     for g in opt['param_groups']:               # (a plain float in the file, whatever this learner keeps it in)
       g['lr'] = float(g['lr'])
-    # (views of the native step's flat vectors would each be saved with the whole vector's storage)
-    opt['state'] = {i: {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in st.items()} for i, st in opt['state'].items()}
-    state = {'dirs': self.dirs, 'config': self.config, 'weights': self.network.get_weights(),
+    # (views of the native step's flat vectors would each be saved with the whole vector's storage; and the writer thread
+    # must not see tensors the next updates change: copies on the host)
+    opt['state'] = {i: {k: (v.detach().to('cpu', copy=True) if torch.is_tensor(v) else v) for k, v in st.items()} for i, st in opt['state'].items()}
+    state = {'dirs': self.dirs, 'config': self.config, 'weights': self._host_weights(),
              'optimizer': opt, 'training_step': self.training_step,
              'total_games': self.throughput['total_games'], 'total_frames': self.throughput['total_frames'],
              'actor_games': _call(self.storage, 'get_stats', 'actor_games')}
     path = path or os.path.join(self.saves_dir, str(self.training_step))
     os.makedirs(os.path.dirname(path), exist_ok=True)
-    torch.save(state, path)
+    self._join_writer()
+    if wait:
+      torch.save(state, path)
+    else:
+      import threading
+      self._writer = threading.Thread(target=torch.save, args=(state, path))
+      self._writer.start()
     return path
+
+  def _join_writer(self):
+    w = getattr(self, '_writer', None)
+    if w is not None:
+      w.join()
+      self._writer = None
 
   # learners.py:85-86
   def send_weights(self):
-    _call(self.storage, 'store_weights', self.network.get_weights(), self.training_step)
+    _call(self.storage, 'store_weights', self._host_weights(), self.training_step)
 
   @property
   def losses_to_log(self):
@@ -868,6 +897,7 @@ class Learner(Logger):
       self._learn_loop(cfg, last, log_every, self._source, gpu_turns)
       self.flush_priorities()
       self._log_losses_behind(log_every, final=True)
+      self._join_writer()
     finally:
       if self._source is not None:
         self._source.close()
@@ -971,7 +1001,7 @@ class Learner(Logger):
     if self.training_step % cfg.send_weights_frequency == 0:
       self.send_weights()
     if self.training_step % getattr(cfg, 'save_state_frequency', 1000) == 0:
-      self.save_state()
+      self.save_state(wait=False)
     if self.training_step % log_every == 0:
       if self.device.type == 'cuda' and self._native is not None:
         self._log_losses_behind(log_every)
