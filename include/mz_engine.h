@@ -376,7 +376,9 @@ int mz_fcl_errors(mz_fcl *c, int slot, float *host_out);
  * (send_weights, save_state, logging; learners.py:132-153).  The replay is reached through the caller's function table
  * (include/mz_replay.h: sample = mzr_sample_batches_full, refresh = mzr_update_errors_f32, last_error = mzr_last_error;
  * libmz_hip.so does not link libmz_replay.so).  words [n_updates][2 batch]: the generator words of the stratified draws
- * (random.getrandbits(64 batch n_updates), least significant word first); np_key [624] / *np_pos: numpy's legacy generator
+ * (random.getrandbits(64 batch n_updates), least significant word first) -- or NULL with py_key [624] / *py_pos = the state of
+ * Python's `random` generator (random.getstate()[1]), from which the same words are generated per update and which comes back
+ * advanced; np_key [624] / *np_pos: numpy's legacy generator
  * state for the padded actions, advanced in place; *beta_inout: the replay's beta (schedule applied per batch); obs_min /
  * obs_range [host][obs_dim] or NULL: --norm_obs; lrs [host][n_updates] or NULL: the learning rate of every update (a
  * scheduler's values; NULL: the device float bound by mz_fcl_bind); loss_sums [dev][3] as mz_fcl_step; *pads_out (may be
@@ -389,14 +391,14 @@ typedef struct mz_fcl_source {
   void *replay;
   int (*sample)(void *replay, const uint32_t *words, int n, int bs, float *obs, int32_t *actions, float *target_rewards,
                 float *target_values, float *target_policies, int64_t *idxs, double *is_weights, uint32_t *np_key, int32_t *np_pos,
-                double *beta_inout, int64_t *pads_out);
+                double *beta_inout, int64_t *pads_out, uint32_t *py_key, int32_t *py_pos);
   int (*refresh)(void *replay, const int64_t *idxs, const float *errors, int64_t n);
   const char *(*last_error)(void);
 } mz_fcl_source;
 int mz_fcl_run(mz_fcl *c, const mz_fcl_source *src, int n_updates, const uint32_t *words, uint32_t *np_key, int32_t *np_pos,
                double *beta_inout, const float *obs_min, const float *obs_range, double beta1, double beta2, double eps,
                double weight_decay, double clip_grad, int adamw, const float *lrs, double *loss_sums, void *stream,
-               int64_t *pads_out);
+               int64_t *pads_out, uint32_t *py_key, int32_t *py_pos);
 /* development hook: mz_fcl_run's host time since the handle was created (or the last reset): out [host][6] = seconds waiting for
  * a staging slot's previous update, in priority refreshes, in sampling, in launching, in the calls as a whole; number of updates */
 int mz_fcl_run_stats(mz_fcl *c, double *out6, int reset);

@@ -134,13 +134,15 @@ int mzr_sample_batches_words(const mz_replay *r, const uint32_t *words, int n, i
  *   draws from the caller's generator words (mzr_sample_batches_words), the padded actions from numpy's legacy global
  *   generator (replay_buffer.py:150-151; its state np_key [624] / *np_pos = np.random.get_state()[1:3], handed back
  *   advanced), the beta schedule (*beta_inout) and is_weights [n][bs] = (N p)^-beta / max (replay_buffer.py:131-132,157-159;
- *   the C library's pow: within one unit in the last place of numpy's, whose own power differs between hosts).
+ *   the C library's pow: within one unit in the last place of numpy's, whose own power differs between hosts).  words NULL: the
+ *   words are generated here from the state of Python's `random` generator (py_key [624] / *py_pos = random.getstate()[1], the same
+ *   MT19937; advanced in place) -- what random.getrandbits(64 bs n) would have returned.
  * All mzr_* entry points of one handle may be called from different threads: they take turns on a lock inside the handle. */
 int mzr_priorities_f32(const mz_replay *r, const float *errors, int64_t n, float *out);
 int mzr_update_errors_f32(mz_replay *r, const int64_t *idxs, const float *errors, int64_t n);
 int mzr_sample_batches_full(mz_replay *r, const uint32_t *words, int n, int bs, float *obs, int32_t *actions, float *target_rewards,
                             float *target_values, float *target_policies, int64_t *idxs, double *is_weights, uint32_t *np_key,
-                            int32_t *np_pos, double *beta_inout, int64_t *pads_out);
+                            int32_t *np_pos, double *beta_inout, int64_t *pads_out, uint32_t *py_key, int32_t *py_pos);
 
 /* number of ingest threads of the handle (mzr_config.ingest_threads at creation; the setter re-creates the pool) */
 int mzr_set_ingest_threads(mz_replay *r, int threads);

@@ -150,7 +150,7 @@ SIGNATURES = {
     'mz_fcl_update': (_I, [_VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _I, _D, _D, _D, _D, _D, _I, _VP, _VP, C.POINTER(_I)]),
     'mz_fcl_errors': (_I, [_VP, _I, _VP]),
     'mz_fcl_run_stats': (_I, [_VP, _VP, _I]),
-    'mz_fcl_run': (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _D, _D, _D, _D, _D, _I, _VP, _VP, _VP, _VP]),
+    'mz_fcl_run': (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _D, _D, _D, _D, _D, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     'mz_fcl_read_grad': (_I, [_VP, _VP, _SZ]),
     'mz_fcl_read_tape': (C.c_longlong, [_VP, _I, _VP, _SZ]),
     'mz_fcl_heads_profile': (_I, [_VP, _I, _VP]),
@@ -224,7 +224,7 @@ REPLAY_SIGNATURES = {
     'mzr_add_initial_throughput': (_I, [_VP, _I64, _I64]),
     'mzr_priorities_f32': (_I, [_VP, _VP, _I64, _VP]),
     'mzr_update_errors_f32': (_I, [_VP, _VP, _VP, _I64]),
-    'mzr_sample_batches_full': (_I, [_VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    'mzr_sample_batches_full': (_I, [_VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     'mzr_store_release_i64': (None, [_VP, _I64]),
     'mzr_load_acquire_i64': (_I64, [_VP]),
 }

@@ -944,9 +944,18 @@ static inline uint32_t np_mt_next(uint32_t *key, int32_t *pos) {
 // is_weights [n][bs]; pads_out (may be null): total number of padded actions.
 int mzr_sample_batches_full(mz_replay *r, const uint32_t *words, int n, int bs, float *obs, int32_t *actions, float *target_rewards,
                             float *target_values, float *target_policies, int64_t *idxs, double *is_weights, uint32_t *np_key,
-                            int32_t *np_pos, double *beta_inout, int64_t *pads_out) {
-  if (!r || !words || !is_weights || !np_key || !np_pos || !beta_inout || n < 1 || bs < 1) return fail("mzr_sample_batches_full: bad argument");
+                            int32_t *np_pos, double *beta_inout, int64_t *pads_out, uint32_t *py_key, int32_t *py_pos) {
+  if (!r || (!words && (!py_key || !py_pos)) || !is_weights || !np_key || !np_pos || !beta_inout || n < 1 || bs < 1)
+    return fail("mzr_sample_batches_full: bad argument");
   MZR_LOCK(r);
+  // words == NULL: the generator words come from the state of Python's `random` module handed over (random.getstate()[1]:
+  // key [624] + position): random.getrandbits(64 bs n) is 2 bs n consecutive MT19937 outputs, least significant word first
+  std::vector<uint32_t> gen;
+  if (!words) {
+    gen.resize((size_t)2 * bs * n);
+    for (size_t i = 0; i < gen.size(); ++i) gen[i] = np_mt_next(py_key, py_pos);
+    words = gen.data();
+  }
   const size_t O = (size_t)r->c.obs_dim, A = (size_t)r->c.action_space, K = (size_t)r->c.num_unroll_steps, B = (size_t)bs;
   uint32_t mask = (uint32_t)(A - 1);
   mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;

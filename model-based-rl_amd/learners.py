@@ -236,6 +236,7 @@ class _NativeFC(object):
     self.versions = None
     self._source = None           # (replay object, its mz_fcl_source table) of run()
     self.in_flight = False        # run() returned with updates in flight whose refreshes are owed
+    self._rng = None              # generator states taken over by run() (release_rng hands them back)
     self.sync(force=True)
 
   def fits(self, host):
@@ -286,8 +287,8 @@ class _NativeFC(object):
     """n updates of Learner.learn's loop body in ONE native call (mz_fcl_run): batches sampled straight into pinned staging by
     the native replay, the five launches per update, priority refreshes handed to the replay as their errors arrive.
     replay: the PrioritizedReplay OBJECT (its native handle is called from this thread; the handle's own lock serialises it
-    with the actors' ingest).  The generator words of all n stratified draws come out of one random.getrandbits call, numpy's
-    legacy generator state (the padded actions, replay_buffer.py:150-151) and the replay's beta travel in and out."""
+    with the actors' ingest).  The states of Python's `random` generator (the stratified draws) and of numpy's legacy one (the
+    padded actions, replay_buffer.py:150-151) and the replay's beta travel in and out."""
     import ctypes as C
     import random
     from . import _abi
@@ -299,10 +300,13 @@ class _NativeFC(object):
                              C.cast(rlib.mzr_last_error, C.c_void_p))
       self._source = (replay, src)
     src = self._source[1]
-    bs = self.bs
-    words = np.frombuffer(random.getrandbits(64 * bs * n).to_bytes(8 * bs * n, 'little'), np.uint32) if n else np.zeros(2, np.uint32)
-    st = np.random.get_state()
-    key, pos = np.array(st[1], np.uint32), C.c_int32(int(st[2]))
+    # the two generators the reference's sample_batch draws from -- Python's `random` (the stratified draws) and numpy's legacy
+    # global one (the padded actions) -- are MT19937 states: taken over once (random.getstate / np.random.get_state), advanced in
+    # place by the native calls, handed back by release_rng() (flush, the end of learn()): no 1.6-Mbit integer per call
+    if self._rng is None:
+      st, ns = random.getstate(), np.random.get_state()
+      self._rng = (np.array(st[1][:624], np.uint32), C.c_int32(int(st[1][624])), np.array(ns[1], np.uint32), C.c_int32(int(ns[2])), st, ns)
+    py_key, py_pos, key, pos = self._rng[:4]
     beta, pads = C.c_double(float(replay.beta)), C.c_int64(0)
     norm = getattr(cfg, 'norm_obs', False)
     O = int(np.prod(self.shape['obs'][1:]))
@@ -311,11 +315,11 @@ class _NativeFC(object):
     lr = None if lrs is None else np.ascontiguousarray(lrs, np.float32)
     ptr = lambda a: None if a is None else C.c_void_p(a.__array_interface__['data'][0])
     b1, b2 = g['betas']
-    _abi.check(lib.mz_fcl_run(self.h, C.byref(src), int(n), ptr(words), ptr(key), C.byref(pos), C.byref(beta), ptr(mn), ptr(rg),
+    _abi.check(lib.mz_fcl_run(self.h, C.byref(src), int(n), None, ptr(key), C.byref(pos), C.byref(beta), ptr(mn), ptr(rg),
                               float(b1), float(b2), float(g['eps']), float(g['weight_decay']), float(getattr(cfg, 'clip_grad', 0) or 0),
                               int(isinstance(self.learner.optimizer, torch.optim.AdamW)), ptr(lr),
-                              C.c_void_p(self.learner._loss_dev.data_ptr()), _stream_ptr(self.flat), C.byref(pads)), 'mz_fcl_run')
-    np.random.set_state((st[0], key, int(pos.value), st[3], st[4]))
+                              C.c_void_p(self.learner._loss_dev.data_ptr()), _stream_ptr(self.flat), C.byref(pads), ptr(py_key),
+                              C.byref(py_pos)), 'mz_fcl_run')
     replay.beta = np.float64(beta.value) if float(replay.beta) < 1 else replay.beta
     self.in_flight = n > 0 or (self.in_flight and n != 0)
     return int(pads.value)
@@ -325,6 +329,16 @@ class _NativeFC(object):
     if self.in_flight and self._source is not None:
       self.run(self._source[0], 0)
       self.in_flight = False
+    self.release_rng()
+
+  def release_rng(self):
+    """hand the generator states run() took over back to `random` and numpy (advanced by what the native calls drew)"""
+    if self._rng is not None:
+      import random
+      py_key, py_pos, key, pos, st, ns = self._rng
+      self._rng = None
+      random.setstate((st[0], tuple(int(x) for x in py_key) + (int(py_pos.value),), st[2]))
+      np.random.set_state((ns[0], key, int(pos.value), ns[3], ns[4]))
 
   def run_stats(self, reset=False):
     """where mz_fcl_run's host time went (development hook): microseconds per update"""
@@ -356,6 +370,7 @@ class _NativeFC(object):
     return res
 
   def close(self):
+    self.release_rng()
     if self.h:
       self.lib.mz_fcl_destroy(self.h)
       self.h = None

@@ -420,8 +420,17 @@ def test_native_sample_batches_full_equals_the_python_path(beta0, A):
   t_rew = np.empty((nb, bs, K + 1), np.float32); t_val = np.empty((nb, bs, K + 1), np.float32); t_pol = np.empty((nb, bs, K + 1, A), np.float32)
   idxs = np.empty((nb, bs), np.int64); w = np.empty((nb, bs), np.float64)
   lib = _abi.load_replay()
-  _abi.check_replay(lib.mzr_sample_batches_full(reps[1]._h, _p(words), nb, bs, _p(obs), _p(act), _p(t_rew), _p(t_val), _p(t_pol), _p(idxs),
-                                                _p(w), _p(key), C.byref(pos), C.byref(beta), C.byref(pads)), 'mzr_sample_batches_full')
+  if A % 2:        # the generator words handed over ...
+    _abi.check_replay(lib.mzr_sample_batches_full(reps[1]._h, _p(words), nb, bs, _p(obs), _p(act), _p(t_rew), _p(t_val), _p(t_pol), _p(idxs),
+                                                  _p(w), _p(key), C.byref(pos), C.byref(beta), C.byref(pads), None, None), 'mzr_sample_batches_full')
+  else:            # ... or generated inside from the state of Python's `random` generator, which comes back advanced alike
+    random.seed(5)
+    pst = random.getstate()
+    py_key, py_pos = np.array(pst[1][:624], np.uint32), C.c_int32(int(pst[1][624]))
+    _abi.check_replay(lib.mzr_sample_batches_full(reps[1]._h, None, nb, bs, _p(obs), _p(act), _p(t_rew), _p(t_val), _p(t_pol), _p(idxs),
+                                                  _p(w), _p(key), C.byref(pos), C.byref(beta), C.byref(pads), _p(py_key), C.byref(py_pos)),
+                      'mzr_sample_batches_full')
+    random.setstate((pst[0], tuple(int(x) for x in py_key) + (int(py_pos.value),), pst[2]))
   assert random.getstate() == py_after
   assert int(pos.value) == int(np_after[2]) and np.array_equal(key, np_after[1])      # numpy's generator: advanced exactly alike
   assert beta.value == float(reps[0].beta)
