@@ -175,3 +175,60 @@ def test_load_state_overrides_accept_both_flag_forms(tmp_path, capsys):
     train.launch = orig
   assert seen['cfg'].training_steps == 8 and seen['cfg'].batch_size == 32
   assert '--batch_size' in capsys.readouterr().err
+
+
+def test_chunk_schedule_and_vectorised_game_statistics():
+  """Host logic of Actor.run_selfplay's device loop (no GPU): the chunk schedule (equal chunks of at most `chunk` moves; the
+  rank without an actor, train._CollectiveOnly, walks the same one) and the vectorised game statistics of a chunk of records
+  (Actor._log_games: games/{return,length,avg_value,max_value}, reference actors.py:99-117) against the move-by-move loop it
+  replaced, on random chunks with none, few and many game ends."""
+  import types
+  from model_based_rl_amd.actors import Actor, chunk_schedule, selfplay_chunk
+  assert list(chunk_schedule(20, 16)) == [10, 10] and list(chunk_schedule(48, 16)) == [16, 16, 16] and list(chunk_schedule(0, 16)) == []
+  assert sum(chunk_schedule(3001, 16)) == 3001 and max(chunk_schedule(3001, 16)) <= 16
+  it = chunk_schedule(None, 8)
+  assert [next(it) for _ in range(3)] == [8, 8, 8]
+  assert selfplay_chunk(types.SimpleNamespace(architecture='FCNetwork')) == 16
+  assert selfplay_chunk(types.SimpleNamespace(architecture='MuZeroNetwork')) == 1
+  assert selfplay_chunk(types.SimpleNamespace(architecture='FCNetwork', selfplay_chunk=4)) == 4
+
+  def sequential(self, rv):          # the loop of rounds 1-4, one move at a time
+    B = rv['done'].shape[1]
+    if self._game_stats is None:
+      self._game_stats = {'ret': np.zeros(B), 'len': np.zeros(B), 'sumv': np.zeros(B), 'maxv': np.full(B, -np.inf)}
+    st = self._game_stats
+    f = max(1, self.config.actor_log_frequency)
+    for m in range(rv['done'].shape[0]):
+      st['ret'] += rv['reward'][m]; st['len'] += 1; st['sumv'] += rv['root_value'][m]
+      st['maxv'] = np.maximum(st['maxv'], rv['root_value'][m])
+      d = rv['done'][m] != 0
+      k = int(d.sum())
+      if k:
+        self.games_played += k
+        if self.games_played // f != (self.games_played - k) // f:
+          self.log_points([('games/return', self.games_played, st['ret'][d].mean()), ('games/length', self.games_played, st['len'][d].mean()),
+                           ('games/avg_value', self.games_played, (st['sumv'][d] / st['len'][d]).mean()),
+                           ('games/max_value', self.games_played, st['maxv'][d].mean())])
+        st['ret'][d] = 0; st['len'][d] = 0; st['sumv'][d] = 0; st['maxv'][d] = -np.inf
+
+  class Fake(object):
+    def __init__(self, f):
+      self._game_stats, self.games_played, self.log = None, 0, []
+      self.config = types.SimpleNamespace(actor_log_frequency=f)
+    def log_points(self, pts):
+      self.log += [(t, int(i), float(v)) for t, i, v in pts]
+
+  rng = np.random.RandomState(0)
+  for trial in range(120):
+    B, f, p = int(rng.randint(1, 40)), int(rng.choice([1, 3, 50])), float(rng.choice([0.0, 0.05, 0.3, 0.9]))
+    a, b = Fake(f), Fake(f)
+    for _ in range(5):
+      M = int(rng.randint(1, 17))
+      rv = {'done': (rng.rand(M, B) < p).astype(np.int32), 'reward': rng.randn(M, B).astype(np.float32), 'root_value': rng.randn(M, B)}
+      sequential(a, rv)
+      Actor._log_games(b, rv)
+    assert a.games_played == b.games_played and len(a.log) == len(b.log)
+    for x, y in zip(a.log, b.log):
+      assert x[0] == y[0] and x[1] == y[1] and abs(x[2] - y[2]) <= 1e-9 * (1 + abs(x[2])), (x, y)
+    for k in a._game_stats:
+      assert np.allclose(a._game_stats[k], b._game_stats[k], rtol=1e-12, atol=1e-12), k
