@@ -219,12 +219,25 @@ class RankStorage(object):
     box = [bytes(uid.raw)]
     dist.broadcast_object_list(box, src=0, group=self.meta_group)      # bootstrap only
     if err is None:
-      try:
-        uid = (C.c_char * 128).from_buffer_copy(box[0])
-        with torch.cuda.device(self.device):
-          _abi.check(self.lib.mz_comm_create(rank, world, uid, C.byref(self.comm)), 'mz_comm_create')
-      except Exception as exc:
-        err = exc
+      # ncclCommInitRank is collective and blocking: it runs on a thread of its own, and a rank that has waited MZ_COMM_TIMEOUT
+      # seconds (default 120) gives up on it -- every rank then does (the wait is symmetric) and the fallback below takes over
+      import threading
+      uid = (C.c_char * 128).from_buffer_copy(box[0])
+      result = []
+
+      def create():
+        try:
+          with torch.cuda.device(self.device):
+            _abi.check(self.lib.mz_comm_create(rank, world, uid, C.byref(self.comm)), 'mz_comm_create')
+          result.append(None)
+        except Exception as exc:
+          result.append(exc)
+      th = threading.Thread(target=create, daemon=True)
+      th.start()
+      th.join(float(os.environ.get('MZ_COMM_TIMEOUT', '120')))
+      err = result[0] if result else RuntimeError('mz_comm_create did not return within MZ_COMM_TIMEOUT')
+      if not result:
+        self.comm = C.c_void_p()        # (the thread may still complete it: never used, never destroyed)
     # all ranks or none: a rank that could not build its communicator sends every rank back to torch.distributed's collectives
     ok = torch.tensor([0 if err is not None else 1], dtype=torch.int64)
     dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.meta_group)
