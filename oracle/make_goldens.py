@@ -19,7 +19,13 @@ reference's object tree so the two can be compared index by index):
   expansion index e: root = 0, the leaf expanded by simulation s = s + 1
   node index:        root = 0, child `a` of the node with expansion index e = 1 + e*A + a
 
-Usage:  python oracle/make_goldens.py [outdir]     (default tests/golden)
+Usage:  python oracle/make_goldens.py [outdir]     (default tests/golden: G1-G3 + the replay batch, 18 files)
+        python oracle/make_goldens.py convnets     (G6: MuZeroNetwork / TinyNetwork forward checksums)
+        python oracle/make_goldens.py learner      (G5: two Learner.update_weights steps of the reference -- TicTacToe batch 16 on the
+                                                    recorded batch; LunarLander shapes batch 256, K = 5 and Pong-ram shapes with
+                                                    --norm_obs on seeded synthetic batches)
+        python oracle/make_goldens.py refresh      (G4b: PrioritizedReplay.update with the learner's float32 errors)
+Every mode is deterministic: a re-run leaves every fixture byte-identical.
 """
 import os
 import random
