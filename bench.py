@@ -252,7 +252,8 @@ def measure_split_f16(device, weights, chunk, moves=384):
   actor = Actor(0, cfg, storage, replay)
   eng = actor.engine
   moves = (moves // chunk) * chunk
-  actor.launch(EPISODE_LEN + 64)         # priming (every env past its first, partial episode) + warm-up
+  # priming (every env past its first, partial episode; the replay's window filled once, as for `value`) + warm-up
+  actor.launch(max(EPISODE_LEN, min(int(cfg.window_size) // B + chunk, 1024)) + 64)
   torch.cuda.synchronize(device)
   f0 = replay.get_throughput.remote().result()['frames']
   t0 = time.perf_counter()
