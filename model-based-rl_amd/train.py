@@ -218,7 +218,9 @@ def _spawn_ranks(n, argv):
 def main(argv=None):
   argv = list(sys.argv[1:] if argv is None else argv)
   p = build_parser()
-  p.add_argument('--max_moves', type=int, default=64)
+  p.add_argument('--max_moves', type=int, default=None,
+                 help='moves per environment (default 64; with --selfplay_only and no --max_moves: 768 priming + 4096 timed moves, so that '
+                      'the printed env-steps/s is the steady state of the loop); negative: until the learner has reached --training_steps')
   p.add_argument('--selfplay_only', action='store_true')
   p.add_argument('--learner_steps', type=int, default=None)
   p.add_argument('--ranks', type=int, default=0,
@@ -232,6 +234,12 @@ def main(argv=None):
                       '--training_steps / --max_moves / --runs_dir given here override it')
   args = vars(p.parse_args(argv))
   max_moves, selfplay_only, learner_steps = args.pop('max_moves'), args.pop('selfplay_only'), args.pop('learner_steps')
+  if max_moves is None:
+    max_moves = 64
+    if selfplay_only:              # `train --selfplay_only --num_envs 4096`: the actors' steady-state rate (what bench.py reports)
+      max_moves = 768 + 4096
+      if not args.get('prime_moves'):
+        args['prime_moves'] = 768
   ranks = args.pop('ranks')
   if ranks and 'RANK' not in os.environ:
     raise SystemExit(_spawn_ranks(ranks, argv))
