@@ -364,7 +364,7 @@ int mz_fcl_step(mz_fcl *c, const float *obs, const void *actions, int actions_ar
                 double weight_decay, double clip_grad, int adamw, int no_update, float *new_errors, double *loss_sums, void *stream);
 /* mz_fcl_update: mz_fcl_step from HOST arrays (what replay_buffer.sample_batch returns, learners.py:165-180): staged through
  * pinned memory (two slots), one host-to-device copy, the step, the new errors copied back -- nothing is waited for except
- * the slot's own use three updates ago.  mz_fcl_errors(slot): the new errors of that update into host_out [batch], waiting for
+ * the slot's own use mz_fcl_slots() updates ago (6 staging slots).  mz_fcl_errors(slot): the new errors of that update into host_out [batch], waiting for
  * their copy (the priority refresh goes to the replay one update behind, as the reference's fire-and-forget refresh does). */
 int mz_fcl_update(mz_fcl *c, const float *obs, const void *actions, int actions_are_i32, const float *target_rewards,
                   const float *target_values, const float *target_policies, const void *is_weights, int weights_are_f64, double beta1,
@@ -384,7 +384,7 @@ int mz_fcl_errors(mz_fcl *c, int slot, float *host_out);
  * scheduler's values; NULL: the device float bound by mz_fcl_bind); loss_sums [dev][3] as mz_fcl_step; *pads_out (may be
  * NULL): padded actions drawn.  Batch i is sampled while update i - 1 runs on the GPU; the refresh of update i reaches the
  * replay before batch i + 2 is drawn (the reference's own lag is up to batches_per_fetch = 15 batches, learners.py:124).
- * Returns with the last (up to three) updates still in flight: the next call hands their refreshes over as their staging slots come
+ * Returns with the last (up to mz_fcl_slots() - 1) updates still in flight: the next call hands their refreshes over as their staging slots come
  * up; n_updates = 0 flushes -- waits for them and hands the refreshes over (before anything else touches the replay's
  * priorities or this handle's staging: mz_fcl_update, a checkpoint, the end of Learner.learn). */
 typedef struct mz_fcl_source {
@@ -402,6 +402,8 @@ int mz_fcl_run(mz_fcl *c, const mz_fcl_source *src, int n_updates, const uint32_
 /* development hook: mz_fcl_run's host time since the handle was created (or the last reset): out [host][6] = seconds waiting for
  * a staging slot's previous update, in priority refreshes, in sampling, in launching, in the calls as a whole; number of updates */
 int mz_fcl_run_stats(mz_fcl *c, double *out6, int reset);
+/* staging slots of this handle: how many updates mz_fcl_update / mz_fcl_run keep in flight before they wait for the oldest */
+int mz_fcl_slots(mz_fcl *c);
 int mz_fcl_read_grad(mz_fcl *c, float *host_out, size_t n);
 /* test hook: tape `which` of the last step into a HOST buffer (0 chain inputs, 1 chain fc1 activations, 2 LayerNorm x-hat, 3 rstd,
  * 4 hidden states, 5 / 6 chain deltas, 7 head fc1 activations, 8 / 9 head deltas, 10 d loss / d hidden state per head, 11 per-sample

@@ -150,6 +150,7 @@ SIGNATURES = {
     'mz_fcl_update': (_I, [_VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _I, _D, _D, _D, _D, _D, _I, _VP, _VP, C.POINTER(_I)]),
     'mz_fcl_errors': (_I, [_VP, _I, _VP]),
     'mz_fcl_run_stats': (_I, [_VP, _VP, _I]),
+    'mz_fcl_slots': (_I, [_VP]),
     'mz_fcl_run': (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _D, _D, _D, _D, _D, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     'mz_fcl_read_grad': (_I, [_VP, _VP, _SZ]),
     'mz_fcl_read_tape': (C.c_longlong, [_VP, _I, _VP, _SZ]),
