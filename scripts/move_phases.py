@@ -1,3 +1,6 @@
+"""Cycles per phase of a MOVE inside the persistent self-play launch (mz_selfplay_phase_profile), mean of four 16-move launches at 4096
+environments; MZ_HIP_LIB selects the library (A/B of two builds: profiles/r05_kernel_experiments.txt).
+usage: move_phases.py <obs_dim> <actions> <simulations>"""
 import sys, os, json, types
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '.'))
 import numpy as np, torch
