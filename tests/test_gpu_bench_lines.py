@@ -61,3 +61,6 @@ def test_learner_line():
   assert line['roofline']['flop_per_update'] == 1425801216        # batch 256, K = 5, LunarLander shapes: 3 x forward
   assert 20 < line['roofline']['us_per_update'] < 400              # the native step (the PyTorch graph: ~900)
   assert line['torch_graph']['gpu_ms_per_update'] > 2e-3 * line['roofline']['us_per_update']
+  # the timed call is Learner.launch, and its stretches between Python boundaries ran in the native loop (mz_fcl_run)
+  assert line['config']['native_loop'] and 'Learner.launch' in line['config']['workload']
+  assert line['config']['native_loop_host_us_per_update']['updates'] >= 60
