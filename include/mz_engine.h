@@ -419,6 +419,15 @@ int mz_fcl_heads_profile(mz_fcl *c, int enable, unsigned long long *host_out);
  * instantiation they mean to exercise. */
 int mz_search_kernel_info(const mz_engine *e, int *out4);
 int mz_selfplay_steps(mz_engine *e, int moves, void *stream);
+/* mz_selfplay_steps with the records written straight into host_records [host, PAGE-LOCKED: hipHostMalloc /
+ * torch pin_memory][moves][B][rec_floats] by the kernels' own stores through the buffer's device mapping (0.6 GB/s of
+ * posted PCIe writes at the benched rate), instead of the device ring + mz_selfplay_drain's D2H copy.  The buffer is
+ * complete once work enqueued on `stream` behind this call has completed (event / synchronise); it must stay untouched
+ * until then.  The device ring must hold no undrained moves; these moves count as drained.  This is the hand-off
+ * Actor.run_selfplay uses (actors.py:160-169's history hand-off): no copy stream, no cross-stream dependency for the
+ * runtime to track -- that dependency kept a runtime thread of every rank spinning (profiles/r05_host_threads.txt).
+ * Fails when host_records is not page-locked. */
+int mz_selfplay_steps_into(mz_engine *e, int moves, float *host_records, void *stream);
 /* mz_selfplay_steps with one pair of HIP events around every search-kernel dispatch (hipExtLaunchKernelGGL start / stop
  * events on `stream`: the timestamps rocprofv3's kernel trace reports).  The k moves are launched eagerly, back to back,
  * with no synchronisation in between (the state of the timed loop); synchronous at the end.  ms_out [host][k] =

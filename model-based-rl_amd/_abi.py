@@ -156,6 +156,7 @@ SIGNATURES = {
     'mz_fcl_read_tape': (C.c_longlong, [_VP, _I, _VP, _SZ]),
     'mz_fcl_heads_profile': (_I, [_VP, _I, _VP]),
     'mz_selfplay_steps': (_I, [_VP, _I, _VP]),
+    'mz_selfplay_steps_into': (_I, [_VP, _I, _VP, _VP]),
     'mz_selfplay_steps_timed': (_I, [_VP, _I, _VP, _VP]),
     'mz_selfplay_phase_profile': (_I, [_VP, _I, _VP, _VP]),
     'mz_selfplay_moves_per_launch': (_I, [_VP]),

@@ -72,8 +72,10 @@ def chunk_schedule(total, chunk):
 
 class _RecordPipe(object):
   """Host side of the device self-play loop (actors.py:126-173 for `num_envs` environments at a time): the actor's thread
-  only launches -- a chunk of moves, then the chunk's records D2H into pinned memory on a copy stream; a worker thread waits
-  for each chunk's copy and hands it over (game statistics of actors.py:99-117, then replay_buffer.ingest_records: the
+  only launches -- a chunk of moves whose records the kernels store straight into one of NBUF pinned buffers
+  (Engine.selfplay_steps_into; MZ_RECORD_COPY=1: into the device ring, then a D2H copy on a copy stream, the path until
+  r05 -- its cross-stream dependency kept a runtime thread spinning, profiles/r05_host_threads.txt); a worker thread waits
+  for each chunk's event and hands it over (game statistics of actors.py:99-117, then replay_buffer.ingest_records: the
   native replay releases the GIL and splits the environments of a chunk over its ingest threads) -- up to NBUF - 1 chunks
   behind the GPU, so that one slow ingest does not idle it.  join() returns when every chunk has been handed over."""
   NBUF = 4
@@ -85,7 +87,7 @@ class _RecordPipe(object):
     self.actor, self.chunk, self.rec_floats = actor, chunk, eng.rec_floats
     self.pinned = [torch.empty(chunk, eng.B, eng.rec_floats, dtype=torch.float32).pin_memory() for _ in range(self.NBUF)]
     self.events = [torch.cuda.Event() for _ in range(self.NBUF)]
-    self.copy_stream = torch.cuda.Stream(actor.device)        # D2H of chunk i overlaps the moves of chunk i + 1
+    self.copy_stream = torch.cuda.Stream(actor.device) if os.environ.get('MZ_RECORD_COPY') == '1' else None
     self.free, self.work, self.failed = queue.Queue(), queue.Queue(), []
     for i in range(self.NBUF):
       self.free.put(i)
@@ -117,14 +119,19 @@ class _RecordPipe(object):
         self.work.task_done()
 
   def submit(self, moves, wait=False):
-    """launch `moves` moves and the copy of their records; wait: until the copy has arrived (a GPU shared in turns)"""
+    """launch `moves` moves into a free pinned buffer; wait: until their records have arrived (a GPU shared in turns)"""
     eng = self.actor.engine
     if self.failed:
       raise self.failed[0]
     i = self.free.get()               # (blocks while the worker is NBUF chunks behind)
-    eng.selfplay_steps(moves)
-    _, n = eng.selfplay_drain(self.pinned[i], moves, copy_stream=self.copy_stream)      # overlaps the next chunk's moves
-    self.events[i].record(self.copy_stream)
+    if self.copy_stream is None:
+      eng.selfplay_steps_into(self.pinned[i], moves)
+      n = moves
+      self.events[i].record()
+    else:
+      eng.selfplay_steps(moves)
+      _, n = eng.selfplay_drain(self.pinned[i], moves, copy_stream=self.copy_stream)      # overlaps the next chunk's moves
+      self.events[i].record(self.copy_stream)
     if wait:
       self.events[i].synchronize()
     self.work.put((i, n))

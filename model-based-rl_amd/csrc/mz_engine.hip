@@ -1049,7 +1049,6 @@ int mz_destroy(mz_engine *e) {
     if (e->wstage[w]) hipHostFree(e->wstage[w]);
     if (e->wstage_ev[w]) hipEventDestroy(e->wstage_ev[w]);
   }
-  if (e->sp.host_ring) hipHostFree(e->sp.host_ring);
   delete e;
   return 0;
 }

@@ -435,6 +435,15 @@ class Engine(object):
   def selfplay_steps(self, moves):
     _abi.check(self.lib.mz_selfplay_steps(self._h, int(moves), self.stream), 'mz_selfplay_steps')
 
+  def selfplay_steps_into(self, out, moves):
+    """moves self-play moves whose records the kernels write straight into `out` (pinned host tensor
+    [>= moves, B, rec_floats]); complete when the work queued on the current stream behind this call is."""
+    if not out.is_pinned() or out.dtype != torch.float32 or not out.is_contiguous() \
+        or out.numel() < int(moves) * self.B * self.rec_floats:
+      raise ValueError('selfplay_steps_into: out must be a pinned contiguous float32 tensor of [moves, B, rec_floats]')
+    _abi.check(self.lib.mz_selfplay_steps_into(self._h, int(moves), C.c_void_p(out.data_ptr()), self.stream),
+               'mz_selfplay_steps_into')
+
   def selfplay_steps_timed(self, moves):
     """moves self-play moves launched eagerly back to back, events around every search-kernel dispatch;
     returns the durations in milliseconds (synchronous)."""

@@ -445,6 +445,55 @@ def test_small_ring_drain_on_copy_stream_is_ordered():
       assert np.array_equal(x, y), streams
 
 
+@pytest.mark.parametrize('O,A,B,sims,T,no_persist,ttt', [(8, 4, 512, 30, 7, False, False), (128, 6, 130, 12, 5, False, False),
+                                                        (8, 4, 64, 10, 4, True, False), (9, 9, 48, 10, 9, False, True)])
+def test_records_stored_into_pinned_memory_equal_the_drained_ring(O, A, B, sims, T, no_persist, ttt, monkeypatch):
+  """mz_selfplay_steps_into (the kernels store each record through the device mapping of the caller's pinned buffer) is
+  mz_selfplay_steps + mz_selfplay_drain bit for bit -- whole moves in one launch, the two kernels per move (MZ_NO_PERSIST)
+  and the device TicTacToe alike -- may alternate with the ring on one engine, rejects pageable memory and refuses to
+  overtake undrained moves."""
+  import torch
+  from model_based_rl_amd.engine import Engine, flatten_weights
+  from model_based_rl_amd.networks import FCNetwork
+  if no_persist:
+    monkeypatch.setenv('MZ_NO_PERSIST', '1')
+  torch.manual_seed(2)
+  flat = flatten_weights(FCNetwork(O, A, torch.device('cpu'), types.SimpleNamespace()).state_dict())
+
+  def make():
+    eng = Engine(B, O, A, sims, seed=9, **({'two_players': True, 'discount': 1.0, 'known_bounds': (-1.0, 1.0)} if ttt else {}))
+    eng.set_weights(flat)
+    if ttt:
+      eng.selfplay_set_env('tictactoe')
+    eng.selfplay_reset(T, 1.0, stagger=True)
+    return eng
+  ring, direct = make(), make()
+  chunks = [16, 5, 16, 1, 23]
+  for i, k in enumerate(chunks):
+    ring.selfplay_steps(k)
+    want, n = ring.selfplay_drain(max_moves=k)
+    assert n == k
+    got = torch.full((k + 1, B, direct.rec_floats), 7.0).pin_memory()
+    if i == 3:              # the ring in between: both paths on one engine
+      direct.selfplay_steps(k)
+      direct.selfplay_drain(got, k)
+    else:
+      direct.selfplay_steps_into(got, k)
+    torch.cuda.synchronize()
+    assert np.array_equal(want.numpy()[:k].view(np.int32), got.numpy()[:k].view(np.int32)), (i, k)
+    assert (got.numpy()[k] == 7.0).all()          # nothing past the launch's moves
+  with pytest.raises(ValueError):
+    direct.selfplay_steps_into(torch.empty(4, B, direct.rec_floats), 4)
+  import ctypes as C
+  pageable = np.zeros((2, B, direct.rec_floats), np.float32)
+  assert direct.lib.mz_selfplay_steps_into(direct._h, 2, pageable.ctypes.data_as(C.c_void_p), direct.stream) != 0
+  assert b'page-locked' in direct.lib.mz_last_error()
+  direct.selfplay_steps(3)
+  with pytest.raises(RuntimeError, match='drain them first'):
+    direct.selfplay_steps_into(torch.empty(3, B, direct.rec_floats).pin_memory(), 3)
+  ring.close(); direct.close()
+
+
 def test_actor_load_state_metrics_and_run_dirs(tmp_path):
   """Actor.load_state (actors.py:75-79): weights, training step and this actor's game count come back from a learner
   checkpoint dictionary; the actor's scalars (actors.py:105-117) land in <run>/<worker>/metrics.csv and the game count is
