@@ -96,8 +96,8 @@ class _RecordPipe(object):
 
   @staticmethod
   def _wait(ev):
-    # the chunk's copy is a few milliseconds out: sleep-poll instead of spinning a core on hipEventSynchronize (one
-    # process per GPU shares the host's cores with seven others)
+    # the chunk's records are a few milliseconds out: sleep-poll instead of hipEventSynchronize, which spins a core with
+    # or without hipEventBlockingSync (one process per GPU shares the host's cores with seven others)
     while not ev.query():
       time.sleep(0.0002)
 
