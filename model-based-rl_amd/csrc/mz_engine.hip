@@ -139,11 +139,23 @@ struct mz_engine {
 
 // Every ABI entry runs on the engine's own device, whatever the calling thread's current device is (an engine may be
 // driven from a worker thread: rayshim actors, a replay/drain thread).
+// every entry runs on the handle's own device and leaves the calling thread's current device as it found it
+struct MzDeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  int enter(int device) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device) {
+      if (hipSetDevice(device) != hipSuccess) return -1;
+      switched = true;
+    }
+    return 0;
+  }
+  ~MzDeviceGuard() { if (switched && prev >= 0) (void)hipSetDevice(prev); }
+};
 #define MZ_ENTER(e)                                                                          \
-  do {                                                                                       \
-    int cur_ = -1;                                                                           \
-    if (hipGetDevice(&cur_) != hipSuccess || cur_ != (e)->device) HIPCHECK(hipSetDevice((e)->device)); \
-  } while (0)
+  MzDeviceGuard mz_guard_;                                                                   \
+  if (mz_guard_.enter((e)->device)) return fail("hipSetDevice(%d) failed", (e)->device)
 
 __global__ void k_store_double(double *dst, double v) { *dst = v; }
 
