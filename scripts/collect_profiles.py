@@ -20,6 +20,7 @@ names = {
     'bench_learner_%s.json': '%s_bench_learner_secondary.json', 'learner_kernels_%s.csv': '%s_learner_kernels.csv',
     'bench_steps20_%s.json': '%s_bench_steps20.json', 'weight_sync_ab_%s.txt': '%s_weight_sync_ab.txt',
     'parity_full_grid_%s.txt': '%s_parity_full_grid.txt',
+    'bench_8ranks_fullsize_1gpu_%s.json': '%s_bench_8ranks_fullsize_1gpu.json', 'host_threads_%s.txt': '%s_host_threads.txt',
 }
 # the product's own entry point (train --selfplay_only): its summary line as JSON
 ts = os.path.join(G, 'train_selfplay_%s.txt' % tag)

@@ -52,6 +52,15 @@ MZ_PARITY_REPORT=$O/parity_full_grid_$TAG.txt python3 -m pytest tests/test_gpu_b
 MZ_BENCH_BACKEND=gloo python3 bench.py --gpus 2 --envs 2048 --no-cpu-baseline > $O/bench_selflaunch_2ranks_1gpu_$TAG.json 2>> $O/bench_$TAG.err
 # ... and eight ranks on this one GPU (512 environments each): shards, host cores of all ranks, seven rings into one replay
 MZ_BENCH_BACKEND=gloo python3 bench.py --gpus 8 --envs 512 --min-seconds 2 --runs 3 --no-cpu-baseline > $O/bench_selflaunch_8ranks_1gpu_$TAG.json 2>> $O/bench_$TAG.err
+# ... and at the FULL size (4096 environments per rank): the host side of an 8-GPU run on the one box there is
+MZ_BENCH_BACKEND=gloo python3 bench.py --gpus 8 --min-seconds 2 --runs 2 --no-cpu-baseline > $O/bench_8ranks_fullsize_1gpu_$TAG.json 2>> $O/bench_$TAG.err
+# host cores per thread of one rank (records stored into pinned memory / the copy-stream path), and what spins in the runtime
+(echo "== scripts/experiments/runtime_spin_probe.py: busiest three threads (cores, tid) per activity; main tid printed last"
+ python3 scripts/experiments/runtime_spin_probe.py 2>&1 | grep -v amdgpu
+ echo; echo "== scripts/experiments/actor_thread_cpu.py, MZ_RECORD_COPY=1 (device ring + D2H copy on a copy stream)"
+ MZ_RECORD_COPY=1 python3 scripts/experiments/actor_thread_cpu.py 2>&1 | grep -v "amdgpu\|online"
+ echo; echo "== scripts/experiments/actor_thread_cpu.py, default (mz_selfplay_steps_into: the kernels store the records into pinned memory)"
+ python3 scripts/experiments/actor_thread_cpu.py 2>&1 | grep -v "amdgpu\|online") > $O/host_threads_$TAG.txt 2>&1
 # the world-size-1 RCCL branch of the bench (process group over nccl, device-side weight broadcasts)
 MZ_BENCH_FORCE_DIST=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29591 bench.py --gpus 1 --no-cpu-baseline > $O/bench_rccl_world1_$TAG.json 2>> $O/bench_$TAG.err
 # host side: ingest thread scaling, the one-replay path of train --ranks 8 with synthetic producers
