@@ -715,8 +715,10 @@ def test_persistent_selfplay_launch_equals_graph_of_kernels(O, A, sims, u8, spli
   assert np.array_equal(out[0][1]['P'][ex], out[1][1]['P'][ex])
 
 
-def test_actor_pipeline_equals_a_plain_engine_loop(tmp_path):
-  """Actor.launch (the product's device loop: _RecordPipe -- launch-ahead chunks, pinned buffers, ingest on a worker thread) hands
+@pytest.mark.parametrize('record_copy', [False, True])
+def test_actor_pipeline_equals_a_plain_engine_loop(tmp_path, monkeypatch, record_copy):
+  """(record_copy: MZ_RECORD_COPY=1, the device ring + D2H copy on a copy stream instead of the kernels' stores into pinned memory)
+  Actor.launch (the product's device loop: _RecordPipe -- launch-ahead chunks, pinned buffers, ingest on a worker thread) hands
   the replay exactly the records a plain engine loop produces, whatever the chunking: one launch of 48 moves, and 20 + 28 moves in
   two calls (the second continues episodes, record ring and pipeline), give the same record stream bit for bit, the same replay
   (every leaf priority, frames, games) as a replay fed by direct ingest, and the same game statistics."""
@@ -731,6 +733,8 @@ def test_actor_pipeline_equals_a_plain_engine_loop(tmp_path):
   g = np.load(os.path.join(G, 'g1_net_lunar.npz'))
   w = {k: torch.from_numpy(v) for k, v in orc.load_weights(g).items()}
   B, moves = 96, 48
+  if record_copy:
+    monkeypatch.setenv('MZ_RECORD_COPY', '1')
 
   def cfg_of(tag):
     return make_config(['--environment', 'LunarLander-v2', '--num_envs', str(B), '--num_simulations', '10', '--episode_length', '7',
