@@ -25,14 +25,20 @@ WEIGHT_ORDER = [
 
 
 def flatten_weights(weights):
-  """state_dict (reference key names, networks.py:137-144) -> one float32 vector in ABI order."""
+  """state_dict (reference key names, networks.py:137-144) -> one float32 vector in ABI order.
+  Copied with numpy: torch.cat parallelises over its intra-op pool once a tensor passes 32 K elements (the 128 x 512 first
+  layer of the -ram- shapes), and the pool's threads spin after every call -- 7 of 16 host cores busy at a pull every 0.1 s."""
   parts = []
   for k in WEIGHT_ORDER:
     v = weights[k]
-    v = v.detach().to('cpu', torch.float32).reshape(-1) if torch.is_tensor(v) else torch.from_numpy(
-        np.ascontiguousarray(v, np.float32).reshape(-1))
-    parts.append(v)
-  return torch.cat(parts).contiguous()
+    parts.append(v.detach().to('cpu', torch.float32).numpy().reshape(-1) if torch.is_tensor(v)
+                 else np.ascontiguousarray(v, np.float32).reshape(-1))
+  out = np.empty(sum(p.size for p in parts), np.float32)
+  pos = 0
+  for p in parts:
+    out[pos:pos + p.size] = p
+    pos += p.size
+  return torch.from_numpy(out)
 
 
 def weights_scale_ok(flat_host, obs_dim, action_space, value_outputs, reward_outputs):

@@ -25,11 +25,15 @@ def task_times():
   return out
 
 THREADS = os.environ.get('MZ_PROBE_INGEST_THREADS')
-cfg = make_config((['--ingest_threads', THREADS] if THREADS else []) + ['--environment', 'LunarLander-v2', '--num_envs', '4096', '--num_simulations', '30', '--seed', '1', '--window_size', str(1 << 21),
-                   '--weight_sync_frequency', '128', '--runs_dir', '/tmp/mz_runs', '--run_tag', 'cpu_probe', '--fixed_temperatures', '1.0'])
+PONG = os.environ.get('MZ_PROBE_WORKLOAD') == 'pong'      # Pong-ram shapes: obs 128 bytes, 6 actions, 50 simulations, --norm_obs
+O, A = (128, 6) if PONG else (8, 4)
+cfg = make_config((['--environment', 'Pong-ramNoFrameskip-v4', '--num_simulations', '50', '--norm_obs', '--obs_range', '0', '255', '--ingest_threads', THREADS or '4']
+                   if PONG else ['--environment', 'LunarLander-v2', '--num_simulations', '30'] + (['--ingest_threads', THREADS] if THREADS else [])) +
+                  ['--num_envs', '4096', '--seed', '1', '--window_size', str(1 << 21), '--weight_sync_frequency', '128', '--runs_dir', '/tmp/mz_runs',
+                   '--run_tag', 'cpu_probe', '--fixed_temperatures', '1.0'])
 storage, replay = ray.remote(SharedStorage).remote(cfg), ray.remote(PrioritizedReplay).remote(cfg)
 torch.manual_seed(0)
-storage.store_weights.remote(FCNetwork(8, 4, torch.device('cpu'), types.SimpleNamespace()).get_weights(), 1).result()
+storage.store_weights.remote(FCNetwork(O, A, torch.device('cpu'), types.SimpleNamespace()).get_weights(), 1).result()
 actor = Actor(0, cfg, storage, replay)
 actor.launch(768)
 names = {t.native_id: t.name for t in threading.enumerate()}
@@ -38,7 +42,8 @@ names[actor._pipe.thread.native_id] = 'record pipe worker'
 names[replay._t.native_id] = 'replay handle (ingest call)'
 names[storage._t.native_id] = 'storage handle'
 t0, w0 = task_times(), time.perf_counter()
-actor.launch(3072)
+MOVES = 1536 if PONG else 3072
+actor.launch(MOVES)
 dt = time.perf_counter() - w0
 t1 = task_times()
 def comm(k):
@@ -50,4 +55,4 @@ rows = sorted(((t1[k] - t0.get(k, 0.0)) / dt, names.get(k, 'native thread %d (%s
 for busy, name in reversed(rows):
   if busy > 0.005:
     print('%-34s %.3f cores' % (name, busy))
-print('total %.3f cores over %.2f s; %.2f M env-steps/s' % (sum(b for b, _ in rows), dt, 4096 * 3072 / dt / 1e6))
+print('total %.3f cores over %.2f s; %.2f M env-steps/s' % (sum(b for b, _ in rows), dt, 4096 * MOVES / dt / 1e6))
