@@ -451,8 +451,9 @@ class Actor(Logger):
 
   def _run_selfplay_torch(self, max_moves=None):
     """The same loop for a torch network (MuZeroNetwork / TinyNetwork, config 5): one move of all environments per
-    iteration through torch_search.TorchSelfplay; the move's records go D2H on a copy stream while the next move is
-    searched, and reach the replay through the same bulk ingest."""
+    iteration through torch_search.TorchSelfplay; the move's records go D2H behind it on the same stream (2 ms of a
+    1.5-s move at Breakout shapes: a copy stream's cross-stream dependency keeps a runtime thread spinning for the whole
+    move, profiles/r05_host_threads.txt) and reach the replay through the same bulk ingest while the next move is searched."""
     cfg, sp = self.config, self.selfplay
     temperature = self._temperature()
     sp.temperature.fill_(temperature)
@@ -460,13 +461,13 @@ class Actor(Logger):
     dev = [torch.empty(sp.B, sp.rec_floats, dtype=torch.float32, device=self.device) for _ in range(2)]
     pinned = [torch.empty(1, sp.B, sp.rec_floats, dtype=torch.float32).pin_memory() for _ in range(2)]
     events = [torch.cuda.Event(), torch.cuda.Event()]
-    copy_stream = torch.cuda.Stream(self.device)
     sync_every = max(1, cfg.weight_sync_frequency)
     pending, k = None, 0
 
     def hand_over(p):
       buf, ev = p
-      ev.synchronize()
+      while not ev.query():       # (sleep-poll: hipEventSynchronize spins a core)
+        time.sleep(0.0005)
       self._log_games(records_view(buf.numpy(), sp.O, sp.A, obs_u8=sp.obs_u8))
       _call(self.replay_buffer, 'ingest_records', buf, 1, sp.B, self.env_base)
 
@@ -476,10 +477,8 @@ class Actor(Logger):
       turn = self._turns.turn(self.device) if self._turns is not None else contextlib.nullcontext()
       with turn:
         sp.play_move(dev[k & 1])
-        copy_stream.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(copy_stream):
-          pinned[k & 1][0].copy_(dev[k & 1], non_blocking=True)
-        events[k & 1].record(copy_stream)
+        pinned[k & 1][0].copy_(dev[k & 1], non_blocking=True)
+        events[k & 1].record()
         if self._turns is not None and turn is not self._turns.NO_TURNS:
           events[k & 1].synchronize()
       if pending is not None:
