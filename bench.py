@@ -692,9 +692,10 @@ def main():
                                   'Learner.send_weights every %.3f s; a pull waits for NOTHING queued on the GPU (mz_set_weights_async: the repack runs '
                                   'in stream order, the clamp-ReLU scale decision is made on the host copy): 0 pipeline drains'
                                   % (sync_every, ' -> broadcast of the flat f32 buffer' if dist is not None else '', syncs_in_region, args.publish_period),
-                   'timed_call': 'Actor.launch(%d) per region (model-based-rl_amd/actors.py: _RecordPipe, %d-move chunks, %d pinned buffers; '
+                   'timed_call': 'Actor.launch(%d) per region (model-based-rl_amd/actors.py: _RecordPipe, %d-move chunks, %d pinned buffers %s; '
                                  'records logged + ingested on its worker thread); storage / replay behind rayshim handles as in train.launch'
-                                 % (per_run, chunk, actor._pipe.NBUF)},
+                                 % (per_run, chunk, actor._pipe.NBUF, 'filled by a D2H copy on a copy stream (MZ_RECORD_COPY=1)' if actor._pipe.copy_stream is not None
+                                    else "that the kernels' own stores fill (mz_selfplay_steps_into: `value` includes the records' way over PCIe)")},
         'env_steps_executed_per_s': env_steps / dt,
         'host_cores_busy_per_rank': host_cores_busy, 'host_cores_busy_max_rank': host_cores_busy_max,
         'host_cores_busy_all_ranks': host_cores_busy_sum, 'shards_env_ids': shards,
