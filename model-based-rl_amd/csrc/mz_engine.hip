@@ -102,6 +102,7 @@ struct mz_engine {
   bool lds_attr_set_head = false;
   bool use_persist = true;          // self-play loop: whole moves inside ONE launch of the search kernel (its HEAD instantiation)
   int persist_moves = 0;            // > 0 only around that launch: moves it plays
+  float *direct_records = nullptr;  // mz_selfplay_steps_into: device mapping of the caller's pinned buffer, around its launches
   unsigned long long *head_prof = nullptr;   // non-null only inside mz_selfplay_phase_profile
   // record drain on a copy stream (mz_selfplay_drain): event behind the last copy, and how far the compute stream
   // has been ordered behind the copies

@@ -530,7 +530,7 @@ __device__ __forceinline__ void mz_finalize_record(const TreeView &t, const Tree
   const int pos = __popc(legal & ((1u << lane) - 1u));
   if (ok) { d[pos] = (double)c; acts[pos] = lane; }
   const unsigned long long move = envs ? *(const unsigned long long *)envs : sp.movecnt[b];
-  float *rec = sp.ring + ((size_t)((move - sp.rec_base) % (unsigned long long)sp.rec_moves) * t.B + b) * sp.rec_floats;
+  float *rec = sp.ring + ((size_t)(move % (unsigned long long)sp.ring_moves) * t.B + b) * sp.rec_floats;
   const int OS = sp.obs_slots;       // float slots of the observation in the record (O, or ceil(O / 4) for packed bytes)
   if (envs && O <= MZ_ENVW - 8 && sp.obs_u8 != 2) { if (lane < O) rec[lane] = ((const float *)envs)[8 + lane]; }
   else for (int k = lane; k < OS; k += TL) rec[k] = mz_rec_obs_slot(sp, sp.obs + (size_t)b * O, O, k);

@@ -35,11 +35,8 @@ struct SelfplayState {
   const double *draw_uniform;   // [B] or null: the uniform select_action consumes, given by the host (parity runs,
                                 // mz_selfplay_set_draws); null = the device RNG keyed (seed, env, move)
   int draws_noise;       // != 0: the Dirichlet draw of the coming moves is the one the host put into TreeView::noise
-  float *ring;           // [rec_moves][B][rec_floats]: where move m's records go, slot (m - rec_base) % rec_moves -- the device
-                         // ring (rec_base 0, rec_moves = ring_moves), or for one launch the caller's pinned host buffer
-                         // (mz_selfplay_steps_into: rec_base = the launch's first move, the kernel's stores cross PCIe themselves)
-  unsigned long long rec_base;
-  int rec_moves;
+  float *ring;           // [ring_moves][B][rec_floats]
+  float *host_ring;      // pinned staging for drains (optional)
   unsigned long long moves_host, drained;
   int env_offset;
   bool ready;
@@ -128,7 +125,7 @@ static __global__ void k_env_step_record(TreeView tv, SelfplayState sp, int B, i
   // Config.select_action + store_search_statistics + root error for this tree (same code as mz_finalize)
   mz_finalize_tree(tv, b, sp.temp, nullptr, seed, move, sp.env_offset, sp.action, sp.child_visits, sp.root_value,
                    sp.error, nullptr);
-  float *rec = sp.ring + ((size_t)((move - sp.rec_base) % (unsigned long long)sp.rec_moves) * B + b) * sp.rec_floats;
+  float *rec = sp.ring + ((size_t)(move % (unsigned long long)sp.ring_moves) * B + b) * sp.rec_floats;
   const int t = sp.t[b], ep = sp.episode[b];
   const int OS = sp.obs_slots;
   for (int k = 0; k < OS; ++k) rec[k] = mz_rec_obs_slot(sp, sp.obs + (size_t)b * O, O, k);
@@ -201,7 +198,7 @@ static __global__ void k_ttt_step_record(TreeView tv, SelfplayState sp, int B, i
   mz_finalize_tree(tv, b, sp.temp, sp.draw_uniform, seed, move, sp.env_offset, sp.action, sp.child_visits, sp.root_value,
                    sp.error, nullptr);
   const int O = 9;
-  float *rec = sp.ring + ((size_t)((move - sp.rec_base) % (unsigned long long)sp.rec_moves) * B + b) * sp.rec_floats;
+  float *rec = sp.ring + ((size_t)(move % (unsigned long long)sp.ring_moves) * B + b) * sp.rec_floats;
   for (int k = 0; k < O; ++k) rec[k] = sp.obs[(size_t)b * O + k];
   for (int a = 0; a < A; ++a) rec[O + a] = (float)sp.child_visits[(size_t)b * A + a];
   mz_ttt_apply(sp, b, sp.action[b], sp.root_value[b], sp.error[b], rec, A);
