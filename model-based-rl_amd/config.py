@@ -137,6 +137,8 @@ def build_parser():
     help='moves per launch / drain / ingest chunk of the device self-play loop (default 16: one launch of the persistent search kernel)')
   a('--gpu_turns', action='store_true',
     help='an actor and a learner of this process share ONE GPU: they take turns, one chunk of moves / one update at a time (gpu_turns.py)')
+  a('--gpu_turn_updates', type=int, default=8,
+    help='with --gpu_turns: updates the learner runs per turn (the actor holds the GPU for one chunk of moves per turn)')
   a('--split_f16', action='store_true',
     help='FCNetwork GEMMs of the search as float16 high/low splits on the f16 matrix pipe (float32-level accuracy, not '
          'bit-identical to the exact-float32 default; include/mz_engine.h mz_config.split_f16)')

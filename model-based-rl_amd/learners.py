@@ -927,14 +927,14 @@ class Learner(Logger):
     replay = getattr(self.replay_buffer, '_obj', self.replay_buffer)
     return (self.device.type == 'cuda' and self.use_graph and isinstance(self.network, FCNetwork) and hasattr(replay, '_h') and
             hasattr(replay, 'sample_batches_arrays') and not getattr(cfg, 'no_native_learner', False) and
-            not getattr(cfg, 'no_native_loop', False) and not getattr(cfg, 'gpu_turns', False) and not getattr(cfg, 'no_support', False))
+            not getattr(cfg, 'no_native_loop', False) and not getattr(cfg, 'no_support', False))
 
   def _native_segment(self, cfg, last, log_every):
     """-> how many updates mz_fcl_run may take from here: up to the next step at which the loop does something in Python
-    (send_weights, save_state, logging; learners.py:132-153); 0 where the native loop does not apply (no native step yet, a
-    replay that is not the native one of this process, --no_native_loop, a GPU shared in turns)"""
+    (send_weights, save_state, logging; learners.py:132-153), on a GPU shared in turns at most --gpu_turn_updates; 0 where the
+    native loop does not apply (no native step yet, a replay that is not the native one of this process, --no_native_loop)"""
     replay = getattr(self.replay_buffer, '_obj', self.replay_buffer)
-    if (self._native is None or getattr(cfg, 'no_native_loop', False) or getattr(cfg, 'gpu_turns', False) or
+    if (self._native is None or getattr(cfg, 'no_native_loop', False) or
         not hasattr(replay, 'sample_batches_arrays') or not hasattr(replay, '_h') or
         int(replay.batch_size) != self._native.bs or int(cfg.num_unroll_steps) != self._native.K):
       return 0, None
@@ -942,6 +942,8 @@ class Learner(Logger):
     n = last - step
     for f in (cfg.send_weights_frequency, getattr(cfg, 'save_state_frequency', 1000), log_every):
       n = min(n, f - step % f)
+    if getattr(cfg, 'gpu_turns', False):
+      n = min(n, max(1, int(getattr(cfg, 'gpu_turn_updates', 8))))
     return int(n), replay
 
   def _scheduled_lrs(self, n):
@@ -965,7 +967,13 @@ class Learner(Logger):
         if self._pending is not None:
           self.flush_priorities()
         self._native.sync()
-        self._native.run(replay, n, self._scheduled_lrs(n))
+        turn = gpu_turns.turn(self.device) if gpu_turns is not None else None
+        if turn is not None and turn is not gpu_turns.NO_TURNS:
+          with turn:      # (an actor on the same GPU: n <= --gpu_turn_updates updates per turn, the GPU idle again at its end)
+            self._native.run(replay, n, self._scheduled_lrs(n))
+            self._native.flush()
+        else:
+          self._native.run(replay, n, self._scheduled_lrs(n))
         self.native_loop_updates += n
         self.training_step += n
         self._after_update(cfg, log_every)
