@@ -276,6 +276,11 @@ int mz_padded_envs(const mz_engine *e);
 #define MZ_REC_EXTRA 10
 int mz_selfplay_reset(mz_engine *e, int episode_len, double temperature, int stagger, void *stream);
 int mz_selfplay_set_temperature(mz_engine *e, double temperature, void *stream);
+/* The move counter of every environment (Actor's count of moves played, actors.py:87-124: keys the device RNG by (seed, env, move)
+ * and places the experience records).  For a caller that wants a resumed run to continue its count instead of replaying the random
+ * stream of its first moves (the reference reseeds on resume: Actor.load_state does not call this), and for the tests, which start
+ * close to 2^30 and 2^32.  The device ring must be drained; synchronous. */
+int mz_selfplay_set_moves(mz_engine *e, unsigned long long moves);
 /* The environment the loop plays (call before mz_selfplay_reset).  0 (default): the synthetic fixed-length episodes above.
  * 1: TicTacToe with the reference's rules (custom_environments/tic_tac_toe.py:5-76: observation turn * board, legal =
  * empty cells, reward 1 for the winning move, done on a win or after nine moves, players alternate) entirely on the device;

@@ -130,6 +130,7 @@ SIGNATURES = {
     'mz_padded_envs': (_I, [_VP]),
     'mz_selfplay_reset': (_I, [_VP, _I, _D, _I, _VP]),
     'mz_selfplay_set_temperature': (_I, [_VP, _D, _VP]),
+    'mz_selfplay_set_moves': (_I, [_VP, _U64]),
     'mz_selfplay_set_obs': (_I, [_VP, _I, _VP, _VP]),
     'mz_selfplay_set_env': (_I, [_VP, _I]),
     'mz_selfplay_set_draws': (_I, [_VP, _VP, _VP, _VP]),

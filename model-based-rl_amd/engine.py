@@ -373,6 +373,10 @@ class Engine(object):
     _abi.check(self.lib.mz_selfplay_set_temperature(self._h, float(temperature), self.stream),
                'mz_selfplay_set_temperature')
 
+  def selfplay_set_moves(self, moves):
+    """every environment's move counter (RNG key, record placement); the device ring must be drained"""
+    _abi.check(self.lib.mz_selfplay_set_moves(self._h, int(moves)), 'mz_selfplay_set_moves')
+
   def selfplay_set_obs(self, uint8_obs=False, obs_min=None, obs_range=None, packed=False):
     """Synthetic observations as bytes (the -ram- envs) and / or --norm_obs (actors.py:55-58,134-137): obs_min and
     obs_range are broadcast to obs_dim like numpy does in the reference's (obs - min) / range.  packed: the experience

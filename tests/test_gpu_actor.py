@@ -494,6 +494,47 @@ def test_records_stored_into_pinned_memory_equal_the_drained_ring(O, A, B, sims,
   ring.close(); direct.close()
 
 
+@pytest.mark.parametrize('base', [(1 << 30) - 20, (1 << 32) - 20])
+def test_move_counter_across_its_word_boundaries(base, monkeypatch):
+  """mz_selfplay_set_moves puts every environment's move counter close to 2^30 (where mz_selfplay_steps_into's 2^30-slot ring
+  would wrap inside a launch: the host switches to its second modulus) and to 2^32 (the counter's high word: RNG keys, record
+  slots): records stored into pinned memory == the drained device ring == the kernel-per-phase launch structure, bit for bit."""
+  import torch
+  from model_based_rl_amd.engine import Engine, flatten_weights
+  from model_based_rl_amd.networks import FCNetwork
+  O, A, B, sims, T = 8, 4, 80, 10, 7
+  torch.manual_seed(3)
+  flat = flatten_weights(FCNetwork(O, A, torch.device('cpu'), types.SimpleNamespace()).state_dict())
+
+  def make():
+    eng = Engine(B, O, A, sims, seed=11)
+    eng.set_weights(flat)
+    eng.selfplay_reset(T, 1.0, stagger=True)
+    eng.selfplay_set_moves(base)
+    return eng
+  ring, direct = make(), make()
+  monkeypatch.setenv('MZ_NO_PERSIST', '1')
+  phases = make()
+  assert ring.selfplay_moves_per_launch() == 16 and phases.selfplay_moves_per_launch() == 0
+  for k in (16, 16, 7):                      # the second chunk crosses the boundary
+    got = torch.zeros(k, B, direct.rec_floats).pin_memory()
+    direct.selfplay_steps_into(got, k)
+    outs = []
+    for eng in (ring, phases):
+      eng.selfplay_steps(k)
+      rec, n = eng.selfplay_drain(max_moves=k)
+      assert n == k
+      outs.append(rec)
+    torch.cuda.synchronize()
+    for rec in outs:
+      assert np.array_equal(rec.numpy()[:k].view(np.int32), got.numpy().view(np.int32)), k
+  ring.selfplay_steps(2)
+  with pytest.raises(RuntimeError, match='drain them first'):
+    ring.selfplay_set_moves(5)
+  for eng in (ring, direct, phases):
+    eng.close()
+
+
 def test_actor_load_state_metrics_and_run_dirs(tmp_path):
   """Actor.load_state (actors.py:75-79): weights, training step and this actor's game count come back from a learner
   checkpoint dictionary; the actor's scalars (actors.py:105-117) land in <run>/<worker>/metrics.csv and the game count is
