@@ -98,6 +98,14 @@ def launch_ranks(config, max_moves, selfplay_only=False, learner_steps=None, sta
   rings, storage, replay, learner, stop = {}, None, None, None, threading.Event()
   if rank == 0:
     storage = ray.remote(SharedStorage).remote(config)
+    if not getattr(config, 'ingest_threads', None) and world > 4:
+      # the ONE replay takes every rank's records: 4 ingest threads accept 72 M LunarLander-shaped records/s (7.2 GPUs' worth), 8
+      # accept 103 M (scripts/one_replay_bench.py); bounded by the CPUs this process may use
+      try:
+        cpus = len(os.sched_getaffinity(0))
+      except AttributeError:
+        cpus = os.cpu_count() or 1
+      config.ingest_threads = max(1, min(8, world, cpus - 1))
     replay = ray.remote(PrioritizedReplay).remote(config)
     rings = {r: D.ShmRing('%s_%d' % (run_id, r), chunk, B, rec, slots=4, create=True) for r in range(1, world)}
   from .actors import _call

@@ -1,16 +1,20 @@
 """The one-replay topology of `train --ranks N` at scale, without N GPUs: N - 1 producer PROCESSES push record chunks (the
-device loop's shape: 8 moves x 4096 envs, LunarLander records) through their ShmRing to rank 0's drain thread
+device loop's shape: 16 moves x 4096 envs; LunarLander records, or --shape pong: the 192-byte Pong-ram records) through their ShmRing to rank 0's drain thread
 (distributed.serve_rings), which feeds THE one native replay with the parallel ingest -- exactly the host path of
 train.launch_ranks, with the GPUs replaced by pre-generated chunks.  Reports the records/s the replay accepts when the
 producers push as fast as the rings take them (the cap of the layout on this host), and how long a producer waited for
-a free slot when it paces itself at one GPU's rate (3.3 ms per chunk).
+a free slot when it paces itself at one GPU's rate (--pace_ms per chunk).
 
-  python scripts/one_replay_bench.py [--ranks 8] [--chunks 150] [--threads 4] [--pace_ms 0]"""
+  python scripts/one_replay_bench.py [--ranks 8] [--chunks 150] [--threads 4] [--pace_ms 0] [--shape lunar|pong]"""
 import argparse, json, multiprocessing as mp, os, sys, threading, time, types
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-B, O, A, T, CH = 4096, 8, 4, 256, 8
-REC = O + A + 10
+B, O, A, T, CH = 4096, 8, 4, 256, 16
+U8 = False
+if '--shape' in sys.argv and sys.argv[sys.argv.index('--shape') + 1] == 'pong':      # Pong-ram records: 128 observation bytes packed
+  O, A, U8 = 128, 6, True                                                             # into 32 float slots, 6 actions (192 bytes)
+OS = (O + 3) // 4 if U8 else O
+REC = OS + A + 10
 
 
 def make_chunks(n, seed, env_base):
@@ -20,7 +24,7 @@ def make_chunks(n, seed, env_base):
   out = []
   for _ in range(n):
     rec = rng.standard_normal((CH, B, REC)).astype(np.float32)
-    ints = rec[..., O + A + 5:].view(np.int32)
+    ints = rec[..., OS + A + 5:].view(np.int32)
     for m in range(CH):
       ints[m, :, 0] = 1; ints[m, :, 1] = (t + 1 >= T); ints[m, :, 2] = t; ints[m, :, 3] = np.arange(B); ints[m, :, 4] = ep
       done = t + 1 >= T
@@ -56,12 +60,14 @@ def main():
   ap.add_argument('--threads', type=int, default=4)
   ap.add_argument('--pace_ms', type=float, default=0.0)
   ap.add_argument('--json', default=None)
+  ap.add_argument('--shape', default='lunar', choices=['lunar', 'pong'])
+  ap.add_argument('--gpu_rate', type=float, default=None, help='records/s of one GPU at this shape (default: 10.0 M lunar, 5.4 M pong)')
   a = ap.parse_args()
   from model_based_rl_amd import distributed as D
   from model_based_rl_amd.replay_buffer import PrioritizedReplay
   cfg = types.SimpleNamespace(batch_size=256, epsilon=0.01, alpha=1.0, beta=1.0, obs_space=(O,), action_space=A, window_size=1 << 21,
                               window_step=None, num_unroll_steps=5, td_steps=10, max_history_length=500, discount=0.997, seed=0,
-                              ingest_threads=a.threads)
+                              ingest_threads=a.threads, obs_u8=U8)
   replay = PrioritizedReplay(cfg)
   run = 'mz_onereplay_%d' % os.getpid()
   rings = {r: D.ShmRing('%s_%d' % (run, r), CH, B, REC, slots=4, create=True) for r in range(1, a.ranks)}
@@ -100,10 +106,11 @@ def main():
     p.join()
   for r in rings.values():
     r.release()
+  gpu_rate = a.gpu_rate or (5.4e6 if a.shape == 'pong' else 10.0e6)
   out = {'ranks': a.ranks, 'ingest_threads': replay.ingest_threads, 'chunks_per_rank': a.chunks, 'pace_ms': a.pace_ms,
          'records_in': a.ranks * a.chunks * CH * B, 'frames_accepted': frames, 'seconds': dt,
-         'records_per_s': a.ranks * a.chunks * CH * B / dt, 'one_gpu_rate_records_per_s': CH * B / 3.3e-3,
-         'gpus_worth': a.ranks * a.chunks * CH * B / dt / (CH * B / 3.3e-3),
+         'records_per_s': a.ranks * a.chunks * CH * B / dt, 'one_gpu_rate_records_per_s': gpu_rate,
+         'gpus_worth': a.ranks * a.chunks * CH * B / dt / gpu_rate, 'shape': a.shape, 'record_bytes': REC * 4, 'moves_per_chunk': CH,
          'producer_seconds_in_put': {int(k): round(v, 3) for k, v in sorted(waits.items())},
          'host_cpus_usable': len(os.sched_getaffinity(0))}
   print(json.dumps(out))
