@@ -148,6 +148,65 @@ def cpu_baseline_reference_shaped():
           'fidelity': 'profiles/r02_ref_shaped_ratio.json (timed beside the imported reference in the build container)'}
 
 
+def build_id():
+  """what this line was measured ON: a hash over the kernel / host sources and this file (the GPU box has no .git: a commit id is
+  not available there).  An N > 1 line looks for an N = 1 line of the same build under profiles/ (efficiency_vs_n1)."""
+  import glob
+  import hashlib
+  h = hashlib.sha256()
+  pkg = os.path.join(ROOT, 'model-based-rl_amd')
+  files = sorted(glob.glob(os.path.join(pkg, 'csrc', '*.hip')) + glob.glob(os.path.join(pkg, 'csrc', '*.h')) +
+                 glob.glob(os.path.join(pkg, 'csrc', '*.inc')) + glob.glob(os.path.join(pkg, 'csrc', '*.cpp')) +
+                 glob.glob(os.path.join(pkg, '*.py')) + [os.path.abspath(__file__)])
+  for f in files:
+    h.update(os.path.basename(f).encode())
+    h.update(open(f, 'rb').read())
+  return h.hexdigest()[:16]
+
+
+def n1_reference(workload, one_replay):
+  """the N = 1 line of this workload under profiles/ (files named *_bench*.json): the one of the same build if there is one, else the
+  newest; -> (value, same_build, file) or None"""
+  import glob
+  bid, best = build_id(), None
+  for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*bench*.json')), key=os.path.getmtime):
+    try:
+      line = json.load(open(f))
+    except (ValueError, OSError):
+      continue
+    if not isinstance(line, dict) or line.get('n_gpus') != 1 or line.get('unit') != 'env-steps/s' or line.get('secondary') or line.get('secondary_line'):
+      continue
+    if not str(line.get('config', {}).get('workload', '')).startswith(workload):
+      continue
+    same = line.get('build_id') == bid
+    if best is None or same or not best[1]:
+      best = (float(line['value']), same, os.path.basename(f))
+  return best
+
+
+def efficiency_vs_n1(value, world, one_replay):
+  """value / (N x the N = 1 line's value) where profiles/ holds one (the driver computes its own from its per-N runs; this is
+  for reading a lone N > 1 record)"""
+  if world <= 1:
+    return None
+  ref = n1_reference(WNAME, one_replay)
+  if ref is None:
+    return None
+  return {'efficiency': value / (world * ref[0]), 'n1_value': ref[0], 'n1_file': ref[2], 'same_build': ref[1]}
+
+
+def preflight_or_exit(world):
+  """before ANY GPU call of a multi-rank run: devices, shared memory for the experience rings of the
+  one-replay layout, host cores -- distributed.preflight; one sentence and a non-zero exit otherwise"""
+  from model_based_rl_amd import distributed as D
+  ram = '-ram' in WNAME
+  rec = ((O + 3) // 4 if ram else O) + A + 10
+  shared = os.environ.get('MZ_BENCH_BACKEND', 'nccl') == 'gloo' or os.environ.get('MZ_SHARED_GPU_OK', '0')[:1] == '1'
+  need = int(os.environ.get('MZ_PREFLIGHT_SHM_NEED', '0')) or D.ring_bytes(world, CHUNK, B, rec)      # (MZ_PREFLIGHT_SHM_NEED: tests)
+  return D.preflight(world, shm_need=need, ingest_threads=ingest_threads_for(world, one_replay_rank0=True) if world > 1 else 0,
+                     shared_gpu_ok=shared)
+
+
 def bench_config(workload_name, envs, sims, episode_len, world, sync_every, ingest_threads, split_f16=False, run_tag='bench'):
   """The run's Config, from the flags `python -m model_based_rl_amd.train` takes (reference config.py:87-231 names): what
   Actor / PrioritizedReplay / SharedStorage are constructed from below, exactly as train.launch constructs them."""
@@ -348,6 +407,9 @@ def main():
   ap.add_argument('--ingest-threads', type=int, default=None, help='ingest threads per replay (default: from usable cores / ranks)')
   ap.add_argument('--no-live-traffic', action='store_true',
                   help='do not measure roofline.traffic with two rocprofv3 --pmc child runs (N = 1 only; ~20 s)')
+  ap.add_argument('--batch', default=None,
+                  help='--workload learner: batch sizes of the sweep, comma separated (default 256,512,1024,2048,4096; the line\'s `value` '
+                       'stays the first one -- 256 = the reference\'s batch_size): updates/s, samples/s, roofline.frac and host us per update each')
   ap.add_argument('--dump-records', default=None,
                   help='(tests) save this rank\'s experience records of the first moves after reset to <path>.rank<r>.npy')
   args = ap.parse_args()
@@ -361,12 +423,14 @@ def main():
     import bench_learner           # secondary line: the learner step in Learner.learn's loop
     return bench_learner.main(args)
   if args.gpus > 1 and 'RANK' not in os.environ:
+    preflight_or_exit(args.gpus)   # (before the ranks exist: one sentence instead of N tracebacks)
     return self_launch(args)       # one process per GPU, started from here (before anything touches the GPU)
   chunk = max(1, args.chunk)
   child = bool(os.environ.get('MZ_BENCH_CHILD'))     # a PMC pass of live_traffic(): every launch must play `chunk` moves
 
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
+  preflight = preflight_or_exit(world) if world > 1 else None      # every rank, before it touches its GPU (launcher-started runs)
   # roofline.traffic, live: the two PMC passes run as child processes before this process initialises the GPU
   measured_traffic = None
   if world == 1 and 'RANK' not in os.environ and not args.no_live_traffic and not args.envs:
@@ -517,7 +581,12 @@ def main():
       dt = time.perf_counter() - t0
       busy = (time.process_time() - c0) / dt      # CPU seconds of this rank (all its threads) per wall second
       frames = layout.frames() - frames0
+      per_rank = [(float(frames), dt)]
       if dist is not None:
+        mine = torch.tensor([frames, dt], dtype=torch.float64, device=ctrl_dev)
+        every_r = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every_r, mine, group=ctrl)
+        per_rank = [(float(x[0]), float(x[1])) for x in every_r]      # each rank's own frames and its own clock
         tt = torch.tensor([dt, busy], dtype=torch.float64, device=ctrl_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=ctrl)
         dt, busy_max = float(tt[0].item()), float(tt[1].item())
@@ -526,7 +595,7 @@ def main():
         frames, busy_sum = float(ff[0].item()), float(ff[1].item())
       else:
         busy_max = busy_sum = busy
-      runs.append((frames, dt, busy, busy_max, busy_sum))
+      runs.append((frames, dt, busy, busy_max, busy_sum, per_rank))
     return runs
 
   OS = (O + 3) // 4 if ram else O
@@ -594,6 +663,21 @@ def main():
   env_steps = world * B * total            # env.step() calls in the timed regions, all ranks
   run_values = [r[0] / r[1] for r in runs]
   flat = rstorage.flat if dist is not None else None
+  # per rank: the frames its own replay accepted over its own clock (the per-rank-replay layout: a slow rank shows here)
+  per_rank_values = [sum(r[5][k][0] for r in runs) / max(1e-9, sum(r[5][k][1] for r in runs)) for k in range(world)]
+  coll_stats = None
+  if dist is not None:
+    torch.cuda.synchronize(device)
+    mine = rstorage.collective_stats()
+    every_c = [None] * world
+    dist.all_gather_object(every_c, mine, group=ctrl)
+    us = [c['broadcast_us'] for c in every_c if c and c.get('broadcast_us')]
+    coll_stats = {'ranks_in_comm': mine['ranks_in_comm'], 'fallback_reason': next((c['fallback_reason'] for c in every_c if c and c['fallback_reason']), None),
+                  'native_rccl_broadcast': all(bool(c and c['native_rccl_broadcast']) for c in every_c), 'broadcasts': mine['broadcasts'],
+                  'broadcast_us': {'mean': float(np.mean([u['mean'] for u in us])), 'max': float(np.max([u['max'] for u in us])),
+                                   'per_rank_mean': [c['broadcast_us']['mean'] if c and c.get('broadcast_us') else None for c in every_c],
+                                   'clock': 'HIP events around mz_broadcast_weights on the side stream' if mine['native_rccl_broadcast']
+                                            else 'host wall time of torch.distributed.broadcast (fallback path)'} if us else None}
 
   # dominant kernel = k_search_fused (one launch = all simulations of all trees of this rank + the end of the move:
   # descent, f32-MFMA dynamics + prediction, expand, backup, action/record).  Its duration is measured live with HIP
@@ -700,8 +784,14 @@ def main():
         'host_cores_busy_per_rank': host_cores_busy, 'host_cores_busy_max_rank': host_cores_busy_max,
         'host_cores_busy_all_ranks': host_cores_busy_sum, 'shards_env_ids': shards,
         'usable_host_cores': _usable_cores(), 'ingest_threads_per_rank': layout.n_ingest,
+        'build_id': build_id(), 'preflight': preflight,
+        'per_rank_values': per_rank_values,
+        'efficiency_vs_n1': efficiency_vs_n1(frames / dt, world, one_replay),
         'collectives': {'backend': backend, 'world': world, 'forced_at_world_1': bool(force_dist and world == 1),
                         'rccl_mapped': rccl_mapped(), 'weights_on_device': bool(flat.is_cuda),
+                        'ranks_in_comm': coll_stats['ranks_in_comm'], 'fallback_reason': coll_stats['fallback_reason'],
+                        'native_rccl_broadcast': coll_stats['native_rccl_broadcast'], 'broadcasts': coll_stats['broadcasts'],
+                        'broadcast_us': coll_stats['broadcast_us'],
                         'broadcast': 'mz_broadcast_weights: ncclBroadcast from libmz_hip.so on a side stream, step / games / scale_ok over a gloo group'
                                      if getattr(rstorage, 'native', False) else 'torch.distributed.broadcast + all_gather',
                         'what': 'broadcast of the flat f32 weights (%d floats) per pull, MAX / SUM all-reduces of the timing, '

@@ -25,6 +25,46 @@ def step_flop(bs, K, O, A, Sv, Sr, H=50, F=512):
   return 3 * bs * fwd
 
 
+def sweep_point(bs, updates, runs=3):
+  """one batch size of the sweep, through the product's loop: Learner.launch(updates) on the handles train.launch builds (native step
+  + native loop); GPU time per update from HIP events around 100+ updates of mz_fcl_run; host microseconds per update inside the call"""
+  from model_based_rl_amd import rayshim as ray
+  cfg, storage, replay, learner = setup(['--batch_size', str(bs)])
+  ray.get(learner.launch.remote(30))
+  vals = []
+  for _ in range(max(1, runs)):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ray.get(learner.launch.remote(updates))
+    torch.cuda.synchronize()
+    vals.append(updates / (time.perf_counter() - t0))
+  lrn = learner._obj
+  assert lrn._native is not None and getattr(lrn, 'native_loop_updates', 0), 'the sweep measures the native step and loop'
+  rep = getattr(replay, '_obj', replay)
+  lrn.flush_priorities()
+  n_ev = max(100, min(300, updates))
+  f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  torch.cuda.synchronize(); f0.record()
+  lrn._native.run(rep, n_ev)
+  lrn._native.flush()
+  f1.record(); torch.cuda.synchronize()
+  us = 1e3 * f0.elapsed_time(f1) / n_ev
+  host = lrn._native.run_stats()
+  K, A = cfg.num_unroll_steps, cfg.action_space
+  O = int(np.prod(cfg.obs_space))
+  Sv, Sr = cfg.value_support_max - cfg.value_support_min + 1, cfg.reward_support_max - cfg.reward_support_min + 1
+  flop = step_flop(bs, K, O, A, Sv, Sr)
+  v = np.array(vals)
+  point = {'batch': bs, 'updates_per_s': float(v.mean()), 'std': float(v.std()), 'samples_per_s': float(v.mean()) * bs, 'timed_updates': updates,
+           'us_per_update_gpu': us, 'frac': flop / (us * 1e-6) / 1e12 / F32_MFMA_TFLOPS,
+           'frac_of_wall': flop * float(v.mean()) / 1e12 / F32_MFMA_TFLOPS, 'flop_per_update': flop,
+           'host_us_per_update': {k: host[k] for k in ('sample_us', 'refresh_us', 'launch_us', 'wait_us', 'call_us')},
+           'replay_sampling_threads': int(getattr(rep, 'ingest_threads', 0) or 0)}
+  if lrn._native is not None:
+    lrn._native.close()
+  return point
+
+
 def setup(extra, updates_hint=1000):
   """storage, replay and learner behind actor handles, wired as train.launch wires them (reference train.py:62-78); the replay is
   filled by the product's own Actor (1024 environments, 128 moves of the device loop) before the learner starts"""
@@ -130,5 +170,13 @@ def main(args):
                                'at a time (pinned staging + two copies)'},
           'torch_graph': {k: out['torch_graph'][k] for k in ('updates_per_second', 'std', 'gpu_ms_per_update')},
           'secondary': True}
+  # the batch sweep: the same loop at batch 256 ... 4096 -- updates/s, samples/s, roofline fraction (GPU time
+  # per update on HIP events), host microseconds per update (sampling runs on the replay's thread pool from batch 512 up)
+  if not os.environ.get('MZ_LEARNER_NO_SWEEP'):
+    batches = [int(x) for x in (getattr(args, 'batch', None) or '256,512,1024,2048,4096').split(',')]
+    with contextlib.redirect_stdout(sys.stderr):
+      line['batch_sweep'] = [sweep_point(b, max(200, min(updates, updates * 512 // b)), runs=min(3, max(1, args.runs))) for b in batches]
+    line['batch_sweep_what'] = ('Learner.launch(n) per point on the handles train.launch builds; frac = algorithmic FLOP / (HIP-event time per update '
+                                'of mz_fcl_run) / %.1f TFLOP/s; frac_of_wall = the same with the wall-clock rate' % F32_MFMA_TFLOPS)
   print(json.dumps(line), flush=True)
   return 0

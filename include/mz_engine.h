@@ -120,6 +120,8 @@ int mz_comm_load(const char *librccl_path);
 int mz_comm_unique_id(void *out128);
 int mz_comm_create(int rank, int world, const void *unique_id128, mz_comm **out);
 int mz_comm_destroy(mz_comm *c);
+/* ranks the communicator spans, as RCCL reports it (ncclCommCount) */
+int mz_comm_count(const mz_comm *c, int *ranks_out);
 int mz_broadcast_weights(mz_comm *c, float *flat, size_t n, int root, void *stream);
 
 /* Diagnostic: how the last mz_set_weights packed the search kernel's weight stream.  out [host][4] =
@@ -168,24 +170,8 @@ int mz_last_paths(mz_engine *e, int32_t *paths, int32_t *lengths, void *stream);
  * no host synchronisation. */
 int mz_search(mz_engine *e, int num_simulations, void *stream);
 
-/* Diagnostic twin of mz_search (call right after mz_root_prepare): the same launches, eagerly, with a
- * hipEvent between every pair of launches on `stream`; synchronous.  ms_out[0] = summed time of the
- * num_simulations recurrent-inference launches, ms_out[1] = summed time of the tree-step launches. */
-int mz_search_profiled(mz_engine *e, int num_simulations, float *ms_out, void *stream);
 
-/* mz_search with HIP events bracketing the dispatch of the fused search kernel itself (hipExtLaunchKernelGGL start /
- * stop events on `stream`, the same timestamps rocprofv3's kernel trace reports); call right after mz_root_prepare;
- * synchronous.  ms_out[0] = duration of the launch in milliseconds.  bench.py's roofline figure comes from here. */
-int mz_search_timed(mz_engine *e, int num_simulations, float *ms_out, void *stream);
 
-/* Diagnostic build of the fused search kernel with in-kernel s_memtime stamps (never used for timing
- * claims): cycles_out [host][4 waves][14 phases] = per-wave cycle totals over num_simulations, averaged
- * over workgroups.  Phases: 0 gather, 1 barrier, 2 dynamics fc1, 3 dynamics fc2, 4 combine, 5 LN/reward,
- * 6 store + prediction fc1, 7 prediction fc2, 8 combine, 9 value/logits, 10 expand, 11 backup, 12 descent, 13 rest of the tree step. */
-int mz_search_phase_profile(mz_engine *e, int num_simulations, unsigned long long *cycles_out, void *stream);
-/* of the last mz_search_phase_profile: out3 [host] = mean, minimum, maximum over the workgroups of a workgroup's total
- * cycles (the launch lasts as long as its slowest workgroup) */
-int mz_search_phase_spread(const mz_engine *e, double *out3);
 
 /* The same loop opened up for an external network (MuZeroNetwork/TinyNetwork through PyTorch, or
  * recorded outputs in the parity tests):
@@ -197,13 +183,6 @@ int mz_search_phase_spread(const mz_engine *e, double *out3);
 int mz_select(mz_engine *e, int32_t *leaf_node, int32_t *parent_slot, int32_t *action, int32_t *depth,
               void *stream);
 int mz_gather_hidden(mz_engine *e, float *hidden_out, void *stream);
-/* One simulation's tree work with a clock on each kernel: mz_select (no outputs) + mz_expand_backup (no hidden state),
- * hipExtLaunchKernelGGL start / stop events around each of the two dispatches (the timestamps rocprofv3's kernel trace
- * reports); synchronous.  ms_out [host][2] = duration of k_tree_select (-1 where the descent was already pending: the
- * first simulation after mz_root_prepare, which selects inside the root kernel), of k_tree_expand_backup, in milliseconds.
- * The roofline clock of `bench.py --workload tree` (the tree kernels against HBM / cache bandwidth). */
-int mz_tree_pair_timed(mz_engine *e, const float *value, const float *reward, const float *logits, float *ms_out,
-                       void *stream);
 int mz_expand_backup(mz_engine *e, const float *value, const float *reward, const float *logits,
                      const float *hidden, void *stream);
 /* mz_expand_backup followed by the next simulation's mz_select (mcts.py:97-99 then 83-94 of the next iteration) in ONE launch:
@@ -298,30 +277,6 @@ int mz_selfplay_set_draws(mz_engine *e, const double *noise, const double *unifo
  * (actors.py:55-58,134-137): the network input is (obs - obs_min) / obs_range in float32, the record keeps the raw
  * observation (the learner normalises its own batches, learners.py:167-168). */
 int mz_selfplay_set_obs(mz_engine *e, int uint8_obs, const float *obs_min, const float *obs_range);
-/* keep != 0: every move of the self-play loop also writes its searched tree back to the node pool (so that
- * mz_export_tree after mz_selfplay_steps shows the last move's tree).  Default 0: the loop never reads it. */
-int mz_selfplay_export_trees(mz_engine *e, int keep);
-/* keep != 0: every move also stores its Dirichlet draw (mcts.py:59; drawn on the device in this loop) in a per-move log
- * as long as the experience ring; mz_selfplay_read_noise copies the draw of move `move` (0 = first move after
- * mz_selfplay_reset, one of the last ring_moves moves) to out [host][B][A] float64, synchronously.  Test
- * instrumentation: any move of a whole-moves launch can be replayed on the CPU by the parity tests with the device's own draw
- * and the observation its record carries. */
-int mz_selfplay_noise_log(mz_engine *e, int keep);
-int mz_selfplay_read_noise(mz_engine *e, uint64_t move, double *out);
-/* Test instrumentation of the fused search kernels' TREE code (the launch mz_search and mz_selfplay_steps run; the
- * stand-alone kernels get their network outputs through mz_expand_backup anyway).  The tree step of a simulation --
- * Node.expand, MCTS.backpropagate, the next select_child descent: mcts.py:47-55,83-92,104-143 -- consumes exactly three
- * things from the network: the value and reward scalars (networks.py:153-154,161-162) and the A policy logits.
- * buf [dev][keep_moves][num_envs][num_simulations + 1][2 + A] float32 is the caller's and must outlive the mode.
- *   mode 1, log:    every simulation s of every tree stores (value, reward, logits[A]) in slot 1 + s of row
- *                   (move % keep_moves, tree); the root of a self-play move stores (value, 0, logits[A]) in slot 0;
- *                   mz_search uses row 0.  The parity tests replay the logged outputs through the CPU oracle's tree and
- *                   demand every tree identical -- no network evaluation on the checker's side, hence no tie margin.
- *   mode 2, inject: mz_search's simulations READ slot 1 + s (row 0, keep_moves = 1) instead of their own network
- *                   outputs: the reference's recorded outputs (tests/golden) reach the fused kernels' own tree code.
- *   mode 0, off:    the production state (a null pointer in the kernels' arguments; buf ignored).
- * Synchronous; drops captured graphs. */
-int mz_sim_io(mz_engine *e, int mode, float *buf, int keep_moves);
 /* The elementwise ends of the learner step (reference learners.py:164-230) as single launches -- the step is launch-bound,
  * and PyTorch spells these as ~45 (targets) and ~11 (each categorical loss) tiny kernels.  Engine-free: device pointers,
  * sizes, a stream; capturable into a graph (no synchronisation, no allocation).
@@ -404,25 +359,8 @@ int mz_fcl_run(mz_fcl *c, const mz_fcl_source *src, int n_updates, const uint32_
                double *beta_inout, const float *obs_min, const float *obs_range, double beta1, double beta2, double eps,
                double weight_decay, double clip_grad, int adamw, const float *lrs, double *loss_sums, void *stream,
                int64_t *pads_out, uint32_t *py_key, int32_t *py_pos);
-/* development hook: mz_fcl_run's host time since the handle was created (or the last reset): out [host][6] = seconds waiting for
- * a staging slot's previous update, in priority refreshes, in sampling, in launching, in the calls as a whole; number of updates */
-int mz_fcl_run_stats(mz_fcl *c, double *out6, int reset);
 /* staging slots of this handle: how many updates mz_fcl_update / mz_fcl_run keep in flight before they wait for the oldest */
 int mz_fcl_slots(mz_fcl *c);
-int mz_fcl_read_grad(mz_fcl *c, float *host_out, size_t n);
-/* test hook: tape `which` of the last step into a HOST buffer (0 chain inputs, 1 chain fc1 activations, 2 LayerNorm x-hat, 3 rstd,
- * 4 hidden states, 5 / 6 chain deltas, 7 head fc1 activations, 8 / 9 head deltas, 10 d loss / d hidden state per head, 11 per-sample
- * losses; [position][row / 16][feature][16 rows] each, heads [head][position]...); host_out null: returns the float count. */
-long long mz_fcl_read_tape(mz_fcl *c, int which, float *host_out, size_t n);
-/* development hook: s_memtime stamps (shader clock) at the phase boundaries of k_fcl_heads, workgroup 0 of every head at unroll
- * position 1 (3 x 16 slots), and of k_fcl_chain_fwd4's position 2 (slots 48..53): enable = 1 arms it for the following steps,
- * enable = 0 reads the stamps of the last step into host_out [64]. */
-int mz_fcl_heads_profile(mz_fcl *c, int enable, unsigned long long *host_out);
-/* Which kernel mz_search / mz_selfplay_steps launch for this engine right now: out4 [host] = kind (0 the stand-alone
- * kernels, 1 k_search_fused, 2 k_search_h2), LDS placement of the trees (0 node pool, 1 whole trees in LDS, 2 compact in
- * LDS; -1 for kind 0), dynamics-fc1 k-steps of the instantiation, lanes per child group.  For tests: they assert the
- * instantiation they mean to exercise. */
-int mz_search_kernel_info(const mz_engine *e, int *out4);
 int mz_selfplay_steps(mz_engine *e, int moves, void *stream);
 /* mz_selfplay_steps with the records written straight into host_records [host, PAGE-LOCKED: hipHostMalloc /
  * torch pin_memory][moves][B][rec_floats] by the kernels' own stores through the buffer's device mapping (0.6 GB/s of
@@ -433,27 +371,12 @@ int mz_selfplay_steps(mz_engine *e, int moves, void *stream);
  * runtime to track -- that dependency kept a runtime thread of every rank spinning (profiles/r05_host_threads.txt).
  * Fails when host_records is not page-locked. */
 int mz_selfplay_steps_into(mz_engine *e, int moves, float *host_records, void *stream);
-/* mz_selfplay_steps with one pair of HIP events around every search-kernel dispatch (hipExtLaunchKernelGGL start / stop
- * events on `stream`: the timestamps rocprofv3's kernel trace reports).  The k moves are launched eagerly, back to back,
- * with no synchronisation in between (the state of the timed loop); synchronous at the end.  ms_out [host][k] =
- * duration of each search launch in milliseconds.  bench.py's roofline figure is the mean of these. */
-int mz_selfplay_steps_timed(mz_engine *e, int k, float *ms_out, void *stream);
-/* Diagnostic: `moves` (<= 16) whole moves in ONE launch of the persistent self-play kernel with s_memtime stamps between
- * the phases of a move; cycles_out [host][8] = shader cycles per move, mean over all waves, in the order of a move:
- * root first stage (observation, obs_dim+1 -> 512), representation out + LayerNorm, prediction, root tree part (Dirichlet
- * draw, root.expand, first descent), resident weight steps + tree set-up, ring priming + barrier, all simulations, end of
- * the move (select_action, env step, record).  Synchronous; the moves' records land in the ring like any others.
- * Exact-f32 kernel only; fails where the self-play loop does not run as whole moves in one launch (two-player games,
- * trees in the global pool, MZ_NO_PERSIST) and for split_f16. */
-int mz_selfplay_phase_profile(mz_engine *e, int moves, double *cycles_out, void *stream);
 /* 16 where mz_selfplay_steps plays whole moves inside one launch of the search kernel (at most that many per launch),
  * 0 where a move is a hipGraph node pair (root kernel, search kernel). */
 int mz_selfplay_moves_per_launch(const mz_engine *e);
 int mz_selfplay_rec_floats(const mz_engine *e);
 int mz_selfplay_ring_moves(const mz_engine *e);
 int mz_selfplay_drain(mz_engine *e, float *out, int max_moves, int *n_moves, void *stream);
-/* observation the synthetic env would emit for (env, episode, t): [host] out[obs_dim]; and reward */
-int mz_synth_obs(const mz_engine *e, int env, int episode, int t, float *out_obs, float *out_reward);
 
 #ifdef __cplusplus
 }

@@ -11,6 +11,7 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 _SO = os.environ.get('MZ_HIP_LIB') or os.path.join(_CSRC, 'libmz_hip.so')      # (MZ_HIP_LIB: A/B runs of two builds on one box)
 _SOURCES = ['mz_engine.hip', 'mz_comm.inc', 'mz_learner.hip.h', 'mz_fcl.hip.h', 'mz_fcl_abi.inc', 'mz_inst.hip', 'mz_kernels.inc', 'mz_common.h', 'mz_net.hip.h', 'mz_tree.hip.h', 'mz_rng.h',
             'mz_selfplay.hip.h', 'mz_selfplay_abi.inc', 'mz_fused.hip.h', 'mz_root.hip.h', 'mz_fused_h2.hip.h']
+_ENGINE_ONLY = ('mz_engine.hip', 'mz_comm.inc', 'mz_learner.hip.h', 'mz_fcl.hip.h', 'mz_fcl_abi.inc', 'mz_selfplay_abi.inc')      # included by mz_engine.hip alone
 _lib = None
 
 HIPCC_FLAGS = ['-O3', '--offload-arch=gfx950', '-ffp-contract=off', '-std=c++17', '-fPIC', '-Wno-unused-value',
@@ -54,8 +55,8 @@ def stale():
   if not os.path.exists(_SO):
     return True
   t = os.path.getmtime(_SO)
-  inc = os.path.join(_CSRC, '..', '..', 'include', 'mz_engine.h')
-  srcs = [os.path.join(_CSRC, s) for s in _SOURCES] + [inc]
+  inc = [os.path.join(_CSRC, '..', '..', 'include', h) for h in ('mz_engine.h', 'mz_engine_debug.h')]
+  srcs = [os.path.join(_CSRC, s) for s in _SOURCES] + inc
   return any(os.path.exists(s) and os.path.getmtime(s) > t for s in srcs)
 
 
@@ -75,9 +76,20 @@ def build(force=False, verbose=False, out=None, extra=None, jobs=None):
     name, src, defs = unit
     obj = os.path.join(objdir, name + '.o')
     cmd = ['hipcc'] + HIPCC_FLAGS + extra + defs + ['-c', src, '-o', obj]
+    # an object is kept when its command line is unchanged and none of the sources its unit includes is newer (the search
+    # kernels' units do not include the learner / host-side files: a learner edit recompiles one unit, not thirteen)
+    deps = [s for s in _SOURCES if src == 'mz_engine.hip' or s not in _ENGINE_ONLY]
+    deps = deps + [os.path.join('..', '..', 'include', h) for h in (('mz_engine.h', 'mz_engine_debug.h') if src == 'mz_engine.hip' else ('mz_engine.h',))]
+    stamp = obj + '.cmd'
+    if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == ' '.join(cmd):
+      t = os.path.getmtime(obj)
+      if all(not os.path.exists(os.path.join(_CSRC, d)) or os.path.getmtime(os.path.join(_CSRC, d)) <= t for d in deps):
+        return obj
     if verbose:
       print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd, cwd=_CSRC)
+    with open(stamp, 'w') as f:
+      f.write(' '.join(cmd))
     return obj
   units = translation_units(extra)
   with ThreadPoolExecutor(max_workers=jobs or min(len(units), os.cpu_count() or 1)) as pool:
@@ -104,6 +116,7 @@ SIGNATURES = {
     'mz_comm_unique_id': (_I, [_VP]),
     'mz_comm_create': (_I, [_I, _I, _VP, C.POINTER(_VP)]),
     'mz_comm_destroy': (_I, [_VP]),
+    'mz_comm_count': (_I, [_VP, C.POINTER(_I)]),
     'mz_broadcast_weights': (_I, [_VP, _VP, _SZ, _I, _VP]),
     'mz_initial_inference': (_I, [_VP, _VP, _VP]),
     'mz_weight_scale': (_I, [_VP, _VP, _VP]),
@@ -181,7 +194,12 @@ def load():
                        'g.build()"`; this engine has no CPU fallback.' % _SO)
   lib = C.CDLL(_SO)
   for name, (res, args) in SIGNATURES.items():
-    fn = getattr(lib, name)      # AttributeError if the library does not export a declared symbol
+    try:
+      fn = getattr(lib, name)    # AttributeError if the library does not export a declared symbol
+    except AttributeError:
+      if os.environ.get('MZ_HIP_LIB') and os.environ.get('MZ_HIP_LIB_OLD', '0')[:1] == '1':
+        continue                 # (kernel development: an A/B build of an OLDER tree lacks entry points added since)
+      raise
     fn.restype, fn.argtypes = res, args
   _lib = lib
   return lib

@@ -9,7 +9,7 @@ environment per Ray actor process).  Two paths:
   * host environments (TicTacToe, or any gym-0.x style env): the per-move body is driven from Python,
     batched over the actor's games; with `config.parity_rng` the Dirichlet noise and the action samples
     come from numpy's global stream in the reference's order, which makes a one-environment actor
-    reproduce the reference's games move for move (tests/test_actor_parity.py).
+    reproduce the reference's games move for move (tests/test_gpu_actor.py::test_actor_reproduces_reference_games).
 """
 import random
 import time

@@ -135,6 +135,9 @@ def build_parser():
   a('--actor_log_frequency', type=int, default=1)
   a('--selfplay_chunk', type=int, default=None,
     help='moves per launch / drain / ingest chunk of the device self-play loop (default 16: one launch of the persistent search kernel)')
+  a('--no_gpu_turns', action='store_true',
+    help='do NOT let an actor and the learner of one process take turns on a GPU they share (train.share_gpu_in_turns switches turns on '
+         'whenever both resolve to the same device; this flag is for measuring what the turns are worth)')
   a('--gpu_turns', action='store_true',
     help='an actor and a learner of this process share ONE GPU: they take turns, one chunk of moves / one update at a time (gpu_turns.py)')
   a('--gpu_turn_updates', type=int, default=8,

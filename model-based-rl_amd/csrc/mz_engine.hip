@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../include/mz_engine.h"
+#include "../../include/mz_engine_debug.h"      // instrumentation / test hooks (not the boundary)
 
 #define MZ_MAX_ACTIONS_K MZ_MAX_ACTIONS
 #include "mz_common.h"

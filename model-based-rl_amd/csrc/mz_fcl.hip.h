@@ -51,6 +51,7 @@ struct FclView {
   float *a1h, *d2h, *d1h, *dH, *lossb;                 // head tapes, [3][K + 1][...][R]
   float *lnpart;                                        // [bs / 4][128] LayerNorm weight / bias gradient partials (per chain workgroup)
   float *new_errors;
+  float *steps; int nsteps;      // the optimiser's per-parameter step counters (torch keeps one per parameter), advanced by k_fcl_heads; nsteps = 0: not this step
   unsigned long long *prof;      // development: s_memtime stamps of k_fcl_heads' phases (workgroup 0 of every head at position 1), else null
 };
 
@@ -245,13 +246,10 @@ __device__ __forceinline__ float fcl_sum32(float x) {
   x += fcl_xchg<1>(x); x += fcl_xchg<2>(x); x += fcl_xchg<4>(x); x += fcl_xchg<8>(x);
   return x + __shfl_xor(x, 16, 32);
 }
-// sum over the 16 lanes of a wave that share lane & 3 (the chain kernels' sample j): lane bits 2..5 -- two row rotations
-// (DPP row_ror:4, row_ror:8: the four lanes of a 16-lane row with the same lane & 3), then the rows by shuffle
-__device__ __forceinline__ float fcl_sum_bits2to5(float x) {
-  x += __int_as_float(mz_dpp_i<0x124>(__float_as_int(x)));
-  x += __int_as_float(mz_dpp_i<0x128>(__float_as_int(x)));
-  x += __shfl_xor(x, 16, 64);
-  return x + __shfl_xor(x, 32, 64);
+// sum over the 16 lanes of a DPP row (no LDS round trip); every lane of the row ends with the same bits
+__device__ __forceinline__ float fcl_sum16(float x) {
+  x += fcl_xchg<1>(x); x += fcl_xchg<2>(x); x += fcl_xchg<4>(x); x += fcl_xchg<8>(x);
+  return x;
 }
 __device__ __forceinline__ float fcl_max32(float x) {
   x = fmaxf(x, fcl_xchg<1>(x)); x = fmaxf(x, fcl_xchg<2>(x)); x = fmaxf(x, fcl_xchg<4>(x)); x = fmaxf(x, fcl_xchg<8>(x));
@@ -266,6 +264,8 @@ __global__ __launch_bounds__(FCL_THREADS, 4) void k_fcl_heads(FclView v) {
   f32x4 *red = (f32x4 *)redf;
   const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, g4 = lane >> 4, m16 = lane & 15;
   const int row0 = blockIdx.x * 16, p = blockIdx.y, hd = blockIdx.z, R = v.R, K1 = v.K + 1, loff = fcl_lane_off(lane), cb = blockIdx.x;
+  // (the step counters advance here, two launches ahead of the optimiser code that reads them)
+  if (blockIdx.x == 0 && p == 0 && hd == 0 && tid < v.nsteps) v.steps[tid] += 1.f;
   if (hd == 2 && p == 0) return;
   int stamp_i = 0;
 #define FCL_STAMP() if (v.prof && blockIdx.x == 0 && p == 1 && tid == 0) v.prof[hd * 16 + stamp_i++] = __builtin_amdgcn_s_memtime();
@@ -276,15 +276,18 @@ __global__ __launch_bounds__(FCL_THREADS, 4) void k_fcl_heads(FclView v) {
   // the layers' weights pass through ONE set of 16 registers per lane, each layer's requested as soon as the previous
   // layer's products have been issued (the compiler barriers keep the requests from being hoisted above those products,
   // which would need a second register set: 128 registers is what two workgroups per CU leave); fc1's now
+  // (loads return in order: the inputs the first barrier waits for are requested BEFORE fc1's weights -- r05 requested the
+  // weights first and every workgroup's first barrier waited for all 128 KB of them)
   f32x4 WA[16];
-  fcl_req_wide(WA, (const f32x4 *)(v.pk + pk.F1), pk.ks1, w, lane);
   const float *src = hd == 2 ? v.xin + (size_t)p * TX : v.h + (size_t)p * T64;
-  for (int idx = tid; idx < 64 * 16; idx += FCL_THREADS) {
-    const int f = idx >> 4, n = idx & 15;
-    X[fcl_at(f, n)] = src[fcl_tp(hd == 2 ? v.XR : 64, cb, f, n)];
+  float xs_in[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int idx = tid + k * FCL_THREADS;
+    xs_in[k] = src[fcl_tp(hd == 2 ? v.XR : 64, cb, idx >> 4, idx & 15)];
   }
-  PV[tid] = v.P[v.hb1[hd] + tid];
-  if (tid < 64) PV[512 + tid] = tid < pk.mout ? v.P[v.hb2[hd] + tid] : 0.f;
+  const float pv1 = v.P[v.hb1[hd] + tid];
+  const float pv2 = (tid < 64 && tid < pk.mout) ? v.P[v.hb2[hd] + tid] : 0.f;
   // this sample's targets and weight: needed after the two forward layers, requested now
   const int n_s = tid >> 5, q_s = tid & 31, row_s = row0 + n_s, M = pk.mout;
   const bool in0 = q_s < M, in1 = q_s + 32 < M;
@@ -297,6 +300,16 @@ __global__ __launch_bounds__(FCL_THREADS, 4) void k_fcl_heads(FclView v) {
   }
   const double wb = v.w_f64 ? ((const double *)v.w)[row_s] : (double)((const float *)v.w)[row_s];
   const float tv0 = v.t_val[(size_t)row_s * K1];
+  asm volatile("" ::: "memory");
+  fcl_req_wide(WA, (const f32x4 *)(v.pk + pk.F1), pk.ks1, w, lane);
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int idx = tid + k * FCL_THREADS;
+    X[fcl_at(idx >> 4, idx & 15)] = xs_in[k];
+  }
+  PV[tid] = pv1;
+  if (tid < 64) PV[512 + tid] = pv2;
   fcl_bar();
   FCL_STAMP()      // 1: inputs in LDS
   f32x4 acc[4];
@@ -467,26 +480,47 @@ __global__ __launch_bounds__(FCL_THREADS) void k_fcl_chain_fwd4(FclView v) {
   const size_t T64 = (size_t)64 * R, T512 = (size_t)512 * R, TX = (size_t)v.XR * R;
 #define FCL_KSTAMP(k) if (v.prof && blockIdx.x == 0 && tid == 0) v.prof[54 + (k)] = __builtin_amdgcn_s_memtime();
   FCL_KSTAMP(0)      // kernel start
-  float WT1[KP], WT2[64];
-  fcl_quad_load<KP>(WT1, v.pk + v.tr.F1 + (size_t)w * KP * 64, lane);
-  fcl_quad_load<64>(WT2, v.pk + v.tr.F2 + (size_t)w * 64 * 64, lane);
-  b1r[tid] = v.P[v.rep_b1 + tid]; b1t[tid] = v.P[v.tr_b1 + tid];
-  if (tid < 64) {
-    b2r[tid] = tid < MZ_H ? v.P[v.rep_b2 + tid] : 0.f; b2t[tid] = tid < MZ_H ? v.P[v.tr_b2 + tid] : 0.f;
-    lnw[tid] = tid < MZ_H ? v.P[v.ln_w + tid] : 0.f; lnb[tid] = tid < MZ_H ? v.P[v.ln_b + tid] : 0.f;
-  }
-  if (tid < 32) {
-    const size_t ai = (size_t)(row0 + (tid >> 3)) * v.K + (tid & 7);
-    acts[tid] = (tid & 7) < v.K ? (v.act_i32 ? ((const int32_t *)v.act)[ai] : (int)((const int64_t *)v.act)[ai]) : -1;
-  }
-  for (int idx = tid; idx < v.xq * 4; idx += FCL_THREADS) {
-    const int f = idx >> 2, n = idx & 3;
-    const float val = f < v.O ? v.obs[(size_t)(row0 + n) * v.O + f] : 0.f;
-    X[n * LDX + f] = val;
-    if (f < v.XR) v.xin[fcl_tp(v.XR, cb, f, n0 + n)] = val;
+  // Loads return in order: what position 0 needs -- the small parameter vectors, the observations, the representation's
+  // fc2 weights -- is requested FIRST; the transition's resident weights (245 KB per workgroup) go out behind position 0's
+  // fc1 products and arrive under the rest of position 0 (r05 requested them first: every workgroup's first barrier waited
+  // 3.8 us for them)
+  float WT1[KP], WT2[64], WR2[64], WR1[16];
+  {
+    const float pb1r = v.P[v.rep_b1 + tid], pb1t = v.P[v.tr_b1 + tid];
+    float pb2r = 0.f, pb2t = 0.f, plnw = 0.f, plnb = 0.f;
+    if (tid < MZ_H) { pb2r = v.P[v.rep_b2 + tid]; pb2t = v.P[v.tr_b2 + tid]; plnw = v.P[v.ln_w + tid]; plnb = v.P[v.ln_b + tid]; }
+    int pact = -1;
+    if (tid < 32 && (tid & 7) < v.K) {
+      const size_t ai = (size_t)(row0 + (tid >> 3)) * v.K + (tid & 7);
+      pact = v.act_i32 ? ((const int32_t *)v.act)[ai] : (int)((const int64_t *)v.act)[ai];
+    }
+    const int f_0 = tid >> 2, n_0 = tid & 3;
+    const float ob0 = (tid < v.xq * 4 && f_0 < v.O) ? v.obs[(size_t)(row0 + n_0) * v.O + f_0] : 0.f;
+    // up to 16 observation features (LunarLander 8, TicTacToe 9): the representation's fc1 weights ride with these small reads, so that
+    // position 0's fc1 products start behind ONE round trip (streamed, their loads queue behind WR2's 128 KB)
+    if (v.O <= 16) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) WR1[k] = k < v.O ? (v.pk + v.rep.F1 + (size_t)w * v.O * 64)[k * 64 + lane] : 0.f;
+    }
+    asm volatile("" ::: "memory");
+    fcl_quad_load<64>(WR2, v.pk + v.rep.F2 + (size_t)w * 64 * 64, lane);
+    asm volatile("" ::: "memory");
+    b1r[tid] = pb1r; b1t[tid] = pb1t;
+    if (tid < 64) { b2r[tid] = pb2r; b2t[tid] = pb2t; lnw[tid] = plnw; lnb[tid] = plnb; }
+    if (tid < 32) acts[tid] = pact;
+    if (tid < v.xq * 4) {
+      X[n_0 * LDX + f_0] = ob0;
+      if (f_0 < v.XR) v.xin[fcl_tp(v.XR, cb, f_0, n0 + n_0)] = ob0;
+    }
+    for (int idx = tid + FCL_THREADS; idx < v.xq * 4; idx += FCL_THREADS) {      // (more than 128 observation features)
+      const int f = idx >> 2, n = idx & 3;
+      const float val = f < v.O ? v.obs[(size_t)(row0 + n) * v.O + f] : 0.f;
+      X[n * LDX + f] = val;
+      if (f < v.XR) v.xin[fcl_tp(v.XR, cb, f, n0 + n)] = val;
+    }
   }
   fcl_bar();
-  FCL_KSTAMP(1)      // requests out, observations in LDS
+  FCL_KSTAMP(1)      // observations in LDS
   // (development: stamps of position 2's phases in workgroup 0, mz_fcl_heads_profile, slots 48..)
 #define FCL_CSTAMP(k) if (v.prof && blockIdx.x == 0 && p == 2 && tid == 0) v.prof[48 + (k)] = __builtin_amdgcn_s_memtime();
   auto rest = [&](int p, f32x4 acc, const float (&W2)[64], const float *b1, const float *b2) __attribute__((always_inline)) {
@@ -509,22 +543,23 @@ __global__ __launch_bounds__(FCL_THREADS) void k_fcl_chain_fwd4(FclView v) {
     fcl_bar();
     FCL_CSTAMP(3)      // fc2 partials + barrier
     if (w == 0) {
-      // wave 0 alone: lane (b, j) adds up rows 4 b + i of the 8 partials, then LayerNorm + ReLU (networks.py:147,165) of
-      // sample j across the 16 lanes that share it (shuffles over the lane bits 2..5), the tapes and the next input
-      // straight from registers
-      const int j = lane & 3, f0 = 4 * (lane >> 2);
+      // wave 0 alone: lane (j, b) = (lane >> 4, lane & 15) adds up rows 4 b + i of sample j of the 8 partials (written by
+      // lane 4 b + j of each wave), then LayerNorm + ReLU (networks.py:147,165) of sample j across ITS DPP ROW -- the two
+      // reductions are four DPP exchanges each, no LDS round trip (r05: lane (b, j), two ds_bpermute per reduction: this
+      // serial part was 2.0 k of a position's 5.3 k cycles) -- the tapes and the next input straight from registers
+      const int j = lane >> 4, f0 = 4 * (lane & 15);
       f32x4 y = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ww = 0; ww < FCL_NW; ++ww) y += *(const f32x4 *)(red + (ww * 64 + lane) * 4);
+      for (int ww = 0; ww < FCL_NW; ++ww) y += *(const f32x4 *)(red + (ww * 64 + f0 + j) * 4);
       float yv[4], s = 0.f;
 #pragma unroll
       for (int i = 0; i < 4; ++i) { yv[i] = (f0 + i < MZ_H) ? y[i] + b2[f0 + i] : 0.f; s += yv[i]; }
-      s = fcl_sum_bits2to5(s);
+      s = fcl_sum16(s);
       const float mean = s / (float)MZ_H;
       float d[4], var = 0.f;
 #pragma unroll
       for (int i = 0; i < 4; ++i) { d[i] = (f0 + i < MZ_H) ? yv[i] - mean : 0.f; var += d[i] * d[i]; }
-      var = fcl_sum_bits2to5(var);
+      var = fcl_sum16(var);
       const float rstd = 1.0f / sqrtf(var / (float)MZ_H + FCL_LN_EPS);
       const int act_p = acts[j * 8 + (p < 7 ? p : 7)];
       f32x4 xv4, xh4;
@@ -538,7 +573,7 @@ __global__ __launch_bounds__(FCL_THREADS) void k_fcl_chain_fwd4(FclView v) {
       }
       *(f32x4 *)(X + j * LDX + f0) = xv4;
       *(f32x4 *)(S + j * 64 + f0) = xh4;
-      if (lane < 4) misc[lane] = rstd;
+      if ((lane & 15) == 0) misc[j] = rstd;
     }
     FCL_CSTAMP(4)      // wave 0: reduce + LayerNorm
     fcl_bar();
@@ -555,10 +590,13 @@ __global__ __launch_bounds__(FCL_THREADS) void k_fcl_chain_fwd4(FclView v) {
       if (t < 4) v.rstd[(size_t)p * R + row0 + t] = misc[t];
     }
   };
-  {   // position 0: the representation, its weights streamed
-    float WR2[64];
-    fcl_quad_load<64>(WR2, v.pk + v.rep.F2 + (size_t)w * 64 * 64, lane);
-    const f32x4 acc = fcl_quad_stream(v.pk + v.rep.F1 + (size_t)w * v.O * 64, v.O, X + (lane & 3) * LDX, lane);
+  {   // position 0: the representation, its fc1 weights streamed
+    const f32x4 acc = v.O <= 16 ? fcl_quad_res<16>(WR1, X + (lane & 3) * LDX)
+                                : fcl_quad_stream(v.pk + v.rep.F1 + (size_t)w * v.O * 64, v.O, X + (lane & 3) * LDX, lane);
+    asm volatile("" ::: "memory");
+    fcl_quad_load<KP>(WT1, v.pk + v.tr.F1 + (size_t)w * KP * 64, lane);
+    fcl_quad_load<64>(WT2, v.pk + v.tr.F2 + (size_t)w * 64 * 64, lane);
+    asm volatile("" ::: "memory");
     rest(0, acc, WR2, b1r, b2r);
   }
   FCL_KSTAMP(2)      // position 0 done
@@ -574,23 +612,20 @@ __global__ __launch_bounds__(FCL_THREADS) void k_fcl_chain_fwd4(FclView v) {
 #undef FCL_KSTAMP
 }
 
-__global__ __launch_bounds__(FCL_THREADS) void k_fcl_chain_bwd4(FclView v) {
-  extern __shared__ __attribute__((aligned(16))) float fcl_smem[];
+__device__ __forceinline__ void fcl_chain_bwd4_body(const FclView &v, const int blk, float *fcl_smem) {
   const int LDX = v.xq + 4;
   float *X = fcl_smem, *A1 = X + 4 * LDX, *red = A1 + 4 * FCL_LDA, *PV = red + 2048 + 16;
   float *D2 = X;                                     // d (pre-LayerNorm output), sample-major like X (rows of >= 64 floats)
   float *lnw = PV;
   const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int cb = blockIdx.x >> 2, n0 = 4 * (blockIdx.x & 3), row0 = blockIdx.x * 4, R = v.R, K1 = v.K + 1, loff = fcl_lane_off4(lane, n0);
+  const int cb = blk >> 2, n0 = 4 * (blk & 3), row0 = blk * 4, R = v.R, K1 = v.K + 1, loff = fcl_lane_off4(lane, n0);
   const size_t T64 = (size_t)64 * R, T512 = (size_t)512 * R;
   float WB2[MZ_H], WB1[64];
-  fcl_quad_load<MZ_H>(WB2, v.pk + v.tr.B2 + (size_t)w * MZ_H * 64, lane);
-  fcl_quad_load<64>(WB1, v.pk + v.tr.B1 + (size_t)w * 64 * 64, lane);
   float WR2[MZ_H];      // the representation's, for position 0 (requested now)
-  fcl_quad_load<MZ_H>(WR2, v.pk + v.rep.B2 + (size_t)w * MZ_H * 64, lane);
-  if (tid < 64) lnw[tid] = tid < MZ_H ? v.P[v.ln_w + tid] : 0.f;
-  // wave 0 carries the per-sample work in registers: lane (b, j) = features 4 b + i of sample j
-  const int j = lane & 3, f0 = 4 * (lane >> 2);
+  const float plnw = tid < MZ_H ? v.P[v.ln_w + tid] : 0.f;
+  // wave 0 carries the per-sample work in registers: lane (j, b) = (lane >> 4, lane & 15) = features 4 b + i of sample j -- a
+  // sample's 16 lanes are one DPP row, its two LayerNorm reductions four DPP exchanges each (as in the forward chain)
+  const int j = lane >> 4, f0 = 4 * (lane & 15);
   float dgam[4] = {0.f, 0.f, 0.f, 0.f}, dbet[4] = {0.f, 0.f, 0.f, 0.f};
   f32x4 dch = (f32x4){0.f, 0.f, 0.f, 0.f};         // d chain: gradient from the transition of position p + 1 into h_p
   float tv[4][5], trs = 0.f;
@@ -610,6 +645,13 @@ __global__ __launch_bounds__(FCL_THREADS) void k_fcl_chain_bwd4(FclView v) {
   };
   for (int idx = tid; idx < 4 * LDX; idx += FCL_THREADS) X[idx] = 0.f;
   request(v.K);
+  // (loads return in order: the small reads above first, then the weights in the order of their first use)
+  asm volatile("" ::: "memory");
+  fcl_quad_load<MZ_H>(WB2, v.pk + v.tr.B2 + (size_t)w * MZ_H * 64, lane);
+  asm volatile("" ::: "memory");
+  if (tid < 64) lnw[tid] = plnw;
+  fcl_quad_load<64>(WB1, v.pk + v.tr.B1 + (size_t)w * 64 * 64, lane);
+  fcl_quad_load<MZ_H>(WR2, v.pk + v.rep.B2 + (size_t)w * MZ_H * 64, lane);
   fcl_bar();
   auto body = [&](int p, const float (&W2)[MZ_H]) __attribute__((always_inline)) {
     if (w == 0) {
@@ -629,7 +671,7 @@ __global__ __launch_bounds__(FCL_THREADS) void k_fcl_chain_bwd4(FclView v) {
         dx[i] = real ? gy[i] * lnw[f0 + i] : 0.f;
         s1 += dx[i]; s2 += dx[i] * xh[i];
       }
-      s1 = fcl_sum_bits2to5(s1); s2 = fcl_sum_bits2to5(s2);
+      s1 = fcl_sum16(s1); s2 = fcl_sum16(s2);
       const float inv = 1.f / (float)MZ_H;
       f32x4 dy;
 #pragma unroll
@@ -665,148 +707,407 @@ __global__ __launch_bounds__(FCL_THREADS) void k_fcl_chain_bwd4(FclView v) {
       if (w == 0) {
         f32x4 y = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ww = 0; ww < FCL_NW; ++ww) y += *(const f32x4 *)(red + (ww * 64 + lane) * 4);
+        for (int ww = 0; ww < FCL_NW; ++ww) y += *(const f32x4 *)(red + (ww * 64 + f0 + j) * 4);      // (written by lane 4 b + j)
         dch = y;            // (rows >= 50 come out of zero weights)
       }
       // (red is next written after two more barriers)
     }
   };
+  // (the last position peeled off the loop: it waits for WB2 alone, WB1's 64 loads arrive under its first phases)
   fcl_quad_settle(WB2);
+  body(v.K, WB2);
   fcl_quad_settle(WB1);
-  for (int p = v.K; p >= 1; --p) body(p, WB2);
+  for (int p = v.K - 1; p >= 1; --p) body(p, WB2);
   body(0, WR2);      // position 0: the representation's fc2
   // LayerNorm weight / bias gradients of this workgroup's 4 samples over all positions
   if (w == 0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       float a = dgam[i], b = dbet[i];
-      a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64);
-      b += __shfl_xor(b, 1, 64); b += __shfl_xor(b, 2, 64);
+      a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+      b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
       if (j == 0 && f0 + i < 64) {
-        v.lnpart[(size_t)blockIdx.x * 128 + f0 + i] = a;
-        v.lnpart[(size_t)blockIdx.x * 128 + 64 + f0 + i] = b;
+        v.lnpart[(size_t)blk * 128 + f0 + i] = a;
+        v.lnpart[(size_t)blk * 128 + 64 + f0 + i] = b;
       }
     }
   }
 }
 
-// ------------------------------------------------------------------------------------------------ weight gradients
-// One workgroup (four waves) per job: G[16 x 64] strip of dW = D . X^T over the R rows of one unroll position's tapes
-// (D: deltas, Mp features per row chunk; X: layer inputs, Np features), out rows 16 tm .., out columns 64 ng ..; the bias
-// gradient = row sums of D.
+__global__ __launch_bounds__(FCL_THREADS) void k_fcl_chain_bwd4(FclView v) {
+  extern __shared__ __attribute__((aligned(16))) float fcl_smem[];
+  fcl_chain_bwd4_body(v, blockIdx.x, fcl_smem);
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradients (+ optimiser)
+// One workgroup (NW waves) per job: the 16 x 64 strip G of dW = D . X^T (D: deltas, Mp features per row chunk; X: layer
+// inputs, Np features) over EVERY unroll position the layer is applied at -- the positions' tapes lie a constant stride
+// apart -- and the rows of one slab of the batch; out rows 16 tm .., out columns 64 ng ..; the bias gradient = row sums of
+// D.  With ONE slab (batch <= 512) the strip IS the gradient of those weights, and the optimiser's update of exactly those
+// weights follows in the same workgroup: no gradient round trip through HBM, no optimiser launch (r05: one strip per
+// position into K + 1 slabs that k_fcl_adam added up: 16.7 + 9.4 us of the 92 us step).
 struct FclJob {
-  size_t d_off, x_off;      // float offsets of the two tapes (feature 0, row 0)
+  size_t d_off, x_off;      // float offsets of the two tapes at the layer's FIRST position (feature 0, row 0)
+  size_t d_ps, x_ps;        // their strides from one position to the next
   size_t w_off, b_off;      // flat offsets of W [M][N] and of its bias (b_off used by the ng == 0 strip)
-  int M, N, Mp, Np, tm, ng, slab;      // Mp, Np: feature counts of the two tapes (their row-chunk strides / 16)
+  int M, N, Mp, Np, tm, ng, npos, na;        // Mp, Np: feature counts of the two tapes (their row-chunk strides / 16); tile: 16 na rows from row 16 na tm, columns from 16 ni ng (ni: the kernel's)
 };
 
-__global__ __launch_bounds__(256) void k_fcl_dw(const FclJob *jobs, int njobs, const float *tapes, float *part, size_t nflat, int R,
-                                                float *steps, int nsteps) {
-  // (the step counters -- torch keeps one per parameter -- advance here, a launch ahead of the optimiser kernel that reads them)
-  if (blockIdx.x == 0 && (int)threadIdx.x < nsteps) steps[threadIdx.x] += 1.f;
-  // four waves per strip, each over a quarter of the rows (the kernel is bound by how many load streams are in flight, its
-  // MFMAs are ~3 us: 17.1 us with two waves per strip, 20.4 with one); the partials meet in LDS and are added in a fixed order
-  __shared__ __attribute__((aligned(16))) float sh[3][17][64];
-  const int qt = threadIdx.x >> 6;          // this wave's quarter of the rows
-  const int wj = blockIdx.x;
-  const bool live = wj < njobs;
-  const FclJob j = jobs[live ? wj : 0];
-  const int lane = threadIdx.x & 63, g4 = lane >> 4, m16 = lane & 15;
-  // tapes: [row chunk][feature][16 rows] -- 16 features x 16 rows of chunk c are one contiguous KiB
-  const float *Dp = tapes + j.d_off + (size_t)(16 * j.tm + m16) * 16 + 4 * g4;
-  const float *Xp = tapes + j.x_off + (size_t)(64 * j.ng + m16) * 16 + 4 * g4;
-  const size_t dstr = (size_t)j.Mp * 16, xstr = (size_t)j.Np * 16;      // floats per row chunk
-  f32x4 acc[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float bsum = 0.f;
-  // (k index g4 of k-step jj of chunk c = row 16 c + 4 g4 + jj, in both operands: the sum over rows is order-free.)
-  // The loads of a wave's chunks (up to 8: 40 x 16 bytes per lane) are requested before the first MFMA of the group
-  const int nch = R >> 4, per = (nch + 3) >> 2, ch0 = qt * per, ch1 = ch0 + per < nch ? ch0 + per : nch;
-  for (int c0 = ch0; live && c0 < ch1; c0 += 8) {
-    f32x4 a[8], b[8][4];
-#pragma unroll
-    for (int cc = 0; cc < 8; ++cc) {
-      const int c = c0 + cc;
-      if (c < ch1) {
-        a[cc] = *(const f32x4 *)(Dp + c * dstr);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) b[cc][i] = *(const f32x4 *)(Xp + c * xstr + 256 * i);
-      }
-    }
-#pragma unroll
-    for (int cc = 0; cc < 8; ++cc) {
-      if (c0 + cc < ch1) {
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) acc[i] = fcl_mfma(a[cc][jj], b[cc][i][jj], acc[i]);
-        }
-        bsum += (a[cc][0] + a[cc][1]) + (a[cc][2] + a[cc][3]);
-      }
-    }
-  }
-  if (qt > 0) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) sh[qt - 1][4 * i + r][lane] = acc[i][r];
-    sh[qt - 1][16][lane] = bsum;
-  }
-  __syncthreads();
-  if (qt > 0 || !live) return;
-#pragma unroll
-  for (int qq = 0; qq < 3; ++qq) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[i][r] += sh[qq][4 * i + r][lane];
-    bsum += sh[qq][16][lane];
-  }
-  float *out = part + (size_t)j.slab * nflat;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int n = 64 * j.ng + 16 * i + m16;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = 16 * j.tm + 4 * g4 + r;
-      if (m < j.M && n < j.N) out[j.w_off + (size_t)m * j.N + n] = acc[i][r];
-    }
-  }
-  bsum += __shfl_xor(bsum, 16, 64);
-  bsum += __shfl_xor(bsum, 32, 64);
-  if (j.ng == 0 && g4 == 0 && 16 * j.tm + m16 < j.M) out[j.b_off + 16 * j.tm + m16] = bsum;
-}
-
-// ------------------------------------------------------------------------------------------------ gradient, optimiser
 struct FclOpt {
   double beta1, beta2, eps, wd;
   float clip;
   int adamw, no_update;
 };
 
-// grad[i] = sum over the unroll positions' strips (LayerNorm parameters: over the workgroups' partials); per-block sum
-// of squares for clip_grad_norm_ (launched only when clipping is on: without it k_fcl_adam adds the strips up itself)
-// one parameter's gradient: the unroll positions' strips in order (LayerNorm parameters: the chain workgroups' partials,
-// eight independent chains so that the loads of a round are in flight together; the order of the sum is fixed)
-__device__ __forceinline__ float fcl_grad_of(size_t i, const float *part, int nslab, const float *lnpart, int nwg, size_t ln_w, size_t nflat) {
-  float g = 0.f;
-  if (i >= ln_w && i < ln_w + 2 * MZ_H) {
-    const int k = (int)(i - ln_w), col = k < MZ_H ? k : 64 + (k - MZ_H);
-    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    int wg = 0;
-    for (; wg + 8 <= nwg; wg += 8) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) a[j] += lnpart[(size_t)(wg + j) * 128 + col];
-    }
-    for (; wg < nwg; ++wg) a[wg & 7] += lnpart[(size_t)wg * 128 + col];
-    g = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-  } else {
-    for (int q = 0; q < nslab; ++q) g += part[(size_t)q * nflat + i];
+struct FclDw {              // what a weight-gradient workgroup does with its strip
+  const float *tapes;
+  int R, S;                 // batch rows; row slabs (1: a strip is a gradient)
+  float *part;              // fuse == 0: strips to part[slab][nflat]
+  size_t nflat;
+  float *grad;              // fuse == 1: the gradient (kept for mz_fcl_read_grad) ...
+  int fuse;                 // ... and Adam / AdamW on the strip's weights, here
+  float *P, *pk;
+  const int32_t *posA, *posB;
+  float *m, *vv;
+  const float *steps, *lr_p;
+  FclOpt o;
+};
+
+// Adam / AdamW on one weight, torch's fused-kernel arithmetic (utils.py:73-83: eps 1.5e-4; the hyper-parameters are doubles
+// in torch's kernel and the moments' updates are evaluated in double there: 1 - 0.999 as a float is 4.7e-5 off); the new
+// weight goes into the flat vector AND into the packed copies the next step's MFMAs read
+__device__ __forceinline__ void fcl_adam_elem(const FclDw &a, size_t i, float g, float p, float ea, float es, int pa, int pb, float bc1,
+                                              float bc2, double lr) {
+  if (a.o.wd != 0.0) {
+    if (a.o.adamw) p = (float)((double)p - lr * a.o.wd * (double)p);
+    else g = (float)((double)g + (double)p * a.o.wd);
   }
+  ea = (float)((double)ea + (1.0 - a.o.beta1) * ((double)g - (double)ea));            // torch lerp, weight < 0.5
+  es = (float)(a.o.beta2 * (double)es + (1.0 - a.o.beta2) * (double)g * (double)g);
+  const float step_size = (float)(lr / (double)bc1), bc2s = sqrtf(bc2);
+  const float denom = (float)((double)(sqrtf(es) / bc2s) + a.o.eps);
+  p -= step_size * ea / denom;
+  a.m[i] = ea; a.vv[i] = es; a.P[i] = p;
+  if (pa >= 0) a.pk[pa] = p;
+  if (pb >= 0) a.pk[pb] = p;
+}
+
+// the two bias corrections of this step (steps[0] has been advanced by k_fcl_heads), by one lane, into LDS
+__device__ __forceinline__ void fcl_bias_corr(const FclDw &a, float *dst) {
+  const double step = (double)a.steps[0];
+  dst[0] = (float)(1.0 - pow(a.o.beta1, step));
+  dst[1] = (float)(1.0 - pow(a.o.beta2, step));
+}
+
+// A job's tile: NA x 16 rows of dW (NA delta fragments per row chunk) by NI x 16 columns (NI input fragments).  One wave's unit of
+// work = one row chunk of one position: NA + NI loads of 16 bytes per lane feed 4 NA NI MFMAs.  Small batches want MANY small
+// jobs (a job lives on one CU: its MFMAs bound its duration) -- NA = 1, NI = 2 or 4; large batches want few loads per MFMA (the
+// kernel is bound by the tapes' way through L2: 16 x 64 strips re-read the input tape once per 16 rows of dW) -- NA up to 4.
+#define FCL_DW_Q(NA, NI) ((NA) * (4 * (NI) + 1))                                   // floats per lane a wave leaves in LDS
+#define FCL_DW_LDS(NW, NA, NI) (((NW) * FCL_DW_Q(NA, NI) * 64 + 4) * 4)            // bytes: the waves' partial tiles + the two bias corrections
+
+template <int NW, int NA, int NI, int NF>
+__device__ __forceinline__ void fcl_dw_job(const FclJob *jp, int slab, const FclDw &a, float *sh) {
+  constexpr int Q = FCL_DW_Q(NA, NI);
+  const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, g4 = lane >> 4, m16 = lane & 15;
+  const FclJob j = *jp;
+  if (a.fuse && tid == NW * 64 - 1) fcl_bias_corr(a, sh + NW * Q * 64);      // (a lane of the last wave: the first waves carry the remainder units)
+  const int nch = a.R >> 4, per = (nch + a.S - 1) / a.S, c_lo = slab * per, c_hi = c_lo + per < nch ? c_lo + per : nch;
+  const int nchs = c_hi > c_lo ? c_hi - c_lo : 0, U = j.npos * nchs;
+  // tapes: [row chunk][feature][16 rows] -- 16 features x 16 rows of chunk c are one contiguous KiB
+  const float *Db = a.tapes + j.d_off + (size_t)c_lo * j.Mp * 16 + (size_t)(16 * NA * j.tm + m16) * 16 + 4 * g4;
+  const float *Xb = a.tapes + j.x_off + (size_t)c_lo * j.Np * 16 + (size_t)(16 * NI * j.ng + m16) * 16 + 4 * g4;
+  const size_t dstr = (size_t)j.Mp * 16, xstr = (size_t)j.Np * 16;      // floats per row chunk
+  f32x4 acc[NA][NI];
+  float bsum[NA];
+#pragma unroll
+  for (int f = 0; f < NA; ++f) {
+    bsum[f] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) acc[f][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  // unit u = (position u / nchs, chunk u % nchs); wave w takes u = w, w + NW, ...: a fixed assignment and a fixed order, so the
+  // sum is deterministic (k index g4 of k-step jj of chunk c = row 16 c + 4 g4 + jj, in both operands).  The loads of
+  // NF units are requested before the first MFMA of the group
+  // Two register sets in turn: the loads of the NEXT NF units are in flight while the MFMAs of this set run (one set: a wave
+  // waited out a round trip to L2 / HBM in front of every NF units of MFMAs, and two waves per SIMD hide little of it)
+  int p = 0, c = w;
+  while (nchs > 0 && c >= nchs) { c -= nchs; ++p; }
+  auto load = [&](f32x4 (&av)[NF][NA], f32x4 (&bv)[NF][NI], int u0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < NF; ++k) {
+      if (u0 + k * NW < U) {
+        const float *Dp = Db + (size_t)p * j.d_ps + (size_t)c * dstr;
+        const float *Xp = Xb + (size_t)p * j.x_ps + (size_t)c * xstr;
+#pragma unroll
+        for (int f = 0; f < NA; ++f) av[k][f] = *(const f32x4 *)(Dp + 256 * f);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) bv[k][i] = *(const f32x4 *)(Xp + 256 * i);
+        c += NW;
+        while (c >= nchs) { c -= nchs; ++p; }
+      }
+    }
+  };
+  auto comp = [&](const f32x4 (&av)[NF][NA], const f32x4 (&bv)[NF][NI], int u0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < NF; ++k) {
+      if (u0 + k * NW < U) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+#pragma unroll
+          for (int f = 0; f < NA; ++f)
+#pragma unroll
+            for (int i = 0; i < NI; ++i) acc[f][i] = fcl_mfma(av[k][f][jj], bv[k][i][jj], acc[f][i]);
+        }
+#pragma unroll
+        for (int f = 0; f < NA; ++f) bsum[f] += (av[k][f][0] + av[k][f][1]) + (av[k][f][2] + av[k][f][3]);
+      }
+    }
+  };
+  if (w < U) {
+    f32x4 avA[NF][NA], bvA[NF][NI], avB[NF][NA], bvB[NF][NI];
+    int u0 = w;
+    load(avA, bvA, u0);
+    for (;;) {
+      const int u1 = u0 + NF * NW;
+      if (u1 < U) load(avB, bvB, u1);
+      comp(avA, bvA, u0);
+      if (u1 >= U) break;
+      const int u2 = u1 + NF * NW;
+      if (u2 < U) load(avA, bvA, u2);
+      comp(avB, bvB, u1);
+      if (u2 >= U) break;
+      u0 = u2;
+    }
+  }
+  // a wave's partial tile in LDS: row q = (f * NI + i) * 4 + r of 64 lanes; the NA bias rows behind them
+#pragma unroll
+  for (int f = 0; f < NA; ++f) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sh[(w * Q + (f * NI + i) * 4 + r) * 64 + lane] = acc[f][i][r];
+    sh[(w * Q + NA * NI * 4 + f) * 64 + lane] = bsum[f];
+  }
+  __syncthreads();
+  // the tile's weights (+ biases): element e = (q, lane l) -> row 16 (NA tm + f) + 4 (l >> 4) + r, column 16 (NI ng + i) + (l & 15);
+  // the waves' partials in wave order
+  constexpr int T = NW * 64, EW = NA * NI * 256, EB = NA * 16, EPT = (EW + EB + T - 1) / T;
+  auto element = [&](int e, float &g, size_t &idx) -> bool {
+    g = 0.f;
+    if (e < EW) {
+      const int q = e >> 6, l = e & 63, fi = q >> 2, f = fi / NI, i = fi - f * NI;
+#pragma unroll
+      for (int ww = 0; ww < NW; ++ww) g += sh[(ww * Q + q) * 64 + l];
+      const int mm = 16 * (NA * j.tm + f) + 4 * (l >> 4) + (q & 3), nn = 16 * (NI * j.ng + i) + (l & 15);
+      idx = j.w_off + (size_t)mm * j.N + nn;
+      return mm < j.M && nn < j.N;
+    }
+    if (e < EW + EB) {
+      const int t = e - EW, f = t >> 4, m = t & 15;
+#pragma unroll
+      for (int ww = 0; ww < NW; ++ww)
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) g += sh[(ww * Q + NA * NI * 4 + f) * 64 + m + 16 * gg];
+      idx = j.b_off + 16 * (NA * j.tm + f) + m;
+      return j.ng == 0 && 16 * (NA * j.tm + f) + m < j.M;
+    }
+    idx = 0;
+    return false;
+  };
+  if (!a.fuse || NA != 1) {        // (a slab's tile: to part[slab]; no arrays of elements kept in registers)
+    float *out = a.part + (size_t)slab * a.nflat;
+    for (int e = tid; e < EW + EB; e += T) {
+      float g;
+      size_t idx;
+      if (element(e, g, idx)) out[idx] = g;
+    }
+    return;
+  }
+  if constexpr (NA == 1) {
+    // fused optimiser: a thread's elements together, so that their loads (weight, moments, pack positions) are one round trip
+    float g[EPT], pv[EPT], ea[EPT], es[EPT];
+    size_t idx[EPT];
+    bool ok[EPT];
+    int pa[EPT], pb[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      ok[k] = element(tid + k * T, g[k], idx[k]);
+      if (ok[k]) { pv[k] = a.P[idx[k]]; ea[k] = a.m[idx[k]]; es[k] = a.vv[idx[k]]; pa[k] = a.posA[idx[k]]; pb[k] = a.posB[idx[k]]; }
+    }
+    const float bc1 = sh[NW * Q * 64], bc2 = sh[NW * Q * 64 + 1];
+    const double lr = (double)*a.lr_p;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      if (ok[k]) {
+        a.grad[idx[k]] = g[k];
+        fcl_adam_elem(a, idx[k], g[k], pv[k], ea[k], es[k], pa[k], pb[k], bc1, bc2, lr);
+      }
+    }
+  }
+}
+
+// LayerNorm weight / bias gradient k (0 .. 2 MZ_H - 1): the chain workgroups' partials, eight independent chains so that the
+// loads of a round are in flight together; the order of the sum is fixed
+__device__ __forceinline__ float fcl_ln_grad(int k, const float *lnpart, int nwg) {
+  const int col = k < MZ_H ? k : 64 + (k - MZ_H);
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int wg = 0;
+  for (; wg + 8 <= nwg; wg += 8) {
+#pragma unroll
+    for (int jx = 0; jx < 8; ++jx) a[jx] += lnpart[(size_t)(wg + jx) * 128 + col];
+  }
+  for (; wg < nwg; ++wg) a[wg & 7] += lnpart[(size_t)wg * 128 + col];
+  return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+}
+
+// the three weighted loss means (learners.py:205-207,228-230) added to loss_acc (_loss_dev order: reward, value, policy), by
+// one workgroup of 256+ threads; shd3: [3][256] doubles of LDS
+__device__ __forceinline__ void fcl_loss_block(const float *lossb, const void *w, int w_f64, int bs, int K1, double *loss_acc, double *shd3) {
+  // the three heads together: every thread's loads are independent (one round trip), one reduction of three doubles
+  double acc[3] = {0.0, 0.0, 0.0};
+  if (threadIdx.x < 256) {
+    // four rows of a thread at a time: their 4 x 17 loads are in flight together (row by row, this block was 38 us of the step at
+    // batch 2048: eight dependent round trips); per row the positions in order, per thread the rows in order: the sums' order is fixed
+    for (int b0 = threadIdx.x; b0 < bs; b0 += 4 * 256) {
+      float lv[4][3][FCL_MAXP];
+      double wb[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int b = b0 + r * 256;
+        wb[r] = 0.0;
+        if (b < bs) {
+#pragma unroll
+          for (int hd = 0; hd < 3; ++hd)
+#pragma unroll
+            for (int p = 0; p < FCL_MAXP; ++p) lv[r][hd][p] = (p < K1 && p >= (hd == 2 ? 1 : 0)) ? lossb[((size_t)hd * K1 + p) * bs + b] : 0.f;
+          wb[r] = w_f64 ? ((const double *)w)[b] : (double)((const float *)w)[b];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (b0 + r * 256 < bs) {
+#pragma unroll
+          for (int hd = 0; hd < 3; ++hd) {
+            float l = 0.f;
+#pragma unroll
+            for (int p = 0; p < FCL_MAXP; ++p)
+              if (p < K1 && p >= (hd == 2 ? 1 : 0)) l += lv[r][hd][p];
+            acc[hd] += wb[r] * (double)l;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int hd = 0; hd < 3; ++hd) shd3[hd * 256 + threadIdx.x] = acc[hd];
+  }
+  __syncthreads();
+  for (int k = 128; k >= 1; k >>= 1) {
+    if ((int)threadIdx.x < k) {
+#pragma unroll
+      for (int hd = 0; hd < 3; ++hd) shd3[hd * 256 + threadIdx.x] += shd3[hd * 256 + threadIdx.x + k];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 3) loss_acc[threadIdx.x == 2 ? 0 : (threadIdx.x == 0 ? 1 : 2)] += shd3[threadIdx.x * 256] / (double)bs;
+}
+
+// the fused step's LAST launch (batch <= 512): the chain layers' weight-gradient jobs as 16 x 32 tiles, one slab, Adam in the
+// workgroup; two more workgroups: the LayerNorm parameters (gradient from the chain workgroups' partials, Adam) and the loss sums
+__global__ __launch_bounds__(FCL_THREADS) void k_fcl_dwa(const FclJob *jobs, int njobs, FclDw a, int tail, const float *lnpart, int nwg,
+                                                         size_t ln_w, const float *lossb, const void *w, int w_f64, int bs, int K1,
+                                                         double *loss_acc) {
+  extern __shared__ __attribute__((aligned(16))) float fcl_smem[];
+  const int b = blockIdx.x;
+  if (b < njobs) {
+    fcl_dw_job<FCL_NW, 1, 2, 4>(jobs + b, 0, a, fcl_smem);
+    return;
+  }
+  if (!tail) return;
+  if (b == njobs) {
+    const int k = threadIdx.x;
+    if (k == 2 * MZ_H) fcl_bias_corr(a, fcl_smem);
+    float g = 0.f, pv = 0.f, ea = 0.f, es = 0.f;
+    int pa = -1, pb = -1;
+    const size_t i = ln_w + (size_t)(k < 2 * MZ_H ? k : 0);
+    if (k < 2 * MZ_H) {
+      pv = a.P[i]; ea = a.m[i]; es = a.vv[i]; pa = a.posA[i]; pb = a.posB[i];
+      g = fcl_ln_grad(k, lnpart, nwg);
+      a.grad[i] = g;
+    }
+    __syncthreads();
+    if (k < 2 * MZ_H && a.fuse) fcl_adam_elem(a, i, g, pv, ea, es, pa, pb, fcl_smem[0], fcl_smem[1], (double)*a.lr_p);
+    return;
+  }
+  fcl_loss_block(lossb, w, w_f64, bs, K1, loss_acc, (double *)fcl_smem);
+}
+
+// larger batches: every (job, row slab) is a workgroup of four waves; a job's tile is 16 NA rows x 64 columns, NA = the job's
+// `na` (4 where the layer has >= 50 output rows: the input tape is read ONCE per 64 rows of dW instead of once per 16); the slabs'
+// tiles go to part[slab] and are added up by k_fcl_adam
+__global__ __launch_bounds__(256, 2) void k_fcl_dwt(const FclJob *jobs, int njobs, FclDw a, const float *lnpart, int nwg, float *lngrad) {
+  extern __shared__ __attribute__((aligned(16))) float fcl_smem[];
+  const int b = blockIdx.x;
+  if (b == njobs * a.S) {
+    // one more workgroup: the LayerNorm parameters' gradients from the chain workgroups' partials [nwg][128] -> lngrad [128].
+    // Thread (half, col) adds the partials of every second workgroup, 16 loads in flight; the halves meet in LDS.  (Summed by
+    // the optimiser kernel's one thread per parameter, batch 2048's 512 partials were 64 dependent round trips: 23 us)
+    const int col = threadIdx.x & 127, half = threadIdx.x >> 7;
+    float acc = 0.f;
+    int wg = half;
+    for (; wg + 2 * 15 < nwg; wg += 2 * 16) {
+      float t[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) t[k] = lnpart[(size_t)(wg + 2 * k) * 128 + col];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc += t[k];
+    }
+    for (; wg < nwg; wg += 2) acc += lnpart[(size_t)wg * 128 + col];
+    fcl_smem[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < 128) lngrad[threadIdx.x] = fcl_smem[threadIdx.x] + fcl_smem[128 + threadIdx.x];
+    return;
+  }
+  if (b > njobs * a.S) return;
+  const FclJob *jp = jobs + b / a.S;
+  const int slab = b % a.S, na = jp->na;
+  if (na == 4) fcl_dw_job<4, 4, 4, 2>(jp, slab, a, fcl_smem);
+  else if (na == 2) fcl_dw_job<4, 2, 4, 3>(jp, slab, a, fcl_smem);
+  else fcl_dw_job<4, 1, 4, 4>(jp, slab, a, fcl_smem);
+}
+
+// The backward chain (batch / 4 workgroups: 64 of 256 CUs at batch 256) and the heads' weight-gradient jobs -- they read only
+// what k_fcl_heads wrote -- in ONE launch: the jobs (16 x 64 strips) run on the CUs the chain leaves idle (r05 tried the same
+// overlap with a side stream and two events: the cross-stream waits cost what it saved)
+__global__ __launch_bounds__(FCL_THREADS) void k_fcl_bwd_dw(FclView v, int nchain, const FclJob *jobs, FclDw a) {
+  extern __shared__ __attribute__((aligned(16))) float fcl_smem[];
+  if ((int)blockIdx.x < nchain) fcl_chain_bwd4_body(v, blockIdx.x, fcl_smem);
+  else fcl_dw_job<FCL_NW, 1, 4, 4>(jobs + ((int)blockIdx.x - nchain), 0, a, fcl_smem);
+}
+
+// ------------------------------------------------------------------------------------------------ gradient, optimiser (unfused paths)
+// one parameter's gradient: the slabs' strips in order (LayerNorm parameters: the chain workgroups' partials)
+// (nwg < 0: lnpart is the reduced vector [128] k_fcl_dwt's last workgroup left -- columns as in the partials)
+__device__ __forceinline__ float fcl_grad_of(size_t i, const float *part, int nslab, const float *lnpart, int nwg, size_t ln_w, size_t nflat) {
+  if (i >= ln_w && i < ln_w + 2 * MZ_H) {
+    const int k = (int)(i - ln_w);
+    return nwg < 0 ? lnpart[k < MZ_H ? k : 64 + (k - MZ_H)] : fcl_ln_grad(k, lnpart, nwg);
+  }
+  float g = 0.f;
+  int q = 0;
+  for (; q + 8 <= nslab; q += 8) {          // eight slabs' loads in flight together, added in slab order
+    float t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = part[(size_t)(q + k) * nflat + i];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) g += t[k];
+  }
+  for (; q < nslab; ++q) g += part[(size_t)q * nflat + i];
   return g;
 }
 
+// grad[i] = sum over the slabs' strips; per-block sum of squares for clip_grad_norm_ (launched only when clipping is on:
+// without it k_fcl_adam adds the strips up itself)
 __global__ __launch_bounds__(256) void k_fcl_grad(const float *part, int nslab, const float *lnpart, int nwg, size_t ln_w,
                                                   size_t nflat, float *grad, float *bsq) {
   __shared__ float sh[256];
@@ -827,7 +1128,7 @@ __global__ __launch_bounds__(256) void k_fcl_grad(const float *part, int nslab, 
 
 // clip_grad_norm_ (learners.py:217-218), Adam / AdamW with torch's fused-kernel arithmetic (utils.py:73-83: eps 1.5e-4),
 // new weights -> flat vector + the packed copies; one more block (the last) adds the three weighted loss means up
-// (learners.py:205-207,228-230).  steps[0] has been advanced by k_fcl_dw.
+// (learners.py:205-207,228-230).  steps[0] has been advanced by k_fcl_heads.
 __global__ __launch_bounds__(256) void k_fcl_adam(float *P, float *pk, const int32_t *posA, const int32_t *posB, float *grad,
                                                   const float *part, int nslab, const float *lnpart, int nwg, size_t ln_w,
                                                   const float *bsq, int nblk, float *m, float *vv, const float *steps,
@@ -836,31 +1137,8 @@ __global__ __launch_bounds__(256) void k_fcl_adam(float *P, float *pk, const int
   __shared__ float sh[256];
   __shared__ float shc[4];
   if ((int)blockIdx.x == nblk) {
-    // the three heads together: every thread's loads are independent (one round trip), one reduction of three doubles
-    // (head by head this block was the kernel's critical path: three dependent rounds of loads + tree reductions)
-    double acc[3] = {0.0, 0.0, 0.0};
-    for (int b = threadIdx.x; b < bs; b += 256) {
-      float l[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-      for (int hd = 0; hd < 3; ++hd)
-        for (int p = (hd == 2 ? 1 : 0); p < K1; ++p) l[hd] += lossb[((size_t)hd * K1 + p) * bs + b];
-      const double wb = w_f64 ? ((const double *)w)[b] : (double)((const float *)w)[b];
-#pragma unroll
-      for (int hd = 0; hd < 3; ++hd) acc[hd] += wb * (double)l[hd];
-    }
-    __shared__ double shd3[3][256];
-#pragma unroll
-    for (int hd = 0; hd < 3; ++hd) shd3[hd][threadIdx.x] = acc[hd];
-    __syncthreads();
-    for (int k = 128; k >= 1; k >>= 1) {
-      if ((int)threadIdx.x < k) {
-#pragma unroll
-        for (int hd = 0; hd < 3; ++hd) shd3[hd][threadIdx.x] += shd3[hd][threadIdx.x + k];
-      }
-      __syncthreads();
-    }
-    // _loss_dev order: reward, value, policy
-    if (threadIdx.x < 3) loss_acc[threadIdx.x == 2 ? 0 : (threadIdx.x == 0 ? 1 : 2)] += shd3[threadIdx.x][0] / (double)bs;
+    __shared__ double shd3[3 * 256];
+    fcl_loss_block(lossb, w, w_f64, bs, K1, loss_acc, shd3);
     return;
   }
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;

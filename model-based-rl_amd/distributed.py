@@ -153,6 +153,55 @@ def serve_rings(rings, replay_call, B, stop):
       time.sleep(0.0005)
 
 
+# ------------------------------------------------------------------------------------------------ pre-flight
+def usable_cores():
+  """cores this process may use: the affinity mask capped by the cgroup CPU quota (the GPU boxes expose 256 logical CPUs under a
+  16-CPU quota; threads beyond the quota only time-slice)"""
+  n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+  try:
+    quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+    if quota != 'max':
+      n = min(n, max(1, int(int(quota) / int(period))))
+  except (OSError, ValueError):
+    pass
+  return n
+
+
+def ring_bytes(world, chunk, B, rec, slots=4):
+  """shared memory the one-replay layout takes: a ShmRing per rank r > 0 (ShmRing.__init__'s size)"""
+  return max(0, world - 1) * (ShmRing.HDR * 8 + slots * (8 + chunk * B * rec * 4))
+
+
+def preflight(world, shm_need=0, ingest_threads=0, shared_gpu_ok=False, devices=None, shm_free=None, cores=None, shm_dir='/dev/shm'):
+  """Checks a multi-rank run needs to pass BEFORE any rank touches a GPU (a failure after that point leaves N - 1 ranks inside
+  a collective): visible devices >= ranks (unless the ranks are meant to share GPUs: the one-GPU self-tests), free shared memory
+  >= the experience rings' bytes (a container's 64 MB /dev/shm default ends `train --ranks 8` with SIGBUS at the first chunk),
+  usable cores >= half a core per rank (the measured host share of a rank, profiles/r05_host_threads.txt) + the replay's ingest
+  threads.  -> a dict of what was found; raises SystemExit with ONE sentence otherwise.  devices / shm_free / cores: overrides (tests)."""
+  if devices is None:
+    devices = torch.cuda.device_count()                # (counting devices does not initialise the GPU)
+  if shm_free is None:
+    try:
+      st = os.statvfs(shm_dir)
+      shm_free = st.f_bavail * st.f_frsize
+    except OSError:
+      shm_free = None
+  if cores is None:
+    cores = usable_cores()
+  found = {'ranks': int(world), 'visible_devices': int(devices), 'shm_need_bytes': int(shm_need), 'shm_free_bytes': shm_free,
+           'usable_cores': int(cores), 'cores_wanted': 0.5 * world + ingest_threads}
+  if world > 1 and not shared_gpu_ok and devices < world:
+    raise SystemExit('pre-flight: %d ranks asked for but %d GPU(s) visible (one process per GPU; set MZ_SHARED_GPU_OK=1 for the '
+                     'several-ranks-on-one-GPU self-test).' % (world, devices))
+  if shm_need and shm_free is not None and shm_free < shm_need:
+    raise SystemExit('pre-flight: the experience rings of %d ranks need %.1f MB of %s and %.1f MB are free (raise the '
+                     'container\'s shm size or lower --num_envs / the chunk).' % (world, shm_need / 1e6, shm_dir, shm_free / 1e6))
+  if world > 1 and cores < 0.5 * world + ingest_threads:
+    raise SystemExit('pre-flight: %d ranks + %d ingest threads want %.1f host cores and %d are usable (affinity mask / cgroup quota).'
+                     % (world, ingest_threads, 0.5 * world + ingest_threads, cores))
+  return found
+
+
 # ------------------------------------------------------------------------------------------------ weights
 class FlatWeights(object):
   """What RankStorage.get_weights hands an actor over RCCL: the device buffer the broadcast fills (`tensor`), the event
@@ -190,6 +239,12 @@ class RankStorage(object):
     self.training_step = 0
     self.broadcasts = 0
     self.native = backend == 'nccl' and os.environ.get('MZ_TORCH_COLLECTIVES', '0')[:1] != '1'
+    # what a multi-rank record needs to be read without the logs (collective_stats): why the library's communicator is not in use
+    # (None: it is), how many ranks RCCL says it spans, HIP-event pairs around every broadcast on the side stream
+    self.fallback_reason = None if self.native else ('backend %s' % backend if backend != 'nccl' else 'MZ_TORCH_COLLECTIVES=1')
+    self.ranks_in_comm = None
+    self._bcast_events, self._bcast_us = [], []
+    self._done_last = None
     n = int(num_weights)
     self.ctrl_group = None          # (None: the default group)
     if not self.native:
@@ -218,6 +273,12 @@ class RankStorage(object):
       err, uid = exc, (C.c_char * 128)()
     box = [bytes(uid.raw)]
     dist.broadcast_object_list(box, src=0, group=self.meta_group)      # bootstrap only
+    # 'ready to create' (ADVICE r05): a rank whose library / librccl / unique id failed never starts the blocking collective
+    # init below, and no other rank does either -- they would sit in ncclCommInitRank for the whole MZ_COMM_TIMEOUT
+    ready = torch.tensor([0 if err is not None else 1], dtype=torch.int64)
+    dist.all_reduce(ready, op=dist.ReduceOp.MIN, group=self.meta_group)
+    if err is None and int(ready[0]) == 0:
+      err = RuntimeError('another rank could not load librccl / the library')
     if err is None:
       # ncclCommInitRank is collective and blocking: it runs on a thread of its own, and a rank that has waited MZ_COMM_TIMEOUT
       # seconds (default 120) gives up on it -- every rank then does (the wait is symmetric) and the fallback below takes over
@@ -235,9 +296,12 @@ class RankStorage(object):
       th = threading.Thread(target=create, daemon=True)
       th.start()
       th.join(float(os.environ.get('MZ_COMM_TIMEOUT', '120')))
-      err = result[0] if result else RuntimeError('mz_comm_create did not return within MZ_COMM_TIMEOUT')
       if not result:
-        self.comm = C.c_void_p()        # (the thread may still complete it: never used, never destroyed)
+        # the thread is still inside ncclCommInitRank: creating ANOTHER communicator on this device beside it (the fallback) would
+        # race it, and a handle completed later would leak.  The process ends here, non-zero; the launcher ends the other ranks.
+        raise SystemExit('RankStorage (rank %d of %d): mz_comm_create (ncclCommInitRank) did not return within MZ_COMM_TIMEOUT = %s s: '
+                         'giving up (no fallback beside a half-initialised communicator)' % (rank, world, os.environ.get('MZ_COMM_TIMEOUT', '120')))
+      err = result[0]
     # all ranks or none: a rank that could not build its communicator sends every rank back to torch.distributed's collectives
     ok = torch.tensor([0 if err is not None else 1], dtype=torch.int64)
     dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.meta_group)
@@ -249,9 +313,13 @@ class RankStorage(object):
         self.lib.mz_comm_destroy(self.comm)
         self.comm = None
       self.native, self.ctrl_group = False, None
+      self.fallback_reason = str(err) if err is not None else 'another rank failed to create its communicator'
       self._flats = [torch.zeros(n, dtype=torch.float32, device=self.cdev)]
       self._last = 0
       return
+    cnt = C.c_int(0)
+    if self.lib.mz_comm_count(self.comm, C.byref(cnt)) == 0:
+      self.ranks_in_comm = int(cnt.value)
     self.side = torch.cuda.Stream(self.device)
     self._flats = [torch.zeros(n, dtype=torch.float32, device=self.device) for _ in range(2)]
     self._pinned = [torch.zeros(n, dtype=torch.float32).pin_memory() for _ in range(2)] if rank == 0 else None
@@ -262,8 +330,26 @@ class RankStorage(object):
 
   @property
   def flat(self):
-    """the buffer the last broadcast filled"""
+    """the buffer the last broadcast filled; the caller's current stream is ordered behind that broadcast (it ran on the side
+    stream: a reader that never went through FlatWeights.event -- train.py's rank_weight_sums on a collective-only rank -- would
+    otherwise race it)"""
+    if self._done_last is not None:
+      torch.cuda.current_stream(self.device).wait_event(self._done_last)
     return self._flats[self._last]
+
+  def collective_stats(self):
+    """the N > 1 bench line's `collectives` block: which path the weights travel, ranks RCCL reports for the communicator,
+    HIP-event time of mz_broadcast_weights on the side stream (mean / max over the pulls whose events have completed)"""
+    keep = []
+    for e0, e1 in self._bcast_events:
+      if e1.query():
+        self._bcast_us.append(1e3 * e0.elapsed_time(e1))
+      else:
+        keep.append((e0, e1))
+    self._bcast_events = keep
+    us = self._bcast_us
+    return {'native_rccl_broadcast': bool(self.native), 'ranks_in_comm': self.ranks_in_comm, 'fallback_reason': self.fallback_reason,
+            'broadcasts': int(self.broadcasts), 'broadcast_us': {'mean': float(np.mean(us)), 'max': float(np.max(us)), 'n': len(us)} if us else None}
 
   def is_ready(self):
     if self.rank == 0:
@@ -289,7 +375,9 @@ class RankStorage(object):
     if not self.native:
       if self.rank == 0:
         self._flats[0].copy_(host.to(self.cdev))
+      t0 = time.perf_counter()
       dist.broadcast(self._flats[0], src=0)
+      self._bcast_us.append(1e6 * (time.perf_counter() - t0))      # (the fallback paths: host wall time of the call)
       self._gather_meta(torch.tensor([step, games], dtype=torch.int64, device=self.cdev))
       self.broadcasts += 1
       flat = self._flats[0]
@@ -313,14 +401,19 @@ class RankStorage(object):
         flat.copy_(self._pinned[k], non_blocking=True)
         self._staged[k] = torch.cuda.Event()
         self._staged[k].record(self.side)
-      # the path's one exchange: RCCL over xGMI, on this side stream
+      # the path's one exchange: RCCL over xGMI, on this side stream (a pair of HIP events around it: collective_stats)
+      t0 = torch.cuda.Event(enable_timing=True)
+      t0.record(self.side)
       _abi.check(self.lib.mz_broadcast_weights(self.comm, C.c_void_p(flat.data_ptr()), flat.numel(), 0, C.c_void_p(self.side.cuda_stream)),
                  'mz_broadcast_weights')
-      done = torch.cuda.Event()
+      done = torch.cuda.Event(enable_timing=True)
       done.record(self.side)
+      self._bcast_events.append((t0, done))
+      if len(self._bcast_events) > 64:
+        self.collective_stats()
     gathered = self._gather_meta(torch.tensor([step, games, ok], dtype=torch.int64), group=self.meta_group)
     self.broadcasts += 1
-    self._last = k
+    self._last, self._done_last = k, done
     return FlatWeights(self, k, flat, int(gathered[0][2]), done), self.training_step
 
   def close(self):

@@ -1,8 +1,7 @@
 """Parameter server with the reference's surface (shared_storage.py:4-25): latest weights + training step,
 per-actor game counts.  In the multi-GPU layout rank 0's storage is the weight source and
-`broadcast_flat` ships one flattened float32 buffer to every actor rank with an RCCL broadcast
-(torch.distributed backend "nccl" on ROCm) instead of Ray's pickled state_dict."""
-import torch
+distributed.RankStorage ships one flattened float32 buffer to every actor rank with an RCCL broadcast
+(mz_broadcast_weights) instead of Ray's pickled state_dict."""
 
 
 class SharedStorage(object):
@@ -25,11 +24,3 @@ class SharedStorage(object):
   def is_ready(self):
     return self.weights is not None
 
-
-def broadcast_flat(flat, src=0):
-  """One collective: the flattened weights (engine.flatten_weights order) from rank `src` to all ranks.
-  0.79 MB for the LunarLander FCNetwork -- latency-bound, so a single un-bucketed broadcast."""
-  import torch.distributed as dist
-  if dist.is_available() and dist.is_initialized():      # (also at world size 1: the single-GPU RCCL self-test runs the collective)
-    dist.broadcast(flat, src=src)
-  return flat

@@ -29,16 +29,37 @@ def publish_initial_weights(config, storage):
   storage.store_weights.remote(net.get_weights(), 0).result()
 
 
+def share_gpu_in_turns(config, actor_keys):
+  """Decided from the DEVICES, not from a flag or the device count: where an Actor and the Learner of this process
+  resolve to the same torch.device (actors.py / learners.py pick theirs from --actors_gpu_device_ids / --learner_gpu_device_id,
+  else the process's current device) they take turns on it (gpu_turns.py) -- two busy queues do not share an MI355X gracefully,
+  both lose ~8 x, and under --ranks N the slowed rank holds every other rank back at each collective weight pull.  Sets
+  config.gpu_turns and says so once; --no_gpu_turns keeps them apart-less (measurements).  -> True where turns were switched on."""
+  if getattr(config, 'gpu_turns', False) or getattr(config, 'no_gpu_turns', False):
+    return False
+  if 'learner' not in getattr(config, 'use_gpu_for', []) or not torch.cuda.is_available():
+    return False
+  cur = torch.cuda.current_device()
+  lid = getattr(config, 'learner_gpu_device_id', None)
+  learner_dev = lid if lid is not None else cur
+  ids = getattr(config, 'actors_gpu_device_ids', None)
+  actor_devs = {(ids[k] if ids else cur) for k in actor_keys}
+  if learner_dev not in actor_devs:
+    return False
+  config.gpu_turns = True
+  print('train: an actor and the learner of this process both run on cuda:%d: they take turns on it (gpu_turns.py; two busy queues '
+        'on one MI355X lose ~8 x each).  Give each its own GPU (--ranks N --dedicated_learner_rank, or --learner_gpu_device_id) to '
+        'run them side by side.' % learner_dev, file=sys.stderr)
+  return True
+
+
 def launch(config, max_moves, selfplay_only=False, learner_steps=None, state=None):
   """train.launch (train.py:62-78); state: a checkpoint written by Learner.save_state (--load_state, train.py:130-134): the
   learner resumes weights, optimiser, training step and throughput totals (learners.py:62-70), every actor its weights,
   training step and game count (actors.py:75-79)"""
   ray.init()
-  if (not selfplay_only and {'actors', 'learner'} <= set(getattr(config, 'use_gpu_for', [])) and not getattr(config, 'gpu_turns', False)
-      and torch.cuda.is_available() and torch.cuda.device_count() == 1):
-    print('train: an actor and a learner share the one GPU of this process; two busy queues do not share an MI355X gracefully '
-          '(both lose ~8 x): add --gpu_turns to let them take turns, or give each its own GPU (--ranks N --dedicated_learner_rank)',
-          file=sys.stderr)
+  if not selfplay_only:
+    share_gpu_in_turns(config, range(config.num_actors))
   storage = ray.remote(SharedStorage).remote(config)
   replay = ray.remote(PrioritizedReplay).remote(config)
   actors = [ray.remote(Actor).remote(k, config, storage, replay, state) for k in range(config.num_actors)]
@@ -82,6 +103,7 @@ def launch_ranks(config, max_moves, selfplay_only=False, learner_steps=None, sta
   from . import distributed as D
   from .networks import flat_size, flatten_state, get_network
   import torch.distributed as dist
+  _preflight_ranks(int(os.environ.get('WORLD_SIZE', '1')), config)      # (before this rank touches its GPU)
   rank, world, device, backend = D.init_process_group()
   config.num_actors = world
   config.actors_gpu_device_ids = None                 # every rank's actor runs on the rank's own current device
@@ -96,6 +118,10 @@ def launch_ranks(config, max_moves, selfplay_only=False, learner_steps=None, sta
   run_id = 'mz_%s_%s' % (os.environ.get('MASTER_PORT', '0'), os.environ.get('TORCHELASTIC_RUN_ID', 'run'))
   ray.init()
   rings, storage, replay, learner, stop = {}, None, None, None, threading.Event()
+  if rank == 0 and not selfplay_only and not (bool(getattr(config, 'dedicated_learner_rank', False)) and world > 1):
+    # rank 0 runs actor 0 AND the learner on one GPU: they take turns (share_gpu_in_turns, decided before either exists); without
+    # turns rank 0 would run at a fraction of the other ranks' pace and every rank would wait for it at each collective weight pull
+    share_gpu_in_turns(config, [0])
   if rank == 0:
     storage = ray.remote(SharedStorage).remote(config)
     if not getattr(config, 'ingest_threads', None) and world > 4:
@@ -129,11 +155,12 @@ def launch_ranks(config, max_moves, selfplay_only=False, learner_steps=None, sta
     actor_replay = D.RingReplay(ring)
   del probe
   dedicated = bool(getattr(config, 'dedicated_learner_rank', False)) and world > 1 and not selfplay_only
+
   if dedicated and config.environment == 'TicTacToe' and (getattr(config, 'parity_rng', False) or B == 1):
     raise SystemExit('--dedicated_learner_rank: host-environment actors pull weights per game, not per move count')
   if dedicated and rank == 0:
-    # rank 0's GPU belongs to the learner alone (an actor beside it would take turns with it, gpu_turns.py, run at a
-    # fraction of the other ranks' pace and hold every rank back at each collective weight pull): rank 0 only joins the
+    # rank 0's GPU belongs to the learner alone (an actor beside it takes turns with it -- share_gpu_in_turns -- and so runs at
+    # about half the other ranks' pace, holding every rank back at each collective weight pull): rank 0 only joins the
     # collectives, at the cadence the actors' loops enter them (Actor.run_selfplay)
     actor = _CollectiveOnly(rank, config, rstorage, chunk)
   else:
@@ -208,6 +235,22 @@ class _CollectiveOnly(object):
     self._sync()
 
 
+def _preflight_ranks(n, config):
+  """distributed.preflight for `train --ranks n`: devices, /dev/shm for the n - 1 experience rings, host cores -- before any GPU call"""
+  from . import distributed as D
+  from .actors import selfplay_chunk
+  try:
+    O, A = int(np.prod(config.obs_space)), int(config.action_space)
+    rec = ((O + 3) // 4 if getattr(config, 'obs_u8', False) else O) + A + 10
+    need = D.ring_bytes(n, selfplay_chunk(config), int(config.num_envs), rec)
+  except (AttributeError, TypeError, ValueError):
+    need = 0
+  need = int(os.environ.get('MZ_PREFLIGHT_SHM_NEED', '0')) or need
+  shared = os.environ.get('MZ_DIST_BACKEND', 'nccl') == 'gloo' or os.environ.get('MZ_SHARED_GPU_OK', '0')[:1] == '1'
+  threads = int(getattr(config, 'ingest_threads', 0) or 0) or (min(8, n) if n > 4 else 1)
+  return D.preflight(n, shm_need=need, ingest_threads=min(threads, 4), shared_gpu_ok=shared)
+
+
 def _spawn_ranks(n, argv):
   """`train --ranks N` without a launcher: start `python -m torch.distributed.run` as a child (before anything in
   this process touches a GPU) and hand its exit code on."""
@@ -249,8 +292,7 @@ def main(argv=None):
       if not args.get('prime_moves'):
         args['prime_moves'] = 768
   ranks = args.pop('ranks')
-  if ranks and 'RANK' not in os.environ:
-    raise SystemExit(_spawn_ranks(ranks, argv))
+  spawn = bool(ranks) and 'RANK' not in os.environ
   if max_moves is not None and max_moves < 0:
     max_moves = None              # run until the learner has reached --training_steps (actors.py:93)
   load_state = args.pop('load_state')
@@ -278,6 +320,9 @@ def main(argv=None):
     cfg.seed = 0
   if cfg.run_tag is None:           # train.py:83-90: a date-stamped run directory (the launcher's start time under --ranks)
     cfg.run_tag = os.environ.get('MZ_RUN_TAG') or time.strftime('%Y-%m-%d_%H-%M-%S')
+  if spawn:                         # `train --ranks N` without a launcher: pre-flight here (one sentence instead of N tracebacks), then the ranks
+    _preflight_ranks(ranks, cfg)
+    raise SystemExit(_spawn_ranks(ranks, argv))
   if 'RANK' in os.environ and int(os.environ.get('WORLD_SIZE', '1')) >= 1 and ranks:
     return launch_ranks(cfg, max_moves, selfplay_only, learner_steps, state)
   return launch(cfg, max_moves, selfplay_only, learner_steps, state)

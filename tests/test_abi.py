@@ -11,10 +11,14 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-  text = open(os.path.join(ROOT, 'include', 'mz_engine.h')).read()
-  text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
-  return sorted(set(re.findall(r'\b(mz_[a-z_0-9]+)\s*\(', text)))
+def declared_symbols(headers=('mz_engine.h', 'mz_engine_debug.h')):
+  """the boundary (mz_engine.h) and the instrumentation / test hooks kept apart from it (mz_engine_debug.h)"""
+  out = set()
+  for h in headers:
+    text = open(os.path.join(ROOT, 'include', h)).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    out |= set(re.findall(r'\b(mz_[a-z_0-9]+)\s*\(', text))
+  return sorted(out)
 
 
 def test_header_symbols_exported():
@@ -27,6 +31,10 @@ def test_header_symbols_exported():
     assert hasattr(lib, s), 'libmz_hip.so does not export %s' % s
   assert set(_abi.SIGNATURES) == set(syms), set(_abi.SIGNATURES) ^ set(syms)
   assert lib.mz_version() == 1
+  # the boundary header carries no profiling / test instrumentation (VERDICT r05 hygiene): those live in mz_engine_debug.h
+  boundary, debug = set(declared_symbols(('mz_engine.h',))), set(declared_symbols(('mz_engine_debug.h',)))
+  assert not (boundary & debug) and len(debug) >= 15
+  assert not [s for s in boundary if re.search(r'profile|timed|_stats|read_tape|read_grad|sim_io|noise_log|phase_spread', s)], boundary
 
 
 def test_replay_header_symbols_exported():
@@ -57,6 +65,7 @@ def test_config_struct_size_matches_c():
 
 def test_header_is_plain_c():
   subprocess.check_call(['gcc', '-std=c99', '-fsyntax-only', '-x', 'c', os.path.join(ROOT, 'include', 'mz_engine.h')])
+  subprocess.check_call(['gcc', '-std=c99', '-fsyntax-only', '-x', 'c', os.path.join(ROOT, 'include', 'mz_engine_debug.h')])
 
 
 def test_no_cpu_fallback():

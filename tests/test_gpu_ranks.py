@@ -120,7 +120,7 @@ def test_train_two_ranks_learner_broadcast_and_one_replay():
 
 def test_bench_over_rccl_at_world_size_1():
   """MZ_BENCH_FORCE_DIST=1 under the launcher with ONE process: bench.py takes its multi-rank branch over backend "nccl"
-  (= RCCL on ROCm): init_process_group on the device, broadcast_flat of the weights INTO DEVICE MEMORY at every pull, the
+  (= RCCL on ROCm): init_process_group on the device, mz_broadcast_weights of the weights INTO DEVICE MEMORY at every pull, the
   MAX / SUM all-reduces, barriers, destroy_process_group.  librccl must be mapped in the rank's process."""
   B, steps = 256, 16
   env = dict(os.environ, MZ_BENCH_FORCE_DIST='1', MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
@@ -134,6 +134,12 @@ def test_bench_over_rccl_at_world_size_1():
   c = line['collectives']
   assert c['backend'] == 'nccl' and c['world'] == 1 and c['forced_at_world_1'] and c['rccl_mapped'] and c['weights_on_device']
   assert c['broadcast'].startswith('mz_broadcast_weights')            # ncclBroadcast from libmz_hip.so, on a side stream
+  # what makes the first 8-GPU record self-diagnosing: RCCL's own rank count, no fallback, the broadcast's
+  # HIP-event time, per-rank values, the build the line was measured on
+  assert c['ranks_in_comm'] == 1 and c['fallback_reason'] is None and c['native_rccl_broadcast'] and c['broadcasts'] >= 2
+  assert c['broadcast_us']['clock'].startswith('HIP events') and 0 < c['broadcast_us']['mean'] <= c['broadcast_us']['max'] < 1e5
+  assert len(line['per_rank_values']) == 1 and abs(line['per_rank_values'][0] - line['value']) < 0.05 * line['value']
+  assert len(line['build_id']) == 16 and line['efficiency_vs_n1'] is None and line['preflight'] is None
   assert '0 pipeline drains' in line['config']['weight_sync']
   assert line['n_gpus'] == 1 and line['metric'].startswith('env-steps/sec') and line['value'] > 0
   pulls = int(line['config']['weight_sync'].split(':')[1].split()[0])
@@ -159,6 +165,8 @@ def test_bench_falls_back_to_torch_collectives_when_the_communicator_fails():
   c = line['collectives']
   assert c['backend'] == 'nccl' and c['broadcast'].startswith('torch.distributed') and c['weights_on_device']
   assert 'falling back' in out.stderr and line['value'] > 0
+  assert 'MZ_COMM_FAIL' in c['fallback_reason'] and not c['native_rccl_broadcast'] and c['ranks_in_comm'] is None      # the record says why
+  assert c['broadcast_us']['clock'].startswith('host wall time')
   assert int(line['config']['weight_sync'].split(':')[1].split()[0]) >= 2
 
 
@@ -250,6 +258,13 @@ def test_bench_eight_ranks_on_one_gpu():
   assert o['host_cores_busy_all_ranks'] <= line['usable_host_cores']
   pulls = int(line['config']['weight_sync'].split(':')[1].split()[0])
   assert pulls >= 2
+  # the self-diagnosing keys of an N > 1 line
+  c = line['collectives']
+  assert c['fallback_reason'] == 'backend gloo' and c['broadcasts'] >= 2 and len(c['broadcast_us']['per_rank_mean']) == N
+  assert len(line['per_rank_values']) == N and abs(sum(line['per_rank_values']) - line['value']) < 0.25 * line['value']
+  assert line['preflight']['ranks'] == N and line['preflight']['shm_need_bytes'] == (N - 1) * (64 + 4 * (8 + 16 * B * 22 * 4))
+  eff = line['efficiency_vs_n1']
+  assert eff is None or (eff['efficiency'] > 0 and eff['n1_file'].endswith('.json'))
   profile = os.environ.get('MZ_SAVE_PROFILE')          # (scripts/round_profile.sh keeps the line under profiles/)
   if profile:
     open(profile, 'w').write(json.dumps(line, indent=1))

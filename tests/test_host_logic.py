@@ -147,7 +147,9 @@ def test_bench_times_the_products_entry_points():
   assert len(loops) == 1 and isinstance(loops[0], ast.For)                 # `for _ in range(n_runs)`: one region per pass
   calls = [n.func.attr for n in ast.walk(fn[0]) if isinstance(n, ast.Call) and isinstance(n.func, ast.Attribute)]
   assert calls.count('launch') == 1
-  assert set(calls) <= {'launch', 'barrier', 'frames', 'perf_counter', 'process_time', 'tensor', 'all_reduce', 'item', 'append'}, set(calls)
+  # (all_gather / zeros_like: the per-rank frames and clocks of the N > 1 line, collected AFTER the region's second clock read)
+  assert set(calls) <= {'launch', 'barrier', 'frames', 'perf_counter', 'process_time', 'tensor', 'all_reduce', 'all_gather', 'zeros_like',
+                        'item', 'append'}, set(calls)
   src = open(os.path.join(root, 'bench.py')).read()
   assert 'class Pipeline' not in src and 'ingest_records(' not in src and 'selfplay_steps(' not in src
   # the learner line: the timed statement is learner.launch.remote(updates) through the handle

@@ -242,6 +242,31 @@ def test_parallel_ingest_is_bit_identical_to_one_thread(T, mhl, window):
       assert np.array_equal(np.asarray(v), np.asarray(other[k])) if not isinstance(v, dict) else v == other[k], k
 
 
+def test_large_batches_sampled_over_the_pool_equal_one_thread():
+  """mzr_sample_batch spreads a batch's blocks of 128 samples over the replay's thread pool (batch >= 512; the learner's native
+  loop samples one batch per update: bench.py --workload learner --batch 2048): every output of sample_batch -- indices,
+  observations, actions, the three targets, the importance weights -- is the one-thread result, bit for bit, at batch sizes that are
+  and are not multiples of the block."""
+  import random
+  from model_based_rl_amd.replay_buffer import PrioritizedReplay
+  O, A, B, moves = 5, 3, 203, 96
+  rec = _bulk_records(np.random.RandomState(11), moves, B, O, A, 40)
+  for bs in (512, 1000, 2048):
+    results = []
+    for threads in (1, 4, 7):
+      rep = PrioritizedReplay(make_cfg(obs_space=(O,), action_space=A, max_history_length=500, window_size=1 << 15, discount=0.997,
+                                       ingest_threads=threads, batch_size=bs))
+      for lo in range(0, moves, 8):
+        rep.ingest_records(rec[lo:lo + 8], 8, B)
+      random.seed(5); np.random.seed(6)
+      (obs, actions, (t_rew, t_val, t_pol)), idxs, isw = rep.sample_batch()
+      assert np.asarray(idxs).shape == (bs,)
+      results.append(dict(obs=obs, actions=np.asarray(actions), t_rew=t_rew, t_val=t_val, t_pol=t_pol, idxs=np.asarray(idxs), isw=isw))
+    for other in results[1:]:
+      for k, v in results[0].items():
+        assert np.array_equal(np.asarray(v), np.asarray(other[k])), (bs, k)
+
+
 def test_ingest_records_refuses_what_records_cannot_express():
   """Device records carry ONE end-of-game flag: a replay configured with --episode_life (terminal != done, game.py:90)
   must refuse them loudly instead of miscounting games; save_history, which takes `terminal` explicitly, still works.
