@@ -563,17 +563,14 @@ def main():
   print('total fixture bytes', total)
 
 
-if __name__ == '__main__' and (len(sys.argv) < 2 or sys.argv[-1] not in ('learner', 'refresh')):
+if __name__ == '__main__' and (len(sys.argv) < 2 or sys.argv[-1] not in ('learner', 'refresh', 'learner_conv')):
   main()
 
 
 # ----------------------------------------------------------------------------- G5: learner step
-def gen_learner(outdir):
-  """One Learner.update_weights step (learners.py:164-230) of the UNMODIFIED reference on the batch recorded in
-  g3_game_ttt_0 (G4).  learners.py / utils.py / wrappers.py / logger.py import ray, gym, cv2 and tensorboard, none of
-  which is installed; they are replaced by empty stand-in modules for the IMPORT only (nothing of them is executed on
-  this path: the environment is the reference's own TicTacToe, logging calls are no-ops)."""
-  import tempfile
+def _stand_in_modules():
+  """learners.py / utils.py / wrappers.py / logger.py import ray, gym, cv2 and tensorboard, none of which is installed: empty
+  stand-in MODULES for the import only (nothing of them runs on the update_weights path)"""
   ray = types.ModuleType('ray'); ray.remote = lambda c: c; ray.get = lambda x: x
   sys.modules['ray'] = ray
   gym = types.ModuleType('gym')
@@ -595,7 +592,17 @@ def gen_learner(outdir):
     def add_histogram(self, *a, **k): pass
   tb.SummaryWriter = SW
   sys.modules['torch.utils.tensorboard'] = tb
-  sys.path.insert(0, REF)
+  if REF not in sys.path:
+    sys.path.insert(0, REF)
+
+
+def gen_learner(outdir):
+  """One Learner.update_weights step (learners.py:164-230) of the UNMODIFIED reference on the batch recorded in
+  g3_game_ttt_0 (G4).  learners.py / utils.py / wrappers.py / logger.py import ray, gym, cv2 and tensorboard, none of
+  which is installed; they are replaced by empty stand-in modules for the IMPORT only (nothing of them is executed on
+  this path: the environment is the reference's own TicTacToe, logging calls are no-ops)."""
+  import tempfile
+  _stand_in_modules()
   import config as rconfig
   import learners as rlearners
   g = np.load(os.path.join(outdir, 'g3_game_ttt_0.npz'))
@@ -742,4 +749,100 @@ if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[-1] == 'learner':
   _out = os.path.abspath(os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden'))
   gen_learner(_out)
   gen_learner_synth(_out, 'g5_learner_lunar', ['--environment', 'LunarLander-v2'], 8, 4, 256, 11)
-  gen_learner_synth(_out, 'g5_learner_pong', ['--environment', 'Pong-ramNoFrameskip-v4', '--norm_obs', '--obs_range', '0', '255'], 128, 6, 64, 12)
+  gen_learner_synth(_out, 'g5_learner_pong', ['--environment', 'Pong-ramNoFrameskip-v4', '--norm_obs', '--obs_range', '0', '255'], 128, 6, 256, 12)      # (batch 256: the size the configs run; 64 until r05)
+
+
+def conv_batch(seed, bs, C, A, K):
+  """the seeded synthetic image batch of g5_learner_conv (tests/test_learner.py regenerates it from the seed: numpy's legacy
+  RandomState stream is stable by NEP 19): byte frames as the replay hands them over (np.float32(obs), learners.py:170-172
+  normalises), actions, targets with absorbing steps, importance weights"""
+  rng = np.random.RandomState(seed)
+  obs = rng.randint(0, 256, size=(bs, C, 96, 96)).astype(np.float32)
+  actions = rng.randint(0, A, size=(bs, K))
+  t_rew = rng.uniform(-1, 1, size=(bs, K + 1)).astype(np.float32)
+  t_val = rng.uniform(-4, 4, size=(bs, K + 1)).astype(np.float32)
+  t_pol = rng.dirichlet([0.5] * A, size=(bs, K + 1)).astype(np.float32)
+  t_pol[rng.rand(bs, K + 1) < 0.05] = 0.0
+  w = rng.uniform(0.2, 1.0, size=bs); w /= w.max()
+  idxs = rng.randint(59999, 119999, size=bs)
+  return obs, actions, t_rew, t_val, t_pol, w, idxs
+
+
+def gen_learner_conv(outdir, name='g5_learner_conv', arch='TinyNetwork', C=4, A=4, bs=8, seed=5, batch_seed=21):
+  """Two Learner.update_weights steps (learners.py:164-230) of the UNMODIFIED reference with a conv network (TinyNetwork,
+  networks.py:657-718; BASELINE.json configs[4] names the conv networks) on a seeded synthetic image batch.  16 MB of weights
+  do not travel (the G6 recipe): the build constructs its modules in the reference's order under the same seed
+  (set_all_seeds(config.seed), learners.py:18, utils.py:136-144), pinned here by per-tensor checksums of the INITIAL weights;
+  after each step: per-tensor float64 sums and absolute sums of every state_dict entry (BatchNorm statistics and batch counters
+  included; tensors of <= 4096 elements in full), the three loss sums, the priorities' new errors."""
+  import tempfile
+  _stand_in_modules()
+  import config as rconfig
+  import learners as rlearners
+  import networks as rnetworks
+  old = sys.argv
+  sys.argv = ['train.py', '--environment', 'BreakoutNoFrameskip-v4', '--architecture', arch, '--stack_obs', str(C), '--norm_obs', '--obs_range', '0', '255',
+              '--seed', str(seed), '--batch_size', str(bs), '--window_size', '60000', '--run_tag', 'g5', '--group_tag', 'g5']
+  try:
+    cfg = rconfig.make_config()
+  finally:
+    sys.argv = old
+  for key in ('seed', 'num_actors', 'lr_init', 'discount', 'window_size', 'window_step', 'batch_size', 'num_simulations',
+              'num_unroll_steps', 'td_steps'):
+    setattr(cfg, key, getattr(cfg, key)[0])
+  cfg.action_space, cfg.obs_space = A, (C, 96, 96)
+
+  class Sink(object):
+    def __init__(self): self.calls = []
+    def __getattr__(self, nm):
+      sink = self
+      class M(object):
+        def remote(self_, *a, **k):
+          sink.calls.append((nm, a, k)); return None
+      return M()
+  replay, storage = Sink(), Sink()
+  probe = rlearners.get_network
+  # (utils.get_network probes the environment through gym.make -- not installed; the direct construction SURVEY.md s8c prescribes)
+  rlearners.get_network = lambda config, device=None: getattr(rnetworks, arch)(C, A, device, config)
+  cwd = os.getcwd()
+  os.chdir(tempfile.mkdtemp())
+  try:
+    learner = rlearners.Learner(cfg, storage, replay)
+  finally:
+    os.chdir(cwd)
+    rlearners.get_network = probe
+  K = cfg.num_unroll_steps
+  obs, actions, t_rew, t_val, t_pol, w, idxs = conv_batch(batch_seed, bs, C, A, K)
+
+  def sums(tag, out):
+    sd = learner.network.state_dict()
+    keys = list(sd.keys())
+    out['keys'] = np.array(keys)
+    out[tag + '.sums'] = np.array([sd[k].detach().numpy().astype(np.float64).sum() for k in keys])
+    out[tag + '.abs_sums'] = np.array([np.abs(sd[k].detach().numpy().astype(np.float64)).sum() for k in keys])
+    out['numel'] = np.array([sd[k].numel() for k in keys], np.int64)
+    for k in keys:
+      if sd[k].numel() <= 4096:
+        out[tag + '.full.' + k] = sd[k].detach().numpy().copy()
+  out = dict(arch=np.array(arch), C=np.int32(C), A=np.int32(A), bs=np.int32(bs), K=np.int32(K), seed=np.int32(seed), batch_seed=np.int32(batch_seed),
+             obs_sum=np.float64(obs.astype(np.float64).sum()), lr_init=np.float64(cfg.lr_init), weight_decay=np.float64(cfg.weight_decay))
+  sums('w0', out)
+  batch = ((obs.copy(), actions.tolist(), (t_rew.copy(), t_val.copy(), t_pol.copy())), idxs.tolist(), w.copy())
+  step_losses = []
+  for step in range(2):
+    before = dict(learner.losses_to_log)
+    learner.update_weights(batch)
+    step_losses.append([learner.losses_to_log[k] - before[k] for k in ('reward', 'value', 'policy')])
+    sums('w%d' % (step + 1), out)
+  out['losses'] = np.array([learner.losses_to_log['reward'], learner.losses_to_log['value'], learner.losses_to_log['policy']])
+  out['step_losses'] = np.array(step_losses)
+  upd = [c for c in replay.calls if c[0] == 'update']
+  out['new_errors'] = np.stack([np.asarray(c[1][1], np.float64) for c in upd])
+  np.savez_compressed(os.path.join(outdir, name), **out)
+  print(name, ': losses (sum of 2 steps)', out['losses'], 'per step', out['step_losses'].tolist(), 'tensors', len(out['keys']),
+        'bytes', os.path.getsize(os.path.join(outdir, name + '.npz')))
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[-1] == 'learner_conv':
+  torch.set_num_threads(1)
+  gen_learner_conv(os.path.abspath(os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden')))
