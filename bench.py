@@ -296,15 +296,15 @@ def live_traffic(workload, split_f16, chunk):
           'launches': [means['FETCH_SIZE'][1], means['WRITE_SIZE'][1]]}
 
 
-def measure_split_f16(device, weights, chunk, moves=384):
-  """Short measurement of the opt-in split-f16 search kernel (mz_config.split_f16, `--split_f16`) on the headline workload,
-  through the SAME product loop as `value` -- an Actor of its own (storage, native replay) driven by Actor.launch: frames
-  accepted by the replay per second over `moves` moves, and the search kernel's launch duration."""
+def measure_actor(device, weights, chunk, moves=384, split_f16=False, run_tag='bench_secondary'):
+  """Short measurement of the headline workload with another weight set / kernel variant, through the SAME product loop as `value`
+  -- an Actor of its own (storage, native replay) driven by Actor.launch: frames accepted by the replay per second over `moves`
+  moves, and the search kernel's launch duration (HIP events on its dispatches)."""
   from model_based_rl_amd import rayshim as ray
   from model_based_rl_amd.actors import Actor
   from model_based_rl_amd.replay_buffer import PrioritizedReplay
   from model_based_rl_amd.shared_storage import SharedStorage
-  cfg = bench_config(WNAME, B, SIMS, EPISODE_LEN, 1, 1 << 20, ingest_threads_for(1), split_f16=True, run_tag='bench_split_f16')
+  cfg = bench_config(WNAME, B, SIMS, EPISODE_LEN, 1, 1 << 20, ingest_threads_for(1), split_f16=split_f16, run_tag=run_tag)
   cfg.selfplay_chunk = chunk
   storage, replay = ray.remote(SharedStorage).remote(cfg), ray.remote(PrioritizedReplay).remote(cfg)
   storage.store_weights.remote(weights, 1).result()
@@ -330,12 +330,82 @@ def measure_split_f16(device, weights, chunk, moves=384):
   persistent = eng.selfplay_moves_per_launch() > 0      # whole moves inside the launch: `us` then includes the (f32) root
   actor.close()
   eng.close()
-  return {'what': 'mz_config.split_f16 = 1: FCNetwork GEMMs as float16 high/low splits on v_mfma_f32_16x16x32_f16, f32 '
-                  'accumulation; float32-level accuracy (every parity test passes), not bit-identical to the exact-f32 path',
-          'env_steps_per_s': frames / dt, 'counted': 'frames accepted by the replay (Actor.launch, the same loop as `value`)',
+  return {'env_steps_per_s': frames / dt, 'counted': 'frames accepted by the replay (Actor.launch, the same loop as `value`)',
           'env_steps_executed_per_s': B * moves / dt, 'ms_per_step': 1e3 * dt / moves,
           'kernel_us_per_move': us, 'root_inside_the_launch': persistent, 'moves': moves,
           'algorithmic_tflops': (SIMS * FLOP_PER_SIM + (FLOP_PER_ROOT if persistent else 0)) * B / (us * 1e-6) / 1e12}
+
+
+def measure_split_f16(device, weights, chunk, moves=384):
+  """the opt-in split-f16 search kernel (mz_config.split_f16, `--split_f16`) on the headline workload (measure_actor)"""
+  out = {'what': 'mz_config.split_f16 = 1: FCNetwork GEMMs as float16 high/low splits on v_mfma_f32_16x16x32_f16, f32 '
+                 'accumulation; float32-level accuracy (every parity test passes), not bit-identical to the exact-f32 path'}
+  out.update(measure_actor(device, weights, chunk, moves, split_f16=True, run_tag='bench_split_f16'))
+  return out
+
+
+def sharpened(weights, gain):
+  """the weight set with the policy head's output layer times `gain`: logits x gain => sharper priors => the search commits to
+  fewer children and descends deeper -- what a TRAINED policy does to the tree (the reference's actors run trained weights,
+  actors.py:81-85; the headline runs torch.manual_seed(0) weights as SURVEY.md s8d prescribes).  Parity is untouched: it is a
+  weight set like any other."""
+  w = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in weights.items()}
+  for k in ('policy_head.policy.weight', 'policy_head.policy.bias'):
+    w[k] = w[k] * float(gain)
+  return w
+
+
+def leaf_depths(eng, obs_dim, n_trees):
+  """mean / max depth of the leaves one search expands (one move of `n_trees` trees of this engine): node n > 0 is child
+  (n - 1) % A of the node with expansion index (n - 1) // A; expansion indices are assigned in order"""
+  eng.initial_inference(torch.randn(n_trees, obs_dim, device=eng.device))
+  eng.root_prepare(None, None, None, device_rng=True, move=0)
+  eng.search()
+  E = eng.export_tree()['E']
+  A_ = eng.A
+  ds = []
+  for b in range(E.shape[0]):
+    nodes = np.flatnonzero(E[b] >= 0)
+    dep = {0: 0}
+    for e, n in sorted((int(E[b, n]), int(n)) for n in nodes if n != 0):
+      dep[e] = dep[(n - 1) // A_] + 1
+    ds += [v for k, v in dep.items() if k != 0]
+  ds = np.array(ds)
+  return float(ds.mean()), int(ds.max())
+
+
+def depth_sensitivity(device, weights, chunk, gains=(1, 2, 4, 8)):
+  """the headline at realistic tree depth.  For every policy gain: env-steps/s through Actor.launch, the search
+  kernel's roofline fraction, mean / max leaf depth of a search, and the two phases of a simulation that grow with depth -- the
+  descent (`t_select`) and the barrier wait for the deepest of a workgroup's 16 trees (`bar`) -- from the stamped build
+  (mz_search_phase_profile: cycles per simulation, wave 0, mean over workgroups)."""
+  from model_based_rl_amd.engine import Engine
+  rows = []
+  base = None
+  for g in gains:
+    w = sharpened(weights, g)
+    m = measure_actor(device, w, chunk, moves=256, run_tag='bench_gain_%g' % g)
+    eng = Engine(B, O, A, SIMS, seed=1, device=device)
+    eng.set_weights(w)
+    mean_d, max_d = leaf_depths(eng, O, B)
+    obs = torch.randn(B, O, device=device)
+    for it in range(2):
+      eng.initial_inference(obs); eng.root_prepare(None, None, None, device_rng=True, move=it)
+      c = eng.search_phase_profile()
+    eng.close()
+    cyc = {'bar': float(c[0, 1]) / SIMS, 't_select': float(c[0, 12]) / SIMS, 't_backup': float(c[0, 11]) / SIMS, 'total': float(c[0].sum()) / SIMS}
+    row = {'policy_gain': g, 'env_steps_per_s': m['env_steps_per_s'], 'kernel_us_per_move': m['kernel_us_per_move'],
+           'frac': m['algorithmic_tflops'] / PEAK_F32_MFMA_TFLOPS, 'mean_leaf_depth': mean_d, 'max_leaf_depth': max_d, 'cycles_per_sim_wave0': cyc}
+    if base is None:
+      base = row
+    else:
+      added = cyc['total'] - base['cycles_per_sim_wave0']['total']
+      row['added_cycles_per_sim'] = added
+      row['share_of_added'] = {k: (cyc[k] - base['cycles_per_sim_wave0'][k]) / added if added > 0 else None for k in ('bar', 't_select', 't_backup')}
+    rows.append(row)
+  return {'what': 'policy-head output layer x gain (sharper priors => deeper trees; random-init weights otherwise): the LunarLander-shape '
+                  'line at the tree depths a trained policy produces; gain 1 = the headline\'s weights',
+          'rows': rows}
 
 
 def ingest_threads_for(world, one_replay_rank0=False):
@@ -407,6 +477,10 @@ def main():
   ap.add_argument('--ingest-threads', type=int, default=None, help='ingest threads per replay (default: from usable cores / ranks)')
   ap.add_argument('--no-live-traffic', action='store_true',
                   help='do not measure roofline.traffic with two rocprofv3 --pmc child runs (N = 1 only; ~20 s)')
+  ap.add_argument('--policy-gain', '--policy_gain', type=float, default=1.0,
+                  help='policy-head output layer x gain for the WHOLE run (sharper priors, deeper trees; secondary line when != 1)')
+  ap.add_argument('--no-depth-sensitivity', action='store_true',
+                  help='skip the depth_sensitivity block (N = 1, default workload: four short runs at policy gains 1, 2, 4, 8; ~10 s)')
   ap.add_argument('--batch', default=None,
                   help='--workload learner: batch sizes of the sweep, comma separated (default 256,512,1024,2048,4096; the line\'s `value` '
                        'stays the first one -- 256 = the reference\'s batch_size): updates/s, samples/s, roofline.frac and host us per update each')
@@ -488,6 +562,9 @@ def main():
   torch.manual_seed(0)
   net = FCNetwork(O, A, torch.device('cpu'), types.SimpleNamespace()).eval()
   weights = net.get_weights()
+  if args.policy_gain != 1.0:
+    weights = sharpened(weights, args.policy_gain)
+    net.load_state_dict(weights)
   n_flat = int(flatten_weights(weights).numel())
   storage = publisher = None
   if rank == 0:
@@ -836,6 +913,16 @@ def main():
           out['split_f16_secondary'] = measure_split_f16(device, weights, chunk)
       except Exception as exc:          # the headline must not depend on it
         out['split_f16_secondary'] = {'error': str(exc)[:200]}
+    if args.policy_gain != 1.0:
+      out['secondary_line'] = True
+      out['config']['policy_gain'] = args.policy_gain
+    if world == 1 and not args.no_depth_sensitivity and WNAME.startswith('Lunar') and not args.envs and not child and not args.split_f16 \
+       and args.policy_gain == 1.0:
+      try:
+        with contextlib.redirect_stdout(sys.stderr):
+          out['depth_sensitivity'] = depth_sensitivity(device, weights, chunk)
+      except Exception as exc:          # the headline must not depend on it
+        out['depth_sensitivity'] = {'error': str(exc)[:200]}
     if world == 1 and not args.no_cpu_baseline:
       out['cpu_baseline'] = cpu_baseline({k: v.numpy() for k, v in net.state_dict().items()})
       out['cpu_baseline']['reference_shaped'] = cpu_baseline_reference_shaped()

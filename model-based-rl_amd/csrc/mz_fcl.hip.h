@@ -51,6 +51,10 @@ struct FclView {
   float *a1h, *d2h, *d1h, *dH, *lossb;                 // head tapes, [3][K + 1][...][R]
   float *lnpart;                                        // [bs / 4][128] LayerNorm weight / bias gradient partials (per chain workgroup)
   float *new_errors;
+  unsigned *flags;               // fused forward launch (k_fcl_fwd): [bs / 16][K + 1] arrival counters -- chain workgroups whose tapes of (sample group, position) are
+                                 // written through; 4 = all of the group's; zeroed by k_fcl_bwd_dw for the next step
+  int nflags;
+  unsigned *err;                 // [host, device-mapped] set to 1 where a unit's wait for its counter ran into its bound (never on a healthy box)
   float *steps; int nsteps;      // the optimiser's per-parameter step counters (torch keeps one per parameter), advanced by k_fcl_heads; nsteps = 0: not this step
   unsigned long long *prof;      // development: s_memtime stamps of k_fcl_heads' phases (workgroup 0 of every head at position 1), else null
 };
@@ -256,19 +260,43 @@ __device__ __forceinline__ float fcl_max32(float x) {
   return fmaxf(x, __shfl_xor(x, 16, 32));
 }
 
+// ------------------------------------------------------------------------------------------------ in-launch hand-off (k_fcl_fwd)
+// The forward chain hands a position's hidden states to the heads' units of the SAME launch (MI355X_MICROARCH.md, inter-workgroup
+// visibility, first row of the table of forms measured without an acquire): the producer's stores of the handed-off bytes are
+// write-through (sc1: relaxed agent-scope atomic stores), every storing wave waits for them (s_waitcnt vmcnt(0)), a workgroup
+// barrier, then ONE lane adds to the counter (agent scope); the consumer polls the counter with sc1 loads in one lane (bounded),
+// a workgroup barrier, then EVERY load of the handed-off bytes is an sc1 load.
+__device__ __forceinline__ void fcl_store_wt(float *p, float x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float fcl_load_wt(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void fcl_signal(unsigned *flag) { __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// one lane: until *flag >= want, or ~40 ms of the constant 100 MHz clock have passed (then *err = 1 and the caller goes on: the
+// step's numbers are wrong, the launch ends, the host sees the word)
+__device__ __forceinline__ void fcl_wait_flag(const unsigned *flag, unsigned want, unsigned *err) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+    __builtin_amdgcn_s_sleep(8);
+    if (__builtin_amdgcn_s_memrealtime() - t0 > 4000000ull) {
+      if (err) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      break;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ heads
 // grid (bs / 16, K + 1, 3): head 0 value (input h_p), 1 policy (h_p), 2 reward (x_p = [h_{p-1} | one-hot], p >= 1)
-__global__ __launch_bounds__(FCL_THREADS, 4) void k_fcl_heads(FclView v) {
-  extern __shared__ __attribute__((aligned(16))) float fcl_smem[];
+// WAIT: a unit of the fused forward launch -- its inputs come from chain workgroups of the same launch: everything else it needs
+// (fc1's weights, biases, targets) is requested FIRST and arrives while one lane polls the group's counter
+template <bool WAIT>
+__device__ __forceinline__ void fcl_heads_body(const FclView &v, const int cb, const int p, const int hd, float *fcl_smem) {
   float *X = fcl_smem, *A1 = X + 1024, *redf = A1 + 8192, *Y = redf + 8192, *S = Y + 1024, *PV = S + 1024;
   f32x4 *red = (f32x4 *)redf;
   const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, g4 = lane >> 4, m16 = lane & 15;
-  const int row0 = blockIdx.x * 16, p = blockIdx.y, hd = blockIdx.z, R = v.R, K1 = v.K + 1, loff = fcl_lane_off(lane), cb = blockIdx.x;
+  const int row0 = cb * 16, R = v.R, K1 = v.K + 1, loff = fcl_lane_off(lane);
   // (the step counters advance here, two launches ahead of the optimiser code that reads them)
-  if (blockIdx.x == 0 && p == 0 && hd == 0 && tid < v.nsteps) v.steps[tid] += 1.f;
+  if (cb == 0 && p == 0 && hd == 0 && tid < v.nsteps) v.steps[tid] += 1.f;
   if (hd == 2 && p == 0) return;
   int stamp_i = 0;
-#define FCL_STAMP() if (v.prof && blockIdx.x == 0 && p == 1 && tid == 0) v.prof[hd * 16 + stamp_i++] = __builtin_amdgcn_s_memtime();
+#define FCL_STAMP() if (v.prof && cb == 0 && p == 1 && tid == 0) v.prof[hd * 16 + stamp_i++] = __builtin_amdgcn_s_memtime();
   FCL_STAMP()
   const size_t T64 = (size_t)64 * R, T512 = (size_t)512 * R, TX = (size_t)v.XR * R;
   const FclPack &pk = v.head[hd];
@@ -280,11 +308,13 @@ __global__ __launch_bounds__(FCL_THREADS, 4) void k_fcl_heads(FclView v) {
   // weights first and every workgroup's first barrier waited for all 128 KB of them)
   f32x4 WA[16];
   const float *src = hd == 2 ? v.xin + (size_t)p * TX : v.h + (size_t)p * T64;
-  float xs_in[2];
+  float xs_in[2] = {0.f, 0.f};
+  if constexpr (!WAIT) {
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int idx = tid + k * FCL_THREADS;
-    xs_in[k] = src[fcl_tp(hd == 2 ? v.XR : 64, cb, idx >> 4, idx & 15)];
+    for (int k = 0; k < 2; ++k) {
+      const int idx = tid + k * FCL_THREADS;
+      xs_in[k] = src[fcl_tp(hd == 2 ? v.XR : 64, cb, idx >> 4, idx & 15)];
+    }
   }
   const float pv1 = v.P[v.hb1[hd] + tid];
   const float pv2 = (tid < 64 && tid < pk.mout) ? v.P[v.hb2[hd] + tid] : 0.f;
@@ -303,6 +333,16 @@ __global__ __launch_bounds__(FCL_THREADS, 4) void k_fcl_heads(FclView v) {
   asm volatile("" ::: "memory");
   fcl_req_wide(WA, (const f32x4 *)(v.pk + pk.F1), pk.ks1, w, lane);
   asm volatile("" ::: "memory");
+  if constexpr (WAIT) {
+    // hidden states of position p (value, policy) / the transition input of position p = what position p - 1 left (reward)
+    if (tid == 0) fcl_wait_flag(v.flags + (size_t)cb * K1 + (hd == 2 ? p - 1 : p), 4u, v.err);
+    fcl_bar();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int idx = tid + k * FCL_THREADS;
+      xs_in[k] = fcl_load_wt(src + fcl_tp(hd == 2 ? v.XR : 64, cb, idx >> 4, idx & 15));
+    }
+  }
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int idx = tid + k * FCL_THREADS;
@@ -394,6 +434,11 @@ __global__ __launch_bounds__(FCL_THREADS, 4) void k_fcl_heads(FclView v) {
 #undef FCL_STAMP
 }
 
+__global__ __launch_bounds__(FCL_THREADS, 4) void k_fcl_heads(FclView v) {
+  extern __shared__ __attribute__((aligned(16))) float fcl_smem[];
+  fcl_heads_body<false>(v, blockIdx.x, blockIdx.y, blockIdx.z, fcl_smem);
+}
+
 // ------------------------------------------------------------------------------------------------ chain (4 samples per workgroup)
 // The chain is the step's only sequential part.  With 16 samples per workgroup (the 16 x 16 x 4 MFMA's columns, as the
 // heads kernel does) it had batch / 16 workgroups: 16 of 256 CUs at batch 256, 42 + 37 us.  v_mfma_f32_4x4x1_16b_f32 (sixteen 4 x 4 outer products per instruction: 64 output rows x 4 columns x 1 k) has the
@@ -467,18 +512,19 @@ __device__ __forceinline__ f32x4 fcl_quad_stream(const float *__restrict__ pk, i
 __device__ __forceinline__ int fcl_lane_off4(int lane, int n0) { return (lane >> 2) * 64 + n0 + (lane & 3); }
 
 // KP: the transition's fc1 input features (50 + actions), padded: 56 (up to 6 actions) or 64
-template <int KP>
-__global__ __launch_bounds__(FCL_THREADS) void k_fcl_chain_fwd4(FclView v) {
-  extern __shared__ __attribute__((aligned(16))) float fcl_smem[];
+// SIG: a chain workgroup of the fused forward launch -- the tapes the heads read (hidden states, transition inputs) are stored
+// write-through and, one phase later, announced on the group's counter (see "in-launch hand-off")
+template <int KP, bool SIG>
+__device__ __forceinline__ void fcl_chain_fwd4_body(const FclView &v, const int blk, float *fcl_smem) {
   const int LDX = v.xq + 4;
   float *X = fcl_smem, *A1 = X + 4 * LDX, *red = A1 + 4 * FCL_LDA, *misc = red + 2048, *PV = misc + 16;
   float *b1r = PV, *b1t = PV + 512, *b2r = PV + 1024, *b2t = PV + 1088, *lnw = PV + 1152, *lnb = PV + 1216;
   int *acts = (int *)(PV + 1280);          // [4 samples][8]
   float *S = PV + 1408;                    // [4 samples][64] x-hat of the position just finished (for the tapes)
   const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int cb = blockIdx.x >> 2, n0 = 4 * (blockIdx.x & 3), row0 = blockIdx.x * 4, R = v.R, loff = fcl_lane_off4(lane, n0);
+  const int cb = blk >> 2, n0 = 4 * (blk & 3), row0 = blk * 4, R = v.R, loff = fcl_lane_off4(lane, n0);
   const size_t T64 = (size_t)64 * R, T512 = (size_t)512 * R, TX = (size_t)v.XR * R;
-#define FCL_KSTAMP(k) if (v.prof && blockIdx.x == 0 && tid == 0) v.prof[54 + (k)] = __builtin_amdgcn_s_memtime();
+#define FCL_KSTAMP(k) if (v.prof && blk == 0 && tid == 0) v.prof[54 + (k)] = __builtin_amdgcn_s_memtime();
   FCL_KSTAMP(0)      // kernel start
   // Loads return in order: what position 0 needs -- the small parameter vectors, the observations, the representation's
   // fc2 weights -- is requested FIRST; the transition's resident weights (245 KB per workgroup) go out behind position 0's
@@ -522,9 +568,15 @@ __global__ __launch_bounds__(FCL_THREADS) void k_fcl_chain_fwd4(FclView v) {
   fcl_bar();
   FCL_KSTAMP(1)      // observations in LDS
   // (development: stamps of position 2's phases in workgroup 0, mz_fcl_heads_profile, slots 48..)
-#define FCL_CSTAMP(k) if (v.prof && blockIdx.x == 0 && p == 2 && tid == 0) v.prof[48 + (k)] = __builtin_amdgcn_s_memtime();
+#define FCL_CSTAMP(k) if (v.prof && blk == 0 && p == 2 && tid == 0) v.prof[48 + (k)] = __builtin_amdgcn_s_memtime();
   auto rest = [&](int p, f32x4 acc, const float (&W2)[64], const float *b1, const float *b2) __attribute__((always_inline)) {
     FCL_CSTAMP(1)      // fc1 products done
+    if constexpr (SIG) {
+      // the tapes of position p - 1 (stored write-through behind its last barrier, by the upper waves, a phase of MFMAs ago):
+      // every storing wave waits for its stores HERE, before it issues this position's; one lane announces them behind the
+      // barrier that follows the epilogue
+      if (p > 0 && tid >= 256) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     {   // fc1 epilogue: bias, ReLU, to LDS (one 16-byte write: the lane's four features of its sample) and to the tape
       const int f0 = 64 * w + 4 * (lane >> 2);
       const f32x4 b = *(const f32x4 *)(b1 + f0);
@@ -538,6 +590,9 @@ __global__ __launch_bounds__(FCL_THREADS) void k_fcl_chain_fwd4(FclView v) {
       *(f32x4 *)(A1 + (lane & 3) * FCL_LDA + f0) = a;
     }
     fcl_bar();
+    if constexpr (SIG) {
+      if (p > 0 && tid == 0) fcl_signal(v.flags + (size_t)cb * (v.K + 1) + (p - 1));
+    }
     FCL_CSTAMP(2)      // epilogue + barrier
     *(f32x4 *)(red + (w * 64 + lane) * 4) = fcl_quad_res<64>(W2, A1 + (lane & 3) * FCL_LDA + 64 * w);
     fcl_bar();
@@ -585,8 +640,13 @@ __global__ __launch_bounds__(FCL_THREADS) void k_fcl_chain_fwd4(FclView v) {
       const float xv = X[n * LDX + f];
       const size_t tp = fcl_tp(64, cb, f, n0 + n);
       v.xhat[(size_t)p * T64 + tp] = S[n * 64 + f];
-      v.h[(size_t)p * T64 + tp] = f < MZ_H ? xv : 0.f;
-      if (p < v.K) v.xin[(size_t)(p + 1) * TX + fcl_tp(v.XR, cb, f, n0 + n)] = xv;
+      if constexpr (SIG) {
+        fcl_store_wt(v.h + (size_t)p * T64 + tp, f < MZ_H ? xv : 0.f);
+        if (p < v.K) fcl_store_wt(v.xin + (size_t)(p + 1) * TX + fcl_tp(v.XR, cb, f, n0 + n), xv);
+      } else {
+        v.h[(size_t)p * T64 + tp] = f < MZ_H ? xv : 0.f;
+        if (p < v.K) v.xin[(size_t)(p + 1) * TX + fcl_tp(v.XR, cb, f, n0 + n)] = xv;
+      }
       if (t < 4) v.rstd[(size_t)p * R + row0 + t] = misc[t];
     }
   };
@@ -610,6 +670,43 @@ __global__ __launch_bounds__(FCL_THREADS) void k_fcl_chain_fwd4(FclView v) {
 #undef FCL_CSTAMP
   FCL_KSTAMP(4)        // positions 1..K done
 #undef FCL_KSTAMP
+  if constexpr (SIG) {          // the last position's tapes
+    if (tid >= 256) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    fcl_bar();
+    if (tid == 0) fcl_signal(v.flags + (size_t)cb * (v.K + 1) + v.K);
+  }
+}
+
+template <int KP>
+__global__ __launch_bounds__(FCL_THREADS) void k_fcl_chain_fwd4(FclView v) {
+  extern __shared__ __attribute__((aligned(16))) float fcl_smem[];
+  fcl_chain_fwd4_body<KP, false>(v, blockIdx.x, fcl_smem);
+}
+
+// The forward pass of batches up to 256 as ONE launch: the chain's workgroups (blocks [0, nchain): dispatched first, always
+// resident) and, behind them, every heads unit ordered by position (value / policy of position 0, then value / policy / reward of
+// position 1, ...).  A unit starts as soon as its sample group's four chain workgroups have announced its position -- the heads of
+// positions 0 .. K - 1 run on the 192 CUs the chain leaves idle WHILE the chain computes the later positions, and a waiting unit has
+// its weights, biases and targets in flight.  As two launches the heads started when the whole chain had ended, 272 units on 256 CUs
+// (a second round on 16 of them): 23.3 + 1.7 + 24.7 us; a unit never waits for anything but chain workgroups, which are resident
+// from the start of the launch: no deadlock however few units fit beside them.
+template <int KP>
+__global__ __launch_bounds__(FCL_THREADS) void k_fcl_fwd(FclView v, int nchain) {
+  extern __shared__ __attribute__((aligned(16))) float fcl_smem[];
+  if ((int)blockIdx.x < nchain) {
+    fcl_chain_fwd4_body<KP, true>(v, blockIdx.x, fcl_smem);
+    return;
+  }
+  const int G = v.bs >> 4;
+  int u = (int)blockIdx.x - nchain, p, hd, cb;
+  if (u < 2 * G) { p = 0; hd = u / G; cb = u - hd * G; }
+  else {
+    u -= 2 * G;
+    p = 1 + u / (3 * G);
+    const int r = u - (p - 1) * 3 * G;
+    hd = r / G; cb = r - hd * G;
+  }
+  fcl_heads_body<true>(v, cb, p, hd, fcl_smem);
 }
 
 __device__ __forceinline__ void fcl_chain_bwd4_body(const FclView &v, const int blk, float *fcl_smem) {
@@ -1081,6 +1178,8 @@ __global__ __launch_bounds__(256, 2) void k_fcl_dwt(const FclJob *jobs, int njob
 // overlap with a side stream and two events: the cross-stream waits cost what it saved)
 __global__ __launch_bounds__(FCL_THREADS) void k_fcl_bwd_dw(FclView v, int nchain, const FclJob *jobs, FclDw a) {
   extern __shared__ __attribute__((aligned(16))) float fcl_smem[];
+  if (blockIdx.x == 0 && v.flags)          // (the fused forward launch's arrival counters, for the next step)
+    for (int i = threadIdx.x; i < v.nflags; i += FCL_THREADS) v.flags[i] = 0u;
   if ((int)blockIdx.x < nchain) fcl_chain_bwd4_body(v, blockIdx.x, fcl_smem);
   else fcl_dw_job<FCL_NW, 1, 4, 4>(jobs + ((int)blockIdx.x - nchain), 0, a, fcl_smem);
 }

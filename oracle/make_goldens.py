@@ -385,7 +385,7 @@ def gen_net(ref, outdir, name, argv, O, A, seed, save_weights=True):
 
 
 # ----------------------------------------------------------------------------- G2: tree traces
-def gen_tree_traces(ref, outdir, nets):
+def gen_tree_traces(ref, outdir, nets, only=None):
   specs = [
       # name, argv, O, A, fake(scale, tie_prob) or None, temperature, moves
       ('g2_tree_ttt_fc', ['--environment', 'TicTacToe', '--two_players', '--known_bounds', '-1', '1',
@@ -397,8 +397,13 @@ def gen_tree_traces(ref, outdir, nets):
                            '--num_simulations', '30', '--seed', '4'], 9, 9, (2.0, 0.15), 0.25, 32),
       ('g2_tree_fake_bounds', ['--known_bounds', '-2', '2', '--num_simulations', '50', '--seed', '5',
                                '--init_value_score', '0.5'], 8, 6, (4.0, 0.3), 1.0, 16),
+      # 18 actions: more than one 16-lane child group -- the 32-lane two-pass select_child of the kernels meets a REFERENCE-made
+      # tree, not only the oracle's (VERDICT r05 item 5 iii)
+      ('g2_tree_fake_a18', ['--num_simulations', '20', '--seed', '6'], 8, 18, (3.0, 0.15), 1.0, 16),
   ]
   for name, argv, O, A, fake, temp, n_moves in specs:
+    if only is not None and name not in only:
+      continue
     cfg = make_ref_config(ref, argv, A, (O,))
     set_all_seeds(cfg.seed)
     if fake is None:
@@ -540,6 +545,10 @@ def gen_convnets(ref, outdir):
 
 
 def main():
+  if len(sys.argv) > 2 and sys.argv[1] == 'tree':          # one tree-trace fixture by name (the fake-network ones need no weights)
+    torch.set_num_threads(1)
+    gen_tree_traces(_import_reference(), os.path.abspath(os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden')), {}, only=sys.argv[2:])
+    return
   if len(sys.argv) > 1 and sys.argv[1] == 'convnets':
     torch.set_num_threads(1)
     gen_convnets(_import_reference(), os.path.abspath(os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden')))

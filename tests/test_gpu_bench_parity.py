@@ -137,14 +137,25 @@ def test_persistent_launch_on_a_full_grid_vs_oracle(shape, split, ntt):
       print(line)
     ok = wide & same
     assert np.all(same_act[ok]), (m, np.flatnonzero(ok & ~same_act)[:8])
-    assert drv[ok].max() <= (1e-5 if ntt else 5e-4) and derr[ok].max() <= (2e-5 if ntt else 5e-4)      # (ntt: mean of 30 values each within 1e-5; error = difference of two)
+    # Scalars per TREE, derived (a constant 5e-4 until r05): root.value() is the mean of <= sims + 1 backed-up
+    # values, each a discounted sum of network scalars that lie within ONE step of the reference's own float32 staircase
+    # (Config.inverse_transform, config.py:27-33: steps of <= 1.5e-4 (1 + |x|)) -- so the mean moves by at most one step at the
+    # tree's LARGEST scalar; the root error is a difference of two such numbers.  smax: from the device's logged outputs of this move.
+    io_m = log[m].cpu().numpy()
+    smax = np.abs(io_m[:, :, :2]).max(axis=(1, 2)).astype(np.float64)
+    step = 1e-5 if ntt else 1.5e-4 * (1.0 + smax)       # (--no_target_transform: no staircase, 1e-5 on every scalar)
+    assert np.all(drv[ok] <= step[ok]) and np.all(derr[ok] <= 2 * step[ok]), (m, (drv[ok] / step[ok]).max(), (derr[ok] / step[ok]).max())
     assert np.all(np.take_along_axis(cv, rv['action'][m][:, None], -1) > 0)
     if ref.get('tree') is not None:                       # the last move: every integer field of the exported trees
       for k in ('N', 'E'):
         eq = np.all(tree[k] == ref['tree'][k], axis=1)
         assert np.all(eq[wide & same]), (k, np.flatnonzero(wide & same & ~eq)[:8])
       whole = np.all(tree['N'] == ref['tree']['N'], axis=1) & np.all(tree['E'] == ref['tree']['E'], axis=1)
-      assert np.abs(tree['W'][whole] - ref['tree']['W'][whole]).max() <= 5e-3
+      # value sums of whole-identical trees: W of a node = the sum of its N backed-up values, each within one staircase step at
+      # the tree's largest scalar (a constant 5e-3 until r05)
+      dW = np.abs(tree['W'] - ref['tree']['W'])
+      lim = tree['N'].astype(np.float64) * step[:, None] + 1e-12
+      assert np.all(dW[whole] <= lim[whole]), float((dW[whole] / lim[whole]).max())
       assert np.array_equal(tree['noise'], noise)
   eng.sim_io('off')
   eng.close()
