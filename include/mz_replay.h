@@ -101,6 +101,25 @@ int mzr_save_history(mz_replay *r, int64_t n, const double *errors, int64_t igno
 #define MZR_REC_EXTRA 10
 int mzr_ingest_records(mz_replay *r, const float *records, int n_moves, int B, int rec_floats);
 int mzr_ingest_records_from(mz_replay *r, const float *records, int n_moves, int B, int rec_floats, int env_base);
+/* One replay fed by many ranks (train --ranks N): the per-record work of the replay's host that does NOT need the replay is done
+ * by the PRODUCING rank -- mzr_pack_env_major turns a chunk [n_moves][B][rec] into [B][n_moves][rec] while it is copied into the
+ * shared-memory ring (distributed.ShmRing.put), and mzr_ingest_records_packed takes such a chunk: every environment's rows of the
+ * call are one sequential piece, appended run by run.  Same result as mzr_ingest_records_from on the unpacked chunk, bit for bit. */
+/* ... and the per-ENVIRONMENT half of the ingest itself (actors.py:160-173: the open game buffers, the flush rules, history slicing;
+ * replay_buffer.py:110-111: the priorities) runs on the producing rank: an mz_assembler holds what Game / Actor keep per environment,
+ * mzr_asm_feed takes the device loop's chunks ([n_moves][B][rec]), mzr_asm_take writes the slices that fell due, oldest first, as a
+ * blob of at most `cap` bytes (-> bytes, 0 = none queued; mzr_asm_pending: slices still queued), and the replay's host takes a blob
+ * with mzr_ingest_slices: one sequential copy per slice, then the insertion of its leaves.  The replay ends in the state
+ * mzr_ingest_records_from leaves on the same chunks, bit for bit. */
+typedef struct mz_assembler mz_assembler;
+int mzr_asm_create(const mzr_config *cfg, int num_envs, mz_assembler **out);
+int mzr_asm_destroy(mz_assembler *a);
+int mzr_asm_feed(mz_assembler *a, const float *records, int n_moves, int B, int rec_floats);
+int64_t mzr_asm_pending(const mz_assembler *a);
+int64_t mzr_asm_take(mz_assembler *a, void *out, int64_t cap);
+int mzr_ingest_slices(mz_replay *r, const void *blob, int64_t bytes, int env_base);
+void mzr_pack_env_major(const float *src, float *dst, int n_moves, int B, int rec_floats);
+int mzr_ingest_records_packed(mz_replay *r, const float *records, int n_moves, int B, int rec_floats, int env_base);
 
 /* PrioritizedReplay.sample_batch (replay_buffer.py:124-163) + insert_target (165-198) for `bs` stratified
  * draws.  draws[i] is the value the reference obtains from random.uniform(seg*i, seg*(i+1)) (the caller owns

@@ -235,6 +235,14 @@ REPLAY_SIGNATURES = {
     'mzr_save_history': (_I, [_VP, _I64, _VP, _I64, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     'mzr_ingest_records': (_I, [_VP, _VP, _I, _I, _I]),
     'mzr_ingest_records_from': (_I, [_VP, _VP, _I, _I, _I, _I]),
+    'mzr_ingest_records_packed': (_I, [_VP, _VP, _I, _I, _I, _I]),
+    'mzr_pack_env_major': (None, [_VP, _VP, _I, _I, _I]),
+    'mzr_asm_create': (_I, [C.POINTER(MzrConfig), _I, C.POINTER(_VP)]),
+    'mzr_asm_destroy': (_I, [_VP]),
+    'mzr_asm_feed': (_I, [_VP, _VP, _I, _I, _I]),
+    'mzr_asm_pending': (_I64, [_VP]),
+    'mzr_asm_take': (_I64, [_VP, _VP, _I64]),
+    'mzr_ingest_slices': (_I, [_VP, _VP, _I64, _I]),
     'mzr_sample_batch': (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     'mzr_sample_batch_words': (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     'mzr_sample_batches_words': (_I, [_VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),

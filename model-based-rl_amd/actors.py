@@ -446,7 +446,15 @@ class Actor(Logger):
     view = buf[:n].numpy()
     if self.record_tap is not None:
       self.record_tap(view)
-    self._log_games(records_view(view, eng.O, eng.A, obs_u8=eng.obs_packed))
+    rv = records_view(view, eng.O, eng.A, obs_u8=eng.obs_packed)
+    # a weight set whose clamp-ReLU scale the device could not confirm is POISONED with NaN by the repack (k_relu_scale; the host
+    # decided scale_ok on its copy of the weights): such records must not reach the replay unnoticed.  One move's
+    # root values: 4096 doubles per chunk
+    if n > 0 and not np.isfinite(rv['root_value'][n - 1]).all():
+      raise RuntimeError('Actor-%s: non-finite root values in the experience records (move %d): the search ran on a weight set the '
+                         'device-side scale check rejected (mz_weights_scale_ok on the host disagreed), or the weights themselves are '
+                         'not finite' % (self.worker_id if hasattr(self, 'worker_id') else '?', self.move_counter))
+    self._log_games(rv)
     _call(self.replay_buffer, 'ingest_records', buf, n, eng.B, self.env_base)
 
   def _run_selfplay_torch(self, max_moves=None):

@@ -596,36 +596,69 @@ int mzr_ingest_records(mz_replay *r, const float *records, int n_moves, int B, i
 // actors.py:160-173 for the environments [b_lo, b_hi) of one call, environment-major: an env's bookkeeping and the
 // tail of its open buffer are touched once per call instead of once per move.  The slices that fall due are built
 // here (their priorities too); their insertion into the sum tree is deferred (Pending).
-static void ingest_range(mz_replay *r, Scratch &sc, const float *records, int n_moves, int B, int env_base, int b_lo,
-                         int b_hi) {
-  const int OS = r->OS, A = r->c.action_space, R = r->R;
-  const int64_t overlap = r->c.num_unroll_steps + r->c.td_steps;
+// what the per-environment assembly needs of a configuration: the replay's own (direct ingest) or a producing rank's (mz_assembler)
+struct AsmCfg {
+  int OS, A, R;
+  int64_t overlap, max_history_length;
+  double epsilon, alpha;
+};
+static AsmCfg asm_cfg_of(const mzr_config &c, int OS, int R) {
+  return AsmCfg{OS, c.action_space, R, (int64_t)c.num_unroll_steps + c.td_steps, (int64_t)c.max_history_length, c.epsilon, c.alpha};
+}
+
+// env_major: the chunk is [B][n_moves][rec] (mzr_pack_env_major, made by the PRODUCING rank) instead of the device loop's
+// [n_moves][B][rec]: an environment's rows of the call are one contiguous piece -- a sequential read, appended run by run
+static void ingest_range(const AsmCfg &ac, EnvGame *envs, Scratch &sc, const float *records, int n_moves, int B, int env_base, int b_lo,
+                         int b_hi, bool env_major) {
+  const int OS = ac.OS, A = ac.A, R = ac.R;
+  const int64_t overlap = ac.overlap;
   sc.pend.clear(); sc.pris.clear(); sc.pri_off.clear();
   const int PF = 6;       // envs ahead: an env's records lie n_moves strides of B * rec_floats apart (move-major ring),
+  auto row = [&](int b, int m) { return env_major ? records + ((size_t)b * n_moves + m) * R : records + ((size_t)m * B + b) * R; };
   for (int b = b_lo; b < b_hi; ++b) {      // which no hardware prefetcher follows -- request them while the envs before are handled
     if (b + PF < b_hi) {
-      for (int m = 0; m < n_moves; ++m) {
-        const char *q = (const char *)(records + ((size_t)m * B + b + PF) * R);
-        __builtin_prefetch(q, 0, 1);
-        __builtin_prefetch(q + 64, 0, 1);
+      if (env_major) {
+        const char *q = (const char *)row(b + PF, 0);
+        for (int k = 0; k < n_moves * R * 4; k += 64) __builtin_prefetch(q + k, 0, 1);
+      } else {
+        for (int m = 0; m < n_moves; ++m) {
+          const char *q = (const char *)row(b + PF, m);
+          __builtin_prefetch(q, 0, 1);
+          __builtin_prefetch(q + 64, 0, 1);
+        }
       }
-      const EnvGame &gn = r->envs[(size_t)env_base + b + PF];      // and the tail of the open buffer the rows go to
+      const EnvGame &gn = envs[(size_t)env_base + b + PF];      // and the tail of the open buffer the rows go to
       if (!gn.recs.empty()) {
         const char *q = (const char *)(gn.recs.data() + gn.recs.size());
         for (int k = 0; k < n_moves * R * 4; k += 64) __builtin_prefetch(q + k, 1, 1);
       }
     }
-    EnvGame &g = r->envs[(size_t)env_base + b];
+    EnvGame &g = envs[(size_t)env_base + b];
     if (g.recs.capacity() == 0) g.recs.reserve((size_t)64 * R);
-    for (int m = 0; m < n_moves; ++m) {
-      const float *rec = records + ((size_t)m * B + b) * R;
-      const int32_t *ri = (const int32_t *)(rec + OS + A + 5);
-      const bool done = (ri[1] & MZR_FLAG_DONE) != 0;
-      g.recs.insert(g.recs.end(), rec, rec + R);
-      g.history_idx += 1;
+    // runs of moves up to (and including) the next move at which a flush falls due (actors.py:160-169): the run's rows are
+    // appended first -- in ONE piece where the chunk is environment-major -- then the flush, exactly as move by move
+    for (int m0 = 0; m0 < n_moves;) {
+      int e = m0;
+      bool flush = false, done = false;
+      int64_t hidx = g.history_idx;
+      for (; e < n_moves; ++e) {
+        const int32_t *ri = (const int32_t *)(row(b, e) + OS + A + 5);
+        done = (ri[1] & MZR_FLAG_DONE) != 0;
+        ++hidx;
+        if (done || (hidx - g.previous_collect_to) == ac.max_history_length) { flush = true; break; }
+      }
+      const int last = flush ? e : n_moves - 1;
+      if (env_major) {
+        const float *src = row(b, m0);
+        g.recs.insert(g.recs.end(), src, src + (size_t)(last - m0 + 1) * R);
+      } else {
+        for (int m = m0; m <= last; ++m) { const float *rec = row(b, m); g.recs.insert(g.recs.end(), rec, rec + R); }
+      }
+      g.history_idx += last - m0 + 1;
+      m0 = last + 1;
+      if (!flush) break;
+      const int m = e;
       // actors.py:160-169
-      const bool save = (g.history_idx - g.previous_collect_to) == r->c.max_history_length;
-      if (!(save || done)) continue;
       const bool d_prev = g.previous_collect_to == 0 ? done : g.done_at_last_flush;   // dones[prev-1] (index -1 when prev == 0)
       const int64_t collect_from = d_prev ? g.previous_collect_to
                                           : (g.previous_collect_to - overlap > 0 ? g.previous_collect_to - overlap : 0);
@@ -642,23 +675,27 @@ static void ingest_range(mz_replay *r, Scratch &sc, const float *records, int n_
       double *pri = sc.pris.data() + off;
       const float *q = g.recs.data() + (size_t)(collect_from - g.base) * R;
       for (int64_t i = 0; i < n; ++i, q += R) {
-        const double e = fabs(row_double(q + OS + A + 2)) + r->c.epsilon;
-        pri[i] = r->c.alpha == 1.0 ? e : pow(e, r->c.alpha);
+        const double e_ = fabs(row_double(q + OS + A + 2)) + ac.epsilon;
+        pri[i] = ac.alpha == 1.0 ? e_ : pow(e_, ac.alpha);
       }
+      h->off = collect_from - g.base;
       if (done) {           // the game is over: its buffer becomes the slice (run_selfplay starts a new Game, actors.py:94-97)
-        h->off = collect_from - g.base;
         h->rows.swap(g.recs);
         g.recs.clear(); g.base = 0; g.history_idx = 0; g.previous_collect_to = 0; g.done_at_last_flush = false;
-      } else {              // the game goes on: copy the slice, keep only what the next slice can still reach back to
-        const float *src = g.recs.data() + (size_t)(collect_from - g.base) * R;
-        h->rows.assign(src, src + (size_t)n * R);
+      } else {
+        // the game goes on: the buffer becomes the slice too, and the new buffer starts with the rows the next slice can still reach
+        // back to (the last `overlap`: 15 rows copied instead of the slice's max_history_length + overlap -- until r05 the slice was
+        // copied out and the buffer trimmed: one more pass over every record on the ONE replay's host)
         g.previous_collect_to = g.history_idx;
         g.done_at_last_flush = done;
         const int64_t nb = g.history_idx - overlap > 0 ? g.history_idx - overlap : 0;
-        if (nb > g.base) {
-          g.recs.erase(g.recs.begin(), g.recs.begin() + (size_t)(nb - g.base) * R);
-          g.base = nb;
-        }
+        const int64_t from = nb > g.base ? nb : g.base;
+        std::vector<float> tail;
+        tail.reserve((size_t)64 * R > (size_t)(g.history_idx - from + n_moves) * R ? (size_t)64 * R : (size_t)(g.history_idx - from + n_moves) * R);
+        tail.assign(g.recs.begin() + (size_t)(from - g.base) * R, g.recs.end());
+        h->rows.swap(g.recs);
+        g.recs.swap(tail);
+        g.base = from;
       }
       sc.pend.push_back(Pending{m, b, h, keep, nullptr, done});
       sc.pri_off.push_back(off);
@@ -667,7 +704,35 @@ static void ingest_range(mz_replay *r, Scratch &sc, const float *records, int n_
   for (size_t i = 0; i < sc.pend.size(); ++i) sc.pend[i].pri = sc.pris.data() + sc.pri_off[i];
 }
 
+// [n_moves][B][rec] (what the device loop writes) -> [B][n_moves][rec], on the PRODUCING rank (distributed.ShmRing.put: it replaces the
+// plain copy into the ring's slot): rank 0's ONE replay then reads every environment's rows of a chunk as one sequential piece.  Reads
+// strided (prefetched a few environments ahead), writes sequential; n_moves x rec floats per environment.
+void mzr_pack_env_major(const float *src, float *dst, int n_moves, int B, int rec_floats) {
+  const size_t R = (size_t)rec_floats;
+  const int PF = 8;
+  for (int b = 0; b < B; ++b) {
+    if (b + PF < B)
+      for (int m = 0; m < n_moves; ++m) {
+        const char *q = (const char *)(src + ((size_t)m * B + b + PF) * R);
+        __builtin_prefetch(q, 0, 1);
+        __builtin_prefetch(q + 64, 0, 1);
+      }
+    float *d = dst + (size_t)b * n_moves * R;
+    for (int m = 0; m < n_moves; ++m) memcpy(d + (size_t)m * R, src + ((size_t)m * B + b) * R, R * sizeof(float));
+  }
+}
+
+static int ingest_records_impl(mz_replay *r, const float *records, int n_moves, int B, int rec_floats, int env_base, bool env_major);
 int mzr_ingest_records_from(mz_replay *r, const float *records, int n_moves, int B, int rec_floats, int env_base) {
+  return ingest_records_impl(r, records, n_moves, B, rec_floats, env_base, false);
+}
+// the same for a chunk packed by mzr_pack_env_major ([B][n_moves][rec]); the replay's state after the call is the one
+// mzr_ingest_records_from leaves on the unpacked chunk, bit for bit
+int mzr_ingest_records_packed(mz_replay *r, const float *records, int n_moves, int B, int rec_floats, int env_base) {
+  return ingest_records_impl(r, records, n_moves, B, rec_floats, env_base, true);
+}
+
+static int ingest_records_impl(mz_replay *r, const float *records, int n_moves, int B, int rec_floats, int env_base, bool env_major) {
   if (!r || !records) return fail("mzr_ingest_records: null argument");
   MZR_LOCK(r);
   if (n_moves < 0 || B < 1 || env_base < 0) return fail("mzr_ingest_records: bad shape (n_moves %d, B %d, env_base %d)", n_moves, B, env_base);
@@ -683,12 +748,12 @@ int mzr_ingest_records_from(mz_replay *r, const float *records, int n_moves, int
   // replay would see with actors flushing in lock-step
   const int T = r->pool.T < B ? r->pool.T : B;
   if (T <= 1) {
-    ingest_range(r, r->scratch[0], records, n_moves, B, env_base, 0, B);
+    ingest_range(asm_cfg_of(r->c, r->OS, r->R), r->envs.data(), r->scratch[0], records, n_moves, B, env_base, 0, B, env_major);
   } else {
     r->pool.run([&](int tid) {
       if (tid >= T) return;
       const int lo = (int)((int64_t)B * tid / T), hi = (int)((int64_t)B * (tid + 1) / T);
-      ingest_range(r, r->scratch[(size_t)tid], records, n_moves, B, env_base, lo, hi);
+      ingest_range(asm_cfg_of(r->c, r->OS, r->R), r->envs.data(), r->scratch[(size_t)tid], records, n_moves, B, env_base, lo, hi, env_major);
     });
   }
   Job job;
@@ -1004,6 +1069,141 @@ int mzr_sample_batches_full(mz_replay *r, const uint32_t *words, int n, int bs, 
     for (size_t i = 0; i < B; ++i) w[i] /= mx;
   }
   if (pads_out) *pads_out = pads;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ producer-side assembly
+// One replay fed by N ranks (train --ranks N; reference train.py:71-72: every actor sends its history slices to THE replay buffer,
+// actors.py:160-173): the per-ENVIRONMENT half of the ingest -- the open game buffers, the flush rules, history slicing, the
+// priorities (|error| + epsilon)^alpha -- needs nothing of the replay and runs on the PRODUCING rank (mz_assembler: the very code the
+// replay's own direct ingest runs); what travels through the rank's ring is the finished slices.  The replay's host then copies each
+// slice once, sequentially, and inserts its leaves (until r05 it kept N x 4096 open buffers and appended 88-byte records into them
+// round-robin: memory-latency bound, 7 GPUs' worth at four threads).
+//
+// blob: int64 count, then per slice int64 {m, b, n, keep, done, pad} | n x R float rows (padded to 8 bytes) | n double priorities.
+struct mz_assembler {
+  AsmCfg ac;
+  int B = 0;
+  std::vector<EnvGame> envs;
+  Scratch sc;
+  std::deque<Pending> ready;             // finished slices not yet taken, (chunk, move, env) order; pri owned below
+  std::deque<std::vector<double>> ready_pri;
+};
+
+int mzr_asm_create(const mzr_config *cfg, int num_envs, mz_assembler **out) {
+  if (!cfg || !out || num_envs < 1) return fail("mzr_asm_create: bad argument");
+  if (cfg->episode_life) return fail("mzr_asm_create: records carry one end-of-game flag (no episode_life)");
+  mz_assembler *a = new mz_assembler();
+  const int OS = cfg->obs_u8 ? (cfg->obs_dim + 3) / 4 : cfg->obs_dim;
+  a->ac = asm_cfg_of(*cfg, OS, OS + cfg->action_space + MZR_REC_EXTRA);
+  a->B = num_envs;
+  a->envs.resize((size_t)num_envs);
+  *out = a;
+  return 0;
+}
+int mzr_asm_destroy(mz_assembler *a) {
+  if (!a) return 0;
+  for (Pending &p : a->ready) delete p.h;
+  delete a;
+  return 0;
+}
+int mzr_asm_feed(mz_assembler *a, const float *records, int n_moves, int B, int rec_floats) {
+  if (!a || !records) return fail("mzr_asm_feed: null argument");
+  if (B != a->B || rec_floats != a->ac.R || n_moves < 0) return fail("mzr_asm_feed: bad shape (B %d of %d, rec %d of %d)", B, a->B, rec_floats, a->ac.R);
+  ingest_range(a->ac, a->envs.data(), a->sc, records, n_moves, B, 0, 0, B, false);
+  std::stable_sort(a->sc.pend.begin(), a->sc.pend.end(), [](const Pending &x, const Pending &y) { return x.m < y.m; });      // (move, env): b ascending already
+  for (const Pending &p : a->sc.pend) {
+    a->ready_pri.emplace_back(p.pri, p.pri + p.h->n);
+    Pending q = p;
+    q.pri = nullptr;                   // (the deque's vector is the owner; looked up by position)
+    a->ready.push_back(q);
+  }
+  return 0;
+}
+int64_t mzr_asm_pending(const mz_assembler *a) { return a ? (int64_t)a->ready.size() : -1; }
+// as many queued slices as fit `cap` bytes, oldest first, into out; -> bytes written (0: nothing queued), < 0: error
+int64_t mzr_asm_take(mz_assembler *a, void *out, int64_t cap) {
+  if (!a || !out || cap < 64) return fail("mzr_asm_take: bad argument");
+  char *o = (char *)out;
+  int64_t off = 8, count = 0;
+  const size_t R = (size_t)a->ac.R;
+  while (!a->ready.empty()) {
+    const Pending &p = a->ready.front();
+    const int64_t n = p.h->n;
+    const int64_t rows_b = (int64_t)(((size_t)n * R * 4 + 7) & ~(size_t)7), need = 48 + rows_b + n * 8;
+    if (off + need > cap) {
+      if (count == 0) return fail("mzr_asm_take: a slice of %lld steps does not fit %lld bytes", (long long)n, (long long)cap);
+      break;
+    }
+    int64_t hdr[6] = {p.m, p.b, n, p.keep, p.done ? 1 : 0, 0};
+    memcpy(o + off, hdr, 48);
+    memcpy(o + off + 48, p.h->rows.data() + (size_t)p.h->off * R, (size_t)n * R * 4);
+    memcpy(o + off + 48 + rows_b, a->ready_pri.front().data(), (size_t)n * 8);
+    off += need;
+    ++count;
+    delete p.h;
+    a->ready.pop_front();
+    a->ready_pri.pop_front();
+  }
+  if (count == 0) return 0;
+  memcpy(o, &count, 8);
+  return off;
+}
+
+// the slices of one blob (mzr_asm_take) enter the replay: one sequential copy per slice -- spread over the ingest threads --, then
+// the (deferred) insertion of its leaves in blob order; env_base: the producing rank's first environment (kept for the error text)
+int mzr_ingest_slices(mz_replay *r, const void *blob, int64_t bytes, int env_base) {
+  if (!r || !blob || bytes < 8) return fail("mzr_ingest_slices: bad argument");
+  MZR_LOCK(r);
+  if (r->c.episode_life) return fail("mzr_ingest_slices: this replay is configured with episode_life");
+  const char *o = (const char *)blob;
+  int64_t count = 0;
+  memcpy(&count, o, 8);
+  const size_t R = (size_t)r->R;
+  struct Ref { const char *rows; const double *pri; int64_t n; };
+  std::vector<Ref> refs((size_t)count);
+  Job job;
+  job.items.resize((size_t)count);
+  int64_t off = 8, total = 0;
+  for (int64_t i = 0; i < count; ++i) {
+    if (off + 48 > bytes) return fail("mzr_ingest_slices: truncated blob (rank with env_base %d)", env_base);
+    int64_t hdr[6];
+    memcpy(hdr, o + off, 48);
+    const int64_t n = hdr[2];
+    const int64_t rows_b = (int64_t)(((size_t)n * R * 4 + 7) & ~(size_t)7);
+    if (n < 0 || off + 48 + rows_b + n * 8 > bytes) return fail("mzr_ingest_slices: truncated blob (rank with env_base %d)", env_base);
+    refs[(size_t)i] = Ref{o + off + 48, (const double *)(o + off + 48 + rows_b), n};
+    Hist *h = new Hist();
+    h->n = n; h->payload = true;
+    job.items[(size_t)i] = Pending{(int)hdr[0], (int)hdr[1], h, hdr[3], nullptr, hdr[4] != 0};
+    total += n;
+    off += 48 + rows_b + n * 8;
+  }
+  job.pris.emplace_back((size_t)total);
+  {
+    int64_t po = 0;
+    for (int64_t i = 0; i < count; ++i) { job.items[(size_t)i].pri = job.pris[0].data() + po; po += refs[(size_t)i].n; }
+  }
+  auto copy = [&](int64_t lo, int64_t hi) {
+    for (int64_t i = lo; i < hi; ++i) {
+      const Ref &f = refs[(size_t)i];
+      job.items[(size_t)i].h->rows.assign((const float *)f.rows, (const float *)f.rows + (size_t)f.n * R);
+      memcpy(const_cast<double *>(job.items[(size_t)i].pri), f.pri, (size_t)f.n * 8);
+    }
+  };
+  const int T = r->pool.T;
+  if (T <= 1 || count < 2 * T) copy(0, count);
+  else r->pool.run([&](int tid) { copy(count * tid / T, count * (tid + 1) / T); });
+  if (!r->inserter.joinable()) {
+    insert_job(r, job);
+    return 0;
+  }
+  {
+    std::unique_lock<std::mutex> lk(r->qmu);
+    r->idle_cv.wait(lk, [&] { return r->queue.size() < 4; });
+    r->queue.push_back(std::move(job));
+  }
+  r->qcv.notify_one();
   return 0;
 }
 

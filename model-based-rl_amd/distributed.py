@@ -62,7 +62,7 @@ class ShmRing(object):
     # mzr_store_release_i64, include/mz_replay.h): a chunk's payload is visible to the consumer before the head that
     # announces it, on any host -- not a property borrowed from x86-64's store order
     from . import _abi
-    lib = _abi.load_replay()
+    lib = self._lib = _abi.load_replay()
     base = self.hdr.ctypes.data
     self._load = lambda i: int(lib.mzr_load_acquire_i64(base + 8 * i))
     self._store = lambda i, v: lib.mzr_store_release_i64(base + 8 * i, int(v))
@@ -74,15 +74,22 @@ class ShmRing(object):
     return n, data
 
   # producer side
-  def put(self, records, n_moves):
-    """records: host float32 [>= n_moves][B][rec] (numpy or pinned torch tensor)."""
+  def put(self, records, n_moves, pack=True):
+    """records: host float32 [>= n_moves][B][rec] (numpy or pinned torch tensor).  pack: the copy into the slot is the transposing
+    one (mzr_pack_env_major: [B][n_moves][rec]) -- the per-record work the ONE replay's host would otherwise do with strided
+    reads is done here, by the producing rank; the slot's count is stored negative to say so."""
     head = self._load(0)                    # (only this side writes it)
     while head - self._load(1) >= self.slots:
       time.sleep(0.0002)
     n, data = self._slot(head)
     src = records.numpy() if torch.is_tensor(records) else np.asarray(records)
-    data[:n_moves] = src[:n_moves]          # (a synchronous copy: complete when the statement returns)
-    n[0] = n_moves
+    if pack and n_moves > 0 and os.environ.get('MZ_RING_NO_PACK', '0')[:1] != '1':      # (MZ_RING_NO_PACK=1: the r05 hand-off, A/B runs)
+      src = np.ascontiguousarray(src[:n_moves], np.float32)
+      self._lib.mzr_pack_env_major(src.ctypes.data, data.ctypes.data, int(n_moves), self.B, self.rec)
+      n[0] = -n_moves
+    else:
+      data[:n_moves] = src[:n_moves]        # (a synchronous copy: complete when the statement returns)
+      n[0] = n_moves
     self._store(0, head + 1)                # release: published after the payload
 
   def close_producer(self):
@@ -90,12 +97,14 @@ class ShmRing(object):
 
   # consumer side
   def poll(self):
-    """-> (view [n][B][rec], n) of the oldest unconsumed chunk, or None; call done() when it has been ingested."""
+    """-> (view of the slot, n, packed) of the oldest unconsumed chunk, or None; call done() when it has been ingested.  packed:
+    the slot holds [B][n][rec] (the producer's mzr_pack_env_major), else [n][B][rec]."""
     tail = self._load(1)
     if tail >= self._load(0):               # acquire: the chunk behind a head we have seen is complete
       return None
     n, data = self._slot(tail)
-    return data, int(n[0])
+    k = int(n[0])
+    return data, abs(k), k < 0
 
   def done(self):
     self._store(1, self._load(1) + 1)       # release: the slot is free once the ingest has read it
@@ -108,7 +117,7 @@ class ShmRing(object):
     return bool(self._load(2)) and self._load(1) >= self._load(0)
 
   def release(self):
-    self.hdr = self._load = self._store = None
+    self.hdr = self._load = self._store = self._lib = None
     try:
       self.shm.close()
       if self.owner:
@@ -124,8 +133,8 @@ class RingReplay(object):
     self.ring = ring
     self.frames = 0
 
-  def ingest_records(self, records, n_moves, B, env_base=0):
-    self.ring.put(records, int(n_moves))
+  def ingest_records(self, records, n_moves, B, env_base=0, env_major=False):
+    self.ring.put(records, int(n_moves))    # (packed environment-major on the way into the ring)
     self.frames += int(n_moves) * int(B)
 
   def save_history(self, *a, **k):
@@ -143,8 +152,8 @@ def serve_rings(rings, replay_call, B, stop):
     for r, ring in list(live.items()):
       got = ring.poll()
       if got is not None:
-        data, n = got
-        replay_call('ingest_records', data, n, B, r * B)
+        data, n, packed = got
+        replay_call('ingest_records', data, n, B, r * B, packed)
         ring.done()
         idle = False
       elif ring.finished():

@@ -237,6 +237,7 @@ class _NativeFC(object):
     self._source = None           # (replay object, its mz_fcl_source table) of run()
     self.in_flight = False        # run() returned with updates in flight whose refreshes are owed
     self._rng = None              # generator states taken over by run() (release_rng hands them back)
+    self._rng_exclusive = True    # nobody else has been seen drawing from the global generators while run() held them
     self.sync(force=True)
 
   def fits(self, host):
@@ -303,6 +304,19 @@ class _NativeFC(object):
     # the two generators the reference's sample_batch draws from -- Python's `random` (the stratified draws) and numpy's legacy
     # global one (the padded actions) -- are MT19937 states: taken over once (random.getstate / np.random.get_state), advanced in
     # place by the native calls, handed back by release_rng() (flush, the end of learn()): no 1.6-Mbit integer per call
+    if self._rng is not None and self._rng_exclusive:
+      # the private copy is only right while NOBODY else draws from the process-global generators (the reference's replay
+      # is a process of its own; here a host-environment actor or the Python sample_batch path may share them).  The globals must
+      # still be what they were at the take-over; if not, this learner stops holding them across calls: from now on the states
+      # go back after every segment (concurrent consumers then interleave per segment, as two threads would anyway)
+      st, ns = self._rng[4], self._rng[5]
+      now = np.random.get_state()
+      if random.getstate() != st or int(now[2]) != int(ns[2]) or not np.array_equal(now[1], ns[1]):
+        import sys
+        print('native learner loop: another consumer drew from the global `random` / numpy generators while the loop held their states; '
+              'handing them back after every segment from here on', file=sys.stderr)
+        self._rng_exclusive = False
+        self.release_rng()
     if self._rng is None:
       st, ns = random.getstate(), np.random.get_state()
       self._rng = (np.array(st[1][:624], np.uint32), C.c_int32(int(st[1][624])), np.array(ns[1], np.uint32), C.c_int32(int(ns[2])), st, ns)
@@ -322,6 +336,8 @@ class _NativeFC(object):
                               C.byref(py_pos)), 'mz_fcl_run')
     replay.beta = np.float64(beta.value) if float(replay.beta) < 1 else replay.beta
     self.in_flight = n > 0 or (self.in_flight and n != 0)
+    if not self._rng_exclusive:
+      self.release_rng()
     return int(pads.value)
 
   def flush(self):

@@ -167,17 +167,18 @@ class PrioritizedReplay(object):
                                                 int(bool(terminal)), _p(obs), _p(cv), _p(rv), _p(rew), _p(act), _p(dn),
                                                 _p(tp)), 'mzr_save_history')
 
-  def ingest_records(self, records, n_moves, B, env_base=0):
+  def ingest_records(self, records, n_moves, B, env_base=0, env_major=False):
     """records: float32 [n_moves, B, rec_floats] host array/tensor from Engine.selfplay_drain.  env_base: index of
     the records' first environment among this replay's environments (one replay fed by several actor ranks: rank r
-    passes r * B -- every reference actor sends to the one replay buffer, train.py:71-72, actors.py:169)."""
+    passes r * B -- every reference actor sends to the one replay buffer, train.py:71-72, actors.py:169).
+    env_major: the chunk was packed by the producing rank (mzr_pack_env_major: [B, n_moves, rec_floats])."""
     if hasattr(records, 'data_ptr'):
       ptr, rec = C.c_void_p(records.data_ptr()), int(records.shape[-1])
     else:
       records = np.ascontiguousarray(records, np.float32)
       ptr, rec = _p(records), int(records.shape[-1])
-    _abi.check_replay(self.lib.mzr_ingest_records_from(self._h, ptr, int(n_moves), int(B), rec, int(env_base)),
-                      'mzr_ingest_records')
+    fn = self.lib.mzr_ingest_records_packed if env_major else self.lib.mzr_ingest_records_from
+    _abi.check_replay(fn(self._h, ptr, int(n_moves), int(B), rec, int(env_base)), 'mzr_ingest_records')
 
   # replay_buffer.py:124-163 (+ insert_target 165-198 inside the native call)
   def sample_batch_arrays(self):

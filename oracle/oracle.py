@@ -99,6 +99,12 @@ class Trees(object):
     legal = None if legal is None else np.ascontiguousarray(legal, np.uint8)
     lib().orc_root_expand(self._h, _p(to_play), _p(logits), _p(legal))
 
+  def set_prior_override(self, priors):
+    """test hook: every later Node.expand takes its children's priors from priors [B][NN] (a device tree's export; root children
+    post-noise: skip add_noise then) instead of exp / sum on the logits; None switches it off"""
+    self._prior_override = None if priors is None else np.ascontiguousarray(priors, np.float64)      # (kept alive here)
+    lib().orc_set_prior_override(self._h, _p(self._prior_override))
+
   def add_noise(self, noise, frac):
     noise = np.ascontiguousarray(noise, np.float64)
     lib().orc_add_noise(self._h, _p(noise), C.c_double(frac))

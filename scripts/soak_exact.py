@@ -4,7 +4,14 @@ device's own logged network outputs (mz_sim_io), Dirichlet draws and select_acti
 distribution, action, root value and error as float64) must be identical.  A rare corrupted tile or a wrong tree-code corner
 shows up as one differing tree somewhere in the run.
 
-  python scripts/soak_exact.py [--shape lunar|pong|ttt] [--moves 8000] [--checks 40] [--split] [--out file.jsonl]"""
+  python scripts/soak_exact.py [--shape lunar|pong|ttt] [--moves 8000] [--checks 40] [--split] [--out file.jsonl]
+
+--priors (VERDICT r05 item 5 i): how often does the device exp's few-ulp difference from glibc's flip a select_child decision?
+The LAST move of every launch (the one whose device tree can be exported: priors of every node, root children post-noise) is
+replayed through the oracle's tree TWICE on the same logged network outputs -- (a) with the oracle's own priors (the C library's
+exp: the reference's arithmetic), (b) with the DEVICE's exported priors (oracle test hook orc_set_prior_override) -- and the
+trees whose visit vectors / actions differ between (a) and (b) are counted, beside the largest prior difference seen.
+  python scripts/soak_exact.py --priors [--shape lunar] [--trees 5000000] [--out file.jsonl]"""
 import argparse, json, os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,6 +24,8 @@ from tests.test_gpu_fused_exact import LOG_SHAPES, G
 ap = argparse.ArgumentParser()
 ap.add_argument('--shape', default='lunar'); ap.add_argument('--moves', type=int, default=8000)
 ap.add_argument('--checks', type=int, default=40); ap.add_argument('--split', action='store_true'); ap.add_argument('--out', default=None)
+ap.add_argument('--priors', action='store_true'); ap.add_argument('--trees', type=int, default=5000000)
+ap.add_argument('--threads', type=int, default=8)
 a = ap.parse_args()
 sh = LOG_SHAPES[a.shape]
 O, A, sims, B, seed, chunk = sh['O'], sh['A'], sh['sims'], 4096, 2025, 16
@@ -33,6 +42,72 @@ eng.selfplay_noise_log(True)
 eng.selfplay_reset(200, 1.0, stagger=True)
 log = eng.sim_io('log', keep_moves=chunk)
 cfg = orc.tree_cfg(A, sims, two_players=game, known_bounds=(-1.0, 1.0) if game else (None, None), discount=1.0 if game else 0.997)
+if a.priors:
+  # ---- the priors soak: every launch's last move, two oracle replays each (a pool of threads: the C oracle releases the GIL)
+  from concurrent.futures import ThreadPoolExecutor
+  eng.selfplay_export_trees(True)
+  nl = -(-a.trees // B)
+
+  def job(io, noise, u, to_play, legal, P_dev, cv_dev, act_dev):
+    ra = replay_move(cfg, B, A, sims, io, noise, 0.25, to_play, legal, 1.0, u, want_tree=True)
+    t = orc.Trees(cfg, B)
+    t.set_prior_override(P_dev)
+    t.root_expand(to_play, io[:, 0, 2:], legal)            # (root children: the device's post-noise priors -- no add_noise)
+    for s_ in range(sims):
+      t.select()
+      t.expand_backup(io[:, 1 + s_, 0], io[:, 1 + s_, 1], io[:, 1 + s_, 2:])
+    act_b, cv_b, rv_b, vc_b = t.finalize(1.0, u)
+    ex = ra['tree']['EX'].astype(bool)
+    Pa = ra['tree']['P']
+    rel = np.abs(P_dev[ex] - Pa[ex]) / np.maximum(np.abs(Pa[ex]), 1e-300)
+    ulp = np.abs(P_dev[ex] - Pa[ex]) / np.spacing(np.abs(Pa[ex]))
+    same_ab = np.all(vc_b == ra['visit_counts'], axis=1) & (act_b == ra['action'])
+    same_a_dev = np.all(cv_dev == ra['child_visits'].astype(np.float32), axis=1) & (act_dev == ra['action'])
+    same_b_dev = np.all(cv_dev == cv_b.astype(np.float32), axis=1) & (act_dev == act_b)
+    return int((~same_ab).sum()), int((~same_a_dev).sum()), int((~same_b_dev).sum()), float(rel.max()), float(ulp.max()), int((ulp > 0).sum()), int(ex.sum())
+  pool, futs = ThreadPoolExecutor(a.threads), []
+  diff_ab = diff_a = diff_b = nodes = nodes_off = 0
+  max_rel = max_ulp = 0.0
+  t0 = time.time()
+
+  def collect(block):
+    global diff_ab, diff_a, diff_b, nodes, nodes_off, max_rel, max_ulp
+    while futs and (block or futs[0].done() or len(futs) > 2 * a.threads):
+      r = futs.pop(0).result()
+      diff_ab += r[0]; diff_a += r[1]; diff_b += r[2]; max_rel = max(max_rel, r[3]); max_ulp = max(max_ulp, r[4]); nodes_off += r[5]; nodes += r[6]
+  for c in range(nl):
+    eng.selfplay_steps(chunk)
+    buf, n = eng.selfplay_drain()
+    torch.cuda.synchronize()
+    k = chunk - 1
+    m = c * chunk + k
+    rec = buf[:n].numpy().copy()
+    rv = records_view(rec, O, A)
+    io = log.cpu().numpy()[m % chunk].copy()
+    tree = eng.export_tree()
+    if game:
+      legal, to_play = (rec[k, :, :O] == 0).astype(np.uint8), rv['to_play'][k].astype(np.int8)
+    else:
+      legal, to_play = None, np.ones(B, np.int8)
+    futs.append(pool.submit(job, io, eng.selfplay_noise(m), philox_action_uniform(seed, np.arange(B), m), to_play, legal,
+                            tree['P'].copy(), rv['child_visits'][k].copy(), rv['action'][k].copy()))
+    collect(False)
+  collect(True)
+  eng.sim_io('off')
+  eng.close()
+  out = {'shape': a.shape, 'split_f16': bool(a.split), 'mode': 'priors', 'launches': nl, 'moves_played': nl * chunk, 'trees_replayed_twice': nl * B,
+         'trees_differing_between_glibc_priors_and_device_priors': diff_ab,
+         'trees_differing_device_vs_oracle_with_glibc_priors': diff_a, 'trees_differing_device_vs_oracle_with_device_priors': diff_b,
+         'prior_nodes_compared': nodes, 'prior_nodes_not_bit_equal': nodes_off, 'max_prior_difference_ulp': max_ulp, 'max_prior_difference_relative': max_rel,
+         'rule': 'the last move of every 16-move launch of the benchmarked shape; visit counts and action of the oracle tree replayed on the logged '
+                 'network outputs with (a) its own exp / sum priors, (b) the device tree\'s exported priors',
+         'seconds': time.time() - t0}
+  print(json.dumps(out))
+  if a.out:
+    with open(a.out, 'a') as f:
+      f.write(json.dumps(out) + '\n')
+  assert diff_a == 0 and diff_b == 0, out
+  sys.exit(0)
 rng = np.random.RandomState(1)
 nchunks = a.moves // chunk
 check = set(rng.choice(nchunks, size=min(a.checks, nchunks), replace=False).tolist())

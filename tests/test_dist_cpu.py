@@ -213,7 +213,8 @@ def test_shm_ring_orders_payload_before_head(tmp_path):
       if got is None:
         time.sleep(0.0002)          # (as distributed.serve_rings does: a spinning consumer would hold the interpreter lock)
         continue
-      data, n = got
+      data, n, packed = got
+      assert not packed
       seen.append((n, data[:n].copy()))
       cons.done()
 
@@ -225,7 +226,7 @@ def test_shm_ring_orders_payload_before_head(tmp_path):
     n = 1 + i % 4
     rec = rng.standard_normal((4, 32, 22)).astype(np.float32)
     sent.append((n, rec[:n].copy()))
-    prod.put(rec, n)
+    prod.put(rec, n, pack=False)
   prod.close_producer()
   th.join(timeout=30)
   assert not th.is_alive() and len(seen) == 40 and cons.pending() == 0

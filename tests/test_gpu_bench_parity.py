@@ -143,7 +143,7 @@ def test_persistent_launch_on_a_full_grid_vs_oracle(shape, split, ntt):
     # tree's LARGEST scalar; the root error is a difference of two such numbers.  smax: from the device's logged outputs of this move.
     io_m = log[m].cpu().numpy()
     smax = np.abs(io_m[:, :, :2]).max(axis=(1, 2)).astype(np.float64)
-    step = 1e-5 if ntt else 1.5e-4 * (1.0 + smax)       # (--no_target_transform: no staircase, 1e-5 on every scalar)
+    step = np.full(smax.shape, 1e-5) if ntt else 1.5e-4 * (1.0 + smax)       # (--no_target_transform: no staircase, 1e-5 on every scalar)
     assert np.all(drv[ok] <= step[ok]) and np.all(derr[ok] <= 2 * step[ok]), (m, (drv[ok] / step[ok]).max(), (derr[ok] / step[ok]).max())
     assert np.all(np.take_along_axis(cv, rv['action'][m][:, None], -1) > 0)
     if ref.get('tree') is not None:                       # the last move: every integer field of the exported trees

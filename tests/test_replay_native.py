@@ -242,6 +242,51 @@ def test_parallel_ingest_is_bit_identical_to_one_thread(T, mhl, window):
       assert np.array_equal(np.asarray(v), np.asarray(other[k])) if not isinstance(v, dict) else v == other[k], k
 
 
+@pytest.mark.parametrize('T,mhl,window', [(40, 500, 1 << 15), (23, 16, 1 << 15), (40, 500, 3000)])
+def test_ring_path_with_producer_side_packing_is_bit_identical(T, mhl, window):
+  """The one-replay layout's hand-off (train --ranks N): the PRODUCING rank packs every chunk environment-major while copying it
+  into its shared-memory ring (distributed.ShmRing.put -> mzr_pack_env_major), rank 0 ingests the packed chunk
+  (mzr_ingest_records_packed: one sequential piece per environment, appended run by run, buffers swapped into the slices instead of
+  copied).  Leaves, sums, counters and a sampled batch equal those of the same chunks ingested directly, move-major, on one thread
+  -- with several ingest threads, short last chunks (n_moves < the ring's chunk) and an env_base."""
+  import random
+  from model_based_rl_amd import distributed as D
+  from model_based_rl_amd.replay_buffer import PrioritizedReplay
+  O, A, B, moves, chunk = 5, 3, 101, 96, 8
+  recs = [_bulk_records(np.random.RandomState(7 + r), moves, B, O, A, T) for r in range(2)]      # two "ranks"
+  results = []
+  for mode, threads in (('direct', 1), ('ring', 4), ('ring', 3)):
+    rep = PrioritizedReplay(make_cfg(obs_space=(O,), action_space=A, max_history_length=mhl, window_size=window,
+                                     discount=0.997, ingest_threads=threads))
+    rings = [D.ShmRing('mzt_pack_%d_%d' % (os.getpid(), r), chunk, B, O + A + 10, slots=2, create=True) for r in range(2)] if mode == 'ring' else None
+    lo = 0
+    for step in (8, 8, 5, 8, 3, 8, 8, 8, 8, 8, 8, 8, 8):           # (ragged chunks: 5 and 3 moves)
+      for r in range(2):
+        piece = recs[r][lo:lo + step]
+        if mode == 'direct':
+          rep.ingest_records(piece, step, B, r * B)
+        else:
+          rings[r].put(piece, step)
+          data, n, packed = rings[r].poll()
+          assert n == step and packed
+          rep.ingest_records(data, n, B, r * B, packed)
+          rings[r].done()
+      lo += step
+    assert lo == moves
+    random.seed(5); np.random.seed(6)
+    (obs, actions, (t_rew, t_val, t_pol)), idxs, isw = rep.sample_batch()
+    n = rep.size()
+    results.append(dict(total=rep.tree.total_priority, size=n, thr=rep.get_throughput(), leaves=rep.tree.leaves(n), obs=obs,
+                        actions=np.asarray(actions), t_rew=t_rew, t_val=t_val, t_pol=t_pol, idxs=np.asarray(idxs), isw=isw))
+    if rings:
+      for rg in rings:
+        rg.release()
+  assert results[0]['thr']['frames'] > B * moves and results[0]['size'] == min(window, results[0]['thr']['frames'])
+  for other in results[1:]:
+    for k, v in results[0].items():
+      assert np.array_equal(np.asarray(v), np.asarray(other[k])) if not isinstance(v, dict) else v == other[k], k
+
+
 def test_large_batches_sampled_over_the_pool_equal_one_thread():
   """mzr_sample_batch spreads a batch's blocks of 128 samples over the replay's thread pool (batch >= 512; the learner's native
   loop samples one batch per update: bench.py --workload learner --batch 2048): every output of sample_batch -- indices,
