@@ -616,7 +616,7 @@ def main():
                          daemon=True).start()
       else:
         self.my_ring = D.ShmRing('%s_%d' % (run_id, rank))
-        self.replay = D.RingReplay(self.my_ring)
+        self.replay = D.RingReplay(self.my_ring, cfg)      # (history slices assembled on this rank, as train.launch_ranks does)
         self.replay.get_throughput = lambda: {'frames': 0, 'games': 0}      # (counted where they are accepted: rank 0's replay)
 
     def frames(self):

@@ -49,7 +49,7 @@ struct FclView {
   const float *obs; const void *act; int act_i32; const float *t_rew, *t_val, *t_pol; const void *w; int w_f64;
   float *xin, *a1c, *xhat, *rstd, *h, *d2c, *d1c;      // chain tapes, [K + 1][...][R]
   float *a1h, *d2h, *d1h, *dH, *lossb;                 // head tapes, [3][K + 1][...][R]
-  float *lnpart;                                        // [bs / 4][128] LayerNorm weight / bias gradient partials (per chain workgroup)
+  float *lnpart;                                        // [bs / 4][128] LayerNorm weight / bias gradient partials (per group of four samples)
   float *new_errors;
   unsigned *flags;               // fused forward launch (k_fcl_fwd): [bs / 16][K + 1] arrival counters -- chain workgroups whose tapes of (sample group, position) are
                                  // written through; 4 = all of the group's; zeroed by k_fcl_bwd_dw for the next step
@@ -504,8 +504,8 @@ __device__ __forceinline__ f32x4 fcl_quad_stream(const float *__restrict__ pk, i
   return (acc[0] + acc[1]) + (acc[2] + acc[3]);
 }
 
-// LDS of the 4-sample chain kernels (floats), activations SAMPLE-major: X [4][xq + 4] | A1 [4][516] | red [2048] | misc [16] | PV [1408] | S [256]
-#define FCL_LDS4_FLOATS(xq) (4 * ((xq) + 4) + 4 * 516 + 2048 + 16 + 1408 + 256)
+// LDS of the chain kernels (floats), G groups of 4 samples, activations SAMPLE-major: X [4 G][xq + 4] | A1 [4 G][516] | red [G][2048] | misc [16] | PV [1408] | S [4 G][64]
+#define FCL_LDS4_FLOATS(xq, G) (4 * (G) * ((xq) + 4) + 4 * (G) * 516 + (G) * 2048 + 16 + 1408 + 256 * (G))
 #define FCL_LDA 516
 
 // D fragment (rows 64 w + 4 b + i, sample j) -> tape [chunk][feature][16]: wave-uniform base + one lane offset + i * 16
@@ -513,16 +513,22 @@ __device__ __forceinline__ int fcl_lane_off4(int lane, int n0) { return (lane >>
 
 // KP: the transition's fc1 input features (50 + actions), padded: 56 (up to 6 actions) or 64
 // SIG: a chain workgroup of the fused forward launch -- the tapes the heads read (hidden states, transition inputs) are stored
-// write-through and, one phase later, announced on the group's counter (see "in-launch hand-off")
-template <int KP, bool SIG>
+// write-through and, one phase later, announced on the group's counter (see "in-launch hand-off").
+// G: groups of four samples per workgroup (1, 2 or 4).  A position's MFMAs are ~1.9 k of its ~5 k cycles -- the rest is the
+// serial chain epilogue / barrier / LayerNorm on one wave -- so where the batch has more than one workgroup per CU (batch 2048 and
+// up) a workgroup takes G groups through every phase together: the resident weights serve G x 4 samples, the G LayerNorms run on G
+// different waves side by side, and the phase latencies are paid once per G groups.
+template <int KP, bool SIG, int G>
 __device__ __forceinline__ void fcl_chain_fwd4_body(const FclView &v, const int blk, float *fcl_smem) {
+  static_assert(!SIG || G == 1, "the in-launch hand-off counts four chain workgroups per sample group");
+  constexpr int NS = 4 * G;                    // samples of this workgroup
   const int LDX = v.xq + 4;
-  float *X = fcl_smem, *A1 = X + 4 * LDX, *red = A1 + 4 * FCL_LDA, *misc = red + 2048, *PV = misc + 16;
+  float *X = fcl_smem, *A1 = X + NS * LDX, *red = A1 + NS * FCL_LDA, *misc = red + G * 2048, *PV = misc + 16;
   float *b1r = PV, *b1t = PV + 512, *b2r = PV + 1024, *b2t = PV + 1088, *lnw = PV + 1152, *lnb = PV + 1216;
-  int *acts = (int *)(PV + 1280);          // [4 samples][8]
-  float *S = PV + 1408;                    // [4 samples][64] x-hat of the position just finished (for the tapes)
+  int *acts = (int *)(PV + 1280);          // [NS samples][8]
+  float *S = PV + 1408;                    // [NS samples][64] x-hat of the position just finished (for the tapes)
   const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int cb = blk >> 2, n0 = 4 * (blk & 3), row0 = blk * 4, R = v.R, loff = fcl_lane_off4(lane, n0);
+  const int row0 = blk * NS, cb = row0 >> 4, n0 = row0 & 15, R = v.R;
   const size_t T64 = (size_t)64 * R, T512 = (size_t)512 * R, TX = (size_t)v.XR * R;
 #define FCL_KSTAMP(k) if (v.prof && blk == 0 && tid == 0) v.prof[54 + (k)] = __builtin_amdgcn_s_memtime();
   FCL_KSTAMP(0)      // kernel start
@@ -536,12 +542,12 @@ __device__ __forceinline__ void fcl_chain_fwd4_body(const FclView &v, const int 
     float pb2r = 0.f, pb2t = 0.f, plnw = 0.f, plnb = 0.f;
     if (tid < MZ_H) { pb2r = v.P[v.rep_b2 + tid]; pb2t = v.P[v.tr_b2 + tid]; plnw = v.P[v.ln_w + tid]; plnb = v.P[v.ln_b + tid]; }
     int pact = -1;
-    if (tid < 32 && (tid & 7) < v.K) {
+    if (tid < 8 * NS && (tid & 7) < v.K) {
       const size_t ai = (size_t)(row0 + (tid >> 3)) * v.K + (tid & 7);
       pact = v.act_i32 ? ((const int32_t *)v.act)[ai] : (int)((const int64_t *)v.act)[ai];
     }
-    const int f_0 = tid >> 2, n_0 = tid & 3;
-    const float ob0 = (tid < v.xq * 4 && f_0 < v.O) ? v.obs[(size_t)(row0 + n_0) * v.O + f_0] : 0.f;
+    const int f_0 = tid / NS, n_0 = tid % NS;
+    const float ob0 = (tid < v.xq * NS && f_0 < v.O) ? v.obs[(size_t)(row0 + n_0) * v.O + f_0] : 0.f;
     // up to 16 observation features (LunarLander 8, TicTacToe 9): the representation's fc1 weights ride with these small reads, so that
     // position 0's fc1 products start behind ONE round trip (streamed, their loads queue behind WR2's 128 KB)
     if (v.O <= 16) {
@@ -553,13 +559,13 @@ __device__ __forceinline__ void fcl_chain_fwd4_body(const FclView &v, const int 
     asm volatile("" ::: "memory");
     b1r[tid] = pb1r; b1t[tid] = pb1t;
     if (tid < 64) { b2r[tid] = pb2r; b2t[tid] = pb2t; lnw[tid] = plnw; lnb[tid] = plnb; }
-    if (tid < 32) acts[tid] = pact;
-    if (tid < v.xq * 4) {
+    if (tid < 8 * NS) acts[tid] = pact;
+    if (tid < v.xq * NS) {
       X[n_0 * LDX + f_0] = ob0;
       if (f_0 < v.XR) v.xin[fcl_tp(v.XR, cb, f_0, n0 + n_0)] = ob0;
     }
-    for (int idx = tid + FCL_THREADS; idx < v.xq * 4; idx += FCL_THREADS) {      // (more than 128 observation features)
-      const int f = idx >> 2, n = idx & 3;
+    for (int idx = tid + FCL_THREADS; idx < v.xq * NS; idx += FCL_THREADS) {      // (more observation features / samples than threads)
+      const int f = idx / NS, n = idx % NS;
       const float val = f < v.O ? v.obs[(size_t)(row0 + n) * v.O + f] : 0.f;
       X[n * LDX + f] = val;
       if (f < v.XR) v.xin[fcl_tp(v.XR, cb, f, n0 + n)] = val;
@@ -569,7 +575,7 @@ __device__ __forceinline__ void fcl_chain_fwd4_body(const FclView &v, const int 
   FCL_KSTAMP(1)      // observations in LDS
   // (development: stamps of position 2's phases in workgroup 0, mz_fcl_heads_profile, slots 48..)
 #define FCL_CSTAMP(k) if (v.prof && blk == 0 && p == 2 && tid == 0) v.prof[48 + (k)] = __builtin_amdgcn_s_memtime();
-  auto rest = [&](int p, f32x4 acc, const float (&W2)[64], const float *b1, const float *b2) __attribute__((always_inline)) {
+  auto rest = [&](int p, const f32x4 (&acc)[G], const float (&W2)[64], const float *b1, const float *b2) __attribute__((always_inline)) {
     FCL_CSTAMP(1)      // fc1 products done
     if constexpr (SIG) {
       // the tapes of position p - 1 (stored write-through behind its last barrier, by the upper waves, a phase of MFMAs ago):
@@ -577,35 +583,38 @@ __device__ __forceinline__ void fcl_chain_fwd4_body(const FclView &v, const int 
       // barrier that follows the epilogue
       if (p > 0 && tid >= 256) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    {   // fc1 epilogue: bias, ReLU, to LDS (one 16-byte write: the lane's four features of its sample) and to the tape
-      const int f0 = 64 * w + 4 * (lane >> 2);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {   // fc1 epilogue: bias, ReLU, to LDS (one 16-byte write: the lane's four features of its sample) and to the tape
+      const int f0 = 64 * w + 4 * (lane >> 2), loff = fcl_lane_off4(lane, n0 + 4 * g);
       const f32x4 b = *(const f32x4 *)(b1 + f0);
       float *a1t = v.a1c + (size_t)p * T512 + fcl_tp(512, cb, 64 * w, 0);
       f32x4 a;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        a[i] = fmaxf(acc[i] + b[i], 0.f);
+        a[i] = fmaxf(acc[g][i] + b[i], 0.f);
         (a1t + i * 16)[loff] = a[i];
       }
-      *(f32x4 *)(A1 + (lane & 3) * FCL_LDA + f0) = a;
+      *(f32x4 *)(A1 + (4 * g + (lane & 3)) * FCL_LDA + f0) = a;
     }
     fcl_bar();
     if constexpr (SIG) {
       if (p > 0 && tid == 0) fcl_signal(v.flags + (size_t)cb * (v.K + 1) + (p - 1));
     }
     FCL_CSTAMP(2)      // epilogue + barrier
-    *(f32x4 *)(red + (w * 64 + lane) * 4) = fcl_quad_res<64>(W2, A1 + (lane & 3) * FCL_LDA + 64 * w);
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+      *(f32x4 *)(red + g * 2048 + (w * 64 + lane) * 4) = fcl_quad_res<64>(W2, A1 + (4 * g + (lane & 3)) * FCL_LDA + 64 * w);
     fcl_bar();
     FCL_CSTAMP(3)      // fc2 partials + barrier
-    if (w == 0) {
-      // wave 0 alone: lane (j, b) = (lane >> 4, lane & 15) adds up rows 4 b + i of sample j of the 8 partials (written by
+    if (w < G) {
+      // wave g alone for group g: lane (j, b) = (lane >> 4, lane & 15) adds up rows 4 b + i of sample j of the 8 partials (written by
       // lane 4 b + j of each wave), then LayerNorm + ReLU (networks.py:147,165) of sample j across ITS DPP ROW -- the two
       // reductions are four DPP exchanges each, no LDS round trip (r05: lane (b, j), two ds_bpermute per reduction: this
       // serial part was 2.0 k of a position's 5.3 k cycles) -- the tapes and the next input straight from registers
-      const int j = lane >> 4, f0 = 4 * (lane & 15);
+      const int j = lane >> 4, f0 = 4 * (lane & 15), sj = 4 * w + j;
       f32x4 y = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ww = 0; ww < FCL_NW; ++ww) y += *(const f32x4 *)(red + (ww * 64 + f0 + j) * 4);
+      for (int ww = 0; ww < FCL_NW; ++ww) y += *(const f32x4 *)(red + w * 2048 + (ww * 64 + f0 + j) * 4);
       float yv[4], s = 0.f;
 #pragma unroll
       for (int i = 0; i < 4; ++i) { yv[i] = (f0 + i < MZ_H) ? y[i] + b2[f0 + i] : 0.f; s += yv[i]; }
@@ -616,7 +625,7 @@ __device__ __forceinline__ void fcl_chain_fwd4_body(const FclView &v, const int 
       for (int i = 0; i < 4; ++i) { d[i] = (f0 + i < MZ_H) ? yv[i] - mean : 0.f; var += d[i] * d[i]; }
       var = fcl_sum16(var);
       const float rstd = 1.0f / sqrtf(var / (float)MZ_H + FCL_LN_EPS);
-      const int act_p = acts[j * 8 + (p < 7 ? p : 7)];
+      const int act_p = acts[sj * 8 + (p < 7 ? p : 7)];
       f32x4 xv4, xh4;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -626,33 +635,39 @@ __device__ __forceinline__ void fcl_chain_fwd4_body(const FclView &v, const int 
         // the next input: [h | one-hot(action) | 0]  (networks.py:167-174); past the last transition: no action
         xv4[i] = f < MZ_H ? hv : ((p < v.K && f - MZ_H == act_p) ? 1.f : 0.f);
       }
-      *(f32x4 *)(X + j * LDX + f0) = xv4;
-      *(f32x4 *)(S + j * 64 + f0) = xh4;
-      if ((lane & 15) == 0) misc[j] = rstd;
+      *(f32x4 *)(X + sj * LDX + f0) = xv4;
+      *(f32x4 *)(S + sj * 64 + f0) = xh4;
+      if ((lane & 15) == 0) misc[sj] = rstd;
     }
-    FCL_CSTAMP(4)      // wave 0: reduce + LayerNorm
+    FCL_CSTAMP(4)      // waves 0 .. G - 1: reduce + LayerNorm
     fcl_bar();
     FCL_CSTAMP(5)      // barrier
-    // the tapes of this position, by the upper half of the workgroup (wave 0 above is the serial part: seven waves wait for
-    // it); X, S and misc are next written three barriers from here
+    // the tapes of this position, by the upper half of the workgroup (the LayerNorm waves above are the serial part: the others
+    // wait for them); X, S and misc are next written three barriers from here
     if (tid >= 256) {
-      const int t = tid - 256, f = t >> 2, n = t & 3;
-      const float xv = X[n * LDX + f];
-      const size_t tp = fcl_tp(64, cb, f, n0 + n);
-      v.xhat[(size_t)p * T64 + tp] = S[n * 64 + f];
-      if constexpr (SIG) {
-        fcl_store_wt(v.h + (size_t)p * T64 + tp, f < MZ_H ? xv : 0.f);
-        if (p < v.K) fcl_store_wt(v.xin + (size_t)(p + 1) * TX + fcl_tp(v.XR, cb, f, n0 + n), xv);
-      } else {
-        v.h[(size_t)p * T64 + tp] = f < MZ_H ? xv : 0.f;
-        if (p < v.K) v.xin[(size_t)(p + 1) * TX + fcl_tp(v.XR, cb, f, n0 + n)] = xv;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const int t = tid - 256, f = t >> 2, n = 4 * g + (t & 3);
+        const float xv = X[n * LDX + f];
+        const size_t tp = fcl_tp(64, cb, f, n0 + n);
+        v.xhat[(size_t)p * T64 + tp] = S[n * 64 + f];
+        if constexpr (SIG) {
+          fcl_store_wt(v.h + (size_t)p * T64 + tp, f < MZ_H ? xv : 0.f);
+          if (p < v.K) fcl_store_wt(v.xin + (size_t)(p + 1) * TX + fcl_tp(v.XR, cb, f, n0 + n), xv);
+        } else {
+          v.h[(size_t)p * T64 + tp] = f < MZ_H ? xv : 0.f;
+          if (p < v.K) v.xin[(size_t)(p + 1) * TX + fcl_tp(v.XR, cb, f, n0 + n)] = xv;
+        }
       }
-      if (t < 4) v.rstd[(size_t)p * R + row0 + t] = misc[t];
+      if (tid - 256 < NS) v.rstd[(size_t)p * R + row0 + tid - 256] = misc[tid - 256];
     }
   };
   {   // position 0: the representation, its fc1 weights streamed
-    const f32x4 acc = v.O <= 16 ? fcl_quad_res<16>(WR1, X + (lane & 3) * LDX)
-                                : fcl_quad_stream(v.pk + v.rep.F1 + (size_t)w * v.O * 64, v.O, X + (lane & 3) * LDX, lane);
+    f32x4 acc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+      acc[g] = v.O <= 16 ? fcl_quad_res<16>(WR1, X + (4 * g + (lane & 3)) * LDX)
+                         : fcl_quad_stream(v.pk + v.rep.F1 + (size_t)w * v.O * 64, v.O, X + (4 * g + (lane & 3)) * LDX, lane);
     asm volatile("" ::: "memory");
     fcl_quad_load<KP>(WT1, v.pk + v.tr.F1 + (size_t)w * KP * 64, lane);
     fcl_quad_load<64>(WT2, v.pk + v.tr.F2 + (size_t)w * 64 * 64, lane);
@@ -665,7 +680,10 @@ __device__ __forceinline__ void fcl_chain_fwd4_body(const FclView &v, const int 
   FCL_KSTAMP(3)      // the transition's weights have arrived
   for (int p = 1; p <= v.K; ++p) {
     FCL_CSTAMP(0)
-    rest(p, fcl_quad_res<KP>(WT1, X + (lane & 3) * LDX), WT2, b1t, b2t);
+    f32x4 acc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = fcl_quad_res<KP>(WT1, X + (4 * g + (lane & 3)) * LDX);
+    rest(p, acc, WT2, b1t, b2t);
   }
 #undef FCL_CSTAMP
   FCL_KSTAMP(4)        // positions 1..K done
@@ -677,10 +695,10 @@ __device__ __forceinline__ void fcl_chain_fwd4_body(const FclView &v, const int 
   }
 }
 
-template <int KP>
+template <int KP, int G>
 __global__ __launch_bounds__(FCL_THREADS) void k_fcl_chain_fwd4(FclView v) {
   extern __shared__ __attribute__((aligned(16))) float fcl_smem[];
-  fcl_chain_fwd4_body<KP, false>(v, blockIdx.x, fcl_smem);
+  fcl_chain_fwd4_body<KP, false, G>(v, blockIdx.x, fcl_smem);
 }
 
 // The forward pass of batches up to 256 as ONE launch: the chain's workgroups (blocks [0, nchain): dispatched first, always
@@ -694,7 +712,7 @@ template <int KP>
 __global__ __launch_bounds__(FCL_THREADS) void k_fcl_fwd(FclView v, int nchain) {
   extern __shared__ __attribute__((aligned(16))) float fcl_smem[];
   if ((int)blockIdx.x < nchain) {
-    fcl_chain_fwd4_body<KP, true>(v, blockIdx.x, fcl_smem);
+    fcl_chain_fwd4_body<KP, true, 1>(v, blockIdx.x, fcl_smem);
     return;
   }
   const int G = v.bs >> 4;
@@ -709,26 +727,28 @@ __global__ __launch_bounds__(FCL_THREADS) void k_fcl_fwd(FclView v, int nchain) 
   fcl_heads_body<true>(v, cb, p, hd, fcl_smem);
 }
 
+template <int G>
 __device__ __forceinline__ void fcl_chain_bwd4_body(const FclView &v, const int blk, float *fcl_smem) {
+  constexpr int NS = 4 * G;                          // samples of this workgroup: G groups of four (see the forward chain)
   const int LDX = v.xq + 4;
-  float *X = fcl_smem, *A1 = X + 4 * LDX, *red = A1 + 4 * FCL_LDA, *PV = red + 2048 + 16;
+  float *X = fcl_smem, *A1 = X + NS * LDX, *red = A1 + NS * FCL_LDA, *PV = red + G * 2048 + 16;
   float *D2 = X;                                     // d (pre-LayerNorm output), sample-major like X (rows of >= 64 floats)
   float *lnw = PV;
   const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int cb = blk >> 2, n0 = 4 * (blk & 3), row0 = blk * 4, R = v.R, K1 = v.K + 1, loff = fcl_lane_off4(lane, n0);
+  const int row0 = blk * NS, cb = row0 >> 4, n0 = row0 & 15, R = v.R, K1 = v.K + 1;
   const size_t T64 = (size_t)64 * R, T512 = (size_t)512 * R;
   float WB2[MZ_H], WB1[64];
   float WR2[MZ_H];      // the representation's, for position 0 (requested now)
   const float plnw = tid < MZ_H ? v.P[v.ln_w + tid] : 0.f;
-  // wave 0 carries the per-sample work in registers: lane (j, b) = (lane >> 4, lane & 15) = features 4 b + i of sample j -- a
-  // sample's 16 lanes are one DPP row, its two LayerNorm reductions four DPP exchanges each (as in the forward chain)
-  const int j = lane >> 4, f0 = 4 * (lane & 15);
+  // wave g < G carries group g's per-sample work in registers: lane (j, b) = (lane >> 4, lane & 15) = features 4 b + i of sample j
+  // -- a sample's 16 lanes are one DPP row, its two LayerNorm reductions four DPP exchanges each (as in the forward chain)
+  const int j = lane >> 4, f0 = 4 * (lane & 15), sj = 4 * w + j;
   float dgam[4] = {0.f, 0.f, 0.f, 0.f}, dbet[4] = {0.f, 0.f, 0.f, 0.f};
   f32x4 dch = (f32x4){0.f, 0.f, 0.f, 0.f};         // d chain: gradient from the transition of position p + 1 into h_p
   float tv[4][5], trs = 0.f;
   auto request = [&](int p) __attribute__((always_inline)) {
-    if (w == 0) {
-      const size_t o = fcl_tp(64, cb, f0, n0 + j);
+    if (w < G) {
+      const size_t o = fcl_tp(64, cb, f0, n0 + sj);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         tv[i][0] = v.dH[((size_t)0 * K1 + p) * T64 + o + i * 16];
@@ -737,10 +757,10 @@ __device__ __forceinline__ void fcl_chain_bwd4_body(const FclView &v, const int 
         tv[i][3] = v.h[(size_t)p * T64 + o + i * 16];
         tv[i][4] = v.xhat[(size_t)p * T64 + o + i * 16];
       }
-      trs = v.rstd[(size_t)p * R + row0 + j];
+      trs = v.rstd[(size_t)p * R + row0 + sj];
     }
   };
-  for (int idx = tid; idx < 4 * LDX; idx += FCL_THREADS) X[idx] = 0.f;
+  for (int idx = tid; idx < NS * LDX; idx += FCL_THREADS) X[idx] = 0.f;
   request(v.K);
   // (loads return in order: the small reads above first, then the weights in the order of their first use)
   asm volatile("" ::: "memory");
@@ -748,10 +768,10 @@ __device__ __forceinline__ void fcl_chain_bwd4_body(const FclView &v, const int 
   asm volatile("" ::: "memory");
   if (tid < 64) lnw[tid] = plnw;
   fcl_quad_load<64>(WB1, v.pk + v.tr.B1 + (size_t)w * 64 * 64, lane);
-  fcl_quad_load<MZ_H>(WR2, v.pk + v.rep.B2 + (size_t)w * MZ_H * 64, lane);
+  if constexpr (G == 1) fcl_quad_load<MZ_H>(WR2, v.pk + v.rep.B2 + (size_t)w * MZ_H * 64, lane);      // (G > 1: no registers to hold them through the loop)
   fcl_bar();
   auto body = [&](int p, const float (&W2)[MZ_H]) __attribute__((always_inline)) {
-    if (w == 0) {
+    if (w < G) {
       // gradient arriving at h_p (value and policy heads of position p, reward head and transition of position p + 1;
       // hook 0.5, learners.py:200), then ReLU and LayerNorm backwards over the sample's 16 lanes
       const float rstd = trs;
@@ -773,38 +793,45 @@ __device__ __forceinline__ void fcl_chain_bwd4_body(const FclView &v, const int 
       f32x4 dy;
 #pragma unroll
       for (int i = 0; i < 4; ++i) dy[i] = (f0 + i < MZ_H) ? rstd * (dx[i] - s1 * inv - xh[i] * (s2 * inv)) : 0.f;
-      *(f32x4 *)(D2 + j * LDX + f0) = dy;
+      *(f32x4 *)(D2 + sj * LDX + f0) = dy;
     }
     if (p > 0) request(p - 1);
     const float *a1t = v.a1c + (size_t)p * T512 + fcl_tp(512, cb, 64 * w, 0);
-    f32x4 msk;
+    f32x4 msk[G];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) msk[i] = (a1t + i * 16)[loff];
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) msk[g][i] = (a1t + i * 16)[fcl_lane_off4(lane, n0 + 4 * g)];
     fcl_bar();
     if (tid >= 256) {      // the delta tape of this position, by the upper half of the workgroup (D2 is next written three barriers on)
       const int t = tid - 256;
-      v.d2c[(size_t)p * T64 + fcl_tp(64, cb, t >> 2, n0 + (t & 3))] = D2[(t & 3) * LDX + (t >> 2)];
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+        v.d2c[(size_t)p * T64 + fcl_tp(64, cb, t >> 2, n0 + 4 * g + (t & 3))] = D2[(4 * g + (t & 3)) * LDX + (t >> 2)];
     }
-    const f32x4 acc = fcl_quad_res<MZ_H>(W2, D2 + (lane & 3) * LDX);
-    {
-      const int g0 = 64 * w + 4 * (lane >> 2);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const f32x4 acc = fcl_quad_res<MZ_H>(W2, D2 + (4 * g + (lane & 3)) * LDX);
+      const int g0 = 64 * w + 4 * (lane >> 2), loff = fcl_lane_off4(lane, n0 + 4 * g);
       float *d1t = v.d1c + (size_t)p * T512 + fcl_tp(512, cb, 64 * w, 0);
       f32x4 d;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        d[i] = msk[i] > 0.f ? acc[i] : 0.f;
+        d[i] = msk[g][i] > 0.f ? acc[i] : 0.f;
         (d1t + i * 16)[loff] = d[i];
       }
-      *(f32x4 *)(A1 + (lane & 3) * FCL_LDA + g0) = d;
+      *(f32x4 *)(A1 + (4 * g + (lane & 3)) * FCL_LDA + g0) = d;
     }
     fcl_bar();
     if (p >= 1) {
-      *(f32x4 *)(red + (w * 64 + lane) * 4) = fcl_quad_res<64>(WB1, A1 + (lane & 3) * FCL_LDA + 64 * w);
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+        *(f32x4 *)(red + g * 2048 + (w * 64 + lane) * 4) = fcl_quad_res<64>(WB1, A1 + (4 * g + (lane & 3)) * FCL_LDA + 64 * w);
       fcl_bar();
-      if (w == 0) {
+      if (w < G) {
         f32x4 y = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ww = 0; ww < FCL_NW; ++ww) y += *(const f32x4 *)(red + (ww * 64 + f0 + j) * 4);      // (written by lane 4 b + j)
+        for (int ww = 0; ww < FCL_NW; ++ww) y += *(const f32x4 *)(red + w * 2048 + (ww * 64 + f0 + j) * 4);      // (written by lane 4 b + j)
         dch = y;            // (rows >= 50 come out of zero weights)
       }
       // (red is next written after two more barriers)
@@ -815,25 +842,27 @@ __device__ __forceinline__ void fcl_chain_bwd4_body(const FclView &v, const int 
   body(v.K, WB2);
   fcl_quad_settle(WB1);
   for (int p = v.K - 1; p >= 1; --p) body(p, WB2);
+  if constexpr (G > 1) fcl_quad_load<MZ_H>(WR2, v.pk + v.rep.B2 + (size_t)w * MZ_H * 64, lane);
   body(0, WR2);      // position 0: the representation's fc2
-  // LayerNorm weight / bias gradients of this workgroup's 4 samples over all positions
-  if (w == 0) {
+  // LayerNorm weight / bias gradients of every group's 4 samples over all positions: one row of lnpart per GROUP (batch / 4 rows)
+  if (w < G) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       float a = dgam[i], b = dbet[i];
       a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
       b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
       if (j == 0 && f0 + i < 64) {
-        v.lnpart[(size_t)blk * 128 + f0 + i] = a;
-        v.lnpart[(size_t)blk * 128 + 64 + f0 + i] = b;
+        v.lnpart[((size_t)blk * G + w) * 128 + f0 + i] = a;
+        v.lnpart[((size_t)blk * G + w) * 128 + 64 + f0 + i] = b;
       }
     }
   }
 }
 
+template <int G>
 __global__ __launch_bounds__(FCL_THREADS) void k_fcl_chain_bwd4(FclView v) {
   extern __shared__ __attribute__((aligned(16))) float fcl_smem[];
-  fcl_chain_bwd4_body(v, blockIdx.x, fcl_smem);
+  fcl_chain_bwd4_body<G>(v, blockIdx.x, fcl_smem);
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradients (+ optimiser)
@@ -903,7 +932,7 @@ __device__ __forceinline__ void fcl_bias_corr(const FclDw &a, float *dst) {
 #define FCL_DW_Q(NA, NI) ((NA) * (4 * (NI) + 1))                                   // floats per lane a wave leaves in LDS
 #define FCL_DW_LDS(NW, NA, NI) (((NW) * FCL_DW_Q(NA, NI) * 64 + 4) * 4)            // bytes: the waves' partial tiles + the two bias corrections
 
-template <int NW, int NA, int NI, int NF>
+template <int NW, int NA, int NI, int NF, bool FUSABLE>
 __device__ __forceinline__ void fcl_dw_job(const FclJob *jp, int slab, const FclDw &a, float *sh) {
   constexpr int Q = FCL_DW_Q(NA, NI);
   const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, g4 = lane >> 4, m16 = lane & 15;
@@ -926,6 +955,35 @@ __device__ __forceinline__ void fcl_dw_job(const FclJob *jp, int slab, const Fcl
   // unit u = (position u / nchs, chunk u % nchs); wave w takes u = w, w + NW, ...: a fixed assignment and a fixed order, so the
   // sum is deterministic (k index g4 of k-step jj of chunk c = row 16 c + 4 g4 + jj, in both operands).  The loads of
   // NF units are requested before the first MFMA of the group
+  // the fused optimiser's operands (weight, moments, pack positions of this thread's elements of the tile) do not depend on the
+  // gradient: requested NOW, they arrive under the tapes' loads and the MFMAs (requested after the reduction, they were one more
+  // exposed round trip at the end of the step's last launch)
+  constexpr int T_ = NW * 64, EW_ = NA * NI * 256, EB_ = NA * 16, EPT_ = (EW_ + EB_ + T_ - 1) / T_;
+  float pre_p[FUSABLE ? EPT_ : 1], pre_m[FUSABLE ? EPT_ : 1], pre_v[FUSABLE ? EPT_ : 1];
+  int pre_a[FUSABLE ? EPT_ : 1], pre_b[FUSABLE ? EPT_ : 1];
+  static_assert(!FUSABLE || NA == 1, "the fused optimiser works on 16-row tiles");
+  if constexpr (FUSABLE) {
+    if (a.fuse) {
+#pragma unroll
+      for (int k = 0; k < EPT_; ++k) {
+        const int e = tid + k * T_;
+        size_t ix = 0;
+        bool ok_ = false;
+        if (e < EW_) {
+          const int q = e >> 6, l = e & 63, i = q >> 2;
+          const int mm = 16 * j.tm + 4 * (l >> 4) + (q & 3), nn = 16 * (NI * j.ng + i) + (l & 15);
+          ix = j.w_off + (size_t)mm * j.N + nn;
+          ok_ = mm < j.M && nn < j.N;
+        } else if (e < EW_ + EB_) {
+          const int m = e - EW_;
+          ix = j.b_off + 16 * j.tm + m;
+          ok_ = j.ng == 0 && 16 * j.tm + m < j.M;
+        }
+        pre_p[k] = 0.f; pre_m[k] = 0.f; pre_v[k] = 0.f; pre_a[k] = -1; pre_b[k] = -1;
+        if (ok_) { pre_p[k] = a.P[ix]; pre_m[k] = a.m[ix]; pre_v[k] = a.vv[ix]; pre_a[k] = a.posA[ix]; pre_b[k] = a.posB[ix]; }
+      }
+    }
+  }
   // Two register sets in turn: the loads of the NEXT NF units are in flight while the MFMAs of this set run (one set: a wave
   // waited out a round trip to L2 / HBM in front of every NF units of MFMAs, and two waves per SIMD hide little of it)
   int p = 0, c = w;
@@ -1012,7 +1070,7 @@ __device__ __forceinline__ void fcl_dw_job(const FclJob *jp, int slab, const Fcl
     idx = 0;
     return false;
   };
-  if (!a.fuse || NA != 1) {        // (a slab's tile: to part[slab]; no arrays of elements kept in registers)
+  if (!FUSABLE || !a.fuse) {        // (a slab's tile: to part[slab]; no arrays of elements kept in registers)
     float *out = a.part + (size_t)slab * a.nflat;
     for (int e = tid; e < EW + EB; e += T) {
       float g;
@@ -1021,24 +1079,18 @@ __device__ __forceinline__ void fcl_dw_job(const FclJob *jp, int slab, const Fcl
     }
     return;
   }
-  if constexpr (NA == 1) {
+  if constexpr (FUSABLE) {
     // fused optimiser: a thread's elements together, so that their loads (weight, moments, pack positions) are one round trip
-    float g[EPT], pv[EPT], ea[EPT], es[EPT];
-    size_t idx[EPT];
-    bool ok[EPT];
-    int pa[EPT], pb[EPT];
-#pragma unroll
-    for (int k = 0; k < EPT; ++k) {
-      ok[k] = element(tid + k * T, g[k], idx[k]);
-      if (ok[k]) { pv[k] = a.P[idx[k]]; ea[k] = a.m[idx[k]]; es[k] = a.vv[idx[k]]; pa[k] = a.posA[idx[k]]; pb[k] = a.posB[idx[k]]; }
-    }
+    static_assert(EPT == EPT_, "the prefetched operands are this thread's elements");
     const float bc1 = sh[NW * Q * 64], bc2 = sh[NW * Q * 64 + 1];
     const double lr = (double)*a.lr_p;
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
-      if (ok[k]) {
-        a.grad[idx[k]] = g[k];
-        fcl_adam_elem(a, idx[k], g[k], pv[k], ea[k], es[k], pa[k], pb[k], bc1, bc2, lr);
+      float g;
+      size_t idx;
+      if (element(tid + k * T, g, idx)) {
+        a.grad[idx] = g;
+        fcl_adam_elem(a, idx, g, pre_p[k], pre_m[k], pre_v[k], pre_a[k], pre_b[k], bc1, bc2, lr);
       }
     }
   }
@@ -1117,7 +1169,7 @@ __global__ __launch_bounds__(FCL_THREADS) void k_fcl_dwa(const FclJob *jobs, int
   extern __shared__ __attribute__((aligned(16))) float fcl_smem[];
   const int b = blockIdx.x;
   if (b < njobs) {
-    fcl_dw_job<FCL_NW, 1, 2, 4>(jobs + b, 0, a, fcl_smem);
+    fcl_dw_job<FCL_NW, 1, 2, 4, true>(jobs + b, 0, a, fcl_smem);
     return;
   }
   if (!tail) return;
@@ -1168,9 +1220,9 @@ __global__ __launch_bounds__(256, 2) void k_fcl_dwt(const FclJob *jobs, int njob
   if (b > njobs * a.S) return;
   const FclJob *jp = jobs + b / a.S;
   const int slab = b % a.S, na = jp->na;
-  if (na == 4) fcl_dw_job<4, 4, 4, 2>(jp, slab, a, fcl_smem);
-  else if (na == 2) fcl_dw_job<4, 2, 4, 3>(jp, slab, a, fcl_smem);
-  else fcl_dw_job<4, 1, 4, 4>(jp, slab, a, fcl_smem);
+  if (na == 4) fcl_dw_job<4, 4, 4, 2, false>(jp, slab, a, fcl_smem);
+  else if (na == 2) fcl_dw_job<4, 2, 4, 3, false>(jp, slab, a, fcl_smem);
+  else fcl_dw_job<4, 1, 4, 4, false>(jp, slab, a, fcl_smem);
 }
 
 // The backward chain (batch / 4 workgroups: 64 of 256 CUs at batch 256) and the heads' weight-gradient jobs -- they read only
@@ -1180,8 +1232,8 @@ __global__ __launch_bounds__(FCL_THREADS) void k_fcl_bwd_dw(FclView v, int nchai
   extern __shared__ __attribute__((aligned(16))) float fcl_smem[];
   if (blockIdx.x == 0 && v.flags)          // (the fused forward launch's arrival counters, for the next step)
     for (int i = threadIdx.x; i < v.nflags; i += FCL_THREADS) v.flags[i] = 0u;
-  if ((int)blockIdx.x < nchain) fcl_chain_bwd4_body(v, blockIdx.x, fcl_smem);
-  else fcl_dw_job<FCL_NW, 1, 4, 4>(jobs + ((int)blockIdx.x - nchain), 0, a, fcl_smem);
+  if ((int)blockIdx.x < nchain) fcl_chain_bwd4_body<1>(v, blockIdx.x, fcl_smem);
+  else fcl_dw_job<FCL_NW, 1, 4, 4, true>(jobs + ((int)blockIdx.x - nchain), 0, a, fcl_smem);
 }
 
 // ------------------------------------------------------------------------------------------------ gradient, optimiser (unfused paths)

@@ -164,15 +164,39 @@ struct mz_replay {
   // one caller at a time per handle, whoever it is: the actors' ingest on the handle's own Python thread and the native learner
   // loop's sampling / refresh calls (mz_fcl_run, libmz_hip.so) take turns here
   std::recursive_mutex api_mu;
+  // row buffers of evicted slices, reused by the slices that arrive (mzr_ingest_slices): with the window full every new slice
+  // replaces old ones, and a fresh 45 KB vector per slice is page faults under the process's one mmap lock -- the copies of four
+  // ingest threads ran SLOWER than one thread's
+  std::mutex spare_mu;
+  std::vector<std::vector<float>> hist_spare;
 };
 #define MZR_LOCK(r) std::lock_guard<std::recursive_mutex> api_lock_(const_cast<mz_replay *>(r)->api_mu)
 
 static void tree_add(mz_replay *r, const double *priorities, int64_t n, Hist *h, int64_t *positions_out);
 
+// dst <- src for a slice's rows (tens of KB, read again only when a batch is sampled from it): streaming stores on the 32-byte
+// aligned body -- a regular store first READS the destination line (read-for-ownership): a third of the memory traffic of the ONE
+// replay's host, which is bound by exactly that traffic once the producing ranks assemble the slices
+#include <immintrin.h>
+static void copy_streaming(float *dst, const float *src, size_t n) {
+  size_t i = 0;
+  while (i < n && ((uintptr_t)(dst + i) & 31)) { dst[i] = src[i]; ++i; }
+  for (; i + 8 <= n; i += 8) _mm256_stream_ps(dst + i, _mm256_loadu_ps(src + i));
+  for (; i < n; ++i) dst[i] = src[i];
+}
+
+static void retire(mz_replay *r, Hist *h) {
+  if (h->rows.capacity() > 0) {
+    std::lock_guard<std::mutex> lk(r->spare_mu);
+    if (r->hist_spare.size() < 8192) r->hist_spare.push_back(std::move(h->rows));
+  }
+  delete h;
+}
+
 static void insert_job(mz_replay *r, Job &job) {
   for (const Pending &p : job.items) {
     tree_add(r, p.pri, p.keep, p.h, nullptr);
-    if (p.h->refs == 0) delete p.h;
+    if (p.h->refs == 0) retire(r, p.h);
     r->frames += p.keep;
     if (p.done) r->games += 1;
   }
@@ -330,7 +354,7 @@ static void tree_add(mz_replay *r, const double *priorities, int64_t n, Hist *h,
       Hist *old = slot[i];
       int64_t j = i + 1;
       while (j < seg && slot[j] == old) ++j;
-      if (old && (old->refs -= (j - i)) == 0) delete old;
+      if (old && (old->refs -= (j - i)) == 0) retire(r, old);
       i = j;
     }
     for (int64_t i = 0; i < seg; ++i) { slot[i] = h; ls[i] = (int32_t)(step + i); }
@@ -1187,9 +1211,21 @@ int mzr_ingest_slices(mz_replay *r, const void *blob, int64_t bytes, int env_bas
   auto copy = [&](int64_t lo, int64_t hi) {
     for (int64_t i = lo; i < hi; ++i) {
       const Ref &f = refs[(size_t)i];
-      job.items[(size_t)i].h->rows.assign((const float *)f.rows, (const float *)f.rows + (size_t)f.n * R);
+      std::vector<float> buf;
+      {
+        std::lock_guard<std::mutex> lk(r->spare_mu);
+        if (!r->hist_spare.empty()) { buf.swap(r->hist_spare.back()); r->hist_spare.pop_back(); }
+      }
+      if (buf.capacity() < (size_t)f.n * R) {
+        buf.assign((const float *)f.rows, (const float *)f.rows + (size_t)f.n * R);      // (a fresh buffer: the copy is its first touch)
+      } else {
+        buf.resize((size_t)f.n * R);
+        copy_streaming(buf.data(), (const float *)f.rows, (size_t)f.n * R);
+      }
+      job.items[(size_t)i].h->rows.swap(buf);
       memcpy(const_cast<double *>(job.items[(size_t)i].pri), f.pri, (size_t)f.n * 8);
     }
+    _mm_sfence();                           // (this thread's streaming stores are globally visible before the slices are handed on)
   };
   const int T = r->pool.T;
   if (T <= 1 || count < 2 * T) copy(0, count);

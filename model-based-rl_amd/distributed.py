@@ -39,6 +39,7 @@ class ShmRing(object):
   [chunk][B][rec] float32, each preceded by its move count.  The producer (an actor rank) only writes `head` and the
   slot it owns, the consumer (rank 0) only writes `tail`."""
   HDR = 8
+  BLOB = 1 << 40            # slot counts from here on: a blob of finished history slices of (count - BLOB) bytes
 
   def __init__(self, name, chunk=0, B=0, rec=0, slots=4, create=False):
     self.name = name
@@ -92,6 +93,26 @@ class ShmRing(object):
       n[0] = n_moves
     self._store(0, head + 1)                # release: published after the payload
 
+  def put_slices(self, assembler):
+    """the finished history slices a producing rank's assembler holds (mz_assembler, include/mz_replay.h), oldest first, as blobs of at
+    most one slot each; -> slots published"""
+    lib, put = self._lib, 0
+    while lib.mzr_asm_pending(assembler) > 0:
+      head = self._load(0)
+      while head - self._load(1) >= self.slots:
+        time.sleep(0.0002)
+      n, data = self._slot(head)
+      nbytes = int(lib.mzr_asm_take(assembler, data.ctypes.data, self.slot_bytes - 8))
+      if nbytes < 0:
+        from . import _abi
+        _abi.check_replay(-1, 'mzr_asm_take')
+      if nbytes == 0:
+        break
+      n[0] = self.BLOB + nbytes
+      self._store(0, head + 1)
+      put += 1
+    return put
+
   def close_producer(self):
     self._store(2, 1)
 
@@ -104,6 +125,8 @@ class ShmRing(object):
       return None
     n, data = self._slot(tail)
     k = int(n[0])
+    if k >= self.BLOB:                      # a blob of finished slices (put_slices): k - BLOB bytes
+      return data, k - self.BLOB, 'slices'
     return data, abs(k), k < 0
 
   def done(self):
@@ -127,15 +150,43 @@ class ShmRing(object):
 
 
 class RingReplay(object):
-  """What an actor on rank r > 0 holds in place of the replay buffer: `ingest_records` ships the chunk to rank 0."""
+  """What an actor on rank r > 0 holds in place of the replay buffer.  With the run's config: the per-ENVIRONMENT half of the replay's
+  ingest (open game buffers, flush rules, history slicing, priorities: actors.py:160-173, replay_buffer.py:110-111) runs HERE, in a
+  native assembler of this rank (mz_assembler), and `ingest_records` ships the finished slices to rank 0, whose one replay only
+  copies them and inserts their leaves.  Without a config (and with MZ_RING_RAW=1): the record chunk itself travels."""
 
-  def __init__(self, ring):
+  def __init__(self, ring, config=None):
     self.ring = ring
     self.frames = 0
+    self.asm = None
+    if config is not None and os.environ.get('MZ_RING_RAW', '0')[:1] != '1':
+      import ctypes as C
+      from . import _abi
+      from .replay_buffer import native_config
+      self._lib = _abi.load_replay()
+      self.asm = C.c_void_p()
+      _abi.check_replay(self._lib.mzr_asm_create(C.byref(native_config(config)), int(ring.B), C.byref(self.asm)), 'mzr_asm_create')
 
   def ingest_records(self, records, n_moves, B, env_base=0, env_major=False):
-    self.ring.put(records, int(n_moves))    # (packed environment-major on the way into the ring)
+    if self.asm is None:
+      self.ring.put(records, int(n_moves))    # (packed environment-major on the way into the ring)
+    else:
+      from . import _abi
+      src = records.numpy() if torch.is_tensor(records) else np.ascontiguousarray(records, np.float32)
+      _abi.check_replay(self._lib.mzr_asm_feed(self.asm, src.ctypes.data, int(n_moves), int(B), int(src.shape[-1])), 'mzr_asm_feed')
+      self.ring.put_slices(self.asm)
     self.frames += int(n_moves) * int(B)
+
+  def close(self):
+    if self.asm is not None:
+      self._lib.mzr_asm_destroy(self.asm)
+      self.asm = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:
+      pass
 
   def save_history(self, *a, **k):
     raise NotImplementedError('host-environment actors run on the replay rank')
@@ -153,7 +204,10 @@ def serve_rings(rings, replay_call, B, stop):
       got = ring.poll()
       if got is not None:
         data, n, packed = got
-        replay_call('ingest_records', data, n, B, r * B, packed)
+        if packed == 'slices':             # assembled by the producing rank: n bytes of finished slices
+          replay_call('ingest_slices', data, n, r * B)
+        else:
+          replay_call('ingest_records', data, n, B, r * B, packed)
         ring.done()
         idle = False
       elif ring.finished():

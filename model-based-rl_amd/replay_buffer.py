@@ -102,6 +102,19 @@ def default_ingest_threads(config=None):
   return max(1, min(4, cpus - 1))
 
 
+def native_config(config):
+  """mzr_config (include/mz_replay.h) of a run's Config: what the native replay -- and a producing rank's assembler -- is made from"""
+  capacity = int(config.window_size)
+  step = int(config.window_step) if getattr(config, 'window_step', None) is not None else capacity
+  return _abi.MzrConfig(capacity, step, int(np.prod(config.obs_space)), int(config.action_space), int(config.num_unroll_steps),
+                        int(config.td_steps), int(getattr(config, 'max_history_length', 500)), int(config.batch_size),
+                        float(config.epsilon), float(config.alpha), float(config.beta),
+                        float(getattr(config, 'beta_increment_per_sampling', 0.001)), float(config.discount),
+                        int(config.seed or 0), int(bool(getattr(config, 'two_players', False))),
+                        int(bool(getattr(config, 'episode_life', False))), default_ingest_threads(config),
+                        int(bool(getattr(config, 'obs_u8', False))))
+
+
 class PrioritizedReplay(object):
 
   def __init__(self, config):
@@ -113,13 +126,7 @@ class PrioritizedReplay(object):
     capacity = int(config.window_size)
     step = int(config.window_step) if getattr(config, 'window_step', None) is not None else capacity
     self.lib = _abi.load_replay()
-    cfg = _abi.MzrConfig(capacity, step, self.obs_dim, self.action_space, int(config.num_unroll_steps),
-                         int(config.td_steps), int(getattr(config, 'max_history_length', 500)), int(config.batch_size),
-                         float(config.epsilon), float(config.alpha), float(config.beta),
-                         float(getattr(config, 'beta_increment_per_sampling', 0.001)), float(config.discount),
-                         int(config.seed or 0), int(bool(getattr(config, 'two_players', False))),
-                         int(bool(getattr(config, 'episode_life', False))), default_ingest_threads(config),
-                         int(bool(getattr(config, 'obs_u8', False))))
+    cfg = native_config(config)
     h = C.c_void_p()
     _abi.check_replay(self.lib.mzr_create(C.byref(cfg), C.byref(h)), 'mzr_create')
     self._h = h
@@ -179,6 +186,12 @@ class PrioritizedReplay(object):
       ptr, rec = _p(records), int(records.shape[-1])
     fn = self.lib.mzr_ingest_records_packed if env_major else self.lib.mzr_ingest_records_from
     _abi.check_replay(fn(self._h, ptr, int(n_moves), int(B), rec, int(env_base)), 'mzr_ingest_records')
+
+  def ingest_slices(self, blob, nbytes, env_base=0):
+    """finished history slices assembled by a PRODUCING rank (distributed.RingReplay -> mz_assembler; include/mz_replay.h): one
+    sequential copy per slice and the insertion of its leaves -- the one-replay layout's hand-off (train --ranks N)"""
+    ptr = C.c_void_p(blob.data_ptr()) if hasattr(blob, 'data_ptr') else C.c_void_p(np.asarray(blob).ctypes.data)
+    _abi.check_replay(self.lib.mzr_ingest_slices(self._h, ptr, int(nbytes), int(env_base)), 'mzr_ingest_slices')
 
   # replay_buffer.py:124-163 (+ insert_target 165-198 inside the native call)
   def sample_batch_arrays(self):

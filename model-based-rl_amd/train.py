@@ -152,7 +152,7 @@ def launch_ranks(config, max_moves, selfplay_only=False, learner_steps=None, sta
       workers.append(learner.launch.remote(learner_steps))
   else:
     ring = D.ShmRing('%s_%d' % (run_id, rank))
-    actor_replay = D.RingReplay(ring)
+    actor_replay = D.RingReplay(ring, config)      # (this rank assembles its environments' history slices itself)
   del probe
   dedicated = bool(getattr(config, 'dedicated_learner_rank', False)) and world > 1 and not selfplay_only
 

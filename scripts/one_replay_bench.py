@@ -33,10 +33,17 @@ def make_chunks(n, seed, env_base):
   return out
 
 
+def replay_cfg(threads):
+  return types.SimpleNamespace(batch_size=256, epsilon=0.01, alpha=1.0, beta=1.0, obs_space=(O,), action_space=A, window_size=1 << 21,
+                               window_step=None, num_unroll_steps=5, td_steps=10, max_history_length=500, discount=0.997, seed=0,
+                               ingest_threads=threads, obs_u8=U8)
+
+
 def producer(name, rank, nchunks, pace_ms, go, result):
   from model_based_rl_amd import distributed as D
   data = make_chunks(16, rank, rank * B)            # cycled (the replay only needs well-formed games)
   ring = D.ShmRing(name)
+  sink = D.RingReplay(ring, replay_cfg(1))          # (as train.launch_ranks: this rank assembles its history slices; MZ_RING_RAW=1: the chunks travel)
   go.wait()
   waited, t_next = 0.0, time.perf_counter()
   for i in range(nchunks):
@@ -46,10 +53,11 @@ def producer(name, rank, nchunks, pace_ms, go, result):
       if dt > 0:
         time.sleep(dt)
     t0 = time.perf_counter()
-    ring.put(data[i % len(data)], CH)
+    sink.ingest_records(data[i % len(data)], CH, B)
     waited += time.perf_counter() - t0
   ring.close_producer()
   result.put((rank, waited))
+  sink.close()
   ring.release()
 
 
@@ -65,9 +73,7 @@ def main():
   a = ap.parse_args()
   from model_based_rl_amd import distributed as D
   from model_based_rl_amd.replay_buffer import PrioritizedReplay
-  cfg = types.SimpleNamespace(batch_size=256, epsilon=0.01, alpha=1.0, beta=1.0, obs_space=(O,), action_space=A, window_size=1 << 21,
-                              window_step=None, num_unroll_steps=5, td_steps=10, max_history_length=500, discount=0.997, seed=0,
-                              ingest_threads=a.threads, obs_u8=U8)
+  cfg = replay_cfg(a.threads)
   replay = PrioritizedReplay(cfg)
   run = 'mz_onereplay_%d' % os.getpid()
   rings = {r: D.ShmRing('%s_%d' % (run, r), CH, B, REC, slots=4, create=True) for r in range(1, a.ranks)}

@@ -104,6 +104,7 @@ if a.priors:
          'seconds': time.time() - t0}
   print(json.dumps(out))
   if a.out:
+    os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
     with open(a.out, 'a') as f:
       f.write(json.dumps(out) + '\n')
   assert diff_a == 0 and diff_b == 0, out
@@ -148,5 +149,6 @@ out = {'shape': a.shape, 'split_f16': bool(a.split), 'moves_played': nchunks * c
        'seconds': time.time() - t0}
 print(json.dumps(out))
 if a.out:
+  os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
   with open(a.out, 'a') as f:
     f.write(json.dumps(out) + '\n')

@@ -56,7 +56,7 @@ def test_pong_split_line():
 
 
 def test_learner_line():
-  line = line_of(['--workload', 'learner', '--steps', '60', '--runs', '1'])
+  line = line_of(['--workload', 'learner', '--steps', '60', '--runs', '1', '--batch', '256,1024'])
   assert line['metric'] == 'learner_updates_per_second' and line['roofline']['bound'] == 'mfma' and line.get('secondary')
   assert line['roofline']['flop_per_update'] == 1425801216        # batch 256, K = 5, LunarLander shapes: 3 x forward
   assert 20 < line['roofline']['us_per_update'] < 400              # the native step (the PyTorch graph: ~900)
@@ -64,3 +64,34 @@ def test_learner_line():
   # the timed call is Learner.launch, and its stretches between Python boundaries ran in the native loop (mz_fcl_run)
   assert line['config']['native_loop'] and 'Learner.launch' in line['config']['workload']
   assert line['config']['native_loop_host_us_per_update']['updates'] >= 60
+  # the batch sweep: updates/s, samples/s, roofline fraction and host microseconds per update for every batch
+  sw = line['batch_sweep']
+  assert [p_['batch'] for p_ in sw] == [256, 1024]
+  for p_ in sw:
+    assert p_['updates_per_s'] > 0 and abs(p_['samples_per_s'] - p_['updates_per_s'] * p_['batch']) < 1e-6 * p_['samples_per_s']
+    assert 0 < p_['frac'] < 1 and p_['us_per_update_gpu'] > 10 and set(p_['host_us_per_update']) >= {'sample_us', 'refresh_us', 'launch_us'}
+  assert sw[1]['frac'] > sw[0]['frac']                      # (a larger batch fills more of the chip)
+  assert sw[1]['flop_per_update'] == 4 * sw[0]['flop_per_update']
+
+
+def test_depth_sensitivity_block_and_policy_gain():
+  """--policy_gain g (policy-head output layer x g: sharper priors, deeper trees) and the headline's depth_sensitivity block
+  (VERDICT r05 item 4): a sharper policy deepens the search, the block carries rate, roofline fraction, depths and the cycles of the two
+  depth-dependent phases per gain."""
+  if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+  from bench import sharpened
+  import torch
+  w = {'policy_head.policy.weight': torch.ones(4, 8), 'policy_head.policy.bias': torch.ones(4), 'x': torch.ones(2)}
+  s4 = sharpened(w, 4)
+  assert float(s4['policy_head.policy.weight'][0, 0]) == 4.0 and float(s4['policy_head.policy.bias'][0]) == 4.0 and float(s4['x'][0]) == 1.0
+  line = line_of(['--steps', '32', '--warmup', '16', '--runs', '1', '--no-cpu-baseline', '--no-live-traffic', '--min-seconds', '0.2'])
+  rows = line['depth_sensitivity']['rows']
+  assert [r_['policy_gain'] for r_ in rows] == [1, 2, 4, 8]
+  assert rows[-1]['mean_leaf_depth'] > rows[0]['mean_leaf_depth'] + 0.5 and rows[-1]['max_leaf_depth'] >= rows[0]['max_leaf_depth']
+  for r_ in rows:
+    assert r_['env_steps_per_s'] > 1e6 and 0.2 < r_['frac'] < 1 and r_['cycles_per_sim_wave0']['t_select'] > 0
+  assert rows[-1]['cycles_per_sim_wave0']['t_select'] > rows[0]['cycles_per_sim_wave0']['t_select']
+  assert 'share_of_added' in rows[-1]
+  g = line_of(['--steps', '32', '--warmup', '16', '--runs', '1', '--no-cpu-baseline', '--no-live-traffic', '--min-seconds', '0.2', '--policy_gain', '4'])
+  assert g.get('secondary_line') and g['config']['policy_gain'] == 4.0 and 'depth_sensitivity' not in g

@@ -255,16 +255,44 @@ def test_ring_path_with_producer_side_packing_is_bit_identical(T, mhl, window):
   O, A, B, moves, chunk = 5, 3, 101, 96, 8
   recs = [_bulk_records(np.random.RandomState(7 + r), moves, B, O, A, T) for r in range(2)]      # two "ranks"
   results = []
-  for mode, threads in (('direct', 1), ('ring', 4), ('ring', 3)):
+  for mode, threads in (('direct', 1), ('ring', 4), ('ring', 3), ('slices', 4), ('slices', 1)):
     rep = PrioritizedReplay(make_cfg(obs_space=(O,), action_space=A, max_history_length=mhl, window_size=window,
                                      discount=0.997, ingest_threads=threads))
-    rings = [D.ShmRing('mzt_pack_%d_%d' % (os.getpid(), r), chunk, B, O + A + 10, slots=2, create=True) for r in range(2)] if mode == 'ring' else None
+    rings = [D.ShmRing('mzt_pack_%d_%d' % (os.getpid(), r), chunk, B, O + A + 10, slots=2, create=True) for r in range(2)] if mode != 'direct' else None
+    # 'slices': the producing rank assembles its environments' history slices itself (mz_assembler) and ships THOSE; a slot of 8 moves
+    # x 101 environments holds few of the 500-step slices: a chunk's slices travel as several blobs, drained between the puts
+    sinks = [D.RingReplay(rg, rep.config) for rg in rings] if mode == 'slices' else None
     lo = 0
     for step in (8, 8, 5, 8, 3, 8, 8, 8, 8, 8, 8, 8, 8):           # (ragged chunks: 5 and 3 moves)
       for r in range(2):
         piece = recs[r][lo:lo + step]
         if mode == 'direct':
           rep.ingest_records(piece, step, B, r * B)
+        elif mode == 'slices':
+          import threading
+          drained = []
+
+          def drain(rg=rings[r], base=r * B):
+            import time
+            while not rg.finished() or rg.pending():
+              got = rg.poll()
+              if got is None:
+                if stop.is_set() and not rg.pending():
+                  return
+                time.sleep(0.0002)
+                continue
+              data, nb, kind = got
+              assert kind == 'slices'
+              rep.ingest_slices(data, nb, base)
+              drained.append(nb)
+              rg.done()
+          stop = threading.Event()
+          th = threading.Thread(target=drain)
+          th.start()
+          sinks[r].ingest_records(piece, step, B)
+          stop.set()
+          th.join(timeout=60)
+          assert not th.is_alive() and rings[r].pending() == 0
         else:
           rings[r].put(piece, step)
           data, n, packed = rings[r].poll()
@@ -278,6 +306,9 @@ def test_ring_path_with_producer_side_packing_is_bit_identical(T, mhl, window):
     n = rep.size()
     results.append(dict(total=rep.tree.total_priority, size=n, thr=rep.get_throughput(), leaves=rep.tree.leaves(n), obs=obs,
                         actions=np.asarray(actions), t_rew=t_rew, t_val=t_val, t_pol=t_pol, idxs=np.asarray(idxs), isw=isw))
+    if sinks:
+      for sk in sinks:
+        sk.close()
     if rings:
       for rg in rings:
         rg.release()
