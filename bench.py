@@ -612,7 +612,8 @@ def main():
       if rank == 0:
         self.replay = make_replay(self.n_ingest)          # (its handle serialises the two callers on rank 0: the actor and the ring server)
         self.ring_stop = threading.Event()
-        threading.Thread(target=D.serve_rings, args=(self.rings, lambda name, *a: _call(self.replay, name, *a), B, self.ring_stop),
+        threading.Thread(target=D.serve_rings, args=(self.rings, lambda name, *a: _call(self.replay, name, *a), B, self.ring_stop,
+                                                     min(4, max(1, len(self.rings))), getattr(self.replay, '_obj', self.replay)),
                          daemon=True).start()
       else:
         self.my_ring = D.ShmRing('%s_%d' % (run_id, rank))

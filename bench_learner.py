@@ -1,6 +1,6 @@
 """Secondary bench line (never the headline): the learner step of SURVEY.md s8 row f2 (reference learners.py:164-230) -- FCNetwork,
 LunarLander shapes, batch 256, K = 5 unroll, AdamW -- as `Learner.learn` runs it: batches from the native replay sampled ahead
-(replay_buffer.sample_batch_arrays through learners._BatchSource), the update as the five HIP launches of mz_fcl_update
+(replay_buffer.sample_batch_arrays through learners._BatchSource), the update as the HIP launches of mz_fcl_update
 (csrc/mz_fcl.hip.h), priority refreshes one update behind.  Called by `bench.py --workload learner`.
 
 `value` = updates per second of that loop (host-bound today); `roofline` prices the update's GPU time (HIP events around 50
@@ -161,11 +161,11 @@ def main(args):
                      'native_loop': n['native_loop'], 'native_loop_host_us_per_update': n['native_loop_host_us_per_update'],
                      'runs': '%d x %d updates: mean +- std' % (len(n['runs']), updates)},
           'runs': {'mean': n['updates_per_second'], 'std': n['std'], 'values': n['runs']},
-          'roofline': {'bound': 'mfma', 'kernel': 'mz_fcl_run / mz_fcl_update (k_fcl_chain_fwd4, k_fcl_heads, k_fcl_chain_bwd4, k_fcl_dw, k_fcl_adam)',
+          'roofline': {'bound': 'mfma', 'kernel': 'mz_fcl_run / mz_fcl_update (k_fcl_fwd, k_fcl_bwd_dw, k_fcl_dwa at batch <= 256)',
                        'achieved': achieved, 'peak': F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / F32_MFMA_TFLOPS, 'traffic': None,
                        'flop_per_update': flop, 'us_per_update': us,
                        'us_per_update_single_calls': 1e3 * n['gpu_ms_per_update'],
-                       'note': 'latency- / launch-bound: dependent phases of a few microseconds (90 us of kernels per update); us_per_update = HIP events around '
+                       'note': 'latency-bound: dependent phases of a few microseconds (three launches per update at batch 256); us_per_update = HIP events around '
                                '300 updates of the native loop (mz_fcl_run), us_per_update_single_calls = the same step driven one mz_fcl_update call '
                                'at a time (pinned staging + two copies)'},
           'torch_graph': {k: out['torch_graph'][k] for k in ('updates_per_second', 'std', 'gpu_ms_per_update')},

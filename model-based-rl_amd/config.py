@@ -117,7 +117,7 @@ def build_parser():
     help='reference config.py:173: batches sampled ahead of the updates that consume them; here a background thread keeps '
          'min(this, 4) batches sampled ahead (1: sample in the learner\'s own thread, just before each update)')
   a('--no_native_learner', action='store_true',
-    help='FCNetwork learner step through PyTorch operators (GEMM library + autograd) instead of the six HIP launches of '
+    help='FCNetwork learner step through PyTorch operators (GEMM library + autograd) instead of the HIP launches (three at batch 256) of '
          'csrc/mz_fcl.hip.h (mz_fcl_step)')
   a('--no_native_loop', action='store_true',
     help='drive the native learner step from Python, one update per call (learners.py), instead of mz_fcl_run taking the loop body '

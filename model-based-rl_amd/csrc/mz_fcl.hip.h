@@ -1,22 +1,26 @@
 // mz_fcl.hip.h -- the FCNetwork learner step (reference learners.py:164-230, networks.py:135-180, config.py:27-33,51-68,
-// utils.py:53-60) as FIVE launches (six with gradient clipping): the whole update -- K-step unroll forward, the three heads'
-// losses, backward, clipping, AdamW -- without a GEMM library or an autograd tape.  The step is ~1.4 GFLOP (batch 256,
-// K = 5): as PyTorch operators it is ~220 kernels of ~4 us of launch floor each; here its shape follows the data
-// dependences instead:
+// utils.py:53-60): the whole update -- K-step unroll forward, the three heads' losses, backward, clipping, AdamW -- without a
+// GEMM library or an autograd tape.  The step is ~1.4 GFLOP (batch 256, K = 5): as PyTorch operators it is ~220 kernels of
+// ~4 us of launch floor each; here its shape follows the data dependences.  THREE launches at the reference's batch 256:
 //
-//   k_fcl_chain_fwd4  one workgroup per 4 samples: h_0 = representation(obs), h_p = dynamics(h_{p-1}, a_{p-1}) -- the only
-//                     sequential part -- on v_mfma_f32_4x4x1_16b_f32 (64 output rows x 4 samples per instruction), the
-//                     transition's weights resident in registers across positions, activations in LDS
-//   k_fcl_heads       one workgroup per (16 samples = the 16 columns of v_mfma_f32_16x16x4_f32, unroll position, head):
-//                     value / policy / reward head forward, two-hot targets, soft cross-entropy, and the head's backward
-//                     down to d loss / d hidden state
-//   k_fcl_chain_bwd4  one workgroup per 4 samples: the chain backwards (gradient hooks 0.5, LayerNorm, ReLU)
-//   k_fcl_dw          every weight gradient dW = sum_rows delta (x) input as 16 x 64 MFMA strips over the activation /
-//                     delta tapes the three kernels above left in HBM (four waves per strip and unroll position, summed
-//                     in a fixed order: deterministic, no atomics)
-//   k_fcl_grad        (only with clip_grad) adds the per-position strips up, squares for the global norm
-//   k_fcl_adam        (adds the strips up,) clip_grad_norm_, Adam / AdamW (torch's fused-kernel arithmetic), the new weights
-//                     into the flat vector AND into the packed copies the next step's MFMAs read; loss sums
+//   k_fcl_fwd      chain workgroups (4 samples each: h_0 = representation(obs), h_p = dynamics(h_{p-1}, a_{p-1}) -- the only
+//                  sequential part -- on v_mfma_f32_4x4x1_16b_f32: 64 output rows x 4 samples per instruction, the transition's
+//                  weights resident in registers across positions, activations in LDS) AND every heads unit (16 samples = the
+//                  16 columns of v_mfma_f32_16x16x4_f32, one unroll position, one head: value / policy / reward head forward,
+//                  two-hot targets, soft cross-entropy, the head's backward down to d loss / d hidden state).  A unit starts
+//                  when its sample group's chain workgroups have announced its position (write-through tapes + an arrival
+//                  counter): the heads of positions 0 .. K - 1 run on the CUs the chain leaves idle while it computes on
+//   k_fcl_bwd_dw   the chain backwards (gradient hooks 0.5, LayerNorm, ReLU; 4 samples per workgroup) AND the heads' weight-
+//                  gradient jobs on the CUs it leaves idle
+//   k_fcl_dwa      the chain layers' weight-gradient jobs + the LayerNorm parameters + the loss sums
+//
+// A weight-gradient job = one tile of a layer's dW = sum_rows delta (x) input over EVERY unroll position the layer is applied at
+// (MFMA strips over the activation / delta tapes in HBM, summed in a fixed order: deterministic, no atomics); with one row slab
+// the tile is the gradient, and Adam / AdamW on exactly those weights (torch's fused-kernel arithmetic; the new weights into the
+// flat vector AND into the packed copies the next step's MFMAs read) follows in the same workgroup.
+// Larger batches: k_fcl_chain_fwd4 / k_fcl_heads as launches of their own from batch 512 (the chain fills the chip), row slabs +
+// 64-row tiles (k_fcl_dwt) + the optimiser kernel (k_fcl_adam; with k_fcl_grad for clip_grad_norm_) from batch 1024, two / four
+// groups of four samples per chain workgroup from batch 2048 / 4096.
 //
 // Layouts.  Tapes in HBM: [position][row chunk of 16][feature][16 rows]: a slice kernel's workgroup owns one contiguous
 // block (a quarter of it: the chain kernels) per position, and k_fcl_dw reads 16 features x 16 rows as ONE contiguous KiB

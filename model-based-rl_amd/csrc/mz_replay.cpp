@@ -1178,16 +1178,18 @@ int64_t mzr_asm_take(mz_assembler *a, void *out, int64_t cap) {
 // the (deferred) insertion of its leaves in blob order; env_base: the producing rank's first environment (kept for the error text)
 int mzr_ingest_slices(mz_replay *r, const void *blob, int64_t bytes, int env_base) {
   if (!r || !blob || bytes < 8) return fail("mzr_ingest_slices: bad argument");
-  MZR_LOCK(r);
   if (r->c.episode_life) return fail("mzr_ingest_slices: this replay is configured with episode_life");
+  // The copies run on the CALLING thread and WITHOUT the handle's lock (they touch nothing of the replay but the spare-buffer
+  // list, which has a lock of its own): the host of the one replay drains several rings from several threads at once
+  // (distributed.serve_rings) and only the hand-over to the inserter is serialised.  (With the copies under the lock and on the
+  // handle's pool, two and four ingest threads accepted the same 118 M records/s: one caller at a time, a pool wake-up per blob.)
   const char *o = (const char *)blob;
   int64_t count = 0;
   memcpy(&count, o, 8);
   const size_t R = (size_t)r->R;
-  struct Ref { const char *rows; const double *pri; int64_t n; };
-  std::vector<Ref> refs((size_t)count);
   Job job;
   job.items.resize((size_t)count);
+  std::vector<const char *> rows((size_t)count);
   int64_t off = 8, total = 0;
   for (int64_t i = 0; i < count; ++i) {
     if (off + 48 > bytes) return fail("mzr_ingest_slices: truncated blob (rank with env_base %d)", env_base);
@@ -1196,7 +1198,7 @@ int mzr_ingest_slices(mz_replay *r, const void *blob, int64_t bytes, int env_bas
     const int64_t n = hdr[2];
     const int64_t rows_b = (int64_t)(((size_t)n * R * 4 + 7) & ~(size_t)7);
     if (n < 0 || off + 48 + rows_b + n * 8 > bytes) return fail("mzr_ingest_slices: truncated blob (rank with env_base %d)", env_base);
-    refs[(size_t)i] = Ref{o + off + 48, (const double *)(o + off + 48 + rows_b), n};
+    rows[(size_t)i] = o + off + 48;
     Hist *h = new Hist();
     h->n = n; h->payload = true;
     job.items[(size_t)i] = Pending{(int)hdr[0], (int)hdr[1], h, hdr[3], nullptr, hdr[4] != 0};
@@ -1206,30 +1208,33 @@ int mzr_ingest_slices(mz_replay *r, const void *blob, int64_t bytes, int env_bas
   job.pris.emplace_back((size_t)total);
   {
     int64_t po = 0;
-    for (int64_t i = 0; i < count; ++i) { job.items[(size_t)i].pri = job.pris[0].data() + po; po += refs[(size_t)i].n; }
-  }
-  auto copy = [&](int64_t lo, int64_t hi) {
-    for (int64_t i = lo; i < hi; ++i) {
-      const Ref &f = refs[(size_t)i];
+    std::vector<std::vector<float>> bufs;
+    {                                       // as many recycled row buffers as there are slices, in one visit of the list
+      std::lock_guard<std::mutex> lk(r->spare_mu);
+      const size_t take = r->hist_spare.size() < (size_t)count ? r->hist_spare.size() : (size_t)count;
+      bufs.reserve(take);
+      for (size_t k = 0; k < take; ++k) { bufs.push_back(std::move(r->hist_spare.back())); r->hist_spare.pop_back(); }
+    }
+    for (int64_t i = 0; i < count; ++i) {
+      Pending &p = job.items[(size_t)i];
+      const int64_t n = p.h->n;
+      const int64_t rows_b = (int64_t)(((size_t)n * R * 4 + 7) & ~(size_t)7);
       std::vector<float> buf;
-      {
-        std::lock_guard<std::mutex> lk(r->spare_mu);
-        if (!r->hist_spare.empty()) { buf.swap(r->hist_spare.back()); r->hist_spare.pop_back(); }
-      }
-      if (buf.capacity() < (size_t)f.n * R) {
-        buf.assign((const float *)f.rows, (const float *)f.rows + (size_t)f.n * R);      // (a fresh buffer: the copy is its first touch)
+      if ((size_t)i < bufs.size()) buf.swap(bufs[(size_t)i]);
+      if (buf.capacity() < (size_t)n * R) {
+        buf.assign((const float *)rows[(size_t)i], (const float *)rows[(size_t)i] + (size_t)n * R);      // (a fresh buffer: the copy is its first touch)
       } else {
-        buf.resize((size_t)f.n * R);
-        copy_streaming(buf.data(), (const float *)f.rows, (size_t)f.n * R);
+        buf.resize((size_t)n * R);
+        copy_streaming(buf.data(), (const float *)rows[(size_t)i], (size_t)n * R);
       }
-      job.items[(size_t)i].h->rows.swap(buf);
-      memcpy(const_cast<double *>(job.items[(size_t)i].pri), f.pri, (size_t)f.n * 8);
+      p.h->rows.swap(buf);
+      p.pri = job.pris[0].data() + po;
+      memcpy(job.pris[0].data() + po, rows[(size_t)i] + rows_b, (size_t)n * 8);
+      po += n;
     }
     _mm_sfence();                           // (this thread's streaming stores are globally visible before the slices are handed on)
-  };
-  const int T = r->pool.T;
-  if (T <= 1 || count < 2 * T) copy(0, count);
-  else r->pool.run([&](int tid) { copy(count * tid / T, count * (tid + 1) / T); });
+  }
+  MZR_LOCK(r);
   if (!r->inserter.joinable()) {
     insert_job(r, job);
     return 0;

@@ -195,8 +195,22 @@ class RingReplay(object):
     return {'frames': self.frames, 'games': 0}
 
 
-def serve_rings(rings, replay_call, B, stop):
-  """rank 0 thread: drain every rank's ring into the one replay (env_base = rank * B) until all producers closed."""
+def serve_rings(rings, replay_call, B, stop, threads=1, direct=None):
+  """rank 0: drain every rank's ring into the one replay (env_base = rank * B) until all producers closed.  threads > 1: the
+  rings are dealt out to that many drain threads -- a blob of slices is copied by the thread that polled it, outside the replay's
+  lock (mzr_ingest_slices), so the copies of several rings overlap and only the hand-over to the inserter is serial.  direct: the
+  replay OBJECT for the slice blobs (a rayshim handle would queue every call on its one thread; the native handle takes calls from
+  any thread)."""
+  if threads > 1 and len(rings) > 1:
+    keys = sorted(rings)
+    parts = [dict((k, rings[k]) for k in keys[i::threads]) for i in range(min(threads, len(keys)))]
+    ths = [threading.Thread(target=serve_rings, args=(p, replay_call, B, stop, 1, direct), daemon=True) for p in parts[1:]]
+    for t in ths:
+      t.start()
+    serve_rings(parts[0], replay_call, B, stop, 1, direct)
+    for t in ths:
+      t.join()
+    return
   live = dict(rings)
   while live and not stop.is_set():
     idle = True
@@ -205,7 +219,10 @@ def serve_rings(rings, replay_call, B, stop):
       if got is not None:
         data, n, packed = got
         if packed == 'slices':             # assembled by the producing rank: n bytes of finished slices
-          replay_call('ingest_slices', data, n, r * B)
+          if direct is not None:
+            direct.ingest_slices(data, n, r * B)
+          else:
+            replay_call('ingest_slices', data, n, r * B)
         else:
           replay_call('ingest_records', data, n, B, r * B, packed)
         ring.done()

@@ -170,8 +170,9 @@ class _SoftCE(torch.autograd.Function):
 
 
 class _NativeFC(object):
-  """The FCNetwork update as the six HIP launches of csrc/mz_fcl.hip.h (mz_fcl_step, include/mz_engine.h): forward chain,
-  heads + losses + their backward, backward chain, weight gradients, gradient norm, Adam / AdamW -- no GEMM library, no
+  """The FCNetwork update as the HIP launches of csrc/mz_fcl.hip.h (mz_fcl_step, include/mz_engine.h; three at batch 256): forward
+  chain + heads (losses, their backward), backward chain + the heads' weight gradients, the chain's weight gradients -- each strip
+  followed by Adam / AdamW on its weights in the same workgroup -- no GEMM library, no
   autograd tape, nothing PyTorch launches.  The network's parameters and the optimiser's exp_avg / exp_avg_sq / step
   tensors become VIEWS of three flat device vectors (engine.WEIGHT_ORDER) the kernels update in place, so state_dicts,
   checkpoints, get_weights and the PyTorch step itself keep working on the same storage.  The kernels read the weights
@@ -286,7 +287,7 @@ class _NativeFC(object):
 
   def run(self, replay, n, lrs=None):
     """n updates of Learner.learn's loop body in ONE native call (mz_fcl_run): batches sampled straight into pinned staging by
-    the native replay, the five launches per update, priority refreshes handed to the replay as their errors arrive.
+    the native replay, the step's launches per update, priority refreshes handed to the replay as their errors arrive.
     replay: the PrioritizedReplay OBJECT (its native handle is called from this thread; the handle's own lock serialises it
     with the actors' ingest).  The states of Python's `random` generator (the stratified draws) and of numpy's legacy one (the
     padded actions, replay_buffer.py:150-151) and the replay's beta travel in and out."""
@@ -791,7 +792,7 @@ class Learner(Logger):
   def _device_step(self, obs, act, t_rew, t_val, t_pol, w):
     cfg = self.config
     from .networks import FCNetwork
-    if self._native is not None:          # the whole update as six HIP launches (csrc/mz_fcl.hip.h)
+    if self._native is not None:          # the whole update as HIP launches (csrc/mz_fcl.hip.h)
       return self._native.step(obs, act, t_rew, t_val, t_pol, w)
     act = act.to(torch.int64)             # (sample_batch_arrays hands int32 actions over)
     if isinstance(self.network, FCNetwork) and not getattr(cfg, 'unbatched_learner', False):
@@ -860,7 +861,7 @@ class Learner(Logger):
         self.flush_priorities()
         self._native = _NativeFC(self, host)
       if self._native is not None:
-        # FCNetwork: five HIP launches from the host batch (mz_fcl_update), no PyTorch operator, no graph to capture
+        # FCNetwork: the step's HIP launches from the host batch (mz_fcl_update), no PyTorch operator, no graph to capture
         self._native.sync()
         slot = self._native.launch(host)
         getter = self._native.errors

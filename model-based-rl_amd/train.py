@@ -142,7 +142,9 @@ def launch_ranks(config, max_moves, selfplay_only=False, learner_steps=None, sta
   dist.barrier(group=ctrl) if ctrl is not None else dist.barrier()      # the rings exist
   if rank == 0:
     actor_replay = replay
-    server = threading.Thread(target=D.serve_rings, args=(rings, lambda name, *a: _call(replay, name, *a), B, stop), daemon=True)
+    # (the rings' slice blobs go to the replay OBJECT from up to four drain threads: the native handle takes calls from any thread)
+    server = threading.Thread(target=D.serve_rings, args=(rings, lambda name, *a: _call(replay, name, *a), B, stop,
+                                                          min(4, max(1, len(rings))), getattr(replay, '_obj', replay)), daemon=True)
     server.start()
     workers = []
     if selfplay_only:

@@ -90,7 +90,7 @@ def main():
   def locked_call(name, *args):
     with lock:                                       # (rayshim serialises calls on the replay handle; here: a lock)
       return call(name, *args)
-  server = threading.Thread(target=D.serve_rings, args=(rings, locked_call, B, stop), daemon=True)
+  server = threading.Thread(target=D.serve_rings, args=(rings, locked_call, B, stop, min(a.threads, 4), replay), daemon=True)
   f0 = replay.get_throughput()['frames']
   t0 = time.perf_counter()
   go.set()
