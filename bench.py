@@ -176,7 +176,7 @@ def n1_reference(workload, one_replay):
       continue
     if not isinstance(line, dict) or line.get('n_gpus') != 1 or line.get('unit') != 'env-steps/s' or line.get('secondary') or line.get('secondary_line'):
       continue
-    if not str(line.get('config', {}).get('workload', '')).startswith(workload):
+    if not str(line.get('config', {}).get('workload', '')).startswith(workload) or line.get('config', {}).get('envs_per_gpu') != B:
       continue
     same = line.get('build_id') == bid
     if best is None or same or not best[1]:
@@ -374,11 +374,13 @@ def leaf_depths(eng, obs_dim, n_trees):
   return float(ds.mean()), int(ds.max())
 
 
-def depth_sensitivity(device, weights, chunk, gains=(1, 2, 4, 8)):
+def depth_sensitivity(device, weights, chunk, gains=(1, 4, 24, 96)):
   """the headline at realistic tree depth.  For every policy gain: env-steps/s through Actor.launch, the search
   kernel's roofline fraction, mean / max leaf depth of a search, and the two phases of a simulation that grow with depth -- the
   descent (`t_select`) and the barrier wait for the deepest of a workgroup's 16 trees (`bar`) -- from the stamped build
-  (mz_search_phase_profile: cycles per simulation, wave 0, mean over workgroups)."""
+  (mz_search_phase_profile: cycles per simulation, wave 0, mean over workgroups).  Gains 24 and 96 put the mean leaf depth at ~4 and
+  ~6 (scripts/experiments/policy_gain_depth_probe.py: 1 -> 2.5, 8 -> 3.0, 24 -> 4.1, 48 -> 5.1, 128 -> 6.4), the Pong-ram / TicTacToe
+  shapes' depths with random-init weights are 3.7 / 5.3."""
   from model_based_rl_amd.engine import Engine
   rows = []
   base = None
@@ -480,7 +482,7 @@ def main():
   ap.add_argument('--policy-gain', '--policy_gain', type=float, default=1.0,
                   help='policy-head output layer x gain for the WHOLE run (sharper priors, deeper trees; secondary line when != 1)')
   ap.add_argument('--no-depth-sensitivity', action='store_true',
-                  help='skip the depth_sensitivity block (N = 1, default workload: four short runs at policy gains 1, 2, 4, 8; ~10 s)')
+                  help='skip the depth_sensitivity block (N = 1, default workload: four short runs at policy gains 1, 4, 24, 96; ~10 s)')
   ap.add_argument('--batch', default=None,
                   help='--workload learner: batch sizes of the sweep, comma separated (default 256,512,1024,2048,4096; the line\'s `value` '
                        'stays the first one -- 256 = the reference\'s batch_size): updates/s, samples/s, roofline.frac and host us per update each')

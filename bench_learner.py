@@ -55,9 +55,10 @@ def sweep_point(bs, updates, runs=3):
   Sv, Sr = cfg.value_support_max - cfg.value_support_min + 1, cfg.reward_support_max - cfg.reward_support_min + 1
   flop = step_flop(bs, K, O, A, Sv, Sr)
   v = np.array(vals)
-  point = {'batch': bs, 'updates_per_s': float(v.mean()), 'std': float(v.std()), 'samples_per_s': float(v.mean()) * bs, 'timed_updates': updates,
-           'us_per_update_gpu': us, 'frac': flop / (us * 1e-6) / 1e12 / F32_MFMA_TFLOPS,
-           'frac_of_wall': flop * float(v.mean()) / 1e12 / F32_MFMA_TFLOPS, 'flop_per_update': flop,
+  mid = float(np.median(v))                           # (median of the timed calls: one slow call on a shared box does not move the point)
+  point = {'batch': bs, 'updates_per_s': mid, 'std': float(v.std()), 'calls': [float(x) for x in v], 'samples_per_s': mid * bs,
+           'timed_updates': updates, 'us_per_update_gpu': us, 'frac': flop / (us * 1e-6) / 1e12 / F32_MFMA_TFLOPS,
+           'frac_of_wall': flop * mid / 1e12 / F32_MFMA_TFLOPS, 'flop_per_update': flop,
            'host_us_per_update': {k: host[k] for k in ('sample_us', 'refresh_us', 'launch_us', 'wait_us', 'call_us')},
            'replay_sampling_threads': int(getattr(rep, 'ingest_threads', 0) or 0)}
   if lrn._native is not None:
@@ -175,7 +176,7 @@ def main(args):
   if not os.environ.get('MZ_LEARNER_NO_SWEEP'):
     batches = [int(x) for x in (getattr(args, 'batch', None) or '256,512,1024,2048,4096').split(',')]
     with contextlib.redirect_stdout(sys.stderr):
-      line['batch_sweep'] = [sweep_point(b, max(200, min(updates, updates * 512 // b)), runs=min(3, max(1, args.runs))) for b in batches]
+      line['batch_sweep'] = [sweep_point(b, max(200, min(updates, updates * 512 // b)), runs=3) for b in batches]
     line['batch_sweep_what'] = ('Learner.launch(n) per point on the handles train.launch builds; frac = algorithmic FLOP / (HIP-event time per update '
                                 'of mz_fcl_run) / %.1f TFLOP/s; frac_of_wall = the same with the wall-clock rate' % F32_MFMA_TFLOPS)
   print(json.dumps(line), flush=True)

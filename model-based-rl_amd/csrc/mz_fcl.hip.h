@@ -339,7 +339,11 @@ __device__ __forceinline__ void fcl_heads_body(const FclView &v, const int cb, c
   asm volatile("" ::: "memory");
   if constexpr (WAIT) {
     // hidden states of position p (value, policy) / the transition input of position p = what position p - 1 left (reward)
+    // (development: the launch's timeline on the constant 100 MHz clock, slots 59..63: chain workgroup 0 start / end, the LAST
+    // position's value unit of group 0 at its start / past its wait / at its end)
+    if (v.prof && cb == 0 && p == v.K && hd == 0 && tid == 0) v.prof[61] = __builtin_amdgcn_s_memrealtime();
     if (tid == 0) fcl_wait_flag(v.flags + (size_t)cb * K1 + (hd == 2 ? p - 1 : p), 4u, v.err);
+    if (v.prof && cb == 0 && p == v.K && hd == 0 && tid == 0) v.prof[62] = __builtin_amdgcn_s_memrealtime();
     fcl_bar();
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -436,6 +440,9 @@ __device__ __forceinline__ void fcl_heads_body(const FclView &v, const int cb, c
   }
   FCL_STAMP()        // 11: d hidden stored
 #undef FCL_STAMP
+  if constexpr (WAIT) {
+    if (v.prof && cb == 0 && p == v.K && hd == 0 && tid == 0) v.prof[63] = __builtin_amdgcn_s_memrealtime();
+  }
 }
 
 __global__ __launch_bounds__(FCL_THREADS, 4) void k_fcl_heads(FclView v) {
@@ -536,6 +543,7 @@ __device__ __forceinline__ void fcl_chain_fwd4_body(const FclView &v, const int 
   const size_t T64 = (size_t)64 * R, T512 = (size_t)512 * R, TX = (size_t)v.XR * R;
 #define FCL_KSTAMP(k) if (v.prof && blk == 0 && tid == 0) v.prof[54 + (k)] = __builtin_amdgcn_s_memtime();
   FCL_KSTAMP(0)      // kernel start
+  if constexpr (SIG) { if (v.prof && blk == 0 && tid == 0) v.prof[59] = __builtin_amdgcn_s_memrealtime(); }
   // Loads return in order: what position 0 needs -- the small parameter vectors, the observations, the representation's
   // fc2 weights -- is requested FIRST; the transition's resident weights (245 KB per workgroup) go out behind position 0's
   // fc1 products and arrive under the rest of position 0 (r05 requested them first: every workgroup's first barrier waited
@@ -673,6 +681,9 @@ __device__ __forceinline__ void fcl_chain_fwd4_body(const FclView &v, const int 
       acc[g] = v.O <= 16 ? fcl_quad_res<16>(WR1, X + (4 * g + (lane & 3)) * LDX)
                          : fcl_quad_stream(v.pk + v.rep.F1 + (size_t)w * v.O * 64, v.O, X + (4 * g + (lane & 3)) * LDX, lane);
     asm volatile("" ::: "memory");
+    // (the wait counter holds 63 loads: with the transition's 120 requests queued BEHIND WR2's, the first use of WR2 would wait
+    // until all but 63 of them had returned too -- WR2, requested at the kernel's start, is settled BEFORE they go out)
+    fcl_quad_settle(WR2);
     fcl_quad_load<KP>(WT1, v.pk + v.tr.F1 + (size_t)w * KP * 64, lane);
     fcl_quad_load<64>(WT2, v.pk + v.tr.F2 + (size_t)w * 64 * 64, lane);
     asm volatile("" ::: "memory");
@@ -696,6 +707,7 @@ __device__ __forceinline__ void fcl_chain_fwd4_body(const FclView &v, const int 
     if (tid >= 256) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     fcl_bar();
     if (tid == 0) fcl_signal(v.flags + (size_t)cb * (v.K + 1) + v.K);
+    if (v.prof && blk == 0 && tid == 0) v.prof[60] = __builtin_amdgcn_s_memrealtime();
   }
 }
 
@@ -771,8 +783,6 @@ __device__ __forceinline__ void fcl_chain_bwd4_body(const FclView &v, const int 
   fcl_quad_load<MZ_H>(WB2, v.pk + v.tr.B2 + (size_t)w * MZ_H * 64, lane);
   asm volatile("" ::: "memory");
   if (tid < 64) lnw[tid] = plnw;
-  fcl_quad_load<64>(WB1, v.pk + v.tr.B1 + (size_t)w * 64 * 64, lane);
-  if constexpr (G == 1) fcl_quad_load<MZ_H>(WR2, v.pk + v.rep.B2 + (size_t)w * MZ_H * 64, lane);      // (G > 1: no registers to hold them through the loop)
   fcl_bar();
   auto body = [&](int p, const float (&W2)[MZ_H]) __attribute__((always_inline)) {
     if (w < G) {
@@ -841,8 +851,12 @@ __device__ __forceinline__ void fcl_chain_bwd4_body(const FclView &v, const int 
       // (red is next written after two more barriers)
     }
   };
-  // (the last position peeled off the loop: it waits for WB2 alone, WB1's 64 loads arrive under its first phases)
+  // (the last position peeled off the loop: it waits for WB2 alone -- the wait counter holds 63 loads, so WB1's 64 (and the
+  // representation's 50) are requested only once WB2 has been settled -- and they arrive under its first phases)
   fcl_quad_settle(WB2);
+  fcl_quad_load<64>(WB1, v.pk + v.tr.B1 + (size_t)w * 64 * 64, lane);
+  if constexpr (G == 1) fcl_quad_load<MZ_H>(WR2, v.pk + v.rep.B2 + (size_t)w * MZ_H * 64, lane);      // (G > 1: no registers to hold them through the loop)
+  asm volatile("" ::: "memory");
   body(v.K, WB2);
   fcl_quad_settle(WB1);
   for (int p = v.K - 1; p >= 1; --p) body(p, WB2);

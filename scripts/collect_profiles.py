@@ -21,6 +21,8 @@ names = {
     'bench_steps20_%s.json': '%s_bench_steps20.json', 'weight_sync_ab_%s.txt': '%s_weight_sync_ab.txt',
     'parity_full_grid_%s.txt': '%s_parity_full_grid.txt',
     'bench_8ranks_fullsize_1gpu_%s.json': '%s_bench_8ranks_fullsize_1gpu.json', 'host_threads_%s.txt': '%s_host_threads.txt',
+    'one_replay_shapes_%s.txt': '%s_one_replay_shapes.txt', 'learner_step_sweep_%s.json': '%s_learner_step_sweep.json',
+    'learner_step_kernels_256_%s.csv': '%s_learner_step_kernels_256.csv', 'learner_step_kernels_2048_%s.csv': '%s_learner_step_kernels_2048.csv',
 }
 # the product's own entry point (train --selfplay_only): its summary line as JSON
 ts = os.path.join(G, 'train_selfplay_%s.txt' % tag)

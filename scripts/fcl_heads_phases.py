@@ -24,6 +24,10 @@ for _ in range(N):
   acc += np.diff(st[:, :12], axis=1) / 100.0
   cacc += np.diff(buf[48:54].astype(np.float64)) / 100.0
   kacc += np.diff(buf[54:59].astype(np.float64)) / 100.0
+tl = buf[59:64].astype(np.float64)
+if tl[0] > 0:      # the fused forward launch's timeline (constant 100 MHz clock): microseconds from chain workgroup 0's start
+  print('fused forward launch (last sample of %d): chain workgroup 0 ends at %.2f us; the last position\'s value unit of group 0 starts at %.2f, '
+        'is past its wait at %.2f, ends at %.2f us' % (N, (tl[1] - tl[0]) / 100.0, (tl[2] - tl[0]) / 100.0, (tl[3] - tl[0]) / 100.0, (tl[4] - tl[0]) / 100.0))
 acc /= N
 for i, nme in enumerate(names):
   print('%-28s value %6.2f  policy %6.2f  reward %6.2f' % (nme, acc[0, i], acc[1, i], acc[2, i]))

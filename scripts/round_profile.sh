@@ -67,4 +67,9 @@ MZ_BENCH_FORCE_DIST=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-no
 python3 scripts/ingest_bench.py --json $O/ingest_bench_$TAG.json > $O/ingest_bench_$TAG.txt 2>&1
 python3 scripts/one_replay_bench.py --ranks 8 --chunks 200 --threads 4 --json $O/one_replay_8ranks_4threads_$TAG.json > /dev/null 2>&1
 python3 scripts/one_replay_bench.py --ranks 8 --chunks 200 --threads 8 --json $O/one_replay_8ranks_8threads_$TAG.json > /dev/null 2>&1
+# ... both record shapes, the r05 hand-off (record chunks, all work on rank 0) beside the r06 one (slices assembled by the producers)
+bash scripts/one_replay_ab.sh one_replay_$TAG > $O/one_replay_shapes_$TAG.txt 2>&1
+# the learner step, kernels only: batch sweep on HIP events + per-kernel durations at batch 256 and 2048 (rocprofv3 kernel trace)
+bash scripts/fcl_sweep.sh fcl_$TAG > /dev/null 2>&1
+cp $O/fcl_$TAG/sweep.json $O/learner_step_sweep_$TAG.json; cp $O/fcl_$TAG/kernels_256.csv $O/learner_step_kernels_256_$TAG.csv; cp $O/fcl_$TAG/kernels_2048.csv $O/learner_step_kernels_2048_$TAG.csv
 f=$(find $O/prof_$TAG -name "*kernel_stats.csv" | head -1); head -8 "$f"

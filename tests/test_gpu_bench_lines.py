@@ -70,7 +70,7 @@ def test_learner_line():
   for p_ in sw:
     assert p_['updates_per_s'] > 0 and abs(p_['samples_per_s'] - p_['updates_per_s'] * p_['batch']) < 1e-6 * p_['samples_per_s']
     assert 0 < p_['frac'] < 1 and p_['us_per_update_gpu'] > 10 and set(p_['host_us_per_update']) >= {'sample_us', 'refresh_us', 'launch_us'}
-  assert sw[1]['frac'] > sw[0]['frac']                      # (a larger batch fills more of the chip)
+  # (no ordering of the two fractions: through the product's loop batch 1024 is bound by the ONE host thread that samples and refreshes)
   assert sw[1]['flop_per_update'] == 4 * sw[0]['flop_per_update']
 
 
@@ -87,8 +87,8 @@ def test_depth_sensitivity_block_and_policy_gain():
   assert float(s4['policy_head.policy.weight'][0, 0]) == 4.0 and float(s4['policy_head.policy.bias'][0]) == 4.0 and float(s4['x'][0]) == 1.0
   line = line_of(['--steps', '32', '--warmup', '16', '--runs', '1', '--no-cpu-baseline', '--no-live-traffic', '--min-seconds', '0.2'])
   rows = line['depth_sensitivity']['rows']
-  assert [r_['policy_gain'] for r_ in rows] == [1, 2, 4, 8]
-  assert rows[-1]['mean_leaf_depth'] > rows[0]['mean_leaf_depth'] + 0.5 and rows[-1]['max_leaf_depth'] >= rows[0]['max_leaf_depth']
+  assert [r_['policy_gain'] for r_ in rows] == [1, 4, 24, 96]
+  assert rows[2]['mean_leaf_depth'] > 3.5 and rows[3]['mean_leaf_depth'] > 5.5 and rows[0]['mean_leaf_depth'] < 3.0      # depth ~4 and ~6 beside the headline's 2.5
   for r_ in rows:
     assert r_['env_steps_per_s'] > 1e6 and 0.2 < r_['frac'] < 1 and r_['cycles_per_sim_wave0']['t_select'] > 0
   assert rows[-1]['cycles_per_sim_wave0']['t_select'] > rows[0]['cycles_per_sim_wave0']['t_select']
