@@ -366,8 +366,8 @@ __device__ __forceinline__ void fcl_heads_body(const FclView &v, const int cb, c
   fcl_load_narrow(WA, (const f32x4 *)(v.pk + pk.F2), w, lane);          // fc2's, under the epilogue
   FCL_STAMP()      // 2: fc1 products
   fcl_fc1_out(acc, PV, A1, v.a1h + hp * T512 + fcl_tp(512, cb, 0, 0), loff, w, lane);
-  fcl_bar();
-  FCL_STAMP()      // 3: fc1 epilogue + barrier
+  // (no barrier: the 16 k-steps of fc2's split-K slice of wave w are the 64 features of A1 wave w has just written itself)
+  FCL_STAMP()      // 3: fc1 epilogue
   if (pk.nt == 1) fcl_narrow_res<1>(WA, A1, red, w, lane);
   else if (pk.nt == 2) fcl_narrow_res<2>(WA, A1, red, w, lane);
   else fcl_narrow_res<4>(WA, A1, red, w, lane);
@@ -426,8 +426,8 @@ __device__ __forceinline__ void fcl_heads_body(const FclView &v, const int cb, c
     for (int i = 0; i < 4; ++i) msk[i] = *(const f32x4 *)(A1 + (((64 * w + 16 * i + 4 * g4) >> 2) * 16 + m16) * 4);
     fcl_mask_out(acc, msk, A1, v.d1h + hp * T512 + fcl_tp(512, cb, 0, 0), loff, w, lane);
   }
-  fcl_bar();
-  FCL_STAMP()      // 8: mask + barrier
+  // (no barrier: wave w's slice of the fc1-transposed product again)
+  FCL_STAMP()      // 8: mask
   fcl_narrow_res<4>(WA, A1, red, w, lane);
   fcl_bar();
   FCL_STAMP()      // 9: fc1-transposed partials + barrier
@@ -519,6 +519,12 @@ __device__ __forceinline__ f32x4 fcl_quad_stream(const float *__restrict__ pk, i
 #define FCL_LDS4_FLOATS(xq, G) (4 * (G) * ((xq) + 4) + 4 * (G) * 516 + (G) * 2048 + 16 + 1408 + 256 * (G))
 #define FCL_LDA 516
 
+// Split-K partials of a 64-row x 4-sample product in LDS: a wave's 64 lanes (b, j) = (lane >> 2, lane & 3) each leave one f32x4 (rows
+// 4 b + i of sample j); the reducing wave reads them as lane (j, b) = (lane >> 4, lane & 15).  Slot of (j, b) among the wave's 64
+// 16-byte slots: 16 j + ((b + 4 j) & 15) -- any 16 consecutive lanes of EITHER side touch 16 different slots modulo 16 (256 bytes = all
+// banks once); the plain slot 4 b + j served the reader's 16 lanes out of 4 of them
+__device__ __forceinline__ int fcl_red_slot(int j, int b) { return 16 * j + ((b + 4 * j) & 15); }
+
 // D fragment (rows 64 w + 4 b + i, sample j) -> tape [chunk][feature][16]: wave-uniform base + one lane offset + i * 16
 __device__ __forceinline__ int fcl_lane_off4(int lane, int n0) { return (lane >> 2) * 64 + n0 + (lane & 3); }
 
@@ -589,12 +595,6 @@ __device__ __forceinline__ void fcl_chain_fwd4_body(const FclView &v, const int 
 #define FCL_CSTAMP(k) if (v.prof && blk == 0 && p == 2 && tid == 0) v.prof[48 + (k)] = __builtin_amdgcn_s_memtime();
   auto rest = [&](int p, const f32x4 (&acc)[G], const float (&W2)[64], const float *b1, const float *b2) __attribute__((always_inline)) {
     FCL_CSTAMP(1)      // fc1 products done
-    if constexpr (SIG) {
-      // the tapes of position p - 1 (stored write-through behind its last barrier, by the upper waves, a phase of MFMAs ago):
-      // every storing wave waits for its stores HERE, before it issues this position's; one lane announces them behind the
-      // barrier that follows the epilogue
-      if (p > 0 && tid >= 256) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
 #pragma unroll
     for (int g = 0; g < G; ++g) {   // fc1 epilogue: bias, ReLU, to LDS (one 16-byte write: the lane's four features of its sample) and to the tape
       const int f0 = 64 * w + 4 * (lane >> 2), loff = fcl_lane_off4(lane, n0 + 4 * g);
@@ -608,28 +608,43 @@ __device__ __forceinline__ void fcl_chain_fwd4_body(const FclView &v, const int 
       }
       *(f32x4 *)(A1 + (4 * g + (lane & 3)) * FCL_LDA + f0) = a;
     }
+    // NO barrier here: fc2's split-K slice of wave w is features [64 w, 64 w + 64) of A1 -- exactly what wave w itself has just written
+    // (a wave's LDS instructions execute in order); the waves drift apart and one's epilogue runs under its SIMD neighbour's MFMAs
+    FCL_CSTAMP(2)      // epilogue
+    // what the LayerNorm wave needs besides the partials, requested in front of the barrier it waits at
+    f32x4 lb2 = (f32x4){0.f, 0.f, 0.f, 0.f}, llw = lb2, llb = lb2;
+    int act_p = -1;
+    if (w < G) {
+      const int f0 = 4 * (lane & 15);
+      lb2 = *(const f32x4 *)(b2 + f0); llw = *(const f32x4 *)(lnw + f0); llb = *(const f32x4 *)(lnb + f0);
+      act_p = acts[(4 * w + (lane >> 4)) * 8 + (p < 7 ? p : 7)];
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+      *(f32x4 *)(red + g * 2048 + w * 256 + fcl_red_slot(lane & 3, lane >> 2) * 4) = fcl_quad_res<64>(W2, A1 + (4 * g + (lane & 3)) * FCL_LDA + 64 * w);
+    if constexpr (SIG) {
+      // the tapes of position p - 1 (stored write-through behind its last barrier, by the upper waves, two phases of MFMAs ago):
+      // every storing wave waits for its stores HERE; one lane announces them behind the barrier that follows
+      if (p > 0 && tid >= 256) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     fcl_bar();
     if constexpr (SIG) {
       if (p > 0 && tid == 0) fcl_signal(v.flags + (size_t)cb * (v.K + 1) + (p - 1));
     }
-    FCL_CSTAMP(2)      // epilogue + barrier
-#pragma unroll
-    for (int g = 0; g < G; ++g)
-      *(f32x4 *)(red + g * 2048 + (w * 64 + lane) * 4) = fcl_quad_res<64>(W2, A1 + (4 * g + (lane & 3)) * FCL_LDA + 64 * w);
-    fcl_bar();
     FCL_CSTAMP(3)      // fc2 partials + barrier
     if (w < G) {
       // wave g alone for group g: lane (j, b) = (lane >> 4, lane & 15) adds up rows 4 b + i of sample j of the 8 partials (written by
-      // lane 4 b + j of each wave), then LayerNorm + ReLU (networks.py:147,165) of sample j across ITS DPP ROW -- the two
-      // reductions are four DPP exchanges each, no LDS round trip (r05: lane (b, j), two ds_bpermute per reduction: this
-      // serial part was 2.0 k of a position's 5.3 k cycles) -- the tapes and the next input straight from registers
+      // lane 4 b + j of each wave into slot fcl_red_slot(j, b): both sides touch 16 different 16-byte slots per 16 lanes), then
+      // LayerNorm + ReLU (networks.py:147,165) of sample j across ITS DPP ROW -- the two reductions are four DPP exchanges each, no
+      // LDS round trip (r05: lane (b, j), two ds_bpermute per reduction: this serial part was 2.0 k of a position's 5.3 k cycles)
+      // -- the tapes and the next input straight from registers
       const int j = lane >> 4, f0 = 4 * (lane & 15), sj = 4 * w + j;
       f32x4 y = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ww = 0; ww < FCL_NW; ++ww) y += *(const f32x4 *)(red + w * 2048 + (ww * 64 + f0 + j) * 4);
+      for (int ww = 0; ww < FCL_NW; ++ww) y += *(const f32x4 *)(red + w * 2048 + ww * 256 + fcl_red_slot(j, lane & 15) * 4);
       float yv[4], s = 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { yv[i] = (f0 + i < MZ_H) ? y[i] + b2[f0 + i] : 0.f; s += yv[i]; }
+      for (int i = 0; i < 4; ++i) { yv[i] = (f0 + i < MZ_H) ? y[i] + lb2[i] : 0.f; s += yv[i]; }
       s = fcl_sum16(s);
       const float mean = s / (float)MZ_H;
       float d[4], var = 0.f;
@@ -637,13 +652,12 @@ __device__ __forceinline__ void fcl_chain_fwd4_body(const FclView &v, const int 
       for (int i = 0; i < 4; ++i) { d[i] = (f0 + i < MZ_H) ? yv[i] - mean : 0.f; var += d[i] * d[i]; }
       var = fcl_sum16(var);
       const float rstd = 1.0f / sqrtf(var / (float)MZ_H + FCL_LN_EPS);
-      const int act_p = acts[sj * 8 + (p < 7 ? p : 7)];
       f32x4 xv4, xh4;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int f = f0 + i;
         xh4[i] = d[i] * rstd;
-        const float hv = f < MZ_H ? fmaxf(xh4[i] * lnw[f] + lnb[f], 0.f) : 0.f;
+        const float hv = f < MZ_H ? fmaxf(xh4[i] * llw[i] + llb[i], 0.f) : 0.f;
         // the next input: [h | one-hot(action) | 0]  (networks.py:167-174); past the last transition: no action
         xv4[i] = f < MZ_H ? hv : ((p < v.K && f - MZ_H == act_p) ? 1.f : 0.f);
       }
@@ -655,7 +669,7 @@ __device__ __forceinline__ void fcl_chain_fwd4_body(const FclView &v, const int 
     fcl_bar();
     FCL_CSTAMP(5)      // barrier
     // the tapes of this position, by the upper half of the workgroup (the LayerNorm waves above are the serial part: the others
-    // wait for them); X, S and misc are next written three barriers from here
+    // wait for them); X, S and misc are next written two barriers from here
     if (tid >= 256) {
 #pragma unroll
       for (int g = 0; g < G; ++g) {
@@ -817,7 +831,7 @@ __device__ __forceinline__ void fcl_chain_bwd4_body(const FclView &v, const int 
 #pragma unroll
       for (int i = 0; i < 4; ++i) msk[g][i] = (a1t + i * 16)[fcl_lane_off4(lane, n0 + 4 * g)];
     fcl_bar();
-    if (tid >= 256) {      // the delta tape of this position, by the upper half of the workgroup (D2 is next written three barriers on)
+    if (tid >= 256) {      // the delta tape of this position, by the upper half of the workgroup (D2 is next written behind the next barrier)
       const int t = tid - 256;
 #pragma unroll
       for (int g = 0; g < G; ++g)
@@ -836,19 +850,19 @@ __device__ __forceinline__ void fcl_chain_bwd4_body(const FclView &v, const int 
       }
       *(f32x4 *)(A1 + (4 * g + (lane & 3)) * FCL_LDA + g0) = d;
     }
-    fcl_bar();
+    // (no barrier: wave w's split-K slice of the fc1-transposed product is features [64 w, 64 w + 64) of A1, its own writes)
     if (p >= 1) {
 #pragma unroll
       for (int g = 0; g < G; ++g)
-        *(f32x4 *)(red + g * 2048 + (w * 64 + lane) * 4) = fcl_quad_res<64>(WB1, A1 + (4 * g + (lane & 3)) * FCL_LDA + 64 * w);
+        *(f32x4 *)(red + g * 2048 + w * 256 + fcl_red_slot(lane & 3, lane >> 2) * 4) = fcl_quad_res<64>(WB1, A1 + (4 * g + (lane & 3)) * FCL_LDA + 64 * w);
       fcl_bar();
       if (w < G) {
         f32x4 y = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ww = 0; ww < FCL_NW; ++ww) y += *(const f32x4 *)(red + w * 2048 + (ww * 64 + f0 + j) * 4);      // (written by lane 4 b + j)
+        for (int ww = 0; ww < FCL_NW; ++ww) y += *(const f32x4 *)(red + w * 2048 + ww * 256 + fcl_red_slot(j, lane & 15) * 4);      // (written by lane 4 b + j)
         dch = y;            // (rows >= 50 come out of zero weights)
       }
-      // (red is next written after two more barriers)
+      // (red is next written after one more barrier; D2 after this one)
     }
   };
   // (the last position peeled off the loop: it waits for WB2 alone -- the wait counter holds 63 loads, so WB1's 64 (and the

@@ -15,6 +15,13 @@ FILES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), 'golden', 'g3_g
 
 # a sanitizer build of the library is under test (tests/test_sanitizers.py: 10-20 x slower): the heavy cases shrink, the code paths stay
 SAN = bool(os.environ.get('MZ_REPLAY_LIB'))
+if SAN:
+  # shared_memory's resource tracker is a child process forked on first use; a fork() out of this (already multi-threaded: BLAS pool,
+  # the replay's threads) process deadlocks inside ThreadSanitizer's fork interceptor.  The ring tests unlink their segments themselves:
+  # the tracker is not needed here
+  from multiprocessing import resource_tracker
+  resource_tracker.register = lambda *a, **k: None
+  resource_tracker.unregister = lambda *a, **k: None
 
 
 def make_cfg(**kw):
