@@ -57,7 +57,9 @@ struct FclView {
   float *new_errors;
   unsigned *flags;               // fused forward launch (k_fcl_fwd): [bs / 16][K + 1] arrival counters -- chain workgroups whose tapes of (sample group, position) are
                                  // written through; 4 = all of the group's; zeroed by k_fcl_bwd_dw for the next step
-  int nflags;
+  int nflags;                    // (k_fcl_fb: [2][bs / 16][K + 1] -- behind the arrival counters, the heads' counters of finished units per (sample group, position
+                                 // whose hidden state the units' d loss / d hidden belongs to): 3 = value, policy and the next position's reward unit; 2 at position K)
+  int order[8];                  // k_fcl_fb: the positions in the order their heads units are dispatched
   unsigned *err;                 // [host, device-mapped] set to 1 where a unit's wait for its counter ran into its bound (never on a healthy box)
   float *steps; int nsteps;      // the optimiser's per-parameter step counters (torch keeps one per parameter), advanced by k_fcl_heads; nsteps = 0: not this step
   unsigned long long *prof;      // development: s_memtime stamps of k_fcl_heads' phases (workgroup 0 of every head at position 1), else null
@@ -186,11 +188,39 @@ __device__ __forceinline__ float fcl_two_hot_at(const FclTwoHot &t, int s) {
   return v;
 }
 
+// ------------------------------------------------------------------------------------------------ in-launch hand-off (k_fcl_fwd)
+// The forward chain hands a position's hidden states to the heads' units of the SAME launch (MI355X_MICROARCH.md, inter-workgroup
+// visibility, first row of the table of forms measured without an acquire): the producer's stores of the handed-off bytes are
+// write-through (sc1: relaxed agent-scope atomic stores), every storing wave waits for them (s_waitcnt vmcnt(0)), a workgroup
+// barrier, then ONE lane adds to the counter (agent scope); the consumer polls the counter with sc1 loads in one lane (bounded),
+// a workgroup barrier, then EVERY load of the handed-off bytes is an sc1 load.
+__device__ __forceinline__ void fcl_store_wt(float *p, float x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float fcl_load_wt(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void fcl_signal(unsigned *flag) { __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// one lane: until *flag >= want, or ~40 ms of the constant 100 MHz clock have passed (then *err = 1 and the caller goes on: the
+// step's numbers are wrong, the launch ends, the host sees the word)
+// (SLEEP: s_sleep units of 64 cycles between two polls -- 8 for a unit or a chain workgroup (few pollers per counter, the wait is on the
+// step's critical path), 64 for a weight-gradient job (168 of them wait ~10 us for three counters: polled every 0.25 us they slowed the
+// units' own counter traffic -- the backward chain's positions arrived 1.5 - 3.6 us later))
+template <int SLEEP = 8>
+__device__ __forceinline__ void fcl_wait_flag(const unsigned *flag, unsigned want, unsigned *err) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+    __builtin_amdgcn_s_sleep(SLEEP);
+    if (__builtin_amdgcn_s_memrealtime() - t0 > 4000000ull) {
+      if (err) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      break;
+    }
+  }
+}
+
 // Tape addressing of a D fragment (rows 64 w + 16 i + 4 g4 + r, column = sample m16): a wave-uniform row base (scalar
 // registers) + ONE per-lane offset, so that no per-(i, r) 64-bit address lives in vector registers across the positions
 __device__ __forceinline__ int fcl_lane_off(int lane) { return 64 * (lane >> 4) + (lane & 15); }
 
 // fc1 epilogue: bias (LDS), ReLU, the activations to LDS (k-step layout) and to the tape
+// (WT: tape stores written through -- a unit whose tapes are read by weight-gradient jobs of the same launch)
+template <bool WT = false>
 __device__ __forceinline__ void fcl_fc1_out(const f32x4 acc[4], const float *b1, float *A1, float *a1t, int loff, int w, int lane) {
   const int g4 = lane >> 4, m16 = lane & 15;
 #pragma unroll
@@ -201,13 +231,15 @@ __device__ __forceinline__ void fcl_fc1_out(const f32x4 acc[4], const float *b1,
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       a[r] = fmaxf(acc[i][r] + b[r], 0.f);
-      (a1t + (64 * w + 16 * i + r) * 16)[loff] = a[r];
+      if constexpr (WT) fcl_store_wt((a1t + (64 * w + 16 * i + r) * 16) + loff, a[r]);
+      else (a1t + (64 * w + 16 * i + r) * 16)[loff] = a[r];
     }
     *(f32x4 *)(A1 + ((f0 >> 2) * 16 + m16) * 4) = a;
   }
 }
 
 // d a1 through the ReLU (mask: the activation a > 0), to LDS and to the delta tape
+template <bool WT = false>
 __device__ __forceinline__ void fcl_mask_out(const f32x4 acc[4], const f32x4 msk[4], float *A1, float *d1t, int loff, int w, int lane) {
   const int g4 = lane >> 4, m16 = lane & 15;
 #pragma unroll
@@ -217,7 +249,8 @@ __device__ __forceinline__ void fcl_mask_out(const f32x4 acc[4], const f32x4 msk
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       d[r] = msk[i][r] > 0.f ? acc[i][r] : 0.f;
-      (d1t + (64 * w + 16 * i + r) * 16)[loff] = d[r];
+      if constexpr (WT) fcl_store_wt((d1t + (64 * w + 16 * i + r) * 16) + loff, d[r]);
+      else (d1t + (64 * w + 16 * i + r) * 16)[loff] = d[r];
     }
     *(f32x4 *)(A1 + ((f0 >> 2) * 16 + m16) * 4) = d;
   }
@@ -264,40 +297,21 @@ __device__ __forceinline__ float fcl_max32(float x) {
   return fmaxf(x, __shfl_xor(x, 16, 32));
 }
 
-// ------------------------------------------------------------------------------------------------ in-launch hand-off (k_fcl_fwd)
-// The forward chain hands a position's hidden states to the heads' units of the SAME launch (MI355X_MICROARCH.md, inter-workgroup
-// visibility, first row of the table of forms measured without an acquire): the producer's stores of the handed-off bytes are
-// write-through (sc1: relaxed agent-scope atomic stores), every storing wave waits for them (s_waitcnt vmcnt(0)), a workgroup
-// barrier, then ONE lane adds to the counter (agent scope); the consumer polls the counter with sc1 loads in one lane (bounded),
-// a workgroup barrier, then EVERY load of the handed-off bytes is an sc1 load.
-__device__ __forceinline__ void fcl_store_wt(float *p, float x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float fcl_load_wt(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void fcl_signal(unsigned *flag) { __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// one lane: until *flag >= want, or ~40 ms of the constant 100 MHz clock have passed (then *err = 1 and the caller goes on: the
-// step's numbers are wrong, the launch ends, the host sees the word)
-__device__ __forceinline__ void fcl_wait_flag(const unsigned *flag, unsigned want, unsigned *err) {
-  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-    __builtin_amdgcn_s_sleep(8);
-    if (__builtin_amdgcn_s_memrealtime() - t0 > 4000000ull) {
-      if (err) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      break;
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------------ heads
 // grid (bs / 16, K + 1, 3): head 0 value (input h_p), 1 policy (h_p), 2 reward (x_p = [h_{p-1} | one-hot], p >= 1)
 // WAIT: a unit of the fused forward launch -- its inputs come from chain workgroups of the same launch: everything else it needs
 // (fc1's weights, biases, targets) is requested FIRST and arrives while one lane polls the group's counter
-template <bool WAIT>
+// SIGD: a unit of k_fcl_fb -- its d loss / d hidden is handed to the backward chain of the SAME launch, its tapes to the head's weight-
+// gradient jobs of the same launch: all stored write-through, announced on the counter of the (sample group, position) whose hidden state
+// the gradient belongs to and on the head's counter of finished units
+template <bool WAIT, bool SIGD = false>
 __device__ __forceinline__ void fcl_heads_body(const FclView &v, const int cb, const int p, const int hd, float *fcl_smem) {
   float *X = fcl_smem, *A1 = X + 1024, *redf = A1 + 8192, *Y = redf + 8192, *S = Y + 1024, *PV = S + 1024;
   f32x4 *red = (f32x4 *)redf;
   const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, g4 = lane >> 4, m16 = lane & 15;
   const int row0 = cb * 16, R = v.R, K1 = v.K + 1, loff = fcl_lane_off(lane);
   // (the step counters advance here, two launches ahead of the optimiser code that reads them)
-  if (cb == 0 && p == 0 && hd == 0 && tid < v.nsteps) v.steps[tid] += 1.f;
+  if constexpr (!SIGD) { if (cb == 0 && p == 0 && hd == 0 && tid < v.nsteps) v.steps[tid] += 1.f; }      // (k_fcl_fb: chain workgroup 0 does)
   if (hd == 2 && p == 0) return;
   int stamp_i = 0;
 #define FCL_STAMP() if (v.prof && cb == 0 && p == 1 && tid == 0) v.prof[hd * 16 + stamp_i++] = __builtin_amdgcn_s_memtime();
@@ -365,7 +379,7 @@ __device__ __forceinline__ void fcl_heads_body(const FclView &v, const int cb, c
   asm volatile("" ::: "memory");
   fcl_load_narrow(WA, (const f32x4 *)(v.pk + pk.F2), w, lane);          // fc2's, under the epilogue
   FCL_STAMP()      // 2: fc1 products
-  fcl_fc1_out(acc, PV, A1, v.a1h + hp * T512 + fcl_tp(512, cb, 0, 0), loff, w, lane);
+  fcl_fc1_out<SIGD>(acc, PV, A1, v.a1h + hp * T512 + fcl_tp(512, cb, 0, 0), loff, w, lane);
   // (no barrier: the 16 k-steps of fc2's split-K slice of wave w are the 64 features of A1 wave w has just written itself)
   FCL_STAMP()      // 3: fc1 epilogue
   if (pk.nt == 1) fcl_narrow_res<1>(WA, A1, red, w, lane);
@@ -413,7 +427,8 @@ __device__ __forceinline__ void fcl_heads_body(const FclView &v, const int cb, c
   FCL_STAMP()      // 6: loss + barrier
   for (int idx = tid; idx < 64 * 16; idx += FCL_THREADS) {
     const int f = idx >> 4, n = idx & 15;
-    v.d2h[hp * T64 + fcl_tp(64, cb, f, n)] = S[fcl_at(f, n)];
+    if constexpr (SIGD) fcl_store_wt(v.d2h + hp * T64 + fcl_tp(64, cb, f, n), S[fcl_at(f, n)]);
+    else v.d2h[hp * T64 + fcl_tp(64, cb, f, n)] = S[fcl_at(f, n)];
   }
   // backward: d a1 = W2^T d logits, through the ReLU; then d x = W1^T d a1 (its first 50 features: d hidden state)
   fcl_wide_regs(WA, pk.ks2, S, lane, acc);
@@ -424,7 +439,7 @@ __device__ __forceinline__ void fcl_heads_body(const FclView &v, const int cb, c
     f32x4 msk[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) msk[i] = *(const f32x4 *)(A1 + (((64 * w + 16 * i + 4 * g4) >> 2) * 16 + m16) * 4);
-    fcl_mask_out(acc, msk, A1, v.d1h + hp * T512 + fcl_tp(512, cb, 0, 0), loff, w, lane);
+    fcl_mask_out<SIGD>(acc, msk, A1, v.d1h + hp * T512 + fcl_tp(512, cb, 0, 0), loff, w, lane);
   }
   // (no barrier: wave w's slice of the fc1-transposed product again)
   FCL_STAMP()      // 8: mask
@@ -436,10 +451,20 @@ __device__ __forceinline__ void fcl_heads_body(const FclView &v, const int cb, c
   FCL_STAMP()      // 10: reduce + barrier
   for (int idx = tid; idx < 64 * 16; idx += FCL_THREADS) {
     const int f = idx >> 4, n = idx & 15;
-    v.dH[hp * T64 + fcl_tp(64, cb, f, n)] = Y[fcl_at(f, n)];
+    if constexpr (SIGD) fcl_store_wt(v.dH + hp * T64 + fcl_tp(64, cb, f, n), Y[fcl_at(f, n)]);
+    else v.dH[hp * T64 + fcl_tp(64, cb, f, n)] = Y[fcl_at(f, n)];
   }
   FCL_STAMP()        // 11: d hidden stored
 #undef FCL_STAMP
+  if constexpr (SIGD) {
+    // every wave has stored (2 x 512 threads cover the 1024 elements): each waits for its stores, the workgroup's barrier, one lane announces
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    fcl_bar();
+    if (tid == 0) {
+      fcl_signal(v.flags + (size_t)(v.bs >> 4) * K1 + (size_t)cb * K1 + (hd == 2 ? p - 1 : p));
+      fcl_signal(v.flags + (size_t)2 * (v.bs >> 4) * K1 + 32 * (1 + hd));      // finished units of this head: its weight-gradient jobs wait for all of them
+    }
+  }
   if constexpr (WAIT) {
     if (v.prof && cb == 0 && p == v.K && hd == 0 && tid == 0) v.prof[63] = __builtin_amdgcn_s_memrealtime();
   }
@@ -757,8 +782,13 @@ __global__ __launch_bounds__(FCL_THREADS) void k_fcl_fwd(FclView v, int nchain) 
   fcl_heads_body<true>(v, cb, p, hd, fcl_smem);
 }
 
-template <int G>
+// WAITD: the chain workgroups of k_fcl_fb -- the backward pass follows the forward pass in the SAME workgroup, and the heads' d loss / d hidden
+// of position p comes from units of the same launch: wave 0 reads the (sample group, position) counter (requested a phase early, so a
+// counter that is already full costs no round trip), then loads what the units stored write-through with sc1 loads; the workgroup's
+// own tapes of the forward pass (same CU, plain stores drained before the pass ended) are read past the L1 too
+template <int G, bool WAITD = false>
 __device__ __forceinline__ void fcl_chain_bwd4_body(const FclView &v, const int blk, float *fcl_smem) {
+  static_assert(!WAITD || G == 1, "the in-launch hand-off counts units per group of 16 samples");
   constexpr int NS = 4 * G;                          // samples of this workgroup: G groups of four (see the forward chain)
   const int LDX = v.xq + 4;
   float *X = fcl_smem, *A1 = X + NS * LDX, *red = A1 + NS * FCL_LDA, *PV = red + G * 2048 + 16;
@@ -776,29 +806,59 @@ __device__ __forceinline__ void fcl_chain_bwd4_body(const FclView &v, const int 
   float dgam[4] = {0.f, 0.f, 0.f, 0.f}, dbet[4] = {0.f, 0.f, 0.f, 0.f};
   f32x4 dch = (f32x4){0.f, 0.f, 0.f, 0.f};         // d chain: gradient from the transition of position p + 1 into h_p
   float tv[4][5], trs = 0.f;
+  const unsigned *dfl = v.flags + (size_t)(v.bs >> 4) * K1 + (size_t)cb * K1;      // (WAITD) finished units per position of this sample group
+  auto ld = [&](const float *q) __attribute__((always_inline)) -> float {
+    if constexpr (WAITD) return fcl_load_wt(q);
+    else return *q;
+  };
   auto request = [&](int p) __attribute__((always_inline)) {
     if (w < G) {
       const size_t o = fcl_tp(64, cb, f0, n0 + sj);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        tv[i][0] = v.dH[((size_t)0 * K1 + p) * T64 + o + i * 16];
-        tv[i][1] = v.dH[((size_t)1 * K1 + p) * T64 + o + i * 16];
-        tv[i][2] = p < v.K ? v.dH[((size_t)2 * K1 + p + 1) * T64 + o + i * 16] : 0.f;
-        tv[i][3] = v.h[(size_t)p * T64 + o + i * 16];
-        tv[i][4] = v.xhat[(size_t)p * T64 + o + i * 16];
+        tv[i][0] = ld(v.dH + ((size_t)0 * K1 + p) * T64 + o + i * 16);
+        tv[i][1] = ld(v.dH + ((size_t)1 * K1 + p) * T64 + o + i * 16);
+        tv[i][2] = p < v.K ? ld(v.dH + ((size_t)2 * K1 + p + 1) * T64 + o + i * 16) : 0.f;
+        tv[i][3] = ld(v.h + (size_t)p * T64 + o + i * 16);
+        tv[i][4] = ld(v.xhat + (size_t)p * T64 + o + i * 16);
       }
-      trs = v.rstd[(size_t)p * R + row0 + sj];
+      trs = ld(v.rstd + (size_t)p * R + row0 + sj);
+    }
+  };
+  // (WAITD) the units of position p have all stored: fl = the counter as read a phase ago; short of its target, one lane polls (bounded)
+  auto arrived = [&](int p, unsigned fl) __attribute__((always_inline)) {
+    if constexpr (WAITD) {
+      const unsigned want = p < v.K ? 3u : 2u;
+      if (w < G && fl < want) {
+        if (lane == 0) fcl_wait_flag(dfl + p, want, v.err);
+        if (v.prof && blk == 0 && lane == 0) v.prof[14] += 1ull;
+      }
+      if (v.prof && blk == 0 && tid == 0 && p < 6) v.prof[p == 0 ? 15 : (p < 5 ? 27 + p : 44)] = __builtin_amdgcn_s_memrealtime();
+      asm volatile("" ::: "memory");      // (the loads of the handed-off bytes stay behind the counter's read)
     }
   };
   for (int idx = tid; idx < NS * LDX; idx += FCL_THREADS) X[idx] = 0.f;
-  request(v.K);
+  if constexpr (!WAITD) request(v.K);
   // (loads return in order: the small reads above first, then the weights in the order of their first use)
   asm volatile("" ::: "memory");
   fcl_quad_load<MZ_H>(WB2, v.pk + v.tr.B2 + (size_t)w * MZ_H * 64, lane);
   asm volatile("" ::: "memory");
+  if constexpr (WAITD) {
+    // every weight of the pass is requested NOW: they arrive while wave 0 waits for the last position's heads units (~ a unit's duration)
+    fcl_quad_load<64>(WB1, v.pk + v.tr.B1 + (size_t)w * 64 * 64, lane);
+    fcl_quad_load<MZ_H>(WR2, v.pk + v.rep.B2 + (size_t)w * MZ_H * 64, lane);
+    asm volatile("" ::: "memory");
+    arrived(v.K, 0u);
+    if (v.prof && blk == 0 && tid == 0) v.prof[12] = __builtin_amdgcn_s_memrealtime();
+    request(v.K);
+  }
   if (tid < 64) lnw[tid] = plnw;
   fcl_bar();
   auto body = [&](int p, const float (&W2)[MZ_H]) __attribute__((always_inline)) {
+    unsigned fl = 0u;
+    if constexpr (WAITD) {
+      if (w < G && p > 0) fl = __hip_atomic_load(dfl + (p - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (w < G) {
       // gradient arriving at h_p (value and policy heads of position p, reward head and transition of position p + 1;
       // hook 0.5, learners.py:200), then ReLU and LayerNorm backwards over the sample's 16 lanes
@@ -823,13 +883,13 @@ __device__ __forceinline__ void fcl_chain_bwd4_body(const FclView &v, const int 
       for (int i = 0; i < 4; ++i) dy[i] = (f0 + i < MZ_H) ? rstd * (dx[i] - s1 * inv - xh[i] * (s2 * inv)) : 0.f;
       *(f32x4 *)(D2 + sj * LDX + f0) = dy;
     }
-    if (p > 0) request(p - 1);
+    if (p > 0) { arrived(p - 1, fl); request(p - 1); }
     const float *a1t = v.a1c + (size_t)p * T512 + fcl_tp(512, cb, 64 * w, 0);
     f32x4 msk[G];
 #pragma unroll
     for (int g = 0; g < G; ++g)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) msk[g][i] = (a1t + i * 16)[fcl_lane_off4(lane, n0 + 4 * g)];
+      for (int i = 0; i < 4; ++i) msk[g][i] = ld((a1t + i * 16) + fcl_lane_off4(lane, n0 + 4 * g));
     fcl_bar();
     if (tid >= 256) {      // the delta tape of this position, by the upper half of the workgroup (D2 is next written behind the next barrier)
       const int t = tid - 256;
@@ -868,8 +928,10 @@ __device__ __forceinline__ void fcl_chain_bwd4_body(const FclView &v, const int 
   // (the last position peeled off the loop: it waits for WB2 alone -- the wait counter holds 63 loads, so WB1's 64 (and the
   // representation's 50) are requested only once WB2 has been settled -- and they arrive under its first phases)
   fcl_quad_settle(WB2);
-  fcl_quad_load<64>(WB1, v.pk + v.tr.B1 + (size_t)w * 64 * 64, lane);
-  if constexpr (G == 1) fcl_quad_load<MZ_H>(WR2, v.pk + v.rep.B2 + (size_t)w * MZ_H * 64, lane);      // (G > 1: no registers to hold them through the loop)
+  if constexpr (!WAITD) {
+    fcl_quad_load<64>(WB1, v.pk + v.tr.B1 + (size_t)w * 64 * 64, lane);
+    if constexpr (G == 1) fcl_quad_load<MZ_H>(WR2, v.pk + v.rep.B2 + (size_t)w * MZ_H * 64, lane);      // (G > 1: no registers to hold them through the loop)
+  }
   asm volatile("" ::: "memory");
   body(v.K, WB2);
   fcl_quad_settle(WB1);
@@ -889,6 +951,7 @@ __device__ __forceinline__ void fcl_chain_bwd4_body(const FclView &v, const int 
       }
     }
   }
+  if constexpr (WAITD) { if (v.prof && blk == 0 && tid == 0) v.prof[13] = __builtin_amdgcn_s_memrealtime(); }
 }
 
 template <int G>
@@ -896,6 +959,17 @@ __global__ __launch_bounds__(FCL_THREADS) void k_fcl_chain_bwd4(FclView v) {
   extern __shared__ __attribute__((aligned(16))) float fcl_smem[];
   fcl_chain_bwd4_body<G>(v, blockIdx.x, fcl_smem);
 }
+
+// Forward chain, every heads unit AND the backward chain in ONE launch (batch <= 256: 64 chain workgroups on 256 CUs).  A chain
+// workgroup runs the forward pass, then -- same workgroup, same CU, its backward weights requested while it waits -- the backward
+// pass, position K first, as soon as the (at most three) heads units that produce d loss / d h_p of its sample group have announced it.
+// The launch boundary between the two passes (all 272 units finished, the chip drained, a cold start) is gone, and only position K's
+// units are on the critical path: the units of positions K - 1 .. 0 finish while the backward chain works its way down.  The units are
+// dispatched in v.order (ascending while a slot is left beside position K's, then descending: the order the backward chain asks).
+// Progress: a unit waits for chain workgroups' FORWARD passes only, and those never wait; a backward pass waits for units, every one of
+// which gets a CU (the chain holds 64 of them) -- so the launch ends wherever all chain workgroups are resident, which the handle checks
+// (2 x chain workgroups <= CUs); every wait is bounded (-> the pinned error word).
+// (the kernel: behind the weight-gradient jobs it also carries)
 
 // ------------------------------------------------------------------------------------------------ weight gradients (+ optimiser)
 // One workgroup (NW waves) per job: the 16 x 64 strip G of dW = D . X^T (D: deltas, Mp features per row chunk; X: layer
@@ -908,7 +982,7 @@ struct FclJob {
   size_t d_off, x_off;      // float offsets of the two tapes at the layer's FIRST position (feature 0, row 0)
   size_t d_ps, x_ps;        // their strides from one position to the next
   size_t w_off, b_off;      // flat offsets of W [M][N] and of its bias (b_off used by the ng == 0 strip)
-  int M, N, Mp, Np, tm, ng, npos, na;        // Mp, Np: feature counts of the two tapes (their row-chunk strides / 16); tile: 16 na rows from row 16 na tm, columns from 16 ni ng (ni: the kernel's)
+  int M, N, Mp, Np, tm, ng, npos, na, hd, pad_;        // Mp, Np: feature counts of the two tapes (their row-chunk strides / 16); tile: 16 na rows from row 16 na tm, columns from 16 ni ng (ni: the kernel's)
 };
 
 struct FclOpt {
@@ -919,6 +993,7 @@ struct FclOpt {
 
 struct FclDw {              // what a weight-gradient workgroup does with its strip
   const float *tapes;
+  unsigned tape_bytes;      // (jobs of k_fcl_fb read the tapes through a buffer descriptor: sc1 loads)
   int R, S;                 // batch rows; row slabs (1: a strip is a gradient)
   float *part;              // fuse == 0: strips to part[slab][nflat]
   size_t nflat;
@@ -964,17 +1039,26 @@ __device__ __forceinline__ void fcl_bias_corr(const FclDw &a, float *dst) {
 #define FCL_DW_Q(NA, NI) ((NA) * (4 * (NI) + 1))                                   // floats per lane a wave leaves in LDS
 #define FCL_DW_LDS(NW, NA, NI) (((NW) * FCL_DW_Q(NA, NI) * 64 + 4) * 4)            // bytes: the waves' partial tiles + the two bias corrections
 
-template <int NW, int NA, int NI, int NF, bool FUSABLE>
-__device__ __forceinline__ void fcl_dw_job(const FclJob *jp, int slab, const FclDw &a, float *sh) {
+// WT: a job of k_fcl_fb -- its tapes were written (through) by heads units and chain workgroups of the SAME launch: the job has its
+// optimiser operands requested, then one lane waits for the head's counter of finished units (`wait_flag` >= `wait_for`), a barrier, and
+// every tape load is an sc1 load (buffer loads: 16 bytes per lane as before)
+template <int NW, int NA, int NI, int NF, bool FUSABLE, bool WT = false>
+__device__ __forceinline__ void fcl_dw_job(const FclJob *jp, int slab, const FclDw &a, float *sh, const unsigned *wait_flag = nullptr,
+                                           unsigned wait_for = 0u, unsigned *err = nullptr) {
   constexpr int Q = FCL_DW_Q(NA, NI);
   const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, g4 = lane >> 4, m16 = lane & 15;
   const FclJob j = *jp;
-  if (a.fuse && tid == NW * 64 - 1) fcl_bias_corr(a, sh + NW * Q * 64);      // (a lane of the last wave: the first waves carry the remainder units)
+  if constexpr (!WT) { if (a.fuse && tid == NW * 64 - 1) fcl_bias_corr(a, sh + NW * Q * 64); }     // (a lane of the last wave: the first waves carry the remainder units)
   const int nch = a.R >> 4, per = (nch + a.S - 1) / a.S, c_lo = slab * per, c_hi = c_lo + per < nch ? c_lo + per : nch;
   const int nchs = c_hi > c_lo ? c_hi - c_lo : 0, U = j.npos * nchs;
   // tapes: [row chunk][feature][16 rows] -- 16 features x 16 rows of chunk c are one contiguous KiB
-  const float *Db = a.tapes + j.d_off + (size_t)c_lo * j.Mp * 16 + (size_t)(16 * NA * j.tm + m16) * 16 + 4 * g4;
-  const float *Xb = a.tapes + j.x_off + (size_t)c_lo * j.Np * 16 + (size_t)(16 * NI * j.ng + m16) * 16 + 4 * g4;
+  const size_t Db = j.d_off + (size_t)c_lo * j.Mp * 16 + (size_t)(16 * NA * j.tm + m16) * 16 + 4 * g4;      // (float offsets into the tapes)
+  const size_t Xb = j.x_off + (size_t)c_lo * j.Np * 16 + (size_t)(16 * NI * j.ng + m16) * 16 + 4 * g4;
+  const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc((void *)a.tapes, 0, WT ? (int)a.tape_bytes : 0, 0x00020000);
+  auto ld16 = [&](size_t off) __attribute__((always_inline)) -> f32x4 {
+    if constexpr (WT) return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(trs, (int)(off * 4), 0, 16));      // (aux 16: sc1)
+    else return *(const f32x4 *)(a.tapes + off);
+  };
   const size_t dstr = (size_t)j.Mp * 16, xstr = (size_t)j.Np * 16;      // floats per row chunk
   f32x4 acc[NA][NI];
   float bsum[NA];
@@ -1024,12 +1108,12 @@ __device__ __forceinline__ void fcl_dw_job(const FclJob *jp, int slab, const Fcl
 #pragma unroll
     for (int k = 0; k < NF; ++k) {
       if (u0 + k * NW < U) {
-        const float *Dp = Db + (size_t)p * j.d_ps + (size_t)c * dstr;
-        const float *Xp = Xb + (size_t)p * j.x_ps + (size_t)c * xstr;
+        const size_t Dp = Db + (size_t)p * j.d_ps + (size_t)c * dstr;
+        const size_t Xp = Xb + (size_t)p * j.x_ps + (size_t)c * xstr;
 #pragma unroll
-        for (int f = 0; f < NA; ++f) av[k][f] = *(const f32x4 *)(Dp + 256 * f);
+        for (int f = 0; f < NA; ++f) av[k][f] = ld16(Dp + 256 * f);
 #pragma unroll
-        for (int i = 0; i < NI; ++i) bv[k][i] = *(const f32x4 *)(Xp + 256 * i);
+        for (int i = 0; i < NI; ++i) bv[k][i] = ld16(Xp + 256 * i);
         c += NW;
         while (c >= nchs) { c -= nchs; ++p; }
       }
@@ -1051,6 +1135,16 @@ __device__ __forceinline__ void fcl_dw_job(const FclJob *jp, int slab, const Fcl
       }
     }
   };
+  if constexpr (WT) {
+    // (the optimiser's operands above are in flight; the step counter was written through by chain workgroup 0 before its first signal)
+    if (tid == 0) fcl_wait_flag<64>(wait_flag, wait_for, err);
+    fcl_bar();
+    if (a.fuse && tid == NW * 64 - 1) {
+      const double step = (double)fcl_load_wt(a.steps);
+      sh[NW * Q * 64] = (float)(1.0 - pow(a.o.beta1, step));
+      sh[NW * Q * 64 + 1] = (float)(1.0 - pow(a.o.beta2, step));
+    }
+  }
   if (w < U) {
     f32x4 avA[NF][NA], bvA[NF][NI], avB[NF][NA], bvB[NF][NI];
     int u0 = w;
@@ -1193,15 +1287,59 @@ __device__ __forceinline__ void fcl_loss_block(const float *lossb, const void *w
   if (threadIdx.x < 3) loss_acc[threadIdx.x == 2 ? 0 : (threadIdx.x == 0 ? 1 : 2)] += shd3[threadIdx.x * 256] / (double)bs;
 }
 
+// (the heads' weight-gradient jobs ride in the same launch, behind the units: a job waits for the counter of its head's finished units and
+// reads the tapes they wrote through -- it runs on the CUs the units have left, beside the backward chain, as it did in k_fcl_bwd_dw)
+template <int KP>
+__global__ __launch_bounds__(FCL_THREADS) void k_fcl_fb(FclView v, int nchain, const FclJob *jobs, FclDw a) {
+  extern __shared__ __attribute__((aligned(16))) float fcl_smem[];
+  const int G = v.bs >> 4, K1 = v.K + 1, units = G * (3 * K1 - 1);
+  if ((int)blockIdx.x < nchain) {
+    // (the optimiser's step counters advance here, written through by a storing wave of chain workgroup 0 -- drained before its first signal)
+    if (blockIdx.x == 0 && (int)threadIdx.x >= 256 && (int)threadIdx.x < 256 + v.nsteps)
+      fcl_store_wt(v.steps + (threadIdx.x - 256), v.steps[threadIdx.x - 256] + 1.f);
+    fcl_chain_fwd4_body<KP, true, 1>(v, blockIdx.x, fcl_smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this workgroup's own tapes (a1c, xhat, rstd: plain stores) are read back below
+    fcl_bar();
+    fcl_chain_bwd4_body<1, true>(v, blockIdx.x, fcl_smem);
+    return;
+  }
+  int u = (int)blockIdx.x - nchain;
+  if (u >= units) {
+    const FclJob *jp = jobs + (u - units);
+    const int hd = jp->hd;
+    fcl_dw_job<FCL_NW, 1, 4, 4, true, true>(jp, 0, a, fcl_smem, v.flags + (size_t)2 * G * K1 + 32 * (1 + hd), (unsigned)(G * (hd == 2 ? v.K : K1)), v.err);      // (a 128-byte line per head's counter)
+    return;
+  }
+  int slot = 0;
+  for (;;) {          // the unit's place in the dispatch order: slot-th position of v.order, 2 G units at position 0 (no reward head), else 3 G
+    const int n = (v.order[slot] == 0 ? 2 : 3) * G;
+    if (u < n) break;
+    u -= n; ++slot;
+  }
+  const int p = v.order[slot], hd = u / G;      // (value, policy, then reward: the reward unit's counter is position p - 1's, asked for one position later)
+  fcl_heads_body<true, true>(v, u % G, p, hd, fcl_smem);
+}
+
 // the fused step's LAST launch (batch <= 512): the chain layers' weight-gradient jobs as 16 x 32 tiles, one slab, Adam in the
 // workgroup; two more workgroups: the LayerNorm parameters (gradient from the chain workgroups' partials, Adam) and the loss sums
-__global__ __launch_bounds__(FCL_THREADS) void k_fcl_dwa(const FclJob *jobs, int njobs, FclDw a, int tail, const float *lnpart, int nwg,
-                                                         size_t ln_w, const float *lossb, const void *w, int w_f64, int bs, int K1,
-                                                         double *loss_acc) {
+// (behind k_fcl_fb this launch carries EVERY job: the first nheads of the list are the heads' layers as 16 x 64 strips; it then also
+// zeroes the hand-off counters for the next step -- the launch that used them has ended)
+// (NFJ, MINW: tape loads in flight per wave and the register budget -- <4, 2>: 217 registers, one workgroup per CU (the chain layers' 224 jobs
+// fit the chip); <2, 4>: 128 registers, two per CU, for the launch that carries all 392 jobs)
+template <int NFJ, int MINW>
+__global__ __launch_bounds__(FCL_THREADS, MINW) void k_fcl_dwa(const FclJob *jobs, int njobs, FclDw a, int tail, const float *lnpart, int nwg,
+                                                                  size_t ln_w, const float *lossb, const void *w, int w_f64, int bs, int K1,
+                                                                  double *loss_acc, int nheads, unsigned *flags, int nflags) {
   extern __shared__ __attribute__((aligned(16))) float fcl_smem[];
   const int b = blockIdx.x;
+  if (b == 0 && flags)
+    for (int i = threadIdx.x; i < nflags; i += FCL_THREADS) flags[i] = 0u;
+  if (b < nheads) {
+    fcl_dw_job<FCL_NW, 1, 4, NFJ, true>(jobs + b, 0, a, fcl_smem);
+    return;
+  }
   if (b < njobs) {
-    fcl_dw_job<FCL_NW, 1, 2, 4, true>(jobs + b, 0, a, fcl_smem);
+    fcl_dw_job<FCL_NW, 1, 2, NFJ, true>(jobs + b, 0, a, fcl_smem);
     return;
   }
   if (!tail) return;

@@ -28,6 +28,11 @@ tl = buf[59:64].astype(np.float64)
 if tl[0] > 0:      # the fused forward launch's timeline (constant 100 MHz clock): microseconds from chain workgroup 0's start
   print('fused forward launch (last sample of %d): chain workgroup 0 ends at %.2f us; the last position\'s value unit of group 0 starts at %.2f, '
         'is past its wait at %.2f, ends at %.2f us' % (N, (tl[1] - tl[0]) / 100.0, (tl[2] - tl[0]) / 100.0, (tl[3] - tl[0]) / 100.0, (tl[4] - tl[0]) / 100.0))
+if buf[12] > 0 and tl[0] > 0:      # k_fcl_fb: the backward pass of chain workgroup 0 on the same clock
+  print('one-launch forward + backward: chain workgroup 0 has the last position\'s d hidden at %.2f us, ends its backward pass at %.2f us; '
+        'later positions it had to poll for (all samples): %d' % ((float(buf[12]) - tl[0]) / 100.0, (float(buf[13]) - tl[0]) / 100.0, int(buf[14])))
+  arr = [float(buf[k]) for k in (15, 28, 29, 30, 31, 44)]
+  print('  positions\' d hidden in hand at (us): ' + ', '.join('p%d %.2f' % (q, (arr[q] - tl[0]) / 100.0) for q in range(5, -1, -1) if arr[q] > 0))
 acc /= N
 for i, nme in enumerate(names):
   print('%-28s value %6.2f  policy %6.2f  reward %6.2f' % (nme, acc[0, i], acc[1, i], acc[2, i]))
