@@ -78,8 +78,10 @@ int mz_fcl_read_grad(mz_fcl *c, float *host_out, size_t n);
 long long mz_fcl_read_tape(mz_fcl *c, int which, float *host_out, size_t n);
 
 /* development hook: s_memtime stamps (shader clock) at the phase boundaries of k_fcl_heads, workgroup 0 of every head at unroll
- * position 1 (3 x 16 slots), and of k_fcl_chain_fwd4's position 2 (slots 48..53): enable = 1 arms it for the following steps,
- * enable = 0 reads the stamps of the last step into host_out [64]. */
+ * position 1 (3 x 16 slots), and of k_fcl_chain_fwd4's position 2 (slots 48..53); slots 12..15, 28..31, 44..47, 59..66: the two-launch
+ * step's timeline on the constant 100 MHz clock (chain workgroup 0's passes, its last two positions' value units, the last unit / job /
+ * chain workgroup to end; scripts/fcl_heads_phases.py names them): enable = 1 arms it for the following steps, enable = 0 reads the stamps
+ * of the last step into host_out [96]. */
 int mz_fcl_heads_profile(mz_fcl *c, int enable, unsigned long long *host_out);
 
 /* Which kernel mz_search / mz_selfplay_steps launch for this engine right now: out4 [host] = kind (0 the stand-alone

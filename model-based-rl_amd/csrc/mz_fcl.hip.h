@@ -59,7 +59,6 @@ struct FclView {
                                  // written through; 4 = all of the group's; zeroed by k_fcl_bwd_dw for the next step
   int nflags;                    // (k_fcl_fb: [2][bs / 16][K + 1] -- behind the arrival counters, the heads' counters of finished units per (sample group, position
                                  // whose hidden state the units' d loss / d hidden belongs to): 3 = value, policy and the next position's reward unit; 2 at position K)
-  int order[8];                  // k_fcl_fb: the positions in the order their heads units are dispatched
   unsigned *err;                 // [host, device-mapped] set to 1 where a unit's wait for its counter ran into its bound (never on a healthy box)
   float *steps; int nsteps;      // the optimiser's per-parameter step counters (torch keeps one per parameter), advanced by k_fcl_heads; nsteps = 0: not this step
   unsigned long long *prof;      // development: s_memtime stamps of k_fcl_heads' phases (workgroup 0 of every head at position 1), else null
@@ -304,8 +303,11 @@ __device__ __forceinline__ float fcl_max32(float x) {
 // SIGD: a unit of k_fcl_fb -- its d loss / d hidden is handed to the backward chain of the SAME launch, its tapes to the head's weight-
 // gradient jobs of the same launch: all stored write-through, announced on the counter of the (sample group, position) whose hidden state
 // the gradient belongs to and on the head's counter of finished units
-template <bool WAIT, bool SIGD = false>
-__device__ __forceinline__ void fcl_heads_body(const FclView &v, const int cb, const int p, const int hd, float *fcl_smem) {
+struct FclNothing { __device__ __forceinline__ void operator()() const {} };
+// requested: called once the unit's own first loads (biases, targets, fc1's weights, its inputs) are on their way -- k_fcl_fb's chain workgroups ask for
+// their backward pass's weights there (loads return in order: asked for in front of the unit, they held its first phase back 3 us)
+template <bool WAIT, bool SIGD = false, class F = FclNothing>
+__device__ __forceinline__ void fcl_heads_body(const FclView &v, const int cb, const int p, const int hd, float *fcl_smem, F requested = F()) {
   float *X = fcl_smem, *A1 = X + 1024, *redf = A1 + 8192, *Y = redf + 8192, *S = Y + 1024, *PV = S + 1024;
   f32x4 *red = (f32x4 *)redf;
   const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, g4 = lane >> 4, m16 = lane & 15;
@@ -351,19 +353,25 @@ __device__ __forceinline__ void fcl_heads_body(const FclView &v, const int cb, c
   asm volatile("" ::: "memory");
   fcl_req_wide(WA, (const f32x4 *)(v.pk + pk.F1), pk.ks1, w, lane);
   asm volatile("" ::: "memory");
+  if constexpr (!WAIT) requested();
   if constexpr (WAIT) {
     // hidden states of position p (value, policy) / the transition input of position p = what position p - 1 left (reward)
     // (development: the launch's timeline on the constant 100 MHz clock, slots 59..63: chain workgroup 0 start / end, the LAST
     // position's value unit of group 0 at its start / past its wait / at its end)
     if (v.prof && cb == 0 && p == v.K && hd == 0 && tid == 0) v.prof[61] = __builtin_amdgcn_s_memrealtime();
+    if (v.prof && cb == 0 && p == v.K - 1 && hd == 0 && tid == 0) v.prof[45] = __builtin_amdgcn_s_memrealtime();
     if (tid == 0) fcl_wait_flag(v.flags + (size_t)cb * K1 + (hd == 2 ? p - 1 : p), 4u, v.err);
     if (v.prof && cb == 0 && p == v.K && hd == 0 && tid == 0) v.prof[62] = __builtin_amdgcn_s_memrealtime();
+    if (v.prof && cb == 0 && p == v.K - 1 && hd == 0 && tid == 0) v.prof[46] = __builtin_amdgcn_s_memrealtime();
     fcl_bar();
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int idx = tid + k * FCL_THREADS;
       xs_in[k] = fcl_load_wt(src + fcl_tp(hd == 2 ? v.XR : 64, cb, idx >> 4, idx & 15));
     }
+    asm volatile("" ::: "memory");
+    requested();      // (behind the inputs: 230 KB of backward weights in front of them kept the first barrier 1.6 us longer)
+    asm volatile("" ::: "memory");
   }
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
@@ -467,6 +475,7 @@ __device__ __forceinline__ void fcl_heads_body(const FclView &v, const int cb, c
   }
   if constexpr (WAIT) {
     if (v.prof && cb == 0 && p == v.K && hd == 0 && tid == 0) v.prof[63] = __builtin_amdgcn_s_memrealtime();
+    if (v.prof && cb == 0 && p == v.K - 1 && hd == 0 && tid == 0) v.prof[47] = __builtin_amdgcn_s_memrealtime();
   }
 }
 
@@ -786,8 +795,10 @@ __global__ __launch_bounds__(FCL_THREADS) void k_fcl_fwd(FclView v, int nchain) 
 // of position p comes from units of the same launch: wave 0 reads the (sample group, position) counter (requested a phase early, so a
 // counter that is already full costs no round trip), then loads what the units stored write-through with sc1 loads; the workgroup's
 // own tapes of the forward pass (same CU, plain stores drained before the pass ended) are read past the L1 too
-template <int G, bool WAITD = false>
-__device__ __forceinline__ void fcl_chain_bwd4_body(const FclView &v, const int blk, float *fcl_smem) {
+// PRE: WB2 and WB1 (the transition's transposed weights) were requested by the caller -- k_fcl_fb asks for them before the workgroup runs its
+// heads unit, so that they are in registers when the backward pass begins
+template <int G, bool WAITD, bool PRE>
+__device__ __forceinline__ void fcl_chain_bwd4_core(const FclView &v, const int blk, float *fcl_smem, float (&WB2)[MZ_H], float (&WB1)[64]) {
   static_assert(!WAITD || G == 1, "the in-launch hand-off counts units per group of 16 samples");
   constexpr int NS = 4 * G;                          // samples of this workgroup: G groups of four (see the forward chain)
   const int LDX = v.xq + 4;
@@ -797,8 +808,7 @@ __device__ __forceinline__ void fcl_chain_bwd4_body(const FclView &v, const int 
   const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int row0 = blk * NS, cb = row0 >> 4, n0 = row0 & 15, R = v.R, K1 = v.K + 1;
   const size_t T64 = (size_t)64 * R, T512 = (size_t)512 * R;
-  float WB2[MZ_H], WB1[64];
-  float WR2[MZ_H];      // the representation's, for position 0 (requested now)
+  float WR2[MZ_H];      // the representation's, for position 0
   const float plnw = tid < MZ_H ? v.P[v.ln_w + tid] : 0.f;
   // wave g < G carries group g's per-sample work in registers: lane (j, b) = (lane >> 4, lane & 15) = features 4 b + i of sample j
   // -- a sample's 16 lanes are one DPP row, its two LayerNorm reductions four DPP exchanges each (as in the forward chain)
@@ -841,12 +851,11 @@ __device__ __forceinline__ void fcl_chain_bwd4_body(const FclView &v, const int 
   if constexpr (!WAITD) request(v.K);
   // (loads return in order: the small reads above first, then the weights in the order of their first use)
   asm volatile("" ::: "memory");
-  fcl_quad_load<MZ_H>(WB2, v.pk + v.tr.B2 + (size_t)w * MZ_H * 64, lane);
+  if constexpr (!PRE) fcl_quad_load<MZ_H>(WB2, v.pk + v.tr.B2 + (size_t)w * MZ_H * 64, lane);
   asm volatile("" ::: "memory");
   if constexpr (WAITD) {
-    // every weight of the pass is requested NOW: they arrive while wave 0 waits for the last position's heads units (~ a unit's duration)
-    fcl_quad_load<64>(WB1, v.pk + v.tr.B1 + (size_t)w * 64 * 64, lane);
-    fcl_quad_load<MZ_H>(WR2, v.pk + v.rep.B2 + (size_t)w * MZ_H * 64, lane);
+    // every weight of the pass is requested before wave 0 waits for the last position's heads units
+    if constexpr (!PRE) fcl_quad_load<64>(WB1, v.pk + v.tr.B1 + (size_t)w * 64 * 64, lane);
     asm volatile("" ::: "memory");
     arrived(v.K, 0u);
     if (v.prof && blk == 0 && tid == 0) v.prof[12] = __builtin_amdgcn_s_memrealtime();
@@ -928,10 +937,8 @@ __device__ __forceinline__ void fcl_chain_bwd4_body(const FclView &v, const int 
   // (the last position peeled off the loop: it waits for WB2 alone -- the wait counter holds 63 loads, so WB1's 64 (and the
   // representation's 50) are requested only once WB2 has been settled -- and they arrive under its first phases)
   fcl_quad_settle(WB2);
-  if constexpr (!WAITD) {
-    fcl_quad_load<64>(WB1, v.pk + v.tr.B1 + (size_t)w * 64 * 64, lane);
-    if constexpr (G == 1) fcl_quad_load<MZ_H>(WR2, v.pk + v.rep.B2 + (size_t)w * MZ_H * 64, lane);      // (G > 1: no registers to hold them through the loop)
-  }
+  if constexpr (!WAITD) fcl_quad_load<64>(WB1, v.pk + v.tr.B1 + (size_t)w * 64 * 64, lane);
+  if constexpr (G == 1) fcl_quad_load<MZ_H>(WR2, v.pk + v.rep.B2 + (size_t)w * MZ_H * 64, lane);      // (G > 1: no registers to hold them through the loop)
   asm volatile("" ::: "memory");
   body(v.K, WB2);
   fcl_quad_settle(WB1);
@@ -951,7 +958,16 @@ __device__ __forceinline__ void fcl_chain_bwd4_body(const FclView &v, const int 
       }
     }
   }
-  if constexpr (WAITD) { if (v.prof && blk == 0 && tid == 0) v.prof[13] = __builtin_amdgcn_s_memrealtime(); }
+  if constexpr (WAITD) {
+    if (v.prof && blk == 0 && tid == 0) v.prof[13] = __builtin_amdgcn_s_memrealtime();
+    if (v.prof && tid == 0) atomicMax(v.prof + 66, (unsigned long long)__builtin_amdgcn_s_memrealtime());      // (the last chain workgroup's end)
+  }
+}
+
+template <int G, bool WAITD = false>
+__device__ __forceinline__ void fcl_chain_bwd4_body(const FclView &v, const int blk, float *fcl_smem) {
+  float WB2[MZ_H], WB1[64];
+  fcl_chain_bwd4_core<G, WAITD, false>(v, blk, fcl_smem, WB2, WB1);
 }
 
 template <int G>
@@ -964,8 +980,7 @@ __global__ __launch_bounds__(FCL_THREADS) void k_fcl_chain_bwd4(FclView v) {
 // workgroup runs the forward pass, then -- same workgroup, same CU, its backward weights requested while it waits -- the backward
 // pass, position K first, as soon as the (at most three) heads units that produce d loss / d h_p of its sample group have announced it.
 // The launch boundary between the two passes (all 272 units finished, the chip drained, a cold start) is gone, and only position K's
-// units are on the critical path: the units of positions K - 1 .. 0 finish while the backward chain works its way down.  The units are
-// dispatched in v.order (ascending while a slot is left beside position K's, then descending: the order the backward chain asks).
+// units are on the critical path: the units of positions K - 1 .. 0 finish while the backward chain works its way down.
 // Progress: a unit waits for chain workgroups' FORWARD passes only, and those never wait; a backward pass waits for units, every one of
 // which gets a CU (the chain holds 64 of them) -- so the launch ends wherever all chain workgroups are resident, which the handle checks
 // (2 x chain workgroups <= CUs); every wait is bounded (-> the pinned error word).
@@ -1075,6 +1090,9 @@ __device__ __forceinline__ void fcl_dw_job(const FclJob *jp, int slab, const Fcl
   // gradient: requested NOW, they arrive under the tapes' loads and the MFMAs (requested after the reduction, they were one more
   // exposed round trip at the end of the step's last launch)
   constexpr int T_ = NW * 64, EW_ = NA * NI * 256, EB_ = NA * 16, EPT_ = (EW_ + EB_ + T_ - 1) / T_;
+  // (the learning rate too: in the native loop it lives in the update's pinned staging -- read where it is used, behind the reduction, it
+  // was a round trip over PCIe at the end of every job)
+  const float lr_pre = (FUSABLE && a.fuse) ? *a.lr_p : 0.f;
   float pre_p[FUSABLE ? EPT_ : 1], pre_m[FUSABLE ? EPT_ : 1], pre_v[FUSABLE ? EPT_ : 1];
   int pre_a[FUSABLE ? EPT_ : 1], pre_b[FUSABLE ? EPT_ : 1];
   static_assert(!FUSABLE || NA == 1, "the fused optimiser works on 16-row tiles");
@@ -1209,7 +1227,7 @@ __device__ __forceinline__ void fcl_dw_job(const FclJob *jp, int slab, const Fcl
     // fused optimiser: a thread's elements together, so that their loads (weight, moments, pack positions) are one round trip
     static_assert(EPT == EPT_, "the prefetched operands are this thread's elements");
     const float bc1 = sh[NW * Q * 64], bc2 = sh[NW * Q * 64 + 1];
-    const double lr = (double)*a.lr_p;
+    const double lr = (double)lr_pre;
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
       float g;
@@ -1289,35 +1307,57 @@ __device__ __forceinline__ void fcl_loss_block(const float *lossb, const void *w
 
 // (the heads' weight-gradient jobs ride in the same launch, behind the units: a job waits for the counter of its head's finished units and
 // reads the tapes they wrote through -- it runs on the CUs the units have left, beside the backward chain, as it did in k_fcl_bwd_dw)
+// (a chain workgroup that has finished its forward pass does not idle the ~13 us until its last position's units have finished: three of a
+// sample group's four chain workgroups run THOSE units themselves -- value, policy, reward of position K: no CU waits 17 us for them with
+// nothing to do -- and the fourth takes one of the other positions' units, which are handed out through a counter in position order)
 template <int KP>
 __global__ __launch_bounds__(FCL_THREADS) void k_fcl_fb(FclView v, int nchain, const FclJob *jobs, FclDw a) {
   extern __shared__ __attribute__((aligned(16))) float fcl_smem[];
-  const int G = v.bs >> 4, K1 = v.K + 1, units = G * (3 * K1 - 1);
-  if ((int)blockIdx.x < nchain) {
+  __shared__ int s_unit;
+  float WB2[MZ_H], WB1[64];
+  const int G = v.bs >> 4, K1 = v.K + 1, units = G * (3 * v.K - 1);      // (units of positions 0 .. K - 1: the queue)
+  const bool chain = (int)blockIdx.x < nchain;
+  if (!chain && (int)blockIdx.x - nchain >= units) {
+    const FclJob *jp = jobs + ((int)blockIdx.x - nchain - units);
+    const int hd = jp->hd;
+    fcl_dw_job<FCL_NW, 1, 4, 4, true, true>(jp, 0, a, fcl_smem, v.flags + (size_t)2 * G * K1 + 32 * (1 + hd), (unsigned)(G * (hd == 2 ? v.K : K1)), v.err);      // (a 128-byte line per head's counter)
+    if (v.prof && threadIdx.x == 0) atomicMax(v.prof + 64, (unsigned long long)__builtin_amdgcn_s_memrealtime());      // (development: the last job's end)
+    return;
+  }
+  if (chain) {
     // (the optimiser's step counters advance here, written through by a storing wave of chain workgroup 0 -- drained before its first signal)
     if (blockIdx.x == 0 && (int)threadIdx.x >= 256 && (int)threadIdx.x < 256 + v.nsteps)
       fcl_store_wt(v.steps + (threadIdx.x - 256), v.steps[threadIdx.x - 256] + 1.f);
     fcl_chain_fwd4_body<KP, true, 1>(v, blockIdx.x, fcl_smem);
+  }
+  // the backward pass's resident weights: requested behind the unit's own first loads, in registers through the unit (the heads code
+  // leaves them room)
+  auto preload = [&]() __attribute__((always_inline)) {
+    if (chain) {
+      const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+      fcl_quad_load<MZ_H>(WB2, v.pk + v.tr.B2 + (size_t)w * MZ_H * 64, lane);
+      fcl_quad_load<64>(WB1, v.pk + v.tr.B1 + (size_t)w * 64 * 64, lane);
+    }
+  };
+  const bool own = chain && (blockIdx.x & 3) < 3;          // chain workgroup j < 3 of its sample group: head j of position K
+  if (!own && threadIdx.x == 0) s_unit = (int)__hip_atomic_fetch_add(v.flags + (size_t)2 * G * K1 + 32 * 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  int u = own ? 0 : s_unit;
+  if (u < units) {
+    int p = v.K, hd = (int)(blockIdx.x & 3), cb = (int)(blockIdx.x >> 2);
+    if (!own) {        // position by position: 2 G units at position 0 (no reward head), 3 G at the others; value, policy, then reward
+      p = 0;
+      if (u >= 2 * G) { u -= 2 * G; p = 1 + u / (3 * G); u -= (p - 1) * 3 * G; }
+      hd = u / G; cb = u - hd * G;
+    }
+    fcl_heads_body<true, true>(v, cb, p, hd, fcl_smem, preload);
+  } else preload();
+  if (v.prof && !chain && threadIdx.x == 0) atomicMax(v.prof + 65, (unsigned long long)__builtin_amdgcn_s_memrealtime());      // (the last unit's end)
+  if (chain) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this workgroup's own tapes (a1c, xhat, rstd: plain stores) are read back below
     fcl_bar();
-    fcl_chain_bwd4_body<1, true>(v, blockIdx.x, fcl_smem);
-    return;
+    fcl_chain_bwd4_core<1, true, true>(v, blockIdx.x, fcl_smem, WB2, WB1);
   }
-  int u = (int)blockIdx.x - nchain;
-  if (u >= units) {
-    const FclJob *jp = jobs + (u - units);
-    const int hd = jp->hd;
-    fcl_dw_job<FCL_NW, 1, 4, 4, true, true>(jp, 0, a, fcl_smem, v.flags + (size_t)2 * G * K1 + 32 * (1 + hd), (unsigned)(G * (hd == 2 ? v.K : K1)), v.err);      // (a 128-byte line per head's counter)
-    return;
-  }
-  int slot = 0;
-  for (;;) {          // the unit's place in the dispatch order: slot-th position of v.order, 2 G units at position 0 (no reward head), else 3 G
-    const int n = (v.order[slot] == 0 ? 2 : 3) * G;
-    if (u < n) break;
-    u -= n; ++slot;
-  }
-  const int p = v.order[slot], hd = u / G;      // (value, policy, then reward: the reward unit's counter is position p - 1's, asked for one position later)
-  fcl_heads_body<true, true>(v, u % G, p, hd, fcl_smem);
 }
 
 // the fused step's LAST launch (batch <= 512): the chain layers' weight-gradient jobs as 16 x 32 tiles, one slab, Adam in the
@@ -1347,6 +1387,7 @@ __global__ __launch_bounds__(FCL_THREADS, MINW) void k_fcl_dwa(const FclJob *job
     const int k = threadIdx.x;
     if (k == 2 * MZ_H) fcl_bias_corr(a, fcl_smem);
     float g = 0.f, pv = 0.f, ea = 0.f, es = 0.f;
+    const float lr_pre = a.fuse ? *a.lr_p : 0.f;
     int pa = -1, pb = -1;
     const size_t i = ln_w + (size_t)(k < 2 * MZ_H ? k : 0);
     if (k < 2 * MZ_H) {
@@ -1355,7 +1396,7 @@ __global__ __launch_bounds__(FCL_THREADS, MINW) void k_fcl_dwa(const FclJob *job
       a.grad[i] = g;
     }
     __syncthreads();
-    if (k < 2 * MZ_H && a.fuse) fcl_adam_elem(a, i, g, pv, ea, es, pa, pb, fcl_smem[0], fcl_smem[1], (double)*a.lr_p);
+    if (k < 2 * MZ_H && a.fuse) fcl_adam_elem(a, i, g, pv, ea, es, pa, pb, fcl_smem[0], fcl_smem[1], (double)lr_pre);
     return;
   }
   fcl_loss_block(lossb, w, w_f64, bs, K1, loss_acc, (double *)fcl_smem);

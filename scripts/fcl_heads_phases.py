@@ -18,7 +18,7 @@ N = 20
 for _ in range(N):
   ls.loop(learner, replay, 3)
   torch.cuda.synchronize()
-  buf = np.zeros(64, np.uint64)
+  buf = np.zeros(96, np.uint64)
   _abi.check(lib.mz_fcl_heads_profile(h, 0, buf.ctypes.data_as(C.c_void_p)), 'read')
   st = buf[:48].reshape(3, 16).astype(np.float64)
   acc += np.diff(st[:, :12], axis=1) / 100.0
@@ -31,6 +31,8 @@ if tl[0] > 0:      # the fused forward launch's timeline (constant 100 MHz clock
 if buf[12] > 0 and tl[0] > 0:      # k_fcl_fb: the backward pass of chain workgroup 0 on the same clock
   print('one-launch forward + backward: chain workgroup 0 has the last position\'s d hidden at %.2f us, ends its backward pass at %.2f us; '
         'later positions it had to poll for (all samples): %d' % ((float(buf[12]) - tl[0]) / 100.0, (float(buf[13]) - tl[0]) / 100.0, int(buf[14])))
+  print('  the value unit of group 0 at position K - 1: starts at %.2f, is past its wait at %.2f, ends at %.2f us' % tuple((float(buf[k]) - tl[0]) / 100.0 for k in (45, 46, 47)))
+  print('  last heads unit ends at %.2f us, last weight-gradient job at %.2f, last chain workgroup at %.2f' % tuple((float(buf[k]) - tl[0]) / 100.0 for k in (65, 64, 66)))
   arr = [float(buf[k]) for k in (15, 28, 29, 30, 31, 44)]
   print('  positions\' d hidden in hand at (us): ' + ', '.join('p%d %.2f' % (q, (arr[q] - tl[0]) / 100.0) for q in range(5, -1, -1) if arr[q] > 0))
 acc /= N
