@@ -1366,24 +1366,24 @@ __global__ __launch_bounds__(FCL_THREADS) void k_fcl_fb(FclView v, int nchain, c
 // zeroes the hand-off counters for the next step -- the launch that used them has ended)
 // (NFJ, MINW: tape loads in flight per wave and the register budget -- <4, 2>: 217 registers, one workgroup per CU (the chain layers' 224 jobs
 // fit the chip); <2, 4>: 128 registers, two per CU, for the launch that carries all 392 jobs)
+// (done_ctr / done_flag / seq: the native loop's completion word -- the workgroup that ends LAST (a device counter every workgroup adds to
+// when it is done; that workgroup zeroes it again) stores `seq` into the update's pinned host word, system scope: every read of the
+// update's staging slot and every store of its results lies before it.  The loop polls that word instead of recording an event behind
+// every update: an event record between two updates cost 3.4 us of the GPU's timeline)
 template <int NFJ, int MINW>
 __global__ __launch_bounds__(FCL_THREADS, MINW) void k_fcl_dwa(const FclJob *jobs, int njobs, FclDw a, int tail, const float *lnpart, int nwg,
                                                                   size_t ln_w, const float *lossb, const void *w, int w_f64, int bs, int K1,
-                                                                  double *loss_acc, int nheads, unsigned *flags, int nflags) {
+                                                                  double *loss_acc, int nheads, unsigned *flags, int nflags,
+                                                                  unsigned *done_ctr, unsigned *done_flag, unsigned seq) {
   extern __shared__ __attribute__((aligned(16))) float fcl_smem[];
   const int b = blockIdx.x;
   if (b == 0 && flags)
     for (int i = threadIdx.x; i < nflags; i += FCL_THREADS) flags[i] = 0u;
   if (b < nheads) {
     fcl_dw_job<FCL_NW, 1, 4, NFJ, true>(jobs + b, 0, a, fcl_smem);
-    return;
-  }
-  if (b < njobs) {
+  } else if (b < njobs) {
     fcl_dw_job<FCL_NW, 1, 2, NFJ, true>(jobs + b, 0, a, fcl_smem);
-    return;
-  }
-  if (!tail) return;
-  if (b == njobs) {
+  } else if (tail && b == njobs) {
     const int k = threadIdx.x;
     if (k == 2 * MZ_H) fcl_bias_corr(a, fcl_smem);
     float g = 0.f, pv = 0.f, ea = 0.f, es = 0.f;
@@ -1397,9 +1397,20 @@ __global__ __launch_bounds__(FCL_THREADS, MINW) void k_fcl_dwa(const FclJob *job
     }
     __syncthreads();
     if (k < 2 * MZ_H && a.fuse) fcl_adam_elem(a, i, g, pv, ea, es, pa, pb, fcl_smem[0], fcl_smem[1], (double)lr_pre);
-    return;
+  } else if (tail) {
+    fcl_loss_block(lossb, w, w_f64, bs, K1, loss_acc, (double *)fcl_smem);
   }
-  fcl_loss_block(lossb, w, w_f64, bs, K1, loss_acc, (double *)fcl_smem);
+  if (done_flag) {
+    __syncthreads();      // (every thread's loads of the staging slot have returned, its stores have been issued)
+    // (no fence: the word says that the staging slot has been READ -- the barrier above has every load back -- and that the launch
+    // BEFORE this one, which stored the new errors into pinned memory, has ended; agent-scope release / acquire fences here cost 9 us)
+    if (threadIdx.x == 0) {
+      if (__hip_atomic_fetch_add(done_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+        __hip_atomic_store(done_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(done_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
 }
 
 // larger batches: every (job, row slab) is a workgroup of four waves; a job's tile is 16 NA rows x 64 columns, NA = the job's

@@ -265,7 +265,7 @@ class _NativeFC(object):
     _abi.check(self.lib.mz_fcl_step(self.h, ptr(obs), ptr(act), int(act.dtype == torch.int32), ptr(t_rew), ptr(t_val), ptr(t_pol), ptr(w), int(w.dtype == torch.float64),
                                     float(b1), float(b2), float(g['eps']), float(g['weight_decay']), float(getattr(cfg, 'clip_grad', 0) or 0),
                                     int(isinstance(self.learner.optimizer, torch.optim.AdamW)), int(bool(no_update)), ptr(new_errors),
-                                    ptr(self.learner._loss_dev), _stream_ptr(obs)), 'mz_fcl_step')
+                                    ptr(self.learner._loss_dev), _stream_ptr(self.flat)), 'mz_fcl_step')
     return new_errors
 
   def launch(self, host):

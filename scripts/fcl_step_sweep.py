@@ -42,6 +42,8 @@ def measure(bs, steps, shape='lunar', K=5, extra=()):
   learner = Learner(cfg, sink, sink)
   host = batch_of(np.random.default_rng(bs), bs, K, O, A)
   dev = [torch.from_numpy(host[k]).to(learner.device) for k in _GraphedUpdate.ORDER]
+  if os.environ.get('MZ_SWEEP_PINNED', '0')[:1] == '1':      # the batch in pinned host memory, read by the kernels over PCIe (what mz_fcl_run does)
+    dev = [torch.from_numpy(host[k]).pin_memory() for k in _GraphedUpdate.ORDER]
   nat = _NativeFC(learner, host)
   for _ in range(10):
     nat.step(*dev)
@@ -49,8 +51,10 @@ def measure(bs, steps, shape='lunar', K=5, extra=()):
   best = None
   for _ in range(3):
     torch.cuda.synchronize(); e0.record()
-    for _ in range(steps):
+    evs = [torch.cuda.Event() for _ in range(6)] if os.environ.get('MZ_SWEEP_EVENTS', '0')[:1] == '1' else None      # (an event record behind every step, as mz_fcl_run has)
+    for i in range(steps):
       nat.step(*dev)
+      if evs: evs[i % 6].record()
     e1.record(); torch.cuda.synchronize()
     us = 1e3 * e0.elapsed_time(e1) / steps
     best = us if best is None else min(best, us)
