@@ -1,19 +1,23 @@
 // mz_fcl.hip.h -- the FCNetwork learner step (reference learners.py:164-230, networks.py:135-180, config.py:27-33,51-68,
 // utils.py:53-60): the whole update -- K-step unroll forward, the three heads' losses, backward, clipping, AdamW -- without a
 // GEMM library or an autograd tape.  The step is ~1.4 GFLOP (batch 256, K = 5): as PyTorch operators it is ~220 kernels of
-// ~4 us of launch floor each; here its shape follows the data dependences.  THREE launches at the reference's batch 256:
+// ~4 us of launch floor each; here its shape follows the data dependences.  TWO launches at the reference's batch 256:
 //
-//   k_fcl_fwd      chain workgroups (4 samples each: h_0 = representation(obs), h_p = dynamics(h_{p-1}, a_{p-1}) -- the only
+//   k_fcl_fb       chain workgroups (4 samples each: h_0 = representation(obs), h_p = dynamics(h_{p-1}, a_{p-1}) -- the only
 //                  sequential part -- on v_mfma_f32_4x4x1_16b_f32: 64 output rows x 4 samples per instruction, the transition's
-//                  weights resident in registers across positions, activations in LDS) AND every heads unit (16 samples = the
+//                  weights resident in registers across positions, activations in LDS), every heads unit (16 samples = the
 //                  16 columns of v_mfma_f32_16x16x4_f32, one unroll position, one head: value / policy / reward head forward,
-//                  two-hot targets, soft cross-entropy, the head's backward down to d loss / d hidden state).  A unit starts
-//                  when its sample group's chain workgroups have announced its position (write-through tapes + an arrival
-//                  counter): the heads of positions 0 .. K - 1 run on the CUs the chain leaves idle while it computes on
-//   k_fcl_bwd_dw   the chain backwards (gradient hooks 0.5, LayerNorm, ReLU; 4 samples per workgroup) AND the heads' weight-
-//                  gradient jobs on the CUs it leaves idle
-//   k_fcl_dwa      the chain layers' weight-gradient jobs + the LayerNorm parameters + the loss sums
+//                  two-hot targets, soft cross-entropy, the head's backward down to d loss / d hidden state), the chain BACKWARDS
+//                  in the same workgroups (gradient hooks 0.5, LayerNorm, ReLU) and the heads' weight-gradient jobs -- handing
+//                  over inside the launch through write-through tapes and counters (see "in-launch hand-off"): a unit starts when
+//                  its sample group's chain workgroups have announced its position; a chain workgroup that has finished its
+//                  forward pass runs one of position K's units itself (or takes a queued one), then walks backwards as the units
+//                  of each position announce their d loss / d hidden; a head's jobs start when all its units have finished
+//   k_fcl_dwa      the chain layers' weight-gradient jobs + the LayerNorm parameters + the loss sums (+ the native loop's
+//                  completion word)
 //
+// (MZ_FCL_FUSE_FB=0: three launches -- k_fcl_fwd: chain + units; k_fcl_bwd_dw: backward chain + the heads' jobs; k_fcl_dwa.
+// MZ_FCL_FUSE_FWD=0: four -- the structure of batch 512.  The same arithmetic in the same order: tests hold the three to equal bits.)
 // A weight-gradient job = one tile of a layer's dW = sum_rows delta (x) input over EVERY unroll position the layer is applied at
 // (MFMA strips over the activation / delta tapes in HBM, summed in a fixed order: deterministic, no atomics); with one row slab
 // the tile is the gradient, and Adam / AdamW on exactly those weights (torch's fused-kernel arithmetic; the new weights into the
@@ -187,12 +191,20 @@ __device__ __forceinline__ float fcl_two_hot_at(const FclTwoHot &t, int s) {
   return v;
 }
 
-// ------------------------------------------------------------------------------------------------ in-launch hand-off (k_fcl_fwd)
-// The forward chain hands a position's hidden states to the heads' units of the SAME launch (MI355X_MICROARCH.md, inter-workgroup
-// visibility, first row of the table of forms measured without an acquire): the producer's stores of the handed-off bytes are
-// write-through (sc1: relaxed agent-scope atomic stores), every storing wave waits for them (s_waitcnt vmcnt(0)), a workgroup
-// barrier, then ONE lane adds to the counter (agent scope); the consumer polls the counter with sc1 loads in one lane (bounded),
-// a workgroup barrier, then EVERY load of the handed-off bytes is an sc1 load.
+// ------------------------------------------------------------------------------------------------ in-launch hand-off (k_fcl_fwd, k_fcl_fb)
+// Workgroups of ONE launch hand data to each other (MI355X_MICROARCH.md, inter-workgroup visibility, first row of the table of forms
+// measured without an acquire): the producer's stores of the handed-off bytes are write-through (sc1: relaxed agent-scope atomic
+// stores), every storing wave waits for them (s_waitcnt vmcnt(0)), a workgroup barrier, then ONE lane adds to the counter (agent
+// scope); the consumer polls the counter with sc1 loads in one lane (bounded), a workgroup barrier (or: the polling wave itself is
+// the only reader), then EVERY load of the handed-off bytes is an sc1 load (4 bytes: relaxed agent-scope atomic loads; 16 bytes:
+// buffer loads with the sc1 bit).  The hand-offs, counters in FclView::flags (zeroed by the step's last launch):
+//   chain forward  -> heads units     hidden states / transition inputs of (sample group, position); counter [group][position] = 4
+//   heads units    -> chain backward  d loss / d hidden of (group, position); counter [G K1 + group][position] = 3 (2 at position K)
+//   heads units    -> the head's jobs the unit's tapes (fc1 activations, both deltas); one counter per head = its number of units
+//   chain forward  -> the heads' jobs (hidden states / transition inputs: covered by the units' counters -- a unit has waited for them)
+//   chain workgroup 0 -> the jobs     the optimiser's step counter, stored before its first signal
+// Every wait depends only on workgroups dispatched EARLIER in the grid (chain, units, jobs, in this order), and the chain's forward
+// passes wait for nothing: the launch ends on any device with CUs left beside the chain workgroups (the handle asks for twice as many CUs).
 __device__ __forceinline__ void fcl_store_wt(float *p, float x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float fcl_load_wt(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void fcl_signal(unsigned *flag) { __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -1057,7 +1069,10 @@ __device__ __forceinline__ void fcl_bias_corr(const FclDw &a, float *dst) {
 // WT: a job of k_fcl_fb -- its tapes were written (through) by heads units and chain workgroups of the SAME launch: the job has its
 // optimiser operands requested, then one lane waits for the head's counter of finished units (`wait_flag` >= `wait_for`), a barrier, and
 // every tape load is an sc1 load (buffer loads: 16 bytes per lane as before)
-template <int NW, int NA, int NI, int NF, bool FUSABLE, bool WT = false>
+// ONEBUF: ONE register set of NF units per wave -- where NF x NW covers the job's units (the chain layers' jobs of the step's last launch:
+// 80 units, NF = 10) every tape load of the job is requested before its first MFMA: one round trip to HBM (the chain's deltas were written
+// by other XCDs in the launch before) instead of three
+template <int NW, int NA, int NI, int NF, bool FUSABLE, bool WT = false, bool ONEBUF = false>
 __device__ __forceinline__ void fcl_dw_job(const FclJob *jp, int slab, const FclDw &a, float *sh, const unsigned *wait_flag = nullptr,
                                            unsigned wait_for = 0u, unsigned *err = nullptr) {
   constexpr int Q = FCL_DW_Q(NA, NI);
@@ -1163,7 +1178,13 @@ __device__ __forceinline__ void fcl_dw_job(const FclJob *jp, int slab, const Fcl
       sh[NW * Q * 64 + 1] = (float)(1.0 - pow(a.o.beta2, step));
     }
   }
-  if (w < U) {
+  if constexpr (ONEBUF) {
+    f32x4 avA[NF][NA], bvA[NF][NI];
+    for (int u0 = w; u0 < U; u0 += NF * NW) {
+      load(avA, bvA, u0);
+      comp(avA, bvA, u0);
+    }
+  } else if (w < U) {
     f32x4 avA[NF][NA], bvA[NF][NI], avB[NF][NA], bvB[NF][NI];
     int u0 = w;
     load(avA, bvA, u0);
@@ -1380,9 +1401,9 @@ __global__ __launch_bounds__(FCL_THREADS, MINW) void k_fcl_dwa(const FclJob *job
   if (b == 0 && flags)
     for (int i = threadIdx.x; i < nflags; i += FCL_THREADS) flags[i] = 0u;
   if (b < nheads) {
-    fcl_dw_job<FCL_NW, 1, 4, NFJ, true>(jobs + b, 0, a, fcl_smem);
+    fcl_dw_job<FCL_NW, 1, 4, 4, true>(jobs + b, 0, a, fcl_smem);
   } else if (b < njobs) {
-    fcl_dw_job<FCL_NW, 1, 2, NFJ, true>(jobs + b, 0, a, fcl_smem);
+    fcl_dw_job<FCL_NW, 1, 2, NFJ, true, false, (NFJ > 4)>(jobs + b, 0, a, fcl_smem);
   } else if (tail && b == njobs) {
     const int k = threadIdx.x;
     if (k == 2 * MZ_H) fcl_bias_corr(a, fcl_smem);
