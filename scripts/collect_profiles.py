@@ -23,6 +23,7 @@ names = {
     'bench_8ranks_fullsize_1gpu_%s.json': '%s_bench_8ranks_fullsize_1gpu.json', 'host_threads_%s.txt': '%s_host_threads.txt',
     'one_replay_shapes_%s.txt': '%s_one_replay_shapes.txt', 'learner_step_sweep_%s.json': '%s_learner_step_sweep.json',
     'learner_step_kernels_256_%s.csv': '%s_learner_step_kernels_256.csv', 'learner_step_kernels_2048_%s.csv': '%s_learner_step_kernels_2048.csv',
+    'learner_timeline_%s.txt': '%s_learner_timeline.txt',
 }
 # the product's own entry point (train --selfplay_only): its summary line as JSON
 ts = os.path.join(G, 'train_selfplay_%s.txt' % tag)
