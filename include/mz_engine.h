@@ -293,7 +293,7 @@ int mz_soft_ce_forward(const float *logits, const float *target, int positions, 
                        int64_t target_row_stride, float *loss, void *stream);
 int mz_soft_ce_backward(const float *logits, const float *target, const float *grad_loss, int positions, int bs, int bins,
                         int64_t target_pos_stride, int64_t target_row_stride, float *grad_logits, void *stream);
-/* ---- The FCNetwork learner step as five launches, six with gradient clipping (csrc/mz_fcl.hip.h): reference learners.py:164-230 (update_weights: K-step
+/* ---- The FCNetwork learner step as two launches at batches up to 256 (four at 512, five to six above or with gradient clipping; csrc/mz_fcl.hip.h): reference learners.py:164-230 (update_weights: K-step
  * unroll, categorical targets, soft cross-entropy, gradient hooks 0.5 and 1 / K, importance weights, clip_grad_norm_,
  * optimizer.step) with networks.py:135-180 (FCNetwork), config.py:27-33,51-68, utils.py:53-60,73-83 (Adam / AdamW,
  * eps 1.5e-4).  No GEMM library, no autograd tape: forward chain, heads + losses + their backward, backward chain, weight

@@ -4,8 +4,8 @@ recurrent steps, 0.5 gradient scale on the hidden state per step (learners.py:20
 cross-entropy losses on the categorical supports, 1/K gradient scale on the total loss (214), AdamW with eps 1.5e-4
 (utils.py:85-97).
 
-On a GPU, for FCNetwork with Adam / AdamW and categorical losses, the whole update is `mz_fcl_update` (_NativeFC): five
-hand-written HIP launches (csrc/mz_fcl.hip.h) straight from the host batch -- no PyTorch operator, no autograd tape, no graph
+On a GPU, for FCNetwork with Adam / AdamW and categorical losses, the whole update is `mz_fcl_update` (_NativeFC): two
+hand-written HIP launches at the reference's batch 256 (csrc/mz_fcl.hip.h) straight from the host batch -- no PyTorch operator, no autograd tape, no graph
 to capture; the parameters and the optimiser's state are views of the flat vectors those kernels update.  Every other case
 (MuZeroNetwork / TinyNetwork, scalar losses, other optimisers, `--no_native_learner`) runs the same step as PyTorch
 operators, captured in ONE hipGraph per update (stock `torch.cuda.CUDAGraph`: static batch tensors, capturable optimiser);
@@ -170,8 +170,8 @@ class _SoftCE(torch.autograd.Function):
 
 
 class _NativeFC(object):
-  """The FCNetwork update as the HIP launches of csrc/mz_fcl.hip.h (mz_fcl_step, include/mz_engine.h; three at batch 256): forward
-  chain + heads (losses, their backward), backward chain + the heads' weight gradients, the chain's weight gradients -- each strip
+  """The FCNetwork update as the HIP launches of csrc/mz_fcl.hip.h (mz_fcl_step, include/mz_engine.h; two at batch 256): forward
+  chain + heads (losses, their backward) + backward chain + the heads' weight gradients handing over inside one launch, the chain's weight gradients -- each strip
   followed by Adam / AdamW on its weights in the same workgroup -- no GEMM library, no
   autograd tape, nothing PyTorch launches.  The network's parameters and the optimiser's exp_avg / exp_avg_sq / step
   tensors become VIEWS of three flat device vectors (engine.WEIGHT_ORDER) the kernels update in place, so state_dicts,
