@@ -29,7 +29,11 @@ def sweep_point(bs, updates, runs=3):
   """one batch size of the sweep, through the product's loop: Learner.launch(updates) on the handles train.launch builds (native step
   + native loop); GPU time per update from HIP events around 100+ updates of mz_fcl_run; host microseconds per update inside the call"""
   from model_based_rl_amd import rayshim as ray
-  cfg, storage, replay, learner = setup(['--batch_size', str(bs)])
+  # the replay's threads (the product's --ingest_threads; its default of 4 is sized for the reference's batch 256): from batch 1024 the
+  # sampling and the priority refresh of a batch are most of the loop's host time, and the point is run with up to 8
+  from model_based_rl_amd.distributed import usable_cores
+  threads = ['--ingest_threads', str(max(4, min(8, usable_cores() - 2)))] if bs >= 1024 else []
+  cfg, storage, replay, learner = setup(['--batch_size', str(bs)] + threads)
   ray.get(learner.launch.remote(30))
   vals = []
   for _ in range(max(1, runs)):
@@ -162,11 +166,11 @@ def main(args):
                      'native_loop': n['native_loop'], 'native_loop_host_us_per_update': n['native_loop_host_us_per_update'],
                      'runs': '%d x %d updates: mean +- std' % (len(n['runs']), updates)},
           'runs': {'mean': n['updates_per_second'], 'std': n['std'], 'values': n['runs']},
-          'roofline': {'bound': 'mfma', 'kernel': 'mz_fcl_run / mz_fcl_update (k_fcl_fwd, k_fcl_bwd_dw, k_fcl_dwa at batch <= 256)',
+          'roofline': {'bound': 'mfma', 'kernel': 'mz_fcl_run / mz_fcl_update (k_fcl_fb, k_fcl_dwa at batch <= 256)',
                        'achieved': achieved, 'peak': F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / F32_MFMA_TFLOPS, 'traffic': None,
                        'flop_per_update': flop, 'us_per_update': us,
                        'us_per_update_single_calls': 1e3 * n['gpu_ms_per_update'],
-                       'note': 'latency-bound: dependent phases of a few microseconds (three launches per update at batch 256); us_per_update = HIP events around '
+                       'note': 'latency-bound: dependent phases of a few microseconds (two launches per update at batch 256); us_per_update = HIP events around '
                                '300 updates of the native loop (mz_fcl_run), us_per_update_single_calls = the same step driven one mz_fcl_update call '
                                'at a time (pinned staging + two copies)'},
           'torch_graph': {k: out['torch_graph'][k] for k in ('updates_per_second', 'std', 'gpu_ms_per_update')},
