@@ -298,6 +298,15 @@ __device__ __forceinline__ float fcl_sum32(float x) {
   x += fcl_xchg<1>(x); x += fcl_xchg<2>(x); x += fcl_xchg<4>(x); x += fcl_xchg<8>(x);
   return x + __shfl_xor(x, 16, 32);
 }
+// sum over the 64 lanes of a wave: the four DPP rows' sums (four exchanges each), read out of a lane of each row and added in a fixed
+// order -- no LDS round trip; every lane ends with the same bits
+__device__ __forceinline__ float fcl_sum16(float x);
+__device__ __forceinline__ float fcl_sum64(float x) {
+  x = fcl_sum16(x);
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 48));
+  return (r0 + r1) + (r2 + r3);
+}
 // sum over the 16 lanes of a DPP row (no LDS round trip); every lane of the row ends with the same bits
 __device__ __forceinline__ float fcl_sum16(float x) {
   x += fcl_xchg<1>(x); x += fcl_xchg<2>(x); x += fcl_xchg<4>(x); x += fcl_xchg<8>(x);
@@ -660,7 +669,12 @@ __device__ __forceinline__ void fcl_chain_fwd4_body(const FclView &v, const int 
     // what the LayerNorm wave needs besides the partials, requested in front of the barrier it waits at
     f32x4 lb2 = (f32x4){0.f, 0.f, 0.f, 0.f}, llw = lb2, llb = lb2;
     int act_p = -1;
-    if (w < G) {
+    if constexpr (G == 1) {
+      if (w < 4) {        // (one sample per wave, lane = feature: see below)
+        lb2[0] = b2[lane]; llw[0] = lnw[lane]; llb[0] = lnb[lane];
+        act_p = acts[w * 8 + (p < 7 ? p : 7)];
+      }
+    } else if (w < G) {
       const int f0 = 4 * (lane & 15);
       lb2 = *(const f32x4 *)(b2 + f0); llw = *(const f32x4 *)(lnw + f0); llb = *(const f32x4 *)(lnb + f0);
       act_p = acts[(4 * w + (lane >> 4)) * 8 + (p < 7 ? p : 7)];
@@ -678,7 +692,27 @@ __device__ __forceinline__ void fcl_chain_fwd4_body(const FclView &v, const int 
       if (p > 0 && tid == 0) fcl_signal(v.flags + (size_t)cb * (v.K + 1) + (p - 1));
     }
     FCL_CSTAMP(3)      // fc2 partials + barrier
-    if (w < G) {
+    if constexpr (G == 1) {
+      // ONE group of four samples: waves 0 .. 3 take one sample each, lane = feature -- a quarter of the per-lane work of the one-wave form
+      // below, and the four samples' divisions and square roots side by side on four SIMDs (the one wave was 1.0 k of a position's 4.7 k
+      // cycles with the other seven waiting); the reductions run over the wave's 64 lanes (fcl_sum64)
+      if (w < 4) {
+        float y = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < FCL_NW; ++ww) y += red[ww * 256 + fcl_red_slot(w, lane >> 2) * 4 + (lane & 3)];      // (row `lane` of sample w: written by lane 4 b + w, register lane & 3)
+        const bool real = lane < MZ_H;
+        const float yv = real ? y + lb2[0] : 0.f;
+        const float mean = fcl_sum64(yv) / (float)MZ_H;
+        const float d = real ? yv - mean : 0.f;
+        const float rstd = 1.0f / sqrtf(fcl_sum64(d * d) / (float)MZ_H + FCL_LN_EPS);
+        const float xh = d * rstd;
+        const float hv = real ? fmaxf(xh * llw[0] + llb[0], 0.f) : 0.f;
+        // the next input: [h | one-hot(action) | 0]  (networks.py:167-174); past the last transition: no action
+        X[w * LDX + lane] = real ? hv : ((p < v.K && lane - MZ_H == act_p) ? 1.f : 0.f);
+        S[w * 64 + lane] = xh;
+        if (lane == 0) misc[w] = rstd;
+      }
+    } else if (w < G) {
       // wave g alone for group g: lane (j, b) = (lane >> 4, lane & 15) adds up rows 4 b + i of sample j of the 8 partials (written by
       // lane 4 b + j of each wave into slot fcl_red_slot(j, b): both sides touch 16 different 16-byte slots per 16 lanes), then
       // LayerNorm + ReLU (networks.py:147,165) of sample j across ITS DPP ROW -- the two reductions are four DPP exchanges each, no
