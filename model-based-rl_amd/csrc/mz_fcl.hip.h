@@ -909,6 +909,15 @@ __device__ __forceinline__ void fcl_chain_bwd4_core(const FclView &v, const int 
   }
   if (tid < 64) lnw[tid] = plnw;
   fcl_bar();
+  f32x4 mskn[G];
+  auto mask_request = [&](int p) __attribute__((always_inline)) {
+    const float *a1t = v.a1c + (size_t)p * T512 + fcl_tp(512, cb, 64 * w, 0);
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) mskn[g][i] = ld((a1t + i * 16) + fcl_lane_off4(lane, n0 + 4 * g));
+  };
+  mask_request(v.K);
   auto body = [&](int p, const float (&W2)[MZ_H]) __attribute__((always_inline)) {
     unsigned fl = 0u;
     if constexpr (WAITD) {
@@ -939,12 +948,11 @@ __device__ __forceinline__ void fcl_chain_bwd4_core(const FclView &v, const int 
       *(f32x4 *)(D2 + sj * LDX + f0) = dy;
     }
     if (p > 0) { arrived(p - 1, fl); request(p - 1); }
-    const float *a1t = v.a1c + (size_t)p * T512 + fcl_tp(512, cb, 64 * w, 0);
+    // (this position's fc1 activations -- the ReLU mask -- were requested one position ago: asked for here, in front of the barrier, they
+    // were a round trip to L2 that the 400 cycles of fc2-transposed MFMAs did not cover)
     f32x4 msk[G];
 #pragma unroll
-    for (int g = 0; g < G; ++g)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) msk[g][i] = ld((a1t + i * 16) + fcl_lane_off4(lane, n0 + 4 * g));
+    for (int g = 0; g < G; ++g) msk[g] = mskn[g];
     fcl_bar();
     if (tid >= 256) {      // the delta tape of this position, by the upper half of the workgroup (D2 is next written behind the next barrier)
       const int t = tid - 256;
@@ -965,6 +973,7 @@ __device__ __forceinline__ void fcl_chain_bwd4_core(const FclView &v, const int 
       }
       *(f32x4 *)(A1 + (4 * g + (lane & 3)) * FCL_LDA + g0) = d;
     }
+    if (p > 0) mask_request(p - 1);
     // (no barrier: wave w's split-K slice of the fc1-transposed product is features [64 w, 64 w + 64) of A1, its own writes)
     if (p >= 1) {
 #pragma unroll
