@@ -29,11 +29,7 @@ def sweep_point(bs, updates, runs=3):
   """one batch size of the sweep, through the product's loop: Learner.launch(updates) on the handles train.launch builds (native step
   + native loop); GPU time per update from HIP events around 100+ updates of mz_fcl_run; host microseconds per update inside the call"""
   from model_based_rl_amd import rayshim as ray
-  # the replay's threads (the product's --ingest_threads; its default of 4 is sized for the reference's batch 256): from batch 1024 the
-  # sampling and the priority refresh of a batch are most of the loop's host time, and the point is run with up to 8
-  from model_based_rl_amd.distributed import usable_cores
-  threads = ['--ingest_threads', str(max(4, min(8, usable_cores() - 2)))] if bs >= 1024 else []
-  cfg, storage, replay, learner = setup(['--batch_size', str(bs)] + threads)
+  cfg, storage, replay, learner = setup(['--batch_size', str(bs)])      # (the replay's threads: the product's default, 8 from batch 1024 up)
   ray.get(learner.launch.remote(30))
   vals = []
   for _ in range(max(1, runs)):

@@ -69,7 +69,7 @@ def build_parser():
   a('--num_envs', type=int, default=4096, help='environments searched in lock-step by one GPU actor')
   a('--episode_length', type=int, default=256, help='synthetic fixed-length episodes (gym is not installed)')
   a('--ingest_threads', type=int, default=None,
-    help='threads the native replay splits the environments of a record chunk over (default: 4, bounded by the CPUs)')
+    help='threads of the native replay: environments of a record chunk, the samples of a batch, a large priority refresh (default: 4, 8 from batch size 1024 up, bounded by the CPUs)')
   a('--max_steps', type=int, default=40000)
   a('--num_simulations', type=int, default=30)
   a('--max_history_length', type=int, default=500)

@@ -90,16 +90,15 @@ class SumTree(object):
 
 
 def default_ingest_threads(config=None):
-  """--ingest_threads, else 4 bounded by the CPUs this process may run on (one is left to the launching thread)"""
-  import os
+  """--ingest_threads, else 4 -- 8 from batch size 1024 up, where sampling a batch and refreshing its priorities (both dealt to these
+  threads) are most of the learner loop's host time -- bounded by the CPUs this process may use (affinity mask and cgroup quota; one is
+  left to the launching thread)"""
   n = getattr(config, 'ingest_threads', None)
   if n:
     return max(1, int(n))
-  try:
-    cpus = len(os.sched_getaffinity(0))
-  except AttributeError:
-    cpus = os.cpu_count() or 1
-  return max(1, min(4, cpus - 1))
+  from .distributed import usable_cores
+  want = 8 if int(getattr(config, 'batch_size', 0) or 0) >= 1024 else 4
+  return max(1, min(want, usable_cores() - 1))
 
 
 def native_config(config):

@@ -234,3 +234,16 @@ def test_chunk_schedule_and_vectorised_game_statistics():
       assert x[0] == y[0] and x[1] == y[1] and abs(x[2] - y[2]) <= 1e-9 * (1 + abs(x[2])), (x, y)
     for k in a._game_stats:
       assert np.allclose(a._game_stats[k], b._game_stats[k], rtol=1e-12, atol=1e-12), k
+
+
+def test_replay_threads_default_follows_the_batch_size():
+  """replay_buffer.default_ingest_threads: --ingest_threads wins; else 4, and 8 from batch size 1024 up (sampling and the priority
+  refresh of such a batch are dealt to the replay's threads: the learner loop's host side), never more than the usable cores less one"""
+  import types
+  from model_based_rl_amd.replay_buffer import default_ingest_threads
+  from model_based_rl_amd.distributed import usable_cores
+  cap = max(1, usable_cores() - 1)
+  assert default_ingest_threads(types.SimpleNamespace(ingest_threads=3, batch_size=4096)) == 3
+  assert default_ingest_threads(types.SimpleNamespace(ingest_threads=None, batch_size=256)) == min(4, cap)
+  assert default_ingest_threads(types.SimpleNamespace(ingest_threads=None, batch_size=2048)) == min(8, cap)
+  assert default_ingest_threads(None) == min(4, cap)
