@@ -16,13 +16,14 @@
 //   k_fcl_dwa      the chain layers' weight-gradient jobs + the LayerNorm parameters + the loss sums (+ the native loop's
 //                  completion word)
 //
-// (MZ_FCL_FUSE_FB=0: three launches -- k_fcl_fwd: chain + units; k_fcl_bwd_dw: backward chain + the heads' jobs; k_fcl_dwa.
-// MZ_FCL_FUSE_FWD=0: four -- the structure of batch 512.  The same arithmetic in the same order: tests hold the three to equal bits.)
+// (MZ_FCL_FUSE_FB=0: three launches -- k_fcl_fwd: chain + units; k_fcl_bwd_dw: backward chain + the heads' jobs; k_fcl_dwa -- the
+// structure of batch 512, where the chain takes half the chip.  MZ_FCL_FUSE_FWD=0: four.  The same arithmetic in the same order: tests
+// hold the three to equal bits.)
 // A weight-gradient job = one tile of a layer's dW = sum_rows delta (x) input over EVERY unroll position the layer is applied at
 // (MFMA strips over the activation / delta tapes in HBM, summed in a fixed order: deterministic, no atomics); with one row slab
 // the tile is the gradient, and Adam / AdamW on exactly those weights (torch's fused-kernel arithmetic; the new weights into the
 // flat vector AND into the packed copies the next step's MFMAs read) follows in the same workgroup.
-// Larger batches: k_fcl_chain_fwd4 / k_fcl_heads as launches of their own from batch 512 (the chain fills the chip), row slabs +
+// Larger batches: k_fcl_chain_fwd4 / k_fcl_heads as launches of their own from batch 1024 (the chain fills the chip), row slabs +
 // 64-row tiles (k_fcl_dwt) + the optimiser kernel (k_fcl_adam; with k_fcl_grad for clip_grad_norm_) from batch 1024, two / four
 // groups of four samples per chain workgroup from batch 2048 / 4096.
 //
