@@ -919,7 +919,9 @@ __device__ __forceinline__ void fcl_chain_bwd4_core(const FclView &v, const int 
       for (int i = 0; i < 4; ++i) mskn[g][i] = ld((a1t + i * 16) + fcl_lane_off4(lane, n0 + 4 * g));
   };
   mask_request(v.K);
+#define FCL_BSTAMP(k) if (v.prof && blk == 0 && p == 2 && tid == 0) v.prof[67 + (k)] = __builtin_amdgcn_s_memtime();
   auto body = [&](int p, const float (&W2)[MZ_H]) __attribute__((always_inline)) {
+    FCL_BSTAMP(0)      // (development: the phases of backward position 2 in workgroup 0, slots 67..)
     unsigned fl = 0u;
     if constexpr (WAITD) {
       if (w < G && p > 0) fl = __hip_atomic_load(dfl + (p - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -948,13 +950,16 @@ __device__ __forceinline__ void fcl_chain_bwd4_core(const FclView &v, const int 
       for (int i = 0; i < 4; ++i) dy[i] = (f0 + i < MZ_H) ? rstd * (dx[i] - s1 * inv - xh[i] * (s2 * inv)) : 0.f;
       *(f32x4 *)(D2 + sj * LDX + f0) = dy;
     }
+    FCL_BSTAMP(1)      // wave 0: LayerNorm backwards
     if (p > 0) { arrived(p - 1, fl); request(p - 1); }
+    FCL_BSTAMP(2)      // next position's requests out
     // (this position's fc1 activations -- the ReLU mask -- were requested one position ago: asked for here, in front of the barrier, they
     // were a round trip to L2 that the 400 cycles of fc2-transposed MFMAs did not cover)
     f32x4 msk[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) msk[g] = mskn[g];
     fcl_bar();
+    FCL_BSTAMP(3)      // barrier
     if (tid >= 256) {      // the delta tape of this position, by the upper half of the workgroup (D2 is next written behind the next barrier)
       const int t = tid - 256;
 #pragma unroll
@@ -974,19 +979,23 @@ __device__ __forceinline__ void fcl_chain_bwd4_core(const FclView &v, const int 
       }
       *(f32x4 *)(A1 + (4 * g + (lane & 3)) * FCL_LDA + g0) = d;
     }
+    FCL_BSTAMP(4)      // fc2-transposed products, mask, tapes
     if (p > 0) mask_request(p - 1);
     // (no barrier: wave w's split-K slice of the fc1-transposed product is features [64 w, 64 w + 64) of A1, its own writes)
     if (p >= 1) {
 #pragma unroll
       for (int g = 0; g < G; ++g)
         *(f32x4 *)(red + g * 2048 + w * 256 + fcl_red_slot(lane & 3, lane >> 2) * 4) = fcl_quad_res<64>(WB1, A1 + (4 * g + (lane & 3)) * FCL_LDA + 64 * w);
+      FCL_BSTAMP(5)      // fc1-transposed partials
       fcl_bar();
+      FCL_BSTAMP(6)      // barrier
       if (w < G) {
         f32x4 y = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ww = 0; ww < FCL_NW; ++ww) y += *(const f32x4 *)(red + w * 2048 + ww * 256 + fcl_red_slot(j, lane & 15) * 4);      // (written by lane 4 b + j)
         dch = y;            // (rows >= 50 come out of zero weights)
       }
+      FCL_BSTAMP(7)      // wave 0: reduce
       // (red is next written after one more barrier; D2 after this one)
     }
   };

@@ -39,6 +39,11 @@ acc /= N
 for i, nme in enumerate(names):
   print('%-28s value %6.2f  policy %6.2f  reward %6.2f' % (nme, acc[0, i], acc[1, i], acc[2, i]))
 print('%-28s value %6.2f  policy %6.2f  reward %6.2f (x 100 cycles)' % ('total', acc[0].sum(), acc[1].sum(), acc[2].sum()))
+if buf[74] > 0:      # backward position 2 of chain workgroup 0 (last sample)
+  bst = np.diff(buf[67:75].astype(np.float64)) / 100.0
+  for nme, x in zip(['wave 0: LayerNorm backwards', 'requests of the next position', 'barrier', 'fc2^T products + mask + tapes', 'fc1^T partials', 'barrier', 'wave 0: reduce'], bst):
+    print('chain bwd position 2: %-36s %6.2f' % (nme, x))
+  print('chain bwd position 2: total %6.2f (x 100 cycles)' % bst.sum())
 cacc /= N
 for nme, x in zip(['fc1 products', 'epilogue + barrier', 'fc2 partials + barrier', 'wave 0: reduce + LayerNorm + tapes', 'barrier'], cacc):
   print('chain fwd position 2: %-36s %6.2f' % (nme, x))
